@@ -1,0 +1,38 @@
+# Builds the MI355X-native library (hand-written HIP for gfx950 behind the C ABI in include/),
+# the CPU oracle (test infrastructure) and the host-compiled arithmetic check used by CPU tests.
+HIPCC    ?= /opt/rocm/bin/hipcc
+ARCH     ?= gfx950
+# -ffp-contract=off + correctly rounded div/sqrt: the arithmetic contract shared with oracle/
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt \
+            -fPIC -Wall -Wno-unused-function -Wno-pass-failed
+PKG      := cuda-sfm_amd
+CSRC     := $(PKG)/csrc
+BUILD    := build
+LIB      := $(PKG)/lib/libsfm_amd.so
+SRCS     := $(wildcard $(CSRC)/*.hip)
+OBJS     := $(patsubst $(CSRC)/%.hip,$(BUILD)/%.o,$(SRCS))
+HDRS     := $(wildcard $(CSRC)/*.hpp) include/sfm_amd.h
+
+all: $(LIB) oracle hostcheck
+
+$(BUILD)/%.o: $(CSRC)/%.hip $(HDRS)
+	@mkdir -p $(BUILD)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(LIB): $(OBJS)
+	@mkdir -p $(PKG)/lib
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS)
+
+oracle:
+	$(MAKE) -C oracle
+
+hostcheck: tests/hostcheck/libhostcheck.so
+
+tests/hostcheck/libhostcheck.so: tests/hostcheck/hostcheck.hip $(CSRC)/device_math.hpp
+	$(HIPCC) -x hip --cuda-host-only -O2 -ffp-contract=off -mfma -fPIC -shared -Wno-pass-failed -o $@ $<
+
+clean:
+	rm -rf $(BUILD) $(LIB) tests/hostcheck/libhostcheck.so
+	$(MAKE) -C oracle clean
+
+.PHONY: all oracle hostcheck clean

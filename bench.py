@@ -1,0 +1,161 @@
+#!/usr/bin/env python3
+"""bench.py -- RANSAC E-matrix hypotheses/sec on MI355X (BASELINE.json metric).
+
+One "step" = one estimateE over a 4096-match synthetic two-view scene with TOTAL_HYPS hypotheses
+(strong scaling: the hypothesis ids are sharded over the N ranks, one 8-byte all-reduce(max)
+selects the winner, every rank finalizes E + inlier mask).  Inputs are resident in HBM before the
+timed region.  Rank 0 prints ONE JSON line.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+N_MATCHES = 4096              # "4k matches" of the BASELINE metric
+TOTAL_HYPS = 1 << 20          # hypotheses per step over the whole job (BASELINE configs[3] count)
+FP32_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: 256 CU x 256 FLOP/clk x 2.4 GHz
+FLOP_PER_POINT = 38           # residual of one (hypothesis, point)
+FLOP_PER_HYP = 720            # A^T A normal equations
+
+
+def cpu_baseline(scene, params, seconds=12.0):
+    """Oracle (CPU port of the same algorithm, OpenMP over hypotheses) on a bounded sample."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle as O
+    cores = len(os.sched_getaffinity(0))
+    _, _, X0, X1 = O.fill_xu(scene["sift"], scene["Kinv"])
+    probe = 256 * cores
+    t0 = time.perf_counter()
+    O.ransac_range(X0, X1, 0, probe, params.threshold, params.jacobi_sweeps, seed=params.seed, want_counts=False, nthreads=cores)
+    rate = probe / (time.perf_counter() - t0)
+    sample = int(max(probe, min(TOTAL_HYPS, rate * seconds)))
+    t0 = time.perf_counter()
+    key, _, _ = O.ransac_range(X0, X1, 0, sample, params.threshold, params.jacobi_sweeps, seed=params.seed, want_counts=False, nthreads=cores)
+    dt = time.perf_counter() - t0
+    return {"value": sample / dt, "unit": "hypotheses/s", "cores": cores, "kind": "port",
+            "sample": f"hypotheses 0..{sample - 1} of the same {N_MATCHES}-match scene, {dt:.1f} s, OpenMP x{cores}"}, (O, X0, X1)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--matches", type=int, default=N_MATCHES)
+    ap.add_argument("--hyps", type=int, default=TOTAL_HYPS)
+    ap.add_argument("--kernel", type=int, default=0)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import cuda_sfm_amd as S
+    from cuda_sfm_amd import synth
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus or world == 1 and args.gpus == 1, f"--gpus {args.gpus} but WORLD_SIZE {world}"
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    n, H = args.matches, args.hyps
+    scene = synth.two_view_scene(n)                       # same bytes on every rank
+    d_sift = torch.from_numpy(scene["sift"].view(np.uint8).reshape(n, 576)).to(dev)
+    ctx = S.Context(local, torch.cuda.current_stream().cuda_stream)
+    pair = S.ImagePair(ctx, scene["K"], scene["Kinv"], 2, n)
+    pair.fillXU(d_sift)
+    params = S.default_params(n, num_hypotheses=H, kernel=args.kernel)
+    key_t = torch.zeros(1, dtype=torch.int64, device=dev)
+
+    def reduce_max(t):
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)      # RCCL over xGMI, 8 bytes
+
+    def step():
+        S.estimate_E_distributed(pair, params, rank, world, key_t, reduce_max)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    ctx.kernel_timing(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    solve_ms, score_ms, calls = ctx.kernel_timing_read()
+    ctx.kernel_timing(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    hyp, cnt = pair.get_best()
+    mask_sum = int(pair.get_inlier_mask().sum())
+    if rank == 0:
+        local_hyps = S.shard_range(H, rank, world)[1]
+        score_s = score_ms / 1e3 / max(calls, 1)
+        solve_s = solve_ms / 1e3 / max(calls, 1)
+        flops = float(local_hyps) * FLOP_PER_POINT * n
+        achieved = flops / score_s / 1e12 if score_s > 0 else 0.0
+        out = {
+            "metric": "RANSAC E-matrix hypotheses/sec (8-point, fused scoring), inlier-mask parity vs CPU oracle",
+            "value": H * args.steps / elapsed,
+            "unit": "hypotheses/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"synthetic two-view scene, {n} matches (30% outliers, 0.5 px noise), "
+                                   f"{H} 8-point hypotheses per step sharded over {world} GPU(s), estimateE end to end "
+                                   "(sample+solve+score+argmax+winner E+inlier mask)",
+                       "matches": n, "hypotheses_per_step": H, "threshold": params.threshold,
+                       "jacobi_sweeps": params.jacobi_sweeps, "kernel": pair.last_launch()},
+            "roofline": {"bound": "valu_fp32", "kernel": "ransac_score_waves", "achieved": achieved,
+                         "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_PEAK_TFLOPS,
+                         "traffic": None,
+                         "flop_per_launch": flops, "avg_launch_ms": 1e3 * score_s,
+                         "solve_kernel_avg_ms": 1e3 * solve_s,
+                         "pipeline_frac": (float(local_hyps) * (FLOP_PER_HYP + FLOP_PER_POINT * n)) /
+                                          max(score_s + solve_s, 1e-12) / 1e12 / FP32_PEAK_TFLOPS},
+            "result": {"best_hypothesis": hyp, "inliers": cnt, "mask_sum": mask_sum},
+        }
+        if world == 1 and not args.no_cpu:
+            base, (O, X0, X1) = cpu_baseline(scene, params)
+            out["cpu_baseline"] = base
+            E = O.hypothesis_E(X0, X1, O.sample8(params.seed, hyp, n), params.jacobi_sweeps)
+            ocnt, omask = O.count_inliers(E, X0, X1, params.threshold)
+            out["result"]["parity_vs_oracle"] = bool(ocnt == cnt and np.array_equal(omask, pair.get_inlier_mask())
+                                                     and np.array_equal(E.view(np.uint32), pair.get_E().view(np.uint32)))
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

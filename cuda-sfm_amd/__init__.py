@@ -1,0 +1,364 @@
+"""cuda-sfm_amd -- MI355X-native two-view geometric estimation (match -> estimateE -> pose -> triangulate).
+
+Python is only the harness here (tests, bench, torch.distributed plumbing).  The product is the
+C-ABI library ``lib/libsfm_amd.so`` (hand-written HIP for gfx950, declared in ``include/sfm_amd.h``)
+and the C++ facade in ``host/`` that keeps the reference's ``SfM::Image_pair`` / ``MatchSiftData``
+call surface (reference: SfM/sfm.h:20-60, CudaSift/cudaSift.h:35-43).
+
+There is NO CPU fallback: importing this package without the built HIP library raises.
+The directory name contains a hyphen, so import it through the ``cuda_sfm_amd`` shim at the
+repository root.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libsfm_amd.so")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} is missing: the HIP extension must be built (python -c 'import __graft_entry__ as g; g.build()' "
+        "or `make`); this package has no CPU fallback")
+
+# One HIP runtime per process: torch bundles its own libamdhip64 / libhsa-runtime64, and a second
+# runtime initialised next to it cannot see the GPU.  Import torch FIRST so that the library's
+# libamdhip64.so.7 dependency binds to the copy torch already loaded (torch is this harness's device
+# memory / stream / torch.distributed plumbing anyway).  Stand-alone C++ users link the system runtime.
+import torch  # noqa: E402,F401
+
+_lib = C.CDLL(LIB_PATH)
+
+# ---- constants (include/sfm_amd.h) --------------------------------------------------------------
+OK, E_INVALID, E_HIP, E_NOMEM, E_STATE, E_SINGULAR = 0, -1, -2, -3, -4, -5
+KERNEL_AUTO, KERNEL_SPLIT, KERNEL_FUSED = 0, 1, 2
+POSE_REFERENCE, POSE_CORRECT = 0, 1
+(BUF_X0, BUF_X1, BUF_U0, BUF_U1, BUF_E, BUF_P, BUF_PINV, BUF_POINTS, BUF_COUNTS, BUF_MASK, BUF_KEY,
+ BUF_ECAND, BUF_PIND) = range(13)
+
+SIFT_DTYPE = np.dtype([
+    ("xpos", "<f4"), ("ypos", "<f4"), ("scale", "<f4"), ("sharpness", "<f4"),
+    ("edgeness", "<f4"), ("orientation", "<f4"), ("score", "<f4"), ("ambiguity", "<f4"),
+    ("match", "<i4"), ("match_xpos", "<f4"), ("match_ypos", "<f4"), ("match_error", "<f4"),
+    ("subsampling", "<f4"), ("empty", "<f4", (3,)), ("data", "<f4", (128,)),
+])
+assert SIFT_DTYPE.itemsize == 576
+
+EXPORTS = [
+    "sfm_abi_version", "sfm_last_error", "sfm_ctx_create", "sfm_ctx_destroy", "sfm_ctx_set_stream",
+    "sfm_ctx_synchronize", "sfm_ctx_timer_start", "sfm_ctx_timer_stop", "sfm_ctx_kernel_timing",
+    "sfm_ctx_kernel_timing_read", "sfm_match", "sfm_match_soa",
+    "sfm_pair_create", "sfm_pair_destroy", "sfm_fill_xu", "sfm_set_points", "sfm_ransac_default_params",
+    "sfm_ransac_permutation_indices", "sfm_estimate_E", "sfm_ransac_score", "sfm_ransac_finalize",
+    "sfm_ransac_finalize_key", "sfm_ransac_export_key", "sfm_pose_candidates", "sfm_choose_pose", "sfm_triangulate",
+    "sfm_pair_device_ptr", "sfm_pair_ld", "sfm_pair_num_points", "sfm_get_XU", "sfm_get_E", "sfm_get_best",
+    "sfm_get_key", "sfm_get_inlier_counts", "sfm_get_inlier_mask", "sfm_get_E_candidates",
+    "sfm_get_pose_candidates", "sfm_get_pose_inverses", "sfm_get_pose_index", "sfm_get_points",
+    "sfm_ransac_last_launch",
+]
+
+
+class RansacParams(C.Structure):
+    """sfm_ransac_params (include/sfm_amd.h)."""
+    _fields_ = [
+        ("num_hypotheses", C.c_uint32), ("hyp_begin", C.c_uint32), ("hyp_count", C.c_uint32),
+        ("seed", C.c_uint32), ("d_indices", C.c_void_p), ("threshold", C.c_float),
+        ("jacobi_sweeps", C.c_int32), ("kernel", C.c_int32), ("reserved", C.c_int32 * 4),
+    ]
+
+
+_vp = C.c_void_p
+_lib.sfm_last_error.restype = C.c_char_p
+_lib.sfm_ctx_create.argtypes = [C.c_int, C.POINTER(_vp)]
+_lib.sfm_ctx_destroy.argtypes = [_vp]
+_lib.sfm_ctx_set_stream.argtypes = [_vp, _vp]
+_lib.sfm_ctx_synchronize.argtypes = [_vp]
+_lib.sfm_ctx_timer_start.argtypes = [_vp]
+_lib.sfm_ctx_timer_stop.argtypes = [_vp, C.POINTER(C.c_float)]
+_lib.sfm_ctx_kernel_timing.argtypes = [_vp, C.c_int]
+_lib.sfm_ctx_kernel_timing_read.argtypes = [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int)]
+_lib.sfm_match.argtypes = [_vp, _vp, C.c_int, _vp, C.c_int]
+_lib.sfm_match_soa.argtypes = [_vp, _vp, C.c_int, C.c_int, _vp, C.c_int, C.c_int, _vp, _vp, _vp]
+_lib.sfm_pair_create.argtypes = [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int, C.c_int, C.POINTER(_vp)]
+_lib.sfm_pair_destroy.argtypes = [_vp]
+_lib.sfm_fill_xu.argtypes = [_vp, _vp]
+_lib.sfm_set_points.argtypes = [_vp, _vp, _vp]
+_lib.sfm_ransac_default_params.argtypes = [C.POINTER(RansacParams), C.c_int]
+_lib.sfm_ransac_default_params.restype = None
+_lib.sfm_ransac_permutation_indices.argtypes = [_vp, C.c_int, C.c_uint32, _vp]
+_lib.sfm_estimate_E.argtypes = [_vp, C.POINTER(RansacParams)]
+_lib.sfm_ransac_score.argtypes = [_vp, C.POINTER(RansacParams)]
+_lib.sfm_ransac_finalize.argtypes = [_vp, C.POINTER(RansacParams), C.c_uint32]
+_lib.sfm_ransac_finalize_key.argtypes = [_vp, C.POINTER(RansacParams), _vp]
+_lib.sfm_ransac_export_key.argtypes = [_vp, _vp]
+_lib.sfm_pose_candidates.argtypes = [_vp, C.c_int]
+_lib.sfm_choose_pose.argtypes = [_vp, C.c_int]
+_lib.sfm_triangulate.argtypes = [_vp, C.c_int]
+_lib.sfm_pair_device_ptr.argtypes = [_vp, C.c_int, C.POINTER(_vp), C.POINTER(C.c_size_t)]
+_lib.sfm_pair_ld.argtypes = [_vp]
+_lib.sfm_pair_num_points.argtypes = [_vp]
+_lib.sfm_get_XU.argtypes = [_vp, C.c_int, _vp]
+_lib.sfm_get_E.argtypes = [_vp, _vp]
+_lib.sfm_get_best.argtypes = [_vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+_lib.sfm_get_key.argtypes = [_vp, C.POINTER(C.c_uint64)]
+_lib.sfm_get_inlier_counts.argtypes = [_vp, _vp, C.c_size_t]
+_lib.sfm_get_inlier_mask.argtypes = [_vp, _vp]
+_lib.sfm_get_E_candidates.argtypes = [_vp, _vp, C.c_size_t]
+_lib.sfm_get_pose_candidates.argtypes = [_vp, _vp]
+_lib.sfm_get_pose_inverses.argtypes = [_vp, _vp]
+_lib.sfm_get_pose_index.argtypes = [_vp, C.POINTER(C.c_int)]
+_lib.sfm_get_points.argtypes = [_vp, _vp]
+_lib.sfm_ransac_last_launch.argtypes = [_vp] + [C.POINTER(C.c_int)] * 4
+
+
+class SfmError(RuntimeError):
+    def __init__(self, code, where):
+        self.code = code
+        msg = _lib.sfm_last_error()
+        super().__init__(f"{where} failed with code {code}: {msg.decode() if msg else ''}")
+
+
+def _check(rc, where):
+    if rc != OK:
+        raise SfmError(rc, where)
+
+
+def lib():
+    """The loaded C-ABI library (ctypes.CDLL)."""
+    return _lib
+
+
+def _ptr(x):
+    """Device pointer of a torch tensor / int / None."""
+    if x is None:
+        return None
+    if isinstance(x, int):
+        return x
+    return x.data_ptr()
+
+
+def default_params(num_points, **kw):
+    p = RansacParams()
+    _lib.sfm_ransac_default_params(C.byref(p), int(num_points))
+    for k, v in kw.items():
+        if k == "d_indices":
+            v = _ptr(v)
+        setattr(p, k, v)
+    return p
+
+
+def pack_key(count, hyp):
+    """(count << 32) | (0xFFFFFFFF - hyp): max() picks the highest count, lowest id on ties
+    (thrust::max_element first-maximum rule, reference sfm.cu:135-137)."""
+    return (int(count) << 32) | (0xFFFFFFFF - int(hyp))
+
+
+def unpack_key(key):
+    key = int(key)
+    return key >> 32, 0xFFFFFFFF - (key & 0xFFFFFFFF)
+
+
+def shard_range(num_hypotheses, rank, world):
+    """Contiguous shard of hypothesis ids owned by `rank`: [begin, begin+count)."""
+    base, rem = divmod(int(num_hypotheses), int(world))
+    begin = rank * base + min(rank, rem)
+    return begin, base + (1 if rank < rem else 0)
+
+
+class Context:
+    """sfm_ctx: device, stream and matcher scratch."""
+
+    def __init__(self, device=0, stream=None):
+        h = _vp()
+        _check(_lib.sfm_ctx_create(int(device), C.byref(h)), "sfm_ctx_create")
+        self._h = h
+        self.device = int(device)
+        if stream is not None:
+            self.set_stream(stream)
+
+    def set_stream(self, stream):
+        """stream: raw hipStream_t value (e.g. torch.cuda.current_stream().cuda_stream) or None."""
+        _check(_lib.sfm_ctx_set_stream(self._h, stream), "sfm_ctx_set_stream")
+
+    def synchronize(self):
+        _check(_lib.sfm_ctx_synchronize(self._h), "sfm_ctx_synchronize")
+
+    def timer_start(self):
+        _check(_lib.sfm_ctx_timer_start(self._h), "sfm_ctx_timer_start")
+
+    def timer_stop(self):
+        ms = C.c_float()
+        _check(_lib.sfm_ctx_timer_stop(self._h, C.byref(ms)), "sfm_ctx_timer_stop")
+        return ms.value
+
+    def kernel_timing(self, enable=True):
+        _check(_lib.sfm_ctx_kernel_timing(self._h, 1 if enable else 0), "sfm_ctx_kernel_timing")
+
+    def kernel_timing_read(self):
+        """(solve_ms, score_ms, calls) summed over the RANSAC launches since the last read."""
+        a = C.c_float(); b = C.c_float(); n = C.c_int()
+        _check(_lib.sfm_ctx_kernel_timing_read(self._h, C.byref(a), C.byref(b), C.byref(n)), "sfm_ctx_kernel_timing_read")
+        return a.value, b.value, n.value
+
+    def match(self, d_sift1, n1, d_sift2, n2):
+        """MatchSiftData core on device SiftPoint arrays (in-place field update of sift1)."""
+        _check(_lib.sfm_match(self._h, _ptr(d_sift1), int(n1), _ptr(d_sift2), int(n2)), "sfm_match")
+
+    def match_soa(self, d1, n1, ld1, d2, n2, ld2, best, second, index):
+        _check(_lib.sfm_match_soa(self._h, _ptr(d1), int(n1), int(ld1), _ptr(d2), int(n2), int(ld2),
+                                  _ptr(best), _ptr(second), _ptr(index)), "sfm_match_soa")
+
+    def permutation_indices(self, num_points, seed, d_indices):
+        _check(_lib.sfm_ransac_permutation_indices(self._h, int(num_points), int(seed), _ptr(d_indices)),
+               "sfm_ransac_permutation_indices")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.sfm_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class ImagePair:
+    """Mirror of SfM::Image_pair (reference SfM/sfm.h:20-60) on top of the C ABI."""
+
+    def __init__(self, ctx, K, Kinv, image_count, num_points):
+        self.ctx = ctx
+        k = np.ascontiguousarray(K, np.float32).reshape(9)
+        ki = np.ascontiguousarray(Kinv, np.float32).reshape(9)
+        h = _vp()
+        _check(_lib.sfm_pair_create(ctx._h, k.ctypes.data_as(C.POINTER(C.c_float)),
+                                    ki.ctypes.data_as(C.POINTER(C.c_float)), int(image_count),
+                                    int(num_points), C.byref(h)), "sfm_pair_create")
+        self._h = h
+        self.num_points = int(num_points)
+        self.ld = _lib.sfm_pair_ld(h)
+
+    # -- reference call surface -----------------------------------------------------------------
+    def fillXU(self, d_sift):
+        _check(_lib.sfm_fill_xu(self._h, _ptr(d_sift)), "sfm_fill_xu")
+
+    def set_points(self, d_X0, d_X1):
+        _check(_lib.sfm_set_points(self._h, _ptr(d_X0), _ptr(d_X1)), "sfm_set_points")
+
+    def estimateE(self, params=None):
+        p = params if params is not None else default_params(self.num_points)
+        _check(_lib.sfm_estimate_E(self._h, C.byref(p)), "sfm_estimate_E")
+
+    def ransac_score(self, params):
+        _check(_lib.sfm_ransac_score(self._h, C.byref(params)), "sfm_ransac_score")
+
+    def ransac_finalize(self, params, hyp):
+        _check(_lib.sfm_ransac_finalize(self._h, C.byref(params), int(hyp)), "sfm_ransac_finalize")
+
+    def export_key(self, d_key_out):
+        _check(_lib.sfm_ransac_export_key(self._h, _ptr(d_key_out)), "sfm_ransac_export_key")
+
+    def ransac_finalize_key(self, params, d_key):
+        _check(_lib.sfm_ransac_finalize_key(self._h, C.byref(params), _ptr(d_key)), "sfm_ransac_finalize_key")
+
+    def computePosecandidates(self, mode=POSE_REFERENCE):
+        _check(_lib.sfm_pose_candidates(self._h, int(mode)), "sfm_pose_candidates")
+
+    def choosePose(self, mode=POSE_REFERENCE):
+        _check(_lib.sfm_choose_pose(self._h, int(mode)), "sfm_choose_pose")
+
+    def linear_triangulation(self, mode=POSE_REFERENCE):
+        _check(_lib.sfm_triangulate(self._h, int(mode)), "sfm_triangulate")
+
+    computePoseCandidates = computePosecandidates     # BASELINE.json spelling
+    linearTriangulate = linear_triangulation
+
+    # -- accessors --------------------------------------------------------------------------------
+    def device_ptr(self, which):
+        p = _vp(); b = C.c_size_t()
+        _check(_lib.sfm_pair_device_ptr(self._h, int(which), C.byref(p), C.byref(b)), "sfm_pair_device_ptr")
+        return p.value, b.value
+
+    def _get(self, fn, name, shape, dtype):
+        out = np.empty(shape, dtype)
+        _check(fn(self._h, out.ctypes.data_as(_vp)), name)
+        return out
+
+    def get_XU(self, which):
+        out = np.empty((3, self.num_points), np.float32)
+        _check(_lib.sfm_get_XU(self._h, int(which), out.ctypes.data_as(_vp)), "sfm_get_XU")
+        return out
+
+    def get_E(self):
+        return self._get(_lib.sfm_get_E, "sfm_get_E", (3, 3), np.float32)
+
+    def get_best(self):
+        h = C.c_uint32(); c = C.c_uint32()
+        _check(_lib.sfm_get_best(self._h, C.byref(h), C.byref(c)), "sfm_get_best")
+        return h.value, c.value
+
+    def get_key(self):
+        k = C.c_uint64()
+        _check(_lib.sfm_get_key(self._h, C.byref(k)), "sfm_get_key")
+        return k.value
+
+    def get_inlier_counts(self, count):
+        out = np.empty(int(count), np.int32)
+        _check(_lib.sfm_get_inlier_counts(self._h, out.ctypes.data_as(_vp), out.size), "sfm_get_inlier_counts")
+        return out
+
+    def get_E_candidates(self, count):
+        out = np.empty((int(count), 9), np.float32)
+        _check(_lib.sfm_get_E_candidates(self._h, out.ctypes.data_as(_vp), int(count)), "sfm_get_E_candidates")
+        return out
+
+    def get_inlier_mask(self):
+        return self._get(_lib.sfm_get_inlier_mask, "sfm_get_inlier_mask", (self.num_points,), np.uint8)
+
+    def get_pose_candidates(self):
+        return self._get(_lib.sfm_get_pose_candidates, "sfm_get_pose_candidates", (4, 4, 4), np.float32)
+
+    def get_pose_inverses(self):
+        return self._get(_lib.sfm_get_pose_inverses, "sfm_get_pose_inverses", (4, 4, 4), np.float32)
+
+    def get_pose_index(self):
+        i = C.c_int()
+        _check(_lib.sfm_get_pose_index(self._h, C.byref(i)), "sfm_get_pose_index")
+        return i.value
+
+    def get_points(self):
+        return self._get(_lib.sfm_get_points, "sfm_get_points", (4, self.num_points), np.float32)
+
+    def last_launch(self):
+        v = [C.c_int() for _ in range(4)]
+        _check(_lib.sfm_ransac_last_launch(self._h, *[C.byref(x) for x in v]), "sfm_ransac_last_launch")
+        return {"kernel": v[0].value, "grid": v[1].value, "block": v[2].value, "lds_bytes": v[3].value}
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.sfm_pair_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def estimate_E_distributed(pair, params, rank, world, key_tensor, all_reduce_max):
+    """Multi-GPU estimateE: every rank scores its contiguous shard of hypothesis ids,
+    ONE all-reduce(max) of the packed 8-byte key picks the winner, every rank finalizes it locally
+    (bit-identical E and mask on every rank, no second collective, no host round trip).
+
+    key_tensor: 1-element int64 device tensor; all_reduce_max(key_tensor) reduces it in place
+    across ranks (torch.distributed.all_reduce(MAX) -> RCCL over xGMI; gloo in the CPU tests).
+    """
+    begin, count = shard_range(params.num_hypotheses, rank, world)
+    params.hyp_begin, params.hyp_count = begin, count     # count == 0 only when begin == H
+    pair.ransac_score(params)                             # empty shard -> key 0
+    pair.export_key(key_tensor)
+    all_reduce_max(key_tensor)
+    pair.ransac_finalize_key(params, key_tensor)

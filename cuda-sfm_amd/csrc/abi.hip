@@ -1,0 +1,478 @@
+// abi.hip -- implementation of the C ABI declared in include/sfm_amd.h.
+#include "common.hpp"
+#include "device_math.hpp"
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <new>
+
+namespace sfm {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+template <typename T>
+static int dev_alloc(T **p, size_t count)
+{
+    SFM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(p), count * sizeof(T)));
+    return SFM_OK;
+}
+
+static int resolve_shard(const sfm_pair *pair, const sfm_ransac_params *p, uint32_t *h0, uint32_t *count)
+{
+    SFM_REQUIRE(pair && p, SFM_E_INVALID, "null pair/params");
+    SFM_REQUIRE(pair->have_points, SFM_E_STATE, "estimateE before fillXU / set_points");
+    SFM_REQUIRE(pair->n >= 8, SFM_E_INVALID, "the 8-point solver needs at least 8 correspondences (have %d)", pair->n);
+    SFM_REQUIRE(p->num_hypotheses > 0, SFM_E_INVALID, "num_hypotheses must be > 0");
+    SFM_REQUIRE(p->hyp_begin <= p->num_hypotheses, SFM_E_INVALID, "hyp_begin %u beyond num_hypotheses %u", p->hyp_begin, p->num_hypotheses);
+    SFM_REQUIRE(p->jacobi_sweeps >= 1 && p->jacobi_sweeps <= 64, SFM_E_INVALID, "jacobi_sweeps out of range");
+    SFM_REQUIRE(p->kernel >= SFM_KERNEL_AUTO && p->kernel <= SFM_KERNEL_FUSED, SFM_E_INVALID, "unknown kernel id %d", p->kernel);
+    uint32_t c = p->hyp_count ? p->hyp_count : p->num_hypotheses - p->hyp_begin;
+    SFM_REQUIRE((uint64_t)p->hyp_begin + c <= p->num_hypotheses, SFM_E_INVALID, "shard [%u, %u) exceeds num_hypotheses %u",
+                p->hyp_begin, p->hyp_begin + c, p->num_hypotheses);
+    *h0 = p->hyp_begin;
+    *count = c;
+    return SFM_OK;
+}
+
+static int copy_out(sfm_pair *pair, void *h_dst, const void *d_src, size_t bytes)
+{
+    SFM_HIP_TRY(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, pair->ctx->stream));
+    SFM_HIP_TRY(hipStreamSynchronize(pair->ctx->stream));
+    return SFM_OK;
+}
+
+} // namespace sfm
+
+using namespace sfm;
+
+extern "C" {
+
+int sfm_abi_version(void) { return SFM_ABI_VERSION; }
+const char *sfm_last_error(void) { return g_err; }
+
+int sfm_ctx_create(int device_id, sfm_ctx **out)
+{
+    SFM_REQUIRE(out, SFM_E_INVALID, "null out pointer");
+    *out = nullptr;
+    int ndev = 0;
+    SFM_HIP_TRY(hipGetDeviceCount(&ndev));
+    SFM_REQUIRE(device_id >= 0 && device_id < ndev, SFM_E_INVALID, "device %d not present (%d HIP devices)", device_id, ndev);
+    SFM_HIP_TRY(hipSetDevice(device_id));
+    hipDeviceProp_t prop;
+    SFM_HIP_TRY(hipGetDeviceProperties(&prop, device_id));
+    sfm_ctx *c = new (std::nothrow) sfm_ctx();
+    SFM_REQUIRE(c, SFM_E_NOMEM, "host allocation failed");
+    c->device = device_id;
+    c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    hipError_t e = hipEventCreate(&c->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&c->ev1);
+    if (e != hipSuccess) { delete c; set_error("hipEventCreate failed: %s", hipGetErrorString(e)); return SFM_E_HIP; }
+    *out = c;
+    return SFM_OK;
+}
+
+int sfm_ctx_destroy(sfm_ctx *ctx)
+{
+    if (!ctx) return SFM_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->match_ws) (void)hipFree(ctx->match_ws);
+    for (auto &t : ctx->tev) for (hipEvent_t e : t) if (e) (void)hipEventDestroy(e);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    delete ctx;
+    return SFM_OK;
+}
+
+int sfm_ctx_set_stream(sfm_ctx *ctx, void *hip_stream)
+{
+    SFM_REQUIRE(ctx, SFM_E_INVALID, "null context");
+    ctx->stream = static_cast<hipStream_t>(hip_stream);
+    return SFM_OK;
+}
+
+int sfm_ctx_synchronize(sfm_ctx *ctx)
+{
+    SFM_REQUIRE(ctx, SFM_E_INVALID, "null context");
+    SFM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return SFM_OK;
+}
+
+int sfm_ctx_timer_start(sfm_ctx *ctx)
+{
+    SFM_REQUIRE(ctx, SFM_E_INVALID, "null context");
+    SFM_HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
+    return SFM_OK;
+}
+
+int sfm_ctx_timer_stop(sfm_ctx *ctx, float *elapsed_ms)
+{
+    SFM_REQUIRE(ctx && elapsed_ms, SFM_E_INVALID, "null argument");
+    SFM_HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
+    SFM_HIP_TRY(hipEventSynchronize(ctx->ev1));
+    SFM_HIP_TRY(hipEventElapsedTime(elapsed_ms, ctx->ev0, ctx->ev1));
+    return SFM_OK;
+}
+
+int sfm_ctx_kernel_timing(sfm_ctx *ctx, int enable)
+{
+    SFM_REQUIRE(ctx, SFM_E_INVALID, "null context");
+    if (enable && !ctx->tev[0][0]) {
+        for (auto &t : ctx->tev) for (hipEvent_t &e : t) SFM_HIP_TRY(hipEventCreate(&e));
+    }
+    ctx->timing = enable != 0;
+    ctx->tcount = 0;
+    return SFM_OK;
+}
+
+int sfm_ctx_kernel_timing_read(sfm_ctx *ctx, float *solve_ms, float *score_ms, int *calls)
+{
+    SFM_REQUIRE(ctx, SFM_E_INVALID, "null context");
+    SFM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    float a = 0.f, b = 0.f;
+    for (int i = 0; i < ctx->tcount; ++i) {
+        float t = 0.f;
+        SFM_HIP_TRY(hipEventElapsedTime(&t, ctx->tev[i][0], ctx->tev[i][1])); a += t;
+        SFM_HIP_TRY(hipEventElapsedTime(&t, ctx->tev[i][1], ctx->tev[i][2])); b += t;
+    }
+    if (solve_ms) *solve_ms = a;
+    if (score_ms) *score_ms = b;
+    if (calls) *calls = ctx->tcount;
+    ctx->tcount = 0;
+    return SFM_OK;
+}
+
+// ---- match ------------------------------------------------------------------------------------
+int sfm_match(sfm_ctx *ctx, sfm_sift_point *d_sift1, int n1, const sfm_sift_point *d_sift2, int n2)
+{
+    SFM_REQUIRE(ctx, SFM_E_INVALID, "null context");
+    SFM_REQUIRE(n1 >= 0 && n2 >= 0, SFM_E_INVALID, "negative point count");
+    if (n1 == 0 || n2 == 0 || !d_sift1 || !d_sift2) return SFM_OK;      // matching.cu:1095-1102
+    SFM_HIP_TRY(hipSetDevice(ctx->device));
+    const int ld = (int)(sizeof(sfm_sift_point) / sizeof(float));
+    return launch_match(ctx, d_sift1->data, n1, ld, d_sift2->data, n2, ld, nullptr, nullptr, nullptr, d_sift1, d_sift2);
+}
+
+int sfm_match_soa(sfm_ctx *ctx, const float *d_desc1, int n1, int ld1, const float *d_desc2, int n2, int ld2,
+                  float *d_best, float *d_second, int32_t *d_index)
+{
+    SFM_REQUIRE(ctx, SFM_E_INVALID, "null context");
+    SFM_REQUIRE(n1 >= 0 && n2 >= 0, SFM_E_INVALID, "negative point count");
+    if (n1 == 0 || n2 == 0) return SFM_OK;
+    SFM_REQUIRE(d_desc1 && d_desc2, SFM_E_INVALID, "null descriptor pointer");
+    SFM_REQUIRE(ld1 >= 128 && ld2 >= 128 && ld1 % 4 == 0 && ld2 % 4 == 0, SFM_E_INVALID, "row strides must be >= 128 and multiples of 4 floats");
+    SFM_REQUIRE(((uintptr_t)d_desc1 & 15) == 0 && ((uintptr_t)d_desc2 & 15) == 0, SFM_E_INVALID, "descriptor rows must be 16-byte aligned");
+    SFM_HIP_TRY(hipSetDevice(ctx->device));
+    return launch_match(ctx, d_desc1, n1, ld1, d_desc2, n2, ld2, d_best, d_second, d_index, nullptr, nullptr);
+}
+
+// ---- Image_pair ---------------------------------------------------------------------------------
+int sfm_pair_create(sfm_ctx *ctx, const float h_K[9], const float h_Kinv[9], int image_count, int num_points, sfm_pair **out)
+{
+    SFM_REQUIRE(out, SFM_E_INVALID, "null out pointer");
+    *out = nullptr;
+    SFM_REQUIRE(ctx && h_K && h_Kinv, SFM_E_INVALID, "null argument");
+    SFM_REQUIRE(image_count == 2, SFM_E_INVALID, "image_count must be 2 (the reference only ever uses two views, sfm.h:31)");
+    SFM_REQUIRE(num_points > 0, SFM_E_INVALID, "num_points must be positive");
+    SFM_HIP_TRY(hipSetDevice(ctx->device));
+    sfm_pair *p = new (std::nothrow) sfm_pair();
+    SFM_REQUIRE(p, SFM_E_NOMEM, "host allocation failed");
+    p->ctx = ctx;
+    p->image_count = image_count;
+    p->n = num_points;
+    p->ld = round_up(num_points, 128);
+    int rc = SFM_OK;
+    auto A = [&](auto **ptr, size_t count) { if (rc == SFM_OK) rc = dev_alloc(ptr, count); };
+    A(&p->d_K, 9); A(&p->d_Kinv, 9);
+    for (int i = 0; i < 2; ++i) { A(&p->d_U[i], (size_t)3 * p->ld); A(&p->d_X[i], (size_t)3 * p->ld); }
+    A(&p->d_E, 9); A(&p->d_P, 64); A(&p->d_Pinv, 64); A(&p->d_Pind, 8);
+    A(&p->d_points, (size_t)4 * num_points);
+    A(&p->d_mask, (size_t)num_points);
+    A(&p->d_key, 2); A(&p->d_best, 2);
+    if (rc != SFM_OK) { sfm_pair_destroy(p); return rc; }
+    hipError_t e = hipMemcpyAsync(p->d_K, h_K, 9 * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(p->d_Kinv, h_Kinv, 9 * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(p->d_key, 0, 2 * sizeof(unsigned long long), ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(p->d_best, 0, 2 * sizeof(uint32_t), ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(p->d_Pind, 0, 8 * sizeof(int), ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);       // host K arrays may go out of scope
+    if (e != hipSuccess) { sfm_pair_destroy(p); set_error("pair init failed: %s", hipGetErrorString(e)); return SFM_E_HIP; }
+    *out = p;
+    return SFM_OK;
+}
+
+int sfm_pair_destroy(sfm_pair *p)
+{
+    if (!p) return SFM_OK;
+    if (p->ctx) { (void)hipSetDevice(p->ctx->device); (void)hipStreamSynchronize(p->ctx->stream); }
+    void *bufs[] = { p->d_K, p->d_Kinv, p->d_U[0], p->d_U[1], p->d_X[0], p->d_X[1], p->d_E, p->d_P, p->d_Pinv, p->d_Pind,
+                     p->d_points, p->d_mask, p->d_key, p->d_best, p->d_counts, p->d_Ecand };
+    for (void *b : bufs) if (b) (void)hipFree(b);
+    delete p;
+    return SFM_OK;
+}
+
+int sfm_fill_xu(sfm_pair *pair, const sfm_sift_point *d_data)
+{
+    SFM_REQUIRE(pair && d_data, SFM_E_INVALID, "null argument");
+    SFM_HIP_TRY(hipSetDevice(pair->ctx->device));
+    int rc = launch_fill_xu(pair, d_data);
+    if (rc == SFM_OK) { pair->have_points = true; pair->have_E = pair->have_P = pair->have_pose = false; }
+    return rc;
+}
+
+int sfm_set_points(sfm_pair *pair, const float *d_X0, const float *d_X1)
+{
+    SFM_REQUIRE(pair && d_X0 && d_X1, SFM_E_INVALID, "null argument");
+    SFM_HIP_TRY(hipSetDevice(pair->ctx->device));
+    int rc = launch_set_points(pair, d_X0, d_X1);
+    if (rc == SFM_OK) { pair->have_points = true; pair->have_E = pair->have_P = pair->have_pose = false; }
+    return rc;
+}
+
+void sfm_ransac_default_params(sfm_ransac_params *p, int num_points)
+{
+    if (!p) return;
+    memset(p, 0, sizeof(*p));
+    p->num_hypotheses = num_points >= 8 ? (uint32_t)(num_points / 8) : 1u;     // sfm.cu:95
+    p->seed = 0x5EED5F3Du;
+    p->threshold = 1e-6f;                                                        // sfm.cu:220
+    p->jacobi_sweeps = 7;
+    p->kernel = SFM_KERNEL_AUTO;
+}
+
+int sfm_ransac_permutation_indices(sfm_ctx *ctx, int num_points, uint32_t seed, int32_t *d_indices)
+{
+    SFM_REQUIRE(ctx && d_indices, SFM_E_INVALID, "null argument");
+    SFM_REQUIRE(num_points >= 8, SFM_E_INVALID, "need at least 8 points");
+    SFM_HIP_TRY(hipSetDevice(ctx->device));
+    return launch_permutation_indices(ctx, num_points, seed, d_indices);
+}
+
+int sfm_ransac_score(sfm_pair *pair, const sfm_ransac_params *p)
+{
+    uint32_t h0, count;
+    int rc = resolve_shard(pair, p, &h0, &count);
+    if (rc != SFM_OK) return rc;
+    SFM_HIP_TRY(hipSetDevice(pair->ctx->device));
+    return launch_ransac_score(pair, *p, h0, count);
+}
+
+int sfm_ransac_finalize(sfm_pair *pair, const sfm_ransac_params *p, uint32_t hyp)
+{
+    uint32_t h0, count;
+    int rc = resolve_shard(pair, p, &h0, &count);
+    if (rc != SFM_OK) return rc;
+    SFM_REQUIRE(hyp < p->num_hypotheses, SFM_E_INVALID, "hypothesis id %u out of range", hyp);
+    SFM_HIP_TRY(hipSetDevice(pair->ctx->device));
+    rc = launch_ransac_finalize(pair, *p, nullptr, hyp, false);
+    if (rc == SFM_OK) { pair->have_E = true; pair->have_P = pair->have_pose = false; }
+    return rc;
+}
+
+int sfm_ransac_export_key(sfm_pair *pair, uint64_t *d_key_out)
+{
+    SFM_REQUIRE(pair && d_key_out, SFM_E_INVALID, "null argument");
+    SFM_HIP_TRY(hipSetDevice(pair->ctx->device));
+    SFM_HIP_TRY(hipMemcpyAsync(d_key_out, pair->d_key, sizeof(uint64_t), hipMemcpyDeviceToDevice, pair->ctx->stream));
+    return SFM_OK;
+}
+
+int sfm_ransac_finalize_key(sfm_pair *pair, const sfm_ransac_params *p, const uint64_t *d_key)
+{
+    uint32_t h0, count;
+    int rc = resolve_shard(pair, p, &h0, &count);
+    if (rc != SFM_OK) return rc;
+    SFM_REQUIRE(d_key, SFM_E_INVALID, "null key pointer");
+    SFM_HIP_TRY(hipSetDevice(pair->ctx->device));
+    rc = launch_ransac_finalize(pair, *p, reinterpret_cast<const unsigned long long *>(d_key), 0, true);
+    if (rc == SFM_OK) { pair->have_E = true; pair->have_P = pair->have_pose = false; }
+    return rc;
+}
+
+int sfm_estimate_E(sfm_pair *pair, const sfm_ransac_params *p)
+{
+    uint32_t h0, count;
+    int rc = resolve_shard(pair, p, &h0, &count);
+    if (rc != SFM_OK) return rc;
+    SFM_REQUIRE(count > 0, SFM_E_INVALID, "empty hypothesis range");
+    SFM_HIP_TRY(hipSetDevice(pair->ctx->device));
+    rc = launch_ransac_score(pair, *p, h0, count);
+    if (rc != SFM_OK) return rc;
+    rc = launch_ransac_finalize(pair, *p, pair->d_key, 0, true);     // arg-max stays on the device
+    if (rc == SFM_OK) { pair->have_E = true; pair->have_P = pair->have_pose = false; }
+    return rc;
+}
+
+int sfm_pose_candidates(sfm_pair *pair, int mode)
+{
+    SFM_REQUIRE(pair, SFM_E_INVALID, "null pair");
+    SFM_REQUIRE(mode == SFM_POSE_REFERENCE || mode == SFM_POSE_CORRECT, SFM_E_INVALID, "unknown pose mode %d", mode);
+    SFM_REQUIRE(pair->have_E, SFM_E_STATE, "computePosecandidates before estimateE");
+    SFM_HIP_TRY(hipSetDevice(pair->ctx->device));
+    int rc = launch_pose_candidates(pair, mode);
+    if (rc == SFM_OK) { pair->have_P = true; pair->have_pose = false; pair->pose_mode = mode; }
+    return rc;
+}
+
+int sfm_choose_pose(sfm_pair *pair, int mode)
+{
+    SFM_REQUIRE(pair, SFM_E_INVALID, "null pair");
+    SFM_REQUIRE(mode == SFM_POSE_REFERENCE || mode == SFM_POSE_CORRECT, SFM_E_INVALID, "unknown pose mode %d", mode);
+    SFM_REQUIRE(pair->have_P, SFM_E_STATE, "choosePose before computePosecandidates");
+    SFM_HIP_TRY(hipSetDevice(pair->ctx->device));
+    int rc = launch_choose_pose(pair, mode);
+    if (rc == SFM_OK) pair->have_pose = true;
+    return rc;
+}
+
+int sfm_triangulate(sfm_pair *pair, int mode)
+{
+    SFM_REQUIRE(pair, SFM_E_INVALID, "null pair");
+    SFM_REQUIRE(mode == SFM_POSE_REFERENCE || mode == SFM_POSE_CORRECT, SFM_E_INVALID, "unknown pose mode %d", mode);
+    SFM_REQUIRE(pair->have_pose, SFM_E_STATE, "linear_triangulation before choosePose");
+    SFM_HIP_TRY(hipSetDevice(pair->ctx->device));
+    return launch_triangulate(pair, mode);
+}
+
+// ---- accessors ------------------------------------------------------------------------------------
+int sfm_pair_ld(const sfm_pair *pair) { return pair ? pair->ld : 0; }
+int sfm_pair_num_points(const sfm_pair *pair) { return pair ? pair->n : 0; }
+
+int sfm_pair_device_ptr(sfm_pair *pair, int which, void **d_ptr, size_t *bytes)
+{
+    SFM_REQUIRE(pair && d_ptr, SFM_E_INVALID, "null argument");
+    void *p = nullptr; size_t b = 0;
+    switch (which) {
+    case SFM_BUF_X0: p = pair->d_X[0]; b = (size_t)3 * pair->ld * 4; break;
+    case SFM_BUF_X1: p = pair->d_X[1]; b = (size_t)3 * pair->ld * 4; break;
+    case SFM_BUF_U0: p = pair->d_U[0]; b = (size_t)3 * pair->ld * 4; break;
+    case SFM_BUF_U1: p = pair->d_U[1]; b = (size_t)3 * pair->ld * 4; break;
+    case SFM_BUF_E: p = pair->d_E; b = 36; break;
+    case SFM_BUF_P: p = pair->d_P; b = 256; break;
+    case SFM_BUF_PINV: p = pair->d_Pinv; b = 256; break;
+    case SFM_BUF_POINTS: p = pair->d_points; b = (size_t)4 * pair->n * 4; break;
+    case SFM_BUF_COUNTS: p = pair->d_counts; b = (size_t)pair->last_count * 4; break;
+    case SFM_BUF_MASK: p = pair->d_mask; b = (size_t)pair->n; break;
+    case SFM_BUF_KEY: p = pair->d_key; b = 8; break;
+    case SFM_BUF_ECAND: p = pair->d_Ecand; b = (size_t)pair->last_count * 36; break;
+    case SFM_BUF_PIND: p = pair->d_Pind; b = 4; break;
+    default: set_error("unknown buffer id %d", which); return SFM_E_INVALID;
+    }
+    *d_ptr = p;
+    if (bytes) *bytes = b;
+    return SFM_OK;
+}
+
+int sfm_get_XU(sfm_pair *pair, int which, float *h_out)
+{
+    SFM_REQUIRE(pair && h_out, SFM_E_INVALID, "null argument");
+    SFM_REQUIRE(which >= SFM_BUF_X0 && which <= SFM_BUF_U1, SFM_E_INVALID, "which must be SFM_BUF_X0..U1");
+    const float *src = which == SFM_BUF_X0 ? pair->d_X[0] : which == SFM_BUF_X1 ? pair->d_X[1]
+                     : which == SFM_BUF_U0 ? pair->d_U[0] : pair->d_U[1];
+    SFM_HIP_TRY(hipMemcpy2DAsync(h_out, (size_t)pair->n * 4, src, (size_t)pair->ld * 4, (size_t)pair->n * 4, 3,
+                                 hipMemcpyDeviceToHost, pair->ctx->stream));
+    SFM_HIP_TRY(hipStreamSynchronize(pair->ctx->stream));
+    return SFM_OK;
+}
+
+int sfm_get_E(sfm_pair *pair, float h_E[9])
+{
+    SFM_REQUIRE(pair && h_E, SFM_E_INVALID, "null argument");
+    SFM_REQUIRE(pair->have_E, SFM_E_STATE, "no E yet");
+    return copy_out(pair, h_E, pair->d_E, 36);
+}
+
+int sfm_get_best(sfm_pair *pair, uint32_t *hyp, uint32_t *count)
+{
+    SFM_REQUIRE(pair, SFM_E_INVALID, "null pair");
+    SFM_REQUIRE(pair->have_E, SFM_E_STATE, "no finalized hypothesis yet");
+    uint32_t b[2];
+    int rc = copy_out(pair, b, pair->d_best, sizeof(b));
+    if (rc != SFM_OK) return rc;
+    if (hyp) *hyp = b[0];
+    if (count) *count = b[1];
+    return SFM_OK;
+}
+
+int sfm_get_key(sfm_pair *pair, uint64_t *key)
+{
+    SFM_REQUIRE(pair && key, SFM_E_INVALID, "null argument");
+    return copy_out(pair, key, pair->d_key, 8);
+}
+
+int sfm_get_inlier_counts(sfm_pair *pair, int32_t *h_counts, size_t capacity)
+{
+    SFM_REQUIRE(pair && h_counts, SFM_E_INVALID, "null argument");
+    SFM_REQUIRE(capacity >= pair->last_count, SFM_E_INVALID, "capacity %zu < %u hypotheses", capacity, pair->last_count);
+    if (pair->last_count == 0) return SFM_OK;
+    return copy_out(pair, h_counts, pair->d_counts, (size_t)pair->last_count * 4);
+}
+
+int sfm_get_E_candidates(sfm_pair *pair, float *h_E, size_t capacity_hyps)
+{
+    SFM_REQUIRE(pair && h_E, SFM_E_INVALID, "null argument");
+    SFM_REQUIRE(capacity_hyps >= pair->last_count, SFM_E_INVALID, "capacity too small");
+    if (pair->last_count == 0) return SFM_OK;
+    return copy_out(pair, h_E, pair->d_Ecand, (size_t)pair->last_count * 36);
+}
+
+int sfm_get_inlier_mask(sfm_pair *pair, uint8_t *h_mask)
+{
+    SFM_REQUIRE(pair && h_mask, SFM_E_INVALID, "null argument");
+    SFM_REQUIRE(pair->have_E, SFM_E_STATE, "no finalized hypothesis yet");
+    return copy_out(pair, h_mask, pair->d_mask, (size_t)pair->n);
+}
+
+int sfm_get_pose_candidates(sfm_pair *pair, float h_P[64])
+{
+    SFM_REQUIRE(pair && h_P, SFM_E_INVALID, "null argument");
+    SFM_REQUIRE(pair->have_P, SFM_E_STATE, "no pose candidates yet");
+    return copy_out(pair, h_P, pair->d_P, 256);
+}
+
+int sfm_get_pose_inverses(sfm_pair *pair, float h_Pinv[64])
+{
+    SFM_REQUIRE(pair && h_Pinv, SFM_E_INVALID, "null argument");
+    SFM_REQUIRE(pair->have_pose, SFM_E_STATE, "choosePose has not run");
+    return copy_out(pair, h_Pinv, pair->d_Pinv, 256);
+}
+
+int sfm_get_pose_index(sfm_pair *pair, int *index)
+{
+    SFM_REQUIRE(pair && index, SFM_E_INVALID, "null argument");
+    SFM_REQUIRE(pair->have_pose, SFM_E_STATE, "choosePose has not run");
+    int v[8];
+    int rc = copy_out(pair, v, pair->d_Pind, sizeof(v));
+    if (rc != SFM_OK) return rc;
+    *index = v[0];
+    if (v[5] & (1 << v[0])) { set_error("chosen pose candidate %d is singular", v[0]); return SFM_E_SINGULAR; }
+    return SFM_OK;
+}
+
+int sfm_get_points(sfm_pair *pair, float *h_points)
+{
+    SFM_REQUIRE(pair && h_points, SFM_E_INVALID, "null argument");
+    SFM_REQUIRE(pair->have_pose, SFM_E_STATE, "linear_triangulation has not run");
+    return copy_out(pair, h_points, pair->d_points, (size_t)4 * pair->n * 4);
+}
+
+int sfm_ransac_last_launch(sfm_pair *pair, int *kernel, int *grid, int *block, int *lds_bytes)
+{
+    SFM_REQUIRE(pair, SFM_E_INVALID, "null pair");
+    if (kernel) *kernel = pair->last_kernel;
+    if (grid) *grid = pair->last_grid;
+    if (block) *block = pair->last_block;
+    if (lds_bytes) *lds_bytes = pair->last_lds;
+    return SFM_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,91 @@
+// common.hpp -- host-side state behind the C ABI (include/sfm_amd.h) and launcher prototypes.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include <string>
+#include "../../include/sfm_amd.h"
+
+namespace sfm {
+
+void set_error(const char *fmt, ...);
+
+#define SFM_HIP_TRY(expr)                                                                      \
+    do {                                                                                       \
+        hipError_t err__ = (expr);                                                             \
+        if (err__ != hipSuccess) {                                                             \
+            ::sfm::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(err__), __FILE__, __LINE__); \
+            return err__ == hipErrorOutOfMemory ? SFM_E_NOMEM : SFM_E_HIP;                     \
+        }                                                                                      \
+    } while (0)
+
+#define SFM_REQUIRE(cond, code, ...)                                                           \
+    do {                                                                                       \
+        if (!(cond)) { ::sfm::set_error(__VA_ARGS__); return (code); }                         \
+    } while (0)
+
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+} // namespace sfm
+
+struct sfm_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int num_cus = 256;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // optional per-kernel stopwatch (sfm_ctx_kernel_timing): event triples around solve / score
+    bool timing = false;
+    static constexpr int kTimingSlots = 256;
+    hipEvent_t tev[kTimingSlots][3] = {};
+    int tcount = 0;
+    // matcher scratch: per-split partial (best, second, index) records
+    void *match_ws = nullptr;
+    size_t match_ws_bytes = 0;
+};
+
+struct sfm_pair {
+    sfm_ctx *ctx = nullptr;
+    int image_count = 2;
+    int n = 0;          // num_points
+    int ld = 0;         // padded row length of X / U (multiple of 128, tail = NaN)
+    float *d_K = nullptr, *d_Kinv = nullptr;
+    float *d_U[2] = { nullptr, nullptr };
+    float *d_X[2] = { nullptr, nullptr };
+    float *d_E = nullptr;              // 9
+    float *d_P = nullptr;              // 4 x 16 candidates
+    float *d_Pinv = nullptr;           // 4 x 16 inverses
+    int   *d_Pind = nullptr;           // chosen index (+ 4 cheirality vote counters)
+    float *d_points = nullptr;         // 4 x n
+    uint8_t *d_mask = nullptr;         // n
+    unsigned long long *d_key = nullptr;   // [0] packed best of last score, [1] scratch
+    uint32_t *d_best = nullptr;        // [0] hyp, [1] count of the finalized hypothesis
+    // per-shard buffers, grown on demand
+    int   *d_counts = nullptr;
+    float *d_Ecand = nullptr;
+    size_t cap_hyps = 0;
+    uint32_t last_count = 0;           // hyp_count of the last score call
+    bool have_points = false, have_E = false, have_P = false, have_pose = false;
+    int pose_mode = SFM_POSE_REFERENCE;
+    int last_kernel = 0, last_grid = 0, last_block = 0, last_lds = 0;
+};
+
+namespace sfm {
+
+// ransac.hip
+int launch_ransac_score(sfm_pair *pair, const sfm_ransac_params &p, uint32_t h0, uint32_t count);
+int launch_ransac_finalize(sfm_pair *pair, const sfm_ransac_params &p, const unsigned long long *d_key, uint32_t hyp_host, bool from_key);
+int launch_permutation_indices(sfm_ctx *ctx, int n, uint32_t seed, int32_t *d_indices);
+
+// pose.hip
+int launch_fill_xu(sfm_pair *pair, const sfm_sift_point *d_data);
+int launch_set_points(sfm_pair *pair, const float *d_X0, const float *d_X1);
+int launch_pose_candidates(sfm_pair *pair, int mode);
+int launch_choose_pose(sfm_pair *pair, int mode);
+int launch_triangulate(sfm_pair *pair, int mode);
+
+// match.hip
+int launch_match(sfm_ctx *ctx, const float *d1, int n1, int ld1, const float *d2, int n2, int ld2,
+                 float *d_best, float *d_second, int32_t *d_index,
+                 sfm_sift_point *sift1, const sfm_sift_point *sift2);
+
+} // namespace sfm

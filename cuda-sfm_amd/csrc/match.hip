@@ -1,0 +1,274 @@
+// match.hip -- brute-force 128-d descriptor matcher on the gfx950 matrix cores.
+//
+// Replaces MatchSiftData / CleanMatches / FindMaxCorr10 (CudaSift/matching.cu:289-397,
+// 1090-1206).  The all-pairs score matrix S = D2 (N2 x 128) . D1^T (128 x N1) is tiled for
+// v_mfma_f32_32x32x2_f32 and never written anywhere: a running (best, second, arg-best) per
+// query is folded straight out of the accumulators.
+//
+// Numerics: one MFMA adds k = 0 then k = 1 with a single rounding per product, and successive
+// MFMAs chain through the accumulator, so every score is the d = 0..127 ordered fused chain
+//     s = fmaf(a[127], b[127], ... fmaf(a[1], b[1], fmaf(a[0], b[0], 0)))
+// i.e. exactly what nvcc emits for matching.cu:338-351 and what the oracle computes -> scores and
+// indices are bit-exact, not "close".
+//
+// Mapping (per wavefront):  MFMA rows i <-> 32 streamed database points p2 (A operand, from LDS),
+//                           MFMA cols j <-> 32 resident query points p1 (B operand, 64 VGPRs/tile).
+// With that orientation lane l owns ONE query (column l & 31) and 16 database rows per tile, so
+// the arg-max epilogue is 16 compare/select steps per lane and no cross-lane traffic until the end.
+//
+// LDS tile: [64 rows][132 floats]; +4 floats of padding per row makes every ds_read_b128 lane
+// group hit 16 distinct 16-byte slots.  Inside each group of 8 floats the order is
+// (d0 d2 d4 d6 | d1 d3 d5 d7) so that one b128 read yields the operands of four consecutive MFMA
+// k-steps for the lane's k-parity (lane >> 5).
+#include "common.hpp"
+#include "device_math.hpp"
+
+namespace sfm {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kRowsPerStage = 64;        // database rows per LDS stage (RT = 2 MFMA row tiles)
+constexpr int kLdsStride = 132;          // floats per staged row
+constexpr int kMatchThreads = 256;       // 4 wavefronts
+
+struct Top2 { float best, second; int idx; };
+
+__device__ __forceinline__ void top2_push(Top2 &t, float s, int p)
+{
+    // matching.cu:352-361 / match.cu:64-68: strict '>', ascending p within a lane
+    if (s > t.best) { t.second = t.best; t.best = s; t.idx = p; }
+    else if (s > t.second) t.second = s;
+}
+
+__device__ __forceinline__ Top2 top2_merge(const Top2 &a, const Top2 &b)
+{
+    // higher score wins; equal scores -> lower index (-1 compares as largest)
+    const bool bwins = (b.best > a.best) || (b.best == a.best && (unsigned)b.idx < (unsigned)a.idx);
+    Top2 r;
+    r.best = bwins ? b.best : a.best;
+    r.idx = bwins ? b.idx : a.idx;
+    const float lo = bwins ? a.best : b.best;
+    r.second = fmaxf(lo, fmaxf(a.second, b.second));
+    return r;
+}
+
+// Stage `rows` descriptor rows (first row `row0`, zero beyond `nrows`) into buf[rows][132].
+__device__ __forceinline__ void stage_load(const float *__restrict__ base, int ld, int row0, int nrows,
+                                           float4 (&regs)[4][2])
+{
+    const int c8 = threadIdx.x & 15;             // which 8-float chunk of the 128
+    const int rr = threadIdx.x >> 4;             // 16 rows per pass
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+        const int row = row0 + pass * 16 + rr;
+        if (row < nrows) {
+            const float4 *src = reinterpret_cast<const float4 *>(base + (size_t)row * ld + 8 * c8);
+            regs[pass][0] = src[0];
+            regs[pass][1] = src[1];
+        } else {
+            regs[pass][0] = make_float4(0.f, 0.f, 0.f, 0.f);
+            regs[pass][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+}
+
+__device__ __forceinline__ void stage_store(float *buf, const float4 (&regs)[4][2])
+{
+    const int c8 = threadIdx.x & 15;
+    const int rr = threadIdx.x >> 4;
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+        float4 *dst = reinterpret_cast<float4 *>(buf + (pass * 16 + rr) * kLdsStride + 8 * c8);
+        const float4 a = regs[pass][0], b = regs[pass][1];
+        dst[0] = make_float4(a.x, a.z, b.x, b.z);      // even d: k-parity 0
+        dst[1] = make_float4(a.y, a.w, b.y, b.w);      // odd d : k-parity 1
+    }
+}
+
+// One block: CT*128 queries (4 waves x CT column tiles) against database rows [row_begin, row_end).
+template <int CT>
+__global__ __launch_bounds__(kMatchThreads)
+void match_mfma_kernel(const float *__restrict__ q, int nq, int ldq,
+                       const float *__restrict__ db, int ndb, int lddb,
+                       int rows_per_split,
+                       float *__restrict__ ws_best, float *__restrict__ ws_second, int *__restrict__ ws_idx)
+{
+    __shared__ __attribute__((aligned(16))) float lds[2][kRowsPerStage * kLdsStride];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int col = lane & 31;
+    const int half = lane >> 5;
+    const int q0 = blockIdx.x * (CT * 128);
+    const int split = blockIdx.y;
+    const int row_begin = split * rows_per_split;
+    const int row_end = min(ndb, row_begin + rows_per_split);
+
+    // ---- prologue: resident query fragments b[ct][2m + half], m = 0..63 --------------------
+    float bq[CT][64];
+    {
+        float4 regs[4][2];
+        constexpr int kChunks = CT * 128 / kRowsPerStage;
+        for (int ch = 0; ch < kChunks; ++ch) {
+            stage_load(q, ldq, q0 + ch * kRowsPerStage, nq, regs);
+            __syncthreads();
+            stage_store(lds[0], regs);
+            __syncthreads();
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                const int r = (wave * CT + ct) * 32 - ch * kRowsPerStage;     // first row of this column tile in the chunk
+                if (r >= 0 && r < kRowsPerStage) {
+                    const float *src = lds[0] + (r + col) * kLdsStride + 4 * half;
+#pragma unroll
+                    for (int m = 0; m < 16; ++m) {
+                        const float4 v = *reinterpret_cast<const float4 *>(src + 8 * m);
+                        bq[ct][4 * m + 0] = v.x; bq[ct][4 * m + 1] = v.y;
+                        bq[ct][4 * m + 2] = v.z; bq[ct][4 * m + 3] = v.w;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    Top2 top[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) { top[ct].best = 0.0f; top[ct].second = 0.0f; top[ct].idx = -1; }
+
+    // ---- main loop over database stages of 64 rows ------------------------------------------
+    const int nstage = (row_end - row_begin + kRowsPerStage - 1) / kRowsPerStage;
+    float4 regs[4][2];
+    if (nstage > 0) {
+        stage_load(db, lddb, row_begin, row_end, regs);
+        stage_store(lds[0], regs);
+    }
+    __syncthreads();
+    for (int s = 0; s < nstage; ++s) {
+        const float *cur = lds[s & 1];
+        if (s + 1 < nstage) stage_load(db, lddb, row_begin + (s + 1) * kRowsPerStage, row_end, regs);
+
+        f32x16 acc[2][CT];
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[rt][ct][r] = 0.0f;
+
+        const float *a0p = cur + col * kLdsStride + 4 * half;
+        const float *a1p = a0p + 32 * kLdsStride;
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+            const float4 a0 = *reinterpret_cast<const float4 *>(a0p + 8 * m);
+            const float4 a1 = *reinterpret_cast<const float4 *>(a1p + 8 * m);
+            const float a0v[4] = { a0.x, a0.y, a0.z, a0.w };
+            const float a1v[4] = { a1.x, a1.y, a1.z, a1.w };
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+                    acc[0][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0v[k], bq[ct][4 * m + k], acc[0][ct], 0, 0, 0);
+                    acc[1][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1v[k], bq[ct][4 * m + k], acc[1][ct], 0, 0, 0);
+                }
+        }
+
+        // fold the 2 x CT accumulator tiles into the running top-2 (ascending database index)
+        const int stage_row0 = row_begin + s * kRowsPerStage;
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int p2 = stage_row0 + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) top2_push(top[ct], acc[rt][ct][r], p2);
+            }
+
+        if (s + 1 < nstage) stage_store(lds[(s + 1) & 1], regs);
+        __syncthreads();
+    }
+
+    // ---- merge the two k-parity halves of each column and emit the split's partial ------------
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        Top2 o;
+        o.best = __shfl_xor(top[ct].best, 32);
+        o.second = __shfl_xor(top[ct].second, 32);
+        o.idx = __shfl_xor(top[ct].idx, 32);
+        const Top2 mrg = top2_merge(top[ct], o);
+        const int p1 = q0 + (wave * CT + ct) * 32 + col;
+        if (half == 0 && p1 < nq) {
+            const size_t w = (size_t)split * nq + p1;
+            ws_best[w] = mrg.best; ws_second[w] = mrg.second; ws_idx[w] = mrg.idx;
+        }
+    }
+}
+
+// Merge the per-split partials (ascending database ranges) and write the results either to
+// plain arrays or into the SiftPoint fields MatchSiftData updates (matching.cu:391-395).
+__global__ __launch_bounds__(256)
+void match_merge_kernel(int nq, int nsplit, const float *__restrict__ ws_best, const float *__restrict__ ws_second,
+                        const int *__restrict__ ws_idx, float *__restrict__ out_best, float *__restrict__ out_second,
+                        int *__restrict__ out_idx, sfm_sift_point *__restrict__ sift1, const sfm_sift_point *__restrict__ sift2)
+{
+    const int p1 = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p1 >= nq) return;
+    Top2 t{ ws_best[p1], ws_second[p1], ws_idx[p1] };
+    for (int s = 1; s < nsplit; ++s) {
+        const size_t w = (size_t)s * nq + p1;
+        t = top2_merge(t, Top2{ ws_best[w], ws_second[w], ws_idx[w] });
+    }
+    if (out_best) out_best[p1] = t.best;
+    if (out_second) out_second[p1] = t.second;
+    if (out_idx) out_idx[p1] = t.idx;
+    if (sift1) {
+        sfm_sift_point *o = sift1 + p1;
+        o->score = t.best;
+        o->match = t.idx;
+        o->match_xpos = t.idx >= 0 ? sift2[t.idx].xpos : 0.0f;
+        o->match_ypos = t.idx >= 0 ? sift2[t.idx].ypos : 0.0f;
+        o->ambiguity = t.second / (t.best + 1e-6f);
+    }
+}
+
+int launch_match(sfm_ctx *ctx, const float *d1, int n1, int ld1, const float *d2, int n2, int ld2,
+                 float *d_best, float *d_second, int32_t *d_index,
+                 sfm_sift_point *sift1, const sfm_sift_point *sift2)
+{
+    if (n1 <= 0 || n2 <= 0) return SFM_OK;                 // matching.cu:1095-1096
+    const int ct = n1 > 4096 ? 2 : 1;
+    const int qblocks = (n1 + ct * 128 - 1) / (ct * 128);
+    // enough (query block, database split) pairs to put ~2 blocks on every CU
+    int nsplit = (2 * ctx->num_cus + qblocks - 1) / qblocks;
+    const int max_split = (n2 + kRowsPerStage - 1) / kRowsPerStage;
+    if (nsplit > max_split) nsplit = max_split;
+    if (nsplit < 1) nsplit = 1;
+    int rows_per_split = (n2 + nsplit - 1) / nsplit;
+    rows_per_split = round_up(rows_per_split, kRowsPerStage);
+    nsplit = (n2 + rows_per_split - 1) / rows_per_split;
+
+    const size_t need = (size_t)nsplit * n1 * 12;
+    if (need > ctx->match_ws_bytes) {
+        SFM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if (ctx->match_ws) (void)hipFree(ctx->match_ws);
+        ctx->match_ws = nullptr; ctx->match_ws_bytes = 0;
+        SFM_HIP_TRY(hipMalloc(&ctx->match_ws, need));
+        ctx->match_ws_bytes = need;
+    }
+    float *wb = static_cast<float *>(ctx->match_ws);
+    float *wsnd = wb + (size_t)nsplit * n1;
+    int *wi = reinterpret_cast<int *>(wsnd + (size_t)nsplit * n1);
+
+    const dim3 grid(qblocks, nsplit);
+    if (ct == 2)
+        hipLaunchKernelGGL(match_mfma_kernel<2>, grid, dim3(kMatchThreads), 0, ctx->stream,
+                           d1, n1, ld1, d2, n2, ld2, rows_per_split, wb, wsnd, wi);
+    else
+        hipLaunchKernelGGL(match_mfma_kernel<1>, grid, dim3(kMatchThreads), 0, ctx->stream,
+                           d1, n1, ld1, d2, n2, ld2, rows_per_split, wb, wsnd, wi);
+    SFM_HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(match_merge_kernel, dim3((n1 + 255) / 256), dim3(256), 0, ctx->stream,
+                       n1, nsplit, wb, wsnd, wi, d_best, d_second, d_index, sift1, sift2);
+    SFM_HIP_TRY(hipGetLastError());
+    return SFM_OK;
+}
+
+} // namespace sfm

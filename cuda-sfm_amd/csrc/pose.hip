@@ -1,0 +1,227 @@
+// pose.hip -- fillXU, pose candidates, choosePose, linear triangulation (gfx950).
+//
+// Replaces, kernel for kernel, what the reference spreads over copy_point + cublasSgemm
+// (SfM/sfm.cu:80-92, kernels.h:261-279,102-109), a host-side svd + candidate_kernels
+// (sfm.cu:238-252, kernels.h:357-385), compute_linear_triangulation_A + cusolverDnSgesvdjBatched
+// + normalize_pt_kernal + 4x (getrf, getri, gemm, two blocking 4-byte copies)
+// (sfm.cu:254-344, kernels.h:132-194,387-450).  All of it is HBM-trivial; the point of these
+// kernels is to remove ~40 mallocs/frees, 3 device syncs and the host round trips per pair.
+#include "common.hpp"
+#include "device_math.hpp"
+
+namespace sfm {
+
+// ---- fillXU -------------------------------------------------------------------------------
+// U = [x; y; 1] (pixels), X = Kinv * U.  Rows are padded to ld (multiple of 128); the X tail is
+// NaN so that padded points can never be inliers, the U tail is 0.
+__global__ __launch_bounds__(256)
+void fill_xu_kernel(const sfm_sift_point *__restrict__ data, int n, int ld, const float *__restrict__ kinv,
+                    float *__restrict__ U0, float *__restrict__ U1, float *__restrict__ X0, float *__restrict__ X1)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= ld) return;
+    const float qnan = __builtin_nanf("");
+    float u0[3] = { 0.0f, 0.0f, 0.0f }, u1[3] = { 0.0f, 0.0f, 0.0f };
+    float x0[3] = { qnan, qnan, qnan }, x1[3] = { qnan, qnan, qnan };
+    if (j < n) {
+        const sfm_sift_point *p = data + j;
+        u0[0] = p->xpos;       u0[1] = p->ypos;       u0[2] = 1.0f;
+        u1[0] = p->match_xpos; u1[1] = p->match_ypos; u1[2] = 1.0f;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            x0[r] = fmaf(kinv[3 * r + 2], u0[2], fmaf(kinv[3 * r + 1], u0[1], kinv[3 * r] * u0[0]));
+            x1[r] = fmaf(kinv[3 * r + 2], u1[2], fmaf(kinv[3 * r + 1], u1[1], kinv[3 * r] * u1[0]));
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        U0[(size_t)r * ld + j] = u0[r];
+        U1[(size_t)r * ld + j] = u1[r];
+        X0[(size_t)r * ld + j] = x0[r];
+        X1[(size_t)r * ld + j] = x1[r];
+    }
+}
+
+__global__ __launch_bounds__(256)
+void set_points_kernel(const float *__restrict__ s0, const float *__restrict__ s1, int n, int ld,
+                       float *__restrict__ X0, float *__restrict__ X1)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= ld) return;
+    const float qnan = __builtin_nanf("");
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        X0[(size_t)r * ld + j] = j < n ? s0[(size_t)r * n + j] : qnan;
+        X1[(size_t)r * ld + j] = j < n ? s1[(size_t)r * n + j] : qnan;
+    }
+}
+
+// ---- pose candidates ------------------------------------------------------------------------
+__global__ __launch_bounds__(64)
+void pose_candidates_kernel(const float *__restrict__ E, int mode, float *__restrict__ P)
+{
+    float e[9], p[64];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) e[k] = E[k];
+    pose_candidates(e, mode, p);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < 64; ++k) P[k] = p[k];
+    }
+}
+
+// ---- choosePose -----------------------------------------------------------------------------
+// d_Pind layout: [0] chosen index, [1..4] cheirality votes, [5] singular-candidate bit mask.
+__global__ __launch_bounds__(64)
+void choose_pose_reference_kernel(const float *__restrict__ X0, const float *__restrict__ X1, int ld,
+                                  const float *__restrict__ P, int sweeps,
+                                  float *__restrict__ Pinv, int *__restrict__ pind)
+{
+    const int i = threadIdx.x & 3;                 // candidate handled by this lane (lanes >= 4 mirror)
+    float Pm[16], Q[16], pt[4];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) Pm[k] = P[16 * i + k];
+    // cheirality on correspondence #0 only (kernels.h:408-409)
+    triangulate_point(X0[0], X0[ld], X1[0], X1[ld], Pm, sweeps, pt);
+    const bool ok = inv4(Pm, Q);                   // in-place inverse of the reference (sfm.cu:286, Q8)
+    if (!ok) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) Q[k] = 0.0f;
+    }
+    float z2 = Q[8] * pt[0];
+#pragma unroll
+    for (int k = 1; k < 4; ++k) z2 = fmaf(Q[8 + k], pt[k], z2);
+    const bool pass = (pt[2] > 0.0f) && (z2 > 0.0f);
+    const unsigned long long m = __ballot(pass) & 0xFull;
+    const unsigned long long sing = __ballot(!ok) & 0xFull;
+    if (threadIdx.x < 4) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) Pinv[16 * i + k] = Q[k];
+        pind[1 + i] = pass ? 1 : 0;
+    }
+    if (threadIdx.x == 0) {
+        pind[0] = m ? (63 - __builtin_clzll(m)) : 0;      // last passing candidate wins (sfm.cu:295-296)
+        pind[5] = (int)sing;
+    }
+}
+
+__global__ __launch_bounds__(256)
+void choose_pose_vote_kernel(const float *__restrict__ X0, const float *__restrict__ X1, int ld, int n,
+                             const float *__restrict__ P, int sweeps, int *__restrict__ pind)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = j < n;
+    const float x1 = live ? X0[j] : 0.0f, y1 = live ? X0[(size_t)ld + j] : 0.0f;
+    const float x2 = live ? X1[j] : 0.0f, y2 = live ? X1[(size_t)ld + j] : 0.0f;
+#pragma unroll 1
+    for (int i = 0; i < 4; ++i) {
+        float Pm[16], pt[4];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) Pm[k] = P[16 * i + k];
+        triangulate_point(x1, y1, x2, y2, Pm, sweeps, pt);
+        float z2 = Pm[8] * pt[0];
+#pragma unroll
+        for (int k = 1; k < 4; ++k) z2 = fmaf(Pm[8 + k], pt[k], z2);
+        const bool pass = live && (pt[2] > 0.0f) && (z2 > 0.0f);
+        const int c = __builtin_popcountll(__ballot(pass));
+        if ((threadIdx.x & 63) == 0 && c) atomicAdd(&pind[1 + i], c);
+    }
+}
+
+__global__ __launch_bounds__(64)
+void choose_pose_pick_kernel(const float *__restrict__ P, float *__restrict__ Pinv, int *__restrict__ pind)
+{
+    const int i = threadIdx.x & 3;
+    float Pm[16], Q[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) Pm[k] = P[16 * i + k];
+    const bool ok = inv4(Pm, Q);
+    if (!ok) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) Q[k] = 0.0f;
+    }
+    const unsigned long long sing = __ballot(!ok) & 0xFull;
+    if (threadIdx.x < 4) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) Pinv[16 * i + k] = Q[k];
+    }
+    if (threadIdx.x == 0) {
+        int best = -1, arg = 0;
+        for (int k = 0; k < 4; ++k)
+            if (pind[1 + k] > best) { best = pind[1 + k]; arg = k; }     // first maximum
+        pind[0] = arg;
+        pind[5] = (int)sing;
+    }
+}
+
+// ---- linear triangulation ---------------------------------------------------------------------
+__global__ __launch_bounds__(256)
+void triangulate_kernel(const float *__restrict__ X0, const float *__restrict__ X1, int ld, int n,
+                        const float *__restrict__ Pset, const int *__restrict__ pind, int sweeps,
+                        float *__restrict__ out)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const float *Psel = Pset + 16 * pind[0];
+    float Pm[16], pt[4];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) Pm[k] = Psel[k];
+    triangulate_point(X0[j], X0[(size_t)ld + j], X1[j], X1[(size_t)ld + j], Pm, sweeps, pt);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) out[(size_t)c * n + j] = pt[c];         // 4 x n row-major (kernels.h:440-449)
+}
+
+// ---- launchers --------------------------------------------------------------------------------
+constexpr int kSweeps4 = 8;     // one-sided Jacobi sweeps for 4x4 systems
+
+int launch_fill_xu(sfm_pair *pair, const sfm_sift_point *d_data)
+{
+    hipLaunchKernelGGL(fill_xu_kernel, dim3((pair->ld + 255) / 256), dim3(256), 0, pair->ctx->stream,
+                       d_data, pair->n, pair->ld, pair->d_Kinv, pair->d_U[0], pair->d_U[1], pair->d_X[0], pair->d_X[1]);
+    SFM_HIP_TRY(hipGetLastError());
+    return SFM_OK;
+}
+
+int launch_set_points(sfm_pair *pair, const float *d_X0, const float *d_X1)
+{
+    hipLaunchKernelGGL(set_points_kernel, dim3((pair->ld + 255) / 256), dim3(256), 0, pair->ctx->stream,
+                       d_X0, d_X1, pair->n, pair->ld, pair->d_X[0], pair->d_X[1]);
+    SFM_HIP_TRY(hipGetLastError());
+    return SFM_OK;
+}
+
+int launch_pose_candidates(sfm_pair *pair, int mode)
+{
+    hipLaunchKernelGGL(pose_candidates_kernel, dim3(1), dim3(64), 0, pair->ctx->stream, pair->d_E, mode, pair->d_P);
+    SFM_HIP_TRY(hipGetLastError());
+    return SFM_OK;
+}
+
+int launch_choose_pose(sfm_pair *pair, int mode)
+{
+    hipStream_t st = pair->ctx->stream;
+    SFM_HIP_TRY(hipMemsetAsync(pair->d_Pind, 0, 8 * sizeof(int), st));
+    if (mode == SFM_POSE_REFERENCE) {
+        hipLaunchKernelGGL(choose_pose_reference_kernel, dim3(1), dim3(64), 0, st,
+                           pair->d_X[0], pair->d_X[1], pair->ld, pair->d_P, kSweeps4, pair->d_Pinv, pair->d_Pind);
+    } else {
+        hipLaunchKernelGGL(choose_pose_vote_kernel, dim3((pair->n + 255) / 256), dim3(256), 0, st,
+                           pair->d_X[0], pair->d_X[1], pair->ld, pair->n, pair->d_P, kSweeps4, pair->d_Pind);
+        SFM_HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(choose_pose_pick_kernel, dim3(1), dim3(64), 0, st, pair->d_P, pair->d_Pinv, pair->d_Pind);
+    }
+    SFM_HIP_TRY(hipGetLastError());
+    return SFM_OK;
+}
+
+int launch_triangulate(sfm_pair *pair, int mode)
+{
+    // REFERENCE triangulates with the matrix choosePose left in d_P, i.e. the inverse (sfm.cu:286,323; Q8)
+    const float *Pset = (mode == SFM_POSE_REFERENCE) ? pair->d_Pinv : pair->d_P;
+    hipLaunchKernelGGL(triangulate_kernel, dim3((pair->n + 255) / 256), dim3(256), 0, pair->ctx->stream,
+                       pair->d_X[0], pair->d_X[1], pair->ld, pair->n, Pset, pair->d_Pind, kSweeps4, pair->d_points);
+    SFM_HIP_TRY(hipGetLastError());
+    return SFM_OK;
+}
+
+} // namespace sfm

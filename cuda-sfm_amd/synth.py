@@ -1,0 +1,128 @@
+"""Portable synthetic inputs for the two-view path.
+
+Everything is derived from SplitMix64 + Box-Muller in numpy uint64/float64 arithmetic, so the same
+seed gives the same bytes on every machine (no std::*_distribution / rand()).  Used by bench.py,
+the smoke test and the parity tests; the oracle and the HIP path both consume these arrays.
+"""
+import numpy as np
+
+SEED = 0x5EED5F3D
+_G = np.uint64(0x9E3779B97F4A7C15)
+_M1 = np.uint64(0xBF58476D1CE4E5B9)
+_M2 = np.uint64(0x94D049BB133111EB)
+
+SIFT_DTYPE = np.dtype([
+    ("xpos", "<f4"), ("ypos", "<f4"), ("scale", "<f4"), ("sharpness", "<f4"),
+    ("edgeness", "<f4"), ("orientation", "<f4"), ("score", "<f4"), ("ambiguity", "<f4"),
+    ("match", "<i4"), ("match_xpos", "<f4"), ("match_ypos", "<f4"), ("match_error", "<f4"),
+    ("subsampling", "<f4"), ("empty", "<f4", (3,)), ("data", "<f4", (128,)),
+])
+
+
+def splitmix64(seed, n, stream=0):
+    """n 64-bit outputs of SplitMix64 started at seed (+ a stream offset)."""
+    with np.errstate(over="ignore"):
+        base = np.uint64(seed & 0xFFFFFFFFFFFFFFFF) + np.uint64(stream) * np.uint64(0xD1342543DE82EF95)
+        z = base + _G * (np.arange(1, n + 1, dtype=np.uint64))
+        z = (z ^ (z >> np.uint64(30))) * _M1
+        z = (z ^ (z >> np.uint64(27))) * _M2
+        return z ^ (z >> np.uint64(31))
+
+
+def uniform01(seed, n, stream=0):
+    return (splitmix64(seed, n, stream) >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+
+
+def normal(seed, n, stream=0):
+    m = (n + 1) // 2
+    u1 = 1.0 - uniform01(seed, m, 2 * stream + 1000)       # (0, 1]
+    u2 = uniform01(seed, m, 2 * stream + 1001)
+    r = np.sqrt(-2.0 * np.log(u1))
+    out = np.concatenate([r * np.cos(2 * np.pi * u2), r * np.sin(2 * np.pi * u2)])
+    return out[:n]
+
+
+def camera(width=720, height=576, focal=2360.0):
+    """K and K^-1 exactly as the reference's caller builds them (src/main.cpp:292-297), float32."""
+    K = np.array([[focal, 0, width / 2.0], [0, focal, height / 2.0], [0, 0, 1]], np.float64).astype(np.float32)
+    Kinv = np.array([[1.0 / focal, 0, -(width / 2.0) / focal],
+                     [0, 1.0 / focal, -(height / 2.0) / focal],
+                     [0, 0, 1]], np.float64).astype(np.float32)
+    return K, Kinv
+
+
+def _rot_y(a):
+    c, s = np.cos(a), np.sin(a)
+    return np.array([[c, 0, s], [0, 1, 0], [-s, 0, c]])
+
+
+def _rot_x(a):
+    c, s = np.cos(a), np.sin(a)
+    return np.array([[1, 0, 0], [0, c, -s], [0, s, c]])
+
+
+def two_view_scene(n, seed=SEED, noise_px=0.5, outlier_frac=0.3, width=720, height=576, focal=2360.0):
+    """N correspondences of a rigid scene packed into SiftPoint records (xpos, ypos, match_xpos,
+    match_ypos), so that fillXU is exercised.  Points uniform in [-1,1]^2 x [4,8] (cam-1 frame),
+    cam-2 = Ry(10 deg) Rx(3 deg), t = normalize(1, 0.1, 0.2), sigma = noise_px, outliers: x2 uniform
+    in the image."""
+    K, Kinv = camera(width, height, focal)
+    K64 = K.astype(np.float64)
+    P = np.stack([2 * uniform01(seed, n, 1) - 1, 2 * uniform01(seed, n, 2) - 1, 4 + 4 * uniform01(seed, n, 3)], 1)
+    R = _rot_y(np.deg2rad(10.0)) @ _rot_x(np.deg2rad(3.0))
+    t = np.array([1.0, 0.1, 0.2]); t /= np.linalg.norm(t)
+    p1 = (K64 @ P.T).T
+    x1 = p1[:, :2] / p1[:, 2:]
+    P2 = (R @ P.T).T + t
+    p2 = (K64 @ P2.T).T
+    x2 = p2[:, :2] / p2[:, 2:]
+    x1 = x1 + noise_px * np.stack([normal(seed, n, 4), normal(seed, n, 5)], 1)
+    x2 = x2 + noise_px * np.stack([normal(seed, n, 6), normal(seed, n, 7)], 1)
+    is_out = uniform01(seed, n, 8) < outlier_frac
+    ox = np.stack([width * uniform01(seed, n, 9), height * uniform01(seed, n, 10)], 1)
+    x2 = np.where(is_out[:, None], ox, x2)
+    sift = np.zeros(n, SIFT_DTYPE)
+    sift["xpos"] = x1[:, 0].astype(np.float32)
+    sift["ypos"] = x1[:, 1].astype(np.float32)
+    sift["match_xpos"] = x2[:, 0].astype(np.float32)
+    sift["match_ypos"] = x2[:, 1].astype(np.float32)
+    sift["match"] = np.arange(n, dtype=np.int32)
+    return {"K": K, "Kinv": Kinv, "sift": sift, "R": R, "t": t, "points3d": P, "outlier": is_out}
+
+
+def normalized_points(scene):
+    """X = Kinv [x; y; 1] in float64 -> float32 (3 x N each); convenience for set_points callers.
+    (The parity tests use fillXU / the oracle's fill_xu instead, which round differently.)"""
+    s = scene["sift"]
+    n = len(s)
+    Ki = scene["Kinv"].astype(np.float64)
+    U0 = np.stack([s["xpos"], s["ypos"], np.ones(n, np.float32)]).astype(np.float64)
+    U1 = np.stack([s["match_xpos"], s["match_ypos"], np.ones(n, np.float32)]).astype(np.float64)
+    return (Ki @ U0).astype(np.float32), (Ki @ U1).astype(np.float32)
+
+
+def descriptors(n, seed=SEED, noise=0.05):
+    """Two descriptor sets shaped like CudaSift output (non-negative, clipped at 0.2, unit L2;
+    reference CudaSift/cudaSiftD.cu:390-409): set 2 = permuted set 1 + noise.  Returns
+    (d1, d2, perm) with d2[i] ~ d1[perm[i]]."""
+    def finish(d):
+        d = d / np.linalg.norm(d, axis=1, keepdims=True)
+        d = np.minimum(d, 0.2)
+        d = d / np.linalg.norm(d, axis=1, keepdims=True)
+        return d
+    d1 = finish(np.abs(normal(seed, n * 128, 20).reshape(n, 128)))
+    key = splitmix64(seed, n, 21)
+    perm = np.argsort(key, kind="stable")
+    d2 = finish(np.abs(d1[perm] + noise * normal(seed, n * 128, 22).reshape(n, 128)))
+    return np.ascontiguousarray(d1, np.float32), np.ascontiguousarray(d2, np.float32), perm
+
+
+def sift_records(desc, seed=SEED, width=720, height=576, stream=30):
+    """Wrap a descriptor matrix into SiftPoint records with random keypoint positions."""
+    n = desc.shape[0]
+    s = np.zeros(n, SIFT_DTYPE)
+    s["xpos"] = (width * uniform01(seed, n, stream)).astype(np.float32)
+    s["ypos"] = (height * uniform01(seed, n, stream + 1)).astype(np.float32)
+    s["data"] = desc
+    s["match"] = -1
+    return s

@@ -1,0 +1,170 @@
+/*
+ * sfm_amd.h -- C ABI of the MI355X-native two-view geometric-estimation path.
+ *
+ * This is the drop-in boundary for the hot path of Black-Phoenix/CUDA-SfM:
+ *     MatchSiftData            (CudaSift/cudaSift.h:42, CudaSift/matching.cu:1090-1206)
+ *     SfM::Image_pair::*       (SfM/sfm.h:20-60, SfM/sfm.cu:28-359)
+ * The reference has no FFI layer (a C++ class and free functions linked statically,
+ * src/main.cpp:282,298-307); the C++ facade in cuda-sfm_amd/host/ keeps those names on top of
+ * this ABI, and INTEGRATION.md shows the binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every function returns SFM_OK (0) or a negative SFM_E_* code; sfm_last_error() returns a
+ *     thread-local description of the last failure (reference convention: print + exit(),
+ *     SfM/common.cu:3-15, CudaSift/cudautils.h:15-39 -- the facade can reproduce that).
+ *   - pointers named d_* are DEVICE pointers (HIP), h_* are host pointers; plain sizes.
+ *   - all matrices are row-major (SfM/common.h:19-20).
+ *   - work is enqueued on the context's HIP stream; functions that return host values
+ *     synchronise that stream, everything else is asynchronous.
+ *   - one context per host thread per device; calls on one context are not re-entrant.
+ */
+#ifndef SFM_AMD_H
+#define SFM_AMD_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SFM_ABI_VERSION 1
+
+#define SFM_OK           0
+#define SFM_E_INVALID   (-1)   /* bad argument                                     */
+#define SFM_E_HIP       (-2)   /* HIP runtime / launch failure                     */
+#define SFM_E_NOMEM     (-3)   /* device allocation failed                         */
+#define SFM_E_STATE     (-4)   /* call order violated (e.g. triangulate before E)  */
+#define SFM_E_SINGULAR  (-5)   /* singular pose candidate (kernels.h:143-161)      */
+
+/* Feature record, identical layout to the reference's SiftPoint (CudaSift/cudaSift.h:6-22). */
+typedef struct sfm_sift_point {
+    float xpos, ypos, scale, sharpness, edgeness, orientation;
+    float score, ambiguity;
+    int32_t match;
+    float match_xpos, match_ypos, match_error, subsampling;
+    float empty[3];
+    float data[128];
+} sfm_sift_point;   /* 576 bytes */
+
+typedef struct sfm_ctx  sfm_ctx;    /* device + stream + matcher scratch                      */
+typedef struct sfm_pair sfm_pair;   /* state of one SfM::Image_pair (sfm.h:20-60)             */
+
+/* ---- context -------------------------------------------------------------------------------- */
+int  sfm_abi_version(void);
+const char *sfm_last_error(void);
+int  sfm_ctx_create(int device_id, sfm_ctx **out);          /* replaces InitCuda + cuBLAS/cuSOLVER handle setup (sfm.cu:46-75) */
+int  sfm_ctx_destroy(sfm_ctx *ctx);
+int  sfm_ctx_set_stream(sfm_ctx *ctx, void *hip_stream);    /* NULL = default stream                                          */
+int  sfm_ctx_synchronize(sfm_ctx *ctx);
+/* HIP-event stopwatch on the context's stream (for callers without their own event API). */
+int  sfm_ctx_timer_start(sfm_ctx *ctx);
+int  sfm_ctx_timer_stop(sfm_ctx *ctx, float *elapsed_ms);   /* synchronises */
+/* Per-kernel stopwatch for the RANSAC launches: when enabled, HIP events are recorded on the
+ * context's stream around the solve and score kernels of every sfm_ransac_score / sfm_estimate_E
+ * call (up to 256 calls between reads).  sfm_ctx_kernel_timing_read synchronises, returns the summed
+ * kernel milliseconds and the number of calls, and resets the counters. */
+int  sfm_ctx_kernel_timing(sfm_ctx *ctx, int enable);
+int  sfm_ctx_kernel_timing_read(sfm_ctx *ctx, float *solve_ms, float *score_ms, int *calls);
+
+/* ---- descriptor match: MatchSiftData (matching.cu:1090-1206, kernel FindMaxCorr10 :301-397) ---
+ * For every record of d_sift1: best / second-best dot product over d_sift2 (128-d, fused d-ordered
+ * accumulation), lowest index on ties; writes score, match, match_xpos, match_ypos, ambiguity
+ * in place.  n1 == 0 or n2 == 0 is a no-op (matching.cu:1095-1096). */
+int sfm_match(sfm_ctx *ctx, sfm_sift_point *d_sift1, int n1, const sfm_sift_point *d_sift2, int n2);
+/* Same contraction on bare descriptor matrices (row stride ld floats, 16-byte aligned rows);
+ * mirrors the layout of the reference's stand-alone benchmark CudaSift/match.cu:916-1081. */
+int sfm_match_soa(sfm_ctx *ctx, const float *d_desc1, int n1, int ld1,
+                  const float *d_desc2, int n2, int ld2,
+                  float *d_best, float *d_second, int32_t *d_index);
+
+/* ---- Image_pair ------------------------------------------------------------------------------ */
+/* Image_pair::Image_pair(k, k_inv, image_count, num_points), sfm.cu:28-78.  h_K / h_Kinv: host. */
+int sfm_pair_create(sfm_ctx *ctx, const float h_K[9], const float h_Kinv[9],
+                    int image_count, int num_points, sfm_pair **out);
+int sfm_pair_destroy(sfm_pair *pair);                                      /* sfm.cu:346-359 */
+
+/* Image_pair::fillXU(SiftPoint *data), sfm.cu:80-92 (+ copy_point kernels.h:261-279). */
+int sfm_fill_xu(sfm_pair *pair, const sfm_sift_point *d_data);
+/* Bypass for callers that already hold normalised coordinates: 3 x num_points row-major each. */
+int sfm_set_points(sfm_pair *pair, const float *d_X0, const float *d_X1);
+
+#define SFM_KERNEL_AUTO   0
+#define SFM_KERNEL_SPLIT  1   /* solve: one hypothesis per lane; score: one hypothesis per wavefront */
+#define SFM_KERNEL_FUSED  2   /* everything one hypothesis per wavefront in LDS                      */
+
+typedef struct sfm_ransac_params {
+    uint32_t num_hypotheses;  /* H: global hypothesis count (reference: N/8, sfm.cu:95)                 */
+    uint32_t hyp_begin;       /* shard [hyp_begin, hyp_begin + hyp_count) scored by this call           */
+    uint32_t hyp_count;       /* 0 = all of [hyp_begin, H)                                              */
+    uint32_t seed;            /* keyed sampler seed (used when d_indices == NULL)                       */
+    const int32_t *d_indices; /* optional device int32[8*H]: explicit 8-tuples, global hypothesis order */
+    float    threshold;       /* inlier iff residual < threshold; reference 1e-6 (sfm.cu:220)           */
+    int32_t  jacobi_sweeps;   /* 9x9 Jacobi sweeps, default 7                                           */
+    int32_t  kernel;          /* SFM_KERNEL_*                                                           */
+    int32_t  reserved[4];
+} sfm_ransac_params;
+
+void sfm_ransac_default_params(sfm_ransac_params *p, int num_points);
+/* Reference-mode sampler (sfm.cu:97-106, Q2): H = n/8 disjoint 8-tuples of one seeded permutation.
+ * Writes int32[8*(n/8)] to d_indices (device). */
+int sfm_ransac_permutation_indices(sfm_ctx *ctx, int num_points, uint32_t seed, int32_t *d_indices);
+
+/* Image_pair::estimateE(), sfm.cu:94-153: score all hypotheses of the shard, arg-max (first
+ * maximum, thrust::max_element semantics without the off-by-one of sfm.cu:137), winner's E and
+ * inlier mask.  No host synchronisation. */
+int sfm_estimate_E(sfm_pair *pair, const sfm_ransac_params *p);
+/* The same in two steps for multi-GPU use: score the local shard (device key = (count << 32) |
+ * (0xFFFFFFFF - hyp), 0 if the shard is empty), exchange keys with one all-reduce(max), then
+ * finalize the winning hypothesis id on every rank. */
+int sfm_ransac_score(sfm_pair *pair, const sfm_ransac_params *p);
+int sfm_ransac_finalize(sfm_pair *pair, const sfm_ransac_params *p, uint32_t hyp);
+/* Device-resident variants: copy the local key into caller memory (e.g. the tensor handed to the
+ * RCCL all-reduce) and finalize from a reduced key without any host round trip. */
+int sfm_ransac_export_key(sfm_pair *pair, uint64_t *d_key_out);
+int sfm_ransac_finalize_key(sfm_pair *pair, const sfm_ransac_params *p, const uint64_t *d_key);
+
+/* Image_pair::computePosecandidates(), sfm.cu:238-252 + candidate_kernels kernels.h:357-385. */
+#define SFM_POSE_REFERENCE 0   /* as written in the reference (quirks Q7, Q8, Q9, Q11 of SURVEY.md) */
+#define SFM_POSE_CORRECT   1   /* textbook decomposition, majority-vote cheirality                  */
+int sfm_pose_candidates(sfm_pair *pair, int mode);
+/* Image_pair::choosePose(), sfm.cu:254-307. */
+int sfm_choose_pose(sfm_pair *pair, int mode);
+/* Image_pair::linear_triangulation(), sfm.cu:309-344. */
+int sfm_triangulate(sfm_pair *pair, int mode);
+
+/* ---- accessors (the reference keeps these private; needed for parity checks) ------------------ */
+#define SFM_BUF_X0      0   /* float 3 x ld   normalised coords image 1 (ld = sfm_pair_ld)   */
+#define SFM_BUF_X1      1
+#define SFM_BUF_U0      2   /* float 3 x ld   pixel coords                                    */
+#define SFM_BUF_U1      3
+#define SFM_BUF_E       4   /* float 9                                                        */
+#define SFM_BUF_P       5   /* float 4 x 16   candidates                                      */
+#define SFM_BUF_PINV    6   /* float 4 x 16   inverses                                        */
+#define SFM_BUF_POINTS  7   /* float 4 x num_points                                           */
+#define SFM_BUF_COUNTS  8   /* int32 hyp_count of the last score call                         */
+#define SFM_BUF_MASK    9   /* uint8 num_points                                               */
+#define SFM_BUF_KEY     10  /* uint64 packed best key of the last score call                  */
+#define SFM_BUF_ECAND   11  /* float 9 x hyp_count of the last score call                     */
+#define SFM_BUF_PIND    12  /* int32 chosen pose index                                        */
+int sfm_pair_device_ptr(sfm_pair *pair, int which, void **d_ptr, size_t *bytes);
+int sfm_pair_ld(const sfm_pair *pair);                 /* padded leading dimension of X/U rows */
+int sfm_pair_num_points(const sfm_pair *pair);
+int sfm_get_XU(sfm_pair *pair, int which, float *h_out /* 3 x num_points */);
+int sfm_get_E(sfm_pair *pair, float h_E[9]);
+int sfm_get_best(sfm_pair *pair, uint32_t *hyp, uint32_t *count);
+int sfm_get_key(sfm_pair *pair, uint64_t *key);
+int sfm_get_inlier_counts(sfm_pair *pair, int32_t *h_counts, size_t capacity);
+int sfm_get_inlier_mask(sfm_pair *pair, uint8_t *h_mask /* num_points */);
+int sfm_get_E_candidates(sfm_pair *pair, float *h_E, size_t capacity_hyps);
+int sfm_get_pose_candidates(sfm_pair *pair, float h_P[64]);
+int sfm_get_pose_inverses(sfm_pair *pair, float h_Pinv[64]);
+int sfm_get_pose_index(sfm_pair *pair, int *index);
+int sfm_get_points(sfm_pair *pair, float *h_points /* 4 x num_points */);
+/* Name and launch geometry of the RANSAC scoring kernel used by the last call (for profiling). */
+int sfm_ransac_last_launch(sfm_pair *pair, int *kernel, int *grid, int *block, int *lds_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SFM_AMD_H */

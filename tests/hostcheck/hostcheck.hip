@@ -1,0 +1,48 @@
+// tests/hostcheck/hostcheck.hip -- TEST HARNESS ONLY.
+// Compiles the product's __host__ __device__ arithmetic (cuda-sfm_amd/csrc/device_math.hpp) as HIP
+// *host* code so that CPU-only tests can compare it bit for bit with the oracle.  Nothing in the
+// product loads this library; it is not a CPU fallback.
+#include "../../cuda-sfm_amd/csrc/device_math.hpp"
+#include <string.h>
+
+extern "C" {
+
+void hc_sample8(uint32_t seed, uint32_t hyp, int n, int *idx) { sfm::sample8(seed, hyp, n, idx); }
+
+void hc_svd3(const float *a, float *u, float *s, float *v) { sfm::svd3(a, u, s, v); }
+
+void hc_normalize_E(float *E) { sfm::normalize_E(E); }
+
+void hc_hypothesis_E(const float *X0, const float *X1, int ld, const int *idx, int sweeps, float *E)
+{
+    float x1[8][3], x2[8][3];
+    for (int k = 0; k < 8; ++k)
+        for (int a = 0; a < 3; ++a) { x1[k][a] = X0[a * ld + idx[k]]; x2[k][a] = X1[a * ld + idx[k]]; }
+    sfm::nullvec9_normal_eq(x1, x2, sweeps, E);
+    sfm::normalize_E(E);
+}
+
+void hc_nullvec9(const float *X0, const float *X1, int ld, const int *idx, int sweeps, float *e)
+{
+    float x1[8][3], x2[8][3];
+    for (int k = 0; k < 8; ++k)
+        for (int a = 0; a < 3; ++a) { x1[k][a] = X0[a * ld + idx[k]]; x2[k][a] = X1[a * ld + idx[k]]; }
+    sfm::nullvec9_normal_eq(x1, x2, sweeps, e);
+}
+
+float hc_residual(const float *E, float x1x, float x1y, float x1z, float x2x, float x2y, float x2z)
+{
+    sfm::Ess e{ E[0], E[1], E[2], E[3], E[4], E[5], E[6], E[7], E[8] };
+    return sfm::residual(e, x1x, x1y, x1z, x2x, x2y, x2z);
+}
+
+void hc_pose_candidates(const float *E, int mode, float *P) { sfm::pose_candidates(E, mode, P); }
+void hc_nullvec4(const float *A, int sweeps, float *v) { sfm::nullvec4(A, sweeps, v); }
+int  hc_inv4(const float *m, float *o) { return sfm::inv4(m, o) ? 1 : 0; }
+void hc_triangulate_point(float x1, float y1, float x2, float y2, const float *Pm, int sweeps, float *out)
+{
+    sfm::triangulate_point(x1, y1, x2, y2, Pm, sweeps, out);
+}
+unsigned long long hc_pack_key(uint32_t c, uint32_t h) { return sfm::pack_key(c, h); }
+
+}

@@ -1,0 +1,144 @@
+"""GPU parity: the HIP RANSAC path (through the C ABI) against the CPU oracle.
+Integer outputs (counts, masks, winner) must be bit-exact; E is bit-exact too because both sides
+follow the same arithmetic contract (tolerance stated where it is not)."""
+import numpy as np
+import pytest
+
+import cuda_sfm_amd as S
+from cuda_sfm_amd import synth
+import oracle as O
+from helpers import same_bits, to_dev, make_pair
+
+pytestmark = pytest.mark.gpu
+
+
+def oracle_xu(scene):
+    return O.fill_xu(scene["sift"], scene["Kinv"])
+
+
+@pytest.mark.parametrize("n", [8, 100, 128, 1000, 2048])
+def test_fill_xu_bit_exact(gpu, n):
+    scene = synth.two_view_scene(n, seed=11 + n)
+    pair, _ = make_pair(S, gpu, scene)
+    U0, U1, X0, X1 = oracle_xu(scene)
+    for which, ref in ((S.BUF_U0, U0), (S.BUF_U1, U1), (S.BUF_X0, X0), (S.BUF_X1, X1)):
+        assert same_bits(pair.get_XU(which), ref)
+
+
+@pytest.mark.parametrize("n,H,kernel", [(64, 50, S.KERNEL_SPLIT), (1000, 300, S.KERNEL_SPLIT),
+                                        (2048, 1024, S.KERNEL_SPLIT), (4096, 2048, S.KERNEL_SPLIT),
+                                        (4500, 600, S.KERNEL_SPLIT)])
+def test_counts_winner_mask_E(gpu, n, H, kernel):
+    scene = synth.two_view_scene(n, seed=5 + n)
+    pair, _ = make_pair(S, gpu, scene)
+    p = S.default_params(n, num_hypotheses=H, seed=77, kernel=kernel)
+    pair.estimateE(p)
+    _, _, X0, X1 = oracle_xu(scene)
+    key, ocounts, oE = O.ransac_range(X0, X1, 0, H, p.threshold, p.jacobi_sweeps, seed=77, want_E=True)
+    assert same_bits(pair.get_E_candidates(H), oE), "per-hypothesis E differs"
+    assert np.array_equal(pair.get_inlier_counts(H), ocounts)
+    assert pair.get_key() == key
+    ocnt, ohyp = O.unpack_key(key)
+    assert pair.get_best() == (ohyp, ocnt)
+    assert same_bits(pair.get_E(), oE[ohyp].reshape(3, 3))
+    _, omask = O.count_inliers(oE[ohyp], X0, X1, p.threshold)
+    assert np.array_equal(pair.get_inlier_mask(), omask)
+    assert ocnt == omask.sum()
+
+
+def test_explicit_indices_and_reference_mode(gpu):
+    """Reference-mode sampler (sfm.cu:95-106): H = N/8 disjoint slices of one permutation."""
+    torch, dev, ctx = gpu
+    n = 2048
+    scene = synth.two_view_scene(n, seed=3)
+    pair, _ = make_pair(S, gpu, scene)
+    d_idx = torch.empty(8 * (n // 8), dtype=torch.int32, device=dev)
+    ctx.permutation_indices(n, 99, d_idx)
+    idx = d_idx.cpu().numpy()
+    assert sorted(idx.tolist()) == list(range(n)), "not a permutation"
+    p = S.default_params(n, d_indices=d_idx)
+    assert p.num_hypotheses == n // 8
+    pair.estimateE(p)
+    _, _, X0, X1 = oracle_xu(scene)
+    key, ocounts, _ = O.ransac_range(X0, X1, 0, n // 8, p.threshold, p.jacobi_sweeps, indices=idx)
+    assert np.array_equal(pair.get_inlier_counts(n // 8), ocounts)
+    assert pair.get_key() == key
+
+
+def test_sharded_score_matches_single(gpu):
+    """Hypothesis shards are independent of how they are cut."""
+    n, H = 1024, 777
+    scene = synth.two_view_scene(n, seed=21)
+    pair, _ = make_pair(S, gpu, scene)
+    p = S.default_params(n, num_hypotheses=H, seed=5)
+    pair.estimateE(p)
+    full = pair.get_inlier_counts(H).copy()
+    full_key = pair.get_key()
+    keys, parts = [], []
+    for r in range(3):
+        b, c = S.shard_range(H, r, 3)
+        q = S.default_params(n, num_hypotheses=H, seed=5, hyp_begin=b, hyp_count=c)
+        pair.ransac_score(q)
+        parts.append(pair.get_inlier_counts(c).copy())
+        keys.append(pair.get_key())
+    assert np.array_equal(np.concatenate(parts), full)
+    assert max(keys) == full_key
+    cnt, hyp = S.unpack_key(max(keys))
+    pair.ransac_finalize(p, hyp)
+    assert pair.get_best() == (hyp, cnt)
+
+
+def test_degenerate_inputs(gpu):
+    """All-identical correspondences (rank-deficient A) and NaN coordinates must not crash and must
+    agree with the oracle (NaN residuals never count)."""
+    n, H = 256, 64
+    scene = synth.two_view_scene(n, seed=8)
+    scene["sift"]["xpos"][:] = 100.0; scene["sift"]["ypos"][:] = 50.0
+    scene["sift"]["match_xpos"][:] = 100.0; scene["sift"]["match_ypos"][:] = 50.0
+    pair, _ = make_pair(S, gpu, scene)
+    p = S.default_params(n, num_hypotheses=H)
+    pair.estimateE(p)
+    _, _, X0, X1 = oracle_xu(scene)
+    key, ocounts, _ = O.ransac_range(X0, X1, 0, H, p.threshold, p.jacobi_sweeps, seed=p.seed)
+    assert np.array_equal(pair.get_inlier_counts(H), ocounts)
+    assert pair.get_key() == key
+
+
+def test_errors(gpu):
+    torch, dev, ctx = gpu
+    scene = synth.two_view_scene(16)
+    pair = S.ImagePair(ctx, scene["K"], scene["Kinv"], 2, 16)
+    with pytest.raises(S.SfmError) as e:
+        pair.estimateE()
+    assert e.value.code == S.E_STATE
+    with pytest.raises(S.SfmError):
+        S.ImagePair(ctx, scene["K"], scene["Kinv"], 3, 16)
+    small = S.ImagePair(ctx, scene["K"], scene["Kinv"], 2, 4)
+    small.fillXU(to_dev(torch, dev, scene["sift"][:4]))
+    with pytest.raises(S.SfmError) as e:
+        small.estimateE()
+    assert e.value.code == S.E_INVALID
+
+
+def test_full_size_properties(gpu):
+    """BASELINE sizes (N=16384, H=65536): oracle too slow for all hypotheses -> size-independent
+    properties: winner's count equals its mask sum, equals the oracle's count for that hypothesis,
+    and a random sample of hypotheses matches the oracle exactly."""
+    n, H = 16384, 65536
+    scene = synth.two_view_scene(n)
+    pair, _ = make_pair(S, gpu, scene)
+    p = S.default_params(n, num_hypotheses=H)
+    pair.estimateE(p)
+    counts = pair.get_inlier_counts(H)
+    hyp, cnt = pair.get_best()
+    assert cnt == counts.max() and hyp == int(np.argmax(counts))      # first maximum
+    assert pair.get_inlier_mask().sum() == cnt
+    _, _, X0, X1 = oracle_xu(scene)
+    rng = np.random.default_rng(0)
+    for h in [hyp] + rng.integers(0, H, 40).tolist():
+        E = O.hypothesis_E(X0, X1, O.sample8(p.seed, h, n), p.jacobi_sweeps)
+        c, _ = O.count_inliers(E, X0, X1, p.threshold, want_mask=False)
+        assert c == counts[h], f"hypothesis {h}: gpu {counts[h]} oracle {c}"
+    truth = ~scene["outlier"]
+    m = pair.get_inlier_mask().astype(bool)
+    assert (m & truth).sum() > 0.5 * truth.sum() and (m & ~truth).sum() < 0.05 * m.sum()
