@@ -427,6 +427,62 @@ SFM_HD float residual(const Ess &E, float x1x, float x1y, float x1z, float x2x, 
     return t1 + t2;
 }
 
+// Inlier predicate "residual(E, x1, x2) < thr" WITHOUT the two IEEE divisions in the common case.
+//   r = n2/da + n2/db = n2 (da + db) / (da db)
+// rf evaluates the right-hand form with one hardware reciprocal (v_rcp_f32, 1 ulp).  Every
+// operation is a single rounding of positive quantities, so |rf - r_exact| <= 8 * 2^-24 * r
+// whenever da*db is a normal number (the 'safe' guard); band.lo / band.hi sit 2^-17 (16 x that
+// bound) either side of thr.  Outside the band the sign of (r_exact - thr) is therefore known and
+// the exact residual is not needed; inside it (about one point in 10^5), or when the guard fails
+// (zero / denormal / huge divisors, NaN), the caller evaluates residual() itself.  The decision is
+// thus ALWAYS the one the oracle takes -- the filter only skips arithmetic, never changes a result.
+struct ThrBand { float thr, lo, hi; };
+
+SFM_HD ThrBand make_band(float thr)
+{
+    ThrBand b;
+    b.thr = thr;
+    if (thr > 1e-25f && thr < 1e25f) {
+        b.lo = (float)((double)thr * (1.0 - 1.0 / 131072.0));
+        b.hi = (float)((double)thr * (1.0 + 1.0 / 131072.0));
+    } else {                       // exotic thresholds: always take the exact path
+        b.lo = -1.0f;              // rf >= 0 is never below lo
+        b.hi = __builtin_huge_valf();
+    }
+    return b;
+}
+
+SFM_HD float fast_rcp(float x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rcpf(x);
+#else
+    return 1.0f / x;
+#endif
+}
+
+// Returns the "certain inlier" flag; `undecided` is set when the caller must fall back to residual().
+SFM_HD bool inlier_filter(const Ess &E, const ThrBand &band, float x1x, float x1y, float x1z,
+                          float x2x, float x2y, float x2z, bool &undecided)
+{
+    const float a0 = fmaf(E.e2, x2z, fmaf(E.e1, x2y, E.e0 * x2x));
+    const float a1 = fmaf(E.e5, x2z, fmaf(E.e4, x2y, E.e3 * x2x));
+    const float a2 = fmaf(E.e8, x2z, fmaf(E.e7, x2y, E.e6 * x2x));
+    const float b0 = fmaf(E.e6, x1z, fmaf(E.e3, x1y, E.e0 * x1x));
+    const float b1 = fmaf(E.e7, x1z, fmaf(E.e4, x1y, E.e1 * x1x));
+    const float nn = fmaf(x1z, a2, fmaf(x1y, a1, x1x * a0));
+    const float n2 = nn * nn;
+    const float da = fmaf(a1, a1, a0 * a0);
+    const float db = fmaf(b1, b1, b0 * b0);
+    const float p = da * db;
+    const float rf = (n2 * (da + db)) * fast_rcp(p);
+    const bool safe = (p > 1e-30f) && (p < 1e30f);
+    const bool sure_in = safe && (rf < band.lo);
+    const bool sure_out = safe && (rf > band.hi);
+    undecided = !(sure_in || sure_out);          // also true for NaN
+    return sure_in;
+}
+
 // ------------------------------------------------------------------------------------------
 // 4x4: DLT rows, one-sided Jacobi null vector, dehomogenisation, inverse
 // ------------------------------------------------------------------------------------------

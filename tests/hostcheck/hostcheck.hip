@@ -36,6 +36,14 @@ float hc_residual(const float *E, float x1x, float x1y, float x1z, float x2x, fl
     return sfm::residual(e, x1x, x1y, x1z, x2x, x2y, x2z);
 }
 
+int hc_inlier_filter(const float *E, float thr, float x1x, float x1y, float x1z, float x2x, float x2y, float x2z)
+{
+    sfm::Ess e{ E[0], E[1], E[2], E[3], E[4], E[5], E[6], E[7], E[8] };
+    bool und;
+    const bool in = sfm::inlier_filter(e, sfm::make_band(thr), x1x, x1y, x1z, x2x, x2y, x2z, und);
+    return und ? -1 : (in ? 1 : 0);
+}
+
 void hc_pose_candidates(const float *E, int mode, float *P) { sfm::pose_candidates(E, mode, P); }
 void hc_nullvec4(const float *A, int sweeps, float *v) { sfm::nullvec4(A, sweeps, v); }
 int  hc_inv4(const float *m, float *o) { return sfm::inv4(m, o) ? 1 : 0; }
