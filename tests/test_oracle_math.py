@@ -1,0 +1,136 @@
+"""CPU: mathematical invariants of the oracle where the reference delegates to closed-source
+cuSOLVER / cuBLAS (parity unpinned there): checked against numpy fp64 LAPACK."""
+import numpy as np
+import pytest
+
+import oracle as O
+from cuda_sfm_amd_synth import synth
+
+
+@pytest.fixture(scope="module")
+def scene():
+    sc = synth.two_view_scene(1024, seed=77)
+    _, _, X0, X1 = O.fill_xu(sc["sift"], sc["Kinv"])
+    return sc, X0, X1
+
+
+def test_fill_xu_matches_fp64(scene):
+    sc, X0, X1 = scene
+    Ki = sc["Kinv"].astype(np.float64)
+    s = sc["sift"]
+    U0 = np.stack([s["xpos"], s["ypos"], np.ones(len(s))]).astype(np.float64)
+    assert np.abs(Ki @ U0 - X0).max() < 1e-6
+    assert (X0[2] == 1).all() and (X1[2] == 1).all()
+
+
+def test_sampler_distinct_uniform():
+    n = 1000
+    seen = np.zeros(n, int)
+    for h in range(4000):
+        idx = O.sample8(3, h, n)
+        assert len(set(idx.tolist())) == 8 and idx.min() >= 0 and idx.max() < n
+        seen[idx] += 1
+    assert seen.min() > 8 and seen.max() < 70        # mean 32
+    assert not np.array_equal(O.sample8(3, 1, n), O.sample8(4, 1, n))
+    for h in range(50):                               # n == 8: a permutation of all points
+        assert sorted(O.sample8(1, h, 8).tolist()) == list(range(8))
+
+
+def test_nullvec9_and_normalizeE(scene):
+    _, X0, X1 = scene
+    angs = []
+    for h in range(300):
+        idx = O.sample8(9, h, X0.shape[1])
+        A = O.build_A(X0, X1, idx)
+        # kron rows: x1^T E x2 = 0 convention (kernels.h:247-257)
+        j = idx[3]
+        assert np.array_equal(A[3], np.kron(X0[:, j], X1[:, j]).astype(np.float32))
+        S = O.AtA9(A)
+        assert np.abs(S - A.astype(np.float64).T @ A.astype(np.float64)).max() < 1e-5 and np.array_equal(S, S.T)
+        e = O.nullvec9(A, 7).astype(np.float64)
+        assert abs(np.linalg.norm(e) - 1) < 1e-4
+        e64 = np.linalg.eigh(S.astype(np.float64))[1][:, 0]
+        angs.append(np.degrees(np.arccos(min(1.0, abs(e @ e64) / np.linalg.norm(e)))))
+        E = O.normalizeE(e.astype(np.float32))
+        sv = np.linalg.svd(E.astype(np.float64), compute_uv=False)
+        assert np.abs(sv - [1, 1, 0]).max() < 1e-4
+    # fp32 normal equations: agreement with fp64 eigh of the same matrix (hard parts)
+    assert np.median(angs) < 0.05 and np.percentile(angs, 90) < 2.0
+
+
+def test_jacobi9_diagonalises():
+    rng = np.random.default_rng(2)
+    for _ in range(50):
+        B = rng.standard_normal((9, 9)); S0 = (B @ B.T).astype(np.float32)
+        S, V = O.jacobi9(S0, 8)
+        off = S - np.diag(np.diag(S))
+        assert np.abs(off).max() < 1e-4 * np.abs(S0).max()
+        assert np.abs(V.T @ V - np.eye(9)).max() < 1e-5
+        assert np.abs(np.sort(np.diag(S)) - np.linalg.eigvalsh(S0.astype(np.float64))).max() < 1e-3 * np.abs(S0).max()
+
+
+def test_residual_formula(scene):
+    _, X0, X1 = scene
+    E = O.hypothesis_E(X0, X1, O.sample8(1, 0, X0.shape[1]), 7)
+    E64 = E.astype(np.float64)
+    for j in range(0, 1024, 37):
+        x1, x2 = X0[:, j].astype(np.float64), X1[:, j].astype(np.float64)
+        n = x1 @ E64 @ x2; a = E64 @ x2; b = E64.T @ x1
+        r = n * n / (a[0] ** 2 + a[1] ** 2) + n * n / (b[0] ** 2 + b[1] ** 2)
+        assert abs(O.residual(E, X0[:, j], X1[:, j]) - r) <= 1e-4 * r + 1e-12
+    # zero divisor zeroes its term (kernels.h:310-314); NaN never counts (kernels.h:350)
+    Z = np.zeros(9, np.float32)
+    assert O.residual(Z, (1, 2, 1), (3, 4, 1)) == 0.0
+    nanE = np.full(9, np.nan, np.float32)
+    assert O.count_inliers(nanE, X0, X1, 1e-6)[0] == 0
+
+
+def test_argmax_first_maximum():
+    """thrust::max_element semantics (sfm.cu:135-136, testThrust_max sfm.cu:455-466): first maximum."""
+    vals = [1, 2, 3, 4, 5, 6]
+    keys = [O.pack_key(v, i) for i, v in enumerate(vals)]
+    assert O.unpack_key(max(keys)) == (6, 5)
+    keys = [O.pack_key(v, i) for i, v in enumerate([3, 7, 7, 1])]
+    assert O.unpack_key(max(keys)) == (7, 1)
+
+
+def test_nullvec4_and_inv4():
+    rng = np.random.default_rng(4)
+    for _ in range(200):
+        A = rng.standard_normal((4, 4))
+        A[3] = 0.3 * A[0] - 0.7 * A[1] + 0.2 * A[2] + 1e-5 * rng.standard_normal(4)
+        v = O.nullvec4(A.astype(np.float32), 8).astype(np.float64)
+        vt = np.linalg.svd(A.astype(np.float32).astype(np.float64))[2][-1]
+        assert abs(abs(v @ vt) / np.linalg.norm(v) - 1) < 1e-6
+        M = rng.standard_normal((4, 4)).astype(np.float32)
+        ok, Mi = O.inv4(M)
+        assert ok and np.abs(Mi.astype(np.float64) @ M - np.eye(4)).max() < 1e-3
+    assert not O.inv4(np.zeros(16, np.float32))[0]
+    assert np.array_equal(O.normalize_pt(np.array([2, 4, 6, 2], np.float32)), [1, 2, 3, 1])
+    assert np.array_equal(O.normalize_pt(np.array([2, 4, 6, 0], np.float32)), [0, 0, 0, 1])
+    assert np.array_equal(O.normalize_pt(np.array([2, 4, 6, 6], np.float32)), [0, 0, 0, 1])   # |w| > 5 (kernels.h:439)
+
+
+def test_pose_correct_mode_recovers_scene():
+    sc = synth.two_view_scene(512, seed=5, noise_px=0.0, outlier_frac=0.0)
+    _, _, X0, X1 = O.fill_xu(sc["sift"], sc["Kinv"])
+    key, counts, Ec = O.ransac_range(X0, X1, 0, 64, 1e-6, 7, seed=1, want_E=True)
+    cnt, hyp = O.unpack_key(key)
+    assert cnt > 0.95 * 512
+    P = O.pose_candidates(Ec[hyp], O.POSE_CORRECT)
+    ind, _, _, _ = O.choose_pose(X0, X1, P, O.POSE_CORRECT, 8)
+    R, t = P[ind][:3, :3].astype(np.float64), P[ind][:3, 3].astype(np.float64)
+    assert np.abs(R - sc["R"]).max() < 2e-3 and np.abs(t / np.linalg.norm(t) - sc["t"]).max() < 2e-3
+    # REFERENCE mode keeps the reference's quirks: translation column is -/+ U[:,2] (Q11)
+    Pr = O.pose_candidates(Ec[hyp], O.POSE_REFERENCE)
+    u, _, _ = O.svd3(Ec[hyp])
+    assert np.allclose(np.abs(Pr[0][:3, 3]), np.abs(u[:, 2]))
+
+
+def test_synth_is_portable():
+    a = synth.splitmix64(1, 3)
+    assert [int(x) for x in a] == [10451216379200822465, 13757245211066428519, 17911839290282890590]
+    sc = synth.two_view_scene(64)
+    assert abs(float(sc["sift"]["xpos"][0]) - float(synth.two_view_scene(64)["sift"]["xpos"][0])) == 0
+    d1, d2, perm = synth.descriptors(32)
+    assert np.allclose(np.linalg.norm(d1, axis=1), 1, atol=1e-5) and d1.max() <= 0.2001 * 1.5 and (d1 >= 0).all()
