@@ -13,7 +13,9 @@ SRCS     := $(wildcard $(CSRC)/*.hip)
 OBJS     := $(patsubst $(CSRC)/%.hip,$(BUILD)/%.o,$(SRCS))
 HDRS     := $(wildcard $(CSRC)/*.hpp) include/sfm_amd.h
 
-all: $(LIB) oracle hostcheck
+DEMO     := $(PKG)/host/two_view_demo
+
+all: $(LIB) oracle hostcheck $(DEMO)
 
 $(BUILD)/%.o: $(CSRC)/%.hip $(HDRS)
 	@mkdir -p $(BUILD)
@@ -26,13 +28,17 @@ $(LIB): $(OBJS)
 oracle:
 	$(MAKE) -C oracle
 
+# plain C++ host program on the facade headers: no HIP headers, links only the C-ABI library
+$(DEMO): $(PKG)/host/two_view_demo.cpp $(PKG)/host/sfm.h $(PKG)/host/cudaSift.h include/sfm_amd.h $(LIB)
+	g++ -O2 -std=c++14 -Wall -o $@ $< -L$(PKG)/lib -lsfm_amd -Wl,-rpath,'$$ORIGIN/../lib' -Wl,-rpath,/opt/rocm/lib
+
 hostcheck: tests/hostcheck/libhostcheck.so
 
 tests/hostcheck/libhostcheck.so: tests/hostcheck/hostcheck.hip $(CSRC)/device_math.hpp
 	$(HIPCC) -x hip --cuda-host-only -O2 -ffp-contract=off -mfma -fPIC -shared -Wno-pass-failed -o $@ $<
 
 clean:
-	rm -rf $(BUILD) $(LIB) tests/hostcheck/libhostcheck.so
+	rm -rf $(BUILD) $(LIB) $(DEMO) tests/hostcheck/libhostcheck.so
 	$(MAKE) -C oracle clean
 
 .PHONY: all oracle hostcheck clean

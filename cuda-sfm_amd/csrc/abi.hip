@@ -150,6 +150,57 @@ int sfm_ctx_kernel_timing_read(sfm_ctx *ctx, float *solve_ms, float *score_ms, i
     return SFM_OK;
 }
 
+int sfm_device_alloc(sfm_ctx *ctx, size_t bytes, void **d_ptr)
+{
+    SFM_REQUIRE(ctx && d_ptr, SFM_E_INVALID, "null argument");
+    *d_ptr = nullptr;
+    if (bytes == 0) return SFM_OK;
+    SFM_HIP_TRY(hipSetDevice(ctx->device));
+    SFM_HIP_TRY(hipMalloc(d_ptr, bytes));
+    return SFM_OK;
+}
+
+int sfm_device_free(sfm_ctx *ctx, void *d_ptr)
+{
+    SFM_REQUIRE(ctx, SFM_E_INVALID, "null context");
+    if (!d_ptr) return SFM_OK;
+    SFM_HIP_TRY(hipSetDevice(ctx->device));
+    SFM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    SFM_HIP_TRY(hipFree(d_ptr));
+    return SFM_OK;
+}
+
+int sfm_copy_to_device(sfm_ctx *ctx, void *d_dst, const void *h_src, size_t bytes)
+{
+    SFM_REQUIRE(ctx && (bytes == 0 || (d_dst && h_src)), SFM_E_INVALID, "null argument");
+    if (bytes == 0) return SFM_OK;
+    SFM_HIP_TRY(hipSetDevice(ctx->device));
+    SFM_HIP_TRY(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    SFM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return SFM_OK;
+}
+
+int sfm_copy_to_host(sfm_ctx *ctx, void *h_dst, const void *d_src, size_t bytes)
+{
+    SFM_REQUIRE(ctx && (bytes == 0 || (h_dst && d_src)), SFM_E_INVALID, "null argument");
+    if (bytes == 0) return SFM_OK;
+    SFM_HIP_TRY(hipSetDevice(ctx->device));
+    SFM_HIP_TRY(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    SFM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return SFM_OK;
+}
+
+int sfm_copy_to_host_2d(sfm_ctx *ctx, void *h_dst, size_t dst_pitch, const void *d_src, size_t src_pitch,
+                        size_t width_bytes, size_t height)
+{
+    SFM_REQUIRE(ctx && h_dst && d_src, SFM_E_INVALID, "null argument");
+    if (width_bytes == 0 || height == 0) return SFM_OK;
+    SFM_HIP_TRY(hipSetDevice(ctx->device));
+    SFM_HIP_TRY(hipMemcpy2DAsync(h_dst, dst_pitch, d_src, src_pitch, width_bytes, height, hipMemcpyDeviceToHost, ctx->stream));
+    SFM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return SFM_OK;
+}
+
 // ---- match ------------------------------------------------------------------------------------
 int sfm_match(sfm_ctx *ctx, sfm_sift_point *d_sift1, int n1, const sfm_sift_point *d_sift2, int n2)
 {

@@ -67,6 +67,16 @@ int  sfm_ctx_timer_stop(sfm_ctx *ctx, float *elapsed_ms);   /* synchronises */
 int  sfm_ctx_kernel_timing(sfm_ctx *ctx, int enable);
 int  sfm_ctx_kernel_timing_read(sfm_ctx *ctx, float *solve_ms, float *score_ms, int *calls);
 
+/* Device memory helpers so that a host without HIP bindings (C, Go/cgo, JNI, ctypes ...) can own the
+ * buffers the reference allocates with cudaMalloc (InitSiftData, CudaSift/cudaSiftH.cu:234-264).
+ * Copies are synchronous with respect to the context's stream. */
+int  sfm_device_alloc(sfm_ctx *ctx, size_t bytes, void **d_ptr);
+int  sfm_device_free(sfm_ctx *ctx, void *d_ptr);
+int  sfm_copy_to_device(sfm_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);
+int  sfm_copy_to_host(sfm_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);
+int  sfm_copy_to_host_2d(sfm_ctx *ctx, void *h_dst, size_t dst_pitch, const void *d_src, size_t src_pitch,
+                         size_t width_bytes, size_t height);          /* cudaMemcpy2D of matching.cu:1195-1199 */
+
 /* ---- descriptor match: MatchSiftData (matching.cu:1090-1206, kernel FindMaxCorr10 :301-397) ---
  * For every record of d_sift1: best / second-best dot product over d_sift2 (128-d, fused d-ordered
  * accumulation), lowest index on ties; writes score, match, match_xpos, match_ypos, ambiguity

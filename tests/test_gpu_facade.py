@@ -1,0 +1,80 @@
+"""GPU: the C++ facade (SfM::Image_pair / MatchSiftData with the reference's names and call order,
+src/main.cpp:269-307) run as a stand-alone C++ program, compared with the oracle's chain
+match -> fillXU -> estimateE -> pose candidates -> choosePose -> triangulation."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle as O
+from cuda_sfm_amd_synth import synth
+from helpers import same_bits
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DEMO = os.path.join(ROOT, "cuda-sfm_amd", "host", "two_view_demo")
+
+
+def make_feature_sets(n, seed):
+    """Set 1 = scene points seen in image 1, set 2 = the same points in image 2, shuffled; descriptors
+    make the brute-force matcher recover the correspondence (plus a few distractors)."""
+    sc = synth.two_view_scene(n, seed=seed, outlier_frac=0.15)
+    d1, d2, perm = synth.descriptors(n, seed=seed + 1)        # d2[i] ~ d1[perm[i]]
+    s1 = synth.sift_records(d1, seed=seed + 2)
+    s1["xpos"], s1["ypos"] = sc["sift"]["xpos"], sc["sift"]["ypos"]
+    s2 = synth.sift_records(d2, seed=seed + 3)
+    s2["xpos"], s2["ypos"] = sc["sift"]["match_xpos"][perm], sc["sift"]["match_ypos"][perm]
+    extra = synth.sift_records(synth.descriptors(57, seed=seed + 4)[0], seed=seed + 5)
+    return s1, np.concatenate([s2, extra]), sc
+
+
+@pytest.mark.parametrize("n,H,mode", [(500, 200, 0), (2048, 1024, 0), (2048, 1024, 1)])
+def test_cpp_facade_end_to_end(tmp_path, n, H, mode):
+    assert os.path.exists(DEMO), "two_view_demo not built (make)"
+    s1, s2, sc = make_feature_sets(n, seed=70 + n)
+    f1, f2, out = (str(tmp_path / x) for x in ("s1.bin", "s2.bin", "out.bin"))
+    s1.tofile(f1); s2.tofile(f2)
+    r = subprocess.run([DEMO, f1, f2, out, str(H), "0x1234", str(mode)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "MatchSiftData time" in r.stdout                      # reference prints this (matching.cu:1203)
+
+    raw = open(out, "rb").read()
+    off = 0
+    def take(fmt, count):
+        nonlocal off
+        a = np.frombuffer(raw, dtype=fmt, count=count, offset=off); off += a.nbytes
+        return a
+    n_out, H_out = take("<i4", 2)
+    E, P, Pinv = take("<f4", 9), take("<f4", 64), take("<f4", 64)
+    pind = int(take("<i4", 1)[0]); hyp, cnt = (int(v) for v in take("<u4", 2))
+    pts = take("<f4", 4 * n).reshape(4, n); mask = take("u1", n)
+    rec = np.frombuffer(raw, dtype=[("score", "<f4"), ("ambiguity", "<f4"), ("match", "<i4"), ("mx", "<f4"), ("my", "<f4")], count=n, offset=off)
+    assert (n_out, H_out) == (n, H)
+
+    m = O.match_sift(s1, s2)
+    assert np.array_equal(rec["match"], m["match"]) and same_bits(rec["score"], m["score"])
+    assert same_bits(rec["ambiguity"], m["ambiguity"]) and same_bits(rec["mx"], m["match_xpos"]) and same_bits(rec["my"], m["match_ypos"])
+    assert (m["match"][: n] < n).mean() > 0.95                     # distractors rarely win
+
+    K, Kinv = synth.camera()
+    _, _, X0, X1 = O.fill_xu(m, Kinv)
+    key, counts, Ec = O.ransac_range(X0, X1, 0, H, 1e-6, 7, seed=0x1234, want_E=True)
+    ocnt, ohyp = O.unpack_key(key)
+    assert (hyp, cnt) == (ohyp, ocnt) and same_bits(E, Ec[ohyp])
+    assert np.array_equal(mask, O.count_inliers(Ec[ohyp], X0, X1, 1e-6)[1])
+    oP = O.pose_candidates(Ec[ohyp], mode)
+    oind, oPinv, _, _ = O.choose_pose(X0, X1, oP, mode, 8)
+    assert same_bits(P, oP.reshape(64)) and same_bits(Pinv, oPinv.reshape(64)) and pind == oind
+    assert same_bits(pts, O.triangulate(X0, X1, oPinv[oind] if mode == 0 else oP[oind], 8))
+
+
+def test_cpp_facade_error_is_print_and_exit(tmp_path):
+    """Reference convention: print and exit non-zero (common.cu:3-15).  Fewer than 8 features cannot
+    feed the 8-point solver."""
+    s1, s2, _ = make_feature_sets(64, seed=5)
+    f1, f2, out = (str(tmp_path / x) for x in ("s1.bin", "s2.bin", "out.bin"))
+    s1[:5].tofile(f1); s2.tofile(f2)
+    r = subprocess.run([DEMO, f1, f2, out, "10"], capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "8-point" in r.stderr
