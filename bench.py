@@ -135,7 +135,8 @@ def main():
                                    "(sample+solve+score+argmax+winner E+inlier mask)",
                        "matches": n, "hypotheses_per_step": H, "threshold": params.threshold,
                        "jacobi_sweeps": params.jacobi_sweeps, "kernel": pair.last_launch()},
-            "roofline": {"bound": "valu_fp32", "kernel": "ransac_score_waves", "achieved": achieved,
+            "roofline": {"bound": "mfma", "bound_detail": "FP32 VALU (v_pk_fma_f32); its 157.3 TFLOP/s peak equals the dense f32 MFMA peak",
+                         "kernel": "ransac_score_waves", "achieved": achieved,
                          "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_PEAK_TFLOPS,
                          "traffic": None,
                          "flop_per_launch": flops, "avg_launch_ms": 1e3 * score_s,

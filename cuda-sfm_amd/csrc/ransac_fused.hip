@@ -1,0 +1,261 @@
+// ransac_fused.hip -- the whole RANSAC pipeline ONE HYPOTHESIS PER WAVEFRONT, state in LDS
+// (SFM_KERNEL_FUSED): sample -> 8 points -> A^T A -> 9x9 round-robin Jacobi -> null vector ->
+// 3x3 SVD projection -> fused scoring of the LDS-resident point tile -> count.  This is the
+// arrangement BASELINE.json's north_star names; the split pipeline (ransac.hip) is the faster default
+// because the eigen-solve is a serial recurrence that keeps only 4..45 of the 64 lanes busy here,
+// and the A/B numbers are recorded in README.md / profiles/.
+//
+// Per-wave LDS scratch (256 floats): P[8][6] sampled points, S[9][9] (both triangles), V[9][9],
+// c[9], sg[9].  Each Jacobi round is three wave-synchronous phases:
+//   1. lanes 0..8   : rotation (c, sg) of the pair that owns index i          (S reads)
+//   2. lanes 0..44  : new S_ij, i <= j ; lanes 0..63 (+17): new V entries       (S, V, c, sg reads)
+//   3. same lanes   : write back
+// Every element is produced by exactly the expression the oracle uses (orc_jacobi9), so E, counts
+// and masks are bit-identical to the oracle and to the split pipeline.
+//
+// The same wave-cooperative solver finalizes the winning hypothesis (ransac_finalize_E_wave): one
+// hypothesis is latency-bound, and 63 short rounds on one wavefront beat one lane grinding through
+// the fully unrolled 44k-instruction solver.
+#include "ransac_device.hpp"
+
+namespace sfm {
+
+constexpr int kWaveScratch = 256;       // floats of LDS per wavefront
+
+__device__ __forceinline__ void wave_sync()
+{
+    // LDS operations of one wavefront execute in order; this only has to stop the compiler from
+    // moving LDS accesses across the phase boundary.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Wave-cooperative 8-point solve.  `ws` = this wave's 256-float scratch.  On return every lane
+// holds the same E[9].
+__device__ __forceinline__ void solve_wave(const float *__restrict__ X0, const float *__restrict__ X1, int ld, int n,
+                                           const int32_t *__restrict__ indices, uint32_t seed, uint32_t hyp,
+                                           int sweeps, float *ws, int lane, float E[9])
+{
+    float *P = ws;            // [8][6]  x1x x1y x1z x2x x2y x2z
+    float *S = ws + 48;       // [9][9]
+    float *V = ws + 129;      // [9][9]
+    float *cc = ws + 210;     // [9]
+    float *sg = ws + 219;     // [9]
+
+    int idx[8];
+    load_tuple(indices, seed, hyp, n, idx);               // wave-uniform
+    if (lane < 48) {
+        const int k = lane / 6, c = lane - 6 * k;
+        int p = idx[0];
+#pragma unroll
+        for (int q = 1; q < 8; ++q) p = (k == q) ? idx[q] : p;
+        P[lane] = (c < 3) ? X0[(size_t)c * ld + p] : X1[(size_t)(c - 3) * ld + p];
+    }
+    wave_sync();
+
+    // packed index -> (i, j), i <= j
+    int ei = 0, ej = 0;
+    if (lane < 45) {
+        int e = lane, i = 0;
+        while (e >= 9 - i) { e -= 9 - i; ++i; }
+        ei = i; ej = i + e;
+        // S_ij = sum_r A[r][i] A[r][j],  A[r][3a+b] = x1[r][a] * x2[r][b]   (kernels.h:247-257)
+        const int ia = ei / 3, ib = ei - 3 * ia, ja = ej / 3, jb = ej - 3 * ja;
+        float acc = (P[ia] * P[3 + ib]) * (P[ja] * P[3 + jb]);
+#pragma unroll
+        for (int r = 1; r < 8; ++r)
+            acc = fmaf(P[6 * r + ia] * P[6 * r + 3 + ib], P[6 * r + ja] * P[6 * r + 3 + jb], acc);
+        S[9 * ei + ej] = acc;
+        S[9 * ej + ei] = acc;
+    }
+    V[lane] = (lane % 10 == 0) ? 1.0f : 0.0f;
+    if (lane < 17) V[64 + lane] = ((64 + lane) % 10 == 0) ? 1.0f : 0.0f;
+    wave_sync();
+
+    const int va0 = lane / 9, vb0 = lane - 9 * va0;                   // V element handled by every lane
+    const int e1 = 64 + lane, va1 = e1 / 9, vb1 = e1 - 9 * va1;       // second V element (lanes 0..16)
+
+    for (int sw = 0; sw < sweeps; ++sw) {
+        for (int t = 0; t < 9; ++t) {
+            if (lane < 9) {
+                const int i = lane, j = (t + 9 - i) % 9;
+                float c = 1.0f, s = 0.0f;
+                if (j != i) {
+                    const int p = i < j ? i : j, q = i < j ? j : i;
+                    float ss;
+                    jacobi_cs(S[10 * p], S[10 * q], S[9 * p + q], c, ss);
+                    s = (i == p) ? -ss : ss;
+                }
+                cc[i] = c;
+                sg[i] = s;
+            }
+            wave_sync();
+            float nv = 0.0f, v0, v1 = 0.0f;
+            if (lane < 45) {
+                const int ri = (t + 9 - ei) % 9, rj = (t + 9 - ej) % 9;
+                const float cj = cc[ej], sj = sg[ej];
+                const float Tij  = fmaf(S[9 * ei + rj], sj, S[9 * ei + ej] * cj);
+                const float Trij = fmaf(S[9 * ri + rj], sj, S[9 * ri + ej] * cj);
+                nv = fmaf(sg[ei], Trij, cc[ei] * Tij);
+            }
+            {
+                const int rb = (t + 9 - vb0) % 9;
+                v0 = fmaf(V[9 * va0 + rb], sg[vb0], V[9 * va0 + vb0] * cc[vb0]);
+            }
+            if (lane < 17) {
+                const int rb = (t + 9 - vb1) % 9;
+                v1 = fmaf(V[9 * va1 + rb], sg[vb1], V[9 * va1 + vb1] * cc[vb1]);
+            }
+            wave_sync();
+            if (lane < 45) { S[9 * ei + ej] = nv; S[9 * ej + ei] = nv; }
+            V[lane] = v0;
+            if (lane < 17) V[64 + lane] = v1;
+            wave_sync();
+        }
+    }
+
+    int m = 0;
+    float best = S[0];
+#pragma unroll
+    for (int i = 1; i < 9; ++i) {
+        const float d = S[10 * i];
+        if (d < best) { best = d; m = i; }
+    }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) E[i] = V[9 * i + m];
+    normalize_E(E);                                                   // wave-uniform
+    wave_sync();                                                      // scratch may be reused by the caller
+}
+
+template <int WPB>
+__global__ __launch_bounds__(WPB * 64)
+void ransac_fused_waves(const float *__restrict__ X0, const float *__restrict__ X1, int ld, int n,
+                        const int32_t *__restrict__ indices, uint32_t seed, int sweeps,
+                        uint32_t h0, uint32_t count, float thr, int tile, int ntiles,
+                        int *__restrict__ counts, float *__restrict__ Ecand, unsigned long long *best_key)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float *ws = lds + 6 * (size_t)tile + (size_t)wave * kWaveScratch;
+    const uint32_t nbatch = (count + WPB - 1) / WPB;
+    unsigned long long wbest = 0;
+    bool staged = false;
+    const ThrBand band = make_band(thr);
+
+    for (uint32_t batch = blockIdx.x; batch < nbatch; batch += gridDim.x) {
+        const uint32_t i = __builtin_amdgcn_readfirstlane(batch * WPB + wave);
+        const bool valid = i < count;
+        float e[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+        if (valid) {
+            solve_wave(X0, X1, ld, n, indices, seed, h0 + i, sweeps, ws, lane, e);
+            if (lane < 9) {
+                float v = e[0];
+#pragma unroll
+                for (int k = 1; k < 9; ++k) v = (lane == k) ? e[k] : v;
+                Ecand[9 * (size_t)i + lane] = v;
+            }
+        }
+        const Ess E{ e[0], e[1], e[2], e[3], e[4], e[5], e[6], e[7], e[8] };
+        int cnt = 0;
+        for (int t = 0; t < ntiles; ++t) {
+            if (ntiles > 1 || !staged) {
+                if (staged) __syncthreads();
+                const int first = t * tile;
+                stage_tile(lds, X0, X1, ld, first, min(tile, ld - first));
+                __syncthreads();
+                staged = true;
+            }
+            if (valid) cnt += score_tile(E, lds, min(tile, ld - t * tile), band, lane);
+        }
+        if (valid) {
+            if (lane == 0) counts[i] = cnt;
+            const unsigned long long key = pack_key((uint32_t)cnt, h0 + i);
+            wbest = key > wbest ? key : wbest;
+        }
+    }
+    __syncthreads();
+    unsigned long long *sbest = reinterpret_cast<unsigned long long *>(lds);      // tile no longer needed
+    if (lane == 0) sbest[wave] = wbest;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long b = sbest[0];
+#pragma unroll
+        for (int w = 1; w < WPB; ++w) b = sbest[w] > b ? sbest[w] : b;
+        if (b) atomicMax(best_key, b);
+    }
+}
+
+// Winner's E from its hypothesis id, one wavefront (see header comment).
+__global__ __launch_bounds__(64)
+void ransac_finalize_E_wave(const float *__restrict__ X0, const float *__restrict__ X1, int ld, int n,
+                            const int32_t *__restrict__ indices, uint32_t seed, int sweeps,
+                            const unsigned long long *__restrict__ key, uint32_t hyp_host, int from_key,
+                            float *__restrict__ E_out, uint32_t *__restrict__ best_out)
+{
+    __shared__ __attribute__((aligned(16))) float ws[kWaveScratch];
+    uint32_t hyp = hyp_host;
+    if (from_key) hyp = 0xFFFFFFFFu - (uint32_t)(key[0] & 0xFFFFFFFFull);
+    hyp = __builtin_amdgcn_readfirstlane(hyp);
+    float E[9];
+    solve_wave(X0, X1, ld, n, indices, seed, hyp, sweeps, ws, threadIdx.x, E);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) E_out[k] = E[k];
+        best_out[0] = hyp;
+        best_out[1] = 0;        // filled by ransac_finalize_mask
+    }
+}
+
+template <int WPB>
+static int launch_fused_t(sfm_pair *pair, const sfm_ransac_params &p, uint32_t h0, uint32_t count, int tile, int ntiles, int grid, size_t lds)
+{
+    static bool attr_set = false;
+    if (!attr_set) {
+        SFM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&ransac_fused_waves<WPB>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(ransac_fused_waves<WPB>, dim3(grid), dim3(WPB * 64), lds, pair->ctx->stream,
+                       pair->d_X[0], pair->d_X[1], pair->ld, pair->n, p.d_indices, p.seed, p.jacobi_sweeps,
+                       h0, count, p.threshold, tile, ntiles, pair->d_counts, pair->d_Ecand, pair->d_key);
+    SFM_HIP_TRY(hipGetLastError());
+    pair->last_grid = grid; pair->last_block = WPB * 64; pair->last_lds = (int)lds;
+    return SFM_OK;
+}
+
+int launch_ransac_fused(sfm_pair *pair, const sfm_ransac_params &p, uint32_t h0, uint32_t count)
+{
+    sfm_ctx *ctx = pair->ctx;
+    const int tile = pair->ld < kTileMax ? pair->ld : kTileMax;
+    const int ntiles = (pair->ld + tile - 1) / tile;
+    int wpb = 16;
+    while (wpb > 4 && (count + wpb - 1) / wpb < (uint32_t)ctx->num_cus) wpb >>= 1;
+    const uint32_t nbatch = (count + wpb - 1) / wpb;
+    const int grid = (int)(nbatch < (uint32_t)ctx->num_cus ? nbatch : (uint32_t)ctx->num_cus);
+    const size_t lds = ((size_t)6 * tile + (size_t)wpb * kWaveScratch) * sizeof(float);
+    const bool timed = ctx->timing && ctx->tcount < sfm_ctx::kTimingSlots;
+    hipEvent_t *tev = timed ? ctx->tev[ctx->tcount] : nullptr;
+    if (timed) { SFM_HIP_TRY(hipEventRecord(tev[0], ctx->stream)); SFM_HIP_TRY(hipEventRecord(tev[1], ctx->stream)); }
+    int rc;
+    switch (wpb) {
+    case 16: rc = launch_fused_t<16>(pair, p, h0, count, tile, ntiles, grid, lds); break;
+    case 8:  rc = launch_fused_t<8>(pair, p, h0, count, tile, ntiles, grid, lds); break;
+    default: rc = launch_fused_t<4>(pair, p, h0, count, tile, ntiles, grid, lds); break;
+    }
+    if (rc == SFM_OK && timed) { SFM_HIP_TRY(hipEventRecord(tev[2], ctx->stream)); ctx->tcount++; }
+    return rc;
+}
+
+int launch_finalize_E_wave(sfm_pair *pair, const sfm_ransac_params &p, const unsigned long long *d_key,
+                           uint32_t hyp_host, bool from_key)
+{
+    hipLaunchKernelGGL(ransac_finalize_E_wave, dim3(1), dim3(64), 0, pair->ctx->stream,
+                       pair->d_X[0], pair->d_X[1], pair->ld, pair->n, p.d_indices, p.seed, p.jacobi_sweeps,
+                       d_key, hyp_host, from_key ? 1 : 0, pair->d_E, pair->d_best);
+    SFM_HIP_TRY(hipGetLastError());
+    return SFM_OK;
+}
+
+} // namespace sfm

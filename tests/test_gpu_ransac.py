@@ -25,9 +25,8 @@ def test_fill_xu_bit_exact(gpu, n):
         assert same_bits(pair.get_XU(which), ref)
 
 
-@pytest.mark.parametrize("n,H,kernel", [(64, 50, S.KERNEL_SPLIT), (1000, 300, S.KERNEL_SPLIT),
-                                        (2048, 1024, S.KERNEL_SPLIT), (4096, 2048, S.KERNEL_SPLIT),
-                                        (4500, 600, S.KERNEL_SPLIT)])
+@pytest.mark.parametrize("kernel", [S.KERNEL_SPLIT, S.KERNEL_FUSED])
+@pytest.mark.parametrize("n,H", [(64, 50), (1000, 300), (2048, 1024), (4096, 2048), (4500, 600), (9000, 100)])
 def test_counts_winner_mask_E(gpu, n, H, kernel):
     scene = synth.two_view_scene(n, seed=5 + n)
     pair, _ = make_pair(S, gpu, scene)
