@@ -428,37 +428,36 @@ SFM_HD float residual(const Ess &E, float x1x, float x1y, float x1z, float x2x, 
 }
 
 // Inlier predicate "residual(E, x1, x2) < thr" WITHOUT the two IEEE divisions in the common case.
-//   r = n2/da + n2/db = n2 (da + db) / (da db)
-// rf evaluates the right-hand form with one hardware reciprocal (v_rcp_f32, 1 ulp).  Every
-// operation is a single rounding of positive quantities, so |rf - r_exact| <= 8 * 2^-24 * r
-// whenever da*db is a normal number (the 'safe' guard); band.lo / band.hi sit 2^-17 (16 x that
-// bound) either side of thr.  Outside the band the sign of (r_exact - thr) is therefore known and
-// the exact residual is not needed; inside it (about one point in 10^5), or when the guard fails
-// (zero / denormal / huge divisors, NaN), the caller evaluates residual() itself.  The decision is
-// thus ALWAYS the one the oracle takes -- the filter only skips arithmetic, never changes a result.
-struct ThrBand { float thr, lo, hi; };
+//   r = n2/da + n2/db = n2 (da + db) / (da db),   so   r < thr  <=>  m < tp,
+//   m = n2 (da + db),  tp = thr (da db)           (da db > 0).
+// m and tp are products / sums of positive floats with one rounding each (5 roundings in all; n2,
+// da, db are the very floats the exact formula uses), so the comparison m < tp is decided correctly
+// whenever m and tp are more than 8 ulp apart and tp is a normal number well inside the exponent
+// range.  The filter therefore answers "undecided" when the two bit patterns are closer than
+// kBandUlps = 64 (positive floats order like their bit patterns) or when tp's bits leave
+// [bits(1e-30), bits(1e30)] (zero / denormal / huge / NaN divisors); exotic thresholds disable it.
+// Undecided points (about one in 10^5) are re-evaluated with residual().  The decision is thus
+// ALWAYS the one the oracle takes -- the filter only skips arithmetic, never changes a result.
+constexpr uint32_t kBandUlps = 64u;
+constexpr uint32_t kTpBitsLo = 0x0DA24260u;     // 1e-30f
+constexpr uint32_t kTpBitsHi = 0x7149F2CAu;     // 1e30f
+
+struct ThrBand { float thr; uint32_t lo_bits, hi_bits; };
 
 SFM_HD ThrBand make_band(float thr)
 {
     ThrBand b;
     b.thr = thr;
-    if (thr > 1e-25f && thr < 1e25f) {
-        b.lo = (float)((double)thr * (1.0 - 1.0 / 131072.0));
-        b.hi = (float)((double)thr * (1.0 + 1.0 / 131072.0));
-    } else {                       // exotic thresholds: always take the exact path
-        b.lo = -1.0f;              // rf >= 0 is never below lo
-        b.hi = __builtin_huge_valf();
-    }
+    if (thr >= 1e-12f && thr <= 1e3f) { b.lo_bits = kTpBitsLo; b.hi_bits = kTpBitsHi; }
+    else { b.lo_bits = 0xFFFFFFFFu; b.hi_bits = 0u; }        // never safe -> always the exact path
     return b;
 }
 
-SFM_HD float fast_rcp(float x)
+SFM_HD uint32_t f32_bits(float x)
 {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __builtin_amdgcn_rcpf(x);
-#else
-    return 1.0f / x;
-#endif
+    union { float f; uint32_t u; } c;
+    c.f = x;
+    return c.u;
 }
 
 // Returns the "certain inlier" flag; `undecided` is set when the caller must fall back to residual().
@@ -474,13 +473,12 @@ SFM_HD bool inlier_filter(const Ess &E, const ThrBand &band, float x1x, float x1
     const float n2 = nn * nn;
     const float da = fmaf(a1, a1, a0 * a0);
     const float db = fmaf(b1, b1, b0 * b0);
-    const float p = da * db;
-    const float rf = (n2 * (da + db)) * fast_rcp(p);
-    const bool safe = (p > 1e-30f) && (p < 1e30f);
-    const bool sure_in = safe && (rf < band.lo);
-    const bool sure_out = safe && (rf > band.hi);
-    undecided = !(sure_in || sure_out);          // also true for NaN
-    return sure_in;
+    const float m = n2 * (da + db);
+    const float tp = (da * db) * band.thr;
+    const uint32_t mb = f32_bits(m), tb = f32_bits(tp);
+    const uint32_t gap = mb > tb ? mb - tb : tb - mb;
+    undecided = (gap < kBandUlps) || (tb < band.lo_bits) || (tb > band.hi_bits);
+    return m < tp;
 }
 
 // ------------------------------------------------------------------------------------------

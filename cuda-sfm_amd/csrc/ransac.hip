@@ -42,8 +42,8 @@ void ransac_solve_lanes(const float *__restrict__ X0, const float *__restrict__ 
 // SPLIT step 2: one hypothesis per wavefront, points in LDS
 // ------------------------------------------------------------------------------------------
 template <int WPB>
-__global__ __launch_bounds__(WPB * 64)
-void ransac_score_waves(const float *__restrict__ X0, const float *__restrict__ X1, int ld,
+__global__ __launch_bounds__(WPB * 64, 8)
+void ransac_score_waves(const float *__restrict__ X0, const float *__restrict__ X1, int ld, int n,
                         const float *__restrict__ Ecand, uint32_t h0, uint32_t count, float thr,
                         int tile, int ntiles, int *__restrict__ counts, unsigned long long *best_key)
 {
@@ -61,7 +61,8 @@ void ransac_score_waves(const float *__restrict__ X0, const float *__restrict__ 
         Ess E{};
         if (valid) {
             const float *e = Ecand + 9 * (size_t)i;
-            E = Ess{ e[0], e[1], e[2], e[3], e[4], e[5], e[6], e[7], e[8] };
+            auto sreg = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); };
+            E = Ess{ sreg(e[0]), sreg(e[1]), sreg(e[2]), sreg(e[3]), sreg(e[4]), sreg(e[5]), sreg(e[6]), sreg(e[7]), sreg(e[8]) };
         }
         int cnt = 0;
         for (int t = 0; t < ntiles; ++t) {
@@ -72,7 +73,7 @@ void ransac_score_waves(const float *__restrict__ X0, const float *__restrict__ 
                 __syncthreads();
                 staged = true;
             }
-            if (valid) cnt += score_tile(E, lds, min(tile, ld - t * tile), band, lane);
+            if (valid) cnt += score_tile(E, lds, min(tile, ld - t * tile), min(tile, n - t * tile), band, lane);
         }
         if (valid) {
             if (lane == 0) counts[i] = cnt;
@@ -141,7 +142,7 @@ static int launch_score_t(sfm_pair *pair, uint32_t h0, uint32_t count, float thr
         attr_set = true;
     }
     hipLaunchKernelGGL(ransac_score_waves<WPB>, dim3(grid), dim3(WPB * 64), lds, pair->ctx->stream,
-                       pair->d_X[0], pair->d_X[1], pair->ld, pair->d_Ecand, h0, count, thr, tile, ntiles,
+                       pair->d_X[0], pair->d_X[1], pair->ld, pair->n, pair->d_Ecand, h0, count, thr, tile, ntiles,
                        pair->d_counts, pair->d_key);
     SFM_HIP_TRY(hipGetLastError());
     pair->last_grid = grid; pair->last_block = WPB * 64; pair->last_lds = (int)lds;
@@ -177,8 +178,13 @@ int launch_ransac_score(sfm_pair *pair, const sfm_ransac_params &p, uint32_t h0,
     int wpb = 16;
     while (wpb > 4 && (count + wpb - 1) / wpb < (uint32_t)ctx->num_cus) wpb >>= 1;
     const uint32_t nbatch = (count + wpb - 1) / wpb;
-    const int grid = (int)(nbatch < (uint32_t)ctx->num_cus ? nbatch : (uint32_t)ctx->num_cus);
     const size_t lds = (size_t)6 * tile * sizeof(float) + 16 * sizeof(unsigned long long);
+    // persistent blocks: as many as are co-resident (LDS and the 2048-thread CU limit)
+    int per_cu = (int)((160 * 1024) / lds);
+    if (per_cu > 2048 / (wpb * 64)) per_cu = 2048 / (wpb * 64);
+    if (per_cu < 1) per_cu = 1;
+    const uint32_t resident = (uint32_t)ctx->num_cus * (uint32_t)per_cu;
+    const int grid = (int)(nbatch < resident ? nbatch : resident);
     switch (wpb) {
     case 16: rc = launch_score_t<16>(pair, h0, count, p.threshold, tile, ntiles, grid, lds); break;
     case 8:  rc = launch_score_t<8>(pair, h0, count, p.threshold, tile, ntiles, grid, lds); break;

@@ -73,9 +73,13 @@ __device__ __forceinline__ v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elem
 __device__ __forceinline__ v2f splat(float s) { return v2f{ s, s }; }
 
 // Two points per lane through the division-free filter (device_math.hpp inlier_filter, same
-// arithmetic element for element); the three ballots go straight to the scalar unit.
-__device__ __forceinline__ void filter_pair(const Ess &E, const ThrBand &band, const float4 q0, const float4 q1, const float4 q2,
-                                            unsigned long long &in_a, unsigned long long &in_b, unsigned long long &und)
+// arithmetic element for element).  Only the two "m < tp" compares go to the scalar unit; the
+// undecided test is carried per lane as running integer min / max (VALU only) and inspected once
+// per tile: gap_min = smallest |bits(m) - bits(tp)| seen, tb_min / tb_max = range of bits(tp).
+struct FilterAcc { uint32_t gap_min, tb_min, tb_max; };
+
+__device__ __forceinline__ void filter_pair(const Ess &E, float thr, const float4 q0, const float4 q1, const float4 q2,
+                                            unsigned long long &in_a, unsigned long long &in_b, FilterAcc &acc)
 {
     const v2f x1x{ q0.x, q0.y }, x1y{ q0.z, q0.w }, x1z{ q1.x, q1.y };
     const v2f x2x{ q1.z, q1.w }, x2y{ q2.x, q2.y }, x2z{ q2.z, q2.w };
@@ -88,45 +92,69 @@ __device__ __forceinline__ void filter_pair(const Ess &E, const ThrBand &band, c
     const v2f n2 = nn * nn;
     const v2f da = fma2(a1, a1, a0 * a0);
     const v2f db = fma2(b1, b1, b0 * b0);
-    const v2f p = da * db;
-    const v2f inv{ __builtin_amdgcn_rcpf(p.x), __builtin_amdgcn_rcpf(p.y) };
-    const v2f rf = (n2 * (da + db)) * inv;
-    const unsigned long long safe_a = __ballot(p.x > 1e-30f) & __ballot(p.x < 1e30f);
-    const unsigned long long safe_b = __ballot(p.y > 1e-30f) & __ballot(p.y < 1e30f);
-    in_a = safe_a & __ballot(rf.x < band.lo);
-    in_b = safe_b & __ballot(rf.y < band.lo);
-    const unsigned long long out_a = safe_a & __ballot(rf.x > band.hi);
-    const unsigned long long out_b = safe_b & __ballot(rf.y > band.hi);
-    und = ~((in_a | out_a) & (in_b | out_b));           // a lane with either point undecided (NaN included)
+    const v2f m = n2 * (da + db);
+    const v2f tp = (da * db) * splat(thr);
+    in_a = __ballot(m.x < tp.x);
+    in_b = __ballot(m.y < tp.y);
+    const uint32_t mxb = __float_as_uint(m.x), myb = __float_as_uint(m.y);
+    const uint32_t txb = __float_as_uint(tp.x), tyb = __float_as_uint(tp.y);
+    uint32_t gapx, gapy;                                   // |bits(m) - bits(tp)| in one instruction each
+    asm("v_sad_u32 %0, %1, %2, 0" : "=v"(gapx) : "v"(mxb), "v"(txb));
+    asm("v_sad_u32 %0, %1, %2, 0" : "=v"(gapy) : "v"(myb), "v"(tyb));
+    acc.gap_min = min(acc.gap_min, min(gapx, gapy));
+    acc.tb_min = min(acc.tb_min, min(txb, tyb));
+    acc.tb_max = max(acc.tb_max, max(txb, tyb));
 }
 
-__device__ __forceinline__ int score_tile(const Ess &E, const float *lds, int len, const ThrBand &band, int lane)
+// `len` = staged points of this tile (multiple of 128, NaN beyond the real data), `nvalid` = real
+// points in it.  Full 128-point iterations run unmasked; a ragged last iteration masks the padding
+// lanes out of the count and out of the undecided trackers (padding must not force the exact path).
+__device__ __forceinline__ int score_tile(const Ess &E, const float *lds, int len, int nvalid, const ThrBand &band, int lane)
 {
     const float4 *rec0 = reinterpret_cast<const float4 *>(lds) + 3 * lane;
-    const int iters = len >> 7;                 // 128 points per wave iteration
+    const int full = nvalid >> 7;               // iterations with all 128 points real
     int cnt = 0;
-    unsigned long long und_any = 0;
+    FilterAcc acc{ 0xFFFFFFFFu, 0xFFFFFFFFu, 0u };
     const float4 *rec = rec0;
-#pragma unroll 2
-    for (int it = 0; it < iters; ++it, rec += 3 * 64) {
+    for (int it = 0; it < full; ++it, rec += 3 * 64) {
         const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
-        unsigned long long in_a, in_b, und;
-        filter_pair(E, band, q0, q1, q2, in_a, in_b, und);
+        unsigned long long in_a, in_b;
+        filter_pair(E, band.thr, q0, q1, q2, in_a, in_b, acc);
         cnt += __builtin_popcountll(in_a) + __builtin_popcountll(in_b);
-        und_any |= und;
     }
-    if (__builtin_expect(und_any != 0ull, 0)) {
-        // Some point of this tile was undecided (about 1 in 1e5; always for NaN padding or a
-        // degenerate E): recount the tile with the exact IEEE residual.  Wave-uniform, rare.
+    const int rest = nvalid - (full << 7);      // 0..127 real points in the ragged iteration
+    unsigned long long va = 0, vb = 0;
+    if (rest > 0) {
+        va = __ballot(2 * lane < rest);
+        vb = __ballot(2 * lane + 1 < rest);
+        const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
+        unsigned long long in_a, in_b;
+        FilterAcc t{ 0xFFFFFFFFu, 0xFFFFFFFFu, 0u };
+        filter_pair(E, band.thr, q0, q1, q2, in_a, in_b, t);
+        // trackers of padding lanes are discarded; a lane holding one real and one padding point
+        // keeps them (NaN padding then reads as "undecided", which is merely conservative)
+        if (2 * lane < rest) {
+            acc.gap_min = min(acc.gap_min, t.gap_min);
+            acc.tb_min = min(acc.tb_min, t.tb_min);
+            acc.tb_max = max(acc.tb_max, t.tb_max);
+        }
+        cnt += __builtin_popcountll(in_a & va) + __builtin_popcountll(in_b & vb);
+    }
+    const bool und = (acc.gap_min < kBandUlps) || (acc.tb_min < band.lo_bits) || (acc.tb_max > band.hi_bits);
+    if (__builtin_expect(__any(und), 0)) {
+        // Some point of this tile was undecided (about 1 in 1e5; always for a degenerate E):
+        // recount the tile with the exact IEEE residual.  Wave-uniform, rare.
         cnt = 0;
         rec = rec0;
+        const int iters = (nvalid + 127) >> 7;
         for (int it = 0; it < iters; ++it, rec += 3 * 64) {
             const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
-            const bool ea = residual(E, q0.x, q0.z, q1.x, q1.z, q2.x, q2.z) < band.thr;
+            const bool ea = residual(E, q0.x, q0.z, q1.x, q1.z, q2.x, q2.z) < band.thr;   // NaN padding never counts
             const bool eb = residual(E, q0.y, q0.w, q1.y, q1.w, q2.y, q2.w) < band.thr;
             cnt += __builtin_popcountll(__ballot(ea)) + __builtin_popcountll(__ballot(eb));
         }
     }
+    (void)len;
     return cnt;
 }
 

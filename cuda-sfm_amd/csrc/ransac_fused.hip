@@ -167,7 +167,7 @@ void ransac_fused_waves(const float *__restrict__ X0, const float *__restrict__ 
                 __syncthreads();
                 staged = true;
             }
-            if (valid) cnt += score_tile(E, lds, min(tile, ld - t * tile), band, lane);
+            if (valid) cnt += score_tile(E, lds, min(tile, ld - t * tile), min(tile, n - t * tile), band, lane);
         }
         if (valid) {
             if (lane == 0) counts[i] = cnt;
