@@ -71,15 +71,73 @@ SFM_HD void sample8(uint32_t seed, uint32_t hyp, int n, int idx[8])
 }
 
 // ------------------------------------------------------------------------------------------
+// Lane-type abstraction.  The solver below is written once for T = float (one hypothesis per
+// caller) and T = v2f (TWO hypotheses per caller, element 0 / element 1).  With v2f every mul, add
+// and fma of the eigen-solver becomes one v_pk_*_f32 instruction on gfx950, i.e. half the VALU
+// issue slots per hypothesis; each element goes through exactly the IEEE operations the scalar
+// instantiation performs, so results are bit-identical per hypothesis.
+// ------------------------------------------------------------------------------------------
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef int v2i __attribute__((ext_vector_type(2)));
+
+template <class T> struct lane_traits;
+template <> struct lane_traits<float> { typedef bool mask; typedef int index; };
+template <> struct lane_traits<v2f> { typedef v2i mask; typedef v2i index; };
+
+template <class T> SFM_HD T splat_t(float s);
+template <> SFM_HD float splat_t<float>(float s) { return s; }
+template <> SFM_HD v2f splat_t<v2f>(float s) { return v2f{ s, s }; }
+
+SFM_HD float fma_t(float a, float b, float c) { return fmaf(a, b, c); }
+SFM_HD v2f fma_t(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+SFM_HD float sqrt_t(float x) { return sqrtf(x); }
+SFM_HD v2f sqrt_t(v2f x) { return v2f{ sqrtf(x.x), sqrtf(x.y) }; }
+SFM_HD float abs_t(float x) { return fabsf(x); }
+SFM_HD v2f abs_t(v2f x) { return v2f{ fabsf(x.x), fabsf(x.y) }; }
+SFM_HD float max_t(float a, float b) { return fmaxf(a, b); }
+SFM_HD v2f max_t(v2f a, v2f b) { return v2f{ fmaxf(a.x, b.x), fmaxf(a.y, b.y) }; }
+
+SFM_HD bool lt_t(float a, float b) { return a < b; }
+SFM_HD v2i lt_t(v2f a, v2f b) { return a < b; }
+SFM_HD bool gt_t(float a, float b) { return a > b; }
+SFM_HD v2i gt_t(v2f a, v2f b) { return a > b; }
+SFM_HD bool ge_t(float a, float b) { return a >= b; }
+SFM_HD v2i ge_t(v2f a, v2f b) { return a >= b; }
+SFM_HD bool ne_t(float a, float b) { return a != b; }
+SFM_HD v2i ne_t(v2f a, v2f b) { return a != b; }
+SFM_HD bool eq_t(float a, float b) { return a == b; }
+SFM_HD v2i eq_t(v2f a, v2f b) { return a == b; }
+SFM_HD float sel_t(bool m, float a, float b) { return m ? a : b; }
+SFM_HD v2f sel_t(v2i m, v2f a, v2f b) { return m ? a : b; }
+SFM_HD int seli_t(bool m, int a, int b) { return m ? a : b; }
+SFM_HD v2i seli_t(v2i m, v2i a, v2i b) { return m ? a : b; }
+SFM_HD bool ieq_t(int a, int b) { return a == b; }
+SFM_HD v2i ieq_t(v2i a, int b) { return a == v2i{ b, b }; }
+SFM_HD int isplat(int, int v) { return v; }
+SFM_HD v2i isplat(v2i, int v) { return v2i{ v, v }; }
+
+// "1.0 / sqrtf(x)": the header's double literal promotes the division (svd.h:129, :250).
+SFM_HD float rsqrt_f64div(float x) { return (float)(1.0 / (double)sqrtf(x)); }
+SFM_HD v2f rsqrt_f64div(v2f x) { return v2f{ rsqrt_f64div(x.x), rsqrt_f64div(x.y) }; }
+// accurateSqrt: x * 1.0 / sqrtf(x) evaluated in double, NaN at 0 (svd.h:33-36)
+SFM_HD float accurate_sqrt(float x) { return (float)(((double)x * 1.0) / (double)sqrtf(x)); }
+SFM_HD v2f accurate_sqrt(v2f x) { return v2f{ accurate_sqrt(x.x), accurate_sqrt(x.y) }; }
+// "_gamma*sh*sh < ch*ch": left side in double, right side a float product widened (svd.h:128)
+SFM_HD bool gamma_test(float sh, float ch2) { return ((5.828427124746190 * (double)sh) * (double)sh) < (double)ch2; }
+SFM_HD v2i gamma_test(v2f sh, v2f ch2) { return v2i{ gamma_test(sh.x, ch2.x) ? -1 : 0, gamma_test(sh.y, ch2.y) ? -1 : 0 }; }
+
+// ------------------------------------------------------------------------------------------
 // 3x3 algebra (svd.h).  Row-major r*3+c.  Unfused, left-to-right sums as the header parses.
 // ------------------------------------------------------------------------------------------
-SFM_HD float dot3u(float a0, float b0, float a1, float b1, float a2, float b2)
+template <class T>
+SFM_HD T dot3u(T a0, T b0, T a1, T b1, T a2, T b2)
 {
-    const float t = a0 * b0, u = a1 * b1, w = a2 * b2;
+    const T t = a0 * b0, u = a1 * b1, w = a2 * b2;
     return (t + u) + w;
 }
 
-SFM_HD void mul_AB(const float *a, const float *b, float *m)   // svd.h:58-65
+template <class T>
+SFM_HD void mul_AB(const T *a, const T *b, T *m)   // svd.h:58-65
 {
 #pragma unroll
     for (int r = 0; r < 3; ++r)
@@ -87,7 +145,8 @@ SFM_HD void mul_AB(const float *a, const float *b, float *m)   // svd.h:58-65
         for (int c = 0; c < 3; ++c)
             m[3 * r + c] = dot3u(a[3 * r], b[c], a[3 * r + 1], b[3 + c], a[3 * r + 2], b[6 + c]);
 }
-SFM_HD void mul_AtB(const float *a, const float *b, float *m)  // svd.h:67-74
+template <class T>
+SFM_HD void mul_AtB(const T *a, const T *b, T *m)  // svd.h:67-74
 {
 #pragma unroll
     for (int r = 0; r < 3; ++r)
@@ -95,7 +154,8 @@ SFM_HD void mul_AtB(const float *a, const float *b, float *m)  // svd.h:67-74
         for (int c = 0; c < 3; ++c)
             m[3 * r + c] = dot3u(a[r], b[c], a[3 + r], b[3 + c], a[6 + r], b[6 + c]);
 }
-SFM_HD void mul_ABt(const float *a, const float *b, float *m)  // svd.h:76-83
+template <class T>
+SFM_HD void mul_ABt(const T *a, const T *b, T *m)  // svd.h:76-83
 {
 #pragma unroll
     for (int r = 0; r < 3; ++r)
@@ -117,44 +177,43 @@ SFM_HD float det3_exact(const float *a)
     return ((((t0 - t1) - t2) + t3) + t4) - t5;
 }
 
-// "1.0 / sqrtf(x)": the header's double literal promotes the division (svd.h:129, :250).
-SFM_HD float rsqrt_f64div(float x) { return (float)(1.0 / (double)sqrtf(x)); }
-
+template <class T>
 struct Svd3 {
+    typedef typename lane_traits<T>::mask M;
     // symmetric 3x3 kept as the six live entries the header touches (indices 0,3,4,6,7,8)
-    float s0, s3, s4, s6, s7, s8;
-    float q[4];
+    T s0, s3, s4, s6, s7, s8;
+    T q[4];
 
     SFM_HD void conj(const int x, const int y, const int z)      // svd.h:135-186
     {
         // approximateGivensQuaternion, svd.h:120-133
-        float ch = 2.0f * (s0 - s4);
-        float sh = s3;
-        const bool keep = ((5.828427124746190 * (double)sh) * (double)sh) < (double)(ch * ch);
-        const float w = rsqrt_f64div(ch * ch + sh * sh);
-        ch = keep ? w * ch : (float)0.923879532511287;
-        sh = keep ? w * sh : (float)0.382683432365090;
+        T ch = splat_t<T>(2.0f) * (s0 - s4);
+        T sh = s3;
+        const M keep = gamma_test(sh, ch * ch);
+        const T w = rsqrt_f64div(ch * ch + sh * sh);
+        ch = sel_t(keep, w * ch, splat_t<T>((float)0.923879532511287));
+        sh = sel_t(keep, w * sh, splat_t<T>((float)0.382683432365090));
 
-        const float scale = ch * ch + sh * sh;
-        const float a = (ch * ch - sh * sh) / scale;
-        const float b = ((2.0f * sh) * ch) / scale;
-        const float nb = -b;
+        const T scale = ch * ch + sh * sh;
+        const T a = (ch * ch - sh * sh) / scale;
+        const T b = ((splat_t<T>(2.0f) * sh) * ch) / scale;
+        const T nb = -b;
 
-        const float n0 = a * (a * s0 + b * s3) + b * (a * s3 + b * s4);
-        const float n3 = a * (nb * s0 + a * s3) + b * (nb * s3 + a * s4);
-        const float n4 = nb * (nb * s0 + a * s3) + a * (nb * s3 + a * s4);
-        const float n6 = a * s6 + b * s7;
-        const float n7 = nb * s6 + a * s7;
-        const float n8 = s8;
+        const T n0 = a * (a * s0 + b * s3) + b * (a * s3 + b * s4);
+        const T n3 = a * (nb * s0 + a * s3) + b * (nb * s3 + a * s4);
+        const T n4 = nb * (nb * s0 + a * s3) + a * (nb * s3 + a * s4);
+        const T n6 = a * s6 + b * s7;
+        const T n7 = nb * s6 + a * s7;
+        const T n8 = s8;
 
-        const float t0 = q[0] * sh, t1 = q[1] * sh, t2 = q[2] * sh;
-        const float tmp[3] = { t0, t1, t2 };
-        sh *= q[3];
-        q[0] *= ch; q[1] *= ch; q[2] *= ch; q[3] *= ch;
-        q[z] += sh;
-        q[3] -= tmp[z];
-        q[x] += tmp[y];
-        q[y] -= tmp[x];
+        const T t0 = q[0] * sh, t1 = q[1] * sh, t2 = q[2] * sh;
+        const T tmp[3] = { t0, t1, t2 };
+        sh = sh * q[3];
+        q[0] = q[0] * ch; q[1] = q[1] * ch; q[2] = q[2] * ch; q[3] = q[3] * ch;
+        q[z] = q[z] + sh;
+        q[3] = q[3] - tmp[z];
+        q[x] = q[x] + tmp[y];
+        q[y] = q[y] - tmp[x];
 
         s0 = n4;
         s3 = n7; s4 = n8;
@@ -162,68 +221,74 @@ struct Svd3 {
     }
 };
 
-SFM_HD void cswapf(bool c, float &x, float &y) { const float z = x; x = c ? y : x; y = c ? z : y; }
-SFM_HD void cnegswapf(bool c, float &x, float &y) { const float z = -x; x = c ? y : x; y = c ? z : y; }
+template <class T, class M>
+SFM_HD void cswap_t(M c, T &x, T &y) { const T z = x; x = sel_t(c, y, x); y = sel_t(c, z, y); }
+template <class T, class M>
+SFM_HD void cnegswap_t(M c, T &x, T &y) { const T z = -x; x = sel_t(c, y, x); y = sel_t(c, z, y); }
 
-SFM_HD void qr_givens(float a1, float a2, float &ch, float &sh)   // svd.h:238-253
+template <class T>
+SFM_HD void qr_givens(T a1, T a2, T &ch, T &sh)   // svd.h:238-253
 {
-    const float eps = (float)1e-6;
-    const float x = a1 * a1 + a2 * a2;
-    const float rho = (float)(((double)x * 1.0) / (double)sqrtf(x));   // accurateSqrt, svd.h:33-36
-    sh = rho > eps ? a2 : 0.0f;
-    ch = fabsf(a1) + fmaxf(rho, eps);
-    cswapf(a1 < 0.0f, sh, ch);
-    const float w = rsqrt_f64div(ch * ch + sh * sh);
-    ch *= w;
-    sh *= w;
+    const T eps = splat_t<T>((float)1e-6);
+    const T x = a1 * a1 + a2 * a2;
+    const T rho = accurate_sqrt(x);
+    sh = sel_t(gt_t(rho, eps), a2, splat_t<T>(0.0f));
+    ch = abs_t(a1) + max_t(rho, eps);
+    cswap_t(lt_t(a1, splat_t<T>(0.0f)), sh, ch);
+    const T w = rsqrt_f64div(ch * ch + sh * sh);
+    ch = ch * w;
+    sh = sh * w;
 }
 
 // svd.h:311-335.  u, s (upper-triangular factor), v are full 3x3 row-major outputs.
-SFM_HD void svd3(const float *a, float *u, float *s, float *v)
+template <class T>
+SFM_HD void svd3(const T *a, T *u, T *s, T *v)
 {
-    float ata[9];
+    typedef typename lane_traits<T>::mask M;
+    const T one = splat_t<T>(1.0f), two = splat_t<T>(2.0f);
+    T ata[9];
     mul_AtB(a, a, ata);
-    Svd3 J;
+    Svd3<T> J;
     J.s0 = ata[0]; J.s3 = ata[3]; J.s4 = ata[4]; J.s6 = ata[6]; J.s7 = ata[7]; J.s8 = ata[8];
-    J.q[0] = 0.0f; J.q[1] = 0.0f; J.q[2] = 0.0f; J.q[3] = 1.0f;
+    J.q[0] = splat_t<T>(0.0f); J.q[1] = splat_t<T>(0.0f); J.q[2] = splat_t<T>(0.0f); J.q[3] = one;
     for (int it = 0; it < 4; ++it) {               // svd.h:201-210
         J.conj(0, 1, 2);
         J.conj(1, 2, 0);
         J.conj(2, 0, 1);
     }
     {   // quatToMat3, svd.h:97-118
-        const float w = J.q[3], x = J.q[0], y = J.q[1], z = J.q[2];
-        const float xx = x * x, yy = y * y, zz = z * z;
-        const float xz = x * z, xy = x * y, yz = y * z;
-        const float wx = w * x, wy = w * y, wz = w * z;
-        v[0] = 1.0f - 2.0f * (yy + zz); v[1] = 2.0f * (xy - wz);        v[2] = 2.0f * (xz + wy);
-        v[3] = 2.0f * (xy + wz);        v[4] = 1.0f - 2.0f * (xx + zz); v[5] = 2.0f * (yz - wx);
-        v[6] = 2.0f * (xz - wy);        v[7] = 2.0f * (yz + wx);        v[8] = 1.0f - 2.0f * (xx + yy);
+        const T w = J.q[3], x = J.q[0], y = J.q[1], z = J.q[2];
+        const T xx = x * x, yy = y * y, zz = z * z;
+        const T xz = x * z, xy = x * y, yz = y * z;
+        const T wx = w * x, wy = w * y, wz = w * z;
+        v[0] = one - two * (yy + zz); v[1] = two * (xy - wz);        v[2] = two * (xz + wy);
+        v[3] = two * (xy + wz);       v[4] = one - two * (xx + zz);  v[5] = two * (yz - wx);
+        v[6] = two * (xz - wy);       v[7] = two * (yz + wx);        v[8] = one - two * (xx + yy);
     }
-    float b[9];
+    T b[9];
     mul_AB(a, v, b);
     {   // sortSingularValues, svd.h:214-236
-        float r1 = (b[0] * b[0] + b[3] * b[3]) + b[6] * b[6];
-        float r2 = (b[1] * b[1] + b[4] * b[4]) + b[7] * b[7];
-        float r3 = (b[2] * b[2] + b[5] * b[5]) + b[8] * b[8];
-        bool c = r1 < r2;
+        T r1 = (b[0] * b[0] + b[3] * b[3]) + b[6] * b[6];
+        T r2 = (b[1] * b[1] + b[4] * b[4]) + b[7] * b[7];
+        T r3 = (b[2] * b[2] + b[5] * b[5]) + b[8] * b[8];
+        M c = lt_t(r1, r2);
 #pragma unroll
-        for (int r = 0; r < 3; ++r) { cnegswapf(c, b[3 * r], b[3 * r + 1]); cnegswapf(c, v[3 * r], v[3 * r + 1]); }
-        cswapf(c, r1, r2);
-        c = r1 < r3;
+        for (int r = 0; r < 3; ++r) { cnegswap_t(c, b[3 * r], b[3 * r + 1]); cnegswap_t(c, v[3 * r], v[3 * r + 1]); }
+        cswap_t(c, r1, r2);
+        c = lt_t(r1, r3);
 #pragma unroll
-        for (int r = 0; r < 3; ++r) { cnegswapf(c, b[3 * r], b[3 * r + 2]); cnegswapf(c, v[3 * r], v[3 * r + 2]); }
-        cswapf(c, r1, r3);
-        c = r2 < r3;
+        for (int r = 0; r < 3; ++r) { cnegswap_t(c, b[3 * r], b[3 * r + 2]); cnegswap_t(c, v[3 * r], v[3 * r + 2]); }
+        cswap_t(c, r1, r3);
+        c = lt_t(r2, r3);
 #pragma unroll
-        for (int r = 0; r < 3; ++r) { cnegswapf(c, b[3 * r + 1], b[3 * r + 2]); cnegswapf(c, v[3 * r + 1], v[3 * r + 2]); }
+        for (int r = 0; r < 3; ++r) { cnegswap_t(c, b[3 * r + 1], b[3 * r + 2]); cnegswap_t(c, v[3 * r + 1], v[3 * r + 2]); }
     }
     {   // QRDecomposition, svd.h:255-309
-        float ch1, sh1, ch2, sh2, ch3, sh3;
+        T ch1, sh1, ch2, sh2, ch3, sh3;
         qr_givens(b[0], b[3], ch1, sh1);
-        float a_ = 1.0f - (2.0f * sh1) * sh1;
-        float g = (2.0f * ch1) * sh1;
-        float r[9], X[9];
+        T a_ = one - (two * sh1) * sh1;
+        T g = (two * ch1) * sh1;
+        T r[9], X[9];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             r[c]     = a_ * b[c] + g * b[3 + c];
@@ -231,8 +296,8 @@ SFM_HD void svd3(const float *a, float *u, float *s, float *v)
             r[6 + c] = b[6 + c];
         }
         qr_givens(r[0], r[6], ch2, sh2);
-        a_ = 1.0f - (2.0f * sh2) * sh2;
-        g = (2.0f * ch2) * sh2;
+        a_ = one - (two * sh2) * sh2;
+        g = (two * ch2) * sh2;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             X[c]     = a_ * r[c] + g * r[6 + c];
@@ -240,50 +305,86 @@ SFM_HD void svd3(const float *a, float *u, float *s, float *v)
             X[6 + c] = (-g) * r[c] + a_ * r[6 + c];
         }
         qr_givens(X[4], X[7], ch3, sh3);
-        a_ = 1.0f - (2.0f * sh3) * sh3;
-        g = (2.0f * ch3) * sh3;
+        a_ = one - (two * sh3) * sh3;
+        g = (two * ch3) * sh3;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             s[c]     = X[c];
             s[3 + c] = a_ * X[3 + c] + g * X[6 + c];
             s[6 + c] = (-g) * X[3 + c] + a_ * X[6 + c];
         }
-        const float s11 = sh1 * sh1, s22 = sh2 * sh2, s33 = sh3 * sh3;
-        const float m1 = -1.0f + 2.0f * s11, m2 = -1.0f + 2.0f * s22, m3 = -1.0f + 2.0f * s33;
-        const float p2 = 1.0f - 2.0f * s22;
+        const T s11 = sh1 * sh1, s22 = sh2 * sh2, s33 = sh3 * sh3;
+        const T mone = splat_t<T>(-1.0f), four = splat_t<T>(4.0f);
+        const T m1 = mone + two * s11, m2 = mone + two * s22, m3 = mone + two * s33;
+        const T p2 = one - two * s22;
         u[0] = m1 * m2;
-        u[1] = ((((4.0f * ch2) * ch3) * m1) * sh2) * sh3 + ((2.0f * ch1) * sh1) * m3;
-        u[2] = (((4.0f * ch1) * ch3) * sh1) * sh3 - ((((2.0f * ch2) * m1) * sh2) * m3);
-        u[3] = ((2.0f * ch1) * sh1) * p2;
-        u[4] = ((((((-8.0f) * ch1) * ch2) * ch3) * sh1) * sh2) * sh3 + m1 * m3;
-        u[5] = ((-2.0f) * ch3) * sh3 + (4.0f * sh1) * ((ch3 * sh1) * sh3 + ((ch1 * ch2) * sh2) * m3);
-        u[6] = (2.0f * ch2) * sh2;
-        u[7] = ((2.0f * ch3) * p2) * sh3;
+        u[1] = ((((four * ch2) * ch3) * m1) * sh2) * sh3 + ((two * ch1) * sh1) * m3;
+        u[2] = (((four * ch1) * ch3) * sh1) * sh3 - ((((two * ch2) * m1) * sh2) * m3);
+        u[3] = ((two * ch1) * sh1) * p2;
+        u[4] = (((((splat_t<T>(-8.0f) * ch1) * ch2) * ch3) * sh1) * sh2) * sh3 + m1 * m3;
+        u[5] = (splat_t<T>(-2.0f) * ch3) * sh3 + (four * sh1) * ((ch3 * sh1) * sh3 + ((ch1 * ch2) * sh2) * m3);
+        u[6] = (two * ch2) * sh2;
+        u[7] = ((two * ch3) * p2) * sh3;
         u[8] = m2 * m3;
     }
 }
 
-SFM_HD void normalize_E(float *E)    // kernels.h:281-295: U diag(1,1,0) V^T, only the diagonal of d overwritten
+template <class T>
+SFM_HD void normalize_E(T *E)    // kernels.h:281-295: U diag(1,1,0) V^T, only the diagonal of d overwritten
 {
-    float u[9], d[9], v[9], t[9];
+    T u[9], d[9], v[9], t[9];
     svd3(E, u, d, v);
-    d[8] = 0.0f; d[4] = 1.0f; d[0] = 1.0f;
+    d[8] = splat_t<T>(0.0f); d[4] = splat_t<T>(1.0f); d[0] = splat_t<T>(1.0f);
     mul_AB(u, d, t);
     mul_ABt(t, v, E);
 }
 
 // ------------------------------------------------------------------------------------------
-// Jacobi rotation (classical formulas, IEEE '/' and sqrtf)
+// Jacobi rotation, division-free.  soft_rsqrt is a bit-trick seed plus three Newton steps made of
+// IEEE mul / fma only, so it is reproducible bit for bit on the CPU oracle AND maps onto
+// v_pk_mul_f32 / v_pk_fma_f32 when two hypotheses share a lane (hardware v_rsq / v_rcp are neither).
 // ------------------------------------------------------------------------------------------
-SFM_HD void jacobi_cs(float app, float aqq, float apq, float &c, float &s)
+SFM_HD float rsqrt_seed(float x)
 {
-    if (apq == 0.0f) { c = 1.0f; s = 0.0f; return; }
-    const float theta = (aqq - app) / (2.0f * apq);
-    const float h = sqrtf(fmaf(theta, theta, 1.0f));
-    const float t = (theta >= 0.0f ? 1.0f : -1.0f) / (fabsf(theta) + h);
-    const float cc = 1.0f / sqrtf(fmaf(t, t, 1.0f));
-    c = cc;
-    s = t * cc;
+    union { float f; uint32_t u; } c;
+    c.f = x;
+    c.u = 0x5F375A86u - (c.u >> 1);
+    return c.f;
+}
+SFM_HD v2f rsqrt_seed(v2f x) { return v2f{ rsqrt_seed(x.x), rsqrt_seed(x.y) }; }
+
+template <class T>
+SFM_HD T soft_rsqrt(T x)
+{
+    T y = rsqrt_seed(x);
+    const T nhx = splat_t<T>(-0.5f) * x;            // -(0.5 x): exact, same bits as negating 0.5 x
+    const T k = splat_t<T>(1.5f);
+    y = y * fma_t(nhx, y * y, k);
+    y = y * fma_t(nhx, y * y, k);
+    y = y * fma_t(nhx, y * y, k);
+    return y;
+}
+
+//   alpha = a_qq - a_pp, beta = 2 a_pq, r = hypot(alpha, beta), d = |alpha| + r,
+//   c = sqrt(d / 2r),  s = sign(alpha) beta / (2 r c);   J = [c s; -s c] annihilates a_pq.
+template <class T>
+SFM_HD void jacobi_cs(T app, T aqq, T apq, T &c, T &s)
+{
+    const T one = splat_t<T>(1.0f), zero = splat_t<T>(0.0f);
+    const T alpha = aqq - app;
+    const T beta = apq + apq;
+    const T r2 = fma_t(alpha, alpha, beta * beta);
+    const T ir = soft_rsqrt(r2);
+    const T r = r2 * ir;
+    const T d = abs_t(alpha) + r;
+    const T hir = splat_t<T>(0.5f) * ir;
+    const T c2 = d * hir;
+    const T ic = soft_rsqrt(c2);
+    const T cc = c2 * ic;
+    const T s0 = (beta * hir) * ic;
+    const auto rotate = ge_t(r2, splat_t<T>(1e-30f)) & ne_t(apq, zero);     // false also for NaN
+    c = sel_t(rotate, cc, one);
+    s = sel_t(rotate, sel_t(ge_t(alpha, zero), s0, -s0), zero);
 }
 
 // packed upper-triangular index of a symmetric 9x9
@@ -292,19 +393,19 @@ SFM_HD constexpr int sym9(int i, int j)
     return i <= j ? (i * 9 - (i * (i - 1)) / 2 + (j - i)) : (j * 9 - (j * (j - 1)) / 2 + (i - j));
 }
 
-// One round (index T of 9) of the parallel-ordered Jacobi sweep on the 9x9 normal matrix: the four
-// disjoint pairs {i, (T - i) mod 9} are rotated together, S <- J^T S J, V <- V J.  T is a template
+// One round (index R of 9) of the parallel-ordered Jacobi sweep on the 9x9 normal matrix: the four
+// disjoint pairs {i, (R - i) mod 9} are rotated together, S <- J^T S J, V <- V J.  R is a template
 // parameter so that every index below is a compile-time constant and S / V stay in registers.
-template <int T>
-SFM_HD void jacobi9_round(float (&S)[45], float (&V)[81])
+template <int R, class T>
+SFM_HD void jacobi9_round(T (&S)[45], T (&V)[81])
 {
-    float c[9], sg[9];
+    T c[9], sg[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i) {
-        const int j = (T + 9 - i) % 9;
-        if (j == i) { c[i] = 1.0f; sg[i] = 0.0f; }
+        const int j = (R + 9 - i) % 9;
+        if (j == i) { c[i] = splat_t<T>(1.0f); sg[i] = splat_t<T>(0.0f); }
         else if (i < j) {
-            float cc, ss;
+            T cc, ss;
             jacobi_cs(S[sym9(i, i)], S[sym9(j, j)], S[sym9(i, j)], cc, ss);
             c[i] = cc; c[j] = cc;
             sg[i] = -ss; sg[j] = ss;
@@ -313,23 +414,23 @@ SFM_HD void jacobi9_round(float (&S)[45], float (&V)[81])
     // S <- J^T S J, one 2x2 block (pair a x pair b) at a time, in place
 #pragma unroll
     for (int a = 0; a < 9; ++a) {
-        const int ra = (T + 9 - a) % 9;
+        const int ra = (R + 9 - a) % 9;
         if (ra >= a) {
 #pragma unroll
             for (int b = a; b < 9; ++b) {
-                const int rb = (T + 9 - b) % 9;
+                const int rb = (R + 9 - b) % 9;
                 if (rb >= b) {
-                    float nv[2][2];
+                    T nv[2][2];
 #pragma unroll
                     for (int ka = 0; ka < 2; ++ka)
 #pragma unroll
                         for (int kb = 0; kb < 2; ++kb) {
                             const int k = ka ? ra : a, l = kb ? rb : b;
                             const int i = k < l ? k : l, j = k < l ? l : k;       // oracle orientation i <= j
-                            const int ri = (T + 9 - i) % 9, rj = (T + 9 - j) % 9;
-                            const float Tij  = fmaf(S[sym9(i, rj)],  sg[j], S[sym9(i, j)]  * c[j]);
-                            const float Trij = fmaf(S[sym9(ri, rj)], sg[j], S[sym9(ri, j)] * c[j]);
-                            nv[ka][kb] = fmaf(sg[i], Trij, c[i] * Tij);
+                            const int ri = (R + 9 - i) % 9, rj = (R + 9 - j) % 9;
+                            const T Tij  = fma_t(S[sym9(i, rj)],  sg[j], S[sym9(i, j)]  * c[j]);
+                            const T Trij = fma_t(S[sym9(ri, rj)], sg[j], S[sym9(ri, j)] * c[j]);
+                            nv[ka][kb] = fma_t(sg[i], Trij, c[i] * Tij);
                         }
                     S[sym9(a, b)]   = nv[0][0];
                     S[sym9(a, rb)]  = nv[0][1];
@@ -344,26 +445,28 @@ SFM_HD void jacobi9_round(float (&S)[45], float (&V)[81])
     for (int i = 0; i < 9; ++i)
 #pragma unroll
         for (int b = 0; b < 9; ++b) {
-            const int rb = (T + 9 - b) % 9;
+            const int rb = (R + 9 - b) % 9;
             if (rb >= b) {
-                const float vb = V[9 * i + b], vr = V[9 * i + rb];
-                V[9 * i + b]  = fmaf(vr, sg[b], vb * c[b]);
-                V[9 * i + rb] = fmaf(vb, sg[rb], vr * c[rb]);
+                const T vb = V[9 * i + b], vr = V[9 * i + rb];
+                V[9 * i + b]  = fma_t(vr, sg[b], vb * c[b]);
+                V[9 * i + rb] = fma_t(vb, sg[rb], vr * c[rb]);
             }
         }
 }
 
 // Null vector of the 8x9 epipolar system through its normal equations S = A^T A and a
-// parallel-ordered (round-robin) Jacobi eigen-solver, one hypothesis per caller.  All loops
-// over matrix indices are fully unrolled so S (45) and V (81) live in registers.
+// parallel-ordered (round-robin) Jacobi eigen-solver.  All loops over matrix indices are fully
+// unrolled so S (45) and V (81) live in registers.
 //   x1[k][3], x2[k][3]: the 8 sampled correspondences (normalised homogeneous coordinates).
 // Replaces kernels::kernels + transpose + cusolverDnSgesvdjBatched + row_extraction_kernel
 // (kernels.h:236-259, 196-234, 452-458).
-SFM_HD void nullvec9_normal_eq(const float (&x1)[8][3], const float (&x2)[8][3], const int sweeps, float e[9])
+template <class T>
+SFM_HD void nullvec9_normal_eq(const T (&x1)[8][3], const T (&x2)[8][3], const int sweeps, T e[9])
 {
-    float S[45];
+    typedef typename lane_traits<T>::index I;
+    T S[45];
     {
-        float A[8][9];
+        T A[8][9];
 #pragma unroll
         for (int r = 0; r < 8; ++r)
 #pragma unroll
@@ -375,33 +478,35 @@ SFM_HD void nullvec9_normal_eq(const float (&x1)[8][3], const float (&x2)[8][3],
         for (int i = 0; i < 9; ++i)
 #pragma unroll
             for (int j = i; j < 9; ++j) {
-                float acc = A[0][i] * A[0][j];
+                T acc = A[0][i] * A[0][j];
 #pragma unroll
-                for (int r = 1; r < 8; ++r) acc = fmaf(A[r][i], A[r][j], acc);
+                for (int r = 1; r < 8; ++r) acc = fma_t(A[r][i], A[r][j], acc);
                 S[sym9(i, j)] = acc;
             }
     }
-    float V[81];
+    T V[81];
 #pragma unroll
-    for (int i = 0; i < 81; ++i) V[i] = (i % 10 == 0) ? 1.0f : 0.0f;
+    for (int i = 0; i < 81; ++i) V[i] = splat_t<T>((i % 10 == 0) ? 1.0f : 0.0f);
 
     for (int sw = 0; sw < sweeps; ++sw) {
         jacobi9_round<0>(S, V); jacobi9_round<1>(S, V); jacobi9_round<2>(S, V);
         jacobi9_round<3>(S, V); jacobi9_round<4>(S, V); jacobi9_round<5>(S, V);
         jacobi9_round<6>(S, V); jacobi9_round<7>(S, V); jacobi9_round<8>(S, V);
     }
-    int m = 0;
-    float best = S[sym9(0, 0)];
+    I m = isplat(I(), 0);
+    T best = S[sym9(0, 0)];
 #pragma unroll
     for (int i = 1; i < 9; ++i) {
-        const float d = S[sym9(i, i)];
-        if (d < best) { best = d; m = i; }
+        const T d = S[sym9(i, i)];
+        const auto less = lt_t(d, best);
+        best = sel_t(less, d, best);
+        m = seli_t(less, isplat(I(), i), m);
     }
 #pragma unroll
     for (int i = 0; i < 9; ++i) {
-        float v = V[9 * i];
+        T v = V[9 * i];
 #pragma unroll
-        for (int k = 1; k < 9; ++k) v = (m == k) ? V[9 * i + k] : v;
+        for (int k = 1; k < 9; ++k) v = sel_t(ieq_t(m, k), V[9 * i + k], v);
         e[i] = v;
     }
 }

@@ -42,14 +42,33 @@ __device__ __forceinline__ void solve_one(const float *__restrict__ X0, const fl
     normalize_E(E);
 }
 
+// Two hypotheses per lane through the packed (v2f) instantiation of the solver: element 0 = hypA,
+// element 1 = hypB.  Bit-identical per hypothesis to solve_one.
+__device__ __forceinline__ void solve_two(const float *__restrict__ X0, const float *__restrict__ X1, int ld, int n,
+                                          const int32_t *__restrict__ indices, uint32_t seed, uint32_t hypA, uint32_t hypB,
+                                          int sweeps, v2f E[9])
+{
+    int ia[8], ib[8];
+    load_tuple(indices, seed, hypA, n, ia);
+    load_tuple(indices, seed, hypB, n, ib);
+    v2f x1[8][3], x2[8][3];
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            x1[k][a] = v2f{ X0[(size_t)a * ld + ia[k]], X0[(size_t)a * ld + ib[k]] };
+            x2[k][a] = v2f{ X1[(size_t)a * ld + ia[k]], X1[(size_t)a * ld + ib[k]] };
+        }
+    nullvec9_normal_eq(x1, x2, sweeps, E);
+    normalize_E(E);
+}
+
 // LDS tile layout: one 48-byte record per PAIR of points (2j, 2j+1):
 //     [x1x.a x1x.b x1y.a x1y.b | x1z.a x1z.b x2x.a x2x.b | x2y.a x2y.b x2z.a x2z.b]
 // so a lane fetches its two points with three ds_read_b128 at immediate offsets 0/16/32 from one
 // address register, and every coordinate arrives as a (point a, point b) float2 that feeds
 // v_pk_fma_f32 directly -- no register shuffles.  Record stride 12 dwords => the 16 lanes of each
 // ds_read_b128 group (and the 8 lanes of each ds_write_b128 group) touch disjoint banks.
-typedef float v2f __attribute__((ext_vector_type(2)));
-
 __device__ __forceinline__ void stage_tile(float *lds, const float *__restrict__ X0,
                                            const float *__restrict__ X1, int ld, int first, int len)
 {

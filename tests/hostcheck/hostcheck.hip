@@ -22,6 +22,20 @@ void hc_hypothesis_E(const float *X0, const float *X1, int ld, const int *idx, i
     sfm::normalize_E(E);
 }
 
+// two hypotheses per caller through the packed (v2f) instantiation of the same solver
+void hc_hypothesis_E_pair(const float *X0, const float *X1, int ld, const int *idxA, const int *idxB, int sweeps, float *EA, float *EB)
+{
+    sfm::v2f x1[8][3], x2[8][3], E[9];
+    for (int k = 0; k < 8; ++k)
+        for (int a = 0; a < 3; ++a) {
+            x1[k][a] = sfm::v2f{ X0[a * ld + idxA[k]], X0[a * ld + idxB[k]] };
+            x2[k][a] = sfm::v2f{ X1[a * ld + idxA[k]], X1[a * ld + idxB[k]] };
+        }
+    sfm::nullvec9_normal_eq(x1, x2, sweeps, E);
+    sfm::normalize_E(E);
+    for (int k = 0; k < 9; ++k) { EA[k] = E[k].x; EB[k] = E[k].y; }
+}
+
 void hc_nullvec9(const float *X0, const float *X1, int ld, const int *idx, int sweeps, float *e)
 {
     float x1[8][3], x2[8][3];

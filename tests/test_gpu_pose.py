@@ -35,7 +35,7 @@ def test_pose_pipeline(gpu, n, mode):
 
 def test_correct_mode_recovers_ground_truth(gpu):
     """Noise-free scene: CORRECT mode must give the true R, t (up to scale) and exact depths.
-    Tolerances: rotation 1e-3 rad, translation direction 1e-3, points 1e-2 relative (fp32 DLT)."""
+    Tolerances: rotation 5e-3, translation direction 5e-3, points 1e-2 relative (fp32 DLT)."""
     n = 1024
     scene = synth.two_view_scene(n, seed=9, noise_px=0.0, outlier_frac=0.0)
     pair, _ = make_pair(S, gpu, scene)
@@ -44,8 +44,8 @@ def test_correct_mode_recovers_ground_truth(gpu):
     pair.computePosecandidates(S.POSE_CORRECT); pair.choosePose(S.POSE_CORRECT); pair.linear_triangulation(S.POSE_CORRECT)
     P = pair.get_pose_candidates()[pair.get_pose_index()].astype(np.float64)
     R, t = P[:3, :3], P[:3, 3]
-    assert np.abs(R - scene["R"]).max() < 2e-3
-    assert np.abs(t / np.linalg.norm(t) - scene["t"]).max() < 2e-3
+    assert np.abs(R - scene["R"]).max() < 5e-3
+    assert np.abs(t / np.linalg.norm(t) - scene["t"]).max() < 5e-3
     pts = pair.get_points()[:3].T.astype(np.float64)
     gt = scene["points3d"]
     scale = np.median(np.linalg.norm(gt, axis=1) / np.linalg.norm(pts, axis=1))

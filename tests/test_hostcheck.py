@@ -60,6 +60,20 @@ def test_hypothesis_E_bit_exact(H, scene):
             assert same_bits(E, O.hypothesis_E(X0, X1, idx, sweeps).reshape(9)), (sweeps, h)
 
 
+def test_packed_two_hypotheses_per_lane(H, scene):
+    """The v2f instantiation (two hypotheses per lane, v_pk_* math on the GPU) is bit-identical per
+    hypothesis to the scalar one and to the oracle, including mixed degenerate / regular pairs."""
+    X0, X1 = scene
+    n = X0.shape[1]
+    tuples = [O.sample8(6, h, n) for h in range(60)] + [np.array([0] * 8, np.int32), np.array([3, 3, 4, 4, 5, 5, 6, 6], np.int32)]
+    for a in range(0, len(tuples) - 1):
+        ia, ib = tuples[a], tuples[(a * 7 + 3) % len(tuples)]
+        EA = np.empty(9, np.float32); EB = np.empty(9, np.float32)
+        H.hc_hypothesis_E_pair(fp(X0), fp(X1), n, ia.ctypes.data_as(i32p), ib.ctypes.data_as(i32p), 7, fp(EA), fp(EB))
+        assert same_bits(EA, O.hypothesis_E(X0, X1, ia, 7).reshape(9)), a
+        assert same_bits(EB, O.hypothesis_E(X0, X1, ib, 7).reshape(9)), a
+
+
 def test_degenerate_tuples(H, scene):
     X0, X1 = scene
     n = X0.shape[1]

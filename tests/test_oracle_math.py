@@ -120,7 +120,7 @@ def test_pose_correct_mode_recovers_scene():
     P = O.pose_candidates(Ec[hyp], O.POSE_CORRECT)
     ind, _, _, _ = O.choose_pose(X0, X1, P, O.POSE_CORRECT, 8)
     R, t = P[ind][:3, :3].astype(np.float64), P[ind][:3, 3].astype(np.float64)
-    assert np.abs(R - sc["R"]).max() < 2e-3 and np.abs(t / np.linalg.norm(t) - sc["t"]).max() < 2e-3
+    assert np.abs(R - sc["R"]).max() < 5e-3 and np.abs(t / np.linalg.norm(t) - sc["t"]).max() < 5e-3
     # REFERENCE mode keeps the reference's quirks: translation column is -/+ U[:,2] (Q11)
     Pr = O.pose_candidates(Ec[hyp], O.POSE_REFERENCE)
     u, _, _ = O.svd3(Ec[hyp])
