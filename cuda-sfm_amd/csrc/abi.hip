@@ -276,7 +276,7 @@ int sfm_fill_xu(sfm_pair *pair, const sfm_sift_point *d_data)
     SFM_REQUIRE(pair && d_data, SFM_E_INVALID, "null argument");
     SFM_HIP_TRY(hipSetDevice(pair->ctx->device));
     int rc = launch_fill_xu(pair, d_data);
-    if (rc == SFM_OK) { pair->have_points = true; pair->have_E = pair->have_P = pair->have_pose = false; }
+    if (rc == SFM_OK) { pair->have_points = true; pair->have_E = pair->have_P = pair->have_pose = false; pair->last_count = 0; }
     return rc;
 }
 
@@ -285,7 +285,7 @@ int sfm_set_points(sfm_pair *pair, const float *d_X0, const float *d_X1)
     SFM_REQUIRE(pair && d_X0 && d_X1, SFM_E_INVALID, "null argument");
     SFM_HIP_TRY(hipSetDevice(pair->ctx->device));
     int rc = launch_set_points(pair, d_X0, d_X1);
-    if (rc == SFM_OK) { pair->have_points = true; pair->have_E = pair->have_P = pair->have_pose = false; }
+    if (rc == SFM_OK) { pair->have_points = true; pair->have_E = pair->have_P = pair->have_pose = false; pair->last_count = 0; }
     return rc;
 }
 

@@ -64,6 +64,9 @@ struct sfm_pair {
     float *d_Ecand = nullptr;
     size_t cap_hyps = 0;
     uint32_t last_count = 0;           // hyp_count of the last score call
+    uint32_t cand_h0 = 0, cand_seed = 0;   // what d_Ecand currently holds: shard start, sampler settings
+    const int32_t *cand_indices = nullptr;
+    int cand_sweeps = 0;
     bool have_points = false, have_E = false, have_P = false, have_pose = false;
     int pose_mode = SFM_POSE_REFERENCE;
     int last_kernel = 0, last_grid = 0, last_block = 0, last_lds = 0;

@@ -173,11 +173,15 @@ int launch_ransac_score(sfm_pair *pair, const sfm_ransac_params &p, uint32_t h0,
     sfm_ctx *ctx = pair->ctx;
     SFM_HIP_TRY(hipMemsetAsync(pair->d_key, 0, 2 * sizeof(unsigned long long), ctx->stream));
     pair->last_count = count;
+    pair->cand_h0 = h0; pair->cand_seed = p.seed; pair->cand_indices = p.d_indices; pair->cand_sweeps = p.jacobi_sweeps;
     if (count == 0) return SFM_OK;
     int rc = ensure_hyp_capacity(pair, count);
     if (rc != SFM_OK) return rc;
 
-    int kernel = p.kernel == SFM_KERNEL_AUTO ? SFM_KERNEL_SPLIT : p.kernel;
+    // AUTO: few hypotheses are latency-bound -> one hypothesis per wavefront (fused, all waves start
+    // at once); many hypotheses are throughput-bound -> lane-parallel solve + wavefront scoring.
+    // Crossover measured at ~8k hypotheses (profiles/r01_small_h_bench.txt).
+    int kernel = p.kernel == SFM_KERNEL_AUTO ? (count <= 8192u ? SFM_KERNEL_FUSED : SFM_KERNEL_SPLIT) : p.kernel;
     pair->last_kernel = kernel;
     if (kernel == SFM_KERNEL_FUSED) return launch_ransac_fused(pair, p, h0, count);
 

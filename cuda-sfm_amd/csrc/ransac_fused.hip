@@ -187,22 +187,31 @@ void ransac_fused_waves(const float *__restrict__ X0, const float *__restrict__ 
     }
 }
 
-// Winner's E from its hypothesis id, one wavefront (see header comment).
+// Winner's E, one wavefront.  When the winner belongs to the shard this rank just scored, its E is
+// already in Ecand (same bits); otherwise (multi-GPU: another rank owns it) it is re-derived from the
+// hypothesis id with the wave-cooperative solver.
 __global__ __launch_bounds__(64)
 void ransac_finalize_E_wave(const float *__restrict__ X0, const float *__restrict__ X1, int ld, int n,
                             const int32_t *__restrict__ indices, uint32_t seed, int sweeps,
                             const unsigned long long *__restrict__ key, uint32_t hyp_host, int from_key,
+                            const float *__restrict__ Ecand, uint32_t h0, uint32_t count,
                             float *__restrict__ E_out, uint32_t *__restrict__ best_out)
 {
     __shared__ __attribute__((aligned(16))) float ws[kWaveScratch];
     uint32_t hyp = hyp_host;
     if (from_key) hyp = 0xFFFFFFFFu - (uint32_t)(key[0] & 0xFFFFFFFFull);
     hyp = __builtin_amdgcn_readfirstlane(hyp);
-    float E[9];
-    solve_wave(X0, X1, ld, n, indices, seed, hyp, sweeps, ws, threadIdx.x, E);
-    if (threadIdx.x == 0) {
+    if (Ecand && hyp >= h0 && hyp - h0 < count) {
+        if (threadIdx.x < 9) E_out[threadIdx.x] = Ecand[9 * (size_t)(hyp - h0) + threadIdx.x];
+    } else {
+        float E[9];
+        solve_wave(X0, X1, ld, n, indices, seed, hyp, sweeps, ws, threadIdx.x, E);
+        if (threadIdx.x == 0) {
 #pragma unroll
-        for (int k = 0; k < 9; ++k) E_out[k] = E[k];
+            for (int k = 0; k < 9; ++k) E_out[k] = E[k];
+        }
+    }
+    if (threadIdx.x == 0) {
         best_out[0] = hyp;
         best_out[1] = 0;        // filled by ransac_finalize_mask
     }
@@ -251,9 +260,13 @@ int launch_ransac_fused(sfm_pair *pair, const sfm_ransac_params &p, uint32_t h0,
 int launch_finalize_E_wave(sfm_pair *pair, const sfm_ransac_params &p, const unsigned long long *d_key,
                            uint32_t hyp_host, bool from_key)
 {
+    // Ecand is only trusted when it was produced by a score call with the same sampler settings
+    const bool cand_ok = pair->last_count > 0 && pair->cand_seed == p.seed && pair->cand_indices == p.d_indices &&
+                         pair->cand_sweeps == p.jacobi_sweeps;
     hipLaunchKernelGGL(ransac_finalize_E_wave, dim3(1), dim3(64), 0, pair->ctx->stream,
                        pair->d_X[0], pair->d_X[1], pair->ld, pair->n, p.d_indices, p.seed, p.jacobi_sweeps,
-                       d_key, hyp_host, from_key ? 1 : 0, pair->d_E, pair->d_best);
+                       d_key, hyp_host, from_key ? 1 : 0,
+                       cand_ok ? pair->d_Ecand : nullptr, pair->cand_h0, pair->last_count, pair->d_E, pair->d_best);
     SFM_HIP_TRY(hipGetLastError());
     return SFM_OK;
 }
