@@ -12,7 +12,8 @@
 #                      __forceinline__ are the HIP toolchain's own, no stand-in header is written.
 #   libref_match.so    CudaSift/match.cu:57-71 MatchC1 (CPU matcher), plain g++.
 #   libref_match_fma.so  same, built with FMA contraction (what nvcc does to matching.cu:338-351).
-#   libref_kernels.so  (ref_build_gpu.sh) device build of the reference's own kernels for gfx950.
+#   libref_kernels.so  (ref_build_gpu.sh) device build of the reference's own kernels for gfx950
+#                      (SfM/kernels.h:236-458, CudaSift/matching.cu:289-397), run by tests/test_gpu_ref_kernels.py.
 #
 # What is NOT buildable here and why: sfm.cu host code, kernels.h wrappers (cuBLAS / cuSOLVER /
 # Thrust, CUDA runtime), CudaSift extraction (CUDA textures) -- see DESIGN.md.

@@ -1,0 +1,57 @@
+#!/bin/sh
+# Device build of the REFERENCE'S OWN KERNELS for gfx950 (test infrastructure only).
+#
+# hipcc compiles CUDA-dialect kernel code natively (__global__, threadIdx, __shared__, float4 ...),
+# so the kernel bodies are taken from the reference sources where they lie -- line ranges located by
+# grep at build time, assembled in a mktemp directory, never copied into the repository -- and only the
+# resulting shared object lands in oracle/_ref/.  No stand-in headers: the ranges are chosen to exclude
+# the #include lines and the cuBLAS / cuSOLVER host wrappers that cannot be built here.
+#
+#   libref_kernels.so   SfM/kernels.h  __global__ kernels (kernels, copy_point, normalizeE, element_wise_*,
+#                       vecnorm, threshold_count, candidate_kernels, compute_linear_triangulation_A,
+#                       normalize_pt_kernal, row_extraction_kernel) + SfM/svd.h device functions,
+#                       built with -ffp-contract=off (the arithmetic contract of the oracle);
+#                       CudaSift/matching.cu CleanMatches + FindMaxCorr10 (the live matcher, :289-397),
+#                       built with -ffp-contract=fast (nvcc's default fmad, which fuses :347-350).
+# Launch geometry in ref_driver_gpu.inc follows the reference's call sites (cited there).
+set -eu
+REF="${1:-/root/reference}"
+OUT="${2:-$(cd "$(dirname "$0")" && pwd)/_ref}"
+HERE="$(cd "$(dirname "$0")" && pwd)"
+TMP="$(mktemp -d)"
+trap 'rm -rf "$TMP"' EXIT
+K="$REF/SfM/kernels.h"; SVD="$REF/SfM/svd.h"; COMMON="$REF/SfM/common.h"; M="$REF/CudaSift/matching.cu"
+
+kb=$(grep -n 'void kernels(float\*d1' "$K" | cut -d: -f1)            # first __global__ after the host wrappers
+kb=$((kb - 1))                                                        # its __global__ line
+ke=$(grep -n 'T\* cuda_alloc_copy' "$K" | cut -d: -f1)                # template that follows the last kernel
+ke=$((ke - 2))
+{
+  echo '#include <hip/hip_runtime.h>'
+  echo '#include <math.h>'
+  echo '#include <assert.h>'
+  echo '#include <string.h>'
+  echo "#include \"$REF/CudaSift/cudaSift.h\""                         # SiftPoint: the reference's own header
+  grep -E '^#define access[23]\(' "$COMMON"
+  grep -E '^#define (x_pos|y_pos|z_pos) ' "$K"
+  grep -v '^#include' "$SVD"
+  echo 'namespace refk {'
+  sed -n "${kb},${ke}p" "$K"
+  echo '}'
+  cat "$HERE/ref_driver_gpu.inc"
+} > "$TMP/ref_kernels.hip"
+
+mb=$(grep -n '^__global__ void CleanMatches' "$M" | cut -d: -f1)
+me=$(grep -n '^#define FMC_GH' "$M" | cut -d: -f1)
+{
+  echo '#include <hip/hip_runtime.h>'
+  echo "#include \"$REF/CudaSift/cudaSift.h\""
+  sed -n "${mb},$((me - 1))p" "$M"
+  cat "$HERE/ref_driver_match_gpu.inc"
+} > "$TMP/ref_matchk.hip"
+
+HIPCC=/opt/rocm/bin/hipcc
+$HIPCC --offload-arch=gfx950 -O2 -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fPIC -w -c "$TMP/ref_kernels.hip" -o "$TMP/a.o"
+$HIPCC --offload-arch=gfx950 -O2 -ffp-contract=fast -fPIC -w -c "$TMP/ref_matchk.hip" -o "$TMP/b.o"
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT/libref_kernels.so" "$TMP/a.o" "$TMP/b.o"
+echo "ref_build_gpu: wrote $OUT/libref_kernels.so"

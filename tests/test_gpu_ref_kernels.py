@@ -1,0 +1,184 @@
+"""GPU: the REFERENCE'S OWN KERNELS (SfM/kernels.h bodies, CudaSift/matching.cu FindMaxCorr10), compiled
+for gfx950 by oracle/ref_build_gpu.sh from the sources where they lie, run on the MI355X and compared
+with the oracle and with the product.  This pins the restated kernel bodies to the reference itself.
+Skipped when oracle/_ref/libref_kernels.so was not built (needs /root/reference at build time)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import cuda_sfm_amd as S
+import oracle as O
+from cuda_sfm_amd_synth import synth
+from helpers import same_bits, to_dev
+
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(not O.ref_available("libref_kernels.so"), reason="oracle/_ref/libref_kernels.so not built")]
+
+f32p, i32p = O.f32p, O.i32p
+
+
+@pytest.fixture(scope="module")
+def R(gpu):
+    lib = O.ref_lib("libref_kernels.so")
+    lib.refk_residual_tail.argtypes = [f32p, f32p, f32p, f32p, C.c_int, C.c_int, C.c_float, i32p]
+    lib.refk_vecnorm.argtypes = [f32p, f32p, C.c_int, C.c_int, C.c_float, C.c_float]
+    return lib
+
+
+def fp(a):
+    return a.ctypes.data_as(f32p)
+
+
+@pytest.fixture(scope="module")
+def scene():
+    sc = synth.two_view_scene(1000, seed=17)
+    U0, U1, X0, X1 = O.fill_xu(sc["sift"], sc["Kinv"])
+    return sc, U0, U1, np.ascontiguousarray(X0), np.ascontiguousarray(X1)
+
+
+def test_copy_point(R, scene):
+    sc, U0, U1, _, _ = scene
+    n = len(sc["sift"])
+    a = np.empty((3, n), np.float32); b = np.empty((3, n), np.float32)
+    assert R.refk_copy_point(sc["sift"].ctypes.data_as(C.c_void_p), n, fp(a), fp(b)) == 0
+    assert same_bits(a, U0) and same_bits(b, U1)
+
+
+def test_kron_rows_kernel(R, scene):
+    _, _, _, X0, X1 = scene
+    n, H = X0.shape[1], 300
+    idx = np.array([O.sample8(3, h, n) for h in range(H)], np.int32)
+    A = np.empty((H, 72), np.float32)
+    assert R.refk_kernels(fp(X0), fp(X1), n, idx.ctypes.data_as(i32p), H, fp(A)) == 0
+    ref = np.array([O.build_A(X0, X1, idx[h]).reshape(72) for h in range(H)])
+    assert same_bits(A, ref)
+
+
+def test_row_extraction_and_normalizeE(R, scene):
+    _, _, _, X0, X1 = scene
+    # testRow_extraction_kernel (sfm.cu:490-502): data[i] = i -> res[b] = 81b+72 .. 81b+80
+    Vt = np.arange(81 * 9, dtype=np.float32)
+    E = np.empty(9 * 9, np.float32)
+    assert R.refk_row_extraction(fp(Vt), 9, fp(E)) == 0
+    assert np.array_equal(E.reshape(9, 9), np.array([[81 * b + 72 + k for k in range(9)] for b in range(9)], np.float32))
+    # normalizeE kernel vs oracle on real null vectors
+    n = X0.shape[1]
+    e0 = np.array([O.nullvec9(O.build_A(X0, X1, O.sample8(5, h, n)), 7) for h in range(200)], np.float32)
+    got = e0.copy()
+    assert R.refk_normalizeE(fp(got), len(got)) == 0
+    ref = np.array([O.normalizeE(e).reshape(9) for e in e0])
+    assert same_bits(got, ref)
+
+
+def test_residual_tail_kernels(R, scene):
+    """element_wise_div (zero divisor -> 0), element_wise_sum, threshold_count (strict <, NaN never
+    counts) as launched at sfm.cu:214-220, fed with the oracle's n^2, da, db."""
+    _, _, _, X0, X1 = scene
+    n, H, thr = X0.shape[1], 40, np.float32(1e-6)
+    n2 = np.empty((H, n), np.float32); da = np.empty_like(n2); db = np.empty_like(n2)
+    counts_o = np.empty(H, np.int32)
+    for h in range(H):
+        Ef = O.hypothesis_E(X0, X1, O.sample8(9, h, n), 7).reshape(9)
+        counts_o[h] = O.count_inliers(Ef, X0, X1, thr, want_mask=False)[0]
+        n2[h], da[h], db[h] = oracle_terms(Ef, X0, X1)
+    counts = np.empty(H, np.int32)
+    assert R.refk_residual_tail(fp(n2.copy()), fp(da), fp(n2.copy()), fp(db), n, H, thr, counts.ctypes.data_as(i32p)) == 0
+    assert np.array_equal(counts, counts_o)
+    # zero divisor and NaN semantics
+    nn = np.array([[1.0, 1.0, np.nan, 0.0]], np.float32); dd = np.array([[0.0, 4.0, 1.0, 0.0]], np.float32)
+    c = np.empty(1, np.int32)
+    assert R.refk_residual_tail(fp(nn.copy()), fp(dd), fp(nn.copy()), fp(dd), 4, 1, np.float32(0.6), c.ctypes.data_as(i32p)) == 0
+    assert c[0] == 3          # 0 (zero divisor), 0.5, NaN (not counted), 0
+
+
+def oracle_terms(E, X0, X1):
+    """n^2, da, db exactly as orc_residual forms them (fmaf chains), via float64 emulation of fmaf:
+    a float32 fma equals rounding the exact float64 product-sum when the exact result fits in 53 bits,
+    which holds for products of two float32 values plus a float32."""
+    f = np.float32
+    def fma(a, b, c):
+        return (a.astype(np.float64) * b.astype(np.float64) + c.astype(np.float64)).astype(np.float32)
+    E = E.astype(f)
+    x1x, x1y, x1z = X0[0], X0[1], X0[2]
+    x2x, x2y, x2z = X1[0], X1[1], X1[2]
+    a0 = fma(np.full_like(x2z, E[2]), x2z, fma(np.full_like(x2y, E[1]), x2y, (E[0] * x2x).astype(f)))
+    a1 = fma(np.full_like(x2z, E[5]), x2z, fma(np.full_like(x2y, E[4]), x2y, (E[3] * x2x).astype(f)))
+    a2 = fma(np.full_like(x2z, E[8]), x2z, fma(np.full_like(x2y, E[7]), x2y, (E[6] * x2x).astype(f)))
+    b0 = fma(np.full_like(x1z, E[6]), x1z, fma(np.full_like(x1y, E[3]), x1y, (E[0] * x1x).astype(f)))
+    b1 = fma(np.full_like(x1z, E[7]), x1z, fma(np.full_like(x1y, E[4]), x1y, (E[1] * x1x).astype(f)))
+    nn = fma(x1z, a2, fma(x1y, a1, (x1x * a0).astype(f)))
+    return (nn * nn).astype(f), fma(a1, a1, (a0 * a0).astype(f)), fma(b1, b1, (b0 * b0).astype(f))
+
+
+def test_vecnorm_literal(R):
+    """testVecnorm (sfm.cu:503-510): 1..9 as 3x3, (row=3, col=3, exp=2, pow=1) -> sqrt(66), sqrt(93), sqrt(126)."""
+    A = np.arange(1, 10, dtype=np.float32)
+    res = np.empty(3, np.float32)
+    assert R.refk_vecnorm(fp(A), fp(res), 3, 3, 2.0, 1.0) == 0
+    assert np.allclose(res, np.sqrt([66, 93, 126]), rtol=2e-6)       # powf: not correctly rounded
+    res2 = np.empty(3, np.float32)
+    assert R.refk_vecnorm(fp(A), fp(res2), 3, 3, 2.0, 2.0) == 0      # exp == final_pow: plain sum of squares
+    assert np.allclose(res2, [66, 93, 126], rtol=2e-6)
+
+
+def test_candidate_kernels(R, scene):
+    _, _, _, X0, X1 = scene
+    n = X0.shape[1]
+    for h in range(60):
+        E = O.hypothesis_E(X0, X1, O.sample8(2, h, n), 7)
+        u, _, v = O.svd3(E)
+        if O.det_ref(O.multABt(u, v)) < 0:        # host part of computePosecandidates (sfm.cu:243-245)
+            v = -v
+        P = np.empty(64, np.float32)
+        assert R.refk_candidates(fp(np.ascontiguousarray(u).reshape(9)), fp(np.ascontiguousarray(v).reshape(9)), fp(P)) == 0
+        assert same_bits(P, O.pose_candidates(E, O.POSE_REFERENCE).reshape(64))
+
+
+def test_triangulation_kernels(R, scene):
+    _, _, _, X0, X1 = scene
+    n = X0.shape[1]
+    E = O.hypothesis_E(X0, X1, O.sample8(2, 7, n), 7)
+    P = O.pose_candidates(E, O.POSE_REFERENCE)
+    I4 = np.eye(4, dtype=np.float32)
+    A = np.empty((4, 16), np.float32)
+    assert R.refk_tri_A(fp(X0), fp(X1), n, fp(I4.reshape(16)), fp(P.reshape(64)), -1, 1, fp(A)) == 0
+    for i in range(4):
+        assert same_bits(A[i], O.tri_A(X0[0, 0], X0[1, 0], X1[0, 0], X1[1, 0], I4, P[i]).reshape(16))
+    An = np.empty((n, 16), np.float32)
+    assert R.refk_tri_A(fp(X0), fp(X1), n, fp(I4.reshape(16)), fp(P.reshape(64)), 2, 0, fp(An)) == 0
+    for j in range(0, n, 13):
+        assert same_bits(An[j], O.tri_A(X0[0, j], X0[1, j], X1[0, j], X1[1, j], I4, P[2]).reshape(16))
+    # normalize_pt_kernal on the oracle's null vectors placed in the last row of V^T (kernels.h:433-450)
+    Vt = np.zeros((n, 16), np.float32)
+    nv = np.array([O.nullvec4(An[j], 8) for j in range(n)], np.float32)
+    nv[5, 3] = 0.0; nv[6, 3] = 7.0
+    Vt[:, 12:16] = nv
+    pts = np.empty((4, n), np.float32)
+    assert R.refk_normalize_pt(fp(Vt), n, fp(pts)) == 0
+    ref = np.array([O.normalize_pt(v) for v in nv]).T
+    assert same_bits(pts, ref)
+
+
+@pytest.mark.parametrize("n1,n2", [(512, 512), (1024, 2048)])
+def test_findmaxcorr10_vs_product_matcher(R, gpu, n1, n2):
+    """The reference's live match kernel on the same GPU: score / match / match_xpos / match_ypos must be
+    bit-identical to the product's MFMA matcher (sizes are multiples of 32, so the tail quirk Q1 is not
+    exercised); its ambiguity uses an approximate second-best that can only be <= the exact one."""
+    torch, dev, ctx = gpu
+    d1, _, _ = synth.descriptors(n1, seed=n1)
+    d2, _, _ = synth.descriptors(n2, seed=n2 + 1)
+    s1 = synth.sift_records(d1, seed=3); s2 = synth.sift_records(d2, seed=4)
+    ref = s1.copy()
+    assert R.refk_match(ref.ctypes.data_as(C.c_void_p), n1, s2.ctypes.data_as(C.c_void_p), n2) == 0
+    t1, t2 = to_dev(torch, dev, s1), to_dev(torch, dev, s2)
+    ctx.match(t1, n1, t2, n2)
+    torch.cuda.synchronize()
+    ours = t1.cpu().numpy().reshape(-1).view(synth.SIFT_DTYPE)
+    assert np.array_equal(ours["match"], ref["match"])
+    for f in ("score", "match_xpos", "match_ypos"):
+        assert same_bits(ours[f], ref[f]), f
+    assert (ref["ambiguity"] <= ours["ambiguity"] * (1 + 1e-6)).all()
+    assert (ref["ambiguity"] == ours["ambiguity"]).mean() > 0.5
+    orc = O.match_sift(s1, s2)
+    assert np.array_equal(orc["match"], ref["match"]) and same_bits(orc["score"], ref["score"])
