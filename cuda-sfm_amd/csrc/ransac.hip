@@ -213,7 +213,8 @@ int launch_ransac_score(sfm_pair *pair, const sfm_ransac_params &p, uint32_t h0,
     if (per_cu < 1) per_cu = 1;
     const uint32_t resident = (uint32_t)ctx->num_cus * (uint32_t)per_cu;
     const int grid = (int)(nbatch < resident ? nbatch : resident);
-    switch (wpb) {
+    if (kernel == SFM_KERNEL_MFMA) rc = launch_score_mfma(pair, p, h0, count);
+    else switch (wpb) {
     case 16: rc = launch_score_t<16>(pair, h0, count, p.threshold, tile, ntiles, grid, lds); break;
     case 8:  rc = launch_score_t<8>(pair, h0, count, p.threshold, tile, ntiles, grid, lds); break;
     default: rc = launch_score_t<4>(pair, h0, count, p.threshold, tile, ntiles, grid, lds); break;

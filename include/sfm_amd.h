@@ -102,6 +102,7 @@ int sfm_set_points(sfm_pair *pair, const float *d_X0, const float *d_X1);
 #define SFM_KERNEL_AUTO   0
 #define SFM_KERNEL_SPLIT  1   /* solve: one hypothesis per lane; score: one hypothesis per wavefront */
 #define SFM_KERNEL_FUSED  2   /* everything one hypothesis per wavefront in LDS                      */
+#define SFM_KERNEL_MFMA   3   /* lane solve; scoring: 32 hypotheses per wavefront, E.X on the matrix cores */
 
 typedef struct sfm_ransac_params {
     uint32_t num_hypotheses;  /* H: global hypothesis count (reference: N/8, sfm.cu:95)                 */

@@ -25,7 +25,7 @@ def test_fill_xu_bit_exact(gpu, n):
         assert same_bits(pair.get_XU(which), ref)
 
 
-@pytest.mark.parametrize("kernel", [S.KERNEL_SPLIT, S.KERNEL_FUSED])
+@pytest.mark.parametrize("kernel", [S.KERNEL_SPLIT, S.KERNEL_FUSED, S.KERNEL_MFMA])
 @pytest.mark.parametrize("n,H", [(64, 50), (1000, 300), (2048, 1024), (4096, 2048), (4500, 600), (9000, 100)])
 def test_counts_winner_mask_E(gpu, n, H, kernel):
     scene = synth.two_view_scene(n, seed=5 + n)
