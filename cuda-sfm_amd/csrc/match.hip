@@ -29,7 +29,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kRowsPerStage = 64;        // database rows per LDS stage (RT = 2 MFMA row tiles)
 constexpr int kLdsStride = 132;          // floats per staged row
-constexpr int kMatchThreads = 256;       // 4 wavefronts
 
 struct Top2 { float best, second; int idx; };
 
@@ -53,14 +52,15 @@ __device__ __forceinline__ Top2 top2_merge(const Top2 &a, const Top2 &b)
 }
 
 // Stage `rows` descriptor rows (first row `row0`, zero beyond `nrows`) into buf[rows][132].
+template <int W>
 __device__ __forceinline__ void stage_load(const float *__restrict__ base, int ld, int row0, int nrows,
-                                           float4 (&regs)[4][2])
+                                           float4 (&regs)[16 / W][2])
 {
     const int c8 = threadIdx.x & 15;             // which 8-float chunk of the 128
-    const int rr = threadIdx.x >> 4;             // 16 rows per pass
+    const int rr = threadIdx.x >> 4;             // 4*W rows per pass
 #pragma unroll
-    for (int pass = 0; pass < 4; ++pass) {
-        const int row = row0 + pass * 16 + rr;
+    for (int pass = 0; pass < 16 / W; ++pass) {
+        const int row = row0 + pass * (4 * W) + rr;
         if (row < nrows) {
             const float4 *src = reinterpret_cast<const float4 *>(base + (size_t)row * ld + 8 * c8);
             regs[pass][0] = src[0];
@@ -72,22 +72,26 @@ __device__ __forceinline__ void stage_load(const float *__restrict__ base, int l
     }
 }
 
-__device__ __forceinline__ void stage_store(float *buf, const float4 (&regs)[4][2])
+template <int W>
+__device__ __forceinline__ void stage_store(float *buf, const float4 (&regs)[16 / W][2])
 {
     const int c8 = threadIdx.x & 15;
     const int rr = threadIdx.x >> 4;
 #pragma unroll
-    for (int pass = 0; pass < 4; ++pass) {
-        float4 *dst = reinterpret_cast<float4 *>(buf + (pass * 16 + rr) * kLdsStride + 8 * c8);
+    for (int pass = 0; pass < 16 / W; ++pass) {
+        float4 *dst = reinterpret_cast<float4 *>(buf + (pass * (4 * W) + rr) * kLdsStride + 8 * c8);
         const float4 a = regs[pass][0], b = regs[pass][1];
         dst[0] = make_float4(a.x, a.z, b.x, b.z);      // even d: k-parity 0
         dst[1] = make_float4(a.y, a.w, b.y, b.w);      // odd d : k-parity 1
     }
 }
 
-// One block: CT*128 queries (4 waves x CT column tiles) against database rows [row_begin, row_end).
-template <int CT>
-__global__ __launch_bounds__(kMatchThreads)
+// One block: W waves x CT column tiles = 32*CT*W queries against database rows [row_begin, row_end).
+// W = 8 puts two wavefronts on every SIMD of the CU (one block per CU, 67.6 KB of LDS): while one
+// folds its accumulators into the running top-2 or waits at the stage barrier, the other keeps the
+// matrix pipe busy.
+template <int CT, int W>
+__global__ __launch_bounds__(W * 64)
 void match_mfma_kernel(const float *__restrict__ q, int nq, int ldq,
                        const float *__restrict__ db, int ndb, int lddb,
                        int rows_per_split,
@@ -98,7 +102,7 @@ void match_mfma_kernel(const float *__restrict__ q, int nq, int ldq,
     const int wave = threadIdx.x >> 6;
     const int col = lane & 31;
     const int half = lane >> 5;
-    const int q0 = blockIdx.x * (CT * 128);
+    const int q0 = blockIdx.x * (CT * 32 * W);
     const int split = blockIdx.y;
     const int row_begin = split * rows_per_split;
     const int row_end = min(ndb, row_begin + rows_per_split);
@@ -106,12 +110,12 @@ void match_mfma_kernel(const float *__restrict__ q, int nq, int ldq,
     // ---- prologue: resident query fragments b[ct][2m + half], m = 0..63 --------------------
     float bq[CT][64];
     {
-        float4 regs[4][2];
-        constexpr int kChunks = CT * 128 / kRowsPerStage;
+        float4 regs[16 / W][2];
+        constexpr int kChunks = CT * 32 * W / kRowsPerStage;
         for (int ch = 0; ch < kChunks; ++ch) {
-            stage_load(q, ldq, q0 + ch * kRowsPerStage, nq, regs);
+            stage_load<W>(q, ldq, q0 + ch * kRowsPerStage, nq, regs);
             __syncthreads();
-            stage_store(lds[0], regs);
+            stage_store<W>(lds[0], regs);
             __syncthreads();
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) {
@@ -136,15 +140,15 @@ void match_mfma_kernel(const float *__restrict__ q, int nq, int ldq,
 
     // ---- main loop over database stages of 64 rows ------------------------------------------
     const int nstage = (row_end - row_begin + kRowsPerStage - 1) / kRowsPerStage;
-    float4 regs[4][2];
+    float4 regs[16 / W][2];
     if (nstage > 0) {
-        stage_load(db, lddb, row_begin, row_end, regs);
-        stage_store(lds[0], regs);
+        stage_load<W>(db, lddb, row_begin, row_end, regs);
+        stage_store<W>(lds[0], regs);
     }
     __syncthreads();
     for (int s = 0; s < nstage; ++s) {
         const float *cur = lds[s & 1];
-        if (s + 1 < nstage) stage_load(db, lddb, row_begin + (s + 1) * kRowsPerStage, row_end, regs);
+        if (s + 1 < nstage) stage_load<W>(db, lddb, row_begin + (s + 1) * kRowsPerStage, row_end, regs);
 
         f32x16 acc[2][CT];
 #pragma unroll
@@ -182,7 +186,7 @@ void match_mfma_kernel(const float *__restrict__ q, int nq, int ldq,
                 for (int ct = 0; ct < CT; ++ct) top2_push(top[ct], acc[rt][ct][r], p2);
             }
 
-        if (s + 1 < nstage) stage_store(lds[(s + 1) & 1], regs);
+        if (s + 1 < nstage) stage_store<W>(lds[(s + 1) & 1], regs);
         __syncthreads();
     }
 
@@ -235,9 +239,12 @@ int launch_match(sfm_ctx *ctx, const float *d1, int n1, int ld1, const float *d2
 {
     if (n1 <= 0 || n2 <= 0) return SFM_OK;                 // matching.cu:1095-1096
     const int ct = n1 > 4096 ? 2 : 1;
-    const int qblocks = (n1 + ct * 128 - 1) / (ct * 128);
-    // enough (query block, database split) pairs to put ~2 blocks on every CU
-    int nsplit = (2 * ctx->num_cus + qblocks - 1) / qblocks;
+    const int wv = n1 > 4096 ? 8 : 4;                       // wavefronts per block
+    const int qper = ct * 32 * wv;                          // queries per block
+    const int qblocks = (n1 + qper - 1) / qper;
+    // enough (query block, database split) pairs to fill every CU (2 blocks/CU at W = 4, 1 at W = 8)
+    const int want = (wv == 8 ? 1 : 2) * ctx->num_cus;
+    int nsplit = (want + qblocks - 1) / qblocks;
     const int max_split = (n2 + kRowsPerStage - 1) / kRowsPerStage;
     if (nsplit > max_split) nsplit = max_split;
     if (nsplit < 1) nsplit = 1;
@@ -259,10 +266,10 @@ int launch_match(sfm_ctx *ctx, const float *d1, int n1, int ld1, const float *d2
 
     const dim3 grid(qblocks, nsplit);
     if (ct == 2)
-        hipLaunchKernelGGL(match_mfma_kernel<2>, grid, dim3(kMatchThreads), 0, ctx->stream,
+        hipLaunchKernelGGL((match_mfma_kernel<2, 8>), grid, dim3(512), 0, ctx->stream,
                            d1, n1, ld1, d2, n2, ld2, rows_per_split, wb, wsnd, wi);
     else
-        hipLaunchKernelGGL(match_mfma_kernel<1>, grid, dim3(kMatchThreads), 0, ctx->stream,
+        hipLaunchKernelGGL((match_mfma_kernel<1, 4>), grid, dim3(256), 0, ctx->stream,
                            d1, n1, ld1, d2, n2, ld2, rows_per_split, wb, wsnd, wi);
     SFM_HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(match_merge_kernel, dim3((n1 + 255) / 256), dim3(256), 0, ctx->stream,
