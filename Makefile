@@ -15,7 +15,9 @@ HDRS     := $(wildcard $(CSRC)/*.hpp) include/sfm_amd.h
 
 DEMO     := $(PKG)/host/two_view_demo
 
-all: $(LIB) oracle hostcheck $(DEMO)
+IOTEST   := tests/cpp/io_test
+
+all: $(LIB) oracle hostcheck $(DEMO) $(IOTEST)
 
 $(BUILD)/%.o: $(CSRC)/%.hip $(HDRS)
 	@mkdir -p $(BUILD)
@@ -32,13 +34,16 @@ oracle:
 $(DEMO): $(PKG)/host/two_view_demo.cpp $(PKG)/host/sfm.h $(PKG)/host/cudaSift.h include/sfm_amd.h $(LIB)
 	g++ -O2 -std=c++14 -Wall -o $@ $< -L$(PKG)/lib -lsfm_amd -Wl,-rpath,'$$ORIGIN/../lib' -Wl,-rpath,/opt/rocm/lib
 
+$(IOTEST): tests/cpp/io_test.cpp $(PKG)/host/sfm_io.h $(PKG)/host/cudaSift.h include/sfm_amd.h
+	g++ -O2 -std=c++14 -Wall -o $@ $<
+
 hostcheck: tests/hostcheck/libhostcheck.so
 
 tests/hostcheck/libhostcheck.so: tests/hostcheck/hostcheck.hip $(CSRC)/device_math.hpp
 	$(HIPCC) -x hip --cuda-host-only -O2 -ffp-contract=off -mfma -fPIC -shared -Wno-pass-failed -o $@ $<
 
 clean:
-	rm -rf $(BUILD) $(LIB) $(DEMO) tests/hostcheck/libhostcheck.so
+	rm -rf $(BUILD) $(LIB) $(DEMO) $(IOTEST) tests/hostcheck/libhostcheck.so
 	$(MAKE) -C oracle clean
 
 .PHONY: all oracle hostcheck clean

@@ -37,7 +37,7 @@ def cpu_baseline(scene, params, seconds=12.0):
     t0 = time.perf_counter()
     O.ransac_range(X0, X1, 0, probe, params.threshold, params.jacobi_sweeps, seed=params.seed, want_counts=False, nthreads=cores)
     rate = probe / (time.perf_counter() - t0)
-    sample = int(max(probe, min(TOTAL_HYPS, rate * seconds)))
+    sample = int(max(probe, min(4 * TOTAL_HYPS, rate * seconds)))     # ids beyond H are further hypotheses of the same scene
     t0 = time.perf_counter()
     key, _, _ = O.ransac_range(X0, X1, 0, sample, params.threshold, params.jacobi_sweeps, seed=params.seed, want_counts=False, nthreads=cores)
     dt = time.perf_counter() - t0
@@ -111,6 +111,14 @@ def main():
 
     hyp, cnt = pair.get_best()
     mask_sum = int(pair.get_inlier_mask().sum())
+    traffic = None                  # HBM bytes per launch, from the committed rocprofv3 PMC passes
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
+            t = json.load(f)["ransac_score_waves"]
+        if t["matches"] == n and t["hypotheses"] == S.shard_range(H, rank, world)[1]:
+            traffic = 1024.0 * (t["fetch_kb"] + t["write_kb"])
+    except (OSError, KeyError, ValueError):
+        pass
     if rank == 0:
         local_hyps = S.shard_range(H, rank, world)[1]
         score_s = score_ms / 1e3 / max(calls, 1)
@@ -138,7 +146,7 @@ def main():
             "roofline": {"bound": "mfma", "bound_detail": "FP32 VALU (v_pk_fma_f32); its 157.3 TFLOP/s peak equals the dense f32 MFMA peak",
                          "kernel": "ransac_score_waves", "achieved": achieved,
                          "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_PEAK_TFLOPS,
-                         "traffic": None,
+                         "traffic": traffic,
                          "flop_per_launch": flops, "avg_launch_ms": 1e3 * score_s,
                          "solve_kernel_avg_ms": 1e3 * solve_s,
                          "pipeline_frac": (float(local_hyps) * (FLOP_PER_HYP + FLOP_PER_POINT * n)) /

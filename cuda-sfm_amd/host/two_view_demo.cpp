@@ -3,7 +3,7 @@
 //   computePosecandidates -> choosePose -> linear_triangulation.
 // SIFT extraction (ExtractSift, OpenCV imread) is outside the hot path, so the two feature sets come
 // from files of raw SiftPoint records:
-//     two_view_demo <sift1.bin> <sift2.bin> <out.bin> [num_hypotheses] [seed] [pose_mode]
+//     two_view_demo <sift1.bin> <sift2.bin> <out.bin> [num_hypotheses] [seed] [pose_mode] [cloud.ply]
 // and everything the pipeline produced is dumped to <out.bin> for the parity test
 // (tests/test_gpu_facade.py).  Plain C++: needs only the facade headers and libsfm_amd.so.
 #include <cstdint>
@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "sfm.h"
+#include "sfm_io.h"
 
 static std::vector<SiftPoint> read_sift(const char *path)
 {
@@ -81,6 +82,10 @@ int main(int argc, char **argv)
         put(o, &p.score, 1); put(o, &p.ambiguity, 1); put(o, &p.match, 1); put(o, &p.match_xpos, 1); put(o, &p.match_ypos, 1);
     }
     std::fclose(o);
+    if (argc > 7) {                                         // optional point-cloud sink (replaces the GL viewer)
+        const int written = WritePLY(argv[7], pts.data(), n, mask.data());
+        std::printf("two_view_demo: wrote %d inlier points to %s\n", written, argv[7]);
+    }
     std::printf("two_view_demo: %d x %d features, %d hypotheses, best hypothesis %u with %u inliers, pose %d\n",
                 n, siftData2.numPts, H, hyp, cnt, pind);
     FreeSiftData(siftData1);
