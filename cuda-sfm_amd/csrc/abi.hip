@@ -240,6 +240,7 @@ int sfm_pair_create(sfm_ctx *ctx, const float h_K[9], const float h_Kinv[9], int
     p->image_count = image_count;
     p->n = num_points;
     p->ld = round_up(num_points, 128);
+    memcpy(p->h_Kinv, h_Kinv, sizeof(p->h_Kinv));
     int rc = SFM_OK;
     auto A = [&](auto **ptr, size_t count) { if (rc == SFM_OK) rc = dev_alloc(ptr, count); };
     A(&p->d_K, 9); A(&p->d_Kinv, 9);
@@ -276,7 +277,12 @@ int sfm_fill_xu(sfm_pair *pair, const sfm_sift_point *d_data)
     SFM_REQUIRE(pair && d_data, SFM_E_INVALID, "null argument");
     SFM_HIP_TRY(hipSetDevice(pair->ctx->device));
     int rc = launch_fill_xu(pair, d_data);
-    if (rc == SFM_OK) { pair->have_points = true; pair->have_E = pair->have_P = pair->have_pose = false; pair->last_count = 0; }
+    if (rc == SFM_OK) {
+        pair->have_points = true; pair->have_E = pair->have_P = pair->have_pose = false; pair->last_count = 0;
+        // X_z = fma(Kinv[8], 1, fma(Kinv[7], y, Kinv[6] * x)) is exactly 1 for finite pixel coordinates when
+        // the last row of K^-1 is (0 0 1): the scoring kernel may then drop z (ransac_device.hpp)
+        pair->unit_z = pair->h_Kinv[6] == 0.0f && pair->h_Kinv[7] == 0.0f && pair->h_Kinv[8] == 1.0f;
+    }
     return rc;
 }
 
@@ -285,7 +291,7 @@ int sfm_set_points(sfm_pair *pair, const float *d_X0, const float *d_X1)
     SFM_REQUIRE(pair && d_X0 && d_X1, SFM_E_INVALID, "null argument");
     SFM_HIP_TRY(hipSetDevice(pair->ctx->device));
     int rc = launch_set_points(pair, d_X0, d_X1);
-    if (rc == SFM_OK) { pair->have_points = true; pair->have_E = pair->have_P = pair->have_pose = false; pair->last_count = 0; }
+    if (rc == SFM_OK) { pair->have_points = true; pair->have_E = pair->have_P = pair->have_pose = false; pair->last_count = 0; pair->unit_z = false; }
     return rc;
 }
 

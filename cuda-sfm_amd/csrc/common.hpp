@@ -68,6 +68,8 @@ struct sfm_pair {
     const int32_t *cand_indices = nullptr;
     int cand_sweeps = 0;
     bool have_points = false, have_E = false, have_P = false, have_pose = false;
+    bool unit_z = false;               // every X z-coordinate is exactly 1 (fillXU with K^-1 last row (0 0 1))
+    float h_Kinv[9] = {};
     int pose_mode = SFM_POSE_REFERENCE;
     int last_kernel = 0, last_grid = 0, last_block = 0, last_lds = 0;
 };

@@ -518,12 +518,13 @@ struct Ess { float e0, e1, e2, e3, e4, e5, e6, e7, e8; };
 
 SFM_HD float residual(const Ess &E, float x1x, float x1y, float x1z, float x2x, float x2y, float x2z)
 {
-    const float a0 = fmaf(E.e2, x2z, fmaf(E.e1, x2y, E.e0 * x2x));
-    const float a1 = fmaf(E.e5, x2z, fmaf(E.e4, x2y, E.e3 * x2x));
-    const float a2 = fmaf(E.e8, x2z, fmaf(E.e7, x2y, E.e6 * x2x));
-    const float b0 = fmaf(E.e6, x1z, fmaf(E.e3, x1y, E.e0 * x1x));
-    const float b1 = fmaf(E.e7, x1z, fmaf(E.e4, x1y, E.e1 * x1x));
-    const float nn = fmaf(x1z, a2, fmaf(x1y, a1, x1x * a0));
+    // z term innermost: with z == 1 the product E*1 is exact, so the unit-z kernels skip it (same bits)
+    const float a0 = fmaf(E.e1, x2y, fmaf(E.e0, x2x, E.e2 * x2z));
+    const float a1 = fmaf(E.e4, x2y, fmaf(E.e3, x2x, E.e5 * x2z));
+    const float a2 = fmaf(E.e7, x2y, fmaf(E.e6, x2x, E.e8 * x2z));
+    const float b0 = fmaf(E.e3, x1y, fmaf(E.e0, x1x, E.e6 * x1z));
+    const float b1 = fmaf(E.e4, x1y, fmaf(E.e1, x1x, E.e7 * x1z));
+    const float nn = fmaf(x1y, a1, fmaf(x1x, a0, a2 * x1z));
     const float n2 = nn * nn;
     const float da = fmaf(a1, a1, a0 * a0);
     const float db = fmaf(b1, b1, b0 * b0);
@@ -569,12 +570,13 @@ SFM_HD uint32_t f32_bits(float x)
 SFM_HD bool inlier_filter(const Ess &E, const ThrBand &band, float x1x, float x1y, float x1z,
                           float x2x, float x2y, float x2z, bool &undecided)
 {
-    const float a0 = fmaf(E.e2, x2z, fmaf(E.e1, x2y, E.e0 * x2x));
-    const float a1 = fmaf(E.e5, x2z, fmaf(E.e4, x2y, E.e3 * x2x));
-    const float a2 = fmaf(E.e8, x2z, fmaf(E.e7, x2y, E.e6 * x2x));
-    const float b0 = fmaf(E.e6, x1z, fmaf(E.e3, x1y, E.e0 * x1x));
-    const float b1 = fmaf(E.e7, x1z, fmaf(E.e4, x1y, E.e1 * x1x));
-    const float nn = fmaf(x1z, a2, fmaf(x1y, a1, x1x * a0));
+    // z term innermost: with z == 1 the product E*1 is exact, so the unit-z kernels skip it (same bits)
+    const float a0 = fmaf(E.e1, x2y, fmaf(E.e0, x2x, E.e2 * x2z));
+    const float a1 = fmaf(E.e4, x2y, fmaf(E.e3, x2x, E.e5 * x2z));
+    const float a2 = fmaf(E.e7, x2y, fmaf(E.e6, x2x, E.e8 * x2z));
+    const float b0 = fmaf(E.e3, x1y, fmaf(E.e0, x1x, E.e6 * x1z));
+    const float b1 = fmaf(E.e4, x1y, fmaf(E.e1, x1x, E.e7 * x1z));
+    const float nn = fmaf(x1y, a1, fmaf(x1x, a0, a2 * x1z));
     const float n2 = nn * nn;
     const float da = fmaf(a1, a1, a0 * a0);
     const float db = fmaf(b1, b1, b0 * b0);

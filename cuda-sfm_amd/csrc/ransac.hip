@@ -60,7 +60,7 @@ void ransac_solve_lanes2(const float *__restrict__ X0, const float *__restrict__
 // ------------------------------------------------------------------------------------------
 // SPLIT step 2: one hypothesis per wavefront, points in LDS
 // ------------------------------------------------------------------------------------------
-template <int WPB>
+template <int WPB, bool UNITZ>
 __global__ __launch_bounds__(WPB * 64, 8)
 void ransac_score_waves(const float *__restrict__ X0, const float *__restrict__ X1, int ld, int n,
                         const float *__restrict__ Ecand, uint32_t h0, uint32_t count, float thr,
@@ -88,11 +88,11 @@ void ransac_score_waves(const float *__restrict__ X0, const float *__restrict__ 
             if (ntiles > 1 || !staged) {
                 if (staged) __syncthreads();                  // everyone done with the previous tile
                 const int first = t * tile;
-                stage_tile(lds, X0, X1, ld, first, min(tile, ld - first));
+                stage_tile<UNITZ>(lds, X0, X1, ld, first, min(tile, ld - first));
                 __syncthreads();
                 staged = true;
             }
-            if (valid) cnt += score_tile(E, lds, min(tile, ld - t * tile), min(tile, n - t * tile), band, lane);
+            if (valid) cnt += score_tile<UNITZ>(E, lds, min(tile, n - t * tile), band, lane);
         }
         if (valid) {
             if (lane == 0) counts[i] = cnt;
@@ -101,8 +101,8 @@ void ransac_score_waves(const float *__restrict__ X0, const float *__restrict__ 
         }
     }
     // one atomic per block (first-maximum tie rule is encoded in the key)
-    unsigned long long *sbest = reinterpret_cast<unsigned long long *>(lds + 6 * (size_t)tile);
     __syncthreads();
+    unsigned long long *sbest = reinterpret_cast<unsigned long long *>(lds);       // tile no longer needed
     if (lane == 0) sbest[wave] = wbest;
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -151,16 +151,16 @@ static int ensure_hyp_capacity(sfm_pair *pair, size_t count)
     return SFM_OK;
 }
 
-template <int WPB>
+template <int WPB, bool UNITZ>
 static int launch_score_t(sfm_pair *pair, uint32_t h0, uint32_t count, float thr, int tile, int ntiles, int grid, size_t lds)
 {
     static bool attr_set = false;
     if (!attr_set) {
-        SFM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&ransac_score_waves<WPB>),
+        SFM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&ransac_score_waves<WPB, UNITZ>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL(ransac_score_waves<WPB>, dim3(grid), dim3(WPB * 64), lds, pair->ctx->stream,
+    hipLaunchKernelGGL((ransac_score_waves<WPB, UNITZ>), dim3(grid), dim3(WPB * 64), lds, pair->ctx->stream,
                        pair->d_X[0], pair->d_X[1], pair->ld, pair->n, pair->d_Ecand, h0, count, thr, tile, ntiles,
                        pair->d_counts, pair->d_key);
     SFM_HIP_TRY(hipGetLastError());
@@ -206,7 +206,9 @@ int launch_ransac_score(sfm_pair *pair, const sfm_ransac_params &p, uint32_t h0,
     int wpb = 16;
     while (wpb > 4 && (count + wpb - 1) / wpb < (uint32_t)ctx->num_cus) wpb >>= 1;
     const uint32_t nbatch = (count + wpb - 1) / wpb;
-    const size_t lds = (size_t)6 * tile * sizeof(float) + 16 * sizeof(unsigned long long);
+    // unit-z layout: fixed 64 KiB (two arrays of kTileMax/2 pair records); generic: 24 B per point
+    const bool uz = pair->unit_z;
+    const size_t lds = uz ? (size_t)2 * kUnitZSecond : (size_t)6 * tile * sizeof(float) + 16 * sizeof(unsigned long long);
     // persistent blocks: as many as are co-resident (LDS and the 2048-thread CU limit)
     int per_cu = (int)((160 * 1024) / lds);
     if (per_cu > 2048 / (wpb * 64)) per_cu = 2048 / (wpb * 64);
@@ -214,10 +216,15 @@ int launch_ransac_score(sfm_pair *pair, const sfm_ransac_params &p, uint32_t h0,
     const uint32_t resident = (uint32_t)ctx->num_cus * (uint32_t)per_cu;
     const int grid = (int)(nbatch < resident ? nbatch : resident);
     if (kernel == SFM_KERNEL_MFMA) rc = launch_score_mfma(pair, p, h0, count);
+    else if (uz) switch (wpb) {
+    case 16: rc = launch_score_t<16, true>(pair, h0, count, p.threshold, tile, ntiles, grid, lds); break;
+    case 8:  rc = launch_score_t<8, true>(pair, h0, count, p.threshold, tile, ntiles, grid, lds); break;
+    default: rc = launch_score_t<4, true>(pair, h0, count, p.threshold, tile, ntiles, grid, lds); break;
+    }
     else switch (wpb) {
-    case 16: rc = launch_score_t<16>(pair, h0, count, p.threshold, tile, ntiles, grid, lds); break;
-    case 8:  rc = launch_score_t<8>(pair, h0, count, p.threshold, tile, ntiles, grid, lds); break;
-    default: rc = launch_score_t<4>(pair, h0, count, p.threshold, tile, ntiles, grid, lds); break;
+    case 16: rc = launch_score_t<16, false>(pair, h0, count, p.threshold, tile, ntiles, grid, lds); break;
+    case 8:  rc = launch_score_t<8, false>(pair, h0, count, p.threshold, tile, ntiles, grid, lds); break;
+    default: rc = launch_score_t<4, false>(pair, h0, count, p.threshold, tile, ntiles, grid, lds); break;
     }
     if (rc == SFM_OK && timed) {
         SFM_HIP_TRY(hipEventRecord(tev[2], ctx->stream));

@@ -63,12 +63,20 @@ __device__ __forceinline__ void solve_two(const float *__restrict__ X0, const fl
     normalize_E(E);
 }
 
-// LDS tile layout: one 48-byte record per PAIR of points (2j, 2j+1):
-//     [x1x.a x1x.b x1y.a x1y.b | x1z.a x1z.b x2x.a x2x.b | x2y.a x2y.b x2z.a x2z.b]
-// so a lane fetches its two points with three ds_read_b128 at immediate offsets 0/16/32 from one
-// address register, and every coordinate arrives as a (point a, point b) float2 that feeds
-// v_pk_fma_f32 directly -- no register shuffles.  Record stride 12 dwords => the 16 lanes of each
-// ds_read_b128 group (and the 8 lanes of each ds_write_b128 group) touch disjoint banks.
+// LDS tile layouts (PAIR of points 2j, 2j+1 per record, so every coordinate arrives as a
+// (point a, point b) float2 that feeds v_pk_fma_f32 directly -- no register shuffles):
+//   generic   one 48-byte record [x1x.a x1x.b x1y.a x1y.b | x1z.a x1z.b x2x.a x2x.b | x2y.a x2y.b x2z.a x2z.b]
+//             -> three ds_read_b128 at immediate offsets 0/16/32; record stride 12 dwords puts the 16
+//             lanes of each read group (and the 8 lanes of each write group) on disjoint banks.
+//   unit z    homogeneous z == 1 for every point (always the case after fillXU with a K^-1 whose last row
+//             is (0 0 1)): z is not stored.  Two arrays of 16-byte records, [x1x.a x1x.b x1y.a x1y.b] at
+//             byte 0 and [x2x.a x2x.b x2y.a x2y.b] at the fixed byte offset kUnitZSecond -> two conflict-free
+//             ds_read_b128 from one address register; 64 KiB per 4096 points instead of 96, so two
+//             1024-thread blocks share a CU.
+typedef float v2f __attribute__((ext_vector_type(2)));
+constexpr int kUnitZSecond = kTileMax / 2 * 16;      // bytes: array 2 starts after kTileMax/2 pair records
+
+template <bool UNITZ>
 __device__ __forceinline__ void stage_tile(float *lds, const float *__restrict__ X0,
                                            const float *__restrict__ X1, int ld, int first, int len)
 {
@@ -81,33 +89,80 @@ __device__ __forceinline__ void stage_tile(float *lds, const float *__restrict__
     const float2 *r5 = reinterpret_cast<const float2 *>(X1 + 2 * (size_t)ld + first);
     float4 *dst = reinterpret_cast<float4 *>(lds);
     for (int k = threadIdx.x; k < npair; k += blockDim.x) {
-        const float2 a = r0[k], b = r1[k], c = r2[k], d = r3[k], e = r4[k], f = r5[k];
-        dst[3 * k + 0] = make_float4(a.x, a.y, b.x, b.y);
-        dst[3 * k + 1] = make_float4(c.x, c.y, d.x, d.y);
-        dst[3 * k + 2] = make_float4(e.x, e.y, f.x, f.y);
+        const float2 a = r0[k], b = r1[k], d = r3[k], e = r4[k];
+        if (UNITZ) {
+            dst[k] = make_float4(a.x, a.y, b.x, b.y);
+            dst[kUnitZSecond / 16 + k] = make_float4(d.x, d.y, e.x, e.y);
+        } else {
+            const float2 c = r2[k], f = r5[k];
+            dst[3 * k + 0] = make_float4(a.x, a.y, b.x, b.y);
+            dst[3 * k + 1] = make_float4(c.x, c.y, d.x, d.y);
+            dst[3 * k + 2] = make_float4(e.x, e.y, f.x, f.y);
+        }
     }
 }
 
 __device__ __forceinline__ v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ v2f splat(float s) { return v2f{ s, s }; }
 
+// The pair of points a lane scores in one iteration.
+struct PairPts { v2f x1x, x1y, x1z, x2x, x2y, x2z; };
+
+template <bool UNITZ>
+__device__ __forceinline__ PairPts load_pair(const float4 *rec)
+{
+    PairPts p;
+    if (UNITZ) {
+        const float4 q0 = rec[0], q1 = rec[kUnitZSecond / 16];
+        p.x1x = v2f{ q0.x, q0.y }; p.x1y = v2f{ q0.z, q0.w };
+        p.x2x = v2f{ q1.x, q1.y }; p.x2y = v2f{ q1.z, q1.w };
+        p.x1z = splat(1.0f); p.x2z = splat(1.0f);
+    } else {
+        const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
+        p.x1x = v2f{ q0.x, q0.y }; p.x1y = v2f{ q0.z, q0.w }; p.x1z = v2f{ q1.x, q1.y };
+        p.x2x = v2f{ q1.z, q1.w }; p.x2y = v2f{ q2.x, q2.y }; p.x2z = v2f{ q2.z, q2.w };
+    }
+    return p;
+}
+
 // Two points per lane through the division-free filter (device_math.hpp inlier_filter, same
-// arithmetic element for element).  Only the two "m < tp" compares go to the scalar unit; the
-// undecided test is carried per lane as running integer min / max (VALU only) and inspected once
-// per tile: gap_min = smallest |bits(m) - bits(tp)| seen, tb_min / tb_max = range of bits(tp).
+// arithmetic element for element; with UNITZ the exact products E*1 and a2*1 are skipped).  Only the
+// two "m < tp" compares go to the scalar unit; the undecided test is carried per lane as running
+// integer min / max (VALU only) and inspected once per tile: gap_min = smallest
+// |bits(m) - bits(tp)| seen, tb_min / tb_max = range of bits(tp).
 struct FilterAcc { uint32_t gap_min, tb_min, tb_max; };
 
-__device__ __forceinline__ void filter_pair(const Ess &E, float thr, const float4 q0, const float4 q1, const float4 q2,
+// Addends of the unit-z chains (E2 E5 E8 E6 E7) as VGPR pairs: a VALU instruction may read only one
+// SGPR, so fma(E0 (sgpr), x, E2) needs E2 in a VGPR; kept loop-invariant instead of re-materialised.
+struct EssAddends { v2f c2, c5, c8, c6, c7; };
+
+__device__ __forceinline__ EssAddends make_addends(const Ess &E)
+{
+    EssAddends a{ splat(E.e2), splat(E.e5), splat(E.e8), splat(E.e6), splat(E.e7) };
+    asm volatile("" : "+v"(a.c2), "+v"(a.c5), "+v"(a.c8), "+v"(a.c6), "+v"(a.c7));
+    return a;
+}
+
+template <bool UNITZ>
+__device__ __forceinline__ void filter_pair(const Ess &E, const EssAddends &ad, float thr, const PairPts &p,
                                             unsigned long long &in_a, unsigned long long &in_b, FilterAcc &acc)
 {
-    const v2f x1x{ q0.x, q0.y }, x1y{ q0.z, q0.w }, x1z{ q1.x, q1.y };
-    const v2f x2x{ q1.z, q1.w }, x2y{ q2.x, q2.y }, x2z{ q2.z, q2.w };
-    const v2f a0 = fma2(splat(E.e2), x2z, fma2(splat(E.e1), x2y, splat(E.e0) * x2x));
-    const v2f a1 = fma2(splat(E.e5), x2z, fma2(splat(E.e4), x2y, splat(E.e3) * x2x));
-    const v2f a2 = fma2(splat(E.e8), x2z, fma2(splat(E.e7), x2y, splat(E.e6) * x2x));
-    const v2f b0 = fma2(splat(E.e6), x1z, fma2(splat(E.e3), x1y, splat(E.e0) * x1x));
-    const v2f b1 = fma2(splat(E.e7), x1z, fma2(splat(E.e4), x1y, splat(E.e1) * x1x));
-    const v2f nn = fma2(x1z, a2, fma2(x1y, a1, x1x * a0));
+    v2f a0, a1, a2, b0, b1, nn;
+    if (UNITZ) {
+        a0 = fma2(splat(E.e1), p.x2y, fma2(splat(E.e0), p.x2x, ad.c2));
+        a1 = fma2(splat(E.e4), p.x2y, fma2(splat(E.e3), p.x2x, ad.c5));
+        a2 = fma2(splat(E.e7), p.x2y, fma2(splat(E.e6), p.x2x, ad.c8));
+        b0 = fma2(splat(E.e3), p.x1y, fma2(splat(E.e0), p.x1x, ad.c6));
+        b1 = fma2(splat(E.e4), p.x1y, fma2(splat(E.e1), p.x1x, ad.c7));
+        nn = fma2(p.x1y, a1, fma2(p.x1x, a0, a2));
+    } else {
+        a0 = fma2(splat(E.e1), p.x2y, fma2(splat(E.e0), p.x2x, splat(E.e2) * p.x2z));
+        a1 = fma2(splat(E.e4), p.x2y, fma2(splat(E.e3), p.x2x, splat(E.e5) * p.x2z));
+        a2 = fma2(splat(E.e7), p.x2y, fma2(splat(E.e6), p.x2x, splat(E.e8) * p.x2z));
+        b0 = fma2(splat(E.e3), p.x1y, fma2(splat(E.e0), p.x1x, splat(E.e6) * p.x1z));
+        b1 = fma2(splat(E.e4), p.x1y, fma2(splat(E.e1), p.x1x, splat(E.e7) * p.x1z));
+        nn = fma2(p.x1y, a1, fma2(p.x1x, a0, a2 * p.x1z));
+    }
     const v2f n2 = nn * nn;
     const v2f da = fma2(a1, a1, a0 * a0);
     const v2f db = fma2(b1, b1, b0 * b0);
@@ -125,31 +180,30 @@ __device__ __forceinline__ void filter_pair(const Ess &E, float thr, const float
     acc.tb_max = max(acc.tb_max, max(txb, tyb));
 }
 
-// `len` = staged points of this tile (multiple of 128, NaN beyond the real data), `nvalid` = real
-// points in it.  Full 128-point iterations run unmasked; a ragged last iteration masks the padding
-// lanes out of the count and out of the undecided trackers (padding must not force the exact path).
-__device__ __forceinline__ int score_tile(const Ess &E, const float *lds, int len, int nvalid, const ThrBand &band, int lane)
+// `nvalid` = real points in the staged tile (the rest is NaN padding up to a multiple of 128).  Full
+// 128-point iterations run unmasked; a ragged last iteration masks the padding lanes out of the count
+// and out of the undecided trackers (padding must not force the exact path).
+template <bool UNITZ>
+__device__ __forceinline__ int score_tile(const Ess &E, const float *lds, int nvalid, const ThrBand &band, int lane)
 {
-    const float4 *rec0 = reinterpret_cast<const float4 *>(lds) + 3 * lane;
+    constexpr int kRec = UNITZ ? 1 : 3;         // float4 per pair record in the first array
+    const float4 *rec0 = reinterpret_cast<const float4 *>(lds) + kRec * lane;
     const int full = nvalid >> 7;               // iterations with all 128 points real
     int cnt = 0;
     FilterAcc acc{ 0xFFFFFFFFu, 0xFFFFFFFFu, 0u };
+    const EssAddends ad = make_addends(E);
     const float4 *rec = rec0;
-    for (int it = 0; it < full; ++it, rec += 3 * 64) {
-        const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
+    for (int it = 0; it < full; ++it, rec += kRec * 64) {
         unsigned long long in_a, in_b;
-        filter_pair(E, band.thr, q0, q1, q2, in_a, in_b, acc);
+        filter_pair<UNITZ>(E, ad, band.thr, load_pair<UNITZ>(rec), in_a, in_b, acc);
         cnt += __builtin_popcountll(in_a) + __builtin_popcountll(in_b);
     }
     const int rest = nvalid - (full << 7);      // 0..127 real points in the ragged iteration
-    unsigned long long va = 0, vb = 0;
     if (rest > 0) {
-        va = __ballot(2 * lane < rest);
-        vb = __ballot(2 * lane + 1 < rest);
-        const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
+        const unsigned long long va = __ballot(2 * lane < rest), vb = __ballot(2 * lane + 1 < rest);
         unsigned long long in_a, in_b;
         FilterAcc t{ 0xFFFFFFFFu, 0xFFFFFFFFu, 0u };
-        filter_pair(E, band.thr, q0, q1, q2, in_a, in_b, t);
+        filter_pair<UNITZ>(E, ad, band.thr, load_pair<UNITZ>(rec), in_a, in_b, t);
         // trackers of padding lanes are discarded; a lane holding one real and one padding point
         // keeps them (NaN padding then reads as "undecided", which is merely conservative)
         if (2 * lane < rest) {
@@ -166,14 +220,13 @@ __device__ __forceinline__ int score_tile(const Ess &E, const float *lds, int le
         cnt = 0;
         rec = rec0;
         const int iters = (nvalid + 127) >> 7;
-        for (int it = 0; it < iters; ++it, rec += 3 * 64) {
-            const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
-            const bool ea = residual(E, q0.x, q0.z, q1.x, q1.z, q2.x, q2.z) < band.thr;   // NaN padding never counts
-            const bool eb = residual(E, q0.y, q0.w, q1.y, q1.w, q2.y, q2.w) < band.thr;
+        for (int it = 0; it < iters; ++it, rec += kRec * 64) {
+            const PairPts p = load_pair<UNITZ>(rec);
+            const bool ea = residual(E, p.x1x.x, p.x1y.x, p.x1z.x, p.x2x.x, p.x2y.x, p.x2z.x) < band.thr;   // NaN padding never counts
+            const bool eb = residual(E, p.x1x.y, p.x1y.y, p.x1z.y, p.x2x.y, p.x2y.y, p.x2z.y) < band.thr;
             cnt += __builtin_popcountll(__ballot(ea)) + __builtin_popcountll(__ballot(eb));
         }
     }
-    (void)len;
     return cnt;
 }
 

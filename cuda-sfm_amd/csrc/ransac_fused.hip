@@ -163,11 +163,11 @@ void ransac_fused_waves(const float *__restrict__ X0, const float *__restrict__ 
             if (ntiles > 1 || !staged) {
                 if (staged) __syncthreads();
                 const int first = t * tile;
-                stage_tile(lds, X0, X1, ld, first, min(tile, ld - first));
+                stage_tile<false>(lds, X0, X1, ld, first, min(tile, ld - first));
                 __syncthreads();
                 staged = true;
             }
-            if (valid) cnt += score_tile(E, lds, min(tile, ld - t * tile), min(tile, n - t * tile), band, lane);
+            if (valid) cnt += score_tile<false>(E, lds, min(tile, n - t * tile), band, lane);
         }
         if (valid) {
             if (lane == 0) counts[i] = cnt;

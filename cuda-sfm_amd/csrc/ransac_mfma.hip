@@ -6,8 +6,8 @@
 //     a_i[h][p] = sum_k E_h[i][k] x2[k][p]   (i = 0,1,2)      b_j[h][p] = sum_k E_h[k][j] x1[k][p]   (j = 0,1)
 // are five 32x32 outer-product tiles with K = 3, i.e. 2 x v_mfma_f32_32x32x2_f32 each (K padded to 4
 // with a (-0.0, +0.0) pair, which leaves every accumulator bit untouched).  One MFMA adds k = 0 then
-// k = 1 with a single rounding per product, so a_i and b_j are exactly the k-ordered fmaf chains of the
-// oracle (orc_residual) -- bit for bit.  The rest (n = x1.a, n^2, da, db and the division-free inlier
+// k = 1 with a single rounding per product, so with k ordered (z, x, y) a_i and b_j are exactly the
+// fmaf chains of the oracle (orc_residual: z term innermost) -- bit for bit.  The rest (n = x1.a, n^2, da, db and the division-free inlier
 // filter) runs on the VALU straight out of the accumulators, two hypotheses per v_pk_*_f32 (adjacent
 // accumulator registers are adjacent hypotheses of the same point).
 //
@@ -61,8 +61,9 @@ __device__ __forceinline__ void issue_group(const float (&A1)[5], const float (&
 {
     g.x1x = r0[p]; g.x1y = r1[p]; g.x1z = r2[p];
     const float x2x = r3[p], x2y = r4[p], x2z = r5[p];
-    const float bA1 = half ? x2y : x2x, bA2 = half ? 0.0f : x2z;      // k = 1 | 0, k = 3 (pad) | 2
-    const float bB1 = half ? g.x1y : g.x1x, bB2 = half ? 0.0f : g.x1z;
+    // k order of the oracle's chain: z (innermost product), x, y, then the (-0, +0) pad
+    const float bA1 = half ? x2x : x2z, bA2 = half ? 0.0f : x2y;      // k = 1 | 0, k = 3 (pad) | 2
+    const float bB1 = half ? g.x1x : g.x1z, bB2 = half ? 0.0f : g.x1y;
 #pragma unroll
     for (int o = 0; o < 5; ++o) {
         const f32x16 zero = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
@@ -83,7 +84,7 @@ __device__ __forceinline__ void finish_group(const GroupAcc &g, float thr, bool 
         const v2f a0{ g.acc[0][2 * rp], g.acc[0][2 * rp + 1] }, a1{ g.acc[1][2 * rp], g.acc[1][2 * rp + 1] };
         const v2f a2{ g.acc[2][2 * rp], g.acc[2][2 * rp + 1] };
         const v2f b0{ g.acc[3][2 * rp], g.acc[3][2 * rp + 1] }, b1{ g.acc[4][2 * rp], g.acc[4][2 * rp + 1] };
-        const v2f nn = fma2(sz, a2, fma2(sy, a1, sx * a0));
+        const v2f nn = fma2(sy, a1, fma2(sx, a0, a2 * sz));
         const v2f n2 = nn * nn;
         const v2f da = fma2(a1, a1, a0 * a0);
         const v2f db = fma2(b1, b1, b0 * b0);
@@ -162,8 +163,9 @@ void ransac_score_mfma(const float *__restrict__ X0, const float *__restrict__ X
 #pragma unroll
         for (int k = 0; k < 9; ++k) e[k] = (wvalid && hi < count) ? Ecand[9 * (size_t)hi + k] : 0.0f;
         const float npad = -0.0f;                            // (-0) * (+0) = -0: x + (-0) == x for every x, also -0
-        const float A1[5] = { half ? e[1] : e[0], half ? e[4] : e[3], half ? e[7] : e[6], half ? e[3] : e[0], half ? e[4] : e[1] };
-        const float A2[5] = { half ? npad : e[2], half ? npad : e[5], half ? npad : e[8], half ? npad : e[6], half ? npad : e[7] };
+        // a_i: k = (z, x, y) -> E[3i+2], E[3i], E[3i+1];   b_j: k = (z, x, y) -> E[6+j], E[j], E[3+j]
+        const float A1[5] = { half ? e[0] : e[2], half ? e[3] : e[5], half ? e[6] : e[8], half ? e[0] : e[6], half ? e[1] : e[7] };
+        const float A2[5] = { half ? npad : e[1], half ? npad : e[4], half ? npad : e[7], half ? npad : e[3], half ? npad : e[4] };
         MfmaState st;
 #pragma unroll
         for (int j = 0; j < 16; ++j) st.cnt[j] = 0;

@@ -454,12 +454,14 @@ void orc_normalizeE(float E[9])
 float orc_residual(const float E[9], float x1x, float x1y, float x1z,
                    float x2x, float x2y, float x2z)
 {
-    float a0 = fmaf(E[2], x2z, fmaf(E[1], x2y, E[0] * x2x));
-    float a1 = fmaf(E[5], x2z, fmaf(E[4], x2y, E[3] * x2x));
-    float a2 = fmaf(E[8], x2z, fmaf(E[7], x2y, E[6] * x2x));
-    float b0 = fmaf(E[6], x1z, fmaf(E[3], x1y, E[0] * x1x));
-    float b1 = fmaf(E[7], x1z, fmaf(E[4], x1y, E[1] * x1x));
-    float nn = fmaf(x1z, a2, fmaf(x1y, a1, x1x * a0));
+    /* z term innermost: with homogeneous z == 1 (always true after fillXU) E[.]*1 is exact, so a
+     * kernel may skip that multiplication and still produce these very bits */
+    float a0 = fmaf(E[1], x2y, fmaf(E[0], x2x, E[2] * x2z));
+    float a1 = fmaf(E[4], x2y, fmaf(E[3], x2x, E[5] * x2z));
+    float a2 = fmaf(E[7], x2y, fmaf(E[6], x2x, E[8] * x2z));
+    float b0 = fmaf(E[3], x1y, fmaf(E[0], x1x, E[6] * x1z));
+    float b1 = fmaf(E[4], x1y, fmaf(E[1], x1x, E[7] * x1z));
+    float nn = fmaf(x1y, a1, fmaf(x1x, a0, a2 * x1z));
     float n2 = nn * nn;
     float da = fmaf(a1, a1, a0 * a0);
     float db = fmaf(b1, b1, b0 * b0);

@@ -102,12 +102,12 @@ def oracle_terms(E, X0, X1):
     E = E.astype(f)
     x1x, x1y, x1z = X0[0], X0[1], X0[2]
     x2x, x2y, x2z = X1[0], X1[1], X1[2]
-    a0 = fma(np.full_like(x2z, E[2]), x2z, fma(np.full_like(x2y, E[1]), x2y, (E[0] * x2x).astype(f)))
-    a1 = fma(np.full_like(x2z, E[5]), x2z, fma(np.full_like(x2y, E[4]), x2y, (E[3] * x2x).astype(f)))
-    a2 = fma(np.full_like(x2z, E[8]), x2z, fma(np.full_like(x2y, E[7]), x2y, (E[6] * x2x).astype(f)))
-    b0 = fma(np.full_like(x1z, E[6]), x1z, fma(np.full_like(x1y, E[3]), x1y, (E[0] * x1x).astype(f)))
-    b1 = fma(np.full_like(x1z, E[7]), x1z, fma(np.full_like(x1y, E[4]), x1y, (E[1] * x1x).astype(f)))
-    nn = fma(x1z, a2, fma(x1y, a1, (x1x * a0).astype(f)))
+    a0 = fma(np.full_like(x2y, E[1]), x2y, fma(np.full_like(x2x, E[0]), x2x, (E[2] * x2z).astype(f)))
+    a1 = fma(np.full_like(x2y, E[4]), x2y, fma(np.full_like(x2x, E[3]), x2x, (E[5] * x2z).astype(f)))
+    a2 = fma(np.full_like(x2y, E[7]), x2y, fma(np.full_like(x2x, E[6]), x2x, (E[8] * x2z).astype(f)))
+    b0 = fma(np.full_like(x1y, E[3]), x1y, fma(np.full_like(x1x, E[0]), x1x, (E[6] * x1z).astype(f)))
+    b1 = fma(np.full_like(x1y, E[4]), x1y, fma(np.full_like(x1x, E[1]), x1x, (E[7] * x1z).astype(f)))
+    nn = fma(x1y, a1, fma(x1x, a0, (a2 * x1z).astype(f)))
     return (nn * nn).astype(f), fma(a1, a1, (a0 * a0).astype(f)), fma(b1, b1, (b0 * b0).astype(f))
 
 
