@@ -411,42 +411,56 @@ SFM_HD void jacobi9_round(T (&S)[45], T (&V)[81])
             sg[i] = -ss; sg[j] = ss;
         }
     }
-    // S <- J^T S J, one 2x2 block (pair a x pair b) at a time, in place
+    // S <- J^T S J, one block (group a x group b, groups ordered by their smaller index) at a time, in
+    // place: T = S_blk J_b (column rotation), S'_blk = J_a^T T (row rotation); the rotation of the idle
+    // index is the identity and is skipped.  Same expressions as orc_jacobi9.
 #pragma unroll
     for (int a = 0; a < 9; ++a) {
         const int ra = (R + 9 - a) % 9;
-        if (ra >= a) {
+        if (ra >= a) {                                    // a leads its group {a, ra} (ra == a: idle index)
+            // own diagonal block of a pair
+            if (ra > a) {
+                const T Taa = fma_t(S[sym9(a, ra)], sg[a], S[sym9(a, a)] * c[a]);
+                const T Tar = fma_t(S[sym9(a, a)], sg[ra], S[sym9(a, ra)] * c[ra]);
+                const T Tra = fma_t(S[sym9(ra, ra)], sg[a], S[sym9(ra, a)] * c[a]);
+                const T Trr = fma_t(S[sym9(ra, a)], sg[ra], S[sym9(ra, ra)] * c[ra]);
+                S[sym9(a, a)]   = fma_t(sg[a], Tra, c[a] * Taa);
+                S[sym9(a, ra)]  = fma_t(sg[a], Trr, c[a] * Tar);
+                S[sym9(ra, ra)] = fma_t(sg[ra], Tar, c[ra] * Trr);
+            }
 #pragma unroll
-            for (int b = a; b < 9; ++b) {
+            for (int b = a + 1; b < 9; ++b) {
                 const int rb = (R + 9 - b) % 9;
-                if (rb >= b) {
-                    T nv[2][2];
+                if (rb >= b && b != ra) {                 // b leads another group, later than a's
+                    // T[x][y]: row x in {a, ra}, column y in {b, rb}
+                    T Tm[2][2];
 #pragma unroll
-                    for (int ka = 0; ka < 2; ++ka)
+                    for (int x = 0; x < 2; ++x)
 #pragma unroll
-                        for (int kb = 0; kb < 2; ++kb) {
-                            const int k = ka ? ra : a, l = kb ? rb : b;
-                            const int i = k < l ? k : l, j = k < l ? l : k;       // oracle orientation i <= j
-                            const int ri = (R + 9 - i) % 9, rj = (R + 9 - j) % 9;
-                            const T Tij  = fma_t(S[sym9(i, rj)],  sg[j], S[sym9(i, j)]  * c[j]);
-                            const T Trij = fma_t(S[sym9(ri, rj)], sg[j], S[sym9(ri, j)] * c[j]);
-                            nv[ka][kb] = fma_t(sg[i], Trij, c[i] * Tij);
+                        for (int y = 0; y < 2; ++y) {
+                            const int row = x ? ra : a, col = y ? rb : b, rcol = y ? b : rb;
+                            Tm[x][y] = (rb == b) ? S[sym9(row, col)]
+                                                 : fma_t(S[sym9(row, rcol)], sg[col], S[sym9(row, col)] * c[col]);
                         }
-                    S[sym9(a, b)]   = nv[0][0];
-                    S[sym9(a, rb)]  = nv[0][1];
-                    S[sym9(ra, b)]  = nv[1][0];
-                    S[sym9(ra, rb)] = nv[1][1];
+#pragma unroll
+                    for (int x = 0; x < 2; ++x)
+#pragma unroll
+                        for (int y = 0; y < 2; ++y) {
+                            const int row = x ? ra : a, col = y ? rb : b;
+                            if ((x == 1 && ra == a) || (y == 1 && rb == b)) continue;      // duplicates of an idle index
+                            S[sym9(row, col)] = (ra == a) ? Tm[x][y] : fma_t(sg[row], Tm[1 - x][y], c[row] * Tm[x][y]);
+                        }
                 }
             }
         }
     }
-    // V <- V J
+    // V <- V J (the idle column is untouched)
 #pragma unroll
     for (int i = 0; i < 9; ++i)
 #pragma unroll
         for (int b = 0; b < 9; ++b) {
             const int rb = (R + 9 - b) % 9;
-            if (rb >= b) {
+            if (rb > b) {
                 const T vb = V[9 * i + b], vr = V[9 * i + rb];
                 V[9 * i + b]  = fma_t(vr, sg[b], vb * c[b]);
                 V[9 * i + rb] = fma_t(vb, sg[rb], vr * c[rb]);

@@ -93,19 +93,36 @@ __device__ __forceinline__ void solve_wave(const float *__restrict__ X0, const f
             wave_sync();
             float nv = 0.0f, v0, v1 = 0.0f;
             if (lane < 45) {
+                // same block-oriented expressions as orc_jacobi9 / jacobi9_round
                 const int ri = (t + 9 - ei) % 9, rj = (t + 9 - ej) % 9;
-                const float cj = cc[ej], sj = sg[ej];
-                const float Tij  = fmaf(S[9 * ei + rj], sj, S[9 * ei + ej] * cj);
-                const float Trij = fmaf(S[9 * ri + rj], sj, S[9 * ri + ej] * cj);
-                nv = fmaf(sg[ei], Trij, cc[ei] * Tij);
+                const int li = ei < ri ? ei : ri, lj = ej < rj ? ej : rj;
+                if (li == lj) {
+                    if (ri == ei) nv = S[10 * ei];                      // idle index: diagonal untouched
+                    else {
+                        const float cj = cc[ej], sj = sg[ej];
+                        const float Tij  = fmaf(S[9 * ei + rj], sj, S[9 * ei + ej] * cj);
+                        const float Trij = fmaf(S[9 * ri + rj], sj, S[9 * ri + ej] * cj);
+                        nv = fmaf(sg[ei], Trij, cc[ei] * Tij);
+                    }
+                } else {
+                    const int rho = li < lj ? ei : ej, kap = li < lj ? ej : ei;
+                    const int rr = (t + 9 - rho) % 9, rk = (t + 9 - kap) % 9;
+                    const float ck = cc[kap], sk = sg[kap];
+                    const float t1 = (rk == kap) ? S[9 * rho + kap] : fmaf(S[9 * rho + rk], sk, S[9 * rho + kap] * ck);
+                    if (rr == rho) nv = t1;
+                    else {
+                        const float t2 = (rk == kap) ? S[9 * rr + kap] : fmaf(S[9 * rr + rk], sk, S[9 * rr + kap] * ck);
+                        nv = fmaf(sg[rho], t2, cc[rho] * t1);
+                    }
+                }
             }
             {
                 const int rb = (t + 9 - vb0) % 9;
-                v0 = fmaf(V[9 * va0 + rb], sg[vb0], V[9 * va0 + vb0] * cc[vb0]);
+                v0 = (rb == vb0) ? V[9 * va0 + vb0] : fmaf(V[9 * va0 + rb], sg[vb0], V[9 * va0 + vb0] * cc[vb0]);
             }
             if (lane < 17) {
                 const int rb = (t + 9 - vb1) % 9;
-                v1 = fmaf(V[9 * va1 + rb], sg[vb1], V[9 * va1 + vb1] * cc[vb1]);
+                v1 = (rb == vb1) ? V[9 * va1 + vb1] : fmaf(V[9 * va1 + rb], sg[vb1], V[9 * va1 + vb1] * cc[vb1]);
             }
             wave_sync();
             if (lane < 45) { S[9 * ei + ej] = nv; S[9 * ej + ei] = nv; }

@@ -387,19 +387,26 @@ static inline void jacobi_cs(float app, float aqq, float apq, float *c, float *s
 }
 
 /* Symmetric eigen-decomposition of the 9x9 normal matrix by parallel-ordered (round-robin)
- * Jacobi: sweep = 9 rounds, round t rotates the 4 disjoint pairs {i, (t - i) mod 9}; all four
- * rotations of a round are computed from the same S and applied as one orthogonal J:
- *     T = S J ; S <- J^T T ; V <- V J.
+ * Jacobi: sweep = 9 rounds, round t rotates the 4 disjoint pairs {i, (t - i) mod 9} (one index sits
+ * out); all four rotations of a round are computed from the same S and applied as one orthogonal J,
+ * S <- J^T S J, V <- V J, block by block:
+ *   - an off-diagonal block between two different pairs a < b (ordered by their smaller index) is
+ *     updated as T = S_blk J_b (column rotation of pair b) then S'_blk = J_a^T T (row rotation of a);
+ *   - against the idle index the corresponding rotation is the identity and is skipped;
+ *   - a pair's own 2x2 diagonal block is T = S_blk J, S' = J^T T with S_qp = S_pq.
  * This replaces cusolverDnSgesvdjBatched on the 8x9 A (kernels.h:211-234, closed source). */
 void orc_jacobi9(float S[81], float V[81], int sweeps)
 {
-    float c[9], sg[9], T[81], Vn[81];
-    int   r[9];
+    float c[9], sg[9], Sn[81], Vn[81];
+    int   r[9], lead[9];
+#define TVAL(row, col) ((r[col] == (col)) ? S[9 * (row) + (col)] \
+                        : fmaf(S[9 * (row) + r[col]], sg[col], S[9 * (row) + (col)] * c[col]))
     for (int sw = 0; sw < sweeps; ++sw) {
         for (int t = 0; t < 9; ++t) {
             for (int i = 0; i < 9; ++i) {
                 int j = (t + 9 - i) % 9;
                 r[i] = j;
+                lead[i] = i < j ? i : j;
                 if (j == i) { c[i] = 1.0f; sg[i] = 0.0f; continue; }
                 int p = i < j ? i : j, q = i < j ? j : i;
                 float cc, ss;
@@ -407,21 +414,30 @@ void orc_jacobi9(float S[81], float V[81], int sweeps)
                 c[i] = cc;
                 sg[i] = (i == p) ? -ss : ss;
             }
+            memcpy(Sn, S, sizeof(Sn));
             for (int k = 0; k < 9; ++k)
-                for (int j = 0; j < 9; ++j)
-                    T[9 * k + j] = fmaf(S[9 * k + r[j]], sg[j], S[9 * k + j] * c[j]);
-            for (int i = 0; i < 9; ++i)
-                for (int j = i; j < 9; ++j) {
-                    float v = fmaf(sg[i], T[9 * r[i] + j], c[i] * T[9 * i + j]);
-                    S[9 * i + j] = v;
-                    S[9 * j + i] = v;
+                for (int l = k; l < 9; ++l) {
+                    float v;
+                    if (lead[k] == lead[l]) {
+                        if (r[k] == k) continue;                   /* idle index: diagonal untouched */
+                        /* own 2x2 block of a pair, orientation (row k, col l), k <= l */
+                        v = fmaf(sg[k], TVAL(r[k], l), c[k] * TVAL(k, l));
+                    } else {
+                        const int rho = lead[k] < lead[l] ? k : l, kap = lead[k] < lead[l] ? l : k;
+                        const float t1 = TVAL(rho, kap);
+                        v = (r[rho] == rho) ? t1 : fmaf(sg[rho], TVAL(r[rho], kap), c[rho] * t1);
+                    }
+                    Sn[9 * k + l] = v;
+                    Sn[9 * l + k] = v;
                 }
+            memcpy(S, Sn, sizeof(Sn));
             for (int i = 0; i < 9; ++i)
                 for (int j = 0; j < 9; ++j)
-                    Vn[9 * i + j] = fmaf(V[9 * i + r[j]], sg[j], V[9 * i + j] * c[j]);
+                    Vn[9 * i + j] = (r[j] == j) ? V[9 * i + j] : fmaf(V[9 * i + r[j]], sg[j], V[9 * i + j] * c[j]);
             memcpy(V, Vn, sizeof(Vn));
         }
     }
+#undef TVAL
 }
 
 void orc_nullvec9(const float A[72], int sweeps, float e[9])
