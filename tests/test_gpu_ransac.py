@@ -141,3 +141,45 @@ def test_full_size_properties(gpu):
     truth = ~scene["outlier"]
     m = pair.get_inlier_mask().astype(bool)
     assert (m & truth).sum() > 0.5 * truth.sum() and (m & ~truth).sum() < 0.05 * m.sum()
+
+
+@pytest.mark.parametrize("n,H", [(8, 1), (9, 2), (127, 63), (129, 65), (4097, 130), (511, 8193), (70000, 40)])
+@pytest.mark.parametrize("kernel", [S.KERNEL_AUTO, S.KERNEL_SPLIT, S.KERNEL_FUSED, S.KERNEL_MFMA])
+def test_ragged_sizes_all_kernels(gpu, n, H, kernel):
+    """Ragged / extreme sizes: every kernel family agrees with the oracle (counts, winner, mask, E)."""
+    scene = synth.two_view_scene(n, seed=1000 + n)
+    pair, _ = make_pair(S, gpu, scene)
+    p = S.default_params(n, num_hypotheses=H, seed=n + H, kernel=kernel)
+    pair.estimateE(p)
+    _, _, X0, X1 = oracle_xu(scene)
+    if n <= 5000:
+        key, ocounts, oE = O.ransac_range(X0, X1, 0, H, p.threshold, p.jacobi_sweeps, seed=n + H, want_E=True)
+        assert np.array_equal(pair.get_inlier_counts(H), ocounts)
+        assert pair.get_key() == key
+        ocnt, ohyp = O.unpack_key(key)
+        assert same_bits(pair.get_E(), oE[ohyp].reshape(3, 3))
+        assert np.array_equal(pair.get_inlier_mask(), O.count_inliers(oE[ohyp], X0, X1, p.threshold)[1])
+    else:
+        counts = pair.get_inlier_counts(H)
+        for h in range(0, H, 7):
+            E = O.hypothesis_E(X0, X1, O.sample8(n + H, h, n), p.jacobi_sweeps)
+            assert O.count_inliers(E, X0, X1, p.threshold, want_mask=False)[0] == counts[h]
+        hyp, cnt = pair.get_best()
+        assert cnt == counts.max() and hyp == int(np.argmax(counts)) and pair.get_inlier_mask().sum() == cnt
+
+
+def test_set_points_generic_z(gpu):
+    """sfm_set_points with arbitrary homogeneous scale (z != 1) takes the generic scoring kernel."""
+    torch, dev, ctx = gpu
+    n, H = 1500, 9000
+    scene = synth.two_view_scene(n, seed=4)
+    _, _, X0, X1 = oracle_xu(scene)
+    w0 = (1.0 + 0.5 * synth.uniform01(7, n)).astype(np.float32); w1 = (2.0 - synth.uniform01(8, n)).astype(np.float32)
+    X0s = np.ascontiguousarray(X0 * w0, np.float32); X1s = np.ascontiguousarray(X1 * w1, np.float32)
+    pair = S.ImagePair(ctx, scene["K"], scene["Kinv"], 2, n)
+    pair.set_points(to_dev(torch, dev, X0s), to_dev(torch, dev, X1s))
+    for kernel in (S.KERNEL_SPLIT, S.KERNEL_FUSED, S.KERNEL_MFMA):
+        p = S.default_params(n, num_hypotheses=H, seed=3, kernel=kernel)
+        pair.estimateE(p)
+        key, ocounts, _ = O.ransac_range(X0s, X1s, 0, H, p.threshold, p.jacobi_sweeps, seed=3)
+        assert np.array_equal(pair.get_inlier_counts(H), ocounts) and pair.get_key() == key
