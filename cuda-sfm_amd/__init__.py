@@ -363,3 +363,52 @@ def estimate_E_distributed(pair, params, rank, world, key_tensor, all_reduce_max
     pair.export_key(key_tensor)
     all_reduce_max(key_tensor)
     pair.ransac_finalize_key(params, key_tensor)
+
+
+# ---- many view pairs (BASELINE configs[4]: 36-view ring, view pairs streamed across the GPUs) -------
+RESULT_FLOATS = 9 + 16 + 3          # E, chosen pose (4x4), [pose index, inlier count, best hypothesis]
+
+
+def pair_schedule(num_pairs, rank, world):
+    """Static round-robin assignment of pair ids to ranks: rank r owns r, r+world, ..."""
+    return list(range(int(rank), int(num_pairs), int(world)))
+
+
+def process_pairs(ctx, pairs, K, Kinv, rank=0, world=1, num_hypotheses=None, pose_mode=POSE_REFERENCE,
+                  all_gather=None, device=None):
+    """Task-parallel two-view estimation over many view pairs: each rank runs the whole per-pair
+    pipeline (fillXU -> estimateE -> pose candidates -> choosePose -> linear triangulation) for the
+    pairs it owns; NO per-pair collective.  Results are fixed-size records
+    [E(9) | P(16) | pose_index, inliers, best_hypothesis] gathered ONCE at the end.
+
+    pairs: sequence of (d_sift, n) device SiftPoint arrays (already matched: match_xpos/ypos filled);
+    all_gather(local_tensor) -> gathered tensor [world * max_local, RESULT_FLOATS] (torch.distributed
+    all_gather_into_tensor over RCCL; identity for world == 1).  Returns {pair_id: record ndarray}.
+    """
+    import torch
+    mine = pair_schedule(len(pairs), rank, world)
+    max_local = (len(pairs) + world - 1) // world
+    rec = np.full((max_local, RESULT_FLOATS + 1), -1.0, np.float32)     # last column: pair id (-1 = empty slot)
+    for slot, pid in enumerate(mine):
+        d_sift, n = pairs[pid]
+        ip = ImagePair(ctx, K, Kinv, 2, n)
+        ip.fillXU(d_sift)
+        p = default_params(n) if num_hypotheses is None else default_params(n, num_hypotheses=num_hypotheses)
+        ip.estimateE(p)
+        ip.computePosecandidates(pose_mode)
+        ip.choosePose(pose_mode)
+        ip.linear_triangulation(pose_mode)
+        hyp, cnt = ip.get_best()
+        pind = ip.get_pose_index()
+        P = (ip.get_pose_inverses() if pose_mode == POSE_REFERENCE else ip.get_pose_candidates())[pind]
+        rec[slot, :9] = ip.get_E().reshape(9)
+        rec[slot, 9:25] = P.reshape(16)
+        rec[slot, 25:28] = (pind, cnt, hyp)
+        rec[slot, 28] = pid
+        ip.close()
+    local = torch.from_numpy(rec)
+    if device is not None:
+        local = local.to(device)
+    gathered = all_gather(local) if (all_gather is not None and world > 1) else local
+    g = gathered.cpu().numpy().reshape(-1, RESULT_FLOATS + 1)
+    return {int(r[28]): r[:RESULT_FLOATS].copy() for r in g if r[28] >= 0}

@@ -1,0 +1,81 @@
+"""Config 5 (many view pairs streamed over the GPUs): round-robin schedule + one gather.
+CPU: schedule properties and the 2-rank gloo gather of fixed-size records; GPU: the per-pair pipeline
+on a handful of synthetic pairs against the oracle."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_schedule_is_a_partition():
+    import cuda_sfm_amd as S
+    for npairs in (0, 1, 7, 36, 630):
+        for world in (1, 2, 8):
+            owned = [S.pair_schedule(npairs, r, world) for r in range(world)]
+            flat = sorted(x for o in owned for x in o)
+            assert flat == list(range(npairs))
+            assert max(len(o) for o in owned) - min(len(o) for o in owned) <= 1
+
+
+def _worker(rank, world, port, q):
+    import sys
+    sys.path.insert(0, ROOT)
+    import cuda_sfm_amd as S
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    npairs = 7
+    max_local = (npairs + world - 1) // world
+    rec = np.full((max_local, S.RESULT_FLOATS + 1), -1.0, np.float32)
+    for slot, pid in enumerate(S.pair_schedule(npairs, rank, world)):
+        rec[slot, :S.RESULT_FLOATS] = pid * 100 + np.arange(S.RESULT_FLOATS)
+        rec[slot, S.RESULT_FLOATS] = pid
+    local = torch.from_numpy(rec)
+    out = torch.empty((world * max_local, S.RESULT_FLOATS + 1), dtype=torch.float32)
+    dist.all_gather_into_tensor(out, local)
+    got = {int(r[-1]): r[:-1].numpy().copy() for r in out if r[-1] >= 0}
+    q.put((rank, sorted(got), all(np.array_equal(got[p], p * 100 + np.arange(S.RESULT_FLOATS, dtype=np.float32)) for p in got)))
+    dist.barrier(); dist.destroy_process_group()
+
+
+def test_two_rank_gather_of_pair_records():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs: p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(60); assert p.exitcode == 0
+    for rank, ids, ok in res:
+        assert ids == list(range(7)) and ok
+
+
+@pytest.mark.gpu
+def test_pairs_pipeline_on_gpu(gpu):
+    import cuda_sfm_amd as S
+    import oracle as O
+    from cuda_sfm_amd_synth import synth
+    from helpers import same_bits, to_dev
+    torch_, dev, ctx = gpu
+    K, Kinv = synth.camera()
+    scenes = [synth.two_view_scene(400 + 40 * i, seed=50 + i, outlier_frac=0.2) for i in range(5)]
+    pairs = [(to_dev(torch_, dev, sc["sift"]), len(sc["sift"])) for sc in scenes]
+    res = S.process_pairs(ctx, pairs, K, Kinv, num_hypotheses=128)
+    assert sorted(res) == list(range(5))
+    for i, sc in enumerate(scenes):
+        _, _, X0, X1 = O.fill_xu(sc["sift"], Kinv)
+        n = len(sc["sift"])
+        p = S.default_params(n, num_hypotheses=128)
+        key, _, Ec = O.ransac_range(X0, X1, 0, 128, p.threshold, p.jacobi_sweeps, seed=p.seed, want_E=True)
+        cnt, hyp = O.unpack_key(key)
+        P = O.pose_candidates(Ec[hyp], 0)
+        ind, Pinv, _, _ = O.choose_pose(X0, X1, P, 0, 8)
+        r = res[i]
+        assert same_bits(r[:9], Ec[hyp]) and same_bits(r[9:25], Pinv[ind].reshape(16))
+        assert tuple(int(v) for v in r[25:28]) == (ind, cnt, hyp)
