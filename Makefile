@@ -3,7 +3,7 @@
 HIPCC    ?= /opt/rocm/bin/hipcc
 ARCH     ?= gfx950
 # -ffp-contract=off + correctly rounded div/sqrt: the arithmetic contract shared with oracle/
-HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt \
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -DOCML_BASIC_ROUNDED_OPERATIONS \
             -fPIC -Wall -Wno-unused-function -Wno-pass-failed
 PKG      := cuda-sfm_amd
 CSRC     := $(PKG)/csrc
@@ -14,10 +14,12 @@ OBJS     := $(patsubst $(CSRC)/%.hip,$(BUILD)/%.o,$(SRCS))
 HDRS     := $(wildcard $(CSRC)/*.hpp) include/sfm_amd.h
 
 DEMO     := $(PKG)/host/two_view_demo
+HDEMO    := $(PKG)/host/homography_demo
 
 IOTEST   := tests/cpp/io_test
+GEOMTEST := tests/cpp/geom_test
 
-all: $(LIB) oracle hostcheck $(DEMO) $(IOTEST)
+all: $(LIB) oracle hostcheck $(DEMO) $(HDEMO) $(IOTEST) $(GEOMTEST)
 
 $(BUILD)/%.o: $(CSRC)/%.hip $(HDRS)
 	@mkdir -p $(BUILD)
@@ -34,8 +36,14 @@ oracle:
 $(DEMO): $(PKG)/host/two_view_demo.cpp $(PKG)/host/sfm.h $(PKG)/host/cudaSift.h include/sfm_amd.h $(LIB)
 	g++ -O2 -std=c++14 -Wall -o $@ $< -L$(PKG)/lib -lsfm_amd -Wl,-rpath,'$$ORIGIN/../lib' -Wl,-rpath,/opt/rocm/lib
 
+$(HDEMO): $(PKG)/host/homography_demo.cpp $(PKG)/host/geomFuncs.h $(PKG)/host/cudaSift.h include/sfm_amd.h $(LIB)
+	g++ -O2 -std=c++14 -ffp-contract=off -Wall -o $@ $< -L$(PKG)/lib -lsfm_amd -Wl,-rpath,'$$ORIGIN/../lib' -Wl,-rpath,/opt/rocm/lib
+
 $(IOTEST): tests/cpp/io_test.cpp $(PKG)/host/sfm_io.h $(PKG)/host/cudaSift.h include/sfm_amd.h
 	g++ -O2 -std=c++14 -Wall -o $@ $<
+
+$(GEOMTEST): tests/cpp/geom_test.cpp $(PKG)/host/geomFuncs.h $(PKG)/host/sfm_io.h $(PKG)/host/cudaSift.h include/sfm_amd.h
+	g++ -O2 -std=c++14 -ffp-contract=off -Wall -o $@ $<
 
 hostcheck: tests/hostcheck/libhostcheck.so
 
@@ -43,7 +51,7 @@ tests/hostcheck/libhostcheck.so: tests/hostcheck/hostcheck.hip $(CSRC)/device_ma
 	$(HIPCC) -x hip --cuda-host-only -O2 -ffp-contract=off -mfma -fPIC -shared -Wno-pass-failed -o $@ $<
 
 clean:
-	rm -rf $(BUILD) $(LIB) $(DEMO) $(IOTEST) tests/hostcheck/libhostcheck.so
+	rm -rf $(BUILD) $(LIB) $(DEMO) $(HDEMO) $(IOTEST) $(GEOMTEST) tests/hostcheck/libhostcheck.so
 	$(MAKE) -C oracle clean
 
 .PHONY: all oracle hostcheck clean

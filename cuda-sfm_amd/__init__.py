@@ -49,7 +49,7 @@ EXPORTS = [
     "sfm_abi_version", "sfm_last_error", "sfm_ctx_create", "sfm_ctx_destroy", "sfm_ctx_set_stream",
     "sfm_ctx_synchronize", "sfm_ctx_timer_start", "sfm_ctx_timer_stop", "sfm_ctx_kernel_timing",
     "sfm_ctx_kernel_timing_read", "sfm_device_alloc", "sfm_device_free", "sfm_copy_to_device", "sfm_copy_to_host",
-    "sfm_copy_to_host_2d", "sfm_match", "sfm_match_soa",
+    "sfm_copy_to_host_2d", "sfm_find_homography", "sfm_match", "sfm_match_soa",
     "sfm_pair_create", "sfm_pair_destroy", "sfm_fill_xu", "sfm_set_points", "sfm_ransac_default_params",
     "sfm_ransac_permutation_indices", "sfm_estimate_E", "sfm_ransac_score", "sfm_ransac_finalize",
     "sfm_ransac_finalize_key", "sfm_ransac_export_key", "sfm_pose_candidates", "sfm_choose_pose", "sfm_triangulate",
@@ -79,6 +79,8 @@ _lib.sfm_ctx_timer_start.argtypes = [_vp]
 _lib.sfm_ctx_timer_stop.argtypes = [_vp, C.POINTER(C.c_float)]
 _lib.sfm_ctx_kernel_timing.argtypes = [_vp, C.c_int]
 _lib.sfm_ctx_kernel_timing_read.argtypes = [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int)]
+_lib.sfm_find_homography.argtypes = [_vp, _vp, C.c_int, _vp, C.POINTER(C.c_int), C.c_int, C.c_float, C.c_float,
+                                     C.c_float, C.c_uint32, _vp, _vp, _vp]
 _lib.sfm_match.argtypes = [_vp, _vp, C.c_int, _vp, C.c_int]
 _lib.sfm_match_soa.argtypes = [_vp, _vp, C.c_int, C.c_int, _vp, C.c_int, C.c_int, _vp, _vp, _vp]
 _lib.sfm_pair_create.argtypes = [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int, C.c_int, C.POINTER(_vp)]
@@ -209,6 +211,24 @@ class Context:
     def match_soa(self, d1, n1, ld1, d2, n2, ld2, best, second, index):
         _check(_lib.sfm_match_soa(self._h, _ptr(d1), int(n1), int(ld1), _ptr(d2), int(n2), int(ld2),
                                   _ptr(best), _ptr(second), _ptr(index)), "sfm_match_soa")
+
+    def find_homography(self, d_sift, num_pts, num_loops=1000, min_score=0.85, max_ambiguity=0.95, thresh=5.0,
+                        seed=0, pts=None, want_all=False):
+        """FindHomography (matching.cu:1000-1087).  Returns (H 3x3, num_matches[, counts, homo 8 x L])."""
+        L = (int(num_loops) + 15) // 16 * 16
+        H = np.zeros(9, np.float32); nm = C.c_int()
+        counts = np.zeros(L, np.int32) if want_all else None
+        homo = np.zeros((8, L), np.float32) if want_all else None
+        p = None
+        if pts is not None:
+            p = np.ascontiguousarray(pts, np.int32)
+            assert p.shape == (4, L)
+        _check(_lib.sfm_find_homography(self._h, _ptr(d_sift), int(num_pts), H.ctypes.data_as(_vp), C.byref(nm), int(num_loops),
+                                        float(min_score), float(max_ambiguity), float(thresh), int(seed),
+                                        p.ctypes.data_as(_vp) if p is not None else None,
+                                        counts.ctypes.data_as(_vp) if want_all else None,
+                                        homo.ctypes.data_as(_vp) if want_all else None), "sfm_find_homography")
+        return (H.reshape(3, 3), nm.value, counts, homo) if want_all else (H.reshape(3, 3), nm.value)
 
     def permutation_indices(self, num_points, seed, d_indices):
         _check(_lib.sfm_ransac_permutation_indices(self._h, int(num_points), int(seed), _ptr(d_indices)),

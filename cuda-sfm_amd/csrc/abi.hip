@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <new>
+#include <vector>
 
 namespace sfm {
 
@@ -85,6 +86,7 @@ int sfm_ctx_destroy(sfm_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->match_ws) (void)hipFree(ctx->match_ws);
+    if (ctx->homo_ws) (void)hipFree(ctx->homo_ws);
     for (auto &t : ctx->tev) for (hipEvent_t e : t) if (e) (void)hipEventDestroy(e);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -223,6 +225,50 @@ int sfm_match_soa(sfm_ctx *ctx, const float *d_desc1, int n1, int ld1, const flo
     SFM_REQUIRE(((uintptr_t)d_desc1 & 15) == 0 && ((uintptr_t)d_desc2 & 15) == 0, SFM_E_INVALID, "descriptor rows must be 16-byte aligned");
     SFM_HIP_TRY(hipSetDevice(ctx->device));
     return launch_match(ctx, d_desc1, n1, ld1, d_desc2, n2, ld2, d_best, d_second, d_index, nullptr, nullptr);
+}
+
+// ---- FindHomography ------------------------------------------------------------------------------
+int sfm_find_homography(sfm_ctx *ctx, const sfm_sift_point *d_sift, int num_pts, float h_H[9], int *num_matches,
+                        int num_loops, float min_score, float max_ambiguity, float thresh, uint32_t seed,
+                        const int32_t *h_pts, int32_t *h_counts, float *h_homo)
+{
+    SFM_REQUIRE(ctx && h_H && num_matches, SFM_E_INVALID, "null argument");
+    *num_matches = 0;
+    for (int i = 0; i < 9; ++i) h_H[i] = (i % 4 == 0) ? 1.0f : 0.0f;           // matching.cu:1002-1005
+    if (!d_sift || num_pts < 8 || num_loops <= 0) return SFM_OK;                // matching.cu:1010-1018
+    SFM_HIP_TRY(hipSetDevice(ctx->device));
+    const int L = round_up(num_loops, 16);                                      // matching.cu:1015
+    std::vector<int32_t> pts;
+    if (!h_pts) {
+        // score / ambiguity gate on the host, as the reference does (matching.cu:1030-1036)
+        std::vector<float> sc((size_t)num_pts), am((size_t)num_pts);
+        SFM_HIP_TRY(hipMemcpy2DAsync(sc.data(), 4, &d_sift[0].score, sizeof(sfm_sift_point), 4, (size_t)num_pts, hipMemcpyDeviceToHost, ctx->stream));
+        SFM_HIP_TRY(hipMemcpy2DAsync(am.data(), 4, &d_sift[0].ambiguity, sizeof(sfm_sift_point), 4, (size_t)num_pts, hipMemcpyDeviceToHost, ctx->stream));
+        SFM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+        std::vector<int32_t> valid;
+        for (int i = 0; i < num_pts; ++i)
+            if (sc[i] > min_score && am[i] < max_ambiguity) valid.push_back(i);
+        const uint32_t nv = (uint32_t)valid.size();
+        if (nv < 8) return SFM_OK;                                              // matching.cu:1037
+        // four distinct valid points per loop from the counter hash (replaces rand(), matching.cu:1038-1049)
+        pts.resize((size_t)4 * L);
+        for (int i = 0; i < L; ++i) {
+            const uint32_t base = hash32(hash32(seed ^ 0x48304D4Fu) + (uint32_t)i);
+            uint32_t pick[4]; int got = 0;
+            for (uint32_t k = 0; got < 4; ++k) {
+                const uint32_t c = mulhi32(hash32(base + k * 0x9E3779B9U), nv);
+                bool dup = false;
+                for (int j = 0; j < got; ++j) dup |= (pick[j] == c);
+                if (!dup) pick[got++] = c;
+            }
+            for (int k = 0; k < 4; ++k) pts[(size_t)k * L + i] = valid[pick[k]];
+        }
+        h_pts = pts.data();
+    } else {
+        for (size_t i = 0; i < (size_t)4 * L; ++i)
+            SFM_REQUIRE(h_pts[i] >= 0 && h_pts[i] < num_pts, SFM_E_INVALID, "sample index %d out of range", h_pts[i]);
+    }
+    return launch_homography(ctx, d_sift, num_pts, h_pts, L, thresh, h_H, num_matches, h_counts, h_homo);
 }
 
 // ---- Image_pair ---------------------------------------------------------------------------------

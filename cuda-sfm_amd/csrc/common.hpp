@@ -41,6 +41,8 @@ struct sfm_ctx {
     // matcher scratch: per-split partial (best, second, index) records
     void *match_ws = nullptr;
     size_t match_ws_bytes = 0;
+    void *homo_ws = nullptr;           // homography RANSAC scratch
+    size_t homo_ws_bytes = 0;
 };
 
 struct sfm_pair {
@@ -93,6 +95,9 @@ int launch_pose_candidates(sfm_pair *pair, int mode);
 int launch_choose_pose(sfm_pair *pair, int mode);
 int launch_triangulate(sfm_pair *pair, int mode);
 
+// homography.hip
+int launch_homography(sfm_ctx *ctx, const sfm_sift_point *d_sift, int n, const int *h_pts, int L, float thresh,
+                      float h_H[9], int *num_matches, int *h_counts, float *h_homo);
 // match.hip
 int launch_match(sfm_ctx *ctx, const float *d1, int n1, int ld1, const float *d2, int n2, int ld2,
                  float *d_best, float *d_second, int32_t *d_index,

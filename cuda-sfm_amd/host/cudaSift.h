@@ -7,7 +7,8 @@
 //   InitCuda                 creates the process-wide context (cudaSiftH.cu:19)
 //   InitSiftData / FreeSiftData   host + device buffers (cudaSiftH.cu:234-264)
 //   MatchSiftData            brute-force matcher, returns elapsed ms (matching.cu:1090-1206)
-// ExtractSift / FindHomography are outside the hot path and are not provided.
+//   FindHomography           RANSAC homography pre-filter (matching.cu:1000-1087)
+// ExtractSift is outside the hot path and is not provided.
 //
 // Error convention of the reference: print and exit (cudautils.h:15-39).  Reproduced here; define
 // SFM_FACADE_THROW to get std::runtime_error instead.
@@ -118,6 +119,26 @@ inline double MatchSiftData(SiftData &data1, SiftData &data2)
     SFM_FACADE_CALL(sfm_ctx_timer_stop(ctx, &ms));
 #ifndef VERBOSE
     std::printf("MatchSiftData time =          %.2f ms\n", ms);
+#endif
+    return ms;
+}
+
+// matching.cu:1000-1087.  Same signature and defaults as the reference (cudaSift.h:43); returns the
+// elapsed milliseconds.  The sample is seeded (SFM_HOMOGRAPHY_SEED, default 0) instead of rand().
+#ifndef SFM_HOMOGRAPHY_SEED
+#define SFM_HOMOGRAPHY_SEED 0u
+#endif
+inline double FindHomography(SiftData &data, float *homography, int *numMatches, int numLoops = 1000,
+                             float minScore = 0.85f, float maxAmbiguity = 0.95f, float thresh = 5.0f)
+{
+    sfm_ctx *ctx = sfm_facade::context();
+    SFM_FACADE_CALL(sfm_ctx_timer_start(ctx));
+    SFM_FACADE_CALL(sfm_find_homography(ctx, data.d_data, data.numPts, homography, numMatches, numLoops, minScore,
+                                        maxAmbiguity, thresh, SFM_HOMOGRAPHY_SEED, nullptr, nullptr, nullptr));
+    float ms = 0.f;
+    SFM_FACADE_CALL(sfm_ctx_timer_stop(ctx, &ms));
+#ifdef VERBOSE
+    std::printf("FindHomography time =         %.2f ms\n", ms);
 #endif
     return ms;
 }

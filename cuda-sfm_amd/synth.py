@@ -101,20 +101,45 @@ def normalized_points(scene):
     return (Ki @ U0).astype(np.float32), (Ki @ U1).astype(np.float32)
 
 
-def descriptors(n, seed=SEED, noise=0.05):
+def descriptors(n, seed=SEED, noise=0.05, sparsity=0.0):
     """Two descriptor sets shaped like CudaSift output (non-negative, clipped at 0.2, unit L2;
     reference CudaSift/cudaSiftD.cu:390-409): set 2 = permuted set 1 + noise.  Returns
-    (d1, d2, perm) with d2[i] ~ d1[perm[i]]."""
+    (d1, d2, perm) with d2[i] ~ d1[perm[i]].  sparsity > 0 zeroes that fraction of the bins, which makes
+    unrelated descriptors less correlated (lower ambiguity, as real SIFT on textured images)."""
     def finish(d):
         d = d / np.linalg.norm(d, axis=1, keepdims=True)
         d = np.minimum(d, 0.2)
         d = d / np.linalg.norm(d, axis=1, keepdims=True)
         return d
-    d1 = finish(np.abs(normal(seed, n * 128, 20).reshape(n, 128)))
+    raw = np.abs(normal(seed, n * 128, 20).reshape(n, 128))
+    if sparsity > 0.0:
+        raw = raw * (uniform01(seed, n * 128, 23).reshape(n, 128) >= sparsity) + 1e-3
+    d1 = finish(raw)
     key = splitmix64(seed, n, 21)
     perm = np.argsort(key, kind="stable")
     d2 = finish(np.abs(d1[perm] + noise * normal(seed, n * 128, 22).reshape(n, 128)))
     return np.ascontiguousarray(d1, np.float32), np.ascontiguousarray(d2, np.float32), perm
+
+
+def homography_scene(n, seed=SEED, noise_px=0.7, outlier_frac=0.35, width=1920, height=1080):
+    """Matched SiftPoint records related by one plane-induced homography (input of FindHomography):
+    xpos/ypos -> match_xpos/match_ypos, score/ambiguity set so that about 10 % fail the default gate."""
+    x = (width * uniform01(seed, n, 40)).astype(np.float64)
+    y = (height * uniform01(seed, n, 41)).astype(np.float64)
+    H = np.array([[0.96, 0.05, 31.0], [-0.04, 1.03, -18.0], [2.0e-5, -1.0e-5, 1.0]])
+    w = H[2, 0] * x + H[2, 1] * y + 1.0
+    x2 = (H[0, 0] * x + H[0, 1] * y + H[0, 2]) / w + noise_px * normal(seed, n, 42)
+    y2 = (H[1, 0] * x + H[1, 1] * y + H[1, 2]) / w + noise_px * normal(seed, n, 43)
+    out = uniform01(seed, n, 44) < outlier_frac
+    x2 = np.where(out, width * uniform01(seed, n, 45), x2)
+    y2 = np.where(out, height * uniform01(seed, n, 46), y2)
+    s = np.zeros(n, SIFT_DTYPE)
+    s["xpos"], s["ypos"] = x.astype(np.float32), y.astype(np.float32)
+    s["match_xpos"], s["match_ypos"] = x2.astype(np.float32), y2.astype(np.float32)
+    s["score"] = (0.80 + 0.2 * uniform01(seed, n, 47)).astype(np.float32)
+    s["ambiguity"] = (0.5 + 0.5 * uniform01(seed, n, 48)).astype(np.float32)
+    s["match"] = np.arange(n, dtype=np.int32)
+    return {"sift": s, "H": H.astype(np.float32), "outlier": out}
 
 
 def sift_records(desc, seed=SEED, width=720, height=576, stream=30):

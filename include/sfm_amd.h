@@ -88,6 +88,18 @@ int sfm_match_soa(sfm_ctx *ctx, const float *d_desc1, int n1, int ld1,
                   const float *d_desc2, int n2, int ld2,
                   float *d_best, float *d_second, int32_t *d_index);
 
+/* ---- homography RANSAC pre-filter: FindHomography (matching.cu:1000-1087) -------------------------
+ * 4-point DLT hypotheses from the matched records of d_sift (xpos, ypos -> match_xpos, match_ypos),
+ * sampled among the points with score > min_score and ambiguity < max_ambiguity; a point supports a
+ * hypothesis when its transfer error is below thresh pixels.  num_loops is rounded up to a multiple of
+ * 16 as in the reference.  h_H receives the best homography (row-major 3x3, h33 = 1; identity when
+ * fewer than 8 usable points), num_matches its support.  Optional: h_pts = explicit 4 x num_loops host
+ * sample (layout pts[k * num_loops + i], as the reference's h_randPts) instead of the seeded sampler;
+ * h_counts[num_loops] / h_homo[8 x num_loops] receive every hypothesis (parity tests).  Synchronous. */
+int sfm_find_homography(sfm_ctx *ctx, const sfm_sift_point *d_sift, int num_pts, float h_H[9], int *num_matches,
+                        int num_loops, float min_score, float max_ambiguity, float thresh, uint32_t seed,
+                        const int32_t *h_pts, int32_t *h_counts, float *h_homo);
+
 /* ---- Image_pair ------------------------------------------------------------------------------ */
 /* Image_pair::Image_pair(k, k_inv, image_count, num_points), sfm.cu:28-78.  h_K / h_Kinv: host. */
 int sfm_pair_create(sfm_ctx *ctx, const float h_K[9], const float h_Kinv[9],

@@ -258,6 +258,71 @@ def match_sift(s1, s2, nthreads=0):
     return s1
 
 
+def homography4(coord, pts):
+    coord = _f32(coord); pts = np.ascontiguousarray(pts, np.int32)
+    h = np.empty(8, np.float32)
+    _L.orc_homography4(_fp(coord), C.c_int(coord.shape[1]), _ip(pts), _fp(h))
+    return h
+
+
+def homography_count(h, coord, n, thresh2):
+    coord = _f32(coord); h = _f32(h).reshape(8)
+    _L.orc_homography_count.argtypes = [f32p, f32p, C.c_int, C.c_int, C.c_float]
+    return int(_L.orc_homography_count(_fp(h), _fp(coord), coord.shape[1], int(n), float(thresh2)))
+
+
+def find_homography(sift, num_loops=1000, min_score=0.85, max_ambiguity=0.95, thresh=5.0, seed=0, want_all=False):
+    """FindHomography end to end (matching.cu:1000-1087) -> (H 3x3, numMatches[, counts, homo 8 x L])."""
+    sift = np.ascontiguousarray(sift)
+    L = (int(num_loops) + 15) // 16 * 16
+    H = np.empty(9, np.float32)
+    counts = np.empty(L, np.int32); homo = np.empty((8, L), np.float32)
+    _L.orc_find_homography.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_uint32, f32p, i32p, f32p]
+    nm = int(_L.orc_find_homography(sift.ctypes.data_as(C.c_void_p), len(sift), int(num_loops), float(min_score), float(max_ambiguity),
+                                    float(thresh), int(seed), _fp(H), _ip(counts), _fp(homo)))
+    return (H.reshape(3, 3), nm, counts, homo) if want_all else (H.reshape(3, 3), nm)
+
+
+def improve_homography(sift, H, num_loops, min_score, max_ambiguity, thresh):
+    """numpy restatement of ImproveHomography (CudaSift/geomFuncs.cpp:6-72): double normal equations,
+    float residuals, 0/1 weights, Cholesky solve.  The reference solves with OpenCV's
+    cv::solve(DECOMP_CHOLESKY) (absent here -> PARITY UNPINNED at that call; compared to ~1e-9).
+    Returns (numfit, H 3x3 float32, match_error float32[n])."""
+    f32, f64 = np.float32, np.float64
+    x, y = sift["xpos"].astype(f32), sift["ypos"].astype(f32)
+    mx, my = sift["match_xpos"].astype(f32), sift["match_ypos"].astype(f32)
+    H = np.asarray(H, f32).reshape(9)
+    A = (H[:8] / H[8]).astype(f64)
+    limit = f32(thresh) * f32(thresh)
+    gate = ~((sift["score"] < f32(min_score)) | (sift["ambiguity"] > f32(max_ambiguity)))
+
+    def errs_exact(A):
+        xd, yd = x.astype(f64), y.astype(f64)
+        den = (A[6] * xd + A[7] * yd + 1.0).astype(f32)
+        dx = ((A[0] * xd + A[1] * yd + A[2]) / den.astype(f64) - mx.astype(f64)).astype(f32)
+        dy = ((A[3] * xd + A[4] * yd + A[5]) / den.astype(f64) - my.astype(f64)).astype(f32)
+        err = (dx * dx + dy * dy).astype(f32)
+        return err
+
+    for _ in range(int(num_loops)):
+        err = errs_exact(A)
+        w = ((err < limit) & gate).astype(f64)
+        xd, yd = x.astype(f64), y.astype(f64)
+        z, o = np.zeros_like(xd), np.ones_like(xd)
+        Y1 = np.stack([xd, yd, o, z, z, z, (-x * mx).astype(f64), (-y * mx).astype(f64)])
+        Y2 = np.stack([z, z, z, xd, yd, o, (-x * my).astype(f64), (-y * my).astype(f64)])
+        M = (Y1 * w) @ Y1.T + (Y2 * w) @ Y2.T
+        X = (Y1 * w) @ mx.astype(f64) + (Y2 * w) @ my.astype(f64)
+        try:
+            L = np.linalg.cholesky(M)
+            A = np.linalg.solve(L.T, np.linalg.solve(L, X))
+        except np.linalg.LinAlgError:
+            A = np.zeros(8)                                      # cv::solve zeroes dst on failure
+    err = errs_exact(A)
+    out = np.append(A, 1.0).astype(f32).reshape(3, 3)
+    return int((err < limit).sum()), out, np.sqrt(err).astype(f32)
+
+
 # ---- in-place builds of the reference (oracle/_ref), optional ---------------------------------
 def ref_available(name):
     return os.path.exists(os.path.join(_REF, name))

@@ -12,7 +12,9 @@
 #                       normalize_pt_kernal, row_extraction_kernel) + SfM/svd.h device functions,
 #                       built with -ffp-contract=off (the arithmetic contract of the oracle);
 #                       CudaSift/matching.cu CleanMatches + FindMaxCorr10 (the live matcher, :289-397),
-#                       built with -ffp-contract=fast (nvcc's default fmad, which fuses :347-350).
+#                       built with -ffp-contract=fast (nvcc's default fmad, which fuses :347-350);
+#                       CudaSift/matching.cu InvertMatrix<8> + ComputeHomographies + TestHomographies
+#                       (:821-996, the FindHomography kernels), built with -ffp-contract=off.
 # Launch geometry in ref_driver_gpu.inc follows the reference's call sites (cited there).
 set -eu
 REF="${1:-/root/reference}"
@@ -50,8 +52,18 @@ me=$(grep -n '^#define FMC_GH' "$M" | cut -d: -f1)
   cat "$HERE/ref_driver_match_gpu.inc"
 } > "$TMP/ref_matchk.hip"
 
+hb=$(grep -n '^template <int size>' "$M" | head -1 | cut -d: -f1)          # InvertMatrix<size>
+he=$(grep -n '^//================= Host matching functions' "$M" | cut -d: -f1)
+{
+  echo '#include <hip/hip_runtime.h>'
+  echo '#include <math.h>'
+  sed -n "${hb},$((he - 1))p" "$M"                                        # InvertMatrix, ComputeHomographies, TestHomographies
+  cat "$HERE/ref_driver_homo_gpu.inc"
+} > "$TMP/ref_homo.hip"
+
 HIPCC=/opt/rocm/bin/hipcc
 $HIPCC --offload-arch=gfx950 -O2 -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fPIC -w -c "$TMP/ref_kernels.hip" -o "$TMP/a.o"
 $HIPCC --offload-arch=gfx950 -O2 -ffp-contract=fast -fPIC -w -c "$TMP/ref_matchk.hip" -o "$TMP/b.o"
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT/libref_kernels.so" "$TMP/a.o" "$TMP/b.o"
+$HIPCC --offload-arch=gfx950 -O2 -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -DOCML_BASIC_ROUNDED_OPERATIONS -fPIC -w -c "$TMP/ref_homo.hip" -o "$TMP/c.o"
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT/libref_kernels.so" "$TMP/a.o" "$TMP/b.o" "$TMP/c.o"
 echo "ref_build_gpu: wrote $OUT/libref_kernels.so"

@@ -800,3 +800,171 @@ void orc_match_sift(orc_sift_point *s1, int n1, const orc_sift_point *s2, int n2
     }
     free(best); free(sec); free(idx);
 }
+
+/* ======================================================================================
+ * Homography RANSAC (FindHomography).  Restated from CudaSift/matching.cu:821-996; pinned by running
+ * the reference's own ComputeHomographies / TestHomographies kernels on the GPU
+ * (oracle/ref_build_gpu.sh, tests/test_gpu_ref_kernels.py).  Products are unfused.
+ * ==================================================================================== */
+
+/* 8x8 inverse by Crout LU with implicit (row-scaled) partial pivoting followed by eight
+ * back-substitutions -- the Numerical-Recipes scheme InvertMatrix<8> uses (matching.cu:821-905),
+ * including its double-precision reciprocals (1.0/x with a double literal) and its 1e-16 / 1e16 guards. */
+static void invert8(float e[8][8], float res[8][8])
+{
+    int indx[8];
+    float vv[8], b[8];
+    int imax = 0;
+    for (int i = 0; i < 8; ++i) {
+        float big = 0.0f;
+        for (int j = 0; j < 8; ++j) { const float t = fabsf(e[i][j]); if (t > big) big = t; }
+        vv[i] = (big > 0.0f) ? (float)(1.0 / (double)big) : (float)1e16;
+        indx[i] = 0;
+    }
+    for (int j = 0; j < 8; ++j) {
+        for (int i = 0; i < j; ++i) {
+            float sum = e[i][j];
+            for (int k = 0; k < i; ++k) sum -= e[i][k] * e[k][j];
+            e[i][j] = sum;
+        }
+        float big = 0.0f;
+        for (int i = j; i < 8; ++i) {
+            float sum = e[i][j];
+            for (int k = 0; k < j; ++k) sum -= e[i][k] * e[k][j];
+            e[i][j] = sum;
+            const float dum = vv[i] * fabsf(sum);
+            if (dum >= big) { big = dum; imax = i; }
+        }
+        if (j != imax) {
+            for (int k = 0; k < 8; ++k) { const float d = e[imax][k]; e[imax][k] = e[j][k]; e[j][k] = d; }
+            vv[imax] = vv[j];
+        }
+        indx[j] = imax;
+        if (e[j][j] == 0.0f) e[j][j] = (float)1e-16;
+        if (j != 7) {
+            const float dum = (float)(1.0 / (double)e[j][j]);
+            for (int i = j + 1; i < 8; ++i) e[i][j] *= dum;
+        }
+    }
+    for (int j = 0; j < 8; ++j) {
+        for (int k = 0; k < 8; ++k) b[k] = 0.0f;
+        b[j] = 1.0f;
+        int ii = -1;
+        for (int i = 0; i < 8; ++i) {
+            const int ip = indx[i];
+            float sum = b[ip];
+            b[ip] = b[i];
+            if (ii != -1) { for (int k = ii; k < i; ++k) sum -= e[i][k] * b[k]; }
+            else if (sum != 0.0f) ii = i;
+            b[i] = sum;
+        }
+        for (int i = 7; i >= 0; --i) {
+            float sum = b[i];
+            for (int k = i + 1; k < 8; ++k) sum -= e[i][k] * b[k];
+            b[i] = sum / e[i][i];
+        }
+        for (int i = 0; i < 8; ++i) res[i][j] = b[i];
+    }
+}
+
+void orc_homography4(const float *coord, int ld, const int pts[4], float h[8])
+{
+    float a[8][8], ia[8][8], b[8];
+    for (int i = 0; i < 4; ++i) {                      /* matching.cu:916-938 */
+        const int pt = pts[i];
+        const float x1 = coord[pt], y1 = coord[pt + ld], x2 = coord[pt + 2 * ld], y2 = coord[pt + 3 * ld];
+        float *r1 = a[2 * i], *r2 = a[2 * i + 1];
+        r1[0] = x1; r1[1] = y1; r1[2] = 1.0f; r1[3] = r1[4] = r1[5] = 0.0f; r1[6] = (-x2) * x1; r1[7] = (-x2) * y1;
+        r2[0] = r2[1] = r2[2] = 0.0f; r2[3] = x1; r2[4] = y1; r2[5] = 1.0f; r2[6] = (-y2) * x1; r2[7] = (-y2) * y1;
+        b[2 * i] = x2; b[2 * i + 1] = y2;
+    }
+    invert8(a, ia);
+    for (int j = 0; j < 8; ++j) {                      /* matching.cu:941-946 */
+        float sum = 0.0f;
+        for (int i = 0; i < 8; ++i) sum += ia[j][i] * b[i];
+        h[j] = sum;
+    }
+}
+
+/* __fmul_rz: the product of two floats is exact in double; truncate it toward zero to float. */
+static inline float mul_rz(float a, float b)
+{
+    const double p = (double)a * (double)b;
+    float f = (float)p;                                 /* round to nearest */
+    if (f != f || f == p || f - f != 0.0f) return f;    /* NaN, exact, or infinite */
+    if (fabs((double)f) > fabs(p)) f = nextafterf(f, 0.0f);
+    return f;
+}
+
+int orc_homography_count(const float h[8], const float *coord, int ld, int n, float thresh2)
+{
+    int cnt = 0;
+    for (int i = 0; i < n; ++i) {                       /* matching.cu:973-985 */
+        const float x1 = coord[i], y1 = coord[i + ld], x2 = coord[i + 2 * ld], y2 = coord[i + 3 * ld];
+        const float nomx = (mul_rz(h[0], x1) + mul_rz(h[1], y1)) + h[2];
+        const float nomy = (mul_rz(h[3], x1) + mul_rz(h[4], y1)) + h[5];
+        const float deno = (mul_rz(h[6], x1) + mul_rz(h[7], y1)) + 1.0f;
+        const float errx = mul_rz(x2, deno) - nomx;
+        const float erry = mul_rz(y2, deno) - nomy;
+        const float err2 = mul_rz(errx, errx) + mul_rz(erry, erry);
+        if (err2 < mul_rz(thresh2, mul_rz(deno, deno))) ++cnt;
+    }
+    return cnt;
+}
+
+/* The keyed 4-sample that replaces rand() in FindHomography (matching.cu:1038-1049): loop i draws four
+ * distinct positions in the gated list from a counter hash; a pure function of (seed, i, nvalid). */
+void orc_homography_sample(uint32_t seed, uint32_t loop, uint32_t nvalid, uint32_t pick[4])
+{
+    uint32_t base = orc_hash32(orc_hash32(seed ^ 0x48304D4FU) + loop);
+    int got = 0;
+    for (uint32_t k = 0; got < 4; ++k) {
+        uint32_t c = (uint32_t)(((uint64_t)orc_hash32(base + k * 0x9E3779B9U) * (uint64_t)nvalid) >> 32);
+        int dup = 0;
+        for (int j = 0; j < got; ++j) dup |= (pick[j] == c);
+        if (!dup) pick[got++] = c;
+    }
+}
+
+/* FindHomography end to end (matching.cu:1000-1087): identity / 0 for < 8 points or < 8 gated points,
+ * numLoops rounded up to 16, gate score > minScore && ambiguity < maxAmbiguity, first maximum wins.
+ * counts[L] / homo[8 x L] optional.  Returns numMatches. */
+int orc_find_homography(const orc_sift_point *s, int n, int num_loops, float min_score, float max_ambiguity,
+                        float thresh, uint32_t seed, float H[9], int *counts, float *homo)
+{
+    for (int i = 0; i < 9; ++i) H[i] = (i % 4 == 0) ? 1.0f : 0.0f;
+    if (n < 8 || num_loops <= 0) return 0;
+    int L = (num_loops + 15) / 16 * 16;
+    int *valid = (int *)malloc(sizeof(int) * (size_t)n);
+    uint32_t nv = 0;
+    for (int i = 0; i < n; ++i)
+        if (s[i].score > min_score && s[i].ambiguity < max_ambiguity) valid[nv++] = i;
+    if (nv < 8) { free(valid); return 0; }
+    float *coord = (float *)malloc(sizeof(float) * 4 * (size_t)n);
+    for (int i = 0; i < n; ++i) {
+        coord[i] = s[i].xpos; coord[n + i] = s[i].ypos;
+        coord[2 * n + i] = s[i].match_xpos; coord[3 * n + i] = s[i].match_ypos;
+    }
+    float *hh = (float *)malloc(sizeof(float) * 8 * (size_t)L);
+    int *cc = (int *)malloc(sizeof(int) * (size_t)L);
+    float thresh2 = thresh * thresh;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
+    for (int l = 0; l < L; ++l) {
+        uint32_t pick[4]; int pts[4];
+        orc_homography_sample(seed, (uint32_t)l, nv, pick);
+        for (int k = 0; k < 4; ++k) pts[k] = valid[pick[k]];
+        orc_homography4(coord, n, pts, hh + 8 * (size_t)l);
+        cc[l] = orc_homography_count(hh + 8 * (size_t)l, coord, n, n, thresh2);
+    }
+    int best = 0, bi = -1;
+    for (int l = 0; l < L; ++l) if (cc[l] > best) { best = cc[l]; bi = l; }     /* matching.cu:1066-1070 */
+    if (bi < 0) bi = 0;          /* all-zero support: the packed-key arg-max of the product returns loop 0 */
+    for (int k = 0; k < 8; ++k) H[k] = hh[8 * (size_t)bi + k];
+    H[8] = 1.0f;
+    if (counts) memcpy(counts, cc, sizeof(int) * (size_t)L);
+    if (homo) for (int l = 0; l < L; ++l) for (int k = 0; k < 8; ++k) homo[(size_t)k * L + l] = hh[8 * (size_t)l + k];
+    free(valid); free(coord); free(hh); free(cc);
+    return best;
+}

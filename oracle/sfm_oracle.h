@@ -98,6 +98,17 @@ void orc_match_desc(const float *d1, int n1, int ld1, const float *d2, int n2, i
                     float *best, float *second, int *index, int nthreads);
 void orc_match_sift(orc_sift_point *s1, int n1, const orc_sift_point *s2, int n2, int nthreads);
 
+/* ---- homography RANSAC pre-filter (FindHomography, matching.cu:1000-1087) ---- */
+/* coord: 4 x ld row-major (x1; y1; x2; y2), pts[4]: sample.  h[8] (h33 = 1 implied).
+ * ComputeHomographies matching.cu:907-948 + InvertMatrix<8> :821-905. */
+void orc_homography4(const float *coord, int ld, const int pts[4], float h[8]);
+/* TestHomographies matching.cu:953-996 (round-toward-zero products), points 0..n-1. */
+int  orc_homography_count(const float h[8], const float *coord, int ld, int n, float thresh2);
+
+void orc_homography_sample(uint32_t seed, uint32_t loop, uint32_t nvalid, uint32_t pick[4]);
+int  orc_find_homography(const orc_sift_point *s, int n, int num_loops, float min_score, float max_ambiguity,
+                         float thresh, uint32_t seed, float H[9], int *counts, float *homo);
+
 int orc_abi_version(void);
 
 #ifdef __cplusplus

@@ -78,3 +78,33 @@ def test_cpp_facade_error_is_print_and_exit(tmp_path):
     s1[:5].tofile(f1); s2.tofile(f2)
     r = subprocess.run([DEMO, f1, f2, out, "10"], capture_output=True, text=True, timeout=120)
     assert r.returncode != 0 and "8-point" in r.stderr
+
+
+def test_cpp_homography_demo(tmp_path):
+    """mainSift.cpp:72-81 re-hosted: MatchSiftData -> FindHomography -> ImproveHomography, against the oracle chain."""
+    demo = os.path.join(ROOT, "cuda-sfm_amd", "host", "homography_demo")
+    assert os.path.exists(demo), "homography_demo not built (make)"
+    n = 1500
+    hs = synth.homography_scene(n, seed=88)["sift"]
+    d1, d2, perm = synth.descriptors(n, seed=89, noise=0.02, sparsity=0.8)   # d2[i] ~ d1[perm[i]]; ambiguity ~0.5
+    s1 = synth.sift_records(d1, seed=90); s1["xpos"], s1["ypos"] = hs["xpos"], hs["ypos"]
+    s2 = synth.sift_records(d2, seed=91); s2["xpos"], s2["ypos"] = hs["match_xpos"][perm], hs["match_ypos"][perm]
+    f1, f2, out = (str(tmp_path / x) for x in ("s1.bin", "s2.bin", "h.bin"))
+    s1.tofile(f1); s2.tofile(f2)
+    r = subprocess.run([demo, f1, f2, out], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    raw = open(out, "rb").read()
+    nm, nfit = np.frombuffer(raw, "<i4", 2)
+    Hr = np.frombuffer(raw, "<f4", 9, 8).reshape(3, 3); Hi = np.frombuffer(raw, "<f4", 9, 44).reshape(3, 3)
+    merr = np.frombuffer(raw, "<f4", n, 80)
+
+    m = O.match_sift(s1, s2)
+    oH, onm = O.find_homography(m, 10000, 0.0, 0.80, 5.0, 0)
+    assert nm == onm and same_bits(Hr, oH)
+    onfit, oHi, oerr = O.improve_homography(m, oH, 5, 0.0, 0.80, 3.0)
+    assert abs(int(nfit) - onfit) <= 1 and np.allclose(Hi, oHi, rtol=1e-6, atol=1e-9)
+    assert np.allclose(merr, oerr, rtol=1e-3, atol=1e-3)
+    assert f"Number of original features: {n} {n}" in r.stdout
+    assert f"Number of matching features: {nfit} {nm} " in r.stdout
+    assert (m["ambiguity"] < 0.8).mean() > 0.9                   # the demo's gate (mainSift.cpp:77) keeps most matches
+    assert nm > 0.55 * n                                         # 65 % of the scene lies on the plane

@@ -134,3 +134,31 @@ def test_synth_is_portable():
     assert abs(float(sc["sift"]["xpos"][0]) - float(synth.two_view_scene(64)["sift"]["xpos"][0])) == 0
     d1, d2, perm = synth.descriptors(32)
     assert np.allclose(np.linalg.norm(d1, axis=1), 1, atol=1e-5) and d1.max() <= 0.2001 * 1.5 and (d1 >= 0).all()
+
+
+def test_homography_oracle_invariants():
+    """orc_homography4 / orc_homography_count (matching.cu:821-996): exact fit of the sample, recovery of
+    the generating plane, round-toward-zero products, strict '<' threshold."""
+    from cuda_sfm_amd_synth import synth
+    sc = synth.homography_scene(512, seed=9, noise_px=0.0, outlier_frac=0.25)
+    s = sc["sift"]; n = len(s)
+    c = np.ascontiguousarray(np.stack([s["xpos"], s["ypos"], s["match_xpos"], s["match_ypos"]]).astype(np.float32))
+    inl = np.flatnonzero(~sc["outlier"])
+    pts = inl[[0, 17, 101, 230]].astype(np.int32)
+    h = O.homography4(c, pts)
+    H = np.append(h, 1).reshape(3, 3).astype(np.float64)
+    p = H @ np.vstack([c[0], c[1], np.ones(n)])
+    err = np.hypot(p[0] / p[2] - c[2], p[1] / p[2] - c[3])
+    assert err[pts].max() < 5e-2                               # interpolates its four points (binary32 LU)
+    assert np.abs(H - sc["H"]).max() / np.abs(sc["H"]).max() < 0.05
+    cnt = O.homography_count(h, c, n, 25.0)
+    assert abs(cnt - len(inl)) <= 0.02 * n
+    assert O.homography_count(h, c, n, 0.0) == 0                 # strict '<'
+    assert O.homography_count(h, c, 0, 25.0) == 0
+    # prefix property: counting n points = counting the first k + the rest
+    k = 200
+    c2 = np.ascontiguousarray(c[:, k:])
+    assert O.homography_count(h, c, k, 25.0) + O.homography_count(h, c2, n - k, 25.0) == cnt
+    # NaN coordinates never count
+    cn = c.copy(); cn[0, :50] = np.nan
+    assert O.homography_count(h, cn, n, 25.0) == O.homography_count(h, np.ascontiguousarray(c[:, 50:]), n - 50, 25.0)
