@@ -49,7 +49,7 @@ EXPORTS = [
     "sfm_abi_version", "sfm_last_error", "sfm_ctx_create", "sfm_ctx_destroy", "sfm_ctx_set_stream",
     "sfm_ctx_synchronize", "sfm_ctx_timer_start", "sfm_ctx_timer_stop", "sfm_ctx_kernel_timing",
     "sfm_ctx_kernel_timing_read", "sfm_device_alloc", "sfm_device_free", "sfm_copy_to_device", "sfm_copy_to_host",
-    "sfm_copy_to_host_2d", "sfm_find_homography", "sfm_match", "sfm_match_soa",
+    "sfm_copy_to_host_2d", "sfm_find_homography", "sfm_sift_temp_layout", "sfm_extract_sift", "sfm_match", "sfm_match_soa",
     "sfm_pair_create", "sfm_pair_destroy", "sfm_fill_xu", "sfm_set_points", "sfm_ransac_default_params",
     "sfm_ransac_permutation_indices", "sfm_estimate_E", "sfm_ransac_score", "sfm_ransac_finalize",
     "sfm_ransac_finalize_key", "sfm_ransac_export_key", "sfm_pose_candidates", "sfm_choose_pose", "sfm_triangulate",
@@ -79,6 +79,16 @@ _lib.sfm_ctx_timer_start.argtypes = [_vp]
 _lib.sfm_ctx_timer_stop.argtypes = [_vp, C.POINTER(C.c_float)]
 _lib.sfm_ctx_kernel_timing.argtypes = [_vp, C.c_int]
 _lib.sfm_ctx_kernel_timing_read.argtypes = [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int)]
+class SiftLayout(C.Structure):
+    """sfm_sift_layout: where every pyramid level and DoG plane lives inside the temp memory (floats)."""
+    _fields_ = [("num_octaves", C.c_int32), ("width", C.c_int32 * 8), ("height", C.c_int32 * 8), ("pitch", C.c_int32 * 8),
+                ("image_offset", C.c_int64 * 8), ("dog_offset", C.c_int64 * 8), ("up_offset", C.c_int64),
+                ("total_floats", C.c_int64)]
+
+
+_lib.sfm_sift_temp_layout.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(SiftLayout)]
+_lib.sfm_extract_sift.argtypes = [_vp, _vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_float, C.c_float,
+                                  C.c_int, _vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
 _lib.sfm_find_homography.argtypes = [_vp, _vp, C.c_int, _vp, C.POINTER(C.c_int), C.c_int, C.c_float, C.c_float,
                                      C.c_float, C.c_uint32, _vp, _vp, _vp]
 _lib.sfm_match.argtypes = [_vp, _vp, C.c_int, _vp, C.c_int]
@@ -151,6 +161,12 @@ def default_params(num_points, **kw):
     return p
 
 
+def sift_temp_layout(width, height, num_octaves=5, scale_up=False):
+    L = SiftLayout()
+    _check(_lib.sfm_sift_temp_layout(int(width), int(height), int(num_octaves), int(bool(scale_up)), C.byref(L)), "sfm_sift_temp_layout")
+    return L
+
+
 def pack_key(count, hyp):
     """(count << 32) | (0xFFFFFFFF - hyp): max() picks the highest count, lowest id on ties
     (thrust::max_element first-maximum rule, reference sfm.cu:135-137)."""
@@ -211,6 +227,15 @@ class Context:
     def match_soa(self, d1, n1, ld1, d2, n2, ld2, best, second, index):
         _check(_lib.sfm_match_soa(self._h, _ptr(d1), int(n1), int(ld1), _ptr(d2), int(n2), int(ld2),
                                   _ptr(best), _ptr(second), _ptr(index)), "sfm_match_soa")
+
+    def extract_sift(self, d_sift, max_pts, d_image, width, height, pitch, num_octaves=5, init_blur=1.0, thresh=3.0,
+                     lowest_scale=0.0, scale_up=False, d_temp=None):
+        """ExtractSift (cudaSiftH.cu:72-147) on device buffers -> (numPts, stored)."""
+        n, st = C.c_int(), C.c_int()
+        _check(_lib.sfm_extract_sift(self._h, _ptr(d_sift), int(max_pts), _ptr(d_image), int(width), int(height), int(pitch),
+                                     int(num_octaves), float(init_blur), float(thresh), float(lowest_scale), int(bool(scale_up)),
+                                     _ptr(d_temp), C.byref(n), C.byref(st)), "sfm_extract_sift")
+        return n.value, st.value
 
     def find_homography(self, d_sift, num_pts, num_loops=1000, min_score=0.85, max_ambiguity=0.95, thresh=5.0,
                         seed=0, pts=None, want_all=False):

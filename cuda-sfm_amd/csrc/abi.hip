@@ -87,6 +87,8 @@ int sfm_ctx_destroy(sfm_ctx *ctx)
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->match_ws) (void)hipFree(ctx->match_ws);
     if (ctx->homo_ws) (void)hipFree(ctx->homo_ws);
+    if (ctx->sift_temp) (void)hipFree(ctx->sift_temp);
+    if (ctx->sift_ws) (void)hipFree(ctx->sift_ws);
     for (auto &t : ctx->tev) for (hipEvent_t e : t) if (e) (void)hipEventDestroy(e);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -225,6 +227,32 @@ int sfm_match_soa(sfm_ctx *ctx, const float *d_desc1, int n1, int ld1, const flo
     SFM_REQUIRE(((uintptr_t)d_desc1 & 15) == 0 && ((uintptr_t)d_desc2 & 15) == 0, SFM_E_INVALID, "descriptor rows must be 16-byte aligned");
     SFM_HIP_TRY(hipSetDevice(ctx->device));
     return launch_match(ctx, d_desc1, n1, ld1, d_desc2, n2, ld2, d_best, d_second, d_index, nullptr, nullptr);
+}
+
+// ---- ExtractSift ---------------------------------------------------------------------------------
+int sfm_sift_temp_layout(int width, int height, int num_octaves, int scale_up, sfm_sift_layout *layout)
+{
+    SFM_REQUIRE(layout, SFM_E_INVALID, "null layout");
+    SFM_REQUIRE(width > 0 && height > 0 && width <= 16384 && height <= 16384, SFM_E_INVALID, "image size %d x %d", width, height);
+    SFM_REQUIRE(num_octaves >= 1 && num_octaves <= 7, SFM_E_INVALID, "num_octaves %d outside 1..7", num_octaves);
+    sift_layout(width, height, num_octaves, scale_up, layout);
+    return SFM_OK;
+}
+
+int sfm_extract_sift(sfm_ctx *ctx, sfm_sift_point *d_sift, int max_pts, const float *d_image, int width, int height,
+                     int pitch, int num_octaves, double init_blur, float thresh, float lowest_scale, int scale_up,
+                     float *d_temp, int *num_pts, int *num_stored)
+{
+    SFM_REQUIRE(ctx && d_sift && d_image && num_pts, SFM_E_INVALID, "null argument");
+    SFM_REQUIRE(width > 0 && height > 0 && width <= 16384 && height <= 16384 && pitch >= width, SFM_E_INVALID,
+                "image %d x %d pitch %d", width, height, pitch);
+    SFM_REQUIRE(num_octaves >= 1 && num_octaves <= 7, SFM_E_INVALID, "num_octaves %d outside 1..7", num_octaves);
+    SFM_REQUIRE(max_pts > 0, SFM_E_INVALID, "max_pts %d", max_pts);
+    *num_pts = 0;
+    if (num_stored) *num_stored = 0;
+    SFM_HIP_TRY(hipSetDevice(ctx->device));
+    return launch_extract_sift(ctx, d_sift, max_pts, d_image, width, height, pitch, num_octaves, init_blur, thresh, lowest_scale,
+                               scale_up ? 1 : 0, d_temp, num_pts, num_stored);
 }
 
 // ---- FindHomography ------------------------------------------------------------------------------

@@ -43,6 +43,10 @@ struct sfm_ctx {
     size_t match_ws_bytes = 0;
     void *homo_ws = nullptr;           // homography RANSAC scratch
     size_t homo_ws_bytes = 0;
+    void *sift_temp = nullptr;         // pyramid + DoG planes when the caller passes no temp memory
+    size_t sift_temp_bytes = 0;
+    void *sift_ws = nullptr;           // counters, candidates, secondary orientations
+    size_t sift_ws_bytes = 0;
 };
 
 struct sfm_pair {
@@ -95,6 +99,11 @@ int launch_pose_candidates(sfm_pair *pair, int mode);
 int launch_choose_pose(sfm_pair *pair, int mode);
 int launch_triangulate(sfm_pair *pair, int mode);
 
+// sift.hip
+void sift_layout(int width, int height, int num_octaves, int scale_up, sfm_sift_layout *L);
+int launch_extract_sift(sfm_ctx *ctx, sfm_sift_point *d_sift, int max_pts, const float *d_image, int width, int height, int pitch,
+                        int num_octaves, double init_blur, float thresh, float lowest_scale, int scale_up, float *d_temp,
+                        int *num_pts, int *num_stored);
 // homography.hip
 int launch_homography(sfm_ctx *ctx, const sfm_sift_point *d_sift, int n, const int *h_pts, int L, float thresh,
                       float h_H[9], int *num_matches, int *h_counts, float *h_homo);

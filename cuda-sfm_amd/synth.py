@@ -142,6 +142,49 @@ def homography_scene(n, seed=SEED, noise_px=0.7, outlier_frac=0.35, width=1920, 
     return {"sift": s, "H": H.astype(np.float32), "outlier": out}
 
 
+def image(width=640, height=480, seed=SEED, blobs=400, shift=(0.0, 0.0)):
+    """8-bit-valued float image (what cv::imread(...,0).convertTo(CV_32FC1) hands to CudaImage): random
+    Gaussian blobs of both polarities and a few oriented bars on a ramp -- rich in DoG extrema at every
+    octave.  `shift` translates the content (second view of the same scene)."""
+    yy, xx = np.mgrid[0:height, 0:width].astype(np.float64)
+    xx = xx - shift[0]; yy = yy - shift[1]
+    img = 110.0 + 0.03 * xx + 0.02 * yy
+    cx = width * uniform01(seed, blobs, 50); cy = height * uniform01(seed, blobs, 51)
+    sg = 1.2 * np.exp(3.0 * uniform01(seed, blobs, 52))                # 1.2 .. 24 px
+    am = 90.0 * (uniform01(seed, blobs, 53) - 0.5)
+    el = 0.6 + 0.8 * uniform01(seed, blobs, 54); th = np.pi * uniform01(seed, blobs, 55)
+    for i in range(blobs):
+        r = int(4 * sg[i] * max(el[i], 1.0)) + 2
+        x0, x1 = max(0, int(cx[i] + shift[0]) - r), min(width, int(cx[i] + shift[0]) + r + 1)
+        y0, y1 = max(0, int(cy[i] + shift[1]) - r), min(height, int(cy[i] + shift[1]) + r + 1)
+        if x0 >= x1 or y0 >= y1:
+            continue
+        dx = xx[y0:y1, x0:x1] - cx[i]; dy = yy[y0:y1, x0:x1] - cy[i]
+        u = np.cos(th[i]) * dx + np.sin(th[i]) * dy; v = -np.sin(th[i]) * dx + np.cos(th[i]) * dy
+        img[y0:y1, x0:x1] += am[i] * np.exp(-0.5 * ((u / (sg[i] * el[i])) ** 2 + (v / sg[i]) ** 2))
+    # hard-edged discs and rotated boxes: sharp structure for the two finest octaves
+    nd = 3 * blobs
+    dx_ = width * uniform01(seed, nd, 56); dy_ = height * uniform01(seed, nd, 57)
+    rad = 1.5 * np.exp(2.2 * uniform01(seed, nd, 58))                   # 1.5 .. 13.5 px
+    amp = 30.0 + 70.0 * uniform01(seed, nd, 59)
+    amp = np.where(uniform01(seed, nd, 60) < 0.5, -amp, amp)
+    box = uniform01(seed, nd, 61) < 0.4; ang = np.pi * uniform01(seed, nd, 62)
+    for i in range(nd):
+        r = int(1.5 * rad[i]) + 3
+        x0, x1 = max(0, int(dx_[i] + shift[0]) - r), min(width, int(dx_[i] + shift[0]) + r + 1)
+        y0, y1 = max(0, int(dy_[i] + shift[1]) - r), min(height, int(dy_[i] + shift[1]) + r + 1)
+        if x0 >= x1 or y0 >= y1:
+            continue
+        ex = xx[y0:y1, x0:x1] - dx_[i]; ey = yy[y0:y1, x0:x1] - dy_[i]
+        if box[i]:
+            u = np.cos(ang[i]) * ex + np.sin(ang[i]) * ey; v = -np.sin(ang[i]) * ex + np.cos(ang[i]) * ey
+            d = np.maximum(np.abs(u), np.abs(v) * 1.4) - rad[i]
+        else:
+            d = np.hypot(ex, ey) - rad[i]
+        img[y0:y1, x0:x1] += amp[i] * np.clip(0.5 - d, 0.0, 1.0)           # one-pixel anti-aliased edge
+    return np.clip(np.rint(img), 0, 255).astype(np.float32)
+
+
 def sift_records(desc, seed=SEED, width=720, height=576, stream=30):
     """Wrap a descriptor matrix into SiftPoint records with random keypoint positions."""
     n = desc.shape[0]

@@ -88,6 +88,31 @@ int sfm_match_soa(sfm_ctx *ctx, const float *d_desc1, int n1, int ld1,
                   const float *d_desc2, int n2, int ld2,
                   float *d_best, float *d_second, int32_t *d_index);
 
+/* ---- SIFT extraction: ExtractSift (CudaSift/cudaSiftH.cu:72-232; cudaSift.h:37-39) ---------------------
+ * d_image: height x pitch floats on the device (8-bit grey values as float, what CudaImage::Download
+ * uploads).  Builds the pyramid (optional 2x upsampling, low pass init_blur, num_octaves levels),
+ * finds DoG extrema above thresh with scale >= lowest_scale, assigns one or two orientations and writes
+ * xpos, ypos, scale, sharpness, edgeness, orientation, subsampling and the 128-d descriptor of every
+ * point into d_sift (other fields untouched).  *num_pts = the count the reference reports
+ * (cudaSiftH.cu:123; excludes the finest octave's secondary orientations), *num_stored (optional) =
+ * records written, both clipped to max_pts.  Points come coarsest octave first; within an octave in
+ * (y, x, scale) order, secondary orientations after them in parent order -- deterministic, unlike the
+ * reference's atomic append.  d_temp: sfm_sift_temp_layout(...).total_floats floats, or NULL to use a
+ * buffer owned by the context; afterwards it holds every pyramid level and DoG plane at the offsets of
+ * the layout.  1 <= num_octaves <= 7.  Synchronous. */
+typedef struct {
+    int32_t num_octaves;
+    int32_t width[8], height[8], pitch[8];   /* level 0 = full (or upsampled) resolution; pitch in floats */
+    int64_t image_offset[8];                 /* low-passed image of every level, floats from d_temp */
+    int64_t dog_offset[8];                   /* 7 DoG planes (height x pitch each) of every level */
+    int64_t up_offset;                       /* upsampled input when scale_up */
+    int64_t total_floats;
+} sfm_sift_layout;
+int sfm_sift_temp_layout(int width, int height, int num_octaves, int scale_up, sfm_sift_layout *layout);
+int sfm_extract_sift(sfm_ctx *ctx, sfm_sift_point *d_sift, int max_pts, const float *d_image, int width, int height,
+                     int pitch, int num_octaves, double init_blur, float thresh, float lowest_scale, int scale_up,
+                     float *d_temp, int *num_pts, int *num_stored);
+
 /* ---- homography RANSAC pre-filter: FindHomography (matching.cu:1000-1087) -------------------------
  * 4-point DLT hypotheses from the matched records of d_sift (xpos, ypos -> match_xpos, match_ypos),
  * sampled among the points with score > min_score and ambiguity < max_ambiguity; a point supports a

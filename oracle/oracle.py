@@ -323,6 +323,112 @@ def improve_homography(sift, H, num_loops, min_score, max_ambiguity, thresh):
     return int((err < limit).sum()), out, np.sqrt(err).astype(f32)
 
 
+# ---- ExtractSift (sift_oracle.c) --------------------------------------------------------------------
+def _img(a):
+    a = np.ascontiguousarray(a, np.float32)
+    assert a.ndim == 2
+    return a
+
+
+def sift_tables(num_octaves):
+    """(laplace kernel table float[8*12*16], scaledown taps[5]) as the reference's host code builds them."""
+    kt = np.zeros(8 * 12 * 16, np.float32); k5 = np.zeros(5, np.float32)
+    _L.orc_sift_laplace_kernels.argtypes = [C.c_int, C.c_float, f32p]
+    _L.orc_sift_laplace_kernels(int(num_octaves), 0.0, _fp(kt))
+    _L.orc_sift_scaledown_kernel.argtypes = [C.c_float, f32p]
+    _L.orc_sift_scaledown_kernel(0.5, _fp(k5))
+    return kt, k5
+
+
+def sift_lowpass_taps(scale):
+    k = np.zeros(9, np.float32)
+    _L.orc_sift_lowpass_kernel.argtypes = [C.c_float, f32p]
+    _L.orc_sift_lowpass_kernel(float(scale), _fp(k))
+    return k
+
+
+def sift_lowpass(img, taps):
+    img = _img(img); out = np.zeros_like(img)
+    _L.orc_sift_lowpass.argtypes = [f32p, C.c_int, C.c_int, C.c_int, f32p, C.c_int, f32p]
+    _L.orc_sift_lowpass(_fp(img), img.shape[1], img.shape[0], img.shape[1], _fp(out), img.shape[1], _fp(_f32(taps)))
+    return out
+
+
+def sift_scaledown(img, taps):
+    img = _img(img); out = np.zeros((img.shape[0] // 2, img.shape[1] // 2), np.float32)
+    _L.orc_sift_scaledown.argtypes = [f32p, C.c_int, C.c_int, C.c_int, f32p, C.c_int, f32p]
+    _L.orc_sift_scaledown(_fp(img), img.shape[1], img.shape[0], img.shape[1], _fp(out), out.shape[1], _fp(_f32(taps)))
+    return out
+
+
+def sift_scaleup(img):
+    img = _img(img); out = np.zeros((img.shape[0] * 2, img.shape[1] * 2), np.float32)
+    _L.orc_sift_scaleup.argtypes = [f32p, C.c_int, C.c_int, C.c_int, f32p, C.c_int]
+    _L.orc_sift_scaleup(_fp(img), img.shape[1], img.shape[0], img.shape[1], _fp(out), out.shape[1])
+    return out
+
+
+def sift_laplace(img, kern8x16):
+    """-> DoG planes (7, h, w)"""
+    img = _img(img); h, w = img.shape
+    out = np.zeros((7, h, w), np.float32)
+    _L.orc_sift_laplace.argtypes = [f32p, C.c_int, C.c_int, C.c_int, f32p, C.c_int, f32p]
+    _L.orc_sift_laplace(_fp(img), w, h, w, _fp(out), w, _fp(_f32(kern8x16)))
+    return out
+
+
+def sift_find_points(dog, subsampling, lowest_scale, thresh, max_pts=32768, factor=0.2, edge_limit=10.0):
+    dog = np.ascontiguousarray(dog, np.float32); _, h, w = dog.shape
+    pts = np.zeros(max_pts, SIFT_DTYPE); cnt = C.c_int(0)
+    _L.orc_sift_find_points.argtypes = [f32p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
+                                        C.c_void_p, C.POINTER(C.c_int), C.c_int]
+    _L.orc_sift_find_points(_fp(dog), w, h, w, float(subsampling), float(lowest_scale), float(thresh), float(factor),
+                            float(edge_limit), pts.ctypes.data_as(C.c_void_p), C.byref(cnt), int(max_pts))
+    return pts[:min(cnt.value, max_pts)], cnt.value
+
+
+def sift_orientation(img, x, y, scale):
+    img = _img(img); ori = np.zeros(2, np.float32)
+    _L.orc_sift_orientation.argtypes = [f32p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, f32p]
+    two = _L.orc_sift_orientation(_fp(img), img.shape[1], img.shape[0], img.shape[1], float(x), float(y), float(scale), _fp(ori))
+    return ori[:2] if two else ori[:1]
+
+
+def sift_descriptor(img, x, y, scale, orientation):
+    img = _img(img); d = np.zeros(128, np.float32)
+    _L.orc_sift_descriptor.argtypes = [f32p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, f32p]
+    _L.orc_sift_descriptor(_fp(img), img.shape[1], img.shape[0], img.shape[1], float(x), float(y), float(scale), float(orientation), _fp(d))
+    return d
+
+
+def sift_math(name, *args):
+    """elementary functions of the extractor: exp2f, expf, atan2f, fast_atan2f, tex (img, x, y), sincosf"""
+    if name == "sincosf":
+        s, c = C.c_float(), C.c_float()
+        _L.orc_sift_sincosf.argtypes = [C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        _L.orc_sift_sincosf(float(args[0]), C.byref(s), C.byref(c))
+        return np.float32(s.value), np.float32(c.value)
+    if name == "tex":
+        img = _img(args[0])
+        _L.orc_sift_tex.argtypes = [f32p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float]; _L.orc_sift_tex.restype = C.c_float
+        return np.float32(_L.orc_sift_tex(_fp(img), img.shape[1], img.shape[1], img.shape[0], float(args[1]), float(args[2])))
+    f = getattr(_L, "orc_sift_" + name)
+    f.argtypes = [C.c_float] * len(args); f.restype = C.c_float
+    return np.float32(f(*[float(a) for a in args]))
+
+
+def extract_sift(image, num_octaves=5, init_blur=1.0, thresh=3.0, lowest_scale=0.0, scale_up=False, max_pts=32768):
+    """ExtractSift (cudaSiftH.cu:72-147) -> (records[:numPts], numPts, stored) ; stored >= numPts counts the
+    records that carry a descriptor (incl. the finest octave's secondary orientations)."""
+    image = _img(image); h, w = image.shape
+    pts = np.zeros(max_pts, SIFT_DTYPE); stored = C.c_int(0)
+    _L.orc_extract_sift.argtypes = [f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_float, C.c_float, C.c_int,
+                                    C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+    n = _L.orc_extract_sift(_fp(image), w, h, w, int(num_octaves), float(init_blur), float(thresh), float(lowest_scale),
+                            int(bool(scale_up)), pts.ctypes.data_as(C.c_void_p), int(max_pts), C.byref(stored))
+    return pts[:stored.value], int(n), int(stored.value)
+
+
 # ---- in-place builds of the reference (oracle/_ref), optional ---------------------------------
 def ref_available(name):
     return os.path.exists(os.path.join(_REF, name))

@@ -14,7 +14,13 @@
 #                       CudaSift/matching.cu CleanMatches + FindMaxCorr10 (the live matcher, :289-397),
 #                       built with -ffp-contract=fast (nvcc's default fmad, which fuses :347-350);
 #                       CudaSift/matching.cu InvertMatrix<8> + ComputeHomographies + TestHomographies
-#                       (:821-996, the FindHomography kernels), built with -ffp-contract=off.
+#                       (:821-996, the FindHomography kernels), built with -ffp-contract=off;
+#                       CudaSift/cudaSiftD.cu ScaleDown (:84-169), ScaleUp (:171-194), LaplaceMultiMem
+#                       (:1753-1790), LowPassBlock (:1986-2038) + the ShiftDown template of cudautils.h,
+#                       built with -ffp-contract=off (with "fast" the compiler fuses the same source
+#                       expression differently at different unroll sites).  The other live SIFT kernels
+#                       cannot be built for gfx950: FindPointsMultiNew needs __any_sync with a 32-bit
+#                       mask, ComputeOrientationsCONST / ExtractSiftDescriptorsCONSTNew need tex2D.
 # Launch geometry in ref_driver_gpu.inc follows the reference's call sites (cited there).
 set -eu
 REF="${1:-/root/reference}"
@@ -61,9 +67,31 @@ he=$(grep -n '^//================= Host matching functions' "$M" | cut -d: -f1)
   cat "$HERE/ref_driver_homo_gpu.inc"
 } > "$TMP/ref_homo.hip"
 
+D="$REF/CudaSift/cudaSiftD.cu"; U="$REF/CudaSift/cudautils.h"
+cb=$(grep -n '^__constant__ int d_MaxNumPoints' "$D" | cut -d: -f1)
+ce=$(grep -n '^__constant__ float d_LaplaceKernel' "$D" | cut -d: -f1)
+sdb=$(grep -n '^__global__ void ScaleDown(float' "$D" | cut -d: -f1)
+sub=$(grep -n '^__global__ void ScaleUp(float' "$D" | cut -d: -f1)
+sue=$(grep -n '^__global__ void ExtractSiftDescriptors(cudaTextureObject_t' "$D" | cut -d: -f1)
+lmb=$(grep -n '^__global__ void LaplaceMultiMem(float' "$D" | cut -d: -f1)
+lme=$(grep -n '^__global__ void LaplaceMultiMemWide(float' "$D" | cut -d: -f1)
+lpb=$(grep -n '^__global__ void LowPassBlock(float' "$D" | cut -d: -f1)
+shd=$(grep -n 'T ShiftDown(T var' "$U" | cut -d: -f1)
+{
+  echo '#include <hip/hip_runtime.h>'
+  echo "#include \"$REF/CudaSift/cudaSiftD.h\""                           # tile constants: the reference's own header
+  sed -n "$((shd - 1)),$((shd + 7))p" "$U"                                 # template ShiftDown (pre-CUDA-9 branch: __shfl_down)
+  sed -n "${cb},${ce}p" "$D"                                              # __constant__ tables
+  sed -n "${sdb},$((sue - 1))p" "$D"                                      # ScaleDown, ScaleUp
+  sed -n "${lmb},$((lme - 1))p" "$D"                                      # LaplaceMultiMem
+  sed -n "${lpb},\$p" "$D"                                                # LowPassBlock (to end of file)
+  cat "$HERE/ref_driver_sift_gpu.inc"
+} > "$TMP/ref_sift.hip"
+
 HIPCC=/opt/rocm/bin/hipcc
 $HIPCC --offload-arch=gfx950 -O2 -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fPIC -w -c "$TMP/ref_kernels.hip" -o "$TMP/a.o"
 $HIPCC --offload-arch=gfx950 -O2 -ffp-contract=fast -fPIC -w -c "$TMP/ref_matchk.hip" -o "$TMP/b.o"
 $HIPCC --offload-arch=gfx950 -O2 -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -DOCML_BASIC_ROUNDED_OPERATIONS -fPIC -w -c "$TMP/ref_homo.hip" -o "$TMP/c.o"
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT/libref_kernels.so" "$TMP/a.o" "$TMP/b.o" "$TMP/c.o"
+$HIPCC --offload-arch=gfx950 -O2 -ffp-contract=off -fPIC -w -c "$TMP/ref_sift.hip" -o "$TMP/d.o"
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT/libref_kernels.so" "$TMP/a.o" "$TMP/b.o" "$TMP/c.o" "$TMP/d.o"
 echo "ref_build_gpu: wrote $OUT/libref_kernels.so"

@@ -109,6 +109,29 @@ void orc_homography_sample(uint32_t seed, uint32_t loop, uint32_t nvalid, uint32
 int  orc_find_homography(const orc_sift_point *s, int n, int num_loops, float min_score, float max_ambiguity,
                          float thresh, uint32_t seed, float H[9], int *counts, float *homo);
 
+/* ---- ExtractSift (CudaSift/cudaSiftH.cu:72-232 + live kernels of cudaSiftD.cu).
+ * Implemented in sift_oracle.c; see its header for pinning status and the documented differences. ---- */
+float orc_sift_exp2f(float t);
+float orc_sift_expf(float x);
+float orc_sift_atan2f(float y, float x);
+float orc_sift_fast_atan2f(float y, float x);                       /* cudaSiftD.cu:296-306 */
+void  orc_sift_sincosf(float th, float *sn, float *cs);
+float orc_sift_tex(const float *img, int pitch, int w, int h, float x, float y);
+void  orc_sift_lowpass_kernel(float scale, float k[9]);             /* cudaSiftH.cu:422-431 */
+void  orc_sift_scaledown_kernel(float variance, float k[5]);        /* cudaSiftH.cu:316-323 */
+void  orc_sift_laplace_kernels(int numOctaves, float initBlur, float *kernel /* 8*12*16 */);
+void  orc_sift_lowpass(const float *src, int w, int h, int ps, float *dst, int pd, const float k[9]);
+void  orc_sift_scaledown(const float *src, int w, int h, int ps, float *dst, int pd, const float k[5]);
+void  orc_sift_scaleup(const float *src, int w, int h, int ps, float *dst, int pd);
+void  orc_sift_laplace(const float *img, int w, int h, int pi, float *dog, int pd, const float *kern);
+void  orc_sift_find_points(const float *dog, int w, int h, int pd, float subsampling, float lowestScale,
+                           float thresh, float factor, float edgeLimit, orc_sift_point *pts, int *count, int maxPts);
+int   orc_sift_orientation(const float *img, int w, int h, int pitch, float xpos, float ypos, float scale, float ori[2]);
+void  orc_sift_descriptor(const float *img, int w, int h, int pitch, float xpos, float ypos, float scale,
+                          float orientation, float desc[128]);
+int   orc_extract_sift(const float *image, int width, int height, int pitch, int numOctaves, double initBlur,
+                       float thresh, float lowestScale, int scaleUp, orc_sift_point *pts, int maxPts, int *total_stored);
+
 int orc_abi_version(void);
 
 #ifdef __cplusplus

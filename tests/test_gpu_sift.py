@@ -1,0 +1,166 @@
+"""GPU: ExtractSift (reference CudaSift/cudaSiftH.cu:72-232 + cudaSiftD.cu).
+ - the oracle's image kernels against the REFERENCE'S OWN ScaleDown / ScaleUp / LowPassBlock /
+   LaplaceMultiMem compiled for gfx950 from cudaSiftD.cu in place (oracle/_ref) -- bit-exact;
+ - the product (sfm_extract_sift through the C ABI) against the oracle: every pyramid level, every DoG
+   plane and every field of every record, bit for bit, in the same (deterministic) order."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import cuda_sfm_amd as S
+import oracle as O
+from cuda_sfm_amd_synth import synth
+from helpers import same_bits
+
+pytestmark = pytest.mark.gpu
+FIELDS = ("xpos", "ypos", "scale", "sharpness", "edgeness", "orientation", "subsampling", "data")
+
+
+def align(a, b=128):
+    return (a + b - 1) // b * b
+
+
+def padded(img, pitch):
+    out = np.zeros((img.shape[0], pitch), np.float32)
+    out[:, :img.shape[1]] = img
+    return out
+
+
+@pytest.fixture(scope="module")
+def R():
+    if not O.ref_available("libref_kernels.so"):
+        pytest.skip("oracle/_ref/libref_kernels.so not built")
+    lib = O.ref_lib("libref_kernels.so")
+    f, i = O.f32p, C.c_int
+    lib.refk_sift_lowpass.argtypes = [f, f, i, i, i, f]
+    lib.refk_sift_scaledown.argtypes = [f, i, i, i, f, i, f]
+    lib.refk_sift_scaleup.argtypes = [f, i, i, i, f, i]
+    lib.refk_sift_laplace.argtypes = [f, i, i, i, f, i, f]
+    return lib
+
+
+def fp(a):
+    return a.ctypes.data_as(O.f32p)
+
+
+@pytest.mark.parametrize("w,h", [(640, 480), (301, 203), (130, 67)])
+def test_oracle_matches_reference_image_kernels(gpu, R, w, h):
+    img = synth.image(w, h, seed=5 + w, blobs=60)
+    p = align(w)
+    src = padded(img, p)
+    # LowPassBlock
+    for blur in (1.0, 1.5, 0.001):
+        k9 = O.sift_lowpass_taps(blur)
+        got = np.zeros_like(src)
+        assert R.refk_sift_lowpass(fp(src), fp(got), w, p, h, fp(k9)) == 0
+        assert same_bits(got[:, :w], O.sift_lowpass(img, k9))
+    # ScaleDown
+    kt, k5 = O.sift_tables(5)
+    p2 = align(w // 2)
+    got = np.zeros((h // 2, p2), np.float32)
+    assert R.refk_sift_scaledown(fp(src), w, p, h, fp(got), p2, fp(k5)) == 0
+    assert same_bits(got[:, :w // 2], O.sift_scaledown(img, k5))
+    # ScaleUp
+    pu = align(2 * w)
+    got = np.zeros((2 * h, pu), np.float32)
+    assert R.refk_sift_scaleup(fp(src), w, p, h, fp(got), pu) == 0
+    assert same_bits(got[:, :2 * w], O.sift_scaleup(img))
+    # LaplaceMultiMem, every octave slot of the table
+    low = O.sift_lowpass(img, O.sift_lowpass_taps(1.0))
+    lsrc = padded(low, p)
+    for octave in (5, 3, 1):
+        got = np.zeros((7, h, p), np.float32)
+        assert R.refk_sift_laplace(fp(lsrc), w, p, h, fp(got), octave, fp(kt)) == 0
+        assert same_bits(got[:, :, :w], O.sift_laplace(low, kt.reshape(8, 192)[octave][:128]))
+
+
+def run_product(gpu, img, max_pts=32768, **kw):
+    torch, dev, ctx = gpu
+    h, w = img.shape
+    p = align(w)
+    d_img = torch.from_numpy(padded(img, p)).to(dev)
+    d_sift = torch.zeros((max_pts, 576), dtype=torch.uint8, device=dev)
+    L = S.sift_temp_layout(w, h, kw.get("num_octaves", 5), kw.get("scale_up", False))
+    d_temp = torch.zeros(L.total_floats, dtype=torch.float32, device=dev)
+    n, stored = ctx.extract_sift(d_sift, max_pts, d_img, w, h, p, d_temp=d_temp, **kw)
+    rec = d_sift.cpu().numpy().view(O.SIFT_DTYPE).reshape(-1)
+    return rec, n, stored, L, d_temp.cpu().numpy()
+
+
+@pytest.mark.parametrize("w,h,octaves", [(640, 480, 5), (301, 203, 4), (130, 67, 2)])
+def test_pyramid_and_dog_match_oracle(gpu, w, h, octaves):
+    img = synth.image(w, h, seed=9 + w, blobs=80)
+    _, _, _, L, temp = run_product(gpu, img, num_octaves=octaves, init_blur=1.0, thresh=3.0)
+    kt, k5 = O.sift_tables(octaves)
+    level = O.sift_lowpass(img, O.sift_lowpass_taps(1.0))
+    for l in range(octaves):
+        wl, hl, pl = L.width[l], L.height[l], L.pitch[l]
+        assert (wl, hl) == (w >> l, h >> l) and pl == align(wl)
+        got = temp[L.image_offset[l]: L.image_offset[l] + pl * hl].reshape(hl, pl)[:, :wl]
+        assert same_bits(got, level), f"pyramid level {l}"
+        dog = temp[L.dog_offset[l]: L.dog_offset[l] + 7 * pl * hl].reshape(7, hl, pl)[:, :, :wl]
+        assert same_bits(dog, O.sift_laplace(level, kt.reshape(8, 192)[octaves - l][:128])), f"DoG level {l}"
+        if l + 1 < octaves:
+            level = O.sift_scaledown(level, k5)
+
+
+@pytest.mark.parametrize("w,h,kw", [
+    (640, 480, dict(num_octaves=5, init_blur=1.0, thresh=3.0)),
+    (301, 203, dict(num_octaves=4, init_blur=1.5, thresh=1.0)),          # main.cpp:270-276 settings
+    (320, 240, dict(num_octaves=3, init_blur=1.0, thresh=2.0, scale_up=True)),
+    (400, 300, dict(num_octaves=5, init_blur=1.0, thresh=3.0, lowest_scale=2.5)),
+    (130, 67, dict(num_octaves=1, init_blur=0.0, thresh=1.5)),
+])
+def test_extract_matches_oracle(gpu, w, h, kw):
+    img = synth.image(w, h, seed=21 + w, blobs=max(40, w * h // 800))
+    rec, n, stored, _, _ = run_product(gpu, img, **kw)
+    opts, on, ostored = O.extract_sift(img, kw.get("num_octaves", 5), kw.get("init_blur", 1.0), kw.get("thresh", 3.0),
+                                       kw.get("lowest_scale", 0.0), kw.get("scale_up", False))
+    assert (n, stored) == (on, ostored)
+    assert n > 20, "scene too poor to test anything"
+    for f in FIELDS:
+        assert same_bits(rec[f][:stored], opts[f][:stored]), f
+    assert not rec["data"][stored:].any()                              # nothing written past the stored records
+    assert not np.isnan(rec["data"][:stored]).any()
+
+
+def test_max_pts_clips_like_the_reference(gpu):
+    img = synth.image(640, 480, seed=3, blobs=500)
+    full, n_full, stored_full, _, _ = run_product(gpu, img, num_octaves=5, thresh=2.0)
+    assert n_full > 1500
+    cap = 1000
+    rec, n, stored, _, _ = run_product(gpu, img, max_pts=cap, num_octaves=5, thresh=2.0)
+    assert n == cap and stored == cap                                   # cudaSiftH.cu:124
+    # coarse octaves come first and fit: identical to the uncapped run up to the octave that overflows
+    sub = full["subsampling"][:cap]
+    last_full_octave = sub[np.flatnonzero(np.diff(sub))[-1]] if np.any(np.diff(sub)) else None
+    keep = np.flatnonzero(full["subsampling"][:cap] >= last_full_octave)
+    for f in ("xpos", "ypos", "scale", "orientation"):
+        assert same_bits(rec[f][keep], full[f][keep]), f
+
+
+def test_deterministic_and_stream_reuse(gpu):
+    img = synth.image(512, 384, seed=8)
+    a, na, sa, _, _ = run_product(gpu, img, thresh=2.0)
+    b, nb, sb, _, _ = run_product(gpu, img, thresh=2.0)
+    assert (na, sa) == (nb, sb) and a.tobytes() == b.tobytes()
+    torch, dev, ctx = gpu
+    p = align(512)
+    d_img = torch.from_numpy(padded(img, p)).to(dev)
+    d_sift = torch.zeros((32768, 576), dtype=torch.uint8, device=dev)
+    n, stored = ctx.extract_sift(d_sift, 32768, d_img, 512, 384, p, thresh=2.0)     # context-owned temp memory
+    c = d_sift.cpu().numpy().view(O.SIFT_DTYPE).reshape(-1)
+    assert (n, stored) == (na, sa) and c[:stored].tobytes() == a[:stored].tobytes()
+
+
+def test_argument_checks(gpu):
+    torch, dev, ctx = gpu
+    d_img = torch.zeros((64, 128), dtype=torch.float32, device=dev)
+    d_sift = torch.zeros((64, 576), dtype=torch.uint8, device=dev)
+    with pytest.raises(S.SfmError):
+        ctx.extract_sift(d_sift, 64, d_img, 100, 64, 128, num_octaves=8)
+    with pytest.raises(S.SfmError):
+        ctx.extract_sift(d_sift, 64, d_img, 100, 64, 64)                # pitch < width
+    n, stored = ctx.extract_sift(d_sift, 64, d_img, 100, 64, 128)       # flat image: nothing found
+    assert (n, stored) == (0, 0)
