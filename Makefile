@@ -15,11 +15,12 @@ HDRS     := $(wildcard $(CSRC)/*.hpp) include/sfm_amd.h
 
 DEMO     := $(PKG)/host/two_view_demo
 HDEMO    := $(PKG)/host/homography_demo
+SDEMO    := $(PKG)/host/sift_demo
 
 IOTEST   := tests/cpp/io_test
 GEOMTEST := tests/cpp/geom_test
 
-all: $(LIB) oracle hostcheck $(DEMO) $(HDEMO) $(IOTEST) $(GEOMTEST)
+all: $(LIB) oracle hostcheck $(DEMO) $(HDEMO) $(SDEMO) $(IOTEST) $(GEOMTEST)
 
 $(BUILD)/%.o: $(CSRC)/%.hip $(HDRS)
 	@mkdir -p $(BUILD)
@@ -39,6 +40,9 @@ $(DEMO): $(PKG)/host/two_view_demo.cpp $(PKG)/host/sfm.h $(PKG)/host/cudaSift.h 
 $(HDEMO): $(PKG)/host/homography_demo.cpp $(PKG)/host/geomFuncs.h $(PKG)/host/cudaSift.h include/sfm_amd.h $(LIB)
 	g++ -O2 -std=c++14 -ffp-contract=off -Wall -o $@ $< -L$(PKG)/lib -lsfm_amd -Wl,-rpath,'$$ORIGIN/../lib' -Wl,-rpath,/opt/rocm/lib
 
+$(SDEMO): $(PKG)/host/sift_demo.cpp $(PKG)/host/cudaImage.h $(PKG)/host/sfm_io.h $(PKG)/host/cudaSift.h include/sfm_amd.h $(LIB)
+	g++ -O2 -std=c++14 -Wall -o $@ $< -L$(PKG)/lib -lsfm_amd -Wl,-rpath,'$$ORIGIN/../lib' -Wl,-rpath,/opt/rocm/lib
+
 $(IOTEST): tests/cpp/io_test.cpp $(PKG)/host/sfm_io.h $(PKG)/host/cudaSift.h include/sfm_amd.h
 	g++ -O2 -std=c++14 -Wall -o $@ $<
 
@@ -47,11 +51,11 @@ $(GEOMTEST): tests/cpp/geom_test.cpp $(PKG)/host/geomFuncs.h $(PKG)/host/sfm_io.
 
 hostcheck: tests/hostcheck/libhostcheck.so
 
-tests/hostcheck/libhostcheck.so: tests/hostcheck/hostcheck.hip $(CSRC)/device_math.hpp
+tests/hostcheck/libhostcheck.so: tests/hostcheck/hostcheck.hip $(CSRC)/device_math.hpp $(CSRC)/sift_math.hpp
 	$(HIPCC) -x hip --cuda-host-only -O2 -ffp-contract=off -mfma -fPIC -shared -Wno-pass-failed -o $@ $<
 
 clean:
-	rm -rf $(BUILD) $(LIB) $(DEMO) $(HDEMO) $(IOTEST) $(GEOMTEST) tests/hostcheck/libhostcheck.so
+	rm -rf $(BUILD) $(LIB) $(DEMO) $(HDEMO) $(SDEMO) $(IOTEST) $(GEOMTEST) tests/hostcheck/libhostcheck.so
 	$(MAKE) -C oracle clean
 
 .PHONY: all oracle hostcheck clean

@@ -49,7 +49,7 @@ EXPORTS = [
     "sfm_abi_version", "sfm_last_error", "sfm_ctx_create", "sfm_ctx_destroy", "sfm_ctx_set_stream",
     "sfm_ctx_synchronize", "sfm_ctx_timer_start", "sfm_ctx_timer_stop", "sfm_ctx_kernel_timing",
     "sfm_ctx_kernel_timing_read", "sfm_device_alloc", "sfm_device_free", "sfm_copy_to_device", "sfm_copy_to_host",
-    "sfm_copy_to_host_2d", "sfm_find_homography", "sfm_sift_temp_layout", "sfm_extract_sift", "sfm_match", "sfm_match_soa",
+    "sfm_copy_to_host_2d", "sfm_copy_to_device_2d", "sfm_find_homography", "sfm_sift_temp_layout", "sfm_extract_sift", "sfm_match", "sfm_match_soa",
     "sfm_pair_create", "sfm_pair_destroy", "sfm_fill_xu", "sfm_set_points", "sfm_ransac_default_params",
     "sfm_ransac_permutation_indices", "sfm_estimate_E", "sfm_ransac_score", "sfm_ransac_finalize",
     "sfm_ransac_finalize_key", "sfm_ransac_export_key", "sfm_pose_candidates", "sfm_choose_pose", "sfm_triangulate",

@@ -205,6 +205,17 @@ int sfm_copy_to_host_2d(sfm_ctx *ctx, void *h_dst, size_t dst_pitch, const void 
     return SFM_OK;
 }
 
+int sfm_copy_to_device_2d(sfm_ctx *ctx, void *d_dst, size_t dst_pitch, const void *h_src, size_t src_pitch,
+                          size_t width_bytes, size_t height)
+{
+    SFM_REQUIRE(ctx && d_dst && h_src, SFM_E_INVALID, "null argument");
+    if (width_bytes == 0 || height == 0) return SFM_OK;
+    SFM_HIP_TRY(hipSetDevice(ctx->device));
+    SFM_HIP_TRY(hipMemcpy2DAsync(d_dst, dst_pitch, h_src, src_pitch, width_bytes, height, hipMemcpyHostToDevice, ctx->stream));
+    SFM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return SFM_OK;
+}
+
 // ---- match ------------------------------------------------------------------------------------
 int sfm_match(sfm_ctx *ctx, sfm_sift_point *d_sift1, int n1, const sfm_sift_point *d_sift2, int n2)
 {

@@ -105,6 +105,8 @@ SFM_HD bool ge_t(float a, float b) { return a >= b; }
 SFM_HD v2i ge_t(v2f a, v2f b) { return a >= b; }
 SFM_HD bool ne_t(float a, float b) { return a != b; }
 SFM_HD v2i ne_t(v2f a, v2f b) { return a != b; }
+SFM_HD bool and_t(bool a, bool b) { return a && b; }
+SFM_HD v2i and_t(v2i a, v2i b) { return a & b; }
 SFM_HD bool eq_t(float a, float b) { return a == b; }
 SFM_HD v2i eq_t(v2f a, v2f b) { return a == b; }
 SFM_HD float sel_t(bool m, float a, float b) { return m ? a : b; }
@@ -382,7 +384,7 @@ SFM_HD void jacobi_cs(T app, T aqq, T apq, T &c, T &s)
     const T ic = soft_rsqrt(c2);
     const T cc = c2 * ic;
     const T s0 = (beta * hir) * ic;
-    const auto rotate = ge_t(r2, splat_t<T>(1e-30f)) & ne_t(apq, zero);     // false also for NaN
+    const auto rotate = and_t(ge_t(r2, splat_t<T>(1e-30f)), ne_t(apq, zero));     // false also for NaN
     c = sel_t(rotate, cc, one);
     s = sel_t(rotate, sel_t(ge_t(alpha, zero), s0, -s0), zero);
 }

@@ -8,7 +8,7 @@
 //   InitSiftData / FreeSiftData   host + device buffers (cudaSiftH.cu:234-264)
 //   MatchSiftData            brute-force matcher, returns elapsed ms (matching.cu:1090-1206)
 //   FindHomography           RANSAC homography pre-filter (matching.cu:1000-1087)
-// ExtractSift is outside the hot path and is not provided.
+//   ExtractSift, AllocSiftTempMemory, FreeSiftTempMemory, PrintSiftData, CudaImage: see cudaImage.h
 //
 // Error convention of the reference: print and exit (cudautils.h:15-39).  Reproduced here; define
 // SFM_FACADE_THROW to get std::runtime_error instead.

@@ -39,6 +39,44 @@ inline bool ReadSiftFile(const char *path, std::vector<SiftPoint> &out)
     return ok;
 }
 
+// Binary PGM (P5) / PPM (P6), maxval <= 255, into a tightly packed float image of grey values 0..255 --
+// what cv::imread(path, 0).convertTo(CV_32FC1) hands to CudaImage in the reference (main.cpp:250-252).
+// Colour is reduced with OpenCV's fixed-point BT.601 weights ((R*4899 + G*9617 + B*1868 + 8192) >> 14).
+inline bool ReadPNM(const char *path, std::vector<float> &pixels, int &width, int &height)
+{
+    FILE *f = std::fopen(path, "rb");
+    if (!f) return false;
+    auto token = [&](int &v) -> bool {                   // next unsigned integer, skipping whitespace and # comments
+        int c = std::fgetc(f);
+        while (c != EOF) {
+            if (c == '#') { while (c != EOF && c != '\n') c = std::fgetc(f); }
+            else if (c == ' ' || c == '\t' || c == '\n' || c == '\r') c = std::fgetc(f);
+            else break;
+        }
+        if (c < '0' || c > '9') return false;
+        v = 0;
+        while (c >= '0' && c <= '9') { v = v * 10 + (c - '0'); c = std::fgetc(f); }
+        return true;                                      // the single whitespace after the token is consumed
+    };
+    char magic[2] = {0, 0};
+    bool ok = std::fread(magic, 1, 2, f) == 2 && magic[0] == 'P' && (magic[1] == '5' || magic[1] == '6');
+    int maxval = 0;
+    ok = ok && token(width) && token(height) && token(maxval) && width > 0 && height > 0 && maxval > 0 && maxval <= 255;
+    if (ok) {
+        const int ch = magic[1] == '6' ? 3 : 1;
+        std::vector<unsigned char> raw((size_t)width * height * ch);
+        ok = std::fread(raw.data(), 1, raw.size(), f) == raw.size();
+        if (ok) {
+            pixels.resize((size_t)width * height);
+            for (size_t i = 0; i < pixels.size(); ++i)
+                pixels[i] = ch == 1 ? (float)raw[i]
+                                    : (float)((raw[3 * i] * 4899 + raw[3 * i + 1] * 9617 + raw[3 * i + 2] * 1868 + 8192) >> 14);
+        }
+    }
+    std::fclose(f);
+    return ok;
+}
+
 // points: 4 x n row-major as returned by SfM::Image_pair::getPoints(); mask (optional) keeps only
 // inliers; points the pipeline zeroed (w == 0 or |w| > 5, kernels.h:439) are dropped.
 inline int WritePLY(const char *path, const float *points4xn, int n, const uint8_t *mask = nullptr)

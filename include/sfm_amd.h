@@ -76,6 +76,8 @@ int  sfm_copy_to_device(sfm_ctx *ctx, void *d_dst, const void *h_src, size_t byt
 int  sfm_copy_to_host(sfm_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);
 int  sfm_copy_to_host_2d(sfm_ctx *ctx, void *h_dst, size_t dst_pitch, const void *d_src, size_t src_pitch,
                          size_t width_bytes, size_t height);          /* cudaMemcpy2D of matching.cu:1195-1199 */
+int  sfm_copy_to_device_2d(sfm_ctx *ctx, void *d_dst, size_t dst_pitch, const void *h_src, size_t src_pitch,
+                           size_t width_bytes, size_t height);        /* CudaImage::Download, cudaImage.cu:59-69 */
 
 /* ---- descriptor match: MatchSiftData (matching.cu:1090-1206, kernel FindMaxCorr10 :301-397) ---
  * For every record of d_sift1: best / second-best dot product over d_sift2 (128-d, fused d-ordered

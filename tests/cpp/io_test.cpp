@@ -1,6 +1,7 @@
 // CPU test of the host-side IO helpers (cuda-sfm_amd/host/sfm_io.h): .sift round trip and PLY sink.
 #include <cstdio>
 #include <cstring>
+#include <string>
 #include <vector>
 #include "../../cuda-sfm_amd/host/sfm_io.h"
 
@@ -27,6 +28,20 @@ int main(int argc, char **argv)
     const uint8_t mask[n] = { 1, 1, 0, 1, 1 };
     if (WritePLY((dir + "/all.ply").c_str(), P, n) != 4) return 8;              // the zeroed point is dropped
     if (WritePLY((dir + "/inl.ply").c_str(), P, n, mask) != 3) return 9;
+    // PNM reader: decode every in*.pnm the test placed in the directory into raw float dumps
+    for (const char *name : { "in_gray.pnm", "in_color.pnm", "in_comment.pnm" }) {
+        std::vector<float> px;
+        int w = 0, h = 0;
+        if (!ReadPNM((dir + "/" + name).c_str(), px, w, h)) continue;
+        FILE *o = std::fopen((dir + "/" + name + ".f32").c_str(), "wb");
+        if (!o) return 10;
+        const int32_t wh[2] = { w, h };
+        std::fwrite(wh, 4, 2, o);
+        std::fwrite(px.data(), 4, px.size(), o);
+        std::fclose(o);
+    }
+    std::vector<float> none; int a = 0, b = 0;
+    if (ReadPNM((dir + "/bad.pnm").c_str(), none, a, b)) return 11;              // truncated / wrong magic must fail
     std::printf("io_test ok\n");
     return 0;
 }

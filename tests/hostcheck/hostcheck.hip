@@ -3,6 +3,7 @@
 // *host* code so that CPU-only tests can compare it bit for bit with the oracle.  Nothing in the
 // product loads this library; it is not a CPU fallback.
 #include "../../cuda-sfm_amd/csrc/device_math.hpp"
+#include "../../cuda-sfm_amd/csrc/sift_math.hpp"
 #include <string.h>
 
 extern "C" {
@@ -67,4 +68,32 @@ void hc_triangulate_point(float x1, float y1, float x2, float y2, const float *P
 }
 unsigned long long hc_pack_key(uint32_t c, uint32_t h) { return sfm::pack_key(c, h); }
 
+
+// ---- sift_math.hpp (ExtractSift arithmetic) ----
+void hc_sift_unary(int which, const float *x, float *out, int n)
+{
+    for (int i = 0; i < n; ++i)
+        out[i] = which == 0 ? sfm::sift::exp2_poly(x[i]) : sfm::sift::exp_poly(x[i]);
+}
+void hc_sift_atan2(int fast, const float *y, const float *x, float *out, int n)
+{
+    for (int i = 0; i < n; ++i) out[i] = fast ? sfm::sift::fast_atan2(y[i], x[i]) : sfm::sift::atan2_poly(y[i], x[i]);
+}
+void hc_sift_sincos(const float *th, float *sn, float *cs, int n)
+{
+    for (int i = 0; i < n; ++i) sfm::sift::sincos_poly(th[i], sn[i], cs[i]);
+}
+void hc_sift_tex(const float *img, int pitch, int w, int h, const float *x, const float *y, float *out, int n)
+{
+    for (int i = 0; i < n; ++i) out[i] = sfm::sift::tex_bilinear(img, pitch, w, h, x[i], y[i]);
+}
+// refine one extremum of a 7-plane DoG stack; returns 0/1, out = xpos, ypos, scale, sharpness, edgeness
+int hc_sift_refine(const float *dog, int w, int h, int pd, int x, int y, int scale, float lowestScale, float factor, float edgeLimit, float *out)
+{
+    const size_t plane = (size_t)h * pd;
+    sfm::sift::Refined q;
+    if (!sfm::sift::refine_extremum(dog + (size_t)(scale + 1) * plane + (size_t)y * pd + x, pd, plane, x, y, scale, lowestScale, factor, edgeLimit, q)) return 0;
+    out[0] = q.xpos; out[1] = q.ypos; out[2] = q.scale; out[3] = q.sharpness; out[4] = q.edgeness;
+    return 1;
+}
 }

@@ -108,3 +108,47 @@ def test_cpp_homography_demo(tmp_path):
     assert f"Number of matching features: {nfit} {nm} " in r.stdout
     assert (m["ambiguity"] < 0.8).mean() > 0.9                   # the demo's gate (mainSift.cpp:77) keeps most matches
     assert nm > 0.55 * n                                         # 65 % of the scene lies on the plane
+
+
+def write_pgm(path, img):
+    h, w = img.shape
+    with open(path, "wb") as f:
+        f.write(b"P5\n%d %d\n255\n" % (w, h)); f.write(img.astype(np.uint8).tobytes())
+
+
+def read_sift(path):
+    raw = open(path, "rb").read()
+    n = int(np.frombuffer(raw[:4], np.int32)[0])
+    return np.frombuffer(raw[4:], O.SIFT_DTYPE, n)
+
+
+@pytest.mark.parametrize("args,kw", [([], dict(thresh=1.0, init_blur=1.5)),
+                                     (["3.0", "1.0", "4", "1"], dict(thresh=3.0, init_blur=1.0, num_octaves=4, scale_up=True))])
+def test_cpp_sift_demo(tmp_path, args, kw):
+    """main.cpp:249-282 re-hosted: read two images, ExtractSift x2 (shared temp memory), MatchSiftData --
+    every record of both sets against the oracle, bit for bit."""
+    demo = os.path.join(ROOT, "cuda-sfm_amd", "host", "sift_demo")
+    assert os.path.exists(demo), "sift_demo not built (make)"
+    a = synth.image(400, 300, seed=12, blobs=150)
+    b = synth.image(400, 300, seed=12, blobs=150, shift=(7.0, -4.0))           # same scene, translated
+    f1, f2, o1, o2 = (str(tmp_path / x) for x in ("a.pgm", "b.pgm", "a.sift", "b.sift"))
+    write_pgm(f1, a); write_pgm(f2, b)
+    r = subprocess.run([demo, f1, f2, o1, o2] + args, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "Image size = (400,300)" in r.stdout and r.stdout.count("SIFT extraction time =") == 2
+    assert "Incl prefiltering & memcpy =" in r.stdout and "MatchSiftData time" in r.stdout
+
+    s1, s2 = read_sift(o1), read_sift(o2)
+    e1, n1, _ = O.extract_sift(a, kw.get("num_octaves", 5), kw["init_blur"], kw["thresh"], 0.0, kw.get("scale_up", False))
+    e2, n2, _ = O.extract_sift(b, kw.get("num_octaves", 5), kw["init_blur"], kw["thresh"], 0.0, kw.get("scale_up", False))
+    assert (len(s1), len(s2)) == (n1, n2) and n1 > 300
+    for f in ("xpos", "ypos", "scale", "sharpness", "edgeness", "orientation", "subsampling", "data"):
+        assert same_bits(s1[f], e1[f][:n1]), f
+        assert same_bits(s2[f], e2[f][:n2]), f
+    m = O.match_sift(e1[:n1].copy(), e2[:n2])
+    for f in ("score", "ambiguity", "match", "match_xpos", "match_ypos"):
+        assert same_bits(s1[f], m[f]), f
+    # the scene moved by (7, -4): confident matches agree with that
+    good = (s1["ambiguity"] < 0.8) & (s1["score"] > 0.9)
+    dx, dy = s1["match_xpos"][good] - s1["xpos"][good], s1["match_ypos"][good] - s1["ypos"][good]
+    assert good.sum() > 100 and abs(np.median(dx) - 7.0) < 0.5 and abs(np.median(dy) + 4.0) < 0.5

@@ -81,3 +81,27 @@ def test_e2e_regression_vectors():
         assert same_bits(P, g[f"P{mode}"]) and ind == int(g[f"pind{mode}"]) and same_bits(Pinv, g[f"Pinv{mode}"])
         pts = O.triangulate(X0, X1, Pinv[ind] if mode == 0 else P[ind], 8)
         assert same_bits(pts, g[f"points{mode}"])
+
+
+def test_reference_gpu_kernels_golden():
+    """Outputs of the REFERENCE'S OWN CUDA kernels (cudaSiftD.cu LowPassBlock / ScaleDown / ScaleUp /
+    LaplaceMultiMem, matching.cu ComputeHomographies / TestHomographies) compiled for gfx950 in place and
+    run on an MI355X (tests/gen_golden_gpu.py) -- the oracle reproduces them bit for bit on the CPU."""
+    g = np.load(os.path.join(G, "ref_gpu_kernels.npz"))
+    img = g["sift_image"]
+    # the filter tables are host code of the reference, restated in the oracle; the fixture stores what was used
+    kt, k5 = O.sift_tables(5)
+    assert same_bits(kt, g["sift_laplace_table"]) and same_bits(k5, g["sift_scaledown_taps"])
+    for tag, blur in (("lp10", 1.0), ("lp15", 1.5)):
+        assert same_bits(O.sift_lowpass_taps(blur), g["sift_" + tag + "_taps"])
+        assert same_bits(O.sift_lowpass(img, g["sift_" + tag + "_taps"]), g["sift_" + tag])
+    assert same_bits(O.sift_scaledown(img, k5), g["sift_scaledown"])
+    assert same_bits(O.sift_scaleup(img), g["sift_scaleup"])
+    for octave in (5, 2):
+        assert same_bits(O.sift_laplace(g["sift_lp10"], kt.reshape(8, 192)[octave][:128]), g[f"sift_dog_octave{octave}"])
+    coord, pts = g["homo_coord"], g["homo_pts"]
+    thr = np.float32(g["homo_thresh"])
+    for l in range(pts.shape[1]):
+        h = O.homography4(coord, pts[:, l])
+        assert same_bits(h, g["homo_h"][:, l].copy())
+        assert O.homography_count(h, coord, coord.shape[1], thr * thr) == g["homo_counts"][l]

@@ -1,0 +1,262 @@
+"""CPU: the ExtractSift oracle (oracle/sift_oracle.c) -- mathematical invariants of every stage (the
+detector refinement, orientation and descriptor of the reference cannot be built here, so these are what
+anchors them), and bit-equality of the product's host-compiled arithmetic (sift_math.hpp via
+tests/hostcheck) with the oracle."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+from scipy import ndimage
+
+import oracle as O
+from cuda_sfm_amd_synth import synth
+from helpers import same_bits
+
+LIB = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hostcheck", "libhostcheck.so")
+f32p = O.f32p
+
+
+def fp(a):
+    return a.ctypes.data_as(f32p)
+
+
+# ---- elementary functions -------------------------------------------------------------------------
+def test_elementary_functions_accuracy():
+    rng = np.random.default_rng(1)
+    t = np.concatenate([rng.uniform(-30, 30, 4000), [-126.5, -200.0, 0.0, 126.0, 127.5]]).astype(np.float32)
+    got = np.array([O.sift_math("exp2f", v) for v in t], np.float64)
+    ref = np.exp2(np.clip(t.astype(np.float64), None, 126.0)); ref[t <= -126.0] = 0.0
+    assert np.max(np.abs(got - ref) / np.maximum(ref, 1e-300)) < 3e-7
+    x = rng.uniform(-40, 2, 2000).astype(np.float32)
+    got = np.array([O.sift_math("expf", v) for v in x], np.float64)
+    assert np.max(np.abs(got / np.exp(x.astype(np.float64)) - 1)) < 4e-6          # includes the rounding of x*log2(e)
+    yy = rng.normal(size=4000).astype(np.float32); xx = rng.normal(size=4000).astype(np.float32)
+    a = np.array([O.sift_math("atan2f", p, q) for p, q in zip(yy, xx)], np.float64)
+    assert np.max(np.abs(a - np.arctan2(yy.astype(np.float64), xx.astype(np.float64)))) < 6e-7
+    fa = np.array([O.sift_math("fast_atan2f", p, q) for p, q in zip(yy, xx)], np.float64)
+    assert np.max(np.abs(fa - np.arctan2(yy.astype(np.float64), xx.astype(np.float64)))) < 2.5e-4   # the polynomial of cudaSiftD.cu:296-306
+    assert O.sift_math("atan2f", 0.0, 0.0) == 0.0 and O.sift_math("fast_atan2f", 0.0, 0.0) == 0.0
+    assert abs(O.sift_math("atan2f", 0.0, -1.0) - np.pi) < 1e-6 and abs(O.sift_math("atan2f", -1.0, 0.0) + np.pi / 2) < 1e-6
+    th = rng.uniform(0, 2 * np.pi * 1.01, 3000).astype(np.float32)
+    sc = np.array([O.sift_math("sincosf", v) for v in th], np.float64)
+    assert np.max(np.abs(sc[:, 0] - np.sin(th.astype(np.float64)))) < 3e-7
+    assert np.max(np.abs(sc[:, 1] - np.cos(th.astype(np.float64)))) < 3e-7
+
+
+def test_texture_fetch_semantics():
+    """tex2D, unnormalised + linear + clamp: texel centres sit at i + 0.5 (CUDA programming guide)."""
+    rng = np.random.default_rng(2)
+    img = rng.uniform(0, 255, (9, 13)).astype(np.float32)
+    for (j, i) in ((0, 0), (4, 7), (8, 12)):
+        assert O.sift_math("tex", img, i + 0.5, j + 0.5) == img[j, i]
+    assert O.sift_math("tex", img, -3.0, -2.0) == img[0, 0] and O.sift_math("tex", img, 40.0, 40.0) == img[8, 12]
+    assert abs(O.sift_math("tex", img, 3.0, 2.5) - 0.5 * (img[2, 2] + img[2, 3])) < 1e-4
+    yy, xx = np.mgrid[0:9, 0:13]
+    ramp = (3.0 * xx + 5.0 * yy + 1.0).astype(np.float32)                      # a plane is reproduced
+    for (x, y) in ((2.25, 3.75), (10.9, 1.1), (6.5, 6.5)):
+        assert abs(O.sift_math("tex", ramp, x, y) - (3.0 * (x - 0.5) + 5.0 * (y - 0.5) + 1.0)) < 1e-4
+
+
+# ---- filter tables and image kernels against float64 scipy ---------------------------------------
+def test_filter_tables():
+    for s in (0.001, 1.0, 1.5):
+        k = O.sift_lowpass_taps(s)
+        assert abs(k.sum() - 1.0) < 1e-6 and same_bits(k, k[::-1].copy())
+        ref = np.exp(-np.arange(-4, 5) ** 2 / (2.0 * max(s, 1e-3) ** 2)); ref /= ref.sum()
+        assert np.allclose(k, ref, atol=1e-6)
+    kt, k5 = O.sift_tables(5)
+    assert abs(k5.sum() - 1.0) < 1e-6 and np.allclose(k5, k5[::-1]) and np.allclose(k5 / k5[2], np.exp(-np.array([4, 1, 0, 1, 4.0])), atol=1e-6)
+    kt = kt.reshape(8, 12, 16)
+    assert not kt[0].any() and not kt[6:].any()                                  # octaves 1..5 only
+    blur = 0.0
+    for octave in range(5, 0, -1):                                               # cudaSiftH.cu:451-471
+        for i in range(8):
+            sigma2 = (2.0 ** ((i - 1) / 5.0)) ** 2 - blur ** 2
+            ref = np.exp(-np.arange(5) ** 2 / 2.0 / sigma2); ref /= ref[0] + 2 * ref[1:].sum()
+            assert np.allclose(kt[octave, i, :5], ref, atol=2e-6), (octave, i)
+        blur = np.sqrt(blur * blur + 0.25) / 2.0
+
+
+def test_image_kernels_against_scipy():
+    img = synth.image(157, 93, seed=4, blobs=30)
+    k9 = O.sift_lowpass_taps(1.3).astype(np.float64)
+    ref = ndimage.correlate1d(ndimage.correlate1d(img.astype(np.float64), k9, axis=1, mode="nearest"), k9, axis=0, mode="nearest")
+    assert np.max(np.abs(O.sift_lowpass(img, k9) - ref)) < 2e-4
+    kt, k5 = O.sift_tables(3)
+    k5d = k5.astype(np.float64)
+    full = ndimage.correlate1d(ndimage.correlate1d(img.astype(np.float64), k5d, axis=1, mode="nearest"), k5d, axis=0, mode="nearest")
+    down = O.sift_scaledown(img, k5)
+    assert down.shape == (46, 78) and np.max(np.abs(down - full[0:92:2, 0:156:2])) < 2e-4
+    up = O.sift_scaleup(img)
+    assert up.shape == (186, 314) and np.array_equal(up[::2, ::2], img) and np.allclose(up[1:-1:2, 1:-1:2], 0.25 * (img[:-1, :-1] + img[:-1, 1:] + img[1:, :-1] + img[1:, 1:]), atol=1e-4)
+    dog = O.sift_laplace(img, kt.reshape(8, 192)[3][:128])
+    kk = kt.reshape(8, 12, 16)[3]
+    g = []
+    for i in range(8):
+        full9 = np.concatenate([kk[i, 4:0:-1], kk[i, :5]]).astype(np.float64)
+        g.append(ndimage.correlate1d(ndimage.correlate1d(img.astype(np.float64), full9, axis=0, mode="nearest"), full9, axis=1, mode="nearest"))
+    for i in range(7):
+        assert np.max(np.abs(dog[i] - (g[i + 1] - g[i]))) < 2e-4
+
+
+# ---- detection / orientation / descriptor: invariants ---------------------------------------------
+def blob_image(w, h, cx, cy, sigma, amp=80.0):
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    return (100.0 + amp * np.exp(-((xx - cx) ** 2 + (yy - cy) ** 2) / (2 * sigma ** 2))).astype(np.float32)
+
+
+@pytest.mark.parametrize("sigma,cx,cy", [(2.0, 40.3, 30.6), (3.5, 61.7, 44.2), (7.0, 50.0, 47.5)])
+def test_detector_localises_a_gaussian_blob(sigma, cx, cy):
+    img = blob_image(128, 96, cx, cy, sigma)
+    pts, n, stored = O.extract_sift(img, 4, 1.0, 2.0)
+    assert n >= 1
+    d = np.hypot(pts["xpos"][:n] - cx, pts["ypos"][:n] - cy)
+    total = np.sqrt(sigma ** 2 + 1.0)                                      # the blob after the initial low pass
+    near = np.flatnonzero(d < 0.35)                                        # sub-pixel refinement (cudaSiftD.cu:1393-1414)
+    assert len(near) >= 1 and len(near) == n                               # nothing is detected anywhere else
+    # characteristic scale: the DoG pair (sigma, 2^(1/5) sigma) labelled with its lower sigma peaks around total/sqrt(2)
+    assert ((pts["scale"][near] > 0.45 * total) & (pts["scale"][near] < 1.3 * total)).all()
+    best = int(near[0])
+    assert (pts["sharpness"][near] < -2.0).all()                           # bright blob: planes are G(larger) - G(smaller) -> negative
+    assert abs(pts["edgeness"][best] - 4.0) < 0.2                          # tr^2/det = 4 for an isotropic extremum
+
+
+def test_edges_are_rejected_and_threshold_scales():
+    yy, xx = np.mgrid[0:96, 0:128].astype(np.float64)
+    edge = (100.0 + 80.0 / (1.0 + np.exp(-(xx - 64.0)))).astype(np.float32)        # a straight soft edge: no corner, no blob
+    _, n, _ = O.extract_sift(edge, 3, 1.0, 1.0)
+    assert n == 0
+    img = synth.image(320, 240, seed=14, blobs=120)
+    counts = [O.extract_sift(img, 4, 1.0, t)[1] for t in (1.0, 2.0, 4.0, 8.0)]
+    assert counts[0] > counts[1] > counts[2] > counts[3] > 0
+    lo = O.extract_sift(img, 4, 1.0, 2.0, lowest_scale=3.0)
+    assert 0 < lo[1] < counts[1] and lo[0]["scale"][:lo[1]].min() >= 3.0         # lowestScale gate (cudaSiftD.cu:1417)
+
+
+@pytest.mark.parametrize("phi", [0.0, 30.0, 90.0, 135.0, 200.0, 315.0])
+def test_orientation_follows_the_gradient(phi):
+    yy, xx = np.mgrid[0:64, 0:64].astype(np.float64)
+    a = np.deg2rad(phi)
+    ramp = (120.0 + 2.0 * (np.cos(a) * (xx - 32) + np.sin(a) * (yy - 32))).astype(np.float32)
+    ori = O.sift_orientation(ramp, 32.0, 32.0, 2.0)
+    # bin = 16*atan2/pi + 16.5 -> a gradient along phi lands at phi + 180 degrees (cudaSiftD.cu:1001, 1040)
+    assert len(ori) == 1 and abs(((ori[0] - 180.0 - phi + 180.0) % 360.0) - 180.0) < 6.0
+
+
+def test_two_dominant_gradients_give_two_orientations():
+    yy, xx = np.mgrid[0:64, 0:64].astype(np.float64)
+    img = (120.0 + 3.0 * np.where(yy < 32, xx - 32, yy - 32)).astype(np.float32)     # x-ramp above row 32, y-ramp below
+    ori = O.sift_orientation(img, 32.0, 31.0, 2.0)
+    assert len(ori) == 2 and abs(abs(ori[0] - ori[1]) - 90.0) < 12.0          # cudaSiftD.cu:1044: second peak > 0.8 * first
+    assert len(O.sift_orientation(img, 32.0, 36.0, 2.0)) == 1                  # mostly inside the y-ramp: one peak
+
+
+def test_descriptor_properties():
+    img = synth.image(200, 160, seed=23, blobs=80)
+    pts, n, stored = O.extract_sift(img, 3, 1.0, 2.0)
+    assert stored > 100
+    d = pts["data"][:stored]
+    assert not np.isnan(d).any() and (d >= 0).all()
+    assert np.allclose(np.linalg.norm(d, axis=1), 1.0, atol=1e-5)            # second normalisation (cudaSiftD.cu:405-409)
+    assert d.max() <= 0.2 / np.sqrt(128 * 0.2 ** 2 / 128) + 1e-6              # every entry went through the 0.2 clip
+    # rotating the image by 90 degrees rotates keypoint and orientation; the descriptor is unchanged
+    i = int(np.argmax((pts["subsampling"][:n] == 1.0) & (np.abs(pts["xpos"][:n] - 100) < 60) & (np.abs(pts["ypos"][:n] - 80) < 40)))
+    low = O.sift_lowpass(img, O.sift_lowpass_taps(1.0))
+    x, y, s, o = (float(pts[f][i]) for f in ("xpos", "ypos", "scale", "orientation"))
+    d0 = O.sift_descriptor(low, x, y, s, o)
+    assert same_bits(d0, pts["data"][i])
+    rot = np.ascontiguousarray(np.rot90(low, k=-1))                           # clockwise: (x, y) -> (H-1-y, x)
+    d1 = O.sift_descriptor(rot, low.shape[0] - 1 - y, x, s, (o + 90.0) % 360.0)
+    assert np.abs(d1 - d0).max() < 2e-3
+
+
+def test_translation_covariance():
+    a = synth.image(300, 220, seed=31, blobs=100)
+    b = synth.image(300, 220, seed=31, blobs=100, shift=(8.0, 4.0))          # integer shift: same pixels, moved
+    assert np.array_equal(a[20:180, 20:250], b[24:184, 28:258])
+    pa, na, _ = O.extract_sift(a, 3, 1.0, 2.0)
+    pb, nb, _ = O.extract_sift(b, 3, 1.0, 2.0)
+    inner = (pa["xpos"][:na] > 60) & (pa["xpos"][:na] < 220) & (pa["ypos"][:na] > 60) & (pa["ypos"][:na] < 150) & (pa["subsampling"][:na] == 1.0)
+    hits = 0
+    for i in np.flatnonzero(inner):
+        j = np.flatnonzero((np.abs(pb["xpos"][:nb] - pa["xpos"][i] - 8.0) < 1e-3) & (np.abs(pb["ypos"][:nb] - pa["ypos"][i] - 4.0) < 1e-3)
+                           & (pb["scale"][:nb] == pa["scale"][i]))
+        hits += any(np.abs(pb["data"][q] - pa["data"][i]).max() < 1e-3 for q in j)     # (a point may carry two orientations)
+    # (x + 8) + dx rounds differently from x + dx: a sample on a histogram-bin border may flip, so allow a few outliers
+    assert inner.sum() > 50 and hits >= 0.97 * inner.sum()
+
+
+def test_extract_structure_and_counts():
+    img = synth.image(320, 240, seed=40, blobs=150)
+    pts, n, stored = O.extract_sift(img, 5, 1.0, 2.0)
+    again, n2, stored2 = O.extract_sift(img, 5, 1.0, 2.0)
+    assert (n, stored) == (n2, stored2) and pts.tobytes() == again.tobytes()
+    assert 0 < n <= stored
+    sub = pts["subsampling"][:stored]
+    assert (np.diff(sub) <= 0).all() and set(np.unique(sub)) <= {1.0, 2.0, 4.0, 8.0, 16.0}     # coarsest octave first
+    assert (sub[n:] == 1.0).all()                       # what numPts leaves out: the finest octave's second orientations
+    ratio = pts["scale"][:stored] / sub                  # 2^(s/5) * 2^(ds/5), s = 0..4, |ds| <= 0.5 unless the fallback of :1409 fired
+    assert (ratio > 0).all() and ((ratio > 0.93) & (ratio < 1.87)).mean() > 0.95
+    # with one extra octave the four finest octaves are unchanged (the recursion only appends a coarser level in front)
+    p6, n6, s6 = O.extract_sift(img, 6, 1.0, 2.0)
+    assert n6 >= n and np.array_equal(p6["xpos"][s6 - stored:s6], pts["xpos"][:stored])
+    capped, nc, sc = O.extract_sift(img, 5, 1.0, 2.0, max_pts=200)
+    assert nc == 200 and sc == 200
+    up, nu, su = O.extract_sift(img, 4, 1.0, 2.0, scale_up=True)
+    assert nu > n * 0.8 and up["scale"][:nu].min() < 1.0          # doubled image finds smaller structures, coordinates rescaled
+
+
+# ---- product arithmetic compiled for the host == oracle, bit for bit --------------------------------
+@pytest.mark.skipif(not os.path.exists(LIB), reason="tests/hostcheck not built (make hostcheck)")
+def test_hostcheck_sift_math_bit_exact():
+    H = C.CDLL(LIB)
+    rng = np.random.default_rng(7)
+    x = np.concatenate([rng.uniform(-140, 130, 5000), [0.0, -126.0, 126.0, 0.5, -0.5, 1.5]]).astype(np.float32)
+    out = np.empty_like(x)
+    for which, name in ((0, "exp2f"), (1, "expf")):
+        H.hc_sift_unary(which, fp(x), fp(out), len(x))
+        assert same_bits(out, np.array([O.sift_math(name, v) for v in x], np.float32)), name
+    y = rng.normal(size=5000).astype(np.float32); xx = rng.normal(size=5000).astype(np.float32)
+    y[:50] = 0.0; xx[25:75] = 0.0; y[100:120] = xx[100:120]
+    for fast, name in ((0, "atan2f"), (1, "fast_atan2f")):
+        out = np.empty_like(y)
+        H.hc_sift_atan2(fast, fp(y), fp(xx), fp(out), len(y))
+        assert same_bits(out, np.array([O.sift_math(name, a, b) for a, b in zip(y, xx)], np.float32)), name
+    th = rng.uniform(0, 6.5, 4000).astype(np.float32)
+    sn = np.empty_like(th); cs = np.empty_like(th)
+    H.hc_sift_sincos(fp(th), fp(sn), fp(cs), len(th))
+    ref = np.array([O.sift_math("sincosf", v) for v in th], np.float32)
+    assert same_bits(sn, ref[:, 0].copy()) and same_bits(cs, ref[:, 1].copy())
+    img = synth.image(64, 48, seed=2, blobs=20)
+    px = rng.uniform(-3, 67, 3000).astype(np.float32); py = rng.uniform(-3, 51, 3000).astype(np.float32)
+    out = np.empty_like(px)
+    H.hc_sift_tex(fp(img), 64, 64, 48, fp(px), fp(py), fp(out), len(px))
+    assert same_bits(out, np.array([O.sift_math("tex", img, a, b) for a, b in zip(px, py)], np.float32))
+
+
+@pytest.mark.skipif(not os.path.exists(LIB), reason="tests/hostcheck not built (make hostcheck)")
+def test_hostcheck_refinement_bit_exact():
+    H = C.CDLL(LIB)
+    H.hc_sift_refine.argtypes = [f32p] + [C.c_int] * 6 + [C.c_float] * 3 + [f32p]
+    img = synth.image(200, 150, seed=6, blobs=80)
+    low = O.sift_lowpass(img, O.sift_lowpass_taps(1.0))
+    kt, _ = O.sift_tables(5)
+    dog = O.sift_laplace(low, kt.reshape(8, 192)[5][:128])
+    pts, cnt = O.sift_find_points(dog, 1.0, 0.0, 1.5)
+    assert cnt > 100
+    # re-derive every candidate's integer position from the oracle output and refine it with the product code
+    got = 0
+    for p in pts[:300]:
+        x, y = int(round(float(p["xpos"]))), int(round(float(p["ypos"])))
+        for xs in (x - 1, x, x + 1):
+            for ys in (y - 1, y, y + 1):
+                for s in range(5):
+                    if not (0 < xs < 199 and 0 < ys < 149):
+                        continue
+                    out = np.zeros(5, np.float32)
+                    ok = H.hc_sift_refine(fp(dog), 200, 150, 200, xs, ys, s, 0.0, 0.2, 10.0, fp(out))
+                    if ok and out[0] == p["xpos"] and out[1] == p["ypos"] and out[2] == p["scale"]:
+                        assert out[3] == p["sharpness"] and out[4] == p["edgeness"]
+                        got += 1
+    assert got >= 290
