@@ -12,9 +12,12 @@
 //     secondary orientations after their octave in parent order, so the output is deterministic
 //     (the reference relies on shared/global atomics and returns points in arbitrary order);
 //   - one wavefront per keypoint for orientation and descriptor, wave-level LDS phases, no block barriers;
-//   - every octave keeps its own DoG planes (the reference reuses one region), so the whole pyramid
-//     stays resident for inspection and the octaves carry no false dependency;
-//   - counters live on the device for the whole call; the host synchronises once, at the end.
+//   - every octave keeps its own DoG planes (the reference reuses one region), so the octaves carry no
+//     false dependency: one launch each for the DoG stack, the extremum search, the orientations and
+//     the descriptors of ALL levels (the reference runs 4 launches per octave, in sequence);
+//   - candidates wait in a per-level stash; their output slots come from two small prefix scans, so
+//     nothing is sorted and nothing depends on the order in which wavefronts ran;
+//   - all bookkeeping lives on the device; the host synchronises once, at the end.
 #include "common.hpp"
 #include "sift_math.hpp"
 #include <cstring>
@@ -24,11 +27,6 @@ using namespace sift;
 
 struct Taps5 { float v[5]; };
 struct LapTaps { float k[kLaplaceS][kLaplaceR + 1]; };
-
-struct Cand {
-    float x, y, scale, sharp, edge;
-    uint32_t key;
-};
 
 __device__ __forceinline__ void wave_phase()
 {
@@ -108,22 +106,49 @@ void sift_scaleup_kernel(const float *__restrict__ src, int ps, int w, int h, fl
     o[pd + 1] = 0.25f * (((vul + vur) + vdl) + vdr);
 }
 
-// ---- 8 Gaussians (columns, then rows) and their 7 differences (LaplaceMultiMem) --------------------------------
+// ---- pyramid description shared by the multi-level kernels -------------------------------------------------
+// One launch covers every pyramid level: a 1-D grid whose block ranges are assigned to levels.
+struct Levels {
+    int n;                         // number of levels; level 0 = finest
+    int w[8], h[8], p[8];
+    long long img[8], dog[8];      // float offsets into the temp memory
+    int blk[9];                    // block range of level l = [blk[l], blk[l+1])
+    int tiles_x[8];                // 64-pixel tiles per row (find kernel)
+    int rowtile[9];                // offset of level l in the rowtile count array (h[l] * tiles_x[l] entries each)
+};
+
+__device__ __forceinline__ int level_of_block(const Levels &L, int b)
+{
+    int l = 0;
+#pragma unroll
+    for (int i = 1; i < 8; ++i) l += (i < L.n && b >= L.blk[i]) ? 1 : 0;
+    return l;
+}
+
+// ---- 8 Gaussians (columns, then rows) and their 7 differences (LaplaceMultiMem), every level ---------------
 // 128 threads = 120 output columns + 2x4 halo; every thread slides a 9-row register window down
 // kLapRows rows, so the image is read ~2x instead of 9x.
 constexpr int kLapCols = 120, kLapRows = 8;
+struct LapTables { LapTaps t[8]; };            // indexed by level
 
 __global__ __launch_bounds__(128)
-void sift_laplace_kernel(const float *__restrict__ img, int pi, int w, int h, float *__restrict__ dog, int pd, LapTaps kt)
+void sift_laplace_kernel(float *__restrict__ temp, Levels L, LapTables tabs)
 {
     __shared__ float buff[kLaplaceS][128];
+    const int lvl = level_of_block(L, blockIdx.x);
+    const int w = L.w[lvl], h = L.h[lvl], pd = L.p[lvl];
+    const float *__restrict__ img = temp + L.img[lvl];
+    float *__restrict__ dog = temp + L.dog[lvl];
+    const LapTaps &kt = tabs.t[lvl];
+    const int nbx = (w + kLapCols - 1) / kLapCols;
+    const int b = blockIdx.x - L.blk[lvl];
     const int tx = threadIdx.x;
-    const int xo = blockIdx.x * kLapCols, y0 = blockIdx.y * kLapRows;
+    const int xo = (b % nbx) * kLapCols, y0 = (b / nbx) * kLapRows;
     const int col = clampi(xo + tx - kLaplaceR, 0, w - 1);
     const size_t plane = (size_t)h * pd;
     float t[2 * kLaplaceR + 1];
 #pragma unroll
-    for (int i = 0; i <= 2 * kLaplaceR; ++i) t[i] = img[(size_t)clampi(y0 + i - kLaplaceR, 0, h - 1) * pi + col];
+    for (int i = 0; i <= 2 * kLaplaceR; ++i) t[i] = img[(size_t)clampi(y0 + i - kLaplaceR, 0, h - 1) * pd + col];
     for (int r = 0; r < kLapRows; ++r) {
         const int y = y0 + r;
         if (y >= h) break;
@@ -140,10 +165,10 @@ void sift_laplace_kernel(const float *__restrict__ img, int pi, int w, int h, fl
             float old = 0.0f;
 #pragma unroll
             for (int s = 0; s < kLaplaceS; ++s) {
-                const float *b = &buff[s][tx + kLaplaceR];
-                float res = kt.k[s][0] * b[0];
+                const float *bb = &buff[s][tx + kLaplaceR];
+                float res = kt.k[s][0] * bb[0];
 #pragma unroll
-                for (int j = 1; j <= kLaplaceR; ++j) res += kt.k[s][j] * (b[-j] + b[j]);
+                for (int j = 1; j <= kLaplaceR; ++j) res += kt.k[s][j] * (bb[-j] + bb[j]);
                 if (s > 0) dog[(size_t)(s - 1) * plane + (size_t)y * pd + x] = res - old;
                 old = res;
             }
@@ -151,201 +176,343 @@ void sift_laplace_kernel(const float *__restrict__ img, int pi, int w, int h, fl
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < 2 * kLaplaceR; ++i) t[i] = t[i + 1];
-        t[2 * kLaplaceR] = img[(size_t)clampi(y + kLaplaceR + 1, 0, h - 1) * pi + col];
+        t[2 * kLaplaceR] = img[(size_t)clampi(y + kLaplaceR + 1, 0, h - 1) * pd + col];
     }
 }
 
-// ---- 3-D extrema + refinement (FindPointsMultiNew) -----------------------------------------------------------
-// counters[2o] is the running (unclipped) point count, pre-set to counters[2o-1] by the previous octave.
+// ---- keypoint candidates ----------------------------------------------------------------------------------------
+// A candidate lives in its level's stash from detection to the final record.  Its place in the output
+// is fixed by (level, y, x, scale), never by the order in which wavefronts happened to run:
+//   rank  = rowtile_offset[level][y][x / 64] + lrank        (lrank: order by (x, scale) inside the row segment)
+//   slot  = base[level] + rank                                 primary orientation
+//   slot2 = base[level] + count[level] + dup_prefix[rank]      secondary orientation
+struct Cand {
+    float x, y, scale, sharp, edge;      // level coordinates
+    float ori1, ori2;
+    uint32_t rowtile;                    // index into the level's rowtile array
+    uint32_t lrank;
+    uint32_t rank;
+    uint32_t has2;
+    uint32_t pad;
+};
+
+struct LevelState {                      // device-resident bookkeeping, one per level
+    unsigned int found;                  // extrema that passed the tests (unclipped; atomic)
+    unsigned int kept;                   // candidates in the stash = min(found, capacity)
+    unsigned int base;                   // first output slot of the level (unclipped)
+    unsigned int dups;                   // secondary orientations of the level
+};
+
+struct Workspace {
+    LevelState *state;                   // [8]
+    unsigned int *result;                // [2]: count as the reference reports it, records stored (both unclipped)
+    Cand *stash;                         // [8][cap]
+    unsigned int *rowtile;               // counts, then exclusive offsets (sift_scan_kernel)
+    unsigned int *dupflag;               // [8][cap]  indexed by rank
+    unsigned int *dupprefix;             // [8][cap]
+    int cap;
+};
+
+// 3-D extrema + refinement (FindPointsMultiNew), every level.  Block = 64 x 4 pixels, all 5 scales;
+// one wavefront = one row segment, so the (x, scale) order inside it comes from ballots.
 __global__ __launch_bounds__(256)
-void sift_find_kernel(const float *__restrict__ dog, int w, int h, int pd, float thresh, float lowestScale, float factor,
-                      float edgeLimit, Cand *__restrict__ cand, unsigned int *counters, int octave, int maxPts)
+void sift_find_kernel(const float *__restrict__ temp, Levels L, Workspace W, float thresh, float lowest_scale, float factor, float edge_limit)
 {
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    const int scale = blockIdx.z;
-    if (x >= w || y >= h) return;
+    const int lvl = level_of_block(L, blockIdx.x);
+    const int w = L.w[lvl], h = L.h[lvl], pd = L.p[lvl];
+    const float *__restrict__ dog = temp + L.dog[lvl];
+    const int b = blockIdx.x - L.blk[lvl];
+    const int ntx = L.tiles_x[lvl];
+    const int bx = b % ntx, by = b / ntx;
+    const int lane = threadIdx.x & 63;
+    const int x = bx * 64 + lane, y = by * 4 + (threadIdx.x >> 6);
+    if (y >= h) return;                                                       // whole wavefront
     const size_t plane = (size_t)h * pd;
-    const float *c = dog + (size_t)(scale + 1) * plane;
-    const float d11 = c[(size_t)y * pd + x];
-    if (!(fabsf(d11) > thresh)) return;
-    const int xm = max(x - 1, 0), xp = min(x + 1, w - 1), ym = max(y - 1, 0), yp = min(y + 1, h - 1);
-    float mn = INFINITY, mx = -INFINITY;
+    const float lowest = lowest_scale / (float)(1 << lvl);                   // lowestScale / subsampling (cudaSiftH.cu:208)
+    Refined q[kNumScales];
+    unsigned int mask = 0;
+    if (x < w) {
+        const int xm = max(x - 1, 0), xp = min(x + 1, w - 1), ym = max(y - 1, 0), yp = min(y + 1, h - 1);
 #pragma unroll
-    for (int dz = -1; dz <= 1; ++dz) {
-        const float *p = c + (ptrdiff_t)dz * (ptrdiff_t)plane;
-        const float *r0 = p + (size_t)ym * pd, *r1 = p + (size_t)y * pd, *r2 = p + (size_t)yp * pd;
-        const float a0 = r0[xm], a1 = r0[x], a2 = r0[xp], b0 = r1[xm], b2 = r1[xp], c0 = r2[xm], c1 = r2[x], c2 = r2[xp];
-        mn = fminf(mn, fminf(fminf(fminf(a0, a1), fminf(a2, b0)), fminf(fminf(b2, c0), fminf(c1, c2))));
-        mx = fmaxf(mx, fmaxf(fmaxf(fmaxf(a0, a1), fmaxf(a2, b0)), fmaxf(fmaxf(b2, c0), fmaxf(c1, c2))));
-        if (dz != 0) { mn = fminf(mn, r1[x]); mx = fmaxf(mx, r1[x]); }
+        for (int scale = 0; scale < kNumScales; ++scale) {
+            const float *c = dog + (size_t)(scale + 1) * plane;
+            const float d11 = c[(size_t)y * pd + x];
+            if (!(fabsf(d11) > thresh)) continue;
+            float mn = INFINITY, mx = -INFINITY;
+#pragma unroll
+            for (int dz = -1; dz <= 1; ++dz) {
+                const float *pl = c + (ptrdiff_t)dz * (ptrdiff_t)plane;
+                const float *r0 = pl + (size_t)ym * pd, *r1 = pl + (size_t)y * pd, *r2 = pl + (size_t)yp * pd;
+                const float a0 = r0[xm], a1 = r0[x], a2 = r0[xp], b0 = r1[xm], b2 = r1[xp], c0 = r2[xm], c1 = r2[x], c2 = r2[xp];
+                mn = fminf(mn, fminf(fminf(fminf(a0, a1), fminf(a2, b0)), fminf(fminf(b2, c0), fminf(c1, c2))));
+                mx = fmaxf(mx, fmaxf(fmaxf(fmaxf(a0, a1), fmaxf(a2, b0)), fmaxf(fmaxf(b2, c0), fmaxf(c1, c2))));
+                if (dz != 0) { mn = fminf(mn, r1[x]); mx = fmaxf(mx, r1[x]); }
+            }
+            if (!((d11 < fminf(-thresh, mn)) || (d11 > fmaxf(thresh, mx)))) continue;
+            if (refine_extremum(c + (size_t)y * pd + x, pd, plane, x, y, scale, lowest, factor, edge_limit, q[scale])) mask |= 1u << scale;
+        }
     }
-    if (!((d11 < fminf(-thresh, mn)) || (d11 > fmaxf(thresh, mx)))) return;
-    Refined q;
-    if (!refine_extremum(c + (size_t)y * pd + x, pd, plane, x, y, scale, lowestScale, factor, edgeLimit, q)) return;
-    const unsigned int base = counters[2 * octave - 1];
-    const unsigned int idx = atomicAdd(&counters[2 * octave], 1u);
-    const unsigned int slot = idx - base;
-    const unsigned int cap = (unsigned int)maxPts - min(base, (unsigned int)maxPts);
-    if (slot < cap) {
-        Cand o;
-        o.x = q.xpos; o.y = q.ypos; o.scale = q.scale; o.sharp = q.sharpness; o.edge = q.edgeness;
-        o.key = (uint32_t)(((size_t)y * w + x) * kNumScales + scale);
-        cand[slot] = o;
+    // order inside the row segment: all candidates at smaller x, then the smaller scales at this x
+    unsigned int before = 0, total = 0;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int s = 0; s < kNumScales; ++s) {
+        const unsigned long long bal = __ballot((mask >> s) & 1u);
+        before += (unsigned int)__builtin_popcountll(bal & lt);
+        total += (unsigned int)__builtin_popcountll(bal);
+    }
+    const unsigned int rt = (unsigned int)(y * ntx + bx);
+    unsigned int base = 0;
+    if (lane == 0 && total > 0) base = atomicAdd(&W.state[lvl].found, total);
+    base = __shfl(base, 0);
+    const unsigned int room = base < (unsigned int)W.cap ? (unsigned int)W.cap - base : 0u;
+    const unsigned int kept = min(total, room);
+    if (lane == 0) W.rowtile[L.rowtile[lvl] + rt] = kept;
+    Cand *stash = W.stash + (size_t)lvl * W.cap;
+#pragma unroll
+    for (int s = 0; s < kNumScales; ++s) {
+        if ((mask >> s) & 1u) {
+            const unsigned int lr = before + (unsigned int)__builtin_popcount(mask & ((1u << s) - 1u));
+            if (lr < kept) {
+                Cand o;
+                o.x = q[s].xpos; o.y = q[s].ypos; o.scale = q[s].scale; o.sharp = q[s].sharpness; o.edge = q[s].edgeness;
+                o.ori1 = 0.0f; o.ori2 = 0.0f; o.rowtile = rt; o.lrank = lr; o.rank = 0; o.has2 = 0; o.pad = 0;
+                stash[base + lr] = o;
+            }
+        }
     }
 }
 
-// rank of every candidate by its unique key -> canonical (y, x, scale) order, written into the records
-__global__ __launch_bounds__(256)
-void sift_emit_kernel(const Cand *__restrict__ cand, const unsigned int *__restrict__ counters, sfm_sift_point *__restrict__ sift,
-                      int octave, float subsampling, int maxPts)
+// block-wide exclusive scan of one value per thread (1024 threads); returns the exclusive prefix, total in *sum
+__device__ __forceinline__ unsigned int block_scan_1024(unsigned int v, unsigned int *wsum /* LDS [17] */, unsigned int *sum)
 {
-    __shared__ uint32_t keys[1024];
-    const unsigned int base = counters[2 * octave - 1];
-    const unsigned int fst = min(base, (unsigned int)maxPts);
-    const unsigned int n = min(counters[2 * octave] - base, (unsigned int)maxPts - fst);
-    const unsigned int stride = gridDim.x * 256;
-    for (unsigned int i0 = blockIdx.x * 256; i0 < n; i0 += stride) {          // uniform per block
-        const unsigned int i = i0 + threadIdx.x;
-        const uint32_t mine = i < n ? cand[i].key : 0u;
-        unsigned int rank = 0;
-        for (unsigned int j0 = 0; j0 < n; j0 += 1024) {
-            __syncthreads();
-            for (unsigned int j = threadIdx.x; j < 1024; j += 256) keys[j] = (j0 + j < n) ? cand[j0 + j].key : 0xFFFFFFFFu;
-            __syncthreads();
-            const unsigned int m = min(1024u, n - j0);
-            for (unsigned int j = 0; j < m; ++j) rank += (keys[j] < mine) ? 1u : 0u;
-        }
-        if (i < n) {
-            const Cand c = cand[i];
-            sfm_sift_point *p = &sift[fst + rank];
-            p->xpos = c.x; p->ypos = c.y; p->scale = c.scale;
-            p->sharpness = c.sharp; p->edgeness = c.edge; p->subsampling = subsampling;
-        }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned int inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned int u = __shfl_up(inc, d);
+        if (lane >= d) inc += u;
+    }
+    __syncthreads();                                     // wsum may still be read from the previous call
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned int acc = 0;
+        for (int i = 0; i < 16; ++i) { const unsigned int t = wsum[i]; wsum[i] = acc; acc += t; }
+        wsum[16] = acc;
+    }
+    __syncthreads();
+    *sum = wsum[16];
+    return wsum[wave] + inc - v;
+}
+
+// rowtile counts -> exclusive offsets, per level; closes LevelState::kept.  One block.
+__global__ __launch_bounds__(1024)
+void sift_scan_kernel(Levels L, Workspace W)
+{
+    __shared__ unsigned int wsum[17];
+    for (int lvl = 0; lvl < L.n; ++lvl) {
+        unsigned int *a = W.rowtile + L.rowtile[lvl];
+        const int n = L.rowtile[lvl + 1] - L.rowtile[lvl];
+        const int per = (n + 1023) / 1024;
+        const int lo = min(n, (int)threadIdx.x * per), hi = min(n, lo + per);
+        unsigned int mine = 0;
+        for (int i = lo; i < hi; ++i) mine += a[i];
+        unsigned int total;
+        unsigned int run = block_scan_1024(mine, wsum, &total);
+        for (int i = lo; i < hi; ++i) { const unsigned int c = a[i]; a[i] = run; run += c; }
+        if (threadIdx.x == 0) W.state[lvl].kept = total;
     }
 }
 
-// ---- orientation histogram, one wavefront per keypoint (ComputeOrientationsCONST) ------------------------
+// ---- orientation histogram, one wavefront per candidate (ComputeOrientationsCONST) ------------------------
 __global__ __launch_bounds__(256)
-void sift_orient_kernel(const float *__restrict__ img, int pitch, int w, int h, sfm_sift_point *__restrict__ sift,
-                        const unsigned int *__restrict__ counters, int octave, int maxPts, float *__restrict__ ori2,
-                        unsigned int *__restrict__ has2)
+void sift_orient_kernel(const float *__restrict__ temp, Levels L, Workspace W)
 {
     __shared__ float lds[4][16 + 128 + 64 + 128];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float *gauss = lds[wave], *sval = gauss + 16, *hist = sval + 128;
     int *sbin = reinterpret_cast<int *>(hist + 64);
-    const unsigned int fst = min(counters[2 * octave - 1], (unsigned int)maxPts);
-    const unsigned int tot = min(counters[2 * octave], (unsigned int)maxPts);
-    for (unsigned int bx = fst + blockIdx.x * 4 + wave; bx < tot; bx += gridDim.x * 4) {
-        const float xpos = sift[bx].xpos, ypos = sift[bx].ypos, scale = sift[bx].scale;
-        const float i2sigma2 = -1.0f / (2.0f * 1.5f * 1.5f * scale * scale);
-        if (lane < 11) gauss[lane] = exp_poly(i2sigma2 * (float)(lane - 5) * (float)(lane - 5));
-        wave_phase();
-        const float xp = xpos - 4.5f, yp = ypos - 4.5f;
+    const unsigned int gw = blockIdx.x * 4 + wave, nw = gridDim.x * 4;
+    for (int lvl = 0; lvl < L.n; ++lvl) {
+        const unsigned int kept = W.state[lvl].kept;
+        const float *__restrict__ img = temp + L.img[lvl];
+        const int w = L.w[lvl], h = L.h[lvl], pitch = L.p[lvl];
+        Cand *stash = W.stash + (size_t)lvl * W.cap;
+        const unsigned int *offs = W.rowtile + L.rowtile[lvl];
+        for (unsigned int c = gw; c < kept; c += nw) {
+            const float xpos = stash[c].x, ypos = stash[c].y, scale = stash[c].scale;
+            const float i2sigma2 = -1.0f / (2.0f * 1.5f * 1.5f * scale * scale);
+            if (lane < 11) gauss[lane] = exp_poly(i2sigma2 * (float)(lane - 5) * (float)(lane - 5));
+            wave_phase();
+            const float xp = xpos - 4.5f, yp = ypos - 4.5f;
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const int t = lane + 64 * r;
-            if (t < 121) {
-                const int yd = t / 11, xd = t - yd * 11;
-                const float xf = xp + (float)xd, yf = yp + (float)yd;
-                const float dx = tex_bilinear(img, pitch, w, h, xf + 1.0f, yf) - tex_bilinear(img, pitch, w, h, xf - 1.0f, yf);
-                const float dy = tex_bilinear(img, pitch, w, h, xf, yf + 1.0f) - tex_bilinear(img, pitch, w, h, xf, yf - 1.0f);
-                int bin = (int)(16.0f * atan2_poly(dy, dx) / 3.1416f + 16.5f);
-                if (bin > 31) bin = 0;
-                const float grad = sqrtf(dx * dx + dy * dy);
-                sbin[t] = bin;
-                sval[t] = grad * gauss[xd] * gauss[yd];
+            for (int r = 0; r < 2; ++r) {
+                const int t = lane + 64 * r;
+                if (t < 121) {
+                    const int yd = t / 11, xd = t - yd * 11;
+                    const float xf = xp + (float)xd, yf = yp + (float)yd;
+                    const float dx = tex_bilinear(img, pitch, w, h, xf + 1.0f, yf) - tex_bilinear(img, pitch, w, h, xf - 1.0f, yf);
+                    const float dy = tex_bilinear(img, pitch, w, h, xf, yf + 1.0f) - tex_bilinear(img, pitch, w, h, xf, yf - 1.0f);
+                    int bin = (int)(16.0f * atan2_poly(dy, dx) / 3.1416f + 16.5f);
+                    if (bin > 31) bin = 0;
+                    const float grad = sqrtf(dx * dx + dy * dy);
+                    sbin[t] = bin;
+                    sval[t] = grad * gauss[xd] * gauss[yd];
+                }
             }
-        }
-        wave_phase();
-        const int x1m = lane >= 1 ? lane - 1 : lane + 31, x1p = lane <= 30 ? lane + 1 : lane - 31;
-        const int x2m = lane >= 2 ? lane - 2 : lane + 30, x2p = lane <= 29 ? lane + 2 : lane - 30;
-        if (lane < 32) {
-            float acc = 0.0f;
-            for (int t = 0; t < 121; ++t) acc += (sbin[t] == lane) ? sval[t] : 0.0f;      // sample order
-            hist[lane] = acc;
-        }
-        wave_phase();
-        if (lane < 32) hist[32 + lane] = 6.0f * hist[lane] + 4.0f * (hist[x1m] + hist[x1p]) + (hist[x2m] + hist[x2p]);
-        wave_phase();
-        if (lane < 32) {
-            const float v = hist[32 + lane];
-            hist[lane] = (v > hist[32 + x1m] && v >= hist[32 + x1p]) ? v : 0.0f;
-        }
-        wave_phase();
-        if (lane == 0) {
-            float maxval1 = 0.0f, maxval2 = 0.0f;
-            int i1 = -1, i2 = -1;
-            for (int i = 0; i < 32; ++i) {
-                const float v = hist[i];
-                if (v > maxval1) { maxval2 = maxval1; maxval1 = v; i2 = i1; i1 = i; }
-                else if (v > maxval2) { maxval2 = v; i2 = i; }
+            wave_phase();
+            const int x1m = lane >= 1 ? lane - 1 : lane + 31, x1p = lane <= 30 ? lane + 1 : lane - 31;
+            const int x2m = lane >= 2 ? lane - 2 : lane + 30, x2p = lane <= 29 ? lane + 2 : lane - 30;
+            if (lane < 32) {
+                float acc = 0.0f;
+                for (int t = 0; t < 121; ++t) acc += (sbin[t] == lane) ? sval[t] : 0.0f;      // sample order
+                hist[lane] = acc;
             }
-            float val1 = hist[32 + ((i1 + 1) & 31)], val2 = hist[32 + ((i1 + 31) & 31)];
-            float peak = (float)i1 + 0.5f * (val1 - val2) / (2.0f * maxval1 - val1 - val2);
-            sift[bx].orientation = 11.25f * (peak < 0.0f ? peak + 32.0f : peak);
-            unsigned int second = 0;
-            if (maxval2 > 0.8f * maxval1) {
-                val1 = hist[32 + ((i2 + 1) & 31)]; val2 = hist[32 + ((i2 + 31) & 31)];
-                peak = (float)i2 + 0.5f * (val1 - val2) / (2.0f * maxval2 - val1 - val2);
-                ori2[bx] = 11.25f * (peak < 0.0f ? peak + 32.0f : peak);
-                second = 1;
+            wave_phase();
+            if (lane < 32) hist[32 + lane] = 6.0f * hist[lane] + 4.0f * (hist[x1m] + hist[x1p]) + (hist[x2m] + hist[x2p]);
+            wave_phase();
+            if (lane < 32) {
+                const float v = hist[32 + lane];
+                hist[lane] = (v > hist[32 + x1m] && v >= hist[32 + x1p]) ? v : 0.0f;
             }
-            has2[bx] = second;
+            wave_phase();
+            if (lane == 0) {
+                float maxval1 = 0.0f, maxval2 = 0.0f;
+                int i1 = -1, i2 = -1;
+                for (int i = 0; i < 32; ++i) {
+                    const float v = hist[i];
+                    if (v > maxval1) { maxval2 = maxval1; maxval1 = v; i2 = i1; i1 = i; }
+                    else if (v > maxval2) { maxval2 = v; i2 = i; }
+                }
+                float val1 = hist[32 + ((i1 + 1) & 31)], val2 = hist[32 + ((i1 + 31) & 31)];
+                float peak = (float)i1 + 0.5f * (val1 - val2) / (2.0f * maxval1 - val1 - val2);
+                stash[c].ori1 = 11.25f * (peak < 0.0f ? peak + 32.0f : peak);
+                unsigned int second = 0;
+                if (maxval2 > 0.8f * maxval1) {
+                    val1 = hist[32 + ((i2 + 1) & 31)]; val2 = hist[32 + ((i2 + 31) & 31)];
+                    peak = (float)i2 + 0.5f * (val1 - val2) / (2.0f * maxval2 - val1 - val2);
+                    stash[c].ori2 = 11.25f * (peak < 0.0f ? peak + 32.0f : peak);
+                    second = 1;
+                }
+                const unsigned int rank = offs[stash[c].rowtile] + stash[c].lrank;
+                stash[c].rank = rank;
+                stash[c].has2 = second;
+                W.dupflag[(size_t)lvl * W.cap + rank] = second;
+            }
+            wave_phase();
         }
-        wave_phase();
     }
 }
 
-// secondary orientations appended after the octave's points, in parent order; closes the octave's counters
+// output slots: levels coarsest first (cudaSiftH.cu:149-168), secondary orientations after each level's
+// points in rank order.  One block.
 __global__ __launch_bounds__(1024)
-void sift_dup_kernel(sfm_sift_point *__restrict__ sift, unsigned int *counters, int octave, int maxPts,
-                     const float *__restrict__ ori2, const unsigned int *__restrict__ has2)
+void sift_place_kernel(Levels L, Workspace W)
 {
-    __shared__ unsigned int part[1024];
-    __shared__ unsigned int running;
-    const unsigned int fst = min(counters[2 * octave - 1], (unsigned int)maxPts);
-    const unsigned int cnt = counters[2 * octave];
-    const unsigned int tot = min(cnt, (unsigned int)maxPts);
-    if (threadIdx.x == 0) running = 0;
-    __syncthreads();
-    for (unsigned int i0 = fst; i0 < tot; i0 += 1024) {
-        const unsigned int i = i0 + threadIdx.x;
-        const unsigned int f = (i < tot) ? has2[i] : 0u;
-        part[threadIdx.x] = f;
-        __syncthreads();
-        for (unsigned int d = 1; d < 1024; d <<= 1) {                       // inclusive Hillis-Steele scan
-            const unsigned int v = threadIdx.x >= d ? part[threadIdx.x - d] : 0u;
-            __syncthreads();
-            part[threadIdx.x] += v;
-            __syncthreads();
+    __shared__ unsigned int wsum[17];
+    unsigned int base = 0, reported = 0;
+    for (int lvl = L.n - 1; lvl >= 0; --lvl) {
+        const unsigned int kept = W.state[lvl].kept, found = W.state[lvl].found;
+        const unsigned int *flag = W.dupflag + (size_t)lvl * W.cap;
+        unsigned int *pre = W.dupprefix + (size_t)lvl * W.cap;
+        unsigned int running = 0;
+        for (unsigned int i0 = 0; i0 < kept; i0 += 1024) {
+            const unsigned int i = i0 + threadIdx.x;
+            const unsigned int f = i < kept ? flag[i] : 0u;
+            unsigned int total;
+            const unsigned int ex = block_scan_1024(f, wsum, &total);
+            if (i < kept) pre[i] = running + ex;
+            running += total;
         }
-        const unsigned int before = running;
-        if (f) {
-            const unsigned int slot = cnt + before + part[threadIdx.x] - 1u;
-            if (slot < (unsigned int)maxPts) {
-                const sfm_sift_point *s = &sift[i];
-                sfm_sift_point *q = &sift[slot];
-                q->xpos = s->xpos; q->ypos = s->ypos; q->scale = s->scale;
-                q->sharpness = s->sharpness; q->edgeness = s->edgeness;
-                q->orientation = ori2[i]; q->subsampling = s->subsampling;
-            }
-        }
-        __syncthreads();
-        if (threadIdx.x == 1023) running = before + part[1023];
-        __syncthreads();
+        if (threadIdx.x == 0) { W.state[lvl].base = base; W.state[lvl].dups = running; }
+        reported = base + found;                         // what d_PointCounter[2*octave] holds after the level
+        base += found + running;
     }
-    if (threadIdx.x == 0) {
-        const unsigned int total = cnt + running;
-        counters[2 * octave + 1] = total;
-        if (2 * octave + 2 < 17) counters[2 * octave + 2] = total;
-    }
+    if (threadIdx.x == 0) { W.result[0] = reported; W.result[1] = base; }
 }
 
-// ---- 4x4x8 gradient histogram, one wavefront per keypoint (ExtractSiftDescriptorsCONSTNew) ---------------
+// ---- 4x4x8 gradient histogram, one wavefront per record (ExtractSiftDescriptorsCONSTNew) -----------------
+__device__ __forceinline__ void describe_and_store(const float *__restrict__ img, int pitch, int w, int h, const Cand &c, float orientation,
+                                                   float subsampling, float rescale, sfm_sift_point *__restrict__ out, const float *gauss,
+                                                   float *sgrad, float *sangf, int *sangi, int lane)
+{
+    const float px = c.x, py = c.y;
+    const float theta = 2.0f * 3.1415f / 360.0f * orientation;
+    float sina, cosa;
+    sincos_poly(theta, sina, cosa);
+    const float scale = 12.0f / 16.0f * c.scale;
+    const float ssina = scale * sina, scosa = scale * cosa;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int s = lane + 64 * r, tx = s & 15, y = s >> 4;
+        const float fx = (float)tx - 7.5f, fy = (float)y - 7.5f;
+        const float xs = px + fx * scosa - fy * ssina + 0.5f;
+        const float ys = py + fx * ssina + fy * scosa + 0.5f;
+        const float dx = tex_bilinear(img, pitch, w, h, xs + cosa, ys + sina) - tex_bilinear(img, pitch, w, h, xs - cosa, ys - sina);
+        const float dy = tex_bilinear(img, pitch, w, h, xs - sina, ys + cosa) - tex_bilinear(img, pitch, w, h, xs + sina, ys - cosa);
+        const float grad = gauss[y] * gauss[tx] * sqrtf(dx * dx + dy * dy);
+        float angf = 4.0f / 3.1415f * fast_atan2(dy, dx) + 4.0f;
+        const int angi = (int)angf;
+        angf -= (float)angi;
+        sgrad[s] = grad;
+        sangf[s] = angf;
+        sangi[s] = angi & 7;
+    }
+    wave_phase();
+    float bins[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int b = lane + 64 * r, cell = b >> 3, ang = b & 7, vcell = cell >> 2, hcell = cell & 3;
+        float acc = 0.0f;
+        const int ylo = max(0, 4 * vcell - 2), yhi = min(15, 4 * vcell + 5);
+        const int xlo = max(0, 4 * hcell - 2), xhi = min(15, 4 * hcell + 5);
+        for (int y = ylo; y <= yhi; ++y) {
+            const int veri = (y + 2) / 4 - 1;
+            const float verf = ((float)y - 1.5f) / 4.0f - (float)veri;
+            const float wy = (veri == vcell) ? 1.0f - verf : verf;
+            for (int tx = xlo; tx <= xhi; ++tx) {
+                const int hori = (tx + 2) / 4 - 1;
+                const float horf = ((float)tx - 1.5f) / 4.0f - (float)hori;
+                const float wx = (hori == hcell) ? 1.0f - horf : horf;
+                const int s = y * 16 + tx;
+                const int angi = sangi[s];
+                const float angf = sangf[s];
+                const float grad2 = wy * (wx * sgrad[s]);
+                if (angi == ang) acc += (1.0f - angf) * grad2;
+                else if (((angi + 1) & 7) == ang) acc += angf * grad2;
+            }
+        }
+        bins[r] = acc;
+    }
+    // two normalisations with the 0.2 clip in between; 32-wide shuffle trees as in the reference
+    float sq0 = bins[0] * bins[0], sq1 = bins[1] * bins[1];
+#pragma unroll
+    for (int i = 16; i > 0; i >>= 1) { sq0 += __shfl_down(sq0, i, 32); sq1 += __shfl_down(sq1, i, 32); }
+    float tsum = __shfl(sq0, 0) + __shfl(sq0, 32) + __shfl(sq1, 0) + __shfl(sq1, 32);
+    const float r1 = 1.0f / sqrtf(tsum);
+    const float t0 = fminf(bins[0] * r1, 0.2f), t1 = fminf(bins[1] * r1, 0.2f);
+    sq0 = t0 * t0; sq1 = t1 * t1;
+#pragma unroll
+    for (int i = 16; i > 0; i >>= 1) { sq0 += __shfl_down(sq0, i, 32); sq1 += __shfl_down(sq1, i, 32); }
+    tsum = __shfl(sq0, 0) + __shfl(sq0, 32) + __shfl(sq1, 0) + __shfl(sq1, 32);
+    const float r2 = 1.0f / sqrtf(tsum);
+    out->data[lane] = t0 * r2;
+    out->data[lane + 64] = t1 * r2;
+    if (lane == 0) {
+        out->xpos = (px * subsampling) * rescale;        // :412-414, then RescalePositions (:753-761) when scaleUp
+        out->ypos = (py * subsampling) * rescale;
+        out->scale = (c.scale * subsampling) * rescale;
+        out->sharpness = c.sharp;
+        out->edgeness = c.edge;
+        out->orientation = orientation;
+        out->subsampling = subsampling;
+    }
+    wave_phase();
+}
+
 __global__ __launch_bounds__(256)
-void sift_desc_kernel(const float *__restrict__ img, int pitch, int w, int h, sfm_sift_point *__restrict__ sift,
-                      const unsigned int *__restrict__ counters, int octave, int maxPts, float subsampling)
+void sift_desc_kernel(const float *__restrict__ temp, Levels L, Workspace W, sfm_sift_point *__restrict__ sift, int max_pts, int scale_up)
 {
     __shared__ float lds[4][16 + 3 * 256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -353,89 +520,28 @@ void sift_desc_kernel(const float *__restrict__ img, int pitch, int w, int h, sf
     int *sangi = reinterpret_cast<int *>(sangf + 256);
     if (lane < 16) gauss[lane] = exp_poly(-((float)lane - 7.5f) * ((float)lane - 7.5f) / 128.0f);
     wave_phase();
-    const unsigned int fst = min(counters[2 * octave - 1], (unsigned int)maxPts);
-    const unsigned int tot = min(counters[2 * octave + 1], (unsigned int)maxPts);
-    for (unsigned int bx = fst + blockIdx.x * 4 + wave; bx < tot; bx += gridDim.x * 4) {
-        const float px = sift[bx].xpos, py = sift[bx].ypos;
-        const float theta = 2.0f * 3.1415f / 360.0f * sift[bx].orientation;
-        float sina, cosa;
-        sincos_poly(theta, sina, cosa);
-        const float scale = 12.0f / 16.0f * sift[bx].scale;
-        const float ssina = scale * sina, scosa = scale * cosa;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int s = lane + 64 * r, tx = s & 15, y = s >> 4;
-            const float fx = (float)tx - 7.5f, fy = (float)y - 7.5f;
-            const float xs = px + fx * scosa - fy * ssina + 0.5f;
-            const float ys = py + fx * ssina + fy * scosa + 0.5f;
-            const float dx = tex_bilinear(img, pitch, w, h, xs + cosa, ys + sina) - tex_bilinear(img, pitch, w, h, xs - cosa, ys - sina);
-            const float dy = tex_bilinear(img, pitch, w, h, xs - sina, ys + cosa) - tex_bilinear(img, pitch, w, h, xs + sina, ys - cosa);
-            const float grad = gauss[y] * gauss[tx] * sqrtf(dx * dx + dy * dy);
-            float angf = 4.0f / 3.1415f * fast_atan2(dy, dx) + 4.0f;
-            const int angi = (int)angf;
-            angf -= (float)angi;
-            sgrad[s] = grad;
-            sangf[s] = angf;
-            sangi[s] = angi & 7;
-        }
-        wave_phase();
-        float bins[2];
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const int b = lane + 64 * r, cell = b >> 3, ang = b & 7, vcell = cell >> 2, hcell = cell & 3;
-            float acc = 0.0f;
-            const int ylo = max(0, 4 * vcell - 2), yhi = min(15, 4 * vcell + 5);
-            const int xlo = max(0, 4 * hcell - 2), xhi = min(15, 4 * hcell + 5);
-            for (int y = ylo; y <= yhi; ++y) {
-                const int veri = (y + 2) / 4 - 1;
-                const float verf = ((float)y - 1.5f) / 4.0f - (float)veri;
-                const float wy = (veri == vcell) ? 1.0f - verf : verf;
-                for (int tx = xlo; tx <= xhi; ++tx) {
-                    const int hori = (tx + 2) / 4 - 1;
-                    const float horf = ((float)tx - 1.5f) / 4.0f - (float)hori;
-                    const float wx = (hori == hcell) ? 1.0f - horf : horf;
-                    const int s = y * 16 + tx;
-                    const int angi = sangi[s];
-                    const float angf = sangf[s];
-                    const float grad2 = wy * (wx * sgrad[s]);
-                    if (angi == ang) acc += (1.0f - angf) * grad2;
-                    else if (((angi + 1) & 7) == ang) acc += angf * grad2;
-                }
+    const unsigned int gw = blockIdx.x * 4 + wave, nw = gridDim.x * 4;
+    const unsigned int reported = min(W.result[0], (unsigned int)max_pts);
+    for (int lvl = 0; lvl < L.n; ++lvl) {
+        const unsigned int kept = W.state[lvl].kept, base = W.state[lvl].base, found = W.state[lvl].found;
+        const float *__restrict__ img = temp + L.img[lvl];
+        const int w = L.w[lvl], h = L.h[lvl], pitch = L.p[lvl];
+        const Cand *stash = W.stash + (size_t)lvl * W.cap;
+        const unsigned int *pre = W.dupprefix + (size_t)lvl * W.cap;
+        const float subsampling = (float)(1 << lvl);
+        for (unsigned int ci = gw; ci < kept; ci += nw) {
+            const Cand c = stash[ci];
+            const unsigned int slot = base + c.rank;
+            if (slot < (unsigned int)max_pts)
+                describe_and_store(img, pitch, w, h, c, c.ori1, subsampling, (scale_up && slot < reported) ? 0.5f : 1.0f, &sift[slot],
+                                   gauss, sgrad, sangf, sangi, lane);
+            if (c.has2) {
+                const unsigned int slot2 = base + found + pre[c.rank];
+                if (slot2 < (unsigned int)max_pts)
+                    describe_and_store(img, pitch, w, h, c, c.ori2, subsampling, (scale_up && slot2 < reported) ? 0.5f : 1.0f, &sift[slot2],
+                                       gauss, sgrad, sangf, sangi, lane);
             }
-            bins[r] = acc;
         }
-        // two normalisations with the 0.2 clip in between; 32-wide shuffle trees as in the reference
-        float sq0 = bins[0] * bins[0], sq1 = bins[1] * bins[1];
-#pragma unroll
-        for (int i = 16; i > 0; i >>= 1) { sq0 += __shfl_down(sq0, i, 32); sq1 += __shfl_down(sq1, i, 32); }
-        float tsum = __shfl(sq0, 0) + __shfl(sq0, 32) + __shfl(sq1, 0) + __shfl(sq1, 32);
-        const float r1 = 1.0f / sqrtf(tsum);
-        const float t0 = fminf(bins[0] * r1, 0.2f), t1 = fminf(bins[1] * r1, 0.2f);
-        sq0 = t0 * t0; sq1 = t1 * t1;
-#pragma unroll
-        for (int i = 16; i > 0; i >>= 1) { sq0 += __shfl_down(sq0, i, 32); sq1 += __shfl_down(sq1, i, 32); }
-        tsum = __shfl(sq0, 0) + __shfl(sq0, 32) + __shfl(sq1, 0) + __shfl(sq1, 32);
-        const float r2 = 1.0f / sqrtf(tsum);
-        sift[bx].data[lane] = t0 * r2;
-        sift[bx].data[lane + 64] = t1 * r2;
-        wave_phase();
-        if (lane == 0) {
-            sift[bx].xpos = px * subsampling;
-            sift[bx].ypos = py * subsampling;
-            sift[bx].scale = sift[bx].scale * subsampling;
-        }
-        wave_phase();
-    }
-}
-
-__global__ __launch_bounds__(256)
-void sift_rescale_kernel(sfm_sift_point *__restrict__ sift, const unsigned int *__restrict__ counters, int slot, int maxPts, float scale)
-{
-    const unsigned int n = min(counters[slot], (unsigned int)maxPts);
-    for (unsigned int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-        sift[i].xpos *= scale;
-        sift[i].ypos *= scale;
-        sift[i].scale *= scale;
     }
 }
 
@@ -510,76 +616,97 @@ int launch_extract_sift(sfm_ctx *ctx, sfm_sift_point *d_sift, int max_pts, const
                         int *num_pts, int *num_stored)
 {
     hipStream_t st = ctx->stream;
-    sfm_sift_layout L;
-    sift_layout(width, height, num_octaves, scale_up, &L);
+    sfm_sift_layout SL;
+    sift_layout(width, height, num_octaves, scale_up, &SL);
     if (!d_temp) {
-        int rc = grow(&ctx->sift_temp, &ctx->sift_temp_bytes, (size_t)L.total_floats * sizeof(float), st);
+        int rc = grow(&ctx->sift_temp, &ctx->sift_temp_bytes, (size_t)SL.total_floats * sizeof(float), st);
         if (rc != SFM_OK) return rc;
         d_temp = static_cast<float *>(ctx->sift_temp);
     }
-    // workspace: 32 counters | candidates | secondary orientation | flags
-    const size_t ws_need = 128 + (size_t)max_pts * (sizeof(Cand) + sizeof(float) + sizeof(unsigned int));
+    // the levels that actually hold pixels (w/2^l can reach 0 for tiny images)
+    Levels L;
+    std::memset(&L, 0, sizeof(L));
+    int n = 0;
+    for (int l = 0; l < num_octaves && SL.width[l] > 0 && SL.height[l] > 0; ++l) ++n;
+    L.n = n;
+    int lap_blocks = 0, find_blocks = 0, rowtiles = 0;
+    Levels LF;                                             // same levels, block ranges of the find kernel
+    for (int l = 0; l < n; ++l) {
+        L.w[l] = SL.width[l]; L.h[l] = SL.height[l]; L.p[l] = SL.pitch[l];
+        L.img[l] = SL.image_offset[l]; L.dog[l] = SL.dog_offset[l];
+        L.tiles_x[l] = (L.w[l] + 63) / 64;
+        L.rowtile[l] = rowtiles;
+        rowtiles += L.h[l] * L.tiles_x[l];
+    }
+    L.rowtile[n] = rowtiles;
+    LF = L;
+    for (int l = 0; l < n; ++l) {
+        L.blk[l] = lap_blocks;
+        lap_blocks += ((L.w[l] + kLapCols - 1) / kLapCols) * ((L.h[l] + kLapRows - 1) / kLapRows);
+        LF.blk[l] = find_blocks;
+        find_blocks += L.tiles_x[l] * ((L.h[l] + 3) / 4);
+    }
+    L.blk[n] = lap_blocks; LF.blk[n] = find_blocks;
+
+    // workspace: level state + result | stash | rowtile | dup flags | dup prefixes
+    const size_t cap = (size_t)max_pts;
+    const size_t o_state = 0, o_result = 8 * sizeof(LevelState), o_stash = 256;
+    const size_t o_rowtile = o_stash + 8 * cap * sizeof(Cand);
+    const size_t o_flag = o_rowtile + (((size_t)rowtiles * 4 + 255) & ~(size_t)255);
+    const size_t o_pre = o_flag + 8 * cap * 4;
+    const size_t ws_need = o_pre + 8 * cap * 4;
     int rc = grow(&ctx->sift_ws, &ctx->sift_ws_bytes, ws_need, st);
     if (rc != SFM_OK) return rc;
     char *ws = static_cast<char *>(ctx->sift_ws);
-    unsigned int *counters = reinterpret_cast<unsigned int *>(ws);
-    Cand *cand = reinterpret_cast<Cand *>(ws + 128);
-    float *ori2 = reinterpret_cast<float *>(ws + 128 + (size_t)max_pts * sizeof(Cand));
-    unsigned int *has2 = reinterpret_cast<unsigned int *>(ori2 + max_pts);
-    SFM_HIP_TRY(hipMemsetAsync(counters, 0, 128, st));
+    Workspace W;
+    W.state = reinterpret_cast<LevelState *>(ws + o_state);
+    W.result = reinterpret_cast<unsigned int *>(ws + o_result);
+    W.stash = reinterpret_cast<Cand *>(ws + o_stash);
+    W.rowtile = reinterpret_cast<unsigned int *>(ws + o_rowtile);
+    W.dupflag = reinterpret_cast<unsigned int *>(ws + o_flag);
+    W.dupprefix = reinterpret_cast<unsigned int *>(ws + o_pre);
+    W.cap = max_pts;
+    SFM_HIP_TRY(hipMemsetAsync(ws, 0, 256, st));
 
-    LapTaps tables[8];
-    std::memset(tables, 0, sizeof(tables));
-    laplace_taps(num_octaves, 0.0f, tables);
+    LapTaps by_octave[8];
+    std::memset(by_octave, 0, sizeof(by_octave));
+    laplace_taps(num_octaves, 0.0f, by_octave);
+    LapTables tabs;
+    std::memset(&tabs, 0, sizeof(tabs));
+    for (int l = 0; l < n; ++l) tabs.t[l] = by_octave[num_octaves - l];      // level l is processed as octave numOctaves - l (:149-168)
     Taps5 lp, sd;
     const double blur = init_blur > (double)0.001f ? init_blur : (double)0.001f;   // max(initBlur, 0.001f), cudaSiftH.cu:120
     lowpass_taps((float)blur, lp);
     scaledown_taps(0.5f, sd);
 
-    const int w0 = L.width[0], h0 = L.height[0], p0 = L.pitch[0];
-    float *img0 = d_temp + L.image_offset[0];
+    const int w0 = SL.width[0], h0 = SL.height[0], p0 = SL.pitch[0];
+    float *img0 = d_temp + SL.image_offset[0];
     const dim3 lpgrid((w0 + kLpW - 1) / kLpW, (h0 + kLpH - 1) / kLpH);
     if (!scale_up) {
         hipLaunchKernelGGL(sift_lowpass_kernel, lpgrid, dim3(256), 0, st, d_image, pitch, img0, p0, w0, h0, lp);
     } else {
-        float *up = d_temp + L.up_offset;
+        float *up = d_temp + SL.up_offset;
         hipLaunchKernelGGL(sift_scaleup_kernel, dim3((width + 63) / 64, (height + 3) / 4), dim3(256), 0, st, d_image, pitch, width, height, up, p0);
         hipLaunchKernelGGL(sift_lowpass_kernel, lpgrid, dim3(256), 0, st, up, p0, img0, p0, w0, h0, lp);
         lowest_scale *= 2.0f;                                                       // cudaSiftH.cu:134
     }
-    for (int l = 1; l < num_octaves; ++l) {
-        const int ws_ = L.width[l - 1], hs = L.height[l - 1];
-        if (L.width[l] <= 0 || L.height[l] <= 0) continue;
-        hipLaunchKernelGGL(sift_scaledown_kernel, dim3((L.width[l] + kSdW - 1) / kSdW, (L.height[l] + kSdH - 1) / kSdH), dim3(256), 0, st,
-                           d_temp + L.image_offset[l - 1], L.pitch[l - 1], ws_, hs, d_temp + L.image_offset[l], L.pitch[l], sd);
+    for (int l = 1; l < n; ++l)
+        hipLaunchKernelGGL(sift_scaledown_kernel, dim3((L.w[l] + kSdW - 1) / kSdW, (L.h[l] + kSdH - 1) / kSdH), dim3(256), 0, st,
+                           d_temp + L.img[l - 1], L.p[l - 1], L.w[l - 1], L.h[l - 1], d_temp + L.img[l], L.p[l], sd);
+    if (n > 0) {
+        hipLaunchKernelGGL(sift_laplace_kernel, dim3(lap_blocks), dim3(128), 0, st, d_temp, L, tabs);
+        hipLaunchKernelGGL(sift_find_kernel, dim3(find_blocks), dim3(256), 0, st, d_temp, LF, W, thresh, lowest_scale, 1.0f / kNumScales, 10.0f);
+        hipLaunchKernelGGL(sift_scan_kernel, dim3(1), dim3(1024), 0, st, LF, W);
+        hipLaunchKernelGGL(sift_orient_kernel, dim3(2048), dim3(256), 0, st, d_temp, LF, W);
+        hipLaunchKernelGGL(sift_place_kernel, dim3(1), dim3(1024), 0, st, LF, W);
+        hipLaunchKernelGGL(sift_desc_kernel, dim3(4096), dim3(256), 0, st, d_temp, LF, W, d_sift, max_pts, scale_up);
     }
-    for (int l = num_octaves - 1; l >= 0; --l) {                                    // coarsest octave first (recursion of :149-168)
-        const int octave = num_octaves - l;
-        const int w = L.width[l], h = L.height[l], p = L.pitch[l];
-        const float subsampling = (float)(1 << l);
-        const float *img = d_temp + L.image_offset[l];
-        float *dog = d_temp + L.dog_offset[l];
-        if (w > 0 && h > 0) {
-            hipLaunchKernelGGL(sift_laplace_kernel, dim3((w + kLapCols - 1) / kLapCols, (h + kLapRows - 1) / kLapRows), dim3(128), 0, st,
-                               img, p, w, h, dog, p, tables[octave]);
-            hipLaunchKernelGGL(sift_find_kernel, dim3((w + 63) / 64, (h + 3) / 4, kNumScales), dim3(256), 0, st, dog, w, h, p, thresh,
-                               lowest_scale / subsampling, 1.0f / kNumScales, 10.0f, cand, counters, octave, max_pts);
-            hipLaunchKernelGGL(sift_emit_kernel, dim3(128), dim3(256), 0, st, cand, counters, d_sift, octave, subsampling, max_pts);
-            hipLaunchKernelGGL(sift_orient_kernel, dim3(512), dim3(256), 0, st, img, p, w, h, d_sift, counters, octave, max_pts, ori2, has2);
-        }
-        hipLaunchKernelGGL(sift_dup_kernel, dim3(1), dim3(1024), 0, st, d_sift, counters, octave, max_pts, ori2, has2);
-        if (w > 0 && h > 0)
-            hipLaunchKernelGGL(sift_desc_kernel, dim3(512), dim3(256), 0, st, img, p, w, h, d_sift, counters, octave, max_pts, subsampling);
-    }
-    if (scale_up)
-        hipLaunchKernelGGL(sift_rescale_kernel, dim3(64), dim3(256), 0, st, d_sift, counters, 2 * num_octaves, max_pts, 0.5f);   // :126
     SFM_HIP_TRY(hipGetLastError());
-    unsigned int hc[17];
-    SFM_HIP_TRY(hipMemcpyAsync(hc, counters, sizeof(hc), hipMemcpyDeviceToHost, st));
+    unsigned int res[2];
+    SFM_HIP_TRY(hipMemcpyAsync(res, W.result, sizeof(res), hipMemcpyDeviceToHost, st));
     SFM_HIP_TRY(hipStreamSynchronize(st));
-    const unsigned int np = hc[2 * num_octaves], ns = hc[2 * num_octaves + 1];
-    *num_pts = (int)(np < (unsigned int)max_pts ? np : (unsigned int)max_pts);      // cudaSiftH.cu:123-124
-    if (num_stored) *num_stored = (int)(ns < (unsigned int)max_pts ? ns : (unsigned int)max_pts);
+    *num_pts = (int)(res[0] < (unsigned int)max_pts ? res[0] : (unsigned int)max_pts);      // cudaSiftH.cu:123-124
+    if (num_stored) *num_stored = (int)(res[1] < (unsigned int)max_pts ? res[1] : (unsigned int)max_pts);
     return SFM_OK;
 }
 
