@@ -113,8 +113,8 @@ struct Levels {
     int w[8], h[8], p[8];
     long long img[8], dog[8];      // float offsets into the temp memory
     int blk[9];                    // block range of level l = [blk[l], blk[l+1])
-    int tiles_x[8];                // 64-pixel tiles per row (find kernel)
-    int rowtile[9];                // offset of level l in the rowtile count array (h[l] * tiles_x[l] entries each)
+    int nseg[8];                   // 256-pixel segments per image row (find kernel)
+    int seg0[9];                   // offset of level l in the per-segment count array (h[l] * nseg[l] entries each)
 };
 
 __device__ __forceinline__ int level_of_block(const Levels &L, int b)
@@ -183,13 +183,13 @@ void sift_laplace_kernel(float *__restrict__ temp, Levels L, LapTables tabs)
 // ---- keypoint candidates ----------------------------------------------------------------------------------------
 // A candidate lives in its level's stash from detection to the final record.  Its place in the output
 // is fixed by (level, y, x, scale), never by the order in which wavefronts happened to run:
-//   rank  = rowtile_offset[level][y][x / 64] + lrank        (lrank: order by (x, scale) inside the row segment)
+//   rank  = seg_offset[level][y][x / 256] + lrank             (lrank: order by (x, scale) inside the row segment)
 //   slot  = base[level] + rank                                 primary orientation
 //   slot2 = base[level] + count[level] + dup_prefix[rank]      secondary orientation
 struct Cand {
     float x, y, scale, sharp, edge;      // level coordinates
     float ori1, ori2;
-    uint32_t rowtile;                    // index into the level's rowtile array
+    uint32_t seg;                        // row segment of the extremum: y * nseg + x / 256
     uint32_t lrank;
     uint32_t rank;
     uint32_t has2;
@@ -197,8 +197,8 @@ struct Cand {
 };
 
 struct LevelState {                      // device-resident bookkeeping, one per level
-    unsigned int found;                  // extrema that passed the tests (unclipped; atomic)
-    unsigned int kept;                   // candidates in the stash = min(found, capacity)
+    unsigned int found;                  // extrema that passed the tests (atomic, block-aggregated)
+    unsigned int kept;                   // sum of the segment counts (== found; closed by sift_scan_kernel)
     unsigned int base;                   // first output slot of the level (unclipped)
     unsigned int dups;                   // secondary orientations of the level
 };
@@ -207,80 +207,125 @@ struct Workspace {
     LevelState *state;                   // [8]
     unsigned int *result;                // [2]: count as the reference reports it, records stored (both unclipped)
     Cand *stash;                         // [8][cap]
-    unsigned int *rowtile;               // counts, then exclusive offsets (sift_scan_kernel)
+    unsigned int *segs;                  // candidates per row segment, then exclusive offsets (sift_scan_kernel)
     unsigned int *dupflag;               // [8][cap]  indexed by rank
     unsigned int *dupprefix;             // [8][cap]
-    int cap;
+    int cap;                             // stash / flag entries per level (4 * max_pts)
 };
 
-// 3-D extrema + refinement (FindPointsMultiNew), every level.  Block = 64 x 4 pixels, all 5 scales;
-// one wavefront = one row segment, so the (x, scale) order inside it comes from ballots.
+// 3-D extrema + refinement (FindPointsMultiNew), every level.  One block = 4 image rows x 256 columns,
+// one wavefront = one row segment, walked left to right in 64-pixel steps; the (x, scale) order inside a
+// segment comes from ballots and a running count, so no sorting is needed.  Each segment's 7-plane neighbourhood
+// (66 x 6 with clamped halo) is staged in LDS once and serves the threshold test, the 26-neighbour test
+// and the refinement.
+constexpr int kFindW = 64, kFindH = 4, kFindSeg = 256, kFindStride = kFindW + 2 + 1;     // +1: odd LDS stride
+constexpr int kFindBuf = 192;
+
 __global__ __launch_bounds__(256)
 void sift_find_kernel(const float *__restrict__ temp, Levels L, Workspace W, float thresh, float lowest_scale, float factor, float edge_limit)
 {
+    __shared__ float tile[kLaplaceS - 1][kFindH + 2][kFindStride];
+    __shared__ Cand buf[kFindBuf];                 // the block's candidates: ONE global atomic per block, not per wavefront
+    __shared__ unsigned int blk_n, blk_base;
+    if (threadIdx.x == 0) blk_n = 0;
     const int lvl = level_of_block(L, blockIdx.x);
     const int w = L.w[lvl], h = L.h[lvl], pd = L.p[lvl];
     const float *__restrict__ dog = temp + L.dog[lvl];
-    const int b = blockIdx.x - L.blk[lvl];
-    const int ntx = L.tiles_x[lvl];
-    const int bx = b % ntx, by = b / ntx;
-    const int lane = threadIdx.x & 63;
-    const int x = bx * 64 + lane, y = by * 4 + (threadIdx.x >> 6);
-    if (y >= h) return;                                                       // whole wavefront
+    const int nseg = L.nseg[lvl];
+    const int bb = blockIdx.x - L.blk[lvl];
+    const int seg = bb % nseg, y0 = (bb / nseg) * kFindH;
+    const int xbeg = seg * kFindSeg, xend = min(w, xbeg + kFindSeg);
+    const int lane = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int y = y0 + ty;
     const size_t plane = (size_t)h * pd;
+    constexpr int kLdsPlane = (kFindH + 2) * kFindStride;
     const float lowest = lowest_scale / (float)(1 << lvl);                   // lowestScale / subsampling (cudaSiftH.cu:208)
-    Refined q[kNumScales];
-    unsigned int mask = 0;
-    if (x < w) {
-        const int xm = max(x - 1, 0), xp = min(x + 1, w - 1), ym = max(y - 1, 0), yp = min(y + 1, h - 1);
-#pragma unroll
-        for (int scale = 0; scale < kNumScales; ++scale) {
-            const float *c = dog + (size_t)(scale + 1) * plane;
-            const float d11 = c[(size_t)y * pd + x];
-            if (!(fabsf(d11) > thresh)) continue;
-            float mn = INFINITY, mx = -INFINITY;
-#pragma unroll
-            for (int dz = -1; dz <= 1; ++dz) {
-                const float *pl = c + (ptrdiff_t)dz * (ptrdiff_t)plane;
-                const float *r0 = pl + (size_t)ym * pd, *r1 = pl + (size_t)y * pd, *r2 = pl + (size_t)yp * pd;
-                const float a0 = r0[xm], a1 = r0[x], a2 = r0[xp], b0 = r1[xm], b2 = r1[xp], c0 = r2[xm], c1 = r2[x], c2 = r2[xp];
-                mn = fminf(mn, fminf(fminf(fminf(a0, a1), fminf(a2, b0)), fminf(fminf(b2, c0), fminf(c1, c2))));
-                mx = fmaxf(mx, fmaxf(fmaxf(fmaxf(a0, a1), fmaxf(a2, b0)), fmaxf(fmaxf(b2, c0), fmaxf(c1, c2))));
-                if (dz != 0) { mn = fminf(mn, r1[x]); mx = fmaxf(mx, r1[x]); }
-            }
-            if (!((d11 < fminf(-thresh, mn)) || (d11 > fmaxf(thresh, mx)))) continue;
-            if (refine_extremum(c + (size_t)y * pd + x, pd, plane, x, y, scale, lowest, factor, edge_limit, q[scale])) mask |= 1u << scale;
-        }
-    }
-    // order inside the row segment: all candidates at smaller x, then the smaller scales at this x
-    unsigned int before = 0, total = 0;
-    const unsigned long long lt = (1ull << lane) - 1ull;
-#pragma unroll
-    for (int s = 0; s < kNumScales; ++s) {
-        const unsigned long long bal = __ballot((mask >> s) & 1u);
-        before += (unsigned int)__builtin_popcountll(bal & lt);
-        total += (unsigned int)__builtin_popcountll(bal);
-    }
-    const unsigned int rt = (unsigned int)(y * ntx + bx);
-    unsigned int base = 0;
-    if (lane == 0 && total > 0) base = atomicAdd(&W.state[lvl].found, total);
-    base = __shfl(base, 0);
-    const unsigned int room = base < (unsigned int)W.cap ? (unsigned int)W.cap - base : 0u;
-    const unsigned int kept = min(total, room);
-    if (lane == 0) W.rowtile[L.rowtile[lvl] + rt] = kept;
     Cand *stash = W.stash + (size_t)lvl * W.cap;
+    unsigned int row_count = 0;                                               // candidates of this row segment kept so far (wave-uniform)
+    for (int x0 = xbeg; x0 < xend; x0 += kFindW) {
+        __syncthreads();
+        // stage 7 planes x 6 rows x 66 columns (clamped halo): wavefront ty takes every 4th row, lane = column
+        {
+            const int cxa = clampi(x0 - 1 + lane, 0, w - 1), cxb = clampi(x0 + 63 + lane, 0, w - 1);
+            constexpr int kRows = (kLaplaceS - 1) * (kFindH + 2), kIter = (kRows + kFindH - 1) / kFindH;
+            float va[kIter], vb[kIter];
 #pragma unroll
-    for (int s = 0; s < kNumScales; ++s) {
-        if ((mask >> s) & 1u) {
-            const unsigned int lr = before + (unsigned int)__builtin_popcount(mask & ((1u << s) - 1u));
-            if (lr < kept) {
-                Cand o;
-                o.x = q[s].xpos; o.y = q[s].ypos; o.scale = q[s].scale; o.sharp = q[s].sharpness; o.edge = q[s].edgeness;
-                o.ori1 = 0.0f; o.ori2 = 0.0f; o.rowtile = rt; o.lrank = lr; o.rank = 0; o.has2 = 0; o.pad = 0;
-                stash[base + lr] = o;
+            for (int it = 0; it < kIter; ++it) {                                     // all loads in flight before the first LDS write
+                const int r = min(ty + it * kFindH, kRows - 1);
+                const int p = r / (kFindH + 2), ry = r - p * (kFindH + 2);           // wave-uniform
+                const float *src = dog + (size_t)p * plane + (size_t)clampi(y0 - 1 + ry, 0, h - 1) * pd;
+                va[it] = src[cxa];
+                vb[it] = lane < 2 ? src[cxb] : 0.0f;
+            }
+#pragma unroll
+            for (int it = 0; it < kIter; ++it) {
+                const int r = ty + it * kFindH;
+                if (r < kRows) {
+                    const int p = r / (kFindH + 2), ry = r - p * (kFindH + 2);
+                    tile[p][ry][lane] = va[it];
+                    if (lane < 2) tile[p][ry][64 + lane] = vb[it];
+                }
             }
         }
+        __syncthreads();
+        const int x = x0 + lane;
+        Refined q[kNumScales];
+        unsigned int mask = 0;
+        if (x < w && y < h) {
+#pragma unroll
+            for (int scale = 0; scale < kNumScales; ++scale) {
+                const float *c = &tile[scale + 1][ty + 1][lane + 1];
+                const float d11 = c[0];
+                if (!(fabsf(d11) > thresh)) continue;                         // most wavefronts leave here as a whole
+                float mn = INFINITY, mx = -INFINITY;
+#pragma unroll
+                for (int dz = -1; dz <= 1; ++dz) {
+                    const float *r1 = c + dz * kLdsPlane, *r0 = r1 - kFindStride, *r2 = r1 + kFindStride;
+                    const float a0 = r0[-1], a1 = r0[0], a2 = r0[1], b0 = r1[-1], b2 = r1[1], c0 = r2[-1], c1 = r2[0], c2 = r2[1];
+                    mn = fminf(mn, fminf(fminf(fminf(a0, a1), fminf(a2, b0)), fminf(fminf(b2, c0), fminf(c1, c2))));
+                    mx = fmaxf(mx, fmaxf(fmaxf(fmaxf(a0, a1), fmaxf(a2, b0)), fmaxf(fmaxf(b2, c0), fmaxf(c1, c2))));
+                    if (dz != 0) { mn = fminf(mn, r1[0]); mx = fmaxf(mx, r1[0]); }
+                }
+                if (!((d11 < fminf(-thresh, mn)) || (d11 > fmaxf(thresh, mx)))) continue;
+                if (refine_extremum(c, kFindStride, (size_t)kLdsPlane, x, y, scale, lowest, factor, edge_limit, q[scale])) mask |= 1u << scale;
+            }
+        }
+        // order inside the row: everything at smaller x, then the smaller scales at this x
+        unsigned int before = 0, total = 0;
+        const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll
+        for (int sc = 0; sc < kNumScales; ++sc) {
+            const unsigned long long bal = __ballot((mask >> sc) & 1u);
+            before += (unsigned int)__builtin_popcountll(bal & lt);
+            total += (unsigned int)__builtin_popcountll(bal);
+        }
+        if (total == 0) continue;                                             // wave-uniform
+        unsigned int base = 0;
+        if (lane == 0) base = atomicAdd(&blk_n, total);                       // LDS
+        base = __shfl(base, 0);
+#pragma unroll
+        for (int sc = 0; sc < kNumScales; ++sc) {
+            if ((mask >> sc) & 1u) {
+                const unsigned int lr = before + (unsigned int)__builtin_popcount(mask & ((1u << sc) - 1u));
+                Cand o;
+                o.x = q[sc].xpos; o.y = q[sc].ypos; o.scale = q[sc].scale; o.sharp = q[sc].sharpness; o.edge = q[sc].edgeness;
+                o.ori1 = 0.0f; o.ori2 = 0.0f; o.seg = (uint32_t)(y * nseg + seg); o.lrank = row_count + lr; o.rank = 0; o.has2 = 0; o.pad = 0;
+                if (base + lr < (unsigned int)kFindBuf) buf[base + lr] = o;
+                else {                                                         // crowded block: straight to the stash
+                    const unsigned int slot = atomicAdd(&W.state[lvl].found, 1u);
+                    if (slot < (unsigned int)W.cap) stash[slot] = o;
+                }
+            }
+        }
+        row_count += total;
     }
+    if (lane == 0 && y < h) W.segs[L.seg0[lvl] + y * nseg + seg] = row_count;
+    __syncthreads();
+    const unsigned int nbuf = min(blk_n, (unsigned int)kFindBuf);
+    if (threadIdx.x == 0 && nbuf > 0) blk_base = atomicAdd(&W.state[lvl].found, nbuf);
+    __syncthreads();
+    for (unsigned int i = threadIdx.x; i < nbuf; i += 256)
+        if (blk_base + i < (unsigned int)W.cap) stash[blk_base + i] = buf[i];
 }
 
 // block-wide exclusive scan of one value per thread (1024 threads); returns the exclusive prefix, total in *sum
@@ -306,22 +351,24 @@ __device__ __forceinline__ unsigned int block_scan_1024(unsigned int v, unsigned
     return wsum[wave] + inc - v;
 }
 
-// rowtile counts -> exclusive offsets, per level; closes LevelState::kept.  One block.
+// per-segment counts -> exclusive offsets, per level; closes LevelState::kept.  One block.
 __global__ __launch_bounds__(1024)
 void sift_scan_kernel(Levels L, Workspace W)
 {
     __shared__ unsigned int wsum[17];
     for (int lvl = 0; lvl < L.n; ++lvl) {
-        unsigned int *a = W.rowtile + L.rowtile[lvl];
-        const int n = L.rowtile[lvl + 1] - L.rowtile[lvl];
-        const int per = (n + 1023) / 1024;
-        const int lo = min(n, (int)threadIdx.x * per), hi = min(n, lo + per);
-        unsigned int mine = 0;
-        for (int i = lo; i < hi; ++i) mine += a[i];
-        unsigned int total;
-        unsigned int run = block_scan_1024(mine, wsum, &total);
-        for (int i = lo; i < hi; ++i) { const unsigned int c = a[i]; a[i] = run; run += c; }
-        if (threadIdx.x == 0) W.state[lvl].kept = total;
+        unsigned int *a = W.segs + L.seg0[lvl];
+        const int n = L.seg0[lvl + 1] - L.seg0[lvl];
+        unsigned int running = 0;
+        for (int i0 = 0; i0 < n; i0 += 1024) {
+            const int i = i0 + (int)threadIdx.x;
+            const unsigned int v = i < n ? a[i] : 0u;
+            unsigned int total;
+            const unsigned int ex = block_scan_1024(v, wsum, &total);
+            if (i < n) a[i] = running + ex;
+            running += total;
+        }
+        if (threadIdx.x == 0) W.state[lvl].kept = min(running, (unsigned int)W.cap);      // running == found
     }
 }
 
@@ -339,7 +386,7 @@ void sift_orient_kernel(const float *__restrict__ temp, Levels L, Workspace W)
         const float *__restrict__ img = temp + L.img[lvl];
         const int w = L.w[lvl], h = L.h[lvl], pitch = L.p[lvl];
         Cand *stash = W.stash + (size_t)lvl * W.cap;
-        const unsigned int *offs = W.rowtile + L.rowtile[lvl];
+        const unsigned int *offs = W.segs + L.seg0[lvl];
         for (unsigned int c = gw; c < kept; c += nw) {
             const float xpos = stash[c].x, ypos = stash[c].y, scale = stash[c].scale;
             const float i2sigma2 = -1.0f / (2.0f * 1.5f * 1.5f * scale * scale);
@@ -395,10 +442,10 @@ void sift_orient_kernel(const float *__restrict__ temp, Levels L, Workspace W)
                     stash[c].ori2 = 11.25f * (peak < 0.0f ? peak + 32.0f : peak);
                     second = 1;
                 }
-                const unsigned int rank = offs[stash[c].rowtile] + stash[c].lrank;
+                const unsigned int rank = offs[stash[c].seg] + stash[c].lrank;
                 stash[c].rank = rank;
                 stash[c].has2 = second;
-                W.dupflag[(size_t)lvl * W.cap + rank] = second;
+                if (rank < (unsigned int)W.cap) W.dupflag[(size_t)lvl * W.cap + rank] = second;
             }
             wave_phase();
         }
@@ -435,7 +482,7 @@ void sift_place_kernel(Levels L, Workspace W)
 // ---- 4x4x8 gradient histogram, one wavefront per record (ExtractSiftDescriptorsCONSTNew) -----------------
 __device__ __forceinline__ void describe_and_store(const float *__restrict__ img, int pitch, int w, int h, const Cand &c, float orientation,
                                                    float subsampling, float rescale, sfm_sift_point *__restrict__ out, const float *gauss,
-                                                   float *sgrad, float *sangf, int *sangi, int lane)
+                                                   float4 *smp, const float (&wyk)[8], const float (&wxk)[8], int s0, int lane)
 {
     const float px = c.x, py = c.y;
     const float theta = 2.0f * 3.1415f / 360.0f * orientation;
@@ -455,50 +502,43 @@ __device__ __forceinline__ void describe_and_store(const float *__restrict__ img
         float angf = 4.0f / 3.1415f * fast_atan2(dy, dx) + 4.0f;
         const int angi = (int)angf;
         angf -= (float)angi;
-        sgrad[s] = grad;
-        sangf[s] = angf;
-        sangi[s] = angi & 7;
+        smp[s] = make_float4(grad, angf, __int_as_float(angi & 7), 0.0f);
     }
     wave_phase();
-    float bins[2];
+    // lane = (cell, a0): bins (cell, a0) and (cell, a0 + 4) share one pass over the cell's 8 x 8 samples,
+    // each bin still summed in sample order
+    const int cell = lane >> 2, a0 = lane & 3;
+    float acc0 = 0.0f, acc1 = 0.0f;
+    // 8 x 8 window of the cell, fully unrolled: constant LDS offsets, weights from registers; samples outside the
+    // cell's support carry weight 0 and add an exact +0
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        const int b = lane + 64 * r, cell = b >> 3, ang = b & 7, vcell = cell >> 2, hcell = cell & 3;
-        float acc = 0.0f;
-        const int ylo = max(0, 4 * vcell - 2), yhi = min(15, 4 * vcell + 5);
-        const int xlo = max(0, 4 * hcell - 2), xhi = min(15, 4 * hcell + 5);
-        for (int y = ylo; y <= yhi; ++y) {
-            const int veri = (y + 2) / 4 - 1;
-            const float verf = ((float)y - 1.5f) / 4.0f - (float)veri;
-            const float wy = (veri == vcell) ? 1.0f - verf : verf;
-            for (int tx = xlo; tx <= xhi; ++tx) {
-                const int hori = (tx + 2) / 4 - 1;
-                const float horf = ((float)tx - 1.5f) / 4.0f - (float)hori;
-                const float wx = (hori == hcell) ? 1.0f - horf : horf;
-                const int s = y * 16 + tx;
-                const int angi = sangi[s];
-                const float angf = sangf[s];
-                const float grad2 = wy * (wx * sgrad[s]);
-                if (angi == ang) acc += (1.0f - angf) * grad2;
-                else if (((angi + 1) & 7) == ang) acc += angf * grad2;
-            }
+    for (int ky = 0; ky < 8; ++ky) {
+#pragma unroll
+        for (int kx = 0; kx < 8; ++kx) {
+            const float4 v = smp[s0 + ky * 16 + kx];
+            const int angi = __float_as_int(v.z), angp = (angi + 1) & 7;
+            const float grad2 = wyk[ky] * (wxk[kx] * v.x);
+            const float lo = (1.0f - v.y) * grad2, hi = v.y * grad2;
+            acc0 += (angi == a0) ? lo : ((angp == a0) ? hi : 0.0f);
+            acc1 += (angi == a0 + 4) ? lo : ((angp == a0 + 4) ? hi : 0.0f);
         }
-        bins[r] = acc;
     }
-    // two normalisations with the 0.2 clip in between; 32-wide shuffle trees as in the reference
-    float sq0 = bins[0] * bins[0], sq1 = bins[1] * bins[1];
-#pragma unroll
-    for (int i = 16; i > 0; i >>= 1) { sq0 += __shfl_down(sq0, i, 32); sq1 += __shfl_down(sq1, i, 32); }
-    float tsum = __shfl(sq0, 0) + __shfl(sq0, 32) + __shfl(sq1, 0) + __shfl(sq1, 32);
-    const float r1 = 1.0f / sqrtf(tsum);
-    const float t0 = fminf(bins[0] * r1, 0.2f), t1 = fminf(bins[1] * r1, 0.2f);
-    sq0 = t0 * t0; sq1 = t1 * t1;
-#pragma unroll
-    for (int i = 16; i > 0; i >>= 1) { sq0 += __shfl_down(sq0, i, 32); sq1 += __shfl_down(sq1, i, 32); }
-    tsum = __shfl(sq0, 0) + __shfl(sq0, 32) + __shfl(sq1, 0) + __shfl(sq1, 32);
-    const float r2 = 1.0f / sqrtf(tsum);
-    out->data[lane] = t0 * r2;
-    out->data[lane + 64] = t1 * r2;
+    // two normalisations with the 0.2 clip in between.  The reference reduces bins 32k..32k+31 with the
+    // shuffle tree i + 16, + 8, + 4, + 2, + 1; in this layout those partners are lane + 8, lane + 4 (cells),
+    // the lane's own second bin (angle + 4), lane + 2, lane + 1 (angles): same additions, same order.
+    auto tree = [&](float v0, float v1) {
+        v0 += __shfl_down(v0, 8); v1 += __shfl_down(v1, 8);
+        v0 += __shfl_down(v0, 4); v1 += __shfl_down(v1, 4);
+        float t = v0 + v1;
+        t += __shfl_down(t, 2);
+        t += __shfl_down(t, 1);
+        return __shfl(t, 0) + __shfl(t, 16) + __shfl(t, 32) + __shfl(t, 48);
+    };
+    const float r1 = 1.0f / sqrtf(tree(acc0 * acc0, acc1 * acc1));
+    const float t0 = fminf(acc0 * r1, 0.2f), t1 = fminf(acc1 * r1, 0.2f);
+    const float r2 = 1.0f / sqrtf(tree(t0 * t0, t1 * t1));
+    out->data[cell * 8 + a0] = t0 * r2;
+    out->data[cell * 8 + a0 + 4] = t1 * r2;
     if (lane == 0) {
         out->xpos = (px * subsampling) * rescale;        // :412-414, then RescalePositions (:753-761) when scaleUp
         out->ypos = (py * subsampling) * rescale;
@@ -514,12 +554,27 @@ __device__ __forceinline__ void describe_and_store(const float *__restrict__ img
 __global__ __launch_bounds__(256)
 void sift_desc_kernel(const float *__restrict__ temp, Levels L, Workspace W, sfm_sift_point *__restrict__ sift, int max_pts, int scale_up)
 {
-    __shared__ float lds[4][16 + 3 * 256];
+    __shared__ float4 samples[4][256];
+    __shared__ float gtab[4][16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float *gauss = lds[wave], *sgrad = gauss + 16, *sangf = sgrad + 256;
-    int *sangi = reinterpret_cast<int *>(sangf + 256);
+    float *gauss = gtab[wave];
+    float4 *smp = samples[wave];
     if (lane < 16) gauss[lane] = exp_poly(-((float)lane - 7.5f) * ((float)lane - 7.5f) / 128.0f);
     wave_phase();
+    // this lane's histogram cell and the trilinear weights of its 8 x 8 sample window (cudaSiftD.cu:345-383)
+    const int vcell = lane >> 4, hcell = (lane >> 2) & 3;
+    const int ys = clampi(4 * vcell - 2, 0, 8), xs = clampi(4 * hcell - 2, 0, 8);
+    float wyk[8], wxk[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int y = ys + k, veri = (y + 2) / 4 - 1;
+        const float verf = ((float)y - 1.5f) / 4.0f - (float)veri;
+        wyk[k] = (veri == vcell) ? 1.0f - verf : ((veri + 1 == vcell) ? verf : 0.0f);
+        const int tx = xs + k, hori = (tx + 2) / 4 - 1;
+        const float horf = ((float)tx - 1.5f) / 4.0f - (float)hori;
+        wxk[k] = (hori == hcell) ? 1.0f - horf : ((hori + 1 == hcell) ? horf : 0.0f);
+    }
+    const int s0 = ys * 16 + xs;
     const unsigned int gw = blockIdx.x * 4 + wave, nw = gridDim.x * 4;
     const unsigned int reported = min(W.result[0], (unsigned int)max_pts);
     for (int lvl = 0; lvl < L.n; ++lvl) {
@@ -534,12 +589,12 @@ void sift_desc_kernel(const float *__restrict__ temp, Levels L, Workspace W, sfm
             const unsigned int slot = base + c.rank;
             if (slot < (unsigned int)max_pts)
                 describe_and_store(img, pitch, w, h, c, c.ori1, subsampling, (scale_up && slot < reported) ? 0.5f : 1.0f, &sift[slot],
-                                   gauss, sgrad, sangf, sangi, lane);
+                                   gauss, smp, wyk, wxk, s0, lane);
             if (c.has2) {
                 const unsigned int slot2 = base + found + pre[c.rank];
                 if (slot2 < (unsigned int)max_pts)
                     describe_and_store(img, pitch, w, h, c, c.ori2, subsampling, (scale_up && slot2 < reported) ? 0.5f : 1.0f, &sift[slot2],
-                                       gauss, sgrad, sangf, sangi, lane);
+                                       gauss, smp, wyk, wxk, s0, lane);
             }
         }
     }
@@ -629,30 +684,30 @@ int launch_extract_sift(sfm_ctx *ctx, sfm_sift_point *d_sift, int max_pts, const
     int n = 0;
     for (int l = 0; l < num_octaves && SL.width[l] > 0 && SL.height[l] > 0; ++l) ++n;
     L.n = n;
-    int lap_blocks = 0, find_blocks = 0, rowtiles = 0;
+    int lap_blocks = 0, find_blocks = 0, segs = 0;
     Levels LF;                                             // same levels, block ranges of the find kernel
     for (int l = 0; l < n; ++l) {
         L.w[l] = SL.width[l]; L.h[l] = SL.height[l]; L.p[l] = SL.pitch[l];
         L.img[l] = SL.image_offset[l]; L.dog[l] = SL.dog_offset[l];
-        L.tiles_x[l] = (L.w[l] + 63) / 64;
-        L.rowtile[l] = rowtiles;
-        rowtiles += L.h[l] * L.tiles_x[l];
+        L.nseg[l] = (L.w[l] + kFindSeg - 1) / kFindSeg;
+        L.seg0[l] = segs;
+        segs += L.h[l] * L.nseg[l];
     }
-    L.rowtile[n] = rowtiles;
+    L.seg0[n] = segs;
     LF = L;
     for (int l = 0; l < n; ++l) {
         L.blk[l] = lap_blocks;
         lap_blocks += ((L.w[l] + kLapCols - 1) / kLapCols) * ((L.h[l] + kLapRows - 1) / kLapRows);
         LF.blk[l] = find_blocks;
-        find_blocks += L.tiles_x[l] * ((L.h[l] + 3) / 4);
+        find_blocks += L.nseg[l] * ((L.h[l] + kFindH - 1) / kFindH);
     }
     L.blk[n] = lap_blocks; LF.blk[n] = find_blocks;
 
-    // workspace: level state + result | stash | rowtile | dup flags | dup prefixes
-    const size_t cap = (size_t)max_pts;
+    // workspace: level state + result | stash | per-segment counts | dup flags | dup prefixes
+    const size_t cap = (size_t)max_pts * 4;
     const size_t o_state = 0, o_result = 8 * sizeof(LevelState), o_stash = 256;
-    const size_t o_rowtile = o_stash + 8 * cap * sizeof(Cand);
-    const size_t o_flag = o_rowtile + (((size_t)rowtiles * 4 + 255) & ~(size_t)255);
+    const size_t o_segs = o_stash + 8 * cap * sizeof(Cand);
+    const size_t o_flag = o_segs + (((size_t)segs * 4 + 255) & ~(size_t)255);
     const size_t o_pre = o_flag + 8 * cap * 4;
     const size_t ws_need = o_pre + 8 * cap * 4;
     int rc = grow(&ctx->sift_ws, &ctx->sift_ws_bytes, ws_need, st);
@@ -662,10 +717,10 @@ int launch_extract_sift(sfm_ctx *ctx, sfm_sift_point *d_sift, int max_pts, const
     W.state = reinterpret_cast<LevelState *>(ws + o_state);
     W.result = reinterpret_cast<unsigned int *>(ws + o_result);
     W.stash = reinterpret_cast<Cand *>(ws + o_stash);
-    W.rowtile = reinterpret_cast<unsigned int *>(ws + o_rowtile);
+    W.segs = reinterpret_cast<unsigned int *>(ws + o_segs);
     W.dupflag = reinterpret_cast<unsigned int *>(ws + o_flag);
     W.dupprefix = reinterpret_cast<unsigned int *>(ws + o_pre);
-    W.cap = max_pts;
+    W.cap = (int)cap;
     SFM_HIP_TRY(hipMemsetAsync(ws, 0, 256, st));
 
     LapTaps by_octave[8];
@@ -703,8 +758,13 @@ int launch_extract_sift(sfm_ctx *ctx, sfm_sift_point *d_sift, int max_pts, const
     }
     SFM_HIP_TRY(hipGetLastError());
     unsigned int res[2];
+    LevelState hs[8];
     SFM_HIP_TRY(hipMemcpyAsync(res, W.result, sizeof(res), hipMemcpyDeviceToHost, st));
+    SFM_HIP_TRY(hipMemcpyAsync(hs, W.state, sizeof(hs), hipMemcpyDeviceToHost, st));
     SFM_HIP_TRY(hipStreamSynchronize(st));
+    for (int l = 0; l < n; ++l)
+        SFM_REQUIRE(hs[l].found <= (unsigned int)cap, SFM_E_CAPACITY,
+                    "level %d produced %u raw extrema, more than 4 * max_pts = %zu: raise thresh or max_pts", l, hs[l].found, cap);
     *num_pts = (int)(res[0] < (unsigned int)max_pts ? res[0] : (unsigned int)max_pts);      // cudaSiftH.cu:123-124
     if (num_stored) *num_stored = (int)(res[1] < (unsigned int)max_pts ? res[1] : (unsigned int)max_pts);
     return SFM_OK;
