@@ -359,27 +359,37 @@ void sift_scan_kernel(Levels L, Workspace W)
     for (int lvl = 0; lvl < L.n; ++lvl) {
         unsigned int *a = W.segs + L.seg0[lvl];
         const int n = L.seg0[lvl + 1] - L.seg0[lvl];
-        unsigned int running = 0;
-        for (int i0 = 0; i0 < n; i0 += 1024) {
-            const int i = i0 + (int)threadIdx.x;
-            const unsigned int v = i < n ? a[i] : 0u;
-            unsigned int total;
-            const unsigned int ex = block_scan_1024(v, wsum, &total);
-            if (i < n) a[i] = running + ex;
-            running += total;
-        }
+        const int per = (n + 1023) / 1024;                          // consecutive entries per thread: one block scan per level
+        const int lo = min(n, (int)threadIdx.x * per), hi = min(n, lo + per);
+        unsigned int mine = 0;
+        for (int i = lo; i < hi; ++i) mine += a[i];
+        unsigned int running;
+        unsigned int run = block_scan_1024(mine, wsum, &running);
+        for (int i = lo; i < hi; ++i) { const unsigned int c = a[i]; a[i] = run; run += c; }
         if (threadIdx.x == 0) W.state[lvl].kept = min(running, (unsigned int)W.cap);      // running == found
     }
 }
 
 // ---- orientation histogram, one wavefront per candidate (ComputeOrientationsCONST) ------------------------
+// arg-max over 32 lanes with "first index wins" (what the serial scan of cudaSiftD.cu:1022-1036 produces)
+__device__ __forceinline__ void first_max32(float &v, int &i)
+{
+#pragma unroll
+    for (int d = 1; d < 32; d <<= 1) {
+        const float ov = __shfl_xor(v, d);
+        const int oi = __shfl_xor(i, d);
+        if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+    }
+}
+
 __global__ __launch_bounds__(256)
 void sift_orient_kernel(const float *__restrict__ temp, Levels L, Workspace W)
 {
-    __shared__ float lds[4][16 + 128 + 64 + 128];
+    __shared__ float2 samples[4][128];
+    __shared__ float lds[4][16 + 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float *gauss = lds[wave], *sval = gauss + 16, *hist = sval + 128;
-    int *sbin = reinterpret_cast<int *>(hist + 64);
+    float *gauss = lds[wave], *hist = gauss + 16;
+    float2 *smp = samples[wave];                       // (bin as float bits, weight)
     const unsigned int gw = blockIdx.x * 4 + wave, nw = gridDim.x * 4;
     for (int lvl = 0; lvl < L.n; ++lvl) {
         const unsigned int kept = W.state[lvl].kept;
@@ -404,8 +414,7 @@ void sift_orient_kernel(const float *__restrict__ temp, Levels L, Workspace W)
                     int bin = (int)(16.0f * atan2_poly(dy, dx) / 3.1416f + 16.5f);
                     if (bin > 31) bin = 0;
                     const float grad = sqrtf(dx * dx + dy * dy);
-                    sbin[t] = bin;
-                    sval[t] = grad * gauss[xd] * gauss[yd];
+                    smp[t] = make_float2(__int_as_float(bin), grad * gauss[xd] * gauss[yd]);
                 }
             }
             wave_phase();
@@ -413,25 +422,32 @@ void sift_orient_kernel(const float *__restrict__ temp, Levels L, Workspace W)
             const int x2m = lane >= 2 ? lane - 2 : lane + 30, x2p = lane <= 29 ? lane + 2 : lane - 30;
             if (lane < 32) {
                 float acc = 0.0f;
-                for (int t = 0; t < 121; ++t) acc += (sbin[t] == lane) ? sval[t] : 0.0f;      // sample order
+#pragma unroll 11
+                for (int t = 0; t < 121; ++t) {                                           // sample order
+                    const float2 sv = smp[t];
+                    acc += (__float_as_int(sv.x) == lane) ? sv.y : 0.0f;
+                }
                 hist[lane] = acc;
             }
             wave_phase();
             if (lane < 32) hist[32 + lane] = 6.0f * hist[lane] + 4.0f * (hist[x1m] + hist[x1p]) + (hist[x2m] + hist[x2p]);
             wave_phase();
+            float pk = 0.0f;
             if (lane < 32) {
                 const float v = hist[32 + lane];
-                hist[lane] = (v > hist[32 + x1m] && v >= hist[32 + x1p]) ? v : 0.0f;
+                pk = (v > hist[32 + x1m] && v >= hist[32 + x1p]) ? v : 0.0f;
             }
-            wave_phase();
+            // two highest peaks, first index on ties (lanes 32..63 mirror lanes 0..31 and do not disturb the result)
+            float maxval1 = __shfl(pk, lane & 31);
+            int i1 = lane & 31;
+            first_max32(maxval1, i1);
+            float maxval2 = __shfl(pk, lane & 31);
+            int i2 = lane & 31;
+            if (i2 == i1) maxval2 = -1.0f;
+            first_max32(maxval2, i2);
+            if (!(maxval1 > 0.0f)) { maxval1 = 0.0f; i1 = -1; }
+            if (!(maxval2 > 0.0f)) { maxval2 = 0.0f; i2 = -1; }
             if (lane == 0) {
-                float maxval1 = 0.0f, maxval2 = 0.0f;
-                int i1 = -1, i2 = -1;
-                for (int i = 0; i < 32; ++i) {
-                    const float v = hist[i];
-                    if (v > maxval1) { maxval2 = maxval1; maxval1 = v; i2 = i1; i1 = i; }
-                    else if (v > maxval2) { maxval2 = v; i2 = i; }
-                }
                 float val1 = hist[32 + ((i1 + 1) & 31)], val2 = hist[32 + ((i1 + 31) & 31)];
                 float peak = (float)i1 + 0.5f * (val1 - val2) / (2.0f * maxval1 - val1 - val2);
                 stash[c].ori1 = 11.25f * (peak < 0.0f ? peak + 32.0f : peak);
@@ -463,15 +479,13 @@ void sift_place_kernel(Levels L, Workspace W)
         const unsigned int kept = W.state[lvl].kept, found = W.state[lvl].found;
         const unsigned int *flag = W.dupflag + (size_t)lvl * W.cap;
         unsigned int *pre = W.dupprefix + (size_t)lvl * W.cap;
-        unsigned int running = 0;
-        for (unsigned int i0 = 0; i0 < kept; i0 += 1024) {
-            const unsigned int i = i0 + threadIdx.x;
-            const unsigned int f = i < kept ? flag[i] : 0u;
-            unsigned int total;
-            const unsigned int ex = block_scan_1024(f, wsum, &total);
-            if (i < kept) pre[i] = running + ex;
-            running += total;
-        }
+        const unsigned int per = (kept + 1023u) / 1024u;
+        const unsigned int lo = min(kept, threadIdx.x * per), hi = min(kept, lo + per);
+        unsigned int mine = 0;
+        for (unsigned int i = lo; i < hi; ++i) mine += flag[i];
+        unsigned int running;
+        unsigned int run = block_scan_1024(mine, wsum, &running);
+        for (unsigned int i = lo; i < hi; ++i) { pre[i] = run; run += flag[i]; }
         if (threadIdx.x == 0) { W.state[lvl].base = base; W.state[lvl].dups = running; }
         reported = base + found;                         // what d_PointCounter[2*octave] holds after the level
         base += found + running;
@@ -480,7 +494,59 @@ void sift_place_kernel(Levels L, Workspace W)
 }
 
 // ---- 4x4x8 gradient histogram, one wavefront per record (ExtractSiftDescriptorsCONSTNew) -----------------
-__device__ __forceinline__ void describe_and_store(const float *__restrict__ img, int pitch, int w, int h, const Cand &c, float orientation,
+// The 16 x 16 sample grid makes 1024 bilinear fetches around the keypoint; their footprint (radius
+// ~8 * scale + 4 pixels) is staged in LDS once per keypoint and shared by both orientations.
+constexpr int kPatchMax = 39;                      // side of the largest staged footprint (local scale < 2.01; larger ones fetch from memory)
+
+struct Patch {
+    const float *p;        // LDS, side x side, texel (ox + i, oy + j) with clamped addressing; nullptr: fetch from memory
+    int side, ox, oy;
+};
+
+// tex_bilinear on the staged footprint: same arithmetic, indices relative to the footprint
+__device__ __forceinline__ float tex_patch(const Patch &P, float x, float y, bool &ok)
+{
+    const float xb = x - 0.5f, yb = y - 0.5f;
+    const float fx = floorf(xb), fy = floorf(yb);
+    const float a = xb - fx, b = yb - fy;
+    const int ix = (int)fx - P.ox, iy = (int)fy - P.oy;
+    ok = ok && ix >= 0 && iy >= 0 && ix + 1 < P.side && iy + 1 < P.side;
+    const int cx = clampi(ix, 0, P.side - 2), cy = clampi(iy, 0, P.side - 2);
+    const float *r0 = P.p + cy * P.side + cx, *r1 = r0 + P.side;
+    const float t00 = r0[0], t10 = r0[1], t01 = r1[0], t11 = r1[1];
+    const float top = fmaf(a, t10 - t00, t00), bot = fmaf(a, t11 - t01, t01);
+    return fmaf(b, bot - top, top);
+}
+
+template <bool STAGED>
+__device__ __forceinline__ bool sample_grid(const float *__restrict__ img, int pitch, int w, int h, const Patch &P, float px, float py,
+                                            float sina, float cosa, float ssina, float scosa, const float *gauss, float4 (&out)[4], int lane)
+{
+    bool ok = true;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int s = lane + 64 * r, tx = s & 15, y = s >> 4;
+        const float fx = (float)tx - 7.5f, fy = (float)y - 7.5f;
+        const float xs = px + fx * scosa - fy * ssina + 0.5f;
+        const float ys = py + fx * ssina + fy * scosa + 0.5f;
+        float dx, dy;
+        if (STAGED) {
+            dx = tex_patch(P, xs + cosa, ys + sina, ok) - tex_patch(P, xs - cosa, ys - sina, ok);
+            dy = tex_patch(P, xs - sina, ys + cosa, ok) - tex_patch(P, xs + sina, ys - cosa, ok);
+        } else {
+            dx = tex_bilinear(img, pitch, w, h, xs + cosa, ys + sina) - tex_bilinear(img, pitch, w, h, xs - cosa, ys - sina);
+            dy = tex_bilinear(img, pitch, w, h, xs - sina, ys + cosa) - tex_bilinear(img, pitch, w, h, xs + sina, ys - cosa);
+        }
+        const float grad = gauss[y] * gauss[tx] * sqrtf(dx * dx + dy * dy);
+        float angf = 4.0f / 3.1415f * fast_atan2(dy, dx) + 4.0f;
+        const int angi = (int)angf;
+        angf -= (float)angi;
+        out[r] = make_float4(grad, angf, __int_as_float(angi & 7), 0.0f);
+    }
+    return __ballot(!ok) == 0ull;
+}
+
+__device__ __forceinline__ void describe_and_store(const float *__restrict__ img, int pitch, int w, int h, const Patch &P, const Cand &c, float orientation,
                                                    float subsampling, float rescale, sfm_sift_point *__restrict__ out, const float *gauss,
                                                    float4 *smp, const float (&wyk)[8], const float (&wxk)[8], int s0, int lane)
 {
@@ -490,20 +556,13 @@ __device__ __forceinline__ void describe_and_store(const float *__restrict__ img
     sincos_poly(theta, sina, cosa);
     const float scale = 12.0f / 16.0f * c.scale;
     const float ssina = scale * sina, scosa = scale * cosa;
+    float4 mine[4];
+    bool done = false;
+    if (P.p) done = sample_grid<true>(img, pitch, w, h, P, px, py, sina, cosa, ssina, scosa, gauss, mine, lane);
+    if (!done) sample_grid<false>(img, pitch, w, h, P, px, py, sina, cosa, ssina, scosa, gauss, mine, lane);   // footprint not staged (huge scale)
+    wave_phase();                                                            // the samples overwrite the footprint they were read from
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int s = lane + 64 * r, tx = s & 15, y = s >> 4;
-        const float fx = (float)tx - 7.5f, fy = (float)y - 7.5f;
-        const float xs = px + fx * scosa - fy * ssina + 0.5f;
-        const float ys = py + fx * ssina + fy * scosa + 0.5f;
-        const float dx = tex_bilinear(img, pitch, w, h, xs + cosa, ys + sina) - tex_bilinear(img, pitch, w, h, xs - cosa, ys - sina);
-        const float dy = tex_bilinear(img, pitch, w, h, xs - sina, ys + cosa) - tex_bilinear(img, pitch, w, h, xs + sina, ys - cosa);
-        const float grad = gauss[y] * gauss[tx] * sqrtf(dx * dx + dy * dy);
-        float angf = 4.0f / 3.1415f * fast_atan2(dy, dx) + 4.0f;
-        const int angi = (int)angf;
-        angf -= (float)angi;
-        smp[s] = make_float4(grad, angf, __int_as_float(angi & 7), 0.0f);
-    }
+    for (int r = 0; r < 4; ++r) smp[lane + 64 * r] = mine[r];
     wave_phase();
     // lane = (cell, a0): bins (cell, a0) and (cell, a0 + 4) share one pass over the cell's 8 x 8 samples,
     // each bin still summed in sample order
@@ -554,11 +613,13 @@ __device__ __forceinline__ void describe_and_store(const float *__restrict__ img
 __global__ __launch_bounds__(256)
 void sift_desc_kernel(const float *__restrict__ temp, Levels L, Workspace W, sfm_sift_point *__restrict__ sift, int max_pts, int scale_up)
 {
-    __shared__ float4 samples[4][256];
+    constexpr int kWaveLds = (kPatchMax * kPatchMax + 3) / 4 > 256 ? (kPatchMax * kPatchMax + 3) / 4 : 256;   // float4 units
+    __shared__ float4 scratch[4][kWaveLds];           // per wavefront: the staged footprint, then (aliased) the 256 samples
     __shared__ float gtab[4][16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float *gauss = gtab[wave];
-    float4 *smp = samples[wave];
+    float4 *smp = scratch[wave];
+    float *fp_lds = reinterpret_cast<float *>(scratch[wave]);
     if (lane < 16) gauss[lane] = exp_poly(-((float)lane - 7.5f) * ((float)lane - 7.5f) / 128.0f);
     wave_phase();
     // this lane's histogram cell and the trilinear weights of its 8 x 8 sample window (cudaSiftD.cu:345-383)
@@ -587,14 +648,33 @@ void sift_desc_kernel(const float *__restrict__ temp, Levels L, Workspace W, sfm
         for (unsigned int ci = gw; ci < kept; ci += nw) {
             const Cand c = stash[ci];
             const unsigned int slot = base + c.rank;
-            if (slot < (unsigned int)max_pts)
-                describe_and_store(img, pitch, w, h, c, c.ori1, subsampling, (scale_up && slot < reported) ? 0.5f : 1.0f, &sift[slot],
+            const unsigned int slot2 = c.has2 ? base + found + pre[c.rank] : 0xFFFFFFFFu;
+            if (slot >= (unsigned int)max_pts && slot2 >= (unsigned int)max_pts) continue;
+            // the sampling footprint: radius >= 7.5 * sqrt(2) * 0.75 * scale + 3.5 texels around the keypoint
+            Patch P;
+            const bool sane = c.scale > 0.0f && c.scale < 8.0f;               // the fallback of cudaSiftD.cu:1409 can produce any scale
+            const int R = sane ? (int)(7.96f * c.scale) + 4 : kPatchMax;
+            P.side = 2 * R + 1; P.ox = (int)floorf(c.x) - R; P.oy = (int)floorf(c.y) - R;
+            const int col = clampi(P.ox + lane, 0, w - 1);
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const unsigned int dst = k == 0 ? slot : slot2;
+                if (dst >= (unsigned int)max_pts) continue;
+                P.p = nullptr;
+                if (P.side <= kPatchMax) {                                    // staged again for the second orientation: the samples overwrote it
+                    for (int j0 = 0; j0 < P.side; j0 += 4) {
+                        float v[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) v[u] = img[(size_t)clampi(P.oy + min(j0 + u, P.side - 1), 0, h - 1) * pitch + col];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                            if (lane < P.side && j0 + u < P.side) fp_lds[(j0 + u) * P.side + lane] = v[u];
+                    }
+                    P.p = fp_lds;
+                    wave_phase();
+                }
+                describe_and_store(img, pitch, w, h, P, c, k == 0 ? c.ori1 : c.ori2, subsampling, (scale_up && dst < reported) ? 0.5f : 1.0f, &sift[dst],
                                    gauss, smp, wyk, wxk, s0, lane);
-            if (c.has2) {
-                const unsigned int slot2 = base + found + pre[c.rank];
-                if (slot2 < (unsigned int)max_pts)
-                    describe_and_store(img, pitch, w, h, c, c.ori2, subsampling, (scale_up && slot2 < reported) ? 0.5f : 1.0f, &sift[slot2],
-                                       gauss, smp, wyk, wxk, s0, lane);
             }
         }
     }
