@@ -16,11 +16,12 @@ HDRS     := $(wildcard $(CSRC)/*.hpp) include/sfm_amd.h
 DEMO     := $(PKG)/host/two_view_demo
 HDEMO    := $(PKG)/host/homography_demo
 SDEMO    := $(PKG)/host/sift_demo
+MAINAPP  := $(PKG)/host/sfm_main
 
 IOTEST   := tests/cpp/io_test
 GEOMTEST := tests/cpp/geom_test
 
-all: $(LIB) oracle hostcheck $(DEMO) $(HDEMO) $(SDEMO) $(IOTEST) $(GEOMTEST)
+all: $(LIB) oracle hostcheck $(DEMO) $(HDEMO) $(SDEMO) $(MAINAPP) $(IOTEST) $(GEOMTEST)
 
 $(BUILD)/%.o: $(CSRC)/%.hip $(HDRS)
 	@mkdir -p $(BUILD)
@@ -43,6 +44,9 @@ $(HDEMO): $(PKG)/host/homography_demo.cpp $(PKG)/host/geomFuncs.h $(PKG)/host/cu
 $(SDEMO): $(PKG)/host/sift_demo.cpp $(PKG)/host/cudaImage.h $(PKG)/host/sfm_io.h $(PKG)/host/cudaSift.h include/sfm_amd.h $(LIB)
 	g++ -O2 -std=c++14 -Wall -o $@ $< -L$(PKG)/lib -lsfm_amd -Wl,-rpath,'$$ORIGIN/../lib' -Wl,-rpath,/opt/rocm/lib
 
+$(MAINAPP): $(PKG)/host/sfm_main.cpp $(PKG)/host/cudaImage.h $(PKG)/host/sfm.h $(PKG)/host/sfm_io.h $(PKG)/host/cudaSift.h include/sfm_amd.h $(LIB)
+	g++ -O2 -std=c++14 -Wall -o $@ $< -L$(PKG)/lib -lsfm_amd -Wl,-rpath,'$$ORIGIN/../lib' -Wl,-rpath,/opt/rocm/lib
+
 $(IOTEST): tests/cpp/io_test.cpp $(PKG)/host/sfm_io.h $(PKG)/host/cudaSift.h include/sfm_amd.h
 	g++ -O2 -std=c++14 -Wall -o $@ $<
 
@@ -55,7 +59,7 @@ tests/hostcheck/libhostcheck.so: tests/hostcheck/hostcheck.hip $(CSRC)/device_ma
 	$(HIPCC) -x hip --cuda-host-only -O2 -ffp-contract=off -mfma -fPIC -shared -Wno-pass-failed -o $@ $<
 
 clean:
-	rm -rf $(BUILD) $(LIB) $(DEMO) $(HDEMO) $(SDEMO) $(IOTEST) $(GEOMTEST) tests/hostcheck/libhostcheck.so
+	rm -rf $(BUILD) $(LIB) $(DEMO) $(HDEMO) $(SDEMO) $(MAINAPP) $(IOTEST) $(GEOMTEST) tests/hostcheck/libhostcheck.so
 	$(MAKE) -C oracle clean
 
 .PHONY: all oracle hostcheck clean

@@ -185,6 +185,29 @@ def image(width=640, height=480, seed=SEED, blobs=400, shift=(0.0, 0.0)):
     return np.clip(np.rint(img), 0, 255).astype(np.float32)
 
 
+def stereo_pair(width=640, height=480, seed=SEED, disparities=(6.0, 10.0, 14.0, 18.0, 22.0, 9.0, 16.0, 12.0), blobs=400):
+    """Two views of a scene made of fronto-parallel textured facets at different depths, camera moved
+    along +x without rotation: every facet (a vertical strip) moves left by its own disparity
+    d = f * tx / Z (integer pixels, so view 2 is an exact resampling).  Returns (img1, img2, strip_of_column, disparities).
+    The textbook essential matrix of this motion is [t]_x with t = (1, 0, 0)."""
+    base = image(width + 64, height, seed=seed, blobs=blobs * (width + 64) // width)
+    img1 = np.ascontiguousarray(base[:, :width])
+    n = len(disparities)
+    edges = np.linspace(0, width, n + 1).astype(int)
+    strip = np.zeros(width, np.int32)
+    img2 = np.zeros_like(img1)
+    for i in range(n):
+        strip[edges[i]:edges[i + 1]] = i
+        d = int(disparities[i])
+        # the facet covers columns [edges[i], edges[i+1]) of view 1 and appears d pixels to the left in view 2
+        lo, hi = max(edges[i] - d, 0), edges[i + 1] - d
+        img2[:, lo:hi] = base[:, lo + d:hi + d]
+    # columns never written (right of the last facet) keep the texture of view 1 shifted by the last disparity
+    d = int(disparities[-1])
+    img2[:, width - d:] = base[:, width:width + d]
+    return img1, np.ascontiguousarray(img2), strip, np.array(disparities, np.float32)
+
+
 def sift_records(desc, seed=SEED, width=720, height=576, stream=30):
     """Wrap a descriptor matrix into SiftPoint records with random keypoint positions."""
     n = desc.shape[0]

@@ -152,3 +152,59 @@ def test_cpp_sift_demo(tmp_path, args, kw):
     good = (s1["ambiguity"] < 0.8) & (s1["score"] > 0.9)
     dx, dy = s1["match_xpos"][good] - s1["xpos"][good], s1["match_ypos"][good] - s1["ypos"][good]
     assert good.sum() > 100 and abs(np.median(dx) - 7.0) < 0.5 and abs(np.median(dy) + 4.0) < 0.5
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_cpp_sfm_main_images_to_points(tmp_path, mode):
+    """src/main.cpp:249-307 start to end: two images -> ExtractSift x2 -> MatchSiftData -> fillXU -> estimateE ->
+    computePosecandidates -> choosePose -> linear_triangulation -> PLY.  Every stage against the oracle
+    chain bit for bit, and the geometry against the synthetic scene (camera moved along +x, no rotation)."""
+    app = os.path.join(ROOT, "cuda-sfm_amd", "host", "sfm_main")
+    assert os.path.exists(app), "sfm_main not built (make)"
+    w, h = 640, 480
+    a, b, strip, disp = synth.stereo_pair(w, h, seed=5)
+    f1, f2, ply, res = (str(tmp_path / x) for x in ("a.pgm", "b.pgm", "cloud.ply", "res.bin"))
+    write_pgm(f1, a); write_pgm(f2, b)
+    H = 2048
+    r = subprocess.run([app, f1, f2, ply, res, str(H), str(mode)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+
+    e1, n1, _ = O.extract_sift(a, 5, 1.5, 1.0)
+    e2, n2, _ = O.extract_sift(b, 5, 1.5, 1.0)
+    m = O.match_sift(e1[:n1].copy(), e2[:n2])
+    K, Kinv = synth.camera(w, h)
+    _, _, X0, X1 = O.fill_xu(m, Kinv)
+    key, counts, Ec = O.ransac_range(X0, X1, 0, H, 1e-6, 7, seed=0x5EED5F3D, want_E=True)
+    ocnt, ohyp = O.unpack_key(key)
+    oP = O.pose_candidates(Ec[ohyp], mode)
+    oind, oPinv, _, _ = O.choose_pose(X0, X1, oP, mode, 8)
+    opts = O.triangulate(X0, X1, oPinv[oind] if mode == 0 else oP[oind], 8)
+
+    raw = open(res, "rb").read()
+    n = int(np.frombuffer(raw, "<i4", 1)[0])
+    E = np.frombuffer(raw, "<f4", 9, 4); pind = int(np.frombuffer(raw, "<i4", 1, 40)[0])
+    hyp, cnt = (int(v) for v in np.frombuffer(raw, "<u4", 2, 44))
+    P = np.frombuffer(raw, "<f4", 16, 52).reshape(4, 4)
+    pts = np.frombuffer(raw, "<f4", 4 * n, 116).reshape(4, n); mask = np.frombuffer(raw, "u1", n, 116 + 16 * n)
+    assert n == n1 and (hyp, cnt) == (ohyp, ocnt) and same_bits(E, Ec[ohyp]) and pind == oind
+    assert same_bits(P, oP[oind]) and same_bits(pts, opts)
+    assert np.array_equal(mask, O.count_inliers(Ec[ohyp], X0, X1, 1e-6)[1])
+
+    # geometry: x1^T E x2 = 0 with E ~ -[t]_x^T ... for t = (1, 0, 0) only E[1,2] and E[2,1] are non-zero, opposite signs
+    En = E.reshape(3, 3) / np.linalg.norm(E)
+    assert abs(abs(En[1, 2]) - np.sqrt(0.5)) < 0.02 and abs(abs(En[2, 1]) - np.sqrt(0.5)) < 0.02 and En[1, 2] * En[2, 1] < 0
+    truth = (np.abs(m["match_xpos"] - m["xpos"] + disp[strip[np.clip(m["xpos"].astype(int), 0, w - 1)]]) < 1.0) & (np.abs(m["match_ypos"] - m["ypos"]) < 1.0)
+    assert truth.mean() > 0.6 and (mask.astype(bool) & truth).sum() > 0.9 * truth.sum()      # the consensus set is the true matches
+    assert (mask.astype(bool) & ~truth).sum() < 0.1 * mask.sum()
+    ply_lines = open(ply).read().splitlines()
+    assert ply_lines[0] == "ply" and int([l for l in ply_lines if l.startswith("element vertex")][0].split()[-1]) > 0.5 * truth.sum()
+    if mode == 1:
+        R = P[:3, :3]; t = P[:3, 3]
+        assert np.abs(R - np.eye(3)).max() < 0.02 and abs(abs(t[0]) - 1.0) < 0.02 and np.abs(t[1:]).max() < 0.05
+        # depth is inversely proportional to disparity: facets with larger disparity are closer
+        ok = mask.astype(bool) & truth & (pts[3] != 0)
+        z = pts[2, ok] / pts[3, ok]
+        d = disp[strip[np.clip(m["xpos"][ok].astype(int), 0, w - 1)]]
+        assert (z > 0).mean() > 0.98 or (z < 0).mean() > 0.98
+        zd = np.abs(z) * d                                                     # = f * |t| = const
+        assert np.std(zd) / np.mean(zd) < 0.05
