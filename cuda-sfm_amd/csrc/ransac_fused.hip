@@ -31,17 +31,54 @@ __device__ __forceinline__ void wave_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// Wave-cooperative 8-point solve.  `ws` = this wave's 256-float scratch.  On return every lane
-// holds the same E[9].
+// packed index -> (i, j), i <= j, of the 45 upper-triangle entries of S
+__device__ __forceinline__ void tri_index(int lane, int &ei, int &ej)
+{
+    int e = lane < 45 ? lane : 0, i = 0;
+    while (e >= 9 - i) { e -= 9 - i; ++i; }
+    ei = i; ej = i + e;
+}
+
+// Static schedule of the wave-cooperative Jacobi.  Which entries a lane combines in round t depends only
+// on (lane, t), not on the sweep or the hypothesis, so the index arithmetic of the block-oriented update
+// (orc_jacobi9 / jacobi9_round) is done once per block and kept in LDS:
+//   nv = idleR ? t1 : fma(s[rho], t2, c[rho] * t1),   t1 = idleK ? S[a0] : fma(S[a1], s[kap], S[a0] * c[kap]),
+//                                                     t2 = idleK ? S[b0] : fma(S[b1], s[kap], S[b0] * c[kap])
+// with rho = the index of (ei, ej) whose rotation group comes first (ties: ei).
+//   .x = a0 | a1 << 8 | b0 << 16 | b1 << 24
+//   .y = rho | kap << 4 | idleK << 8 | idleR << 9 | V partner << 10 | V idle << 17 | V2 partner << 18 | V2 idle << 25 | rotation partner << 26
+__device__ __forceinline__ void build_jacobi_schedule(uint2 (*sched)[64], int lane)
+{
+    int ei, ej;
+    tri_index(lane, ei, ej);
+    const int va0 = lane / 9, vb0 = lane - 9 * va0;
+    const int e1 = 64 + lane, va1 = e1 / 9, vb1 = e1 - 9 * va1;
+    for (int t = 0; t < 9; ++t) {
+        const int ri = (t + 9 - ei) % 9, rj = (t + 9 - ej) % 9;
+        const int li = ei < ri ? ei : ri, lj = ej < rj ? ej : rj;
+        const bool first = li <= lj;
+        const int rho = first ? ei : ej, kap = first ? ej : ei, rr = first ? ri : rj, rk = first ? rj : ri;
+        const int rb0 = (t + 9 - vb0) % 9, rb1 = (t + 9 - vb1) % 9;
+        const int vi1 = lane < 17 ? 9 * va1 + rb1 : 0;
+        uint2 wv;
+        wv.x = (uint32_t)(9 * rho + kap) | (uint32_t)(9 * rho + rk) << 8 | (uint32_t)(9 * rr + kap) << 16 | (uint32_t)(9 * rr + rk) << 24;
+        wv.y = (uint32_t)rho | (uint32_t)kap << 4 | (uint32_t)(rk == kap) << 8 | (uint32_t)(rr == rho) << 9 |
+               (uint32_t)(9 * va0 + rb0) << 10 | (uint32_t)(rb0 == vb0) << 17 | (uint32_t)vi1 << 18 | (uint32_t)(rb1 == vb1) << 25 |
+               (uint32_t)((t + 9 - (lane < 9 ? lane : 0)) % 9) << 26;
+        sched[t][lane] = wv;
+    }
+}
+
+// Wave-cooperative 8-point solve.  `ws` = this wave's 256-float scratch, `sched` = the block's static
+// schedule.  On return every lane holds the same E[9].
 __device__ __forceinline__ void solve_wave(const float *__restrict__ X0, const float *__restrict__ X1, int ld, int n,
                                            const int32_t *__restrict__ indices, uint32_t seed, uint32_t hyp,
-                                           int sweeps, float *ws, int lane, float E[9])
+                                           int sweeps, float *ws, const uint2 (*sched)[64], int lane, float E[9])
 {
     float *P = ws;            // [8][6]  x1x x1y x1z x2x x2y x2z
     float *S = ws + 48;       // [9][9]
     float *V = ws + 129;      // [9][9]
-    float *cc = ws + 210;     // [9]
-    float *sg = ws + 219;     // [9]
+    float2 *cs = reinterpret_cast<float2 *>(ws + 210);     // [9] (cos, sin) of the rotation every index takes part in
 
     int idx[8];
     load_tuple(indices, seed, hyp, n, idx);               // wave-uniform
@@ -54,12 +91,9 @@ __device__ __forceinline__ void solve_wave(const float *__restrict__ X0, const f
     }
     wave_sync();
 
-    // packed index -> (i, j), i <= j
-    int ei = 0, ej = 0;
+    int ei, ej;
+    tri_index(lane, ei, ej);
     if (lane < 45) {
-        int e = lane, i = 0;
-        while (e >= 9 - i) { e -= 9 - i; ++i; }
-        ei = i; ej = i + e;
         // S_ij = sum_r A[r][i] A[r][j],  A[r][3a+b] = x1[r][a] * x2[r][b]   (kernels.h:247-257)
         const int ia = ei / 3, ib = ei - 3 * ia, ja = ej / 3, jb = ej - 3 * ja;
         float acc = (P[ia] * P[3 + ib]) * (P[ja] * P[3 + jb]);
@@ -76,56 +110,45 @@ __device__ __forceinline__ void solve_wave(const float *__restrict__ X0, const f
     const int va0 = lane / 9, vb0 = lane - 9 * va0;                   // V element handled by every lane
     const int e1 = 64 + lane, va1 = e1 / 9, vb1 = e1 - 9 * va1;       // second V element (lanes 0..16)
 
+    const int sidx = lane < 45 ? 9 * ei + ej : 0, sidxT = lane < 45 ? 9 * ej + ei : 0;
+    const int v1idx = lane < 17 ? 64 + lane : 0;
+
+    uint2 plan[9];                                                    // this lane's 9 rounds, in registers
+#pragma unroll
+    for (int t = 0; t < 9; ++t) plan[t] = sched[t][lane];
+
     for (int sw = 0; sw < sweeps; ++sw) {
+#pragma unroll
         for (int t = 0; t < 9; ++t) {
+            const uint32_t a = plan[t].x, b = plan[t].y;
             if (lane < 9) {
-                const int i = lane, j = (t + 9 - i) % 9;
-                float c = 1.0f, s = 0.0f;
-                if (j != i) {
-                    const int p = i < j ? i : j, q = i < j ? j : i;
+                const int i = lane, jj = (int)(b >> 26);
+                float c = 1.0f, sn = 0.0f;
+                if (jj != i) {
+                    const int p = i < jj ? i : jj, q = i < jj ? jj : i;
                     float ss;
                     jacobi_cs(S[10 * p], S[10 * q], S[9 * p + q], c, ss);
-                    s = (i == p) ? -ss : ss;
+                    sn = (i == p) ? -ss : ss;
                 }
-                cc[i] = c;
-                sg[i] = s;
+                cs[i] = make_float2(c, sn);
             }
             wave_sync();
-            float nv = 0.0f, v0, v1 = 0.0f;
-            if (lane < 45) {
-                // same block-oriented expressions as orc_jacobi9 / jacobi9_round
-                const int ri = (t + 9 - ei) % 9, rj = (t + 9 - ej) % 9;
-                const int li = ei < ri ? ei : ri, lj = ej < rj ? ej : rj;
-                if (li == lj) {
-                    if (ri == ei) nv = S[10 * ei];                      // idle index: diagonal untouched
-                    else {
-                        const float cj = cc[ej], sj = sg[ej];
-                        const float Tij  = fmaf(S[9 * ei + rj], sj, S[9 * ei + ej] * cj);
-                        const float Trij = fmaf(S[9 * ri + rj], sj, S[9 * ri + ej] * cj);
-                        nv = fmaf(sg[ei], Trij, cc[ei] * Tij);
-                    }
-                } else {
-                    const int rho = li < lj ? ei : ej, kap = li < lj ? ej : ei;
-                    const int rr = (t + 9 - rho) % 9, rk = (t + 9 - kap) % 9;
-                    const float ck = cc[kap], sk = sg[kap];
-                    const float t1 = (rk == kap) ? S[9 * rho + kap] : fmaf(S[9 * rho + rk], sk, S[9 * rho + kap] * ck);
-                    if (rr == rho) nv = t1;
-                    else {
-                        const float t2 = (rk == kap) ? S[9 * rr + kap] : fmaf(S[9 * rr + rk], sk, S[9 * rr + kap] * ck);
-                        nv = fmaf(sg[rho], t2, cc[rho] * t1);
-                    }
-                }
-            }
-            {
-                const int rb = (t + 9 - vb0) % 9;
-                v0 = (rb == vb0) ? V[9 * va0 + vb0] : fmaf(V[9 * va0 + rb], sg[vb0], V[9 * va0 + vb0] * cc[vb0]);
-            }
-            if (lane < 17) {
-                const int rb = (t + 9 - vb1) % 9;
-                v1 = (rb == vb1) ? V[9 * va1 + vb1] : fmaf(V[9 * va1 + rb], sg[vb1], V[9 * va1 + vb1] * cc[vb1]);
-            }
+            const int rho = (int)(b & 15u), kap = (int)((b >> 4) & 15u);
+            const float2 rk2 = cs[kap], rr2 = cs[rho];
+            const float ck = rk2.x, sk = rk2.y, cr = rr2.x, sr = rr2.y;
+            const float sa0 = S[a & 255u], sa1 = S[(a >> 8) & 255u], sb0 = S[(a >> 16) & 255u], sb1 = S[a >> 24];
+            const bool idleK = (b >> 8) & 1u, idleR = (b >> 9) & 1u;
+            const float t1 = idleK ? sa0 : fmaf(sa1, sk, sa0 * ck);
+            const float t2 = idleK ? sb0 : fmaf(sb1, sk, sb0 * ck);
+            const float nv = idleR ? t1 : fmaf(sr, t2, cr * t1);
+            const float2 rv0 = cs[vb0], rv1 = cs[vb1];
+            const float cv0 = rv0.x, sv0 = rv0.y, cv1 = rv1.x, sv1 = rv1.y;
+            const float vo0 = V[lane], vp0 = V[(b >> 10) & 127u];
+            const float vo1 = V[v1idx], vp1 = V[(b >> 18) & 127u];
+            const float v0 = ((b >> 17) & 1u) ? vo0 : fmaf(vp0, sv0, vo0 * cv0);
+            const float v1 = ((b >> 25) & 1u) ? vo1 : fmaf(vp1, sv1, vo1 * cv1);
             wave_sync();
-            if (lane < 45) { S[9 * ei + ej] = nv; S[9 * ej + ei] = nv; }
+            if (lane < 45) { S[sidx] = nv; S[sidxT] = nv; }
             V[lane] = v0;
             if (lane < 17) V[64 + lane] = v1;
             wave_sync();
@@ -153,8 +176,11 @@ void ransac_fused_waves(const float *__restrict__ X0, const float *__restrict__ 
                         int *__restrict__ counts, float *__restrict__ Ecand, unsigned long long *best_key)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    uint2 (*sched)[64] = reinterpret_cast<uint2 (*)[64]>(lds + 6 * (size_t)tile + (size_t)WPB * kWaveScratch);   // after the wave scratches
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (wave == 0) build_jacobi_schedule(sched, lane);
+    __syncthreads();
     float *ws = lds + 6 * (size_t)tile + (size_t)wave * kWaveScratch;
     const uint32_t nbatch = (count + WPB - 1) / WPB;
     unsigned long long wbest = 0;
@@ -166,7 +192,7 @@ void ransac_fused_waves(const float *__restrict__ X0, const float *__restrict__ 
         const bool valid = i < count;
         float e[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
         if (valid) {
-            solve_wave(X0, X1, ld, n, indices, seed, h0 + i, sweeps, ws, lane, e);
+            solve_wave(X0, X1, ld, n, indices, seed, h0 + i, sweeps, ws, sched, lane, e);
             if (lane < 9) {
                 float v = e[0];
 #pragma unroll
@@ -215,6 +241,7 @@ void ransac_finalize_E_wave(const float *__restrict__ X0, const float *__restric
                             float *__restrict__ E_out, uint32_t *__restrict__ best_out)
 {
     __shared__ __attribute__((aligned(16))) float ws[kWaveScratch];
+    __shared__ uint2 sched[9][64];
     uint32_t hyp = hyp_host;
     if (from_key) hyp = 0xFFFFFFFFu - (uint32_t)(key[0] & 0xFFFFFFFFull);
     hyp = __builtin_amdgcn_readfirstlane(hyp);
@@ -222,7 +249,9 @@ void ransac_finalize_E_wave(const float *__restrict__ X0, const float *__restric
         if (threadIdx.x < 9) E_out[threadIdx.x] = Ecand[9 * (size_t)(hyp - h0) + threadIdx.x];
     } else {
         float E[9];
-        solve_wave(X0, X1, ld, n, indices, seed, hyp, sweeps, ws, threadIdx.x, E);
+        build_jacobi_schedule(sched, threadIdx.x);
+        wave_sync();
+        solve_wave(X0, X1, ld, n, indices, seed, hyp, sweeps, ws, sched, threadIdx.x, E);
         if (threadIdx.x == 0) {
 #pragma unroll
             for (int k = 0; k < 9; ++k) E_out[k] = E[k];
@@ -256,17 +285,16 @@ int launch_ransac_fused(sfm_pair *pair, const sfm_ransac_params &p, uint32_t h0,
     sfm_ctx *ctx = pair->ctx;
     const int tile = pair->ld < kTileMax ? pair->ld : kTileMax;
     const int ntiles = (pair->ld + tile - 1) / tile;
-    int wpb = 16;
+    int wpb = 8;                        // 16 wavefronts per block would cap the kernel at 128 VGPRs and spill the Jacobi schedule
     while (wpb > 4 && (count + wpb - 1) / wpb < (uint32_t)ctx->num_cus) wpb >>= 1;
     const uint32_t nbatch = (count + wpb - 1) / wpb;
     const int grid = (int)(nbatch < (uint32_t)ctx->num_cus ? nbatch : (uint32_t)ctx->num_cus);
-    const size_t lds = ((size_t)6 * tile + (size_t)wpb * kWaveScratch) * sizeof(float);
+    const size_t lds = ((size_t)6 * tile + (size_t)wpb * kWaveScratch) * sizeof(float) + 9 * 64 * sizeof(uint2);   // + Jacobi schedule
     const bool timed = ctx->timing && ctx->tcount < sfm_ctx::kTimingSlots;
     hipEvent_t *tev = timed ? ctx->tev[ctx->tcount] : nullptr;
     if (timed) { SFM_HIP_TRY(hipEventRecord(tev[0], ctx->stream)); SFM_HIP_TRY(hipEventRecord(tev[1], ctx->stream)); }
     int rc;
     switch (wpb) {
-    case 16: rc = launch_fused_t<16>(pair, p, h0, count, tile, ntiles, grid, lds); break;
     case 8:  rc = launch_fused_t<8>(pair, p, h0, count, tile, ntiles, grid, lds); break;
     default: rc = launch_fused_t<4>(pair, p, h0, count, tile, ntiles, grid, lds); break;
     }
