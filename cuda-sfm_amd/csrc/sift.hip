@@ -197,8 +197,9 @@ struct Cand {
 };
 
 struct LevelState {                      // device-resident bookkeeping, one per level
-    unsigned int found;                  // extrema that passed the tests (atomic, block-aggregated)
-    unsigned int kept;                   // sum of the segment counts (== found; closed by sift_scan_kernel)
+    unsigned int alloc;                  // stash allocation cursor (atomic, block-aggregated)
+    unsigned int found;                  // extrema that passed the tests = sum of the segment counts (sift_scan_kernel)
+    unsigned int kept;                   // candidates present in the stash = min(found, capacity)
     unsigned int base;                   // first output slot of the level (unclipped)
     unsigned int dups;                   // secondary orientations of the level
 };
@@ -222,8 +223,11 @@ constexpr int kFindW = 64, kFindH = 4, kFindSeg = 256, kFindStride = kFindW + 2 
 constexpr int kFindBuf = 192;
 
 __global__ __launch_bounds__(256)
-void sift_find_kernel(const float *__restrict__ temp, Levels L, Workspace W, float thresh, float lowest_scale, float factor, float edge_limit)
+void sift_find_kernel(const float *__restrict__ temp, Levels L, Workspace W, float thresh, float lowest_scale, float factor, float edge_limit, int mode)
 {
+    // mode 0: detect, count per segment and stash through an allocation cursor (the normal single pass);
+    // mode 1: detect and count only; mode 2: detect again and store every candidate at stash[rank] -- the
+    // exact two-pass path taken when a level yields more raw extrema than the stash holds.
     __shared__ float tile[kLaplaceS - 1][kFindH + 2][kFindStride];
     __shared__ Cand buf[kFindBuf];                 // the block's candidates: ONE global atomic per block, not per wavefront
     __shared__ unsigned int blk_n, blk_base;
@@ -301,28 +305,35 @@ void sift_find_kernel(const float *__restrict__ temp, Levels L, Workspace W, flo
         }
         if (total == 0) continue;                                             // wave-uniform
         unsigned int base = 0;
-        if (lane == 0) base = atomicAdd(&blk_n, total);                       // LDS
-        base = __shfl(base, 0);
+        if (mode == 0) {
+            if (lane == 0) base = atomicAdd(&blk_n, total);                   // LDS
+            base = __shfl(base, 0);
+        }
+        const unsigned int seg_id = (unsigned int)(y * nseg + seg);
+        const unsigned int seg_off = mode == 2 ? W.segs[L.seg0[lvl] + seg_id] : 0u;
 #pragma unroll
         for (int sc = 0; sc < kNumScales; ++sc) {
-            if ((mask >> sc) & 1u) {
+            if (((mask >> sc) & 1u) && mode != 1) {
                 const unsigned int lr = before + (unsigned int)__builtin_popcount(mask & ((1u << sc) - 1u));
                 Cand o;
                 o.x = q[sc].xpos; o.y = q[sc].ypos; o.scale = q[sc].scale; o.sharp = q[sc].sharpness; o.edge = q[sc].edgeness;
-                o.ori1 = 0.0f; o.ori2 = 0.0f; o.seg = (uint32_t)(y * nseg + seg); o.lrank = row_count + lr; o.rank = 0; o.has2 = 0; o.pad = 0;
-                if (base + lr < (unsigned int)kFindBuf) buf[base + lr] = o;
+                o.ori1 = 0.0f; o.ori2 = 0.0f; o.seg = seg_id; o.lrank = row_count + lr; o.rank = 0; o.has2 = 0; o.pad = 0;
+                if (mode == 2) {
+                    const unsigned int rank = seg_off + row_count + lr;
+                    if (rank < (unsigned int)W.cap) stash[rank] = o;
+                } else if (base + lr < (unsigned int)kFindBuf) buf[base + lr] = o;
                 else {                                                         // crowded block: straight to the stash
-                    const unsigned int slot = atomicAdd(&W.state[lvl].found, 1u);
+                    const unsigned int slot = atomicAdd(&W.state[lvl].alloc, 1u);
                     if (slot < (unsigned int)W.cap) stash[slot] = o;
                 }
             }
         }
         row_count += total;
     }
-    if (lane == 0 && y < h) W.segs[L.seg0[lvl] + y * nseg + seg] = row_count;
+    if (lane == 0 && y < h && mode != 2) W.segs[L.seg0[lvl] + y * nseg + seg] = row_count;
     __syncthreads();
     const unsigned int nbuf = min(blk_n, (unsigned int)kFindBuf);
-    if (threadIdx.x == 0 && nbuf > 0) blk_base = atomicAdd(&W.state[lvl].found, nbuf);
+    if (threadIdx.x == 0 && nbuf > 0) blk_base = atomicAdd(&W.state[lvl].alloc, nbuf);
     __syncthreads();
     for (unsigned int i = threadIdx.x; i < nbuf; i += 256)
         if (blk_base + i < (unsigned int)W.cap) stash[blk_base + i] = buf[i];
@@ -366,7 +377,7 @@ void sift_scan_kernel(Levels L, Workspace W)
         unsigned int running;
         unsigned int run = block_scan_1024(mine, wsum, &running);
         for (int i = lo; i < hi; ++i) { const unsigned int c = a[i]; a[i] = run; run += c; }
-        if (threadIdx.x == 0) W.state[lvl].kept = min(running, (unsigned int)W.cap);      // running == found
+        if (threadIdx.x == 0) { W.state[lvl].found = running; W.state[lvl].kept = min(running, (unsigned int)W.cap); }
     }
 }
 
@@ -828,23 +839,33 @@ int launch_extract_sift(sfm_ctx *ctx, sfm_sift_point *d_sift, int max_pts, const
     for (int l = 1; l < n; ++l)
         hipLaunchKernelGGL(sift_scaledown_kernel, dim3((L.w[l] + kSdW - 1) / kSdW, (L.h[l] + kSdH - 1) / kSdH), dim3(256), 0, st,
                            d_temp + L.img[l - 1], L.p[l - 1], L.w[l - 1], L.h[l - 1], d_temp + L.img[l], L.p[l], sd);
-    if (n > 0) {
-        hipLaunchKernelGGL(sift_laplace_kernel, dim3(lap_blocks), dim3(128), 0, st, d_temp, L, tabs);
-        hipLaunchKernelGGL(sift_find_kernel, dim3(find_blocks), dim3(256), 0, st, d_temp, LF, W, thresh, lowest_scale, 1.0f / kNumScales, 10.0f);
-        hipLaunchKernelGGL(sift_scan_kernel, dim3(1), dim3(1024), 0, st, LF, W);
+    unsigned int res[2] = { 0, 0 };
+    LevelState hs[8];
+    if (n > 0) hipLaunchKernelGGL(sift_laplace_kernel, dim3(lap_blocks), dim3(128), 0, st, d_temp, L, tabs);
+    for (int pass = 0; pass < 2 && n > 0; ++pass) {
+        const float factor = 1.0f / kNumScales, edge_limit = 10.0f;
+        if (pass == 0) {
+            hipLaunchKernelGGL(sift_find_kernel, dim3(find_blocks), dim3(256), 0, st, d_temp, LF, W, thresh, lowest_scale, factor, edge_limit, 0);
+            hipLaunchKernelGGL(sift_scan_kernel, dim3(1), dim3(1024), 0, st, LF, W);
+        } else {
+            // some level found more raw extrema than its stash holds: count, scan, then store by rank (lowest ranks survive)
+            SFM_HIP_TRY(hipMemsetAsync(ws, 0, 256, st));
+            hipLaunchKernelGGL(sift_find_kernel, dim3(find_blocks), dim3(256), 0, st, d_temp, LF, W, thresh, lowest_scale, factor, edge_limit, 1);
+            hipLaunchKernelGGL(sift_scan_kernel, dim3(1), dim3(1024), 0, st, LF, W);
+            hipLaunchKernelGGL(sift_find_kernel, dim3(find_blocks), dim3(256), 0, st, d_temp, LF, W, thresh, lowest_scale, factor, edge_limit, 2);
+        }
         hipLaunchKernelGGL(sift_orient_kernel, dim3(2048), dim3(256), 0, st, d_temp, LF, W);
         hipLaunchKernelGGL(sift_place_kernel, dim3(1), dim3(1024), 0, st, LF, W);
         hipLaunchKernelGGL(sift_desc_kernel, dim3(4096), dim3(256), 0, st, d_temp, LF, W, d_sift, max_pts, scale_up);
+        SFM_HIP_TRY(hipGetLastError());
+        SFM_HIP_TRY(hipMemcpyAsync(res, W.result, sizeof(res), hipMemcpyDeviceToHost, st));
+        SFM_HIP_TRY(hipMemcpyAsync(hs, W.state, sizeof(hs), hipMemcpyDeviceToHost, st));
+        SFM_HIP_TRY(hipStreamSynchronize(st));
+        bool overflow = false;
+        for (int l = 0; l < n; ++l) overflow = overflow || hs[l].found > (unsigned int)cap;
+        if (!overflow) break;
     }
     SFM_HIP_TRY(hipGetLastError());
-    unsigned int res[2];
-    LevelState hs[8];
-    SFM_HIP_TRY(hipMemcpyAsync(res, W.result, sizeof(res), hipMemcpyDeviceToHost, st));
-    SFM_HIP_TRY(hipMemcpyAsync(hs, W.state, sizeof(hs), hipMemcpyDeviceToHost, st));
-    SFM_HIP_TRY(hipStreamSynchronize(st));
-    for (int l = 0; l < n; ++l)
-        SFM_REQUIRE(hs[l].found <= (unsigned int)cap, SFM_E_CAPACITY,
-                    "level %d produced %u raw extrema, more than 4 * max_pts = %zu: raise thresh or max_pts", l, hs[l].found, cap);
     *num_pts = (int)(res[0] < (unsigned int)max_pts ? res[0] : (unsigned int)max_pts);      // cudaSiftH.cu:123-124
     if (num_stored) *num_stored = (int)(res[1] < (unsigned int)max_pts ? res[1] : (unsigned int)max_pts);
     return SFM_OK;

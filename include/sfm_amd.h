@@ -36,7 +36,6 @@ extern "C" {
 #define SFM_E_NOMEM     (-3)   /* device allocation failed                         */
 #define SFM_E_STATE     (-4)   /* call order violated (e.g. triangulate before E)  */
 #define SFM_E_SINGULAR  (-5)   /* singular pose candidate (kernels.h:143-161)      */
-#define SFM_E_CAPACITY  (-6)   /* internal capacity exceeded (sfm_extract_sift)    */
 
 /* Feature record, identical layout to the reference's SiftPoint (CudaSift/cudaSift.h:6-22). */
 typedef struct sfm_sift_point {
@@ -103,8 +102,7 @@ int sfm_match_soa(sfm_ctx *ctx, const float *d_desc1, int n1, int ld1,
  * reference's atomic append.  d_temp: sfm_sift_temp_layout(...).total_floats floats, or NULL to use a
  * buffer owned by the context; afterwards it holds every pyramid level and DoG plane at the offsets of
  * the layout.  1 <= num_octaves <= 7.  Synchronous.  When more than max_pts points exist the first
- * max_pts in that order are kept (the reference keeps an arbitrary subset).  SFM_E_CAPACITY when a
- * single octave yields more than 4 * max_pts raw extrema (threshold far too low for max_pts). */
+ * max_pts in that order are kept (the reference keeps an arbitrary subset). */
 typedef struct {
     int32_t num_octaves;
     int32_t width[8], height[8], pitch[8];   /* level 0 = full (or upsampled) resolution; pitch in floats */

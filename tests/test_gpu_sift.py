@@ -164,3 +164,52 @@ def test_argument_checks(gpu):
         ctx.extract_sift(d_sift, 64, d_img, 100, 64, 64)                # pitch < width
     n, stored = ctx.extract_sift(d_sift, 64, d_img, 100, 64, 128)       # flat image: nothing found
     assert (n, stored) == (0, 0)
+
+
+@pytest.mark.parametrize("w,h,octaves", [(40, 30, 5), (17, 9, 3), (64, 4, 2), (129, 65, 7), (1, 1, 1)])
+def test_tiny_and_degenerate_sizes(gpu, w, h, octaves):
+    """levels shrink to a pixel or vanish (w >> l == 0): pyramid, DoG planes and records still equal the oracle's"""
+    rng = np.random.default_rng(w * 131 + h)
+    img = np.rint(rng.uniform(0, 255, (h, w))).astype(np.float32)
+    rec, n, stored, L, temp = run_product(gpu, img, num_octaves=octaves, init_blur=1.0, thresh=0.5)
+    opts, on, ostored = O.extract_sift(img, octaves, 1.0, 0.5)
+    assert (n, stored) == (on, ostored)
+    for f in FIELDS:
+        assert same_bits(rec[f][:stored], opts[f][:stored]), f
+    kt, k5 = O.sift_tables(octaves)
+    level = O.sift_lowpass(img, O.sift_lowpass_taps(1.0))
+    for l in range(octaves):
+        wl, hl, pl = L.width[l], L.height[l], L.pitch[l]
+        if wl == 0 or hl == 0:
+            break
+        got = temp[L.image_offset[l]: L.image_offset[l] + pl * hl].reshape(hl, pl)[:, :wl]
+        assert same_bits(got, level), f"pyramid level {l}"
+        dog = temp[L.dog_offset[l]: L.dog_offset[l] + 7 * pl * hl].reshape(7, hl, pl)[:, :, :wl]
+        assert same_bits(dog, O.sift_laplace(level, kt.reshape(8, 192)[octaves - l][:128])), f"DoG level {l}"
+        if l + 1 < octaves and wl // 2 > 0 and hl // 2 > 0:
+            level = O.sift_scaledown(level, k5)
+
+
+def test_noise_image_many_points_and_capacity(gpu):
+    """white noise at a tiny threshold: thousands of extrema per octave.  With room for them the result equals
+    the oracle; with max_pts far below the number of raw extrema (the internal stash overflows and the exact
+    two-pass path runs) the first max_pts records of the full result survive -- deterministic, unlike the
+    reference, which keeps an arbitrary subset (cudaSiftD.cu:1421)."""
+    rng = np.random.default_rng(5)
+    img = np.rint(rng.uniform(0, 255, (240, 320))).astype(np.float32)
+    rec, n, stored, _, _ = run_product(gpu, img, num_octaves=3, init_blur=1.0, thresh=0.05)
+    opts, on, ostored = O.extract_sift(img, 3, 1.0, 0.05)
+    assert (n, stored) == (on, ostored) and n > 3000
+    for f in FIELDS:
+        assert same_bits(rec[f][:stored], opts[f][:stored]), f
+    first_fine = int(np.argmax(rec["subsampling"][:stored] == 1.0))
+    for cap in (2000, 700, 100, 8):
+        crec, cn, cstored, _, _ = run_product(gpu, img, max_pts=cap, num_octaves=3, init_blur=1.0, thresh=0.05)
+        ocrec, ocn, ocstored = O.extract_sift(img, 3, 1.0, 0.05, max_pts=cap)
+        assert (cn, cstored) == (cap, cap) == (ocn, ocstored)
+        for f in FIELDS:
+            assert same_bits(crec[f][:cap], ocrec[f][:cap]), (cap, f)
+        # octaves that fit are complete; the octave that overflows keeps its first points in (y, x, scale) order and no
+        # secondary orientations (they would start after ALL of the octave's points, cudaSiftD.cu:1041)
+        k = min(cap, first_fine)
+        assert same_bits(crec["data"][:k], rec["data"][:k])
