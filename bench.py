@@ -53,6 +53,7 @@ def main():
     ap.add_argument("--matches", type=int, default=N_MATCHES)
     ap.add_argument("--hyps", type=int, default=TOTAL_HYPS)
     ap.add_argument("--kernel", type=int, default=0)
+    ap.add_argument("--sweeps", type=int, default=-1, help="null-vector solver: -1 library default, 0 Householder, k > 0 Jacobi sweeps")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     args = ap.parse_args()
 
@@ -79,6 +80,8 @@ def main():
     pair = S.ImagePair(ctx, scene["K"], scene["Kinv"], 2, n)
     pair.fillXU(d_sift)
     params = S.default_params(n, num_hypotheses=H, kernel=args.kernel)
+    if args.sweeps >= 0:
+        params.jacobi_sweeps = args.sweeps
     key_t = torch.zeros(1, dtype=torch.int64, device=dev)
 
     def reduce_max(t):
@@ -142,7 +145,9 @@ def main():
                                    f"{H} 8-point hypotheses per step sharded over {world} GPU(s), estimateE end to end "
                                    "(sample+solve+score+argmax+winner E+inlier mask)",
                        "matches": n, "hypotheses_per_step": H, "threshold": params.threshold,
-                       "jacobi_sweeps": params.jacobi_sweeps, "kernel": pair.last_launch()},
+                       "jacobi_sweeps": params.jacobi_sweeps,
+                       "solver": "householder QR of the 8x9 system" if params.jacobi_sweeps == 0 else f"normal equations + {params.jacobi_sweeps} Jacobi sweeps",
+                       "kernel": pair.last_launch()},
             "roofline": {"bound": "mfma", "bound_detail": "FP32 VALU (v_pk_fma_f32); its 157.3 TFLOP/s peak equals the dense f32 MFMA peak",
                          "kernel": "ransac_score_waves", "achieved": achieved,
                          "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_PEAK_TFLOPS,

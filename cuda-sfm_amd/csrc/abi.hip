@@ -33,7 +33,7 @@ static int resolve_shard(const sfm_pair *pair, const sfm_ransac_params *p, uint3
     SFM_REQUIRE(pair->n >= 8, SFM_E_INVALID, "the 8-point solver needs at least 8 correspondences (have %d)", pair->n);
     SFM_REQUIRE(p->num_hypotheses > 0, SFM_E_INVALID, "num_hypotheses must be > 0");
     SFM_REQUIRE(p->hyp_begin <= p->num_hypotheses, SFM_E_INVALID, "hyp_begin %u beyond num_hypotheses %u", p->hyp_begin, p->num_hypotheses);
-    SFM_REQUIRE(p->jacobi_sweeps >= 1 && p->jacobi_sweeps <= 64, SFM_E_INVALID, "jacobi_sweeps out of range");
+    SFM_REQUIRE(p->jacobi_sweeps >= 0 && p->jacobi_sweeps <= 64, SFM_E_INVALID, "jacobi_sweeps out of range (0 = Householder solver)");
     SFM_REQUIRE(p->kernel >= SFM_KERNEL_AUTO && p->kernel <= SFM_KERNEL_MFMA, SFM_E_INVALID, "unknown kernel id %d", p->kernel);
     uint32_t c = p->hyp_count ? p->hyp_count : p->num_hypotheses - p->hyp_begin;
     SFM_REQUIRE((uint64_t)p->hyp_begin + c <= p->num_hypotheses, SFM_E_INVALID, "shard [%u, %u) exceeds num_hypotheses %u",
@@ -387,7 +387,7 @@ void sfm_ransac_default_params(sfm_ransac_params *p, int num_points)
     p->num_hypotheses = num_points >= 8 ? (uint32_t)(num_points / 8) : 1u;     // sfm.cu:95
     p->seed = 0x5EED5F3Du;
     p->threshold = 1e-6f;                                                        // sfm.cu:220
-    p->jacobi_sweeps = 7;
+    p->jacobi_sweeps = 0;                                                        // Householder null-vector solver
     p->kernel = SFM_KERNEL_AUTO;
 }
 

@@ -180,8 +180,10 @@ int launch_ransac_score(sfm_pair *pair, const sfm_ransac_params &p, uint32_t h0,
 
     // AUTO: few hypotheses are latency-bound -> one hypothesis per wavefront (fused, all waves start
     // at once); many hypotheses are throughput-bound -> lane-parallel solve + wavefront scoring.
-    // Crossover measured between 4k and 8k hypotheses (profiles/small_h_bench.py).
-    int kernel = p.kernel == SFM_KERNEL_AUTO ? (count <= 4096u ? SFM_KERNEL_FUSED : SFM_KERNEL_SPLIT) : p.kernel;
+    // Crossovers measured with profiles/small_h_bench.py: between 4k and 8k hypotheses with the Jacobi solver,
+    // between 1k and 4k with the (much cheaper) Householder solver.
+    const uint32_t fused_max = p.jacobi_sweeps > 0 ? 4096u : 1024u;
+    int kernel = p.kernel == SFM_KERNEL_AUTO ? (count <= fused_max ? SFM_KERNEL_FUSED : SFM_KERNEL_SPLIT) : p.kernel;
     if (kernel == SFM_KERNEL_MFMA && pair->n >= 65536) kernel = SFM_KERNEL_SPLIT;   // its packed counters are 16-bit
     pair->last_kernel = kernel;
     if (kernel == SFM_KERNEL_FUSED) return launch_ransac_fused(pair, p, h0, count);

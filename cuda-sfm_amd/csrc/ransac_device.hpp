@@ -38,7 +38,7 @@ __device__ __forceinline__ void solve_one(const float *__restrict__ X0, const fl
             x1[k][a] = X0[(size_t)a * ld + idx[k]];
             x2[k][a] = X1[(size_t)a * ld + idx[k]];
         }
-    nullvec9_normal_eq(x1, x2, sweeps, E);
+    nullvec9(x1, x2, sweeps, E);
     normalize_E(E);
 }
 
@@ -59,7 +59,7 @@ __device__ __forceinline__ void solve_two(const float *__restrict__ X0, const fl
             x1[k][a] = v2f{ X0[(size_t)a * ld + ia[k]], X0[(size_t)a * ld + ib[k]] };
             x2[k][a] = v2f{ X1[(size_t)a * ld + ia[k]], X1[(size_t)a * ld + ib[k]] };
         }
-    nullvec9_normal_eq(x1, x2, sweeps, E);
+    nullvec9(x1, x2, sweeps, E);
     normalize_E(E);
 }
 

@@ -91,6 +91,20 @@ __device__ __forceinline__ void solve_wave(const float *__restrict__ X0, const f
     }
     wave_sync();
 
+    if (sweeps <= 0) {
+        // Householder solver: a few hundred dependent operations, nothing to spread over the lanes --
+        // every lane runs the same scalar code on the broadcast sample (identical E in all lanes)
+        float x1[8][3], x2[8][3];
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+#pragma unroll
+            for (int a = 0; a < 3; ++a) { x1[k][a] = P[6 * k + a]; x2[k][a] = P[6 * k + 3 + a]; }
+        nullvec9_householder(x1, x2, E);
+        normalize_E(E);
+        wave_sync();
+        return;
+    }
+
     int ei, ej;
     tri_index(lane, ei, ej);
     if (lane < 45) {

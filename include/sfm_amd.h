@@ -151,7 +151,8 @@ typedef struct sfm_ransac_params {
     uint32_t seed;            /* keyed sampler seed (used when d_indices == NULL)                       */
     const int32_t *d_indices; /* optional device int32[8*H]: explicit 8-tuples, global hypothesis order */
     float    threshold;       /* inlier iff residual < threshold; reference 1e-6 (sfm.cu:220)           */
-    int32_t  jacobi_sweeps;   /* 9x9 Jacobi sweeps, default 7                                           */
+    int32_t  jacobi_sweeps;   /* null vector of the 8x9 system: 0 (default) = Householder QR of A^T;       */
+                              /* k > 0 = normal equations A^T A + k sweeps of 9x9 Jacobi (7 converges)    */
     int32_t  kernel;          /* SFM_KERNEL_*                                                           */
     int32_t  reserved[4];
 } sfm_ransac_params;

@@ -61,7 +61,8 @@ void orc_sample8(uint32_t seed, uint32_t hyp, int n, int idx[8]);
 void orc_build_A(const float *X0, const float *X1, int n, const int idx[8], float A[72]);
 void orc_AtA9(const float A[72], float S[81]);
 void orc_jacobi9(float S[81], float V[81], int sweeps);
-void orc_nullvec9(const float A[72], int sweeps, float e[9]);
+void orc_nullvec9(const float A[72], int sweeps, float e[9]);   /* sweeps > 0: normal equations + Jacobi; 0: Householder */
+void orc_nullvec9_qr(const float A[72], float e[9]);
 void orc_normalizeE(float E[9]);
 float orc_residual(const float E[9], float x1x, float x1y, float x1z,
                    float x2x, float x2y, float x2z);

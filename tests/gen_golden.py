@@ -98,8 +98,12 @@ def gen_e2e():
         ind, Pinv, d1, d2 = O.choose_pose(X0, X1, P, mode, 8)
         pts = O.triangulate(X0, X1, Pinv[ind] if mode == 0 else P[ind], 8)
         out.update({f"P{mode}": P, f"Pinv{mode}": Pinv, f"pind{mode}": np.int32(ind), f"points{mode}": pts})
+    # the same scene through the Householder null-vector solver (jacobi_sweeps = 0, the library default)
+    keyq, countsq, Ecq = O.ransac_range(X0, X1, 0, H, 1e-6, 0, seed=42, want_E=True)
+    cq, hq = O.unpack_key(keyq)
+    out.update(qr_counts=countsq, qr_Ecand=Ecq, qr_key=np.uint64(keyq), qr_mask=O.count_inliers(Ecq[hq], X0, X1, 1e-6)[1])
     np.savez_compressed(os.path.join(OUT, "e2e_oracle.npz"), **out)
-    print("e2e_oracle.npz best", hyp, cnt)
+    print("e2e_oracle.npz best", hyp, cnt, "householder best", hq, cq)
 
 
 if __name__ == "__main__":

@@ -19,7 +19,7 @@ void hc_hypothesis_E(const float *X0, const float *X1, int ld, const int *idx, i
     float x1[8][3], x2[8][3];
     for (int k = 0; k < 8; ++k)
         for (int a = 0; a < 3; ++a) { x1[k][a] = X0[a * ld + idx[k]]; x2[k][a] = X1[a * ld + idx[k]]; }
-    sfm::nullvec9_normal_eq(x1, x2, sweeps, E);
+    sfm::nullvec9(x1, x2, sweeps, E);
     sfm::normalize_E(E);
 }
 
@@ -32,7 +32,7 @@ void hc_hypothesis_E_pair(const float *X0, const float *X1, int ld, const int *i
             x1[k][a] = sfm::v2f{ X0[a * ld + idxA[k]], X0[a * ld + idxB[k]] };
             x2[k][a] = sfm::v2f{ X1[a * ld + idxA[k]], X1[a * ld + idxB[k]] };
         }
-    sfm::nullvec9_normal_eq(x1, x2, sweeps, E);
+    sfm::nullvec9(x1, x2, sweeps, E);
     sfm::normalize_E(E);
     for (int k = 0; k < 9; ++k) { EA[k] = E[k].x; EB[k] = E[k].y; }
 }
@@ -42,7 +42,7 @@ void hc_nullvec9(const float *X0, const float *X1, int ld, const int *idx, int s
     float x1[8][3], x2[8][3];
     for (int k = 0; k < 8; ++k)
         for (int a = 0; a < 3; ++a) { x1[k][a] = X0[a * ld + idx[k]]; x2[k][a] = X1[a * ld + idx[k]]; }
-    sfm::nullvec9_normal_eq(x1, x2, sweeps, e);
+    sfm::nullvec9(x1, x2, sweeps, e);
 }
 
 float hc_residual(const float *E, float x1x, float x1y, float x1z, float x2x, float x2y, float x2z)

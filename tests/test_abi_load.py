@@ -31,7 +31,7 @@ def test_struct_layouts_match_header():
     assert S.SIFT_DTYPE.itemsize == 576 and S.SIFT_DTYPE.fields["data"][1] == 64
     assert S.SIFT_DTYPE.fields["score"][1] == 24 and S.SIFT_DTYPE.fields["match"][1] == 32   # cudaSift.h:6-22 offsets
     p = S.default_params(4096)
-    assert p.num_hypotheses == 512 and abs(p.threshold - 1e-6) < 1e-12 and p.jacobi_sweeps == 7
+    assert p.num_hypotheses == 512 and abs(p.threshold - 1e-6) < 1e-12 and p.jacobi_sweeps == 0
 
 
 def test_no_cpu_fallback():

@@ -60,7 +60,7 @@ def test_cpp_facade_end_to_end(tmp_path, n, H, mode):
 
     K, Kinv = synth.camera()
     _, _, X0, X1 = O.fill_xu(m, Kinv)
-    key, counts, Ec = O.ransac_range(X0, X1, 0, H, 1e-6, 7, seed=0x1234, want_E=True)
+    key, counts, Ec = O.ransac_range(X0, X1, 0, H, 1e-6, 0, seed=0x1234, want_E=True)       # library default: Householder
     ocnt, ohyp = O.unpack_key(key)
     assert (hyp, cnt) == (ohyp, ocnt) and same_bits(E, Ec[ohyp])
     assert np.array_equal(mask, O.count_inliers(Ec[ohyp], X0, X1, 1e-6)[1])
@@ -174,7 +174,7 @@ def test_cpp_sfm_main_images_to_points(tmp_path, mode):
     m = O.match_sift(e1[:n1].copy(), e2[:n2])
     K, Kinv = synth.camera(w, h)
     _, _, X0, X1 = O.fill_xu(m, Kinv)
-    key, counts, Ec = O.ransac_range(X0, X1, 0, H, 1e-6, 7, seed=0x5EED5F3D, want_E=True)
+    key, counts, Ec = O.ransac_range(X0, X1, 0, H, 1e-6, 0, seed=0x5EED5F3D, want_E=True)
     ocnt, ohyp = O.unpack_key(key)
     oP = O.pose_candidates(Ec[ohyp], mode)
     oind, oPinv, _, _ = O.choose_pose(X0, X1, oP, mode, 8)

@@ -25,12 +25,13 @@ def test_fill_xu_bit_exact(gpu, n):
         assert same_bits(pair.get_XU(which), ref)
 
 
+@pytest.mark.parametrize("sweeps", [0, 7])          # 0 = Householder null-vector solver, 7 = normal equations + Jacobi
 @pytest.mark.parametrize("kernel", [S.KERNEL_SPLIT, S.KERNEL_FUSED, S.KERNEL_MFMA])
 @pytest.mark.parametrize("n,H", [(64, 50), (1000, 300), (2048, 1024), (4096, 2048), (4500, 600), (9000, 100)])
-def test_counts_winner_mask_E(gpu, n, H, kernel):
+def test_counts_winner_mask_E(gpu, n, H, kernel, sweeps):
     scene = synth.two_view_scene(n, seed=5 + n)
     pair, _ = make_pair(S, gpu, scene)
-    p = S.default_params(n, num_hypotheses=H, seed=77, kernel=kernel)
+    p = S.default_params(n, num_hypotheses=H, seed=77, kernel=kernel, jacobi_sweeps=sweeps)
     pair.estimateE(p)
     _, _, X0, X1 = oracle_xu(scene)
     key, ocounts, oE = O.ransac_range(X0, X1, 0, H, p.threshold, p.jacobi_sweeps, seed=77, want_E=True)

@@ -52,7 +52,7 @@ def test_sampler(H):
 def test_hypothesis_E_bit_exact(H, scene):
     X0, X1 = scene
     n = X0.shape[1]
-    for sweeps in (1, 4, 7):
+    for sweeps in (0, 1, 4, 7):                     # 0 = Householder solver
         for h in range(200):
             idx = O.sample8(5, h, n)
             E = np.empty(9, np.float32)

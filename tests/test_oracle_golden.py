@@ -75,6 +75,9 @@ def test_e2e_regression_vectors():
     assert hyp == int(np.argmax(counts)) and cnt == counts.max()          # first maximum
     _, mask = O.count_inliers(Ec[hyp], X0, X1, 1e-6)
     assert np.array_equal(mask, g["mask"])
+    keyq, countsq, Ecq = O.ransac_range(X0, X1, 0, H, 1e-6, 0, seed=42, want_E=True)      # Householder solver
+    assert np.array_equal(countsq, g["qr_counts"]) and keyq == int(g["qr_key"]) and same_bits(Ecq, g["qr_Ecand"])
+    assert np.array_equal(O.count_inliers(Ecq[O.unpack_key(keyq)[1]], X0, X1, 1e-6)[1], g["qr_mask"])
     for mode in (0, 1):
         P = O.pose_candidates(Ec[hyp], mode)
         ind, Pinv, _, _ = O.choose_pose(X0, X1, P, mode, 8)

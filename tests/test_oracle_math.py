@@ -162,3 +162,30 @@ def test_homography_oracle_invariants():
     # NaN coordinates never count
     cn = c.copy(); cn[0, :50] = np.nan
     assert O.homography_count(h, cn, n, 25.0) == O.homography_count(h, np.ascontiguousarray(c[:, 50:]), n - 50, 25.0)
+
+
+def test_householder_null_vector_is_accurate_and_matches_the_svd():
+    """jacobi_sweeps = 0: Householder QR of A^T.  Its vector is the sigma = 0 right singular vector of the
+    8 x 9 system (what the reference reads from gesvdjBatched, kernels.h:196-234, 452-458) to ~1e-4 rad, far
+    closer than the normal-equations eigen-solver, which squares the condition number."""
+    from cuda_sfm_amd_synth import synth
+    sc = synth.two_view_scene(2048, seed=9)
+    _, _, X0, X1 = O.fill_xu(sc["sift"], sc["Kinv"])
+    X0 = np.ascontiguousarray(X0); X1 = np.ascontiguousarray(X1)
+    n = X0.shape[1]
+    worst_q, worst_j, resid = 0.0, 0.0, 0.0
+    for h in range(400):
+        A = O.build_A(X0, X1, O.sample8(3, h, n))
+        eq = O.nullvec9(A, 0).astype(np.float64); ej = O.nullvec9(A, 7).astype(np.float64)
+        t = np.linalg.svd(A.astype(np.float64))[2][-1]
+        assert abs(np.linalg.norm(eq) - 1.0) < 1e-5                      # a column of an orthogonal matrix
+        worst_q = max(worst_q, np.arccos(min(1.0, abs(eq @ t))))
+        worst_j = max(worst_j, np.arccos(min(1.0, abs(ej @ t) / np.linalg.norm(ej))))
+        resid = max(resid, np.abs(A.astype(np.float64) @ eq).max() / np.abs(A).max())
+    assert worst_q < 2e-3 and resid < 2e-6
+    assert worst_q < 0.1 * worst_j                                          # and at least 10x closer than A^T A + Jacobi
+    # degenerate samples (repeated points -> rank < 8) still return a unit vector in the null space
+    for idx in ([0] * 8, [0, 0, 1, 1, 2, 2, 3, 3]):
+        A = O.build_A(X0, X1, np.array(idx, np.int32))
+        e = O.nullvec9(A, 0).astype(np.float64)
+        assert np.isfinite(e).all() and abs(np.linalg.norm(e) - 1.0) < 1e-5 and np.abs(A @ e).max() < 1e-5
