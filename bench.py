@@ -41,8 +41,19 @@ def cpu_baseline(scene, params, seconds=12.0):
     t0 = time.perf_counter()
     key, _, _ = O.ransac_range(X0, X1, 0, sample, params.threshold, params.jacobi_sweeps, seed=params.seed, want_counts=False, nthreads=cores)
     dt = time.perf_counter() - t0
-    return {"value": sample / dt, "unit": "hypotheses/s", "cores": cores, "kind": "port",
-            "sample": f"hypotheses 0..{sample - 1} of the same {N_MATCHES}-match scene, {dt:.1f} s, OpenMP x{cores}"}, (O, X0, X1)
+    out = {"value": sample / dt, "unit": "hypotheses/s", "cores": cores, "kind": "port",
+           "sample": f"hypotheses 0..{sample - 1} of the same {N_MATCHES}-match scene, {dt:.1f} s, OpenMP x{cores}"}
+    # north_star also asks for OpenCV's cv::findEssentialMat (a 5-point solver: wall-time sanity, not a parity target)
+    try:
+        import cv2
+        p1 = np.stack([scene["sift"]["xpos"], scene["sift"]["ypos"]], 1).astype(np.float64)
+        p2 = np.stack([scene["sift"]["match_xpos"], scene["sift"]["match_ypos"]], 1).astype(np.float64)
+        t0 = time.perf_counter()
+        _, m = cv2.findEssentialMat(p1, p2, scene["K"].astype(np.float64), cv2.RANSAC, 0.999, 1.0)
+        out["opencv_findEssentialMat"] = {"ms": 1e3 * (time.perf_counter() - t0), "inliers": int(m.sum()), "threads": cv2.getNumThreads()}
+    except ImportError:
+        out["opencv_findEssentialMat"] = "unavailable: OpenCV (cv2) is not installed in this image"
+    return out, (O, X0, X1)
 
 
 def main():
