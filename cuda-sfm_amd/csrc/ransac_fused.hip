@@ -182,7 +182,7 @@ __device__ __forceinline__ void solve_wave(const float *__restrict__ X0, const f
     wave_sync();                                                      // scratch may be reused by the caller
 }
 
-template <int WPB>
+template <int WPB, bool UNITZ>
 __global__ __launch_bounds__(WPB * 64)
 void ransac_fused_waves(const float *__restrict__ X0, const float *__restrict__ X1, int ld, int n,
                         const int32_t *__restrict__ indices, uint32_t seed, int sweeps,
@@ -190,12 +190,13 @@ void ransac_fused_waves(const float *__restrict__ X0, const float *__restrict__ 
                         int *__restrict__ counts, float *__restrict__ Ecand, unsigned long long *best_key)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    uint2 (*sched)[64] = reinterpret_cast<uint2 (*)[64]>(lds + 6 * (size_t)tile + (size_t)WPB * kWaveScratch);   // after the wave scratches
+    const size_t tile_floats = UNITZ ? (size_t)(2 * kUnitZSecond / sizeof(float)) : 6 * (size_t)tile;                  // point tile, then the wave scratches
+    uint2 (*sched)[64] = reinterpret_cast<uint2 (*)[64]>(lds + tile_floats + (size_t)WPB * kWaveScratch);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (wave == 0) build_jacobi_schedule(sched, lane);
     __syncthreads();
-    float *ws = lds + 6 * (size_t)tile + (size_t)wave * kWaveScratch;
+    float *ws = lds + tile_floats + (size_t)wave * kWaveScratch;
     const uint32_t nbatch = (count + WPB - 1) / WPB;
     unsigned long long wbest = 0;
     bool staged = false;
@@ -220,11 +221,11 @@ void ransac_fused_waves(const float *__restrict__ X0, const float *__restrict__ 
             if (ntiles > 1 || !staged) {
                 if (staged) __syncthreads();
                 const int first = t * tile;
-                stage_tile<false>(lds, X0, X1, ld, first, min(tile, ld - first));
+                stage_tile<UNITZ>(lds, X0, X1, ld, first, min(tile, ld - first));
                 __syncthreads();
                 staged = true;
             }
-            if (valid) cnt += score_tile<false>(E, lds, min(tile, n - t * tile), band, lane);
+            if (valid) cnt += score_tile<UNITZ>(E, lds, min(tile, n - t * tile), band, lane);
         }
         if (valid) {
             if (lane == 0) counts[i] = cnt;
@@ -277,16 +278,16 @@ void ransac_finalize_E_wave(const float *__restrict__ X0, const float *__restric
     }
 }
 
-template <int WPB>
+template <int WPB, bool UNITZ>
 static int launch_fused_t(sfm_pair *pair, const sfm_ransac_params &p, uint32_t h0, uint32_t count, int tile, int ntiles, int grid, size_t lds)
 {
     static bool attr_set = false;
     if (!attr_set) {
-        SFM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&ransac_fused_waves<WPB>),
+        SFM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&ransac_fused_waves<WPB, UNITZ>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL(ransac_fused_waves<WPB>, dim3(grid), dim3(WPB * 64), lds, pair->ctx->stream,
+    hipLaunchKernelGGL((ransac_fused_waves<WPB, UNITZ>), dim3(grid), dim3(WPB * 64), lds, pair->ctx->stream,
                        pair->d_X[0], pair->d_X[1], pair->ld, pair->n, p.d_indices, p.seed, p.jacobi_sweeps,
                        h0, count, p.threshold, tile, ntiles, pair->d_counts, pair->d_Ecand, pair->d_key);
     SFM_HIP_TRY(hipGetLastError());
@@ -303,14 +304,16 @@ int launch_ransac_fused(sfm_pair *pair, const sfm_ransac_params &p, uint32_t h0,
     while (wpb > 4 && (count + wpb - 1) / wpb < (uint32_t)ctx->num_cus) wpb >>= 1;
     const uint32_t nbatch = (count + wpb - 1) / wpb;
     const int grid = (int)(nbatch < (uint32_t)ctx->num_cus ? nbatch : (uint32_t)ctx->num_cus);
-    const size_t lds = ((size_t)6 * tile + (size_t)wpb * kWaveScratch) * sizeof(float) + 9 * 64 * sizeof(uint2);   // + Jacobi schedule
+    const bool uz = pair->unit_z;
+    const size_t lds = (uz ? (size_t)2 * kUnitZSecond : (size_t)6 * tile * sizeof(float)) + (size_t)wpb * kWaveScratch * sizeof(float) +
+                       9 * 64 * sizeof(uint2);                                                          // tile + wave scratches + Jacobi schedule
     const bool timed = ctx->timing && ctx->tcount < sfm_ctx::kTimingSlots;
     hipEvent_t *tev = timed ? ctx->tev[ctx->tcount] : nullptr;
     if (timed) { SFM_HIP_TRY(hipEventRecord(tev[0], ctx->stream)); SFM_HIP_TRY(hipEventRecord(tev[1], ctx->stream)); }
     int rc;
     switch (wpb) {
-    case 8:  rc = launch_fused_t<8>(pair, p, h0, count, tile, ntiles, grid, lds); break;
-    default: rc = launch_fused_t<4>(pair, p, h0, count, tile, ntiles, grid, lds); break;
+    case 8:  rc = uz ? launch_fused_t<8, true>(pair, p, h0, count, tile, ntiles, grid, lds) : launch_fused_t<8, false>(pair, p, h0, count, tile, ntiles, grid, lds); break;
+    default: rc = uz ? launch_fused_t<4, true>(pair, p, h0, count, tile, ntiles, grid, lds) : launch_fused_t<4, false>(pair, p, h0, count, tile, ntiles, grid, lds); break;
     }
     if (rc == SFM_OK && timed) { SFM_HIP_TRY(hipEventRecord(tev[2], ctx->stream)); ctx->tcount++; }
     return rc;
