@@ -55,7 +55,7 @@ EXPORTS = [
     "sfm_ransac_finalize_key", "sfm_ransac_export_key", "sfm_pose_candidates", "sfm_choose_pose", "sfm_triangulate",
     "sfm_pair_device_ptr", "sfm_pair_ld", "sfm_pair_num_points", "sfm_get_XU", "sfm_get_E", "sfm_get_best",
     "sfm_get_key", "sfm_get_inlier_counts", "sfm_get_inlier_mask", "sfm_get_E_candidates",
-    "sfm_get_pose_candidates", "sfm_get_pose_inverses", "sfm_get_pose_index", "sfm_get_points",
+    "sfm_get_pose_candidates", "sfm_get_pose_inverses", "sfm_get_pose_index", "sfm_get_points", "sfm_copy_points_to_vbo",
     "sfm_ransac_last_launch",
 ]
 
@@ -89,6 +89,7 @@ class SiftLayout(C.Structure):
 _lib.sfm_sift_temp_layout.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(SiftLayout)]
 _lib.sfm_extract_sift.argtypes = [_vp, _vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_float, C.c_float,
                                   C.c_int, _vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+_lib.sfm_copy_points_to_vbo.argtypes = [_vp, _vp, _vp, C.c_float]
 _lib.sfm_find_homography.argtypes = [_vp, _vp, C.c_int, _vp, C.POINTER(C.c_int), C.c_int, C.c_float, C.c_float,
                                      C.c_float, C.c_uint32, _vp, _vp, _vp]
 _lib.sfm_match.argtypes = [_vp, _vp, C.c_int, _vp, C.c_int]
@@ -376,6 +377,10 @@ class ImagePair:
 
     def get_points(self):
         return self._get(_lib.sfm_get_points, "sfm_get_points", (4, self.num_points), np.float32)
+
+    def copy_points_to_vbo(self, d_positions, d_velocities, scale=1.0):
+        """Image_pair::copyBoidsToVBO (sfm.cu:374-383) into device buffers of 4 * num_points floats."""
+        _check(_lib.sfm_copy_points_to_vbo(self._h, _ptr(d_positions), _ptr(d_velocities), float(scale)), "sfm_copy_points_to_vbo")
 
     def last_launch(self):
         v = [C.c_int() for _ in range(4)]

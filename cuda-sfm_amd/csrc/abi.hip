@@ -607,6 +607,15 @@ int sfm_get_points(sfm_pair *pair, float *h_points)
     return copy_out(pair, h_points, pair->d_points, (size_t)4 * pair->n * 4);
 }
 
+int sfm_copy_points_to_vbo(sfm_pair *pair, float *d_positions, float *d_velocities, float scale)
+{
+    SFM_REQUIRE(pair, SFM_E_INVALID, "null pair");
+    SFM_REQUIRE(pair->have_pose, SFM_E_STATE, "linear_triangulation has not run");
+    SFM_REQUIRE((((uintptr_t)d_positions | (uintptr_t)d_velocities) & 15u) == 0, SFM_E_INVALID, "vertex buffers must be 16-byte aligned");
+    SFM_HIP_TRY(hipSetDevice(pair->ctx->device));
+    return launch_points_to_vbo(pair, d_positions, d_velocities, scale);
+}
+
 int sfm_ransac_last_launch(sfm_pair *pair, int *kernel, int *grid, int *block, int *lds_bytes)
 {
     SFM_REQUIRE(pair, SFM_E_INVALID, "null pair");

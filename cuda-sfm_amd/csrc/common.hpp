@@ -98,6 +98,7 @@ int launch_set_points(sfm_pair *pair, const float *d_X0, const float *d_X1);
 int launch_pose_candidates(sfm_pair *pair, int mode);
 int launch_choose_pose(sfm_pair *pair, int mode);
 int launch_triangulate(sfm_pair *pair, int mode);
+int launch_points_to_vbo(sfm_pair *pair, float *d_positions, float *d_velocities, float scale);
 
 // sift.hip
 void sift_layout(int width, int height, int num_octaves, int scale_up, sfm_sift_layout *L);

@@ -224,4 +224,22 @@ int launch_triangulate(sfm_pair *pair, int mode)
     return SFM_OK;
 }
 
+// kernCopyPositionsToVBO + kernCopyVelocitiesToVBO (kernels.h:471-494) in one launch
+__global__ __launch_bounds__(256)
+void points_to_vbo_kernel(int n, int ld, const float *__restrict__ pts, float *__restrict__ pos, float *__restrict__ vel, float scale)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    if (pos) reinterpret_cast<float4 *>(pos)[i] = make_float4(pts[i] * scale, pts[ld + i] * scale, pts[2 * ld + i] * scale, 1.0f);
+    if (vel) reinterpret_cast<float4 *>(vel)[i] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+}
+
+int launch_points_to_vbo(sfm_pair *pair, float *d_positions, float *d_velocities, float scale)
+{
+    hipLaunchKernelGGL(points_to_vbo_kernel, dim3((pair->n + 255) / 256), dim3(256), 0, pair->ctx->stream, pair->n, pair->n, pair->d_points,
+                       d_positions, d_velocities, scale);
+    SFM_HIP_TRY(hipGetLastError());
+    return SFM_OK;
+}
+
 } // namespace sfm

@@ -74,6 +74,12 @@ public:
     void getPoseCandidates(float P[64]) { SFM_FACADE_CALL(sfm_get_pose_candidates(pair_, P)); }
     void getPoseInverses(float P[64]) { SFM_FACADE_CALL(sfm_get_pose_inverses(pair_, P)); }
     int getPoseIndex() { int i = 0; SFM_FACADE_CALL(sfm_get_pose_index(pair_, &i)); return i; }
+    // sfm.cu:374-383: (x, y, z, 1) vertices and the constant colour buffer, into DEVICE buffers of 4 * N floats
+    void copyBoidsToVBO(float *vbodptr_positions, float *vbodptr_velocities)
+    {
+        SFM_FACADE_CALL(sfm_copy_points_to_vbo(pair_, vbodptr_positions, vbodptr_velocities, 1.0f));
+        SFM_FACADE_CALL(sfm_ctx_synchronize(sfm_facade::context()));            // cudaDeviceSynchronize of sfm.cu:382
+    }
     std::vector<float> getPoints()          // 4 x N row-major [x; y; z; 1] (d_final_points, sfm.cu:77,335)
     {
         std::vector<float> p((size_t)4 * num_points_);

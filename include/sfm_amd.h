@@ -213,6 +213,10 @@ int sfm_get_pose_candidates(sfm_pair *pair, float h_P[64]);
 int sfm_get_pose_inverses(sfm_pair *pair, float h_Pinv[64]);
 int sfm_get_pose_index(sfm_pair *pair, int *index);
 int sfm_get_points(sfm_pair *pair, float *h_points /* 4 x num_points */);
+/* Image_pair::copyBoidsToVBO (sfm.cu:374-383; kernCopyPositionsToVBO / kernCopyVelocitiesToVBO kernels.h:471-494):
+ * interleaved (x, y, z, 1) * scale vertices and the constant (1, 1, 1, 1) colour buffer, written to DEVICE
+ * buffers of 4 * num_points floats each (in the reference: the mapped GL buffer objects).  Either may be NULL. */
+int sfm_copy_points_to_vbo(sfm_pair *pair, float *d_positions, float *d_velocities, float scale);
 /* Name and launch geometry of the RANSAC scoring kernel used by the last call (for profiling). */
 int sfm_ransac_last_launch(sfm_pair *pair, int *kernel, int *grid, int *block, int *lds_bytes);
 

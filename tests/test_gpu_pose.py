@@ -60,3 +60,20 @@ def test_call_order_errors(gpu):
         with pytest.raises(S.SfmError) as e:
             fn()
         assert e.value.code == S.E_STATE
+
+
+def test_copy_points_to_vbo(gpu):
+    """Image_pair::copyBoidsToVBO (sfm.cu:374-383): interleaved (x, y, z, 1) * scale and the constant colour buffer"""
+    torch, dev, ctx = gpu
+    n = 777
+    scene = synth.two_view_scene(n, seed=4)
+    pair, _ = make_pair(S, gpu, scene)
+    pair.estimateE(S.default_params(n, num_hypotheses=64))
+    pair.computePosecandidates(); pair.choosePose(); pair.linear_triangulation()
+    pts = pair.get_points()
+    pos = torch.full((n, 4), -7.0, dtype=torch.float32, device=dev); vel = torch.zeros((n, 4), dtype=torch.float32, device=dev)
+    pair.copy_points_to_vbo(pos, vel, 2.0)
+    torch.cuda.synchronize()
+    want = np.stack([pts[0] * np.float32(2), pts[1] * np.float32(2), pts[2] * np.float32(2), np.ones(n, np.float32)], 1)
+    assert same_bits(pos.cpu().numpy(), want) and (vel.cpu().numpy() == 1.0).all()
+    pair.copy_points_to_vbo(pos, None)                                  # either buffer may be absent
