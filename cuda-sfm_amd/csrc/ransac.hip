@@ -67,6 +67,8 @@ void ransac_score_waves(const float *__restrict__ X0, const float *__restrict__ 
                         int tile, int ntiles, int *__restrict__ counts, unsigned long long *best_key)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    // bits of the largest |coordinate| in the staged tile, kept right behind the tile
+    unsigned int &tile_bound = *reinterpret_cast<unsigned int *>(lds + (UNITZ ? (size_t)(2 * kUnitZSecond / sizeof(float)) : 6 * (size_t)tile));
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t nbatch = (count + WPB - 1) / WPB;
@@ -83,16 +85,28 @@ void ransac_score_waves(const float *__restrict__ X0, const float *__restrict__ 
             auto sreg = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); };
             E = Ess{ sreg(e[0]), sreg(e[1]), sreg(e[2]), sreg(e[3]), sreg(e[4]), sreg(e[5]), sreg(e[6]), sreg(e[7]), sreg(e[8]) };
         }
+        // a normalised E has entries <= 1; anything else (degenerate sample -> NaN / inf) keeps the full range tracking
+        const bool e_tame = fabsf(E.e0) <= 2.0f && fabsf(E.e1) <= 2.0f && fabsf(E.e2) <= 2.0f && fabsf(E.e3) <= 2.0f && fabsf(E.e4) <= 2.0f &&
+                            fabsf(E.e5) <= 2.0f && fabsf(E.e6) <= 2.0f && fabsf(E.e7) <= 2.0f && fabsf(E.e8) <= 2.0f;
         int cnt = 0;
         for (int t = 0; t < ntiles; ++t) {
             if (ntiles > 1 || !staged) {
                 if (staged) __syncthreads();                  // everyone done with the previous tile
+                if (threadIdx.x == 0) tile_bound = 0u;
+                __syncthreads();
                 const int first = t * tile;
-                stage_tile<UNITZ>(lds, X0, X1, ld, first, min(tile, ld - first));
+                const float big = stage_tile<UNITZ>(lds, X0, X1, ld, first, min(tile, ld - first));
+                atomicMax(&tile_bound, __float_as_uint(big));   // non-negative floats order like their bits
                 __syncthreads();
                 staged = true;
             }
-            if (valid) cnt += score_tile<UNITZ>(E, lds, min(tile, n - t * tile), band, lane);
+            if (valid) {
+                const int nv = min(tile, n - t * tile);
+                if (e_tame && tile_bound < 0x47C35000u)       // 1e5f
+                    cnt += score_tile<UNITZ, false>(E, lds, nv, band, lane);
+                else
+                    cnt += score_tile<UNITZ, true>(E, lds, nv, band, lane);
+            }
         }
         if (valid) {
             if (lane == 0) counts[i] = cnt;
@@ -211,7 +225,7 @@ int launch_ransac_score(sfm_pair *pair, const sfm_ransac_params &p, uint32_t h0,
     const uint32_t nbatch = (count + wpb - 1) / wpb;
     // unit-z layout: fixed 64 KiB (two arrays of kTileMax/2 pair records); generic: 24 B per point
     const bool uz = pair->unit_z;
-    const size_t lds = uz ? (size_t)2 * kUnitZSecond : (size_t)6 * tile * sizeof(float) + 16 * sizeof(unsigned long long);
+    const size_t lds = (uz ? (size_t)2 * kUnitZSecond : (size_t)6 * tile * sizeof(float)) + 16 * sizeof(unsigned long long);   // tile + bound / per-wave maxima
     // persistent blocks: as many as are co-resident (LDS and the 2048-thread CU limit)
     int per_cu = (int)((160 * 1024) / lds);
     if (per_cu > 2048 / (wpb * 64)) per_cu = 2048 / (wpb * 64);

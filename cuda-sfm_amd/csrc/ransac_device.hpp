@@ -76,10 +76,13 @@ __device__ __forceinline__ void solve_two(const float *__restrict__ X0, const fl
 typedef float v2f __attribute__((ext_vector_type(2)));
 constexpr int kUnitZSecond = kTileMax / 2 * 16;      // bytes: array 2 starts after kTileMax/2 pair records
 
+// Returns the largest |coordinate| this thread copied (NaN padding ignored) -- the score kernel reduces it
+// over the block to know whether thr * da * db can leave the float range at all.
 template <bool UNITZ>
-__device__ __forceinline__ void stage_tile(float *lds, const float *__restrict__ X0,
-                                           const float *__restrict__ X1, int ld, int first, int len)
+__device__ __forceinline__ float stage_tile(float *lds, const float *__restrict__ X0,
+                                            const float *__restrict__ X1, int ld, int first, int len)
 {
+    float big = 0.0f;
     const int npair = len >> 1;                 // ld, first, len are multiples of 128
     const float2 *r0 = reinterpret_cast<const float2 *>(X0 + first);
     const float2 *r1 = reinterpret_cast<const float2 *>(X0 + (size_t)ld + first);
@@ -90,16 +93,20 @@ __device__ __forceinline__ void stage_tile(float *lds, const float *__restrict__
     float4 *dst = reinterpret_cast<float4 *>(lds);
     for (int k = threadIdx.x; k < npair; k += blockDim.x) {
         const float2 a = r0[k], b = r1[k], d = r3[k], e = r4[k];
+        big = fmaxf(fmaxf(fmaxf(big, fmaxf(fabsf(a.x), fabsf(a.y))), fmaxf(fabsf(b.x), fabsf(b.y))),
+                    fmaxf(fmaxf(fabsf(d.x), fabsf(d.y)), fmaxf(fabsf(e.x), fabsf(e.y))));
         if (UNITZ) {
             dst[k] = make_float4(a.x, a.y, b.x, b.y);
             dst[kUnitZSecond / 16 + k] = make_float4(d.x, d.y, e.x, e.y);
         } else {
             const float2 c = r2[k], f = r5[k];
+            big = fmaxf(big, fmaxf(fmaxf(fabsf(c.x), fabsf(c.y)), fmaxf(fabsf(f.x), fabsf(f.y))));
             dst[3 * k + 0] = make_float4(a.x, a.y, b.x, b.y);
             dst[3 * k + 1] = make_float4(c.x, c.y, d.x, d.y);
             dst[3 * k + 2] = make_float4(e.x, e.y, f.x, f.y);
         }
     }
+    return big;
 }
 
 __device__ __forceinline__ v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
@@ -143,7 +150,7 @@ __device__ __forceinline__ EssAddends make_addends(const Ess &E)
     return a;
 }
 
-template <bool UNITZ>
+template <bool UNITZ, bool TRACK_HI = true>
 __device__ __forceinline__ void filter_pair(const Ess &E, const EssAddends &ad, float thr, const PairPts &p,
                                             unsigned long long &in_a, unsigned long long &in_b, FilterAcc &acc)
 {
@@ -177,13 +184,16 @@ __device__ __forceinline__ void filter_pair(const Ess &E, const EssAddends &ad, 
     asm("v_sad_u32 %0, %1, %2, 0" : "=v"(gapy) : "v"(myb), "v"(tyb));
     acc.gap_min = min(acc.gap_min, min(gapx, gapy));
     acc.tb_min = min(acc.tb_min, min(txb, tyb));
-    acc.tb_max = max(acc.tb_max, max(txb, tyb));
+    if (TRACK_HI) acc.tb_max = max(acc.tb_max, max(txb, tyb));
 }
 
 // `nvalid` = real points in the staged tile (the rest is NaN padding up to a multiple of 128).  Full
 // 128-point iterations run unmasked; a ragged last iteration masks the padding lanes out of the count
 // and out of the undecided trackers (padding must not force the exact path).
-template <bool UNITZ>
+// TRACK_HI = false drops the upper range check of tp (one VALU instruction per pair of points).  The caller may
+// only do that when overflow is impossible: every |E_ij| <= 2 and every |coordinate| <= B < 1e5 give |a_i|, |b_j| <= 6B,
+// da, db <= 72 B^2, tp = thr * da * db <= 1e3 * 5184 B^4 < 5.2e26 < 1e30, and m = n^2 (da + db) <= 324 B^4 * 144 B^2 finite.
+template <bool UNITZ, bool TRACK_HI = true>
 __device__ __forceinline__ int score_tile(const Ess &E, const float *lds, int nvalid, const ThrBand &band, int lane)
 {
     constexpr int kRec = UNITZ ? 1 : 3;         // float4 per pair record in the first array
@@ -193,9 +203,20 @@ __device__ __forceinline__ int score_tile(const Ess &E, const float *lds, int nv
     FilterAcc acc{ 0xFFFFFFFFu, 0xFFFFFFFFu, 0u };
     const EssAddends ad = make_addends(E);
     const float4 *rec = rec0;
-    for (int it = 0; it < full; ++it, rec += kRec * 64) {
+    int it = 0;
+    // four iterations per trip by hand (the ballots are convergent, so the compiler will not unroll a loop with a
+    // run-time trip count): the record offsets become ds_read immediates, one address update per 512 points
+    for (; it + 4 <= full; it += 4, rec += 4 * kRec * 64) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            unsigned long long in_a, in_b;
+            filter_pair<UNITZ, TRACK_HI>(E, ad, band.thr, load_pair<UNITZ>(rec + u * kRec * 64), in_a, in_b, acc);
+            cnt += __builtin_popcountll(in_a) + __builtin_popcountll(in_b);
+        }
+    }
+    for (; it < full; ++it, rec += kRec * 64) {
         unsigned long long in_a, in_b;
-        filter_pair<UNITZ>(E, ad, band.thr, load_pair<UNITZ>(rec), in_a, in_b, acc);
+        filter_pair<UNITZ, TRACK_HI>(E, ad, band.thr, load_pair<UNITZ>(rec), in_a, in_b, acc);
         cnt += __builtin_popcountll(in_a) + __builtin_popcountll(in_b);
     }
     const int rest = nvalid - (full << 7);      // 0..127 real points in the ragged iteration

@@ -184,3 +184,23 @@ def test_set_points_generic_z(gpu):
         pair.estimateE(p)
         key, ocounts, _ = O.ransac_range(X0s, X1s, 0, H, p.threshold, p.jacobi_sweeps, seed=3)
         assert np.array_equal(pair.get_inlier_counts(H), ocounts) and pair.get_key() == key
+
+
+@pytest.mark.parametrize("scale", [3.0e4, 2.0e5, 1.0e9])
+def test_huge_coordinates_keep_the_full_range_tracking(gpu, scale):
+    """The scoring kernel drops the upper range check of thr*da*db only when every |coordinate| < 1e5 (then it
+    cannot overflow).  Points in pixel-like or absurd units (homogeneous scale is free) must still count exactly
+    like the oracle, through the variant that keeps the check and, for 1e9, through the exact fallback."""
+    torch, dev, ctx = gpu
+    n, H = 1100, 3000
+    scene = synth.two_view_scene(n, seed=14)
+    _, _, X0, X1 = oracle_xu(scene)
+    X0s = np.ascontiguousarray(X0 * np.float32(scale), np.float32); X1s = np.ascontiguousarray(X1 * np.float32(scale), np.float32)
+    pair = S.ImagePair(ctx, scene["K"], scene["Kinv"], 2, n)
+    pair.set_points(to_dev(torch, dev, X0s), to_dev(torch, dev, X1s))
+    thr = float(np.float32(1e-6) * np.float32(scale) * np.float32(scale)) if scale < 1e8 else 1e-6
+    for kernel in (S.KERNEL_SPLIT, S.KERNEL_FUSED):
+        p = S.default_params(n, num_hypotheses=H, seed=5, kernel=kernel, threshold=thr)
+        pair.estimateE(p)
+        key, ocounts, _ = O.ransac_range(X0s, X1s, 0, H, p.threshold, p.jacobi_sweeps, seed=5)
+        assert np.array_equal(pair.get_inlier_counts(H), ocounts) and pair.get_key() == key
