@@ -200,13 +200,11 @@ struct LevelState {                      // device-resident bookkeeping, one per
     unsigned int alloc;                  // stash allocation cursor (atomic, block-aggregated)
     unsigned int found;                  // extrema that passed the tests = sum of the segment counts (sift_scan_kernel)
     unsigned int kept;                   // candidates present in the stash = min(found, capacity)
-    unsigned int base;                   // first output slot of the level (unclipped)
-    unsigned int dups;                   // secondary orientations of the level
+    unsigned int dups;                   // secondary orientations of the level (sift_place_kernel)
 };
 
 struct Workspace {
     LevelState *state;                   // [8]
-    unsigned int *result;                // [2]: count as the reference reports it, records stored (both unclipped)
     Cand *stash;                         // [8][cap]
     unsigned int *segs;                  // candidates per row segment, then exclusive offsets (sift_scan_kernel)
     unsigned int *dupflag;               // [8][cap]  indexed by rank
@@ -362,12 +360,13 @@ __device__ __forceinline__ unsigned int block_scan_1024(unsigned int v, unsigned
     return wsum[wave] + inc - v;
 }
 
-// per-segment counts -> exclusive offsets, per level; closes LevelState::kept.  One block.
+// per-segment counts -> exclusive offsets; closes LevelState::found / kept.  One block per level.
 __global__ __launch_bounds__(1024)
 void sift_scan_kernel(Levels L, Workspace W)
 {
     __shared__ unsigned int wsum[17];
-    for (int lvl = 0; lvl < L.n; ++lvl) {
+    {
+        const int lvl = blockIdx.x;
         unsigned int *a = W.segs + L.seg0[lvl];
         const int n = L.seg0[lvl + 1] - L.seg0[lvl];
         const int per = (n + 1023) / 1024;                          // consecutive entries per thread: one block scan per level
@@ -479,29 +478,39 @@ void sift_orient_kernel(const float *__restrict__ temp, Levels L, Workspace W)
     }
 }
 
-// output slots: levels coarsest first (cudaSiftH.cu:149-168), secondary orientations after each level's
-// points in rank order.  One block.
+// exclusive prefix of the secondary-orientation flags in rank order; closes LevelState::dups.  One block per
+// level.  The output slots follow from the level totals (level_bases): levels coarsest first
+// (cudaSiftH.cu:149-168), a level's secondary orientations after all of its points.
 __global__ __launch_bounds__(1024)
 void sift_place_kernel(Levels L, Workspace W)
 {
     __shared__ unsigned int wsum[17];
-    unsigned int base = 0, reported = 0;
-    for (int lvl = L.n - 1; lvl >= 0; --lvl) {
-        const unsigned int kept = W.state[lvl].kept, found = W.state[lvl].found;
-        const unsigned int *flag = W.dupflag + (size_t)lvl * W.cap;
-        unsigned int *pre = W.dupprefix + (size_t)lvl * W.cap;
-        const unsigned int per = (kept + 1023u) / 1024u;
-        const unsigned int lo = min(kept, threadIdx.x * per), hi = min(kept, lo + per);
-        unsigned int mine = 0;
-        for (unsigned int i = lo; i < hi; ++i) mine += flag[i];
-        unsigned int running;
-        unsigned int run = block_scan_1024(mine, wsum, &running);
-        for (unsigned int i = lo; i < hi; ++i) { pre[i] = run; run += flag[i]; }
-        if (threadIdx.x == 0) { W.state[lvl].base = base; W.state[lvl].dups = running; }
-        reported = base + found;                         // what d_PointCounter[2*octave] holds after the level
-        base += found + running;
+    const int lvl = blockIdx.x;
+    const unsigned int kept = W.state[lvl].kept;
+    const unsigned int *flag = W.dupflag + (size_t)lvl * W.cap;
+    unsigned int *pre = W.dupprefix + (size_t)lvl * W.cap;
+    const unsigned int per = (kept + 1023u) / 1024u;
+    const unsigned int lo = min(kept, threadIdx.x * per), hi = min(kept, lo + per);
+    unsigned int mine = 0;
+    for (unsigned int i = lo; i < hi; ++i) mine += flag[i];
+    unsigned int running;
+    unsigned int run = block_scan_1024(mine, wsum, &running);
+    for (unsigned int i = lo; i < hi; ++i) { pre[i] = run; run += flag[i]; }
+    if (threadIdx.x == 0) W.state[lvl].dups = running;
+}
+
+// first output slot of every level, the count the reference reports (d_PointCounter[2*numOctaves]) and the
+// number of records stored (all unclipped)
+SFM_HD void level_bases(const LevelState *st, int n, unsigned int base[8], unsigned int &reported, unsigned int &stored)
+{
+    unsigned int run = 0;
+    reported = 0;
+    for (int lvl = n - 1; lvl >= 0; --lvl) {
+        base[lvl] = run;
+        reported = run + st[lvl].found;
+        run += st[lvl].found + st[lvl].dups;
     }
-    if (threadIdx.x == 0) { W.result[0] = reported; W.result[1] = base; }
+    stored = run;
 }
 
 // ---- 4x4x8 gradient histogram, one wavefront per record (ExtractSiftDescriptorsCONSTNew) -----------------
@@ -648,9 +657,11 @@ void sift_desc_kernel(const float *__restrict__ temp, Levels L, Workspace W, sfm
     }
     const int s0 = ys * 16 + xs;
     const unsigned int gw = blockIdx.x * 4 + wave, nw = gridDim.x * 4;
-    const unsigned int reported = min(W.result[0], (unsigned int)max_pts);
+    unsigned int bases[8], rep, sto;
+    level_bases(W.state, L.n, bases, rep, sto);
+    const unsigned int reported = min(rep, (unsigned int)max_pts);
     for (int lvl = 0; lvl < L.n; ++lvl) {
-        const unsigned int kept = W.state[lvl].kept, base = W.state[lvl].base, found = W.state[lvl].found;
+        const unsigned int kept = W.state[lvl].kept, base = bases[lvl], found = W.state[lvl].found;
         const float *__restrict__ img = temp + L.img[lvl];
         const int w = L.w[lvl], h = L.h[lvl], pitch = L.p[lvl];
         const Cand *stash = W.stash + (size_t)lvl * W.cap;
@@ -796,7 +807,7 @@ int launch_extract_sift(sfm_ctx *ctx, sfm_sift_point *d_sift, int max_pts, const
 
     // workspace: level state + result | stash | per-segment counts | dup flags | dup prefixes
     const size_t cap = (size_t)max_pts * 4;
-    const size_t o_state = 0, o_result = 8 * sizeof(LevelState), o_stash = 256;
+    const size_t o_state = 0, o_stash = 256;
     const size_t o_segs = o_stash + 8 * cap * sizeof(Cand);
     const size_t o_flag = o_segs + (((size_t)segs * 4 + 255) & ~(size_t)255);
     const size_t o_pre = o_flag + 8 * cap * 4;
@@ -806,7 +817,6 @@ int launch_extract_sift(sfm_ctx *ctx, sfm_sift_point *d_sift, int max_pts, const
     char *ws = static_cast<char *>(ctx->sift_ws);
     Workspace W;
     W.state = reinterpret_cast<LevelState *>(ws + o_state);
-    W.result = reinterpret_cast<unsigned int *>(ws + o_result);
     W.stash = reinterpret_cast<Cand *>(ws + o_stash);
     W.segs = reinterpret_cast<unsigned int *>(ws + o_segs);
     W.dupflag = reinterpret_cast<unsigned int *>(ws + o_flag);
@@ -846,21 +856,22 @@ int launch_extract_sift(sfm_ctx *ctx, sfm_sift_point *d_sift, int max_pts, const
         const float factor = 1.0f / kNumScales, edge_limit = 10.0f;
         if (pass == 0) {
             hipLaunchKernelGGL(sift_find_kernel, dim3(find_blocks), dim3(256), 0, st, d_temp, LF, W, thresh, lowest_scale, factor, edge_limit, 0);
-            hipLaunchKernelGGL(sift_scan_kernel, dim3(1), dim3(1024), 0, st, LF, W);
+            hipLaunchKernelGGL(sift_scan_kernel, dim3(n), dim3(1024), 0, st, LF, W);
         } else {
             // some level found more raw extrema than its stash holds: count, scan, then store by rank (lowest ranks survive)
             SFM_HIP_TRY(hipMemsetAsync(ws, 0, 256, st));
             hipLaunchKernelGGL(sift_find_kernel, dim3(find_blocks), dim3(256), 0, st, d_temp, LF, W, thresh, lowest_scale, factor, edge_limit, 1);
-            hipLaunchKernelGGL(sift_scan_kernel, dim3(1), dim3(1024), 0, st, LF, W);
+            hipLaunchKernelGGL(sift_scan_kernel, dim3(n), dim3(1024), 0, st, LF, W);
             hipLaunchKernelGGL(sift_find_kernel, dim3(find_blocks), dim3(256), 0, st, d_temp, LF, W, thresh, lowest_scale, factor, edge_limit, 2);
         }
         hipLaunchKernelGGL(sift_orient_kernel, dim3(2048), dim3(256), 0, st, d_temp, LF, W);
-        hipLaunchKernelGGL(sift_place_kernel, dim3(1), dim3(1024), 0, st, LF, W);
+        hipLaunchKernelGGL(sift_place_kernel, dim3(n), dim3(1024), 0, st, LF, W);
         hipLaunchKernelGGL(sift_desc_kernel, dim3(4096), dim3(256), 0, st, d_temp, LF, W, d_sift, max_pts, scale_up);
         SFM_HIP_TRY(hipGetLastError());
-        SFM_HIP_TRY(hipMemcpyAsync(res, W.result, sizeof(res), hipMemcpyDeviceToHost, st));
         SFM_HIP_TRY(hipMemcpyAsync(hs, W.state, sizeof(hs), hipMemcpyDeviceToHost, st));
         SFM_HIP_TRY(hipStreamSynchronize(st));
+        unsigned int bases[8];
+        level_bases(hs, n, bases, res[0], res[1]);
         bool overflow = false;
         for (int l = 0; l < n; ++l) overflow = overflow || hs[l].found > (unsigned int)cap;
         if (!overflow) break;
