@@ -182,3 +182,31 @@ def test_findmaxcorr10_vs_product_matcher(R, gpu, n1, n2):
     assert (ref["ambiguity"] == ours["ambiguity"]).mean() > 0.5
     orc = O.match_sift(s1, s2)
     assert np.array_equal(orc["match"], ref["match"]) and same_bits(orc["score"], ref["score"])
+
+
+def test_findmaxcorr10_tail_quirk_q1(R, gpu):
+    """Quirk Q1 (matching.cu:325): the reference's tile loop never visits the last numPts2 % 32 points of the
+    second set.  The product visits all of them; restricted to the points the reference does visit it
+    reproduces the reference bit for bit, and the full call differs exactly where a skipped point wins."""
+    torch, dev, ctx = gpu
+    n1, n2 = 512, 1024 + 13
+    d1, _, _ = synth.descriptors(n1, seed=21)
+    d2, _, _ = synth.descriptors(n2, seed=22)
+    d2[-13:] = d1[:13]                                        # the skipped tail holds the true partners of points 0..12
+    s1 = synth.sift_records(d1, seed=3); s2 = synth.sift_records(d2, seed=4)
+    ref = s1.copy()
+    assert R.refk_match(ref.ctypes.data_as(C.c_void_p), n1, s2.ctypes.data_as(C.c_void_p), n2) == 0
+    t2 = to_dev(torch, dev, s2)
+    t1 = to_dev(torch, dev, s1)
+    ctx.match(t1, n1, t2, n2 - n2 % 32)                      # what the reference actually searches
+    torch.cuda.synchronize()
+    cut = t1.cpu().numpy().reshape(-1).view(synth.SIFT_DTYPE)
+    assert np.array_equal(cut["match"], ref["match"]) and same_bits(cut["score"], ref["score"])
+    assert (ref["match"] < n2 - 13).all()
+    t1 = to_dev(torch, dev, s1)
+    ctx.match(t1, n1, t2, n2)                                # the product's answer
+    torch.cuda.synchronize()
+    full = t1.cpu().numpy().reshape(-1).view(synth.SIFT_DTYPE)
+    assert np.array_equal(full["match"][:13], np.arange(n2 - 13, n2)) and (full["score"][:13] > 0.999).all()
+    rest = full["match"] < n2 - 13                          # wherever no skipped point wins the two agree
+    assert rest[13:].mean() > 0.9 and np.array_equal(full["match"][rest], ref["match"][rest]) and same_bits(full["score"][rest], ref["score"][rest])
