@@ -34,9 +34,14 @@ struct Top2 { float best, second; int idx; };
 
 __device__ __forceinline__ void top2_push(Top2 &t, float s, int p)
 {
-    // matching.cu:352-361 / match.cu:64-68: strict '>', ascending p within a lane
-    if (s > t.best) { t.second = t.best; t.best = s; t.idx = p; }
-    else if (s > t.second) t.second = s;
+    // matching.cu:352-361 / match.cu:64-68: strict '>', ascending p within a lane:
+    //   if (s > best) { second = best; best = s; idx = p; } else if (s > second) second = s;
+    // With best >= second that is: second' = median(best, second, s), best' = max(best, s), idx moves on a strict win --
+    // branch-free, one v_med3_f32 per statistic.
+    const bool wins = s > t.best;
+    t.second = __builtin_amdgcn_fmed3f(t.best, t.second, s);
+    t.best = __builtin_amdgcn_fmed3f(t.best, s, __builtin_inff());
+    t.idx = wins ? p : t.idx;
 }
 
 __device__ __forceinline__ Top2 top2_merge(const Top2 &a, const Top2 &b)
