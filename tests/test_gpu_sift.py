@@ -213,3 +213,33 @@ def test_noise_image_many_points_and_capacity(gpu):
         # secondary orientations (they would start after ALL of the octave's points, cudaSiftD.cu:1041)
         k = min(cap, first_fine)
         assert same_bits(crec["data"][:k], rec["data"][:k])
+
+
+def test_randomised_configurations(gpu):
+    """a sweep over image sizes, octave counts, blurs, thresholds, lowest scales and the upsampling switch, on
+    images of three kinds (blobs + hard shapes, white noise, smooth ramps with a few blobs): every record equals
+    the oracle's"""
+    rng = np.random.default_rng(2026)
+    seen = 0
+    for trial in range(14):
+        w, h = int(rng.integers(33, 420)), int(rng.integers(33, 320))
+        kind = trial % 3
+        if kind == 0:
+            img = synth.image(w, h, seed=100 + trial, blobs=max(10, w * h // 1500))
+        elif kind == 1:
+            img = np.rint(rng.uniform(0, 255, (h, w))).astype(np.float32)
+        else:
+            yy, xx = np.mgrid[0:h, 0:w]
+            img = np.rint(60 + 0.2 * xx + 0.3 * yy + 40 * np.sin(xx / 7.0) * np.cos(yy / 5.0)).astype(np.float32)
+        kw = dict(num_octaves=int(rng.integers(1, 6)), init_blur=float(rng.choice([0.0, 1.0, 1.5, 2.0])),
+                  thresh=float(rng.choice([0.3, 1.0, 2.0, 3.5])), lowest_scale=float(rng.choice([0.0, 0.0, 1.3, 3.0])),
+                  scale_up=bool(rng.integers(0, 4) == 0))
+        if kw["scale_up"] and w * h > 60000:
+            kw["scale_up"] = False
+        rec, n, stored, _, _ = run_product(gpu, img, **kw)
+        opts, on, ostored = O.extract_sift(img, kw["num_octaves"], kw["init_blur"], kw["thresh"], kw["lowest_scale"], kw["scale_up"])
+        assert (n, stored) == (on, ostored), (trial, w, h, kw)
+        for f in FIELDS:
+            assert same_bits(rec[f][:stored], opts[f][:stored]), (trial, w, h, kw, f)
+        seen += stored
+    assert seen > 5000
