@@ -462,3 +462,73 @@ def process_pairs(ctx, pairs, K, Kinv, rank=0, world=1, num_hypotheses=None, pos
     gathered = all_gather(local) if (all_gather is not None and world > 1) else local
     g = gathered.cpu().numpy().reshape(-1, RESULT_FLOATS + 1)
     return {int(r[28]): r[:RESULT_FLOATS].copy() for r in g if r[28] >= 0}
+
+
+def ring_pairs(num_views):
+    """Neighbouring views of a closed ring: (0,1), (1,2), ..., (V-1,0) -- BASELINE configs[4]."""
+    return [(i, (i + 1) % num_views) for i in range(num_views)] if num_views > 2 else [(0, 1)][:max(0, num_views - 1)]
+
+
+def view_slot(v, world, slots):
+    """Row of view v in the gathered feature tensor: rank v % world holds it in its local slot v // world."""
+    return (int(v) % int(world)) * int(slots) + int(v) // int(world)
+
+
+def process_views(ctx, images, K, Kinv, pairs=None, rank=0, world=1, max_pts=8192, sift=None, num_hypotheses=None,
+                  pose_mode=POSE_REFERENCE, gather_features=None, gather_results=None, device=None):
+    """Many-view front end of process_pairs: images -> ExtractSift per view (views round-robin over the ranks) ->
+    ONE exchange of fixed-size feature blocks -> per pair MatchSiftData + the two-view pipeline on the rank that
+    owns the pair -> ONE gather of fixed-size result records.
+
+    images: list of equally sized 2-D float32 arrays (grey values 0..255).  sift: dict of ExtractSift arguments
+    (num_octaves, init_blur, thresh, lowest_scale, scale_up).  gather_features(uint8 tensor [slots, max_pts*576 + 64])
+    and gather_results(float tensor) are all_gather_into_tensor wrappers (identity when world == 1).
+    Returns ({pair_id: record}, counts) with record = [E(9) | P(16) | pose index, inliers, best hypothesis] as in
+    process_pairs and counts = number of features of every view."""
+    import torch
+    dev = device if device is not None else torch.device("cuda", ctx.device)
+    sift = dict(sift or {})
+    V = len(images)
+    pairs = ring_pairs(V) if pairs is None else list(pairs)
+    h, w = images[0].shape
+    p = (w + 127) // 128 * 128
+    slots = (V + world - 1) // world
+    rec_bytes = max_pts * 576
+    block = torch.zeros((slots, rec_bytes + 64), dtype=torch.uint8, device=dev)       # records | int32 count in the tail
+    L = sift_temp_layout(w, h, sift.get("num_octaves", 5), sift.get("scale_up", False))
+    d_temp = torch.empty(L.total_floats, dtype=torch.float32, device=dev)
+    for slot, v in enumerate(range(rank, V, world)):
+        pad = np.zeros((h, p), np.float32)
+        pad[:, :w] = images[v]
+        d_img = torch.from_numpy(pad).to(dev)
+        n, _ = ctx.extract_sift(block[slot], max_pts, d_img, w, h, p, d_temp=d_temp, **sift)
+        block[slot, rec_bytes:rec_bytes + 4] = torch.from_numpy(np.array([n], np.int32).view(np.uint8)).to(dev)
+    feats = gather_features(block) if (gather_features is not None and world > 1) else block
+    feats = feats.reshape(-1, rec_bytes + 64)
+
+    def view(v):
+        row = feats[view_slot(v, world, slots)]
+        n = int(row[rec_bytes:rec_bytes + 4].cpu().numpy().view(np.int32)[0])
+        return row[:rec_bytes].reshape(max_pts, 576), n
+
+    counts = [view(v)[1] for v in range(V)]
+    matched = {}
+    for pid in pair_schedule(len(pairs), rank, world):
+        i, j = pairs[pid]
+        (s1, n1), (s2, n2) = view(i), view(j)
+        if n1 < 8 or n2 < 1:
+            continue
+        m = s1[:n1].clone()                                   # MatchSiftData writes score .. match_ypos into set 1
+        ctx.match(m, n1, s2, n2)
+        matched[pid] = (m, n1)
+    order = sorted(matched)
+    res = process_pairs(ctx, [matched[k] for k in order], K, Kinv, 0, 1, num_hypotheses, pose_mode, None, None)
+    max_local = (len(pairs) + world - 1) // world
+    rec = np.full((max_local, RESULT_FLOATS + 1), -1.0, np.float32)
+    for slot, pid in enumerate(order):
+        rec[slot, :RESULT_FLOATS] = res[slot]
+        rec[slot, RESULT_FLOATS] = pid
+    local = torch.from_numpy(rec).to(dev)
+    gathered = gather_results(local) if (gather_results is not None and world > 1) else local
+    g = gathered.cpu().numpy().reshape(-1, RESULT_FLOATS + 1)
+    return {int(r[RESULT_FLOATS]): r[:RESULT_FLOATS].copy() for r in g if r[RESULT_FLOATS] >= 0}, counts

@@ -79,3 +79,57 @@ def test_pairs_pipeline_on_gpu(gpu):
         r = res[i]
         assert same_bits(r[:9], Ec[hyp]) and same_bits(r[9:25], Pinv[ind].reshape(16))
         assert tuple(int(v) for v in r[25:28]) == (ind, cnt, hyp)
+
+
+def test_view_slots_cover_the_gathered_feature_tensor():
+    """process_views: views are extracted round-robin (rank r owns r, r + world, ...) into local slots; after the
+    all_gather (rank-major concatenation) every view must sit at view_slot() and nowhere else."""
+    import cuda_sfm_amd as S
+    for V in (1, 2, 5, 36, 37):
+        for world in (1, 2, 3, 8):
+            slots = (V + world - 1) // world
+            gathered = np.full(world * slots, -1)
+            for rank in range(world):
+                for slot, v in enumerate(range(rank, V, world)):
+                    gathered[rank * slots + slot] = v                     # what all_gather_into_tensor produces
+            for v in range(V):
+                assert gathered[S.view_slot(v, world, slots)] == v
+            assert sorted(x for x in gathered if x >= 0) == list(range(V))
+    assert S.ring_pairs(4) == [(0, 1), (1, 2), (2, 3), (3, 0)] and S.ring_pairs(2) == [(0, 1)] and S.ring_pairs(1) == []
+    assert len(S.ring_pairs(36)) == 36
+
+
+@pytest.mark.gpu
+def test_process_views_ring_from_images(gpu):
+    """BASELINE configs[4] from the image files on: 4 views of one scene (camera sliding along +x), ExtractSift per
+    view, ring pairs (0,1) (1,2) (2,3) (3,0), MatchSiftData + the two-view pipeline per pair -- every pair's E,
+    pose and support against the oracle chain run on the same images."""
+    import cuda_sfm_amd as S
+    import oracle as O
+    from cuda_sfm_amd_synth import synth
+    from helpers import same_bits
+    torch, dev, ctx = gpu
+    w, h = 512, 384
+    base_d = np.array([5.0, 8.0, 12.0, 16.0, 7.0, 10.0], np.float32)
+    views = [synth.stereo_pair(w, h, seed=9, disparities=tuple(k * base_d))[1] if k else synth.stereo_pair(w, h, seed=9)[0] for k in range(4)]
+    K, Kinv = synth.camera(w, h)
+    sift = dict(num_octaves=4, init_blur=1.0, thresh=2.0)
+    H = 512
+    res, counts = S.process_views(ctx, views, K, Kinv, max_pts=8192, sift=sift, num_hypotheses=H, pose_mode=S.POSE_CORRECT, device=dev)
+    assert sorted(res) == [0, 1, 2, 3]
+    feats = [O.extract_sift(v, 4, 1.0, 2.0, max_pts=8192) for v in views]
+    assert counts == [f[1] for f in feats] and min(counts) > 500
+    p = S.default_params(100)
+    for pid, (i, j) in enumerate(S.ring_pairs(4)):
+        m = O.match_sift(feats[i][0][:feats[i][1]].copy(), feats[j][0][:feats[j][1]])
+        _, _, X0, X1 = O.fill_xu(m, Kinv)
+        key, _, Ec = O.ransac_range(X0, X1, 0, H, p.threshold, p.jacobi_sweeps, seed=p.seed, want_E=True)
+        ocnt, ohyp = O.unpack_key(key)
+        r = res[pid]
+        assert same_bits(r[:9], Ec[ohyp]) and (int(r[26]), int(r[27])) == (ocnt, ohyp)
+        oP = O.pose_candidates(Ec[ohyp], S.POSE_CORRECT)
+        oind, _, _, _ = O.choose_pose(X0, X1, oP, S.POSE_CORRECT, 8)
+        assert int(r[25]) == oind and same_bits(r[9:25], oP[oind].reshape(16))
+        if pid < 3:                                               # neighbouring views: pure +x translation, no rotation
+            P = r[9:25].reshape(4, 4)
+            assert np.abs(P[:3, :3] - np.eye(3)).max() < 0.03 and abs(abs(P[0, 3]) - 1.0) < 0.03
