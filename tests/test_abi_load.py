@@ -55,3 +55,34 @@ def test_host_logic_keys_and_shards():
             for (b0, c0), (b1, _) in zip(parts, parts[1:]):
                 assert b0 + c0 == b1
             assert max(c for _, c in parts) - min(c for _, c in parts) <= 1
+
+
+def test_header_is_plain_c_and_links(tmp_path):
+    """include/sfm_amd.h is the drop-in boundary: it must compile as C99 without any HIP / C++ header and a
+    plain C program must link against libsfm_amd.so using nothing else (struct sizes as the reference's FFI expects)."""
+    import subprocess
+    src = tmp_path / "abi.c"
+    src.write_text(r'''
+#include <stdio.h>
+#include "sfm_amd.h"
+int main(void)
+{
+    sfm_ransac_params p;
+    sfm_sift_layout L;
+    sfm_ransac_default_params(&p, 4096);
+    if (sizeof(sfm_sift_point) != 576 || sizeof(p) != 56) return 2;
+    if (sfm_sift_temp_layout(1920, 1080, 5, 0, &L) != SFM_OK || L.width[4] != 120 || L.pitch[0] != 1920) return 3;
+    if (sfm_sift_temp_layout(0, 10, 5, 0, &L) != SFM_E_INVALID) return 4;
+    printf("%d %u %d %lld\n", sfm_abi_version(), p.num_hypotheses, p.jacobi_sweeps, (long long)L.total_floats);
+    return 0;
+}
+''')
+    exe = tmp_path / "abi"
+    lib = os.path.join(ROOT, "cuda-sfm_amd", "lib")
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+                        "-L", lib, "-lsfm_amd", f"-Wl,-rpath,{lib}", "-Wl,-rpath,/opt/rocm/lib"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
+    ver, hyps, sweeps, floats = r.stdout.split()
+    assert (int(ver), int(hyps), int(sweeps)) == (1, 512, 0) and int(floats) > 8 * 1920 * 1080
