@@ -111,9 +111,10 @@ def test_pyramid_and_dog_match_oracle(gpu, w, h, octaves):
     (320, 240, dict(num_octaves=3, init_blur=1.0, thresh=2.0, scale_up=True)),
     (400, 300, dict(num_octaves=5, init_blur=1.0, thresh=3.0, lowest_scale=2.5)),
     (130, 67, dict(num_octaves=1, init_blur=0.0, thresh=1.5)),
+    (1920, 1080, dict(num_octaves=5, init_blur=1.0, thresh=3.0)),       # the size of the reference's README table
 ])
 def test_extract_matches_oracle(gpu, w, h, kw):
-    img = synth.image(w, h, seed=21 + w, blobs=max(40, w * h // 800))
+    img = synth.image(w, h, seed=21 + w, blobs=min(2500, max(40, w * h // 800)))
     rec, n, stored, _, _ = run_product(gpu, img, **kw)
     opts, on, ostored = O.extract_sift(img, kw.get("num_octaves", 5), kw.get("init_blur", 1.0), kw.get("thresh", 3.0),
                                        kw.get("lowest_scale", 0.0), kw.get("scale_up", False))
