@@ -16,11 +16,15 @@
 #                       CudaSift/matching.cu InvertMatrix<8> + ComputeHomographies + TestHomographies
 #                       (:821-996, the FindHomography kernels), built with -ffp-contract=off;
 #                       CudaSift/cudaSiftD.cu ScaleDown (:84-169), ScaleUp (:171-194), LaplaceMultiMem
-#                       (:1753-1790), LowPassBlock (:1986-2038) + the ShiftDown template of cudautils.h,
+#                       (:1753-1790), LowPassBlock (:1986-2038), FindPointsMulti (:1433-1574, the detector the
+#                       reference launches when built with MANAGEDMEM, cudaSiftH.cu:508-510: the same tests
+#                       and sub-pixel refinement as the default FindPointsMultiNew, candidates compacted with
+#                       a shared-memory atomic instead of warp votes) + the shuffle templates of cudautils.h,
 #                       built with -ffp-contract=off (with "fast" the compiler fuses the same source
-#                       expression differently at different unroll sites).  The other live SIFT kernels
-#                       cannot be built for gfx950: FindPointsMultiNew needs __any_sync with a 32-bit
-#                       mask, ComputeOrientationsCONST / ExtractSiftDescriptorsCONSTNew need tex2D.
+#                       expression differently at different unroll sites) and correctly rounded division
+#                       (HIP's __fdividef is a plain '/').  Not buildable for gfx950: FindPointsMultiNew
+#                       (__any_sync with a 32-bit mask), ComputeOrientationsCONST /
+#                       ExtractSiftDescriptorsCONSTNew (tex2D).
 # Launch geometry in ref_driver_gpu.inc follows the reference's call sites (cited there).
 set -eu
 REF="${1:-/root/reference}"
@@ -76,13 +80,18 @@ sue=$(grep -n '^__global__ void ExtractSiftDescriptors(cudaTextureObject_t' "$D"
 lmb=$(grep -n '^__global__ void LaplaceMultiMem(float' "$D" | cut -d: -f1)
 lme=$(grep -n '^__global__ void LaplaceMultiMemWide(float' "$D" | cut -d: -f1)
 lpb=$(grep -n '^__global__ void LowPassBlock(float' "$D" | cut -d: -f1)
+fpb=$(grep -n '^__global__ void FindPointsMulti(float' "$D" | cut -d: -f1)
+fpe=$(grep -n '^__global__ void FindPointsMultiOld(float' "$D" | cut -d: -f1)
 shd=$(grep -n 'T ShiftDown(T var' "$U" | cut -d: -f1)
+she=$(grep -n '^#endif' "$U" | tail -1 | cut -d: -f1)
 {
   echo '#include <hip/hip_runtime.h>'
   echo "#include \"$REF/CudaSift/cudaSiftD.h\""                           # tile constants: the reference's own header
-  sed -n "$((shd - 1)),$((shd + 7))p" "$U"                                 # template ShiftDown (pre-CUDA-9 branch: __shfl_down)
+  echo "#include \"$REF/CudaSift/cudaSift.h\""                            # SiftPoint
+  sed -n "$((shd - 1)),$((she - 1))p" "$U"                                 # templates ShiftDown / ShiftUp / Shuffle (pre-CUDA-9 branch: __shfl_*)
   sed -n "${cb},${ce}p" "$D"                                              # __constant__ tables
   sed -n "${sdb},$((sue - 1))p" "$D"                                      # ScaleDown, ScaleUp
+  sed -n "${fpb},$((fpe - 1))p" "$D"                                      # FindPointsMulti (the MANAGEDMEM-path detector)
   sed -n "${lmb},$((lme - 1))p" "$D"                                      # LaplaceMultiMem
   sed -n "${lpb},\$p" "$D"                                                # LowPassBlock (to end of file)
   cat "$HERE/ref_driver_sift_gpu.inc"
@@ -92,6 +101,6 @@ HIPCC=/opt/rocm/bin/hipcc
 $HIPCC --offload-arch=gfx950 -O2 -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fPIC -w -c "$TMP/ref_kernels.hip" -o "$TMP/a.o"
 $HIPCC --offload-arch=gfx950 -O2 -ffp-contract=fast -fPIC -w -c "$TMP/ref_matchk.hip" -o "$TMP/b.o"
 $HIPCC --offload-arch=gfx950 -O2 -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -DOCML_BASIC_ROUNDED_OPERATIONS -fPIC -w -c "$TMP/ref_homo.hip" -o "$TMP/c.o"
-$HIPCC --offload-arch=gfx950 -O2 -ffp-contract=off -fPIC -w -c "$TMP/ref_sift.hip" -o "$TMP/d.o"
+$HIPCC --offload-arch=gfx950 -O2 -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fPIC -w -c "$TMP/ref_sift.hip" -o "$TMP/d.o"
 $HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT/libref_kernels.so" "$TMP/a.o" "$TMP/b.o" "$TMP/c.o" "$TMP/d.o"
 echo "ref_build_gpu: wrote $OUT/libref_kernels.so"

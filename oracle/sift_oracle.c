@@ -7,10 +7,15 @@
  *   - ScaleDown (:84-169), ScaleUp (:171-194), LowPassBlock (:1986-2038), LaplaceMultiMem (:1753-1790):
  *     bit-exact against the reference's own kernels compiled for gfx950 in place and run on the MI355X
  *     (oracle/ref_build_gpu.sh, tests/test_gpu_sift.py), both sides without FMA contraction.
- *   - FindPointsMultiNew (:1292-1430) uses __any_sync / 32-bit warp masks, ComputeOrientationsCONST
- *     (:972-1060) and ExtractSiftDescriptorsCONSTNew (:308-417) sample a CUDA texture: none of them
- *     can be built for gfx950 (no image instructions) -> PARITY UNPINNED for detection refinement,
- *     orientation and descriptor; restated from the source and checked through invariants.
+ *   - detection: FindPointsMultiNew (:1292-1430) needs __any_sync with a 32-bit mask and cannot be built for
+ *     gfx950, but FindPointsMulti (:1433-1574) -- the detector the reference launches when built with
+ *     MANAGEDMEM (cudaSiftH.cu:508-510): same extremum test, edge test, sub-pixel refinement and scale gate,
+ *     candidates compacted with a shared atomic instead of warp votes -- can.  Run on the MI355X it finds
+ *     exactly the points of orc_sift_find_points with xpos, ypos, sharpness, edgeness bit-identical and scale
+ *     within 4e-7 (device powf / exp2f against the table / polynomial used here).
+ *   - ComputeOrientationsCONST (:972-1060) and ExtractSiftDescriptorsCONSTNew (:308-417) sample a CUDA
+ *     texture; gfx950 has no image instructions -> PARITY UNPINNED for orientation and descriptor;
+ *     restated from the source and checked through invariants.
  *
  * Deliberate, documented differences from the reference:
  *   D1 texture fetch = exact binary32 bilinear interpolation (NVIDIA filters with 8-bit weights);

@@ -3,7 +3,7 @@
 CUDA kernels compiled for gfx950 from /root/reference in place (oracle/ref_build_gpu.sh ->
 oracle/_ref/libref_kernels.so, which travels with the snapshot) and run on the MI355X:
 
-  CudaSift/cudaSiftD.cu   LowPassBlock, ScaleDown, ScaleUp, LaplaceMultiMem       (-ffp-contract=off)
+  CudaSift/cudaSiftD.cu   LowPassBlock, ScaleDown, ScaleUp, LaplaceMultiMem, FindPointsMulti  (-ffp-contract=off)
   CudaSift/matching.cu    ComputeHomographies + InvertMatrix<8>, TestHomographies  (-ffp-contract=off)
 
     gpurun -- 'python tests/gen_golden_gpu.py gpurun_out/ref_gpu_kernels.npz'
@@ -74,6 +74,16 @@ def main(path):
         got = np.zeros((7, h, p), np.float32)
         assert R.refk_sift_laplace(fp(low), w, p, h, fp(got), octave, fp(kt)) == 0
         out[f"sift_dog_octave{octave}"] = got[:, :, :w].copy()
+
+    # FindPointsMulti (the MANAGEDMEM-path detector) on the octave-5 DoG stack
+    R.refk_sift_findpoints.argtypes = [f32p, i, i, i, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, i, i, C.c_void_p, C.POINTER(C.c_int)]
+    dogp = np.zeros((7, h, p), np.float32); dogp[:, :, :w] = out["sift_dog_octave5"]
+    rec = np.zeros(4096, O.SIFT_DTYPE); cnt = C.c_int(0)
+    assert R.refk_sift_findpoints(fp(dogp), w, p, h, 1.0, 0.0, 1.5, 0.2, 10.0, 5, 4096, rec.ctypes.data_as(C.c_void_p), C.byref(cnt)) == 0
+    rec = rec[:cnt.value]
+    rec = rec[np.lexsort((rec["scale"], rec["xpos"], rec["ypos"]))]          # the kernel appends in arbitrary order
+    out.update(find_thresh=np.float32(1.5), find_xpos=rec["xpos"].copy(), find_ypos=rec["ypos"].copy(), find_scale=rec["scale"].copy(),
+               find_sharpness=rec["sharpness"].copy(), find_edgeness=rec["edgeness"].copy())
 
     n, L = 256, 64
     s = synth.homography_scene(n, seed=5)["sift"]

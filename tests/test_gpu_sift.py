@@ -244,3 +244,33 @@ def test_randomised_configurations(gpu):
             assert same_bits(rec[f][:stored], opts[f][:stored]), (trial, w, h, kw, f)
         seen += stored
     assert seen > 5000
+
+
+@pytest.mark.parametrize("w,h,octave,thresh,lowest", [(640, 480, 5, 2.0, 0.0), (301, 203, 3, 1.0, 0.0), (200, 150, 5, 3.0, 1.3)])
+def test_oracle_detector_matches_reference_findpointsmulti(gpu, R, w, h, octave, thresh, lowest):
+    """FindPointsMulti (cudaSiftD.cu:1433-1574) is the detector the reference launches when it is built with
+    MANAGEDMEM (cudaSiftH.cu:508-510): the same extremum test, edge test and sub-pixel refinement as the default
+    FindPointsMultiNew -- which cannot be built for gfx950 -- compacting candidates with a shared atomic
+    instead of warp votes.  Run on the MI355X it must find exactly the oracle's points; every field but
+    `scale` (device powf / exp2f vs. the oracle's table / polynomial) bit for bit."""
+    R.refk_sift_findpoints.argtypes = [O.f32p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int,
+                                       C.c_int, C.c_void_p, C.POINTER(C.c_int)]
+    img = synth.image(w, h, seed=31 + w, blobs=max(60, w * h // 900))
+    low = O.sift_lowpass(img, O.sift_lowpass_taps(1.0))
+    kt, _ = O.sift_tables(5)
+    dog = O.sift_laplace(low, kt.reshape(8, 192)[octave][:128])
+    p = align(w)
+    dogp = np.zeros((7, h, p), np.float32); dogp[:, :, :w] = dog
+    max_pts = 32768
+    out = np.zeros(max_pts, O.SIFT_DTYPE); cnt = C.c_int(0)
+    sub = 2.0
+    assert R.refk_sift_findpoints(fp(dogp), w, p, h, sub, lowest / sub, thresh, 0.2, 10.0, octave, max_pts, out.ctypes.data_as(C.c_void_p), C.byref(cnt)) == 0
+    ref = out[:cnt.value]
+    opts, ocnt = O.sift_find_points(dog, sub, lowest / sub, thresh, max_pts)
+    assert cnt.value == ocnt and ocnt > 100
+    # the reference appends with atomicInc (arbitrary order): compare as sets keyed by the refined position
+    ro = np.lexsort((ref["scale"], ref["xpos"], ref["ypos"])); oo = np.lexsort((opts["scale"], opts["xpos"], opts["ypos"]))
+    ref, opts = ref[ro], opts[oo]
+    for f in ("xpos", "ypos", "sharpness", "edgeness", "subsampling"):
+        assert same_bits(ref[f], opts[f]), f
+    assert np.abs(ref["scale"] / opts["scale"] - 1.0).max() < 4e-7

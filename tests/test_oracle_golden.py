@@ -88,7 +88,7 @@ def test_e2e_regression_vectors():
 
 def test_reference_gpu_kernels_golden():
     """Outputs of the REFERENCE'S OWN CUDA kernels (cudaSiftD.cu LowPassBlock / ScaleDown / ScaleUp /
-    LaplaceMultiMem, matching.cu ComputeHomographies / TestHomographies) compiled for gfx950 in place and
+    LaplaceMultiMem / FindPointsMulti, matching.cu ComputeHomographies / TestHomographies) compiled for gfx950 in place and
     run on an MI355X (tests/gen_golden_gpu.py) -- the oracle reproduces them bit for bit on the CPU."""
     g = np.load(os.path.join(G, "ref_gpu_kernels.npz"))
     img = g["sift_image"]
@@ -102,6 +102,13 @@ def test_reference_gpu_kernels_golden():
     assert same_bits(O.sift_scaleup(img), g["sift_scaleup"])
     for octave in (5, 2):
         assert same_bits(O.sift_laplace(g["sift_lp10"], kt.reshape(8, 192)[octave][:128]), g[f"sift_dog_octave{octave}"])
+    # FindPointsMulti: same point set, fields bit for bit (scale: device powf / exp2f, 4e-7)
+    fpts, fcnt = O.sift_find_points(g["sift_dog_octave5"], 1.0, 0.0, float(g["find_thresh"]), 4096)
+    assert fcnt == len(g["find_xpos"]) and fcnt > 50
+    fpts = fpts[np.lexsort((fpts["scale"], fpts["xpos"], fpts["ypos"]))]
+    for f in ("xpos", "ypos", "sharpness", "edgeness"):
+        assert same_bits(fpts[f], g["find_" + f]), f
+    assert np.abs(fpts["scale"] / g["find_scale"] - 1.0).max() < 4e-7
     coord, pts = g["homo_coord"], g["homo_pts"]
     thr = np.float32(g["homo_thresh"])
     for l in range(pts.shape[1]):
