@@ -371,3 +371,38 @@ def test_orientation_and_descriptor_against_an_independent_float64_transcription
         worst_desc = max(worst_desc, np.abs(d64 - p["data"]).max())
         checked += 1
     assert checked > 300 and worst_ori < 1e-3 and worst_desc < 1e-4                # measured: 4.5e-5 degrees, 8.8e-6
+
+
+def test_features_are_repeatable_under_rotation_and_scale():
+    """End-to-end quality of the restated extractor + matcher: the same scene rotated by 25 degrees and scaled by 1.3.
+    Confident matches must land where the similarity transform says, with the matching change of keypoint scale and
+    orientation -- what makes the features usable for the two-view stage that follows."""
+    from scipy import ndimage
+    a = synth.image(360, 280, seed=77, blobs=140)
+    ang, sc = np.deg2rad(25.0), 1.3
+    c, s_ = np.cos(ang), np.sin(ang)
+    # output pixel (x', y') takes the value at A^-1 (x' - c') + c; forward map of a point p: p' = sc * R (p - ctr) + ctr'
+    ctr = np.array([180.0, 140.0]); ctr2 = np.array([260.0, 200.0])
+    Rf = sc * np.array([[c, -s_], [s_, c]])                       # (x, y) forward
+    Ainv = np.linalg.inv(Rf)
+    M = Ainv[::-1, ::-1]                                           # ndimage works in (row, col) = (y, x)
+    off = ctr[::-1] - M @ ctr2[::-1]
+    b = ndimage.affine_transform(a.astype(np.float64), M, offset=off, output_shape=(400, 520), order=1, mode="nearest").astype(np.float32)
+    pa, na, _ = O.extract_sift(a, 4, 1.0, 2.0)
+    pb, nb, _ = O.extract_sift(b, 4, 1.0, 2.0)
+    assert na > 300 and nb > 300
+    m = O.match_sift(pa[:na].copy(), pb[:nb])
+    good = (m["ambiguity"] < 0.9) & (m["score"] > 0.85)           # the synthetic scene repeats shapes: ambiguity is high
+    assert good.sum() > 300
+    src = np.stack([m["xpos"][good], m["ypos"][good]], 1).astype(np.float64)
+    pred = (Rf @ (src - ctr).T).T + ctr2
+    err = np.hypot(pred[:, 0] - m["match_xpos"][good], pred[:, 1] - m["match_ypos"][good])
+    assert (err < 2.5).mean() > 0.9, (err < 2.5).mean()
+    all_src = np.stack([m["xpos"], m["ypos"]], 1).astype(np.float64)
+    all_pred = (Rf @ (all_src - ctr).T).T + ctr2
+    assert (np.hypot(all_pred[:, 0] - m["match_xpos"], all_pred[:, 1] - m["match_ypos"]) < 2.5).mean() > 0.55   # even ungated
+    ok = np.flatnonzero(good)[err < 2.5]
+    ratio = pb["scale"][m["match"][ok]] / m["scale"][ok]
+    assert abs(np.median(ratio) - sc) < 0.12                        # keypoint scale follows the image scale
+    dori = ((pb["orientation"][m["match"][ok]] - m["orientation"][ok] - 25.0 + 180.0) % 360.0) - 180.0
+    assert np.abs(np.median(dori)) < 3.0 and (np.abs(dori) < 12.0).mean() > 0.8
