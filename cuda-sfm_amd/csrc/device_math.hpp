@@ -122,11 +122,17 @@ SFM_HD v2i ieq_t(v2i a, int b) { return a == v2i{ b, b }; }
 SFM_HD int isplat(int, int v) { return v; }
 SFM_HD v2i isplat(v2i, int v) { return v2i{ v, v }; }
 
-// "1.0 / sqrtf(x)": the header's double literal promotes the division (svd.h:129, :250).
-SFM_HD float rsqrt_f64div(float x) { return (float)(1.0 / (double)sqrtf(x)); }
+// "1.0 / sqrtf(x)": the header's double literal promotes the division (svd.h:129, :250), i.e. the reference
+// computes RN32(RN64(1 / s)) with s = sqrtf(x).  That equals the plain binary32 quotient RN32(1 / s): a double
+// rounding can only change the result when 1/s lies within 2^-53 (relative) of a midpoint m between two floats,
+// but m has a 25-bit odd significand and s a 24-bit one, so m*s is an integer multiple of a 49-bit grid and
+// either equals 1 (impossible: 1/s is then a float, not a midpoint) or differs from it by >= 2^-49 relative.
+// The oracle keeps the double path; tests/test_hostcheck.py and every GPU E-matrix test compare the two bit for bit.
+SFM_HD float rsqrt_f64div(float x) { return 1.0f / sqrtf(x); }
 SFM_HD v2f rsqrt_f64div(v2f x) { return v2f{ rsqrt_f64div(x.x), rsqrt_f64div(x.y) }; }
-// accurateSqrt: x * 1.0 / sqrtf(x) evaluated in double, NaN at 0 (svd.h:33-36)
-SFM_HD float accurate_sqrt(float x) { return (float)(((double)x * 1.0) / (double)sqrtf(x)); }
+// accurateSqrt: x * 1.0 / sqrtf(x) evaluated in double, NaN at 0 (svd.h:33-36).  Same argument: a midpoint m would
+// need m*s within 2^-53 of x, but m*s sits on a 49-bit grid and m (odd, 25 bits) cannot divide x (24 bits).
+SFM_HD float accurate_sqrt(float x) { return x / sqrtf(x); }
 SFM_HD v2f accurate_sqrt(v2f x) { return v2f{ accurate_sqrt(x.x), accurate_sqrt(x.y) }; }
 // "_gamma*sh*sh < ch*ch": left side in double, right side a float product widened (svd.h:128)
 SFM_HD bool gamma_test(float sh, float ch2) { return ((5.828427124746190 * (double)sh) * (double)sh) < (double)ch2; }

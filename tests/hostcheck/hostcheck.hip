@@ -96,4 +96,10 @@ int hc_sift_refine(const float *dog, int w, int h, int pd, int x, int y, int sca
     out[0] = q.xpos; out[1] = q.ypos; out[2] = q.scale; out[3] = q.sharpness; out[4] = q.edgeness;
     return 1;
 }
+
+// binary32 forms of the header's double-promoted "1.0/sqrtf(x)" and accurateSqrt (device_math.hpp)
+void hc_rsqrt_forms(const float *x, float *rs, float *as, int n)
+{
+    for (int i = 0; i < n; ++i) { rs[i] = sfm::rsqrt_f64div(x[i]); as[i] = sfm::accurate_sqrt(x[i]); }
+}
 }

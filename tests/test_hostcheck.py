@@ -146,3 +146,20 @@ def test_pose_and_4x4(H, scene):
         ref = O.triangulate(X0[:, h:h + 1], X1[:, h:h + 1], Pm, 8)[:, 0]
         assert same_bits(out, ref)
     assert H.hc_pack_key(C.c_uint32(7), C.c_uint32(3)) == O.pack_key(7, 3)
+
+
+def test_binary32_reciprocal_sqrt_equals_the_double_promoted_form(H):
+    """svd.h evaluates 1.0/sqrtf(x) and x*1.0/sqrtf(x) in double and rounds to float (svd.h:33-36, 129, 250).  The
+    product code uses plain binary32 division; a double rounding cannot change the result (device_math.hpp).  Checked
+    here on 4 million floats of every magnitude plus the special values."""
+    rng = np.random.default_rng(12)
+    bits = rng.integers(0, 0x7F800000, 4_000_000, dtype=np.uint32)            # every positive finite float is equally likely
+    x = np.concatenate([bits.view(np.float32), np.array([0.0, 1.0, 4.0, 2.0, 3.0, 1e-45, 1.17549435e-38, 3.4028235e38, np.inf, -1.0, np.nan], np.float32)])
+    rs = np.empty_like(x); acs = np.empty_like(x)
+    H.hc_rsqrt_forms(fp(x), fp(rs), fp(acs), len(x))
+    with np.errstate(all="ignore"):
+        s = np.sqrt(x).astype(np.float64)                                      # sqrtf: correctly rounded
+        want_rs = (1.0 / s).astype(np.float32)
+        want_as = ((x.astype(np.float64) * 1.0) / s).astype(np.float32)
+    assert same_bits(rs, want_rs)
+    assert same_bits(acs, want_as)
