@@ -8,7 +8,7 @@
 TAG=${1:-r01}
 R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_stats -o bench -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu --no-variants > $O/${TAG}_bench_prof.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_stats -o bench -- python3 $R/bench.py --steps 100 --warmup 20 --no-cpu --no-variants > $O/${TAG}_bench_prof.log 2>&1
 cp $O/${TAG}_stats/bench_kernel_stats.csv $O/${TAG}_bench_kernel_stats.csv
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/${TAG}_fetch -o p -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu --no-variants > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/${TAG}_write -o p -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu --no-variants > /dev/null 2>&1
