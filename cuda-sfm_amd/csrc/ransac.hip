@@ -73,45 +73,46 @@ void ransac_score_waves(const float *__restrict__ X0, const float *__restrict__ 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t nbatch = (count + WPB - 1) / WPB;
     unsigned long long wbest = 0;
-    bool staged = false;
     const ThrBand band = make_band(thr);
 
-    for (uint32_t batch = blockIdx.x; batch < nbatch; batch += gridDim.x) {
-        const uint32_t i = __builtin_amdgcn_readfirstlane(batch * WPB + wave);
-        const bool valid = i < count;
-        Ess E{};
-        if (valid) {
+    // Tile-outer order: a tile is staged ONCE per block and every hypothesis batch of the block runs over it before
+    // the next tile comes in (with more than one tile the per-hypothesis partial counts live in counts[]; a
+    // hypothesis is always scored by the same wavefront, lane 0 reads and writes its entry).
+    for (int t = 0; t < ntiles; ++t) {
+        if (t > 0) __syncthreads();                       // everyone done with the previous tile
+        if (threadIdx.x == 0) tile_bound = 0u;
+        __syncthreads();
+        const int first = t * tile;
+        const float big = stage_tile<UNITZ>(lds, X0, X1, ld, first, min(tile, ld - first));
+        atomicMax(&tile_bound, __float_as_uint(big));     // non-negative floats order like their bits
+        __syncthreads();
+        const int nv = min(tile, n - first);
+        const bool tame_tile = tile_bound < 0x47C35000u;  // 1e5f
+        for (uint32_t batch = blockIdx.x; batch < nbatch; batch += gridDim.x) {
+            const uint32_t i = __builtin_amdgcn_readfirstlane(batch * WPB + wave);
+            if (i >= count) continue;
             const float *e = Ecand + 9 * (size_t)i;
             auto sreg = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); };
-            E = Ess{ sreg(e[0]), sreg(e[1]), sreg(e[2]), sreg(e[3]), sreg(e[4]), sreg(e[5]), sreg(e[6]), sreg(e[7]), sreg(e[8]) };
-        }
-        // a normalised E has entries <= 1; anything else (degenerate sample -> NaN / inf) keeps the full range tracking
-        const bool e_tame = fabsf(E.e0) <= 2.0f && fabsf(E.e1) <= 2.0f && fabsf(E.e2) <= 2.0f && fabsf(E.e3) <= 2.0f && fabsf(E.e4) <= 2.0f &&
-                            fabsf(E.e5) <= 2.0f && fabsf(E.e6) <= 2.0f && fabsf(E.e7) <= 2.0f && fabsf(E.e8) <= 2.0f;
-        int cnt = 0;
-        for (int t = 0; t < ntiles; ++t) {
-            if (ntiles > 1 || !staged) {
-                if (staged) __syncthreads();                  // everyone done with the previous tile
-                if (threadIdx.x == 0) tile_bound = 0u;
-                __syncthreads();
-                const int first = t * tile;
-                const float big = stage_tile<UNITZ>(lds, X0, X1, ld, first, min(tile, ld - first));
-                atomicMax(&tile_bound, __float_as_uint(big));   // non-negative floats order like their bits
-                __syncthreads();
-                staged = true;
+            const Ess E{ sreg(e[0]), sreg(e[1]), sreg(e[2]), sreg(e[3]), sreg(e[4]), sreg(e[5]), sreg(e[6]), sreg(e[7]), sreg(e[8]) };
+            // a normalised E has entries <= 1; anything else (degenerate sample -> NaN / inf) keeps the full range tracking
+            const bool e_tame = fabsf(E.e0) <= 2.0f && fabsf(E.e1) <= 2.0f && fabsf(E.e2) <= 2.0f && fabsf(E.e3) <= 2.0f && fabsf(E.e4) <= 2.0f &&
+                                fabsf(E.e5) <= 2.0f && fabsf(E.e6) <= 2.0f && fabsf(E.e7) <= 2.0f && fabsf(E.e8) <= 2.0f;
+            int cnt = (e_tame && tame_tile) ? score_tile<UNITZ, false>(E, lds, nv, band, lane)
+                                            : score_tile<UNITZ, true>(E, lds, nv, band, lane);
+            if (ntiles > 1) {
+                int total = cnt;
+                if (lane == 0) {
+                    if (t > 0) total += counts[i];
+                    counts[i] = total;
+                }
+                cnt = __builtin_amdgcn_readfirstlane(total);
+            } else if (lane == 0) {
+                counts[i] = cnt;
             }
-            if (valid) {
-                const int nv = min(tile, n - t * tile);
-                if (e_tame && tile_bound < 0x47C35000u)       // 1e5f
-                    cnt += score_tile<UNITZ, false>(E, lds, nv, band, lane);
-                else
-                    cnt += score_tile<UNITZ, true>(E, lds, nv, band, lane);
+            if (t == ntiles - 1) {
+                const unsigned long long key = pack_key((uint32_t)cnt, h0 + i);
+                wbest = key > wbest ? key : wbest;
             }
-        }
-        if (valid) {
-            if (lane == 0) counts[i] = cnt;
-            const unsigned long long key = pack_key((uint32_t)cnt, h0 + i);
-            wbest = key > wbest ? key : wbest;
         }
     }
     // one atomic per block (first-maximum tie rule is encoded in the key)
