@@ -400,14 +400,23 @@ void sift_orient_kernel(const float *__restrict__ temp, Levels L, Workspace W)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float *gauss = lds[wave], *hist = gauss + 16;
     float2 *smp = samples[wave];                       // (bin as float bits, weight)
-    const unsigned int gw = blockIdx.x * 4 + wave, nw = gridDim.x * 4;
-    for (int lvl = 0; lvl < L.n; ++lvl) {
-        const unsigned int kept = W.state[lvl].kept;
-        const float *__restrict__ img = temp + L.img[lvl];
-        const int w = L.w[lvl], h = L.h[lvl], pitch = L.p[lvl];
-        Cand *stash = W.stash + (size_t)lvl * W.cap;
-        const unsigned int *offs = W.segs + L.seg0[lvl];
-        for (unsigned int c = gw; c < kept; c += nw) {
+    // the candidates of all levels form ONE list (level 0 first) dealt round-robin to the wavefronts: a per-level
+    // loop would hand the first candidates of every level to the same low-numbered wavefronts
+    const unsigned int gw = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(wave), nw = gridDim.x * 4;
+    unsigned int cum[9];
+    cum[0] = 0;
+    for (int l = 0; l < 8; ++l) cum[l + 1] = cum[l] + (l < L.n ? W.state[l].kept : 0u);
+    {
+        for (unsigned int g = gw; g < cum[8]; g += nw) {
+            int lvl = 0;
+            unsigned int first = 0;
+#pragma unroll
+            for (int l = 1; l < 8; ++l) { const bool ge = g >= cum[l]; lvl += ge ? 1 : 0; first = ge ? cum[l] : first; }
+            const unsigned int c = g - first;
+            const float *__restrict__ img = temp + L.img[lvl];
+            const int w = L.w[lvl], h = L.h[lvl], pitch = L.p[lvl];
+            Cand *stash = W.stash + (size_t)lvl * W.cap;
+            const unsigned int *offs = W.segs + L.seg0[lvl];
             const float xpos = stash[c].x, ypos = stash[c].y, scale = stash[c].scale;
             const float i2sigma2 = -1.0f / (2.0f * 1.5f * 1.5f * scale * scale);
             if (lane < 11) gauss[lane] = exp_poly(i2sigma2 * (float)(lane - 5) * (float)(lane - 5));
@@ -630,7 +639,7 @@ __device__ __forceinline__ void describe_and_store(const float *__restrict__ img
     wave_phase();
 }
 
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(256, 4)
 void sift_desc_kernel(const float *__restrict__ temp, Levels L, Workspace W, sfm_sift_point *__restrict__ sift, int max_pts, int scale_up)
 {
     constexpr int kWaveLds = (kPatchMax * kPatchMax + 3) / 4 > 256 ? (kPatchMax * kPatchMax + 3) / 4 : 256;   // float4 units
@@ -656,18 +665,27 @@ void sift_desc_kernel(const float *__restrict__ temp, Levels L, Workspace W, sfm
         wxk[k] = (hori == hcell) ? 1.0f - horf : ((hori + 1 == hcell) ? horf : 0.0f);
     }
     const int s0 = ys * 16 + xs;
-    const unsigned int gw = blockIdx.x * 4 + wave, nw = gridDim.x * 4;
-    unsigned int bases[8], rep, sto;
+    const unsigned int gw = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(wave), nw = gridDim.x * 4;
+    unsigned int bases[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, rep, sto;
     level_bases(W.state, L.n, bases, rep, sto);
     const unsigned int reported = min(rep, (unsigned int)max_pts);
-    for (int lvl = 0; lvl < L.n; ++lvl) {
-        const unsigned int kept = W.state[lvl].kept, base = bases[lvl], found = W.state[lvl].found;
-        const float *__restrict__ img = temp + L.img[lvl];
-        const int w = L.w[lvl], h = L.h[lvl], pitch = L.p[lvl];
-        const Cand *stash = W.stash + (size_t)lvl * W.cap;
-        const unsigned int *pre = W.dupprefix + (size_t)lvl * W.cap;
-        const float subsampling = (float)(1 << lvl);
-        for (unsigned int ci = gw; ci < kept; ci += nw) {
+    // one list over all levels, dealt round-robin to the wavefronts (see sift_orient_kernel)
+    unsigned int cum[9];
+    cum[0] = 0;
+    for (int l = 0; l < 8; ++l) cum[l + 1] = cum[l] + (l < L.n ? W.state[l].kept : 0u);
+    {
+        for (unsigned int g = gw; g < cum[8]; g += nw) {
+            int lvl = 0;
+            unsigned int first = 0, base = bases[0];
+#pragma unroll
+            for (int l = 1; l < 8; ++l) { const bool ge = g >= cum[l]; lvl += ge ? 1 : 0; first = ge ? cum[l] : first; base = ge ? bases[l] : base; }
+            const unsigned int ci = g - first;
+            const unsigned int found = W.state[lvl].found;
+            const float *__restrict__ img = temp + L.img[lvl];
+            const int w = L.w[lvl], h = L.h[lvl], pitch = L.p[lvl];
+            const Cand *stash = W.stash + (size_t)lvl * W.cap;
+            const unsigned int *pre = W.dupprefix + (size_t)lvl * W.cap;
+            const float subsampling = (float)(1 << lvl);
             const Cand c = stash[ci];
             const unsigned int slot = base + c.rank;
             const unsigned int slot2 = c.has2 ? base + found + pre[c.rank] : 0xFFFFFFFFu;
@@ -684,12 +702,14 @@ void sift_desc_kernel(const float *__restrict__ temp, Levels L, Workspace W, sfm
                 if (dst >= (unsigned int)max_pts) continue;
                 P.p = nullptr;
                 if (P.side <= kPatchMax) {                                    // staged again for the second orientation: the samples overwrote it
-                    for (int j0 = 0; j0 < P.side; j0 += 4) {
-                        float v[4];
+                    // kStageRows rows in flight per round trip to memory: the footprint arrives in at most two
+                    constexpr int kStageRows = 20;
+                    for (int j0 = 0; j0 < P.side; j0 += kStageRows) {
+                        float v[kStageRows];
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) v[u] = img[(size_t)clampi(P.oy + min(j0 + u, P.side - 1), 0, h - 1) * pitch + col];
+                        for (int u = 0; u < kStageRows; ++u) v[u] = img[(size_t)clampi(P.oy + min(j0 + u, P.side - 1), 0, h - 1) * pitch + col];
 #pragma unroll
-                        for (int u = 0; u < 4; ++u)
+                        for (int u = 0; u < kStageRows; ++u)
                             if (lane < P.side && j0 + u < P.side) fp_lds[(j0 + u) * P.side + lane] = v[u];
                     }
                     P.p = fp_lds;
