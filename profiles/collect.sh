@@ -27,3 +27,4 @@ python3 $R/profiles/pmc_summary.py $O/${TAG}_fetch $O/${TAG}_write > $O/${TAG}_t
 python3 $R/profiles/pmc_summary.py $O/${TAG}_mfetch $O/${TAG}_mwrite $O/${TAG}_mpmc > $O/${TAG}_traffic_match.txt
 cd $R && sh profiles/pmc_ransac.sh $TAG > /dev/null 2>&1
 cat $O/${TAG}_bench_kernel_stats.csv | head -8; cat $O/${TAG}_traffic_bench.txt | head -30; cat $O/${TAG}_match_kernel_stats.csv | head -5; cat $O/${TAG}_traffic_match.txt; cat $O/${TAG}_sift_kernel_stats.csv | head -12; cat $O/${TAG}_traffic_sift.txt | head -30
+python3 $R/profiles/sift_timeline.py $O/${TAG}_sstats/sift_kernel_trace.csv > $O/${TAG}_sift_timeline_1080p.json
