@@ -577,7 +577,7 @@ __device__ __forceinline__ bool sample_grid(const float *__restrict__ img, int p
 
 __device__ __forceinline__ void describe_and_store(const float *__restrict__ img, int pitch, int w, int h, const Patch &P, const Cand &c, float orientation,
                                                    float subsampling, float rescale, sfm_sift_point *__restrict__ out, const float *gauss,
-                                                   float4 *smp, const float (&wyk)[8], const float (&wxk)[8], int s0, int lane)
+                                                   float4 *smp, float *part, int lane)
 {
     const float px = c.x, py = c.y;
     const float theta = 2.0f * 3.1415f / 360.0f * orientation;
@@ -592,41 +592,53 @@ __device__ __forceinline__ void describe_and_store(const float *__restrict__ img
     wave_phase();                                                            // the samples overwrite the footprint they were read from
 #pragma unroll
     for (int r = 0; r < 4; ++r) smp[lane + 64 * r] = mine[r];
-    wave_phase();
-    // lane = (cell, a0): bins (cell, a0) and (cell, a0 + 4) share one pass over the cell's 8 x 8 samples,
-    // each bin still summed in sample order
-    const int cell = lane >> 2, a0 = lane & 3;
-    float acc0 = 0.0f, acc1 = 0.0f;
-    // 8 x 8 window of the cell, fully unrolled: constant LDS offsets, weights from registers; samples outside the
-    // cell's support carry weight 0 and add an exact +0
+    // Histogram (D3): every bin is the sum over the sample columns tx (ascending) of that column's partial sum over the
+    // rows y (ascending).  Two passes of 8 cells; in a pass lane = (cell, column kx of the cell's 8 x 8 window) scatters its
+    // 8 samples into 8 private bins in LDS (9-float stride), then lane = (cell, angle) adds the 8 column partials.
+    // After both passes a lane holds bins `lane` and `64 + lane` -- the reference's own thread <-> bin layout.
+    float bin[2];
+    float *own = part + 9 * lane;
 #pragma unroll
-    for (int ky = 0; ky < 8; ++ky) {
+    for (int pass = 0; pass < 2; ++pass) {
+        const int cell = 8 * pass + (lane >> 3), kx = lane & 7;
+        const int vcell = cell >> 2, hcell = cell & 3;
+        const int ys = clampi(4 * vcell - 2, 0, 8), tx = clampi(4 * hcell - 2, 0, 8) + kx;
+        const int hori = (tx + 2) / 4 - 1;
+        const float horf = ((float)tx - 1.5f) / 4.0f - (float)hori;
+        const float wx = (hori == hcell) ? 1.0f - horf : ((hori + 1 == hcell) ? horf : 0.0f);     // cudaSiftD.cu:345-383
 #pragma unroll
-        for (int kx = 0; kx < 8; ++kx) {
-            const float4 v = smp[s0 + ky * 16 + kx];
+        for (int a = 0; a < 8; ++a) own[a] = 0.0f;
+        wave_phase();                                                        // samples visible; the previous pass is done with `part`
+#pragma unroll
+        for (int ky = 0; ky < 8; ++ky) {
+            const int y = ys + ky, veri = (y + 2) / 4 - 1;
+            const float verf = ((float)y - 1.5f) / 4.0f - (float)veri;
+            const float wy = (veri == vcell) ? 1.0f - verf : ((veri + 1 == vcell) ? verf : 0.0f);
+            const float4 v = smp[y * 16 + tx];
             const int angi = __float_as_int(v.z), angp = (angi + 1) & 7;
-            const float grad2 = wyk[ky] * (wxk[kx] * v.x);
-            const float lo = (1.0f - v.y) * grad2, hi = v.y * grad2;
-            acc0 += (angi == a0) ? lo : ((angp == a0) ? hi : 0.0f);
-            acc1 += (angi == a0 + 4) ? lo : ((angp == a0 + 4) ? hi : 0.0f);
+            const float grad2 = wy * (wx * v.x);
+            own[angi] += (1.0f - v.y) * grad2;                               // weight-0 samples add an exact +0
+            own[angp] += v.y * grad2;
         }
+        wave_phase();
+        float acc = 0.0f;
+        const float *colp = part + 9 * (lane & ~7) + (lane & 7);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc += colp[9 * k];
+        bin[pass] = acc;
     }
-    // two normalisations with the 0.2 clip in between.  The reference reduces bins 32k..32k+31 with the
-    // shuffle tree i + 16, + 8, + 4, + 2, + 1; in this layout those partners are lane + 8, lane + 4 (cells),
-    // the lane's own second bin (angle + 4), lane + 2, lane + 1 (angles): same additions, same order.
+    // two normalisations with the 0.2 clip in between: the reference's shuffle tree (ShiftDown 16, 8, 4, 2, 1 inside each
+    // group of 32 bins; lanes 0 and 32 end with the group sums), then sums[0] + sums[1] + sums[2] + sums[3]
     auto tree = [&](float v0, float v1) {
-        v0 += __shfl_down(v0, 8); v1 += __shfl_down(v1, 8);
-        v0 += __shfl_down(v0, 4); v1 += __shfl_down(v1, 4);
-        float t = v0 + v1;
-        t += __shfl_down(t, 2);
-        t += __shfl_down(t, 1);
-        return __shfl(t, 0) + __shfl(t, 16) + __shfl(t, 32) + __shfl(t, 48);
+#pragma unroll
+        for (int d = 16; d > 0; d >>= 1) { v0 += __shfl_down(v0, d); v1 += __shfl_down(v1, d); }
+        return ((__shfl(v0, 0) + __shfl(v0, 32)) + __shfl(v1, 0)) + __shfl(v1, 32);
     };
-    const float r1 = 1.0f / sqrtf(tree(acc0 * acc0, acc1 * acc1));
-    const float t0 = fminf(acc0 * r1, 0.2f), t1 = fminf(acc1 * r1, 0.2f);
+    const float r1 = 1.0f / sqrtf(tree(bin[0] * bin[0], bin[1] * bin[1]));
+    const float t0 = fminf(bin[0] * r1, 0.2f), t1 = fminf(bin[1] * r1, 0.2f);
     const float r2 = 1.0f / sqrtf(tree(t0 * t0, t1 * t1));
-    out->data[cell * 8 + a0] = t0 * r2;
-    out->data[cell * 8 + a0 + 4] = t1 * r2;
+    out->data[lane] = t0 * r2;
+    out->data[64 + lane] = t1 * r2;
     if (lane == 0) {
         out->xpos = (px * subsampling) * rescale;        // :412-414, then RescalePositions (:753-761) when scaleUp
         out->ypos = (py * subsampling) * rescale;
@@ -639,32 +651,19 @@ __device__ __forceinline__ void describe_and_store(const float *__restrict__ img
     wave_phase();
 }
 
-__global__ __launch_bounds__(256, 4)
+__global__ __launch_bounds__(256)
 void sift_desc_kernel(const float *__restrict__ temp, Levels L, Workspace W, sfm_sift_point *__restrict__ sift, int max_pts, int scale_up)
 {
     constexpr int kWaveLds = (kPatchMax * kPatchMax + 3) / 4 > 256 ? (kPatchMax * kPatchMax + 3) / 4 : 256;   // float4 units
     __shared__ float4 scratch[4][kWaveLds];           // per wavefront: the staged footprint, then (aliased) the 256 samples
     __shared__ float gtab[4][16];
+    __shared__ float partial[4][9 * 64];             // per wavefront: 64 x 8 private histogram bins, 9-float stride
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float *gauss = gtab[wave];
     float4 *smp = scratch[wave];
     float *fp_lds = reinterpret_cast<float *>(scratch[wave]);
     if (lane < 16) gauss[lane] = exp_poly(-((float)lane - 7.5f) * ((float)lane - 7.5f) / 128.0f);
     wave_phase();
-    // this lane's histogram cell and the trilinear weights of its 8 x 8 sample window (cudaSiftD.cu:345-383)
-    const int vcell = lane >> 4, hcell = (lane >> 2) & 3;
-    const int ys = clampi(4 * vcell - 2, 0, 8), xs = clampi(4 * hcell - 2, 0, 8);
-    float wyk[8], wxk[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const int y = ys + k, veri = (y + 2) / 4 - 1;
-        const float verf = ((float)y - 1.5f) / 4.0f - (float)veri;
-        wyk[k] = (veri == vcell) ? 1.0f - verf : ((veri + 1 == vcell) ? verf : 0.0f);
-        const int tx = xs + k, hori = (tx + 2) / 4 - 1;
-        const float horf = ((float)tx - 1.5f) / 4.0f - (float)hori;
-        wxk[k] = (hori == hcell) ? 1.0f - horf : ((hori + 1 == hcell) ? horf : 0.0f);
-    }
-    const int s0 = ys * 16 + xs;
     const unsigned int gw = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(wave), nw = gridDim.x * 4;
     unsigned int bases[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, rep, sto;
     level_bases(W.state, L.n, bases, rep, sto);
@@ -708,15 +707,17 @@ void sift_desc_kernel(const float *__restrict__ temp, Levels L, Workspace W, sfm
                         float v[kStageRows];
 #pragma unroll
                         for (int u = 0; u < kStageRows; ++u) v[u] = img[(size_t)clampi(P.oy + min(j0 + u, P.side - 1), 0, h - 1) * pitch + col];
+                        if (lane < P.side) {
 #pragma unroll
-                        for (int u = 0; u < kStageRows; ++u)
-                            if (lane < P.side && j0 + u < P.side) fp_lds[(j0 + u) * P.side + lane] = v[u];
+                            for (int u = 0; u < kStageRows; ++u)
+                                if (j0 + u < P.side) fp_lds[(j0 + u) * P.side + lane] = v[u];      // wave-uniform test
+                        }
                     }
                     P.p = fp_lds;
                     wave_phase();
                 }
                 describe_and_store(img, pitch, w, h, P, c, k == 0 ? c.ori1 : c.ori2, subsampling, (scale_up && dst < reported) ? 0.5f : 1.0f, &sift[dst],
-                                   gauss, smp, wyk, wxk, s0, lane);
+                                   gauss, smp, partial[wave], lane);
             }
         }
     }

@@ -21,7 +21,9 @@
  *   D1 texture fetch = exact binary32 bilinear interpolation (NVIDIA filters with 8-bit weights);
  *   D2 exp / exp2 / sin / cos / atan2 / rsqrt = the polynomial forms below (the reference uses the SFU
  *      intrinsics __expf, __sinf, __cosf, rsqrtf, __fdividef, whose bits are not reproducible);
- *   D3 histogram sums run in sample order (the reference uses shared-memory atomicAdd, order undefined);
+ *   D3 histogram sums have a fixed order (the reference uses shared-memory atomicAdd, order undefined): the 32
+ *      orientation bins in sample order; a descriptor bin = the partial sums of the 16 sample columns (each over
+ *      its rows, ascending) added in column order;
  *   D4 points of an octave are emitted in (y, x, scale) order, secondary orientations after them in
  *      the order of their parents (the reference uses atomicInc, order undefined);
  *   D5 descriptor angle bin 8 (angle == pi) wraps to bin 0 of the same cell (the reference spills it
@@ -412,8 +414,10 @@ void orc_sift_descriptor(const float *img, int w, int h, int pitch, float xpos, 
     orc_sift_sincosf(theta, &sina, &cosa);
     float scale = 12.0f / 16.0f * scale_in;
     float ssina = scale * sina, scosa = scale * cosa;
-    for (int y = 0; y < 16; ++y)
-        for (int tx = 0; tx < 16; ++tx) {
+    for (int tx = 0; tx < 16; ++tx) {                       /* D3: column partial sums, then the columns in order */
+        float col[128];
+        for (int i = 0; i < 128; ++i) col[i] = 0.0f;
+        for (int y = 0; y < 16; ++y) {
             float fx = (float)tx - 7.5f, fy = (float)y - 7.5f;
             float xs = xpos + fx * scosa - fy * ssina + 0.5f;
             float ys = ypos + fx * ssina + fy * scosa + 0.5f;
@@ -434,15 +438,17 @@ void orc_sift_descriptor(const float *img, int w, int h, int pitch, float xpos, 
             int p1 = angi + hist, p2 = angp + hist;
             if (tx >= 2) {
                 float grad1 = ihorf * grad;
-                if (y >= 2)  { float g2 = iverf * grad1; buffer[p1] += iangf * g2;      buffer[p2] += angf * g2; }
-                if (y <= 13) { float g2 = verf * grad1;  buffer[p1 + 32] += iangf * g2; buffer[p2 + 32] += angf * g2; }
+                if (y >= 2)  { float g2 = iverf * grad1; col[p1] += iangf * g2;      col[p2] += angf * g2; }
+                if (y <= 13) { float g2 = verf * grad1;  col[p1 + 32] += iangf * g2; col[p2 + 32] += angf * g2; }
             }
             if (tx <= 13) {
                 float grad1 = horf * grad;
-                if (y >= 2)  { float g2 = iverf * grad1; buffer[p1 + 8] += iangf * g2;  buffer[p2 + 8] += angf * g2; }
-                if (y <= 13) { float g2 = verf * grad1;  buffer[p1 + 40] += iangf * g2; buffer[p2 + 40] += angf * g2; }
+                if (y >= 2)  { float g2 = iverf * grad1; col[p1 + 8] += iangf * g2;  col[p2 + 8] += angf * g2; }
+                if (y <= 13) { float g2 = verf * grad1;  col[p1 + 40] += iangf * g2; col[p2 + 40] += angf * g2; }
             }
         }
+        for (int i = 0; i < 128; ++i) buffer[i] += col[i];
+    }
     float sq[128], sums[4], t1[128];
     for (int i = 0; i < 128; ++i) sq[i] = buffer[i] * buffer[i];
     for (int k = 0; k < 4; ++k) sums[k] = tree32(sq + 32 * k);
