@@ -1,0 +1,153 @@
+"""Time-budgeted randomised parity run on the GPU (not collected by pytest: run it by hand on the GPU box).
+
+    python tests/fuzz_gpu.py [seconds] [seed]
+
+Every round draws a random configuration of one of the product paths (RANSAC in all kernel families and both
+null-vector solvers, with ordinary, degenerate, generic-z and huge-coordinate point sets; the matcher; the
+homography search; SIFT extraction), runs it through the C ABI and compares with the CPU oracle bit for bit.
+Prints one JSON line with the number of rounds per path and every mismatch (configuration included).
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    import torch
+    import cuda_sfm_amd as S
+    from cuda_sfm_amd import synth
+    import oracle as O
+    from helpers import same_bits, to_dev
+
+    assert torch.cuda.is_available()
+    dev = torch.device("cuda", 0)
+    ctx = S.Context(0, torch.cuda.current_stream().cuda_stream)
+    rng = np.random.default_rng(seed)
+    rounds = {"ransac": 0, "match": 0, "homography": 0, "sift": 0}
+    bad = []
+
+    def ransac_round():
+        n = int(rng.choice([rng.integers(8, 200), rng.integers(200, 3000), rng.integers(3000, 9000)]))
+        H = int(rng.choice([rng.integers(1, 64), rng.integers(64, 1500), rng.integers(1500, 6000)]))
+        kernel = int(rng.choice([S.KERNEL_AUTO, S.KERNEL_SPLIT, S.KERNEL_FUSED, S.KERNEL_MFMA]))
+        sweeps = int(rng.choice([0, 0, 7, 3]))
+        thr = float(np.float32(10.0 ** rng.uniform(-9, -2)))
+        flavour = str(rng.choice(["plain", "plain", "clean", "dup", "epipole", "genericz", "huge", "nan"]))
+        sseed = int(rng.integers(1, 1 << 30))
+        scene = synth.two_view_scene(n, seed=sseed, noise_px=float(rng.choice([0.0, 0.3, 2.0])),
+                                     outlier_frac=float(rng.choice([0.0, 0.3, 0.8])) if flavour != "clean" else 0.0)
+        cfg = dict(path="ransac", n=n, H=H, kernel=kernel, sweeps=sweeps, thr=thr, flavour=flavour, scene_seed=sseed)
+        sift = scene["sift"]
+        if flavour == "dup":                          # repeated correspondences -> rank-deficient samples
+            k = int(rng.integers(1, max(2, n // 2)))
+            src = rng.integers(0, n, k); dst = rng.integers(0, n, k)
+            for f in ("xpos", "ypos", "match_xpos", "match_ypos"):
+                sift[f][dst] = sift[f][src]
+        if flavour == "nan":
+            sift["xpos"][rng.integers(0, n, max(1, n // 50))] = np.nan
+        _, _, X0, X1 = O.fill_xu(sift, scene["Kinv"])
+        pair = S.ImagePair(ctx, scene["K"], scene["Kinv"], 2, n)
+        if flavour in ("genericz", "huge", "epipole"):
+            X0 = X0.copy(); X1 = X1.copy()
+            if flavour == "genericz":
+                X0 *= (0.5 + synth.uniform01(sseed, n)).astype(np.float32); X1 *= (2.0 - synth.uniform01(sseed + 1, n)).astype(np.float32)
+            elif flavour == "huge":
+                sc = np.float32(10.0 ** rng.uniform(2, 9)); X0 *= sc; X1 *= sc
+                cfg["scale"] = float(sc)
+            else:                                     # many points exactly on one spot of image 2 (a likely epipole of bad hypotheses)
+                idx = rng.integers(0, n, max(1, n // 10)); X1[0, idx] = X1[0, idx[0]]; X1[1, idx] = X1[1, idx[0]]
+            X0 = np.ascontiguousarray(X0, np.float32); X1 = np.ascontiguousarray(X1, np.float32)
+            pair.set_points(to_dev(torch, dev, X0), to_dev(torch, dev, X1))
+        else:
+            pair.fillXU(to_dev(torch, dev, sift))
+        p = S.default_params(n, num_hypotheses=H, seed=sseed & 0xFFFF, kernel=kernel, jacobi_sweeps=sweeps, threshold=thr)
+        pair.estimateE(p)
+        key, ocounts, oE = O.ransac_range(X0, X1, 0, H, p.threshold, p.jacobi_sweeps, seed=p.seed, want_E=True)
+        ok = np.array_equal(pair.get_inlier_counts(H), ocounts) and pair.get_key() == key and same_bits(pair.get_E_candidates(H), oE)
+        if ok:
+            ocnt, ohyp = O.unpack_key(key)
+            _, omask = O.count_inliers(oE[ohyp], X0, X1, p.threshold)
+            ok = np.array_equal(pair.get_inlier_mask(), omask) and same_bits(pair.get_E(), oE[ohyp].reshape(3, 3))
+        return ok, cfg
+
+    def match_round():
+        n1 = int(rng.choice([rng.integers(1, 100), rng.integers(100, 3000)])); n2 = int(rng.choice([rng.integers(1, 100), rng.integers(100, 3000)]))
+        sseed = int(rng.integers(1, 1 << 30))
+        d = synth.descriptors(max(n1, n2), seed=sseed, noise=float(rng.choice([0.0, 0.05, 0.3])), sparsity=float(rng.choice([0.0, 0.7])))
+        d1 = np.ascontiguousarray(d[0][:n1]); d2 = np.ascontiguousarray(d[1][:n2]).copy()
+        if rng.random() < 0.3 and n2 > 4:             # exact duplicates in the database: tie rule
+            d2[rng.integers(0, n2, n2 // 4)] = d2[rng.integers(0, n2, n2 // 4)]
+        t1, t2 = to_dev(torch, dev, d1), to_dev(torch, dev, d2)
+        best = torch.empty(n1, dtype=torch.float32, device=dev); sec = torch.empty(n1, dtype=torch.float32, device=dev)
+        idx = torch.empty(n1, dtype=torch.int32, device=dev)
+        ctx.match_soa(t1, n1, 128, t2, n2, 128, best, sec, idx)
+        torch.cuda.synchronize()
+        ob, os_, oi = O.match_desc(d1, d2)
+        ok = np.array_equal(idx.cpu().numpy(), oi) and same_bits(best.cpu().numpy(), ob) and same_bits(sec.cpu().numpy(), os_)
+        return ok, dict(path="match", n1=n1, n2=n2, seed=sseed)
+
+    def homography_round():
+        n = int(rng.integers(8, 4000)); L = int(rng.choice([rng.integers(1, 100), rng.integers(100, 4000)]))
+        sseed = int(rng.integers(1, 1 << 30))
+        sc = synth.homography_scene(n, seed=sseed, noise_px=float(rng.choice([0.0, 0.7, 3.0])), outlier_frac=float(rng.choice([0.0, 0.35, 0.9])))
+        thr = float(rng.choice([1.0, 5.0, 25.0])); hs = int(rng.integers(0, 1 << 30))
+        ms, ma = float(rng.choice([0.0, 0.85])), float(rng.choice([1.0, 0.95]))
+        H, nm = ctx.find_homography(to_dev(torch, dev, sc["sift"]), n, num_loops=L, min_score=ms, max_ambiguity=ma, thresh=thr, seed=hs)
+        oH, onm = O.find_homography(sc["sift"], L, ms, ma, thr, hs)
+        return (nm == onm and same_bits(H, oH)), dict(path="homography", n=n, loops=L, thr=thr, seed=sseed, hseed=hs, min_score=ms, max_ambiguity=ma)
+
+    def sift_round():
+        w = int(rng.integers(24, 700)); h = int(rng.integers(24, 500))
+        octaves = int(rng.integers(1, 6)); up = bool(rng.random() < 0.2)
+        thresh = float(rng.choice([1.0, 2.0, 3.5, 6.0])); blur = float(rng.choice([0.0, 0.5, 1.0])); lowest = float(rng.choice([0.0, 1.5]))
+        sseed = int(rng.integers(1, 1 << 30)); max_pts = int(rng.choice([64, 1000, 8192]))
+        img = synth.image(w, h, seed=sseed, blobs=int(rng.integers(5, 300)))
+        if rng.random() < 0.2:
+            img = img + 20.0 * synth.normal(sseed, w * h).reshape(h, w).astype(np.float32)
+        img = np.ascontiguousarray(img, np.float32)
+        pitch = (w + 127) // 128 * 128
+        pad = np.zeros((h, pitch), np.float32); pad[:, :w] = img
+        d_sift = torch.zeros((max_pts, 576), dtype=torch.uint8, device=dev)
+        npts, nstored = ctx.extract_sift(d_sift, max_pts, torch.from_numpy(pad).to(dev), w, h, pitch, num_octaves=octaves, init_blur=blur,
+                                         thresh=thresh, lowest_scale=lowest, scale_up=up)
+        pts = d_sift.cpu().numpy().view(O.SIFT_DTYPE).reshape(-1)
+        opts, onp, ons = O.extract_sift(img, octaves, blur, thresh, lowest, up, max_pts)
+        ok = (npts, nstored) == (onp, ons)
+        if ok:
+            a = pts[:nstored]; b = opts[:nstored]
+            ok = all(same_bits(a[f], b[f]) for f in ("xpos", "ypos", "scale", "sharpness", "edgeness", "orientation", "subsampling", "data"))
+        return ok, dict(path="sift", w=w, h=h, octaves=octaves, up=up, thresh=thresh, blur=blur, lowest=lowest, seed=sseed, max_pts=max_pts, npts=int(npts))
+
+    table = [("ransac", ransac_round, 0.55), ("match", match_round, 0.15), ("homography", homography_round, 0.15), ("sift", sift_round, 0.15)]
+    t0 = time.time()
+    while time.time() - t0 < budget:
+        r = rng.random(); acc = 0.0
+        for name, fn, pr in table:
+            acc += pr
+            if r < acc:
+                break
+        try:
+            ok, cfg = fn()
+        except Exception as e:                        # an exception in a legal configuration is a finding too
+            ok, cfg = False, dict(path=name, exception=repr(e))
+        rounds[name] += 1
+        if not ok:
+            bad.append(cfg)
+            if len(bad) >= 20:
+                break
+    print(json.dumps({"seconds": round(time.time() - t0, 1), "seed": seed, "rounds": rounds, "mismatches": bad}))
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
