@@ -47,7 +47,26 @@ struct sfm_ctx {
     size_t sift_temp_bytes = 0;
     void *sift_ws = nullptr;           // counters, candidates, secondary orientations
     size_t sift_ws_bytes = 0;
+    // kernels that already opted in to > 64 KiB of dynamic LDS on THIS context's device (function attributes are
+    // per device; a context is used by one host thread at a time, so no process-wide flag)
+    static constexpr int kBigLdsSlots = 16;
+    const void *big_lds_done[kBigLdsSlots] = {};
 };
+
+// Allows `kernel` up to 160 KiB of dynamic LDS on the context's device, once per context.
+inline int allow_big_lds(sfm_ctx *ctx, const void *kernel)
+{
+    for (int i = 0; i < sfm_ctx::kBigLdsSlots; ++i) {
+        if (ctx->big_lds_done[i] == kernel) return SFM_OK;
+        if (ctx->big_lds_done[i] == nullptr) {
+            SFM_HIP_TRY(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            ctx->big_lds_done[i] = kernel;
+            return SFM_OK;
+        }
+    }
+    SFM_HIP_TRY(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));   // table full: just set it
+    return SFM_OK;
+}
 
 struct sfm_pair {
     sfm_ctx *ctx = nullptr;

@@ -169,12 +169,8 @@ static int ensure_hyp_capacity(sfm_pair *pair, size_t count)
 template <int WPB, bool UNITZ>
 static int launch_score_t(sfm_pair *pair, uint32_t h0, uint32_t count, float thr, int tile, int ntiles, int grid, size_t lds)
 {
-    static bool attr_set = false;
-    if (!attr_set) {
-        SFM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&ransac_score_waves<WPB, UNITZ>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    const int rc_lds = allow_big_lds(pair->ctx, reinterpret_cast<const void *>(&ransac_score_waves<WPB, UNITZ>));
+    if (rc_lds != SFM_OK) return rc_lds;
     hipLaunchKernelGGL((ransac_score_waves<WPB, UNITZ>), dim3(grid), dim3(WPB * 64), lds, pair->ctx->stream,
                        pair->d_X[0], pair->d_X[1], pair->ld, pair->n, pair->d_Ecand, h0, count, thr, tile, ntiles,
                        pair->d_counts, pair->d_key);

@@ -281,12 +281,8 @@ void ransac_finalize_E_wave(const float *__restrict__ X0, const float *__restric
 template <int WPB, bool UNITZ>
 static int launch_fused_t(sfm_pair *pair, const sfm_ransac_params &p, uint32_t h0, uint32_t count, int tile, int ntiles, int grid, size_t lds)
 {
-    static bool attr_set = false;
-    if (!attr_set) {
-        SFM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&ransac_fused_waves<WPB, UNITZ>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    const int rc_lds = allow_big_lds(pair->ctx, reinterpret_cast<const void *>(&ransac_fused_waves<WPB, UNITZ>));
+    if (rc_lds != SFM_OK) return rc_lds;
     hipLaunchKernelGGL((ransac_fused_waves<WPB, UNITZ>), dim3(grid), dim3(WPB * 64), lds, pair->ctx->stream,
                        pair->d_X[0], pair->d_X[1], pair->ld, pair->n, p.d_indices, p.seed, p.jacobi_sweeps,
                        h0, count, p.threshold, tile, ntiles, pair->d_counts, pair->d_Ecand, pair->d_key);

@@ -268,12 +268,8 @@ void ransac_score_mfma(const float *__restrict__ X0, const float *__restrict__ X
 template <int WPB>
 static int launch_mfma_t(sfm_pair *pair, uint32_t h0, uint32_t count, float thr, int tile, int ntiles, int grid, size_t lds)
 {
-    static bool attr_set = false;
-    if (!attr_set) {
-        SFM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&ransac_score_mfma<WPB>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    const int rc_lds = allow_big_lds(pair->ctx, reinterpret_cast<const void *>(&ransac_score_mfma<WPB>));
+    if (rc_lds != SFM_OK) return rc_lds;
     hipLaunchKernelGGL(ransac_score_mfma<WPB>, dim3(grid), dim3(WPB * 64), lds, pair->ctx->stream,
                        pair->d_X[0], pair->d_X[1], pair->ld, pair->n, pair->d_Ecand, h0, count, thr, tile, ntiles,
                        pair->d_counts, pair->d_key);
