@@ -57,39 +57,49 @@ for n, H in ((2048, 256), (2048, 1024), (16384, 65536)):
 # ---- the whole application run of the reference (src/main.cpp:249-307; img/data.xlsx total 47.36 ms incl. 6.96 ms SIFT,
 # dino frames 720x576): two images -> ExtractSift x2 -> match -> fillXU -> estimateE -> poses -> triangulation, synthetic
 # stereo pair of that size, everything resident on the device, default parameters of main.cpp (thresh 1.0, initBlur 1.5).
-w, h = 720, 576
-a, b, _, _ = synth.stereo_pair(w, h, seed=5)
-p = (w + 127) // 128 * 128
+def whole_run(a, b, label, extra):
+    h, w = a.shape
+    p = (w + 127) // 128 * 128
+
+    def dev_img(img):
+        pad = np.zeros((h, p), np.float32); pad[:, :w] = img
+        return torch.from_numpy(pad).to(dev)
+
+    da, db = dev_img(a), dev_img(b)
+    s1 = torch.zeros((32768, 576), dtype=torch.uint8, device=dev); s2 = torch.zeros_like(s1)
+    L = S.sift_temp_layout(w, h, 5, False)
+    tmp = torch.zeros(L.total_floats, dtype=torch.float32, device=dev)
+    K, Kinv = synth.camera(w, h)                        # main.cpp:292-297: f = 2360, principal point = image centre
+    state = {}
+
+    def whole():
+        n1, _ = ctx.extract_sift(s1, 32768, da, w, h, p, 5, 1.5, 1.0, 0.0, False, tmp)
+        n2, _ = ctx.extract_sift(s2, 32768, db, w, h, p, 5, 1.5, 1.0, 0.0, False, tmp)
+        ctx.match(s1, n1, s2, n2)
+        pr = state.get(n1)
+        if pr is None:
+            pr = state[n1] = S.ImagePair(ctx, K, Kinv, 2, n1)
+        pr.fillXU(s1)
+        pr.estimateE(S.default_params(n1))
+        pr.computePosecandidates(); pr.choosePose(); pr.linear_triangulation()
+        return n1, n2, pr
+
+    n1, n2, pr = whole()
+    ms = timed(whole, reps=30)
+    sift_ms = timed(lambda: (ctx.extract_sift(s1, 32768, da, w, h, p, 5, 1.5, 1.0, 0.0, False, tmp),
+                             ctx.extract_sift(s2, 32768, db, w, h, p, 5, 1.5, 1.0, 0.0, False, tmp)), reps=30)
+    _, cnt = pr.get_best()
+    out = {"features": [n1, n2], "hypotheses": n1 // 8, "inliers": cnt, "ms": ms, "sift_x2_ms": sift_ms,
+           "published_ms_1080Ti": 47.36, "published_sift_ms": 6.96, "speedup": 47.36 / ms}
+    out.update(extra)
+    print(json.dumps({label: out}))
 
 
-def dev_img(img):
-    pad = np.zeros((h, p), np.float32); pad[:, :w] = img
-    return torch.from_numpy(pad).to(dev)
-
-
-da, db = dev_img(a), dev_img(b)
-s1 = torch.zeros((32768, 576), dtype=torch.uint8, device=dev); s2 = torch.zeros_like(s1)
-L = S.sift_temp_layout(w, h, 5, False)
-tmp = torch.zeros(L.total_floats, dtype=torch.float32, device=dev)
-K, Kinv = synth.camera(w, h)
-state = {}
-
-
-def whole():
-    n1, _ = ctx.extract_sift(s1, 32768, da, w, h, p, 5, 1.5, 1.0, 0.0, False, tmp)
-    n2, _ = ctx.extract_sift(s2, 32768, db, w, h, p, 5, 1.5, 1.0, 0.0, False, tmp)
-    ctx.match(s1, n1, s2, n2)
-    pr = state.get(n1)
-    if pr is None:
-        pr = state[n1] = S.ImagePair(ctx, K, Kinv, 2, n1)
-    pr.fillXU(s1)
-    pr.estimateE(S.default_params(n1))
-    pr.computePosecandidates(); pr.choosePose(); pr.linear_triangulation()
-    return n1, n2, pr
-
-
-n1, n2, pr = whole()
-ms = timed(whole, reps=30)
-_, cnt = pr.get_best()
-print(json.dumps({"whole_run_720x576": {"features": [n1, n2], "hypotheses": n1 // 8, "inliers": cnt, "ms": ms,
-                                         "published_ms_1080Ti": 47.36, "speedup": 47.36 / ms}}))
+a, b, _, _ = synth.stereo_pair(720, 576, seed=5)
+whole_run(a, b, "whole_run_720x576", {"input": "synthetic stereo pair"})
+# the reference program's own input (src/main.cpp:250-251), kept as a fixture: the published 47.36 ms are for THIS pair
+dino = os.path.join(ROOT, "tests", "golden", "dino")
+if os.path.exists(os.path.join(dino, "viff.000.ppm")):
+    sys.path.insert(0, os.path.join(ROOT, "tests")); from helpers import read_pnm_grey
+    whole_run(read_pnm_grey(os.path.join(dino, "viff.000.ppm")), read_pnm_grey(os.path.join(dino, "viff.001.ppm")),
+              "whole_run_dino_pair", {"input": "data/dino/viff.000.ppm + viff.001.ppm (the reference program's input)"})

@@ -10,6 +10,8 @@
   e2e_oracle.npz   seeded two-view scene -> oracle E / counts / mask / poses / points.  These are
                    ORACLE outputs (regression vectors for the HIP path and for oracle refactors),
                    not reference outputs: the reference's estimateE is not reproducible.
+  dino/, dino_oracle.npz   the reference program's own input images (data/dino/viff.000/001.ppm, frames 2-3 as grey
+                   PGM) and the oracle's results on that pair (ORACLE outputs, see gen_dino).
 Only data is written; no reference source text is stored."""
 import ctypes as C
 import os
@@ -106,6 +108,38 @@ def gen_e2e():
     print("e2e_oracle.npz best", hyp, cnt, "householder best", hq, cq)
 
 
+def gen_dino():
+    """The reference program's own input (src/main.cpp:250-251 reads data/dino/viff.000.ppm and viff.001.ppm):
+    the two frames are copied as data fixtures (plus frames 2 and 3 as grey PGM for the 4-view ring), and the
+    oracle's results on the pair are frozen so that a drift of the oracle shows up in the CPU suite."""
+    import shutil
+    from helpers import read_pnm_grey, DINO_KINV, DINO_SIFT
+    src = "/root/reference/data/dino"
+    dst = os.path.join(OUT, "dino"); os.makedirs(dst, exist_ok=True)
+    for k in (0, 1):
+        shutil.copyfile(f"{src}/viff.{k:03d}.ppm", f"{dst}/viff.{k:03d}.ppm"); os.chmod(f"{dst}/viff.{k:03d}.ppm", 0o644)
+    for k in (2, 3):
+        g = read_pnm_grey(f"{src}/viff.{k:03d}.ppm").astype(np.uint8)
+        with open(f"{dst}/viff.{k:03d}.pgm", "wb") as f:
+            f.write(b"P5\n%d %d\n255\n" % (g.shape[1], g.shape[0])); f.write(g.tobytes())
+    imgs = [read_pnm_grey(f"{dst}/viff.{k:03d}.ppm") for k in (0, 1)]
+    feats = [O.extract_sift(im, DINO_SIFT["num_octaves"], DINO_SIFT["init_blur"], DINO_SIFT["thresh"], 0.0, False, 32768) for im in imgs]
+    n1 = feats[0][1]
+    m = O.match_sift(feats[0][0][:n1].copy(), feats[1][0][:feats[1][1]])
+    _, _, X0, X1 = O.fill_xu(m, DINO_KINV)
+    H = n1 // 8                                                  # the reference's operating point (sfm.cu:95)
+    key, counts, Ec = O.ransac_range(X0, X1, 0, H, 1e-6, 0, seed=0x5EED5F3D, want_E=True)      # the library's default seed
+    cnt, hyp = O.unpack_key(key)
+    out = {"num_pts": np.array([feats[0][1], feats[1][1]]), "stored": np.array([feats[0][2], feats[1][2]]),
+           "xpos0": feats[0][0]["xpos"][:n1], "ypos0": feats[0][0]["ypos"][:n1], "scale0": feats[0][0]["scale"][:n1],
+           "orientation0": feats[0][0]["orientation"][:n1], "desc0_head": feats[0][0]["data"][:32],
+           "match": m["match"], "score": m["score"], "ambiguity": m["ambiguity"],
+           "counts": counts, "best": np.array([hyp, cnt]), "E": Ec[hyp]}
+    np.savez_compressed(os.path.join(OUT, "dino_oracle.npz"), **out)
+    print("dino: features", out["num_pts"], "inliers", cnt, "of", n1, "hypothesis", hyp)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    gen_svd3(); gen_match(); gen_e2e()
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    gen_svd3(); gen_match(); gen_e2e(); gen_dino()

@@ -27,3 +27,34 @@ def make_pair(S, gpu, scene):
     pair = S.ImagePair(ctx, scene["K"], scene["Kinv"], 2, n)
     pair.fillXU(d_sift)
     return pair, d_sift
+
+
+def read_pnm_grey(path):
+    """Binary PGM / PPM -> float32 grey image exactly as cv::imread(path, 0).convertTo(CV_32FC1) delivers it to the
+    reference program (src/main.cpp:249-252): 8-bit fixed-point RGB -> grey (4899 R + 9617 G + 1868 B + 8192) >> 14.
+    Python twin of ReadPNM in cuda-sfm_amd/host/sfm_io.h."""
+    b = open(path, "rb").read()
+    toks, i = [], 0
+    while len(toks) < 4:
+        while b[i:i + 1].isspace():
+            i += 1
+        if b[i:i + 1] == b"#":
+            while b[i:i + 1] != b"\n":
+                i += 1
+            continue
+        j = i
+        while not b[j:j + 1].isspace():
+            j += 1
+        toks.append(b[i:j]); i = j
+    i += 1
+    kind, w, h, mx = toks[0], int(toks[1]), int(toks[2]), int(toks[3])
+    assert kind in (b"P5", b"P6") and mx == 255
+    if kind == b"P5":
+        return np.frombuffer(b, np.uint8, w * h, i).reshape(h, w).astype(np.float32)
+    c = np.frombuffer(b, np.uint8, w * h * 3, i).reshape(h, w, 3).astype(np.int64)
+    return ((c[..., 0] * 4899 + c[..., 1] * 9617 + c[..., 2] * 1868 + 8192) >> 14).astype(np.float32)
+
+
+DINO_K = np.array([[2360.0, 0.0, 360.0], [0.0, 2360.0, 288.0], [0.0, 0.0, 1.0]], np.float32)          # src/main.cpp:292-297
+DINO_KINV = np.array([[1.0 / 2360, 0.0, -360.0 / 2360], [0.0, 1.0 / 2360, -288.0 / 2360], [0.0, 0.0, 1.0]], np.float32)
+DINO_SIFT = dict(num_octaves=5, init_blur=1.5, thresh=1.0, lowest_scale=0.0, scale_up=False)       # src/main.cpp:267-277

@@ -1,0 +1,116 @@
+"""BASELINE configs[1] on the REAL data: the two frames the reference program reads (src/main.cpp:250-251,
+data/dino/viff.000.ppm / viff.001.ppm, kept as fixtures under tests/golden/dino/), its own parameters
+(initBlur 1.5, thresh 1.0, 5 octaves, 32768 points, K of main.cpp:292-297, H = N/8, threshold 1e-6):
+ExtractSift x2 -> MatchSiftData -> fillXU -> estimateE -> computePosecandidates -> choosePose ->
+linear_triangulation, every stage bit for bit against the oracle chain and the frozen oracle results; then the
+4-view ring (configs[4] in miniature) and the re-hosted main program on the same files."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import cuda_sfm_amd as S
+import oracle as O
+from helpers import DINO_K, DINO_KINV, DINO_SIFT, read_pnm_grey, same_bits
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DINO = os.path.join(ROOT, "tests", "golden", "dino")
+FIELDS = ("xpos", "ypos", "scale", "sharpness", "edgeness", "orientation", "subsampling", "data")
+
+
+def frame(k):
+    ext = "ppm" if k < 2 else "pgm"
+    return os.path.join(DINO, f"viff.{k:03d}.{ext}")
+
+
+def extract(gpu, img, max_pts=32768):
+    torch, dev, ctx = gpu
+    h, w = img.shape
+    pitch = (w + 127) // 128 * 128
+    pad = np.zeros((h, pitch), np.float32); pad[:, :w] = img
+    d_sift = torch.zeros((max_pts, 576), dtype=torch.uint8, device=dev)
+    n, stored = ctx.extract_sift(d_sift, max_pts, torch.from_numpy(pad).to(dev), w, h, pitch, **DINO_SIFT)
+    return d_sift, n, stored
+
+
+def oracle_features(img):
+    return O.extract_sift(img, DINO_SIFT["num_octaves"], DINO_SIFT["init_blur"], DINO_SIFT["thresh"], 0.0, False, 32768)
+
+
+def test_dino_pair_every_stage(gpu):
+    torch, dev, ctx = gpu
+    g = np.load(os.path.join(ROOT, "tests", "golden", "dino_oracle.npz"))
+    imgs = [read_pnm_grey(frame(k)) for k in (0, 1)]
+    assert imgs[0].shape == (576, 720)
+    d, n, st = zip(*[extract(gpu, im) for im in imgs])
+    of = [oracle_features(im) for im in imgs]
+    assert list(n) == [f[1] for f in of] == g["num_pts"].tolist() and list(st) == [f[2] for f in of]
+    for k in (0, 1):
+        rec = d[k].cpu().numpy().view(O.SIFT_DTYPE).reshape(-1)
+        for f in FIELDS:
+            assert same_bits(rec[f][:st[k]], of[k][0][f][:st[k]]), (k, f)
+    n1, n2 = n
+    ctx.match(d[0], n1, d[1], n2)                                              # MatchSiftData
+    m = d[0].cpu().numpy().view(O.SIFT_DTYPE).reshape(-1)[:n1]
+    om = O.match_sift(of[0][0][:n1].copy(), of[1][0][:n2])
+    assert np.array_equal(m["match"], om["match"]) and np.array_equal(m["match"], g["match"])
+    for f in ("score", "ambiguity", "match_xpos", "match_ypos"):
+        assert same_bits(m[f], om[f]), f
+
+    pair = S.ImagePair(ctx, DINO_K, DINO_KINV, 2, n1)                          # main.cpp:298-307
+    pair.fillXU(d[0])
+    p = S.default_params(n1)
+    assert p.num_hypotheses == n1 // 8
+    pair.estimateE(p)
+    _, _, X0, X1 = O.fill_xu(om, DINO_KINV)
+    key, ocounts, oE = O.ransac_range(X0, X1, 0, p.num_hypotheses, p.threshold, p.jacobi_sweeps, seed=p.seed, want_E=True)
+    ocnt, ohyp = O.unpack_key(key)
+    assert np.array_equal(pair.get_inlier_counts(p.num_hypotheses), ocounts) and np.array_equal(ocounts, g["counts"])
+    assert pair.get_best() == (ohyp, ocnt) == tuple(int(v) for v in g["best"])
+    assert same_bits(pair.get_E(), oE[ohyp].reshape(3, 3)) and same_bits(oE[ohyp], g["E"])
+    assert ocnt > 0.25 * n1                                                    # a real consensus set (594 of 2155)
+    assert np.array_equal(pair.get_inlier_mask(), O.count_inliers(oE[ohyp], X0, X1, p.threshold)[1])
+    for mode in (S.POSE_REFERENCE, S.POSE_CORRECT):
+        pair.computePosecandidates(mode); pair.choosePose(mode); pair.linear_triangulation(mode)
+        oP = O.pose_candidates(oE[ohyp], mode)
+        oind, oPinv, _, _ = O.choose_pose(X0, X1, oP, mode, 8)
+        assert pair.get_pose_index() == oind and same_bits(pair.get_pose_candidates(), oP)
+        opts = O.triangulate(X0, X1, oPinv[oind] if mode == S.POSE_REFERENCE else oP[oind], 8)
+        assert same_bits(pair.get_points(), opts)
+
+
+def test_dino_ring_of_four_views(gpu):
+    """configs[4] in miniature on real frames 0..3: process_views (extract per view, ring pairs, per-pair pipeline)."""
+    torch, dev, ctx = gpu
+    views = [read_pnm_grey(frame(k)) for k in range(4)]
+    res, counts = S.process_views(ctx, views, DINO_K, DINO_KINV, max_pts=32768, sift=DINO_SIFT, device=dev)
+    feats = [oracle_features(v) for v in views]
+    assert counts == [f[1] for f in feats] and min(counts) > 1500
+    for pid, (i, j) in enumerate(S.ring_pairs(4)):
+        ni = feats[i][1]
+        m = O.match_sift(feats[i][0][:ni].copy(), feats[j][0][:feats[j][1]])
+        _, _, X0, X1 = O.fill_xu(m, DINO_KINV)
+        p = S.default_params(ni)
+        key, _, Ec = O.ransac_range(X0, X1, 0, p.num_hypotheses, p.threshold, p.jacobi_sweeps, seed=p.seed, want_E=True)
+        ocnt, ohyp = O.unpack_key(key)
+        r = res[pid]
+        assert same_bits(r[:9], Ec[ohyp]) and (int(r[26]), int(r[27])) == (ocnt, ohyp)
+
+
+def test_dino_main_program(tmp_path):
+    """host/sfm_main (src/main.cpp:249-307 re-hosted) on the reference's own two files with its own defaults."""
+    app = os.path.join(ROOT, "cuda-sfm_amd", "host", "sfm_main")
+    assert os.path.exists(app), "sfm_main not built (make)"
+    ply, res = str(tmp_path / "dino.ply"), str(tmp_path / "dino.bin")
+    r = subprocess.run([app, frame(0), frame(1), ply, res], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    g = np.load(os.path.join(ROOT, "tests", "golden", "dino_oracle.npz"))
+    raw = open(res, "rb").read()
+    n = int(np.frombuffer(raw, "<i4", 1)[0])
+    E = np.frombuffer(raw, "<f4", 9, 4)
+    hyp, cnt = (int(v) for v in np.frombuffer(raw, "<u4", 2, 44))
+    assert n == int(g["num_pts"][0]) and (hyp, cnt) == tuple(int(v) for v in g["best"]) and same_bits(E, g["E"])
+    lines = open(ply).read().splitlines()
+    assert lines[0] == "ply" and int([l for l in lines if l.startswith("element vertex")][0].split()[-1]) > 100

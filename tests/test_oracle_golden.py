@@ -115,3 +115,23 @@ def test_reference_gpu_kernels_golden():
         h = O.homography4(coord, pts[:, l])
         assert same_bits(h, g["homo_h"][:, l].copy())
         assert O.homography_count(h, coord, coord.shape[1], thr * thr) == g["homo_counts"][l]
+
+
+def test_dino_pair_oracle_results_are_frozen():
+    """The oracle chain on the reference program's own input pair (tests/golden/dino, src/main.cpp:250-307 parameters)
+    reproduces the committed results: features, matches, per-hypothesis counts, winner, E."""
+    from helpers import DINO_KINV, DINO_SIFT, read_pnm_grey
+    gold = np.load(os.path.join(G, "dino_oracle.npz"))
+    imgs = [read_pnm_grey(os.path.join(G, "dino", f"viff.{k:03d}.ppm")) for k in (0, 1)]
+    feats = [O.extract_sift(im, DINO_SIFT["num_octaves"], DINO_SIFT["init_blur"], DINO_SIFT["thresh"], 0.0, False, 32768) for im in imgs]
+    assert [f[1] for f in feats] == gold["num_pts"].tolist() and [f[2] for f in feats] == gold["stored"].tolist()
+    n1 = feats[0][1]
+    for f, k in (("xpos", "xpos0"), ("ypos", "ypos0"), ("scale", "scale0"), ("orientation", "orientation0")):
+        assert same_bits(feats[0][0][f][:n1], gold[k]), f
+    assert same_bits(feats[0][0]["data"][:32], gold["desc0_head"])
+    m = O.match_sift(feats[0][0][:n1].copy(), feats[1][0][:feats[1][1]])
+    assert np.array_equal(m["match"], gold["match"]) and same_bits(m["score"], gold["score"]) and same_bits(m["ambiguity"], gold["ambiguity"])
+    _, _, X0, X1 = O.fill_xu(m, DINO_KINV)
+    key, counts, Ec = O.ransac_range(X0, X1, 0, n1 // 8, 1e-6, 0, seed=0x5EED5F3D, want_E=True)
+    cnt, hyp = O.unpack_key(key)
+    assert np.array_equal(counts, gold["counts"]) and [hyp, cnt] == gold["best"].tolist() and same_bits(Ec[hyp], gold["E"])
