@@ -9,6 +9,7 @@ PKG      := cuda-sfm_amd
 CSRC     := $(PKG)/csrc
 BUILD    := build
 LIB      := $(PKG)/lib/libsfm_amd.so
+COMMLIB  := $(PKG)/lib/libsfm_amd_rccl.so
 SRCS     := $(wildcard $(CSRC)/*.hip)
 OBJS     := $(patsubst $(CSRC)/%.hip,$(BUILD)/%.o,$(SRCS))
 HDRS     := $(wildcard $(CSRC)/*.hpp) include/sfm_amd.h
@@ -21,7 +22,7 @@ MAINAPP  := $(PKG)/host/sfm_main
 IOTEST   := tests/cpp/io_test
 GEOMTEST := tests/cpp/geom_test
 
-all: $(LIB) oracle hostcheck $(DEMO) $(HDEMO) $(SDEMO) $(MAINAPP) $(IOTEST) $(GEOMTEST)
+all: $(LIB) $(COMMLIB) oracle hostcheck $(DEMO) $(HDEMO) $(SDEMO) $(MAINAPP) $(IOTEST) $(GEOMTEST)
 
 $(BUILD)/%.o: $(CSRC)/%.hip $(HDRS)
 	@mkdir -p $(BUILD)
@@ -30,6 +31,10 @@ $(BUILD)/%.o: $(CSRC)/%.hip $(HDRS)
 $(LIB): $(OBJS)
 	@mkdir -p $(PKG)/lib
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS)
+
+# the RCCL exchange step lives in its own library: libsfm_amd.so itself has no RCCL dependency
+$(COMMLIB): $(CSRC)/comm.cpp include/sfm_amd_comm.h include/sfm_amd.h $(LIB)
+	$(HIPCC) -x hip --cuda-host-only -O2 -fPIC -shared -Iinclude -o $@ $< -L$(PKG)/lib -lsfm_amd -L/opt/rocm/lib -lrccl -Wl,-rpath,'$$ORIGIN' -Wl,-rpath,/opt/rocm/lib
 
 oracle:
 	$(MAKE) -C oracle

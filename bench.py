@@ -67,6 +67,9 @@ def main():
     ap.add_argument("--hyps", type=int, default=TOTAL_HYPS)
     ap.add_argument("--kernel", type=int, default=0)
     ap.add_argument("--sweeps", type=int, default=-1, help="null-vector solver: -1 library default, 0 Householder, k > 0 Jacobi sweeps")
+    ap.add_argument("--comm", choices=["torch", "rccl"], default="torch",
+                    help="multi-GPU exchange step: torch.distributed all_reduce (default) or the C-level RCCL path of "
+                         "include/sfm_amd_comm.h (sfm_estimate_E_sharded: score, ncclAllReduce and finalize on ONE stream)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-variants", action="store_true", help="skip the short run with the other null-vector solver")
     args = ap.parse_args()
@@ -102,8 +105,18 @@ def main():
         if world > 1:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)      # RCCL over xGMI, 8 bytes
 
+    comm = None
+    if args.comm == "rccl":
+        uid = [S.Comm.unique_id() if rank == 0 else None]
+        if world > 1:
+            dist.broadcast_object_list(uid, src=0)      # the out-of-band hand-over of the ncclUniqueId
+        comm = S.Comm(ctx, uid[0], rank, world)
+
     def step():
-        S.estimate_E_distributed(pair, params, rank, world, key_t, reduce_max)
+        if comm is not None:
+            comm.estimate_E(pair, params)
+        else:
+            S.estimate_E_distributed(pair, params, rank, world, key_t, reduce_max)
 
     def fence():
         if world > 1:
@@ -189,7 +202,8 @@ def main():
                        "matches": n, "hypotheses_per_step": H, "threshold": params.threshold,
                        "jacobi_sweeps": params.jacobi_sweeps,
                        "solver": "householder QR of the 8x9 system" if params.jacobi_sweeps == 0 else f"normal equations + {params.jacobi_sweeps} Jacobi sweeps",
-                       "kernel": pair.last_launch()},
+                       "kernel": pair.last_launch(), "exchange": "none" if world == 1 and comm is None else
+                       ("ncclAllReduce(max, u64) on the compute stream (libsfm_amd_rccl.so)" if comm is not None else "torch.distributed all_reduce(MAX), 8 bytes")},
             "roofline": {"bound": "mfma", "bound_detail": "FP32 VALU (v_pk_fma_f32); its 157.3 TFLOP/s peak equals the dense f32 MFMA peak",
                          "kernel": "ransac_score_waves", "achieved": achieved,
                          "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_PEAK_TFLOPS,
@@ -209,7 +223,14 @@ def main():
             ocnt, omask = O.count_inliers(E, X0, X1, params.threshold)
             out["result"]["parity_vs_oracle"] = bool(ocnt == cnt and np.array_equal(omask, main_mask)
                                                      and np.array_equal(E.view(np.uint32), main_E.view(np.uint32)))
+        try:                                        # RCCL writes a start-up banner through C stdio: push it out BEFORE the JSON line
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
         print(json.dumps(out), flush=True)
+    if comm is not None:
+        comm.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

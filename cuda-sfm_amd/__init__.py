@@ -47,7 +47,7 @@ assert SIFT_DTYPE.itemsize == 576
 
 EXPORTS = [
     "sfm_abi_version", "sfm_last_error", "sfm_ctx_create", "sfm_ctx_destroy", "sfm_ctx_set_stream",
-    "sfm_ctx_synchronize", "sfm_ctx_timer_start", "sfm_ctx_timer_stop", "sfm_ctx_kernel_timing",
+    "sfm_ctx_synchronize", "sfm_ctx_get_stream", "sfm_ctx_get_device", "sfm_ctx_timer_start", "sfm_ctx_timer_stop", "sfm_ctx_kernel_timing",
     "sfm_ctx_kernel_timing_read", "sfm_device_alloc", "sfm_device_free", "sfm_copy_to_device", "sfm_copy_to_host",
     "sfm_copy_to_host_2d", "sfm_copy_to_device_2d", "sfm_find_homography", "sfm_sift_temp_layout", "sfm_extract_sift", "sfm_match", "sfm_match_soa",
     "sfm_pair_create", "sfm_pair_destroy", "sfm_fill_xu", "sfm_set_points", "sfm_ransac_default_params",
@@ -413,6 +413,64 @@ def estimate_E_distributed(pair, params, rank, world, key_tensor, all_reduce_max
     pair.export_key(key_tensor)
     all_reduce_max(key_tensor)
     pair.ransac_finalize_key(params, key_tensor)
+
+
+# ---- RCCL exchange step in C (include/sfm_amd_comm.h, libsfm_amd_rccl.so) ----------------------------
+COMM_EXPORTS = ["sfm_comm_unique_id", "sfm_comm_init", "sfm_comm_destroy", "sfm_comm_rank", "sfm_estimate_E_sharded"]
+COMM_LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), "libsfm_amd_rccl.so")
+COMM_ID_BYTES = 128
+_comm_lib = None
+
+
+def comm_lib():
+    """libsfm_amd_rccl.so, loaded on first use (it pulls in librccl; the core library does not)."""
+    global _comm_lib
+    if _comm_lib is None:
+        if not os.path.exists(COMM_LIB_PATH):
+            raise ImportError(f"{COMM_LIB_PATH} is missing: run `make` (or __graft_entry__.build())")
+        L = C.CDLL(COMM_LIB_PATH)
+        L.sfm_comm_unique_id.argtypes = [_vp]
+        L.sfm_comm_init.argtypes = [_vp, _vp, C.c_int, C.c_int, C.POINTER(_vp)]
+        L.sfm_comm_destroy.argtypes = [_vp]
+        L.sfm_comm_rank.argtypes = [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.sfm_estimate_E_sharded.argtypes = [_vp, C.POINTER(RansacParams), _vp]
+        _comm_lib = L
+    return _comm_lib
+
+
+class Comm:
+    """sfm_comm: one RCCL communicator over the ranks of the job, bound to a Context (its device and stream).
+    `unique_id` = the 128 bytes of Comm.unique_id() made on rank 0 and handed to every rank out of band."""
+
+    @staticmethod
+    def unique_id():
+        buf = C.create_string_buffer(COMM_ID_BYTES)
+        _check(comm_lib().sfm_comm_unique_id(buf), "sfm_comm_unique_id")
+        return buf.raw
+
+    def __init__(self, ctx, unique_id, rank, world):
+        assert len(unique_id) == COMM_ID_BYTES
+        self._ctx = ctx
+        h = _vp()
+        _check(comm_lib().sfm_comm_init(ctx._h, C.create_string_buffer(bytes(unique_id), COMM_ID_BYTES), int(rank), int(world), C.byref(h)),
+               "sfm_comm_init")
+        self._h = h
+        self.rank, self.world = int(rank), int(world)
+
+    def estimate_E(self, pair, params):
+        """estimateE over all ranks (params.num_hypotheses = global count): shard, ONE all-reduce(max), local finalize."""
+        _check(comm_lib().sfm_estimate_E_sharded(pair._h, C.byref(params), self._h), "sfm_estimate_E_sharded")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            comm_lib().sfm_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 # ---- many view pairs (BASELINE configs[4]: 36-view ring, view pairs streamed across the GPUs) -------

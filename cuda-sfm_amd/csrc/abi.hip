@@ -110,6 +110,20 @@ int sfm_ctx_synchronize(sfm_ctx *ctx)
     return SFM_OK;
 }
 
+int sfm_ctx_get_stream(sfm_ctx *ctx, void **hip_stream)
+{
+    SFM_REQUIRE(ctx && hip_stream, SFM_E_INVALID, "null argument");
+    *hip_stream = static_cast<void *>(ctx->stream);
+    return SFM_OK;
+}
+
+int sfm_ctx_get_device(sfm_ctx *ctx, int *device_id)
+{
+    SFM_REQUIRE(ctx && device_id, SFM_E_INVALID, "null argument");
+    *device_id = ctx->device;
+    return SFM_OK;
+}
+
 int sfm_ctx_timer_start(sfm_ctx *ctx)
 {
     SFM_REQUIRE(ctx, SFM_E_INVALID, "null context");

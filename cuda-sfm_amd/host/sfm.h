@@ -43,6 +43,10 @@ public:
     void computePosecandidates() { SFM_FACADE_CALL(sfm_pose_candidates(pair_, pose_mode_)); } // sfm.cu:238-252
     void choosePose() { SFM_FACADE_CALL(sfm_choose_pose(pair_, pose_mode_)); }                // sfm.cu:254-307
     void linear_triangulation() { SFM_FACADE_CALL(sfm_triangulate(pair_, pose_mode_)); }      // sfm.cu:309-344
+#ifdef SFM_AMD_COMM_H
+    // multi-GPU estimateE (include sfm_amd_comm.h first): num_hypotheses is the global count, every rank calls it
+    void estimateE(sfm_comm *comm) { SFM_FACADE_CALL(sfm_estimate_E_sharded(pair_, &params_, comm)); }
+#endif
     void computePoseCandidates() { computePosecandidates(); }
     void linearTriangulate() { linear_triangulation(); }
 

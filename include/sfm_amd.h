@@ -57,6 +57,8 @@ int  sfm_ctx_create(int device_id, sfm_ctx **out);          /* replaces InitCuda
 int  sfm_ctx_destroy(sfm_ctx *ctx);
 int  sfm_ctx_set_stream(sfm_ctx *ctx, void *hip_stream);    /* NULL = default stream                                          */
 int  sfm_ctx_synchronize(sfm_ctx *ctx);
+int  sfm_ctx_get_stream(sfm_ctx *ctx, void **hip_stream);    /* the stream work is enqueued on (for callers that add their own, e.g. RCCL) */
+int  sfm_ctx_get_device(sfm_ctx *ctx, int *device_id);
 /* HIP-event stopwatch on the context's stream (for callers without their own event API). */
 int  sfm_ctx_timer_start(sfm_ctx *ctx);
 int  sfm_ctx_timer_stop(sfm_ctx *ctx, float *elapsed_ms);   /* synchronises */

@@ -1,0 +1,39 @@
+/* sfm_amd_comm.h -- multi-GPU layer of the C ABI: hypothesis shards + ONE RCCL all-reduce(max).
+ *
+ * The reference is single-GPU (src/main.cpp:243-245 merely selects a device; sfm.cu:94-153 scores all hypotheses
+ * on it and takes thrust::max_element, sfm.cu:135-140).  This header adds the one exchange step a node of
+ * MI355X needs: every rank (one process per GPU) scores its contiguous shard of hypothesis ids, the packed
+ * 8-byte key (inlier count << 32 | 0xFFFFFFFF - hypothesis id) goes through ncclAllReduce(ncclMax, ncclUint64)
+ * on the context's own HIP stream (RCCL over xGMI), and every rank finalizes the winner locally -- the result is
+ * bit-identical on every rank and identical to the single-GPU sfm_estimate_E.
+ *
+ * Lives in its own library (libsfm_amd_rccl.so, links librccl) so that libsfm_amd.so has no RCCL dependency.
+ * The unique id is produced on rank 0 and must reach the other ranks out of band (a file, MPI, torch.distributed
+ * broadcast, ...): exactly the ncclGetUniqueId / ncclCommInitRank contract.
+ */
+#ifndef SFM_AMD_COMM_H
+#define SFM_AMD_COMM_H
+
+#include "sfm_amd.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SFM_COMM_ID_BYTES 128                 /* = NCCL_UNIQUE_ID_BYTES */
+typedef struct sfm_comm sfm_comm;
+
+int sfm_comm_unique_id(void *id128);          /* rank 0: ncclGetUniqueId                                   */
+int sfm_comm_init(sfm_ctx *ctx, const void *id128, int rank, int nranks, sfm_comm **out);   /* ncclCommInitRank */
+int sfm_comm_destroy(sfm_comm *comm);
+int sfm_comm_rank(const sfm_comm *comm, int *rank, int *nranks);
+
+/* Image_pair::estimateE over all ranks: p->num_hypotheses is the GLOBAL count; the call overrides
+ * p->hyp_begin / p->hyp_count with this rank's shard, scores it, all-reduces the key and finalizes the winner.
+ * Asynchronous (context stream) like sfm_estimate_E; every rank must call it with the same arguments. */
+int sfm_estimate_E_sharded(sfm_pair *pair, sfm_ransac_params *p, sfm_comm *comm);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

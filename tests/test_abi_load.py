@@ -25,6 +25,20 @@ def test_header_symbols_exported():
     assert S.lib().sfm_abi_version() == 1
 
 
+def test_comm_header_symbols_exported():
+    """include/sfm_amd_comm.h <-> libsfm_amd_rccl.so (the RCCL exchange step lives in its own library)."""
+    import cuda_sfm_amd as S
+    txt = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "sfm_amd_comm.h")).read(), flags=re.S)
+    names = sorted(set(re.findall(r"\b(sfm_[a-z0-9_A-Z]+)\s*\(", txt)))
+    assert names == sorted(S.COMM_EXPORTS)
+    L = S.comm_lib()
+    assert not [n for n in names if not hasattr(L, n)]
+    # the core library stays free of RCCL
+    import subprocess
+    needed = subprocess.run(["readelf", "-d", S.LIB_PATH], capture_output=True, text=True).stdout
+    assert "rccl" not in needed and "nccl" not in needed
+
+
 def test_struct_layouts_match_header():
     import cuda_sfm_amd as S
     assert C.sizeof(S.RansacParams) == 56

@@ -204,3 +204,23 @@ def test_huge_coordinates_keep_the_full_range_tracking(gpu, scale):
         pair.estimateE(p)
         key, ocounts, _ = O.ransac_range(X0s, X1s, 0, H, p.threshold, p.jacobi_sweeps, seed=5)
         assert np.array_equal(pair.get_inlier_counts(H), ocounts) and pair.get_key() == key
+
+
+def test_rccl_comm_single_rank_equals_estimateE(gpu):
+    """include/sfm_amd_comm.h with one rank: shard = everything, the all-reduce is the identity; results must equal
+    sfm_estimate_E (the N > 1 behaviour is the same code with smaller shards; covered by tests/test_dist_gloo.py on the
+    host logic and measured by bench.py --gpus N --comm rccl)."""
+    torch, dev, ctx = gpu
+    n, H = 3000, 5000
+    scene = synth.two_view_scene(n, seed=77)
+    pair, _ = make_pair(S, gpu, scene)
+    p = S.default_params(n, num_hypotheses=H, seed=9)
+    pair.estimateE(p)
+    ref = (pair.get_key(), pair.get_E().copy(), pair.get_inlier_mask().copy(), pair.get_inlier_counts(H).copy())
+    comm = S.Comm(ctx, S.Comm.unique_id(), 0, 1)
+    q = S.default_params(n, num_hypotheses=H, seed=9)
+    comm.estimate_E(pair, q)
+    assert (q.hyp_begin, q.hyp_count) == (0, H)
+    assert pair.get_key() == ref[0] and same_bits(pair.get_E(), ref[1]) and np.array_equal(pair.get_inlier_mask(), ref[2])
+    assert np.array_equal(pair.get_inlier_counts(H), ref[3])
+    comm.close()
