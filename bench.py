@@ -29,17 +29,20 @@ FLOP_PER_POINT = 38           # residual of one (hypothesis, point)
 FLOP_PER_HYP = 720            # A^T A normal equations
 
 
-def cpu_baseline(scene, params, seconds=12.0):
+def cpu_baseline(scene, params, seconds=15.0):
     """Oracle (CPU port of the same algorithm, OpenMP over hypotheses) on a bounded sample."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle as O
     cores = len(os.sched_getaffinity(0))
     _, _, X0, X1 = O.fill_xu(scene["sift"], scene["Kinv"])
     probe = 256 * cores
-    t0 = time.perf_counter()
-    O.ransac_range(X0, X1, 0, probe, params.threshold, params.jacobi_sweeps, seed=params.seed, want_counts=False, nthreads=cores)
-    rate = probe / (time.perf_counter() - t0)
-    sample = int(max(probe, min(4 * TOTAL_HYPS, rate * seconds)))     # ids beyond H are further hypotheses of the same scene
+    rate = 0.0
+    for _ in range(2):                               # thread start-up dominates the first probe: size the second from it (~1 s)
+        t0 = time.perf_counter()
+        O.ransac_range(X0, X1, 0, probe, params.threshold, params.jacobi_sweeps, seed=params.seed, want_counts=False, nthreads=cores)
+        rate = probe / (time.perf_counter() - t0)
+        probe = int(max(probe, rate * 1.0))
+    sample = int(max(probe, min(16 * TOTAL_HYPS, rate * seconds)))    # ids beyond H are further hypotheses of the same scene
     t0 = time.perf_counter()
     key, _, _ = O.ransac_range(X0, X1, 0, sample, params.threshold, params.jacobi_sweeps, seed=params.seed, want_counts=False, nthreads=cores)
     dt = time.perf_counter() - t0
