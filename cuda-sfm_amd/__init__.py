@@ -50,7 +50,7 @@ EXPORTS = [
     "sfm_ctx_synchronize", "sfm_ctx_get_stream", "sfm_ctx_get_device", "sfm_ctx_timer_start", "sfm_ctx_timer_stop", "sfm_ctx_kernel_timing",
     "sfm_ctx_kernel_timing_read", "sfm_device_alloc", "sfm_device_free", "sfm_copy_to_device", "sfm_copy_to_host",
     "sfm_copy_to_host_2d", "sfm_copy_to_device_2d", "sfm_find_homography", "sfm_sift_temp_layout", "sfm_extract_sift", "sfm_match", "sfm_match_soa",
-    "sfm_pair_create", "sfm_pair_destroy", "sfm_fill_xu", "sfm_set_points", "sfm_ransac_default_params",
+    "sfm_pair_create", "sfm_pair_destroy", "sfm_pair_reset", "sfm_get_result", "sfm_fill_xu", "sfm_set_points", "sfm_ransac_default_params",
     "sfm_ransac_permutation_indices", "sfm_estimate_E", "sfm_ransac_score", "sfm_ransac_finalize",
     "sfm_ransac_finalize_key", "sfm_ransac_export_key", "sfm_pose_candidates", "sfm_choose_pose", "sfm_triangulate",
     "sfm_pair_device_ptr", "sfm_pair_ld", "sfm_pair_num_points", "sfm_get_XU", "sfm_get_E", "sfm_get_best",
@@ -123,6 +123,8 @@ _lib.sfm_get_pose_candidates.argtypes = [_vp, _vp]
 _lib.sfm_get_pose_inverses.argtypes = [_vp, _vp]
 _lib.sfm_get_pose_index.argtypes = [_vp, C.POINTER(C.c_int)]
 _lib.sfm_get_points.argtypes = [_vp, _vp]
+_lib.sfm_pair_reset.argtypes = [_vp, C.c_int]
+_lib.sfm_get_result.argtypes = [_vp, _vp]
 _lib.sfm_ransac_last_launch.argtypes = [_vp] + [C.POINTER(C.c_int)] * 4
 
 
@@ -288,6 +290,18 @@ class ImagePair:
         self.ld = _lib.sfm_pair_ld(h)
 
     # -- reference call surface -----------------------------------------------------------------
+    def reset(self, num_points):
+        """Re-use the pair for another correspondence set of at most its creation-time size (no allocation)."""
+        _check(_lib.sfm_pair_reset(self._h, int(num_points)), "sfm_pair_reset")
+        self.num_points = int(num_points)
+        self.ld = _lib.sfm_pair_ld(self._h)
+
+    def get_result(self):
+        """[E(9) | chosen pose (16) | pose index, inlier count, best hypothesis] with one synchronisation."""
+        rec = np.empty(RESULT_FLOATS, np.float32)
+        _check(_lib.sfm_get_result(self._h, rec.ctypes.data_as(_vp)), "sfm_get_result")
+        return rec
+
     def fillXU(self, d_sift):
         _check(_lib.sfm_fill_xu(self._h, _ptr(d_sift)), "sfm_fill_xu")
 
@@ -482,6 +496,18 @@ def pair_schedule(num_pairs, rank, world):
     return list(range(int(rank), int(num_pairs), int(world)))
 
 
+def _two_view(ip, d_sift, n, num_hypotheses, pose_mode):
+    """fillXU -> estimateE -> pose candidates -> choosePose -> linear triangulation on a pooled Image_pair -> record."""
+    ip.reset(n)
+    ip.fillXU(d_sift)
+    p = default_params(n) if num_hypotheses is None else default_params(n, num_hypotheses=num_hypotheses)
+    ip.estimateE(p)
+    ip.computePosecandidates(pose_mode)
+    ip.choosePose(pose_mode)
+    ip.linear_triangulation(pose_mode)
+    return ip.get_result()
+
+
 def process_pairs(ctx, pairs, K, Kinv, rank=0, world=1, num_hypotheses=None, pose_mode=POSE_REFERENCE,
                   all_gather=None, device=None):
     """Task-parallel two-view estimation over many view pairs: each rank runs the whole per-pair
@@ -497,22 +523,13 @@ def process_pairs(ctx, pairs, K, Kinv, rank=0, world=1, num_hypotheses=None, pos
     mine = pair_schedule(len(pairs), rank, world)
     max_local = (len(pairs) + world - 1) // world
     rec = np.full((max_local, RESULT_FLOATS + 1), -1.0, np.float32)     # last column: pair id (-1 = empty slot)
+    # ONE Image_pair at the largest size, reset per pair (the reference builds one per pair: ~20 allocations each)
+    ip = ImagePair(ctx, K, Kinv, 2, max(pairs[pid][1] for pid in mine)) if mine else None
     for slot, pid in enumerate(mine):
         d_sift, n = pairs[pid]
-        ip = ImagePair(ctx, K, Kinv, 2, n)
-        ip.fillXU(d_sift)
-        p = default_params(n) if num_hypotheses is None else default_params(n, num_hypotheses=num_hypotheses)
-        ip.estimateE(p)
-        ip.computePosecandidates(pose_mode)
-        ip.choosePose(pose_mode)
-        ip.linear_triangulation(pose_mode)
-        hyp, cnt = ip.get_best()
-        pind = ip.get_pose_index()
-        P = (ip.get_pose_inverses() if pose_mode == POSE_REFERENCE else ip.get_pose_candidates())[pind]
-        rec[slot, :9] = ip.get_E().reshape(9)
-        rec[slot, 9:25] = P.reshape(16)
-        rec[slot, 25:28] = (pind, cnt, hyp)
+        rec[slot, :RESULT_FLOATS] = _two_view(ip, d_sift, n, num_hypotheses, pose_mode)
         rec[slot, 28] = pid
+    if ip is not None:
         ip.close()
     local = torch.from_numpy(rec)
     if device is not None:
@@ -564,28 +581,26 @@ def process_views(ctx, images, K, Kinv, pairs=None, rank=0, world=1, max_pts=819
     feats = gather_features(block) if (gather_features is not None and world > 1) else block
     feats = feats.reshape(-1, rec_bytes + 64)
 
-    def view(v):
-        row = feats[view_slot(v, world, slots)]
-        n = int(row[rec_bytes:rec_bytes + 4].cpu().numpy().view(np.int32)[0])
-        return row[:rec_bytes].reshape(max_pts, 576), n
+    # feature counts of all views with ONE read-back; MatchSiftData then writes its result fields (score .. match_ypos)
+    # straight into the first view's records -- nothing else of a record changes, so no per-pair copy is needed
+    counts = [int(c) for c in feats[:, rec_bytes:rec_bytes + 4].cpu().numpy().view(np.int32).reshape(-1)[[view_slot(v, world, slots) for v in range(V)]]]
 
-    counts = [view(v)[1] for v in range(V)]
-    matched = {}
-    for pid in pair_schedule(len(pairs), rank, world):
-        i, j = pairs[pid]
-        (s1, n1), (s2, n2) = view(i), view(j)
-        if n1 < 8 or n2 < 1:
-            continue
-        m = s1[:n1].clone()                                   # MatchSiftData writes score .. match_ypos into set 1
-        ctx.match(m, n1, s2, n2)
-        matched[pid] = (m, n1)
-    order = sorted(matched)
-    res = process_pairs(ctx, [matched[k] for k in order], K, Kinv, 0, 1, num_hypotheses, pose_mode, None, None)
+    def view(v):
+        return feats[view_slot(v, world, slots)][:rec_bytes].reshape(max_pts, 576), counts[v]
+
+    mine = pair_schedule(len(pairs), rank, world)
     max_local = (len(pairs) + world - 1) // world
     rec = np.full((max_local, RESULT_FLOATS + 1), -1.0, np.float32)
-    for slot, pid in enumerate(order):
-        rec[slot, :RESULT_FLOATS] = res[slot]
+    usable = [pid for pid in mine if counts[pairs[pid][0]] >= 8 and counts[pairs[pid][1]] >= 1]
+    ip = ImagePair(ctx, K, Kinv, 2, max(counts[pairs[pid][0]] for pid in usable)) if usable else None
+    for slot, pid in enumerate(usable):
+        i, j = pairs[pid]
+        (s1, n1), (s2, n2) = view(i), view(j)
+        ctx.match(s1, n1, s2, n2)
+        rec[slot, :RESULT_FLOATS] = _two_view(ip, s1, n1, num_hypotheses, pose_mode)
         rec[slot, RESULT_FLOATS] = pid
+    if ip is not None:
+        ip.close()
     local = torch.from_numpy(rec).to(dev)
     gathered = gather_results(local) if (gather_results is not None and world > 1) else local
     g = gathered.cpu().numpy().reshape(-1, RESULT_FLOATS + 1)

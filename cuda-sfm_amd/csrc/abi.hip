@@ -338,6 +338,7 @@ int sfm_pair_create(sfm_ctx *ctx, const float h_K[9], const float h_Kinv[9], int
     p->ctx = ctx;
     p->image_count = image_count;
     p->n = num_points;
+    p->cap_points = num_points;
     p->ld = round_up(num_points, 128);
     memcpy(p->h_Kinv, h_Kinv, sizeof(p->h_Kinv));
     int rc = SFM_OK;
@@ -357,6 +358,18 @@ int sfm_pair_create(sfm_ctx *ctx, const float h_K[9], const float h_Kinv[9], int
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);       // host K arrays may go out of scope
     if (e != hipSuccess) { sfm_pair_destroy(p); set_error("pair init failed: %s", hipGetErrorString(e)); return SFM_E_HIP; }
     *out = p;
+    return SFM_OK;
+}
+
+int sfm_pair_reset(sfm_pair *pair, int num_points)
+{
+    SFM_REQUIRE(pair, SFM_E_INVALID, "null pair");
+    SFM_REQUIRE(num_points > 0 && num_points <= pair->cap_points, SFM_E_INVALID,
+                "num_points %d outside (0, %d] (the size the pair was created with)", num_points, pair->cap_points);
+    pair->n = num_points;
+    pair->ld = round_up(num_points, 128);
+    pair->have_points = pair->have_E = pair->have_P = pair->have_pose = false;
+    pair->last_count = 0;
     return SFM_OK;
 }
 
@@ -611,6 +624,24 @@ int sfm_get_pose_index(sfm_pair *pair, int *index)
     if (rc != SFM_OK) return rc;
     *index = v[0];
     if (v[5] & (1 << v[0])) { set_error("chosen pose candidate %d is singular", v[0]); return SFM_E_SINGULAR; }
+    return SFM_OK;
+}
+
+int sfm_get_result(sfm_pair *pair, float h_record[28])
+{
+    SFM_REQUIRE(pair && h_record, SFM_E_INVALID, "null argument");
+    SFM_REQUIRE(pair->have_E && pair->have_pose, SFM_E_STATE, "estimateE / choosePose have not run");
+    float P[64]; int v[8]; uint32_t b[2];
+    hipStream_t st = pair->ctx->stream;
+    SFM_HIP_TRY(hipMemcpyAsync(h_record, pair->d_E, 9 * sizeof(float), hipMemcpyDeviceToHost, st));
+    SFM_HIP_TRY(hipMemcpyAsync(P, pair->pose_mode == SFM_POSE_REFERENCE ? pair->d_Pinv : pair->d_P, sizeof(P), hipMemcpyDeviceToHost, st));
+    SFM_HIP_TRY(hipMemcpyAsync(v, pair->d_Pind, sizeof(v), hipMemcpyDeviceToHost, st));
+    SFM_HIP_TRY(hipMemcpyAsync(b, pair->d_best, sizeof(b), hipMemcpyDeviceToHost, st));
+    SFM_HIP_TRY(hipStreamSynchronize(st));
+    const int ind = v[0] >= 0 && v[0] < 4 ? v[0] : 0;
+    for (int k = 0; k < 16; ++k) h_record[9 + k] = P[16 * ind + k];
+    h_record[25] = (float)v[0]; h_record[26] = (float)b[1]; h_record[27] = (float)b[0];
+    if (v[5] & (1 << ind)) { set_error("chosen pose candidate %d is singular", ind); return SFM_E_SINGULAR; }
     return SFM_OK;
 }
 

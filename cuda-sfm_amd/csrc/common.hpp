@@ -72,6 +72,7 @@ struct sfm_pair {
     sfm_ctx *ctx = nullptr;
     int image_count = 2;
     int n = 0;          // num_points
+    int cap_points = 0; // creation-time num_points (sfm_pair_reset may shrink n below it)
     int ld = 0;         // padded row length of X / U (multiple of 128, tail = NaN)
     float *d_K = nullptr, *d_Kinv = nullptr;
     float *d_U[2] = { nullptr, nullptr };

@@ -58,6 +58,14 @@ public:
         params_.hyp_begin = 0; params_.hyp_count = 0;
     }
     void setPoseMode(int mode) { pose_mode_ = mode; }
+    // another correspondence set of at most the constructor's num_points, without re-allocating anything
+    void reset(int num_points)
+    {
+        SFM_FACADE_CALL(sfm_pair_reset(pair_, num_points));
+        num_points_ = num_points;
+        sfm_ransac_default_params(&params_, num_points);
+    }
+    void getResult(float record[28]) { SFM_FACADE_CALL(sfm_get_result(pair_, record)); }
     int numPoints() const { return num_points_; }
     sfm_pair *handle() { return pair_; }
 

@@ -135,6 +135,10 @@ int sfm_find_homography(sfm_ctx *ctx, const sfm_sift_point *d_sift, int num_pts,
 int sfm_pair_create(sfm_ctx *ctx, const float h_K[9], const float h_Kinv[9],
                     int image_count, int num_points, sfm_pair **out);
 int sfm_pair_destroy(sfm_pair *pair);                                      /* sfm.cu:346-359 */
+/* Re-use an Image_pair for another correspondence set of at most its creation-time size: no allocation, no
+ * synchronisation (the reference constructs one Image_pair per image pair, main.cpp:298 -- ~20 cudaMalloc/cudaFree
+ * each; a many-pairs driver creates one at the largest size and resets it). */
+int sfm_pair_reset(sfm_pair *pair, int num_points);
 
 /* Image_pair::fillXU(SiftPoint *data), sfm.cu:80-92 (+ copy_point kernels.h:261-279). */
 int sfm_fill_xu(sfm_pair *pair, const sfm_sift_point *d_data);
@@ -215,6 +219,9 @@ int sfm_get_pose_candidates(sfm_pair *pair, float h_P[64]);
 int sfm_get_pose_inverses(sfm_pair *pair, float h_Pinv[64]);
 int sfm_get_pose_index(sfm_pair *pair, int *index);
 int sfm_get_points(sfm_pair *pair, float *h_points /* 4 x num_points */);
+/* Everything a many-pairs driver keeps of one pair, with ONE synchronisation:
+ * [E (9) | chosen pose 4x4 (16): P^-1 in SFM_POSE_REFERENCE, P in SFM_POSE_CORRECT | pose index, inlier count, best hypothesis]. */
+int sfm_get_result(sfm_pair *pair, float h_record[28]);
 /* Image_pair::copyBoidsToVBO (sfm.cu:374-383; kernCopyPositionsToVBO / kernCopyVelocitiesToVBO kernels.h:471-494):
  * interleaved (x, y, z, 1) * scale vertices and the constant (1, 1, 1, 1) colour buffer, written to DEVICE
  * buffers of 4 * num_points floats each (in the reference: the mapped GL buffer objects).  Either may be NULL. */

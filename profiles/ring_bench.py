@@ -1,0 +1,33 @@
+"""BASELINE configs[4] on ONE GPU: 36 views (720x576, the dino frame size) -> ExtractSift per view -> ring pairs
+(36) and all unordered pairs (630): MatchSiftData + fillXU + estimateE (H = N/8) + pose + triangulation per pair
+(cuda_sfm_amd.process_views; with --gpus N the views and pairs are dealt round-robin over the ranks).
+Synthetic views (one textured scene, camera sliding along x).  Run on the GPU box: python profiles/ring_bench.py"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import cuda_sfm_amd as S
+from cuda_sfm_amd import synth
+
+dev = torch.device("cuda:0")
+ctx = S.Context(0, torch.cuda.current_stream().cuda_stream)
+V, w, h = 36, 720, 576
+base = np.array([5.0, 8.0, 12.0, 16.0, 7.0, 10.0], np.float32)
+views = [synth.stereo_pair(w, h, seed=9, disparities=tuple((0.1 * k) * base))[1] if k else synth.stereo_pair(w, h, seed=9)[0] for k in range(V)]
+K, Kinv = synth.camera(w, h)
+sift = dict(num_octaves=5, init_blur=1.5, thresh=1.0)          # src/main.cpp:267-277
+for name, pairs in (("ring_36_pairs", S.ring_pairs(V)), ("all_630_pairs", [(i, j) for i in range(V) for j in range(i + 1, V)])):
+    S.process_views(ctx, views[:4], K, Kinv, max_pts=8192, sift=sift, device=dev)      # warm-up (buffers, clocks)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    res, counts = S.process_views(ctx, views, K, Kinv, pairs=pairs, max_pts=8192, sift=sift, device=dev)
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    inl = [int(r[26]) for r in res.values()]
+    print(json.dumps({name: {"views": V, "pairs": len(pairs), "done": len(res), "features_per_view": [min(counts), max(counts)],
+                             "ms_total": 1e3 * dt, "ms_per_pair": 1e3 * dt / len(pairs), "median_inliers": int(np.median(inl)),
+                             "note": "host images -> device inside the timed region (PCIe-inclusive), Python orchestration"}}))

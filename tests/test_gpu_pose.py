@@ -5,7 +5,7 @@ import pytest
 import cuda_sfm_amd as S
 from cuda_sfm_amd import synth
 import oracle as O
-from helpers import same_bits, make_pair
+from helpers import same_bits, make_pair, to_dev
 
 pytestmark = pytest.mark.gpu
 
@@ -77,3 +77,42 @@ def test_copy_points_to_vbo(gpu):
     want = np.stack([pts[0] * np.float32(2), pts[1] * np.float32(2), pts[2] * np.float32(2), np.ones(n, np.float32)], 1)
     assert same_bits(pos.cpu().numpy(), want) and (vel.cpu().numpy() == 1.0).all()
     pair.copy_points_to_vbo(pos, None)                                  # either buffer may be absent
+
+
+def test_pair_reset_reuses_buffers_and_result_record(gpu):
+    """sfm_pair_reset: one Image_pair serves correspondence sets of different sizes (<= its creation size) with the
+    results a fresh pair gives; sfm_get_result is the individual getters in one record."""
+    torch, dev, ctx = gpu
+    big, small = synth.two_view_scene(3000, seed=31), synth.two_view_scene(1700, seed=32)
+
+    def run(pair, scene, mode):
+        n = len(scene["sift"])
+        pair.fillXU(to_dev(torch, dev, scene["sift"]))
+        pair.estimateE(S.default_params(n, num_hypotheses=700, seed=3))
+        pair.computePosecandidates(mode); pair.choosePose(mode); pair.linear_triangulation(mode)
+        rec = pair.get_result()
+        hyp, cnt = pair.get_best()
+        pind = pair.get_pose_index()
+        P = (pair.get_pose_inverses() if mode == S.POSE_REFERENCE else pair.get_pose_candidates())[pind]
+        assert same_bits(rec[:9], pair.get_E().reshape(9)) and same_bits(rec[9:25], P.reshape(16))
+        assert tuple(int(v) for v in rec[25:28]) == (pind, cnt, hyp)
+        return rec, pair.get_inlier_mask().copy(), pair.get_points().copy()
+
+    fresh = {}
+    for name, sc in (("big", big), ("small", small)):
+        p = S.ImagePair(ctx, sc["K"], sc["Kinv"], 2, len(sc["sift"]))
+        fresh[name] = [run(p, sc, m) for m in (S.POSE_REFERENCE, S.POSE_CORRECT)]
+        p.close()
+    pool = S.ImagePair(ctx, big["K"], big["Kinv"], 2, 3000)
+    for name, sc in (("big", big), ("small", small), ("big", big), ("small", small)):
+        pool.reset(len(sc["sift"]))
+        with pytest.raises(S.SfmError):                       # state is cleared: nothing to read before fillXU / estimateE
+            pool.get_result()
+        for k, m in enumerate((S.POSE_REFERENCE, S.POSE_CORRECT)):
+            rec, mask, pts = run(pool, sc, m)
+            assert same_bits(rec, fresh[name][k][0]) and np.array_equal(mask, fresh[name][k][1]) and same_bits(pts, fresh[name][k][2])
+    with pytest.raises(S.SfmError) as e:
+        pool.reset(3001)
+    assert e.value.code == S.E_INVALID
+    with pytest.raises(S.SfmError):
+        pool.reset(0)
