@@ -243,13 +243,15 @@ int launch_match(sfm_ctx *ctx, const float *d1, int n1, int ld1, const float *d2
                  sfm_sift_point *sift1, const sfm_sift_point *sift2)
 {
     if (n1 <= 0 || n2 <= 0) return SFM_OK;                 // matching.cu:1095-1096
-    const int ct = n1 > 4096 ? 2 : 1;
-    const int wv = n1 > 4096 ? 8 : 4;                       // wavefronts per block
+    const int big = 5000;                                   // measured crossover of the two configurations (4500: 0.065 vs 0.074 ms, 5500: 0.105 vs 0.091)
+    const int ct = n1 > big ? 2 : 1;
+    const int wv = n1 > big ? 8 : 4;                       // wavefronts per block
     const int qper = ct * 32 * wv;                          // queries per block
     const int qblocks = (n1 + qper - 1) / qper;
-    // enough (query block, database split) pairs to fill every CU (2 blocks/CU at W = 4, 1 at W = 8)
-    const int want = (wv == 8 ? 1 : 2) * ctx->num_cus;
-    int nsplit = (want + qblocks - 1) / qblocks;
+    // (query block, database split) pairs: as many as fit in ONE round over the CUs, not more -- rounding the split
+    // count up (11 x 24 = 264 blocks on 256 CUs) costs a whole second round (12000 x 12000: 0.44 -> 0.30 ms), and two
+    // blocks per CU of the small configuration only add prologues and partials (2048 x 2048: 0.026 -> 0.022 ms)
+    int nsplit = ctx->num_cus / qblocks;
     const int max_split = (n2 + kRowsPerStage - 1) / kRowsPerStage;
     if (nsplit > max_split) nsplit = max_split;
     if (nsplit < 1) nsplit = 1;
