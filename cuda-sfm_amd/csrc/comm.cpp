@@ -13,7 +13,6 @@ struct sfm_comm {
     sfm_ctx *ctx = nullptr;
     ncclComm_t nccl = nullptr;
     int rank = 0, nranks = 1;
-    uint64_t *d_key = nullptr;          // the 8 bytes that travel
 };
 
 namespace {
@@ -50,7 +49,6 @@ extern "C" int sfm_comm_init(sfm_ctx *ctx, const void *id128, int rank, int nran
     ncclUniqueId id = *static_cast<const ncclUniqueId *>(id128);
     ncclResult_t r = ncclCommInitRank(&c->nccl, nranks, id, rank);
     if (r != ncclSuccess) { delete c; return fail("ncclCommInitRank", ncclGetErrorString(r)); }
-    if (hipMalloc(&c->d_key, sizeof(uint64_t)) != hipSuccess) { ncclCommDestroy(c->nccl); delete c; return SFM_E_NOMEM; }
     *out = c;
     return SFM_OK;
 }
@@ -59,7 +57,6 @@ extern "C" int sfm_comm_destroy(sfm_comm *c)
 {
     if (!c) return SFM_OK;
     (void)sfm_ctx_synchronize(c->ctx);
-    if (c->d_key) (void)hipFree(c->d_key);
     if (c->nccl) (void)ncclCommDestroy(c->nccl);
     delete c;
     return SFM_OK;
@@ -86,8 +83,11 @@ extern "C" int sfm_estimate_E_sharded(sfm_pair *pair, sfm_ransac_params *p, sfm_
     if (rc != SFM_OK) return rc;
     rc = sfm_ransac_score(pair, p);
     if (rc != SFM_OK) return rc;
-    rc = sfm_ransac_export_key(pair, c->d_key);
+    // the key travels in place: all-reduce the pair's own 8 bytes, finalize from them (no export copy)
+    void *d_key = nullptr; size_t bytes = 0;
+    rc = sfm_pair_device_ptr(pair, SFM_BUF_KEY, &d_key, &bytes);
     if (rc != SFM_OK) return rc;
-    COMM_NCCL_TRY(ncclAllReduce(c->d_key, c->d_key, 1, ncclUint64, ncclMax, c->nccl, static_cast<hipStream_t>(stream)));
-    return sfm_ransac_finalize_key(pair, p, c->d_key);
+    if (!d_key || bytes < sizeof(uint64_t)) return fail("sfm_pair_device_ptr", "no key buffer");
+    COMM_NCCL_TRY(ncclAllReduce(d_key, d_key, 1, ncclUint64, ncclMax, c->nccl, static_cast<hipStream_t>(stream)));
+    return sfm_ransac_finalize_key(pair, p, static_cast<const uint64_t *>(d_key));
 }
