@@ -39,6 +39,7 @@ void ransac_solve_lanes(const float *__restrict__ X0, const float *__restrict__ 
 }
 
 // Two hypotheses per lane (2i, 2i+1): every mul / add / fma of the solver is a v_pk_*_f32.
+template <bool QR>
 __global__ __launch_bounds__(64)
 void ransac_solve_lanes2(const float *__restrict__ X0, const float *__restrict__ X1, int ld, int n,
                          const int32_t *__restrict__ indices, uint32_t seed, uint32_t h0, uint32_t count,
@@ -48,7 +49,7 @@ void ransac_solve_lanes2(const float *__restrict__ X0, const float *__restrict__
     if (i >= count) return;
     const uint32_t j = (i + 1 < count) ? i + 1 : i;         // odd count: the last lane solves its hypothesis twice
     v2f E[9];
-    solve_two(X0, X1, ld, n, indices, seed, h0 + i, h0 + j, sweeps, E);
+    solve_two<QR>(X0, X1, ld, n, indices, seed, h0 + i, h0 + j, sweeps, E);
 #pragma unroll
     for (int k = 0; k < 9; ++k) Ecand[9 * (size_t)i + k] = E[k].x;
     if (j != i) {
@@ -206,8 +207,12 @@ int launch_ransac_score(sfm_pair *pair, const sfm_ransac_params &p, uint32_t h0,
         hipLaunchKernelGGL(ransac_solve_lanes, dim3((count + 63) / 64), dim3(64), 0, ctx->stream,
                            pair->d_X[0], pair->d_X[1], pair->ld, pair->n, p.d_indices, p.seed, h0, count,
                            p.jacobi_sweeps, pair->d_Ecand);
-    else                             // default: two hypotheses per lane (packed math)
-        hipLaunchKernelGGL(ransac_solve_lanes2, dim3((count + 127) / 128), dim3(64), 0, ctx->stream,
+    else if (p.jacobi_sweeps <= 0)   // default: two hypotheses per lane (packed math), Householder instantiation
+        hipLaunchKernelGGL(ransac_solve_lanes2<true>, dim3((count + 127) / 128), dim3(64), 0, ctx->stream,
+                           pair->d_X[0], pair->d_X[1], pair->ld, pair->n, p.d_indices, p.seed, h0, count,
+                           p.jacobi_sweeps, pair->d_Ecand);
+    else
+        hipLaunchKernelGGL(ransac_solve_lanes2<false>, dim3((count + 127) / 128), dim3(64), 0, ctx->stream,
                            pair->d_X[0], pair->d_X[1], pair->ld, pair->n, p.d_indices, p.seed, h0, count,
                            p.jacobi_sweeps, pair->d_Ecand);
     SFM_HIP_TRY(hipGetLastError());

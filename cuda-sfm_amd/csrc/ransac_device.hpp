@@ -44,6 +44,8 @@ __device__ __forceinline__ void solve_one(const float *__restrict__ X0, const fl
 
 // Two hypotheses per lane through the packed (v2f) instantiation of the solver: element 0 = hypA,
 // element 1 = hypB.  Bit-identical per hypothesis to solve_one.
+// QR = true instantiates the Householder solver only (no Jacobi code, a third of its registers); false dispatches on sweeps.
+template <bool QR = false>
 __device__ __forceinline__ void solve_two(const float *__restrict__ X0, const float *__restrict__ X1, int ld, int n,
                                           const int32_t *__restrict__ indices, uint32_t seed, uint32_t hypA, uint32_t hypB,
                                           int sweeps, v2f E[9])
@@ -59,7 +61,8 @@ __device__ __forceinline__ void solve_two(const float *__restrict__ X0, const fl
             x1[k][a] = v2f{ X0[(size_t)a * ld + ia[k]], X0[(size_t)a * ld + ib[k]] };
             x2[k][a] = v2f{ X1[(size_t)a * ld + ia[k]], X1[(size_t)a * ld + ib[k]] };
         }
-    nullvec9(x1, x2, sweeps, E);
+    if (QR) nullvec9_householder(x1, x2, E);
+    else nullvec9(x1, x2, sweeps, E);
     normalize_E(E);
 }
 
