@@ -215,7 +215,9 @@ void ransac_fused_waves(const float *__restrict__ X0, const float *__restrict__ 
                 Ecand[9 * (size_t)i + lane] = v;
             }
         }
-        const Ess E{ e[0], e[1], e[2], e[3], e[4], e[5], e[6], e[7], e[8] };
+        // every lane holds the same E: move it to scalar registers (the scoring loop reads E as SGPR operands)
+        auto sreg = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); };
+        const Ess E{ sreg(e[0]), sreg(e[1]), sreg(e[2]), sreg(e[3]), sreg(e[4]), sreg(e[5]), sreg(e[6]), sreg(e[7]), sreg(e[8]) };
         int cnt = 0;
         for (int t = 0; t < ntiles; ++t) {
             if (ntiles > 1 || !staged) {
