@@ -291,37 +291,13 @@ int sfm_find_homography(sfm_ctx *ctx, const sfm_sift_point *d_sift, int num_pts,
     if (!d_sift || num_pts < 8 || num_loops <= 0) return SFM_OK;                // matching.cu:1010-1018
     SFM_HIP_TRY(hipSetDevice(ctx->device));
     const int L = round_up(num_loops, 16);                                      // matching.cu:1015
-    std::vector<int32_t> pts;
-    if (!h_pts) {
-        // score / ambiguity gate on the host, as the reference does (matching.cu:1030-1036)
-        std::vector<float> sc((size_t)num_pts), am((size_t)num_pts);
-        SFM_HIP_TRY(hipMemcpy2DAsync(sc.data(), 4, &d_sift[0].score, sizeof(sfm_sift_point), 4, (size_t)num_pts, hipMemcpyDeviceToHost, ctx->stream));
-        SFM_HIP_TRY(hipMemcpy2DAsync(am.data(), 4, &d_sift[0].ambiguity, sizeof(sfm_sift_point), 4, (size_t)num_pts, hipMemcpyDeviceToHost, ctx->stream));
-        SFM_HIP_TRY(hipStreamSynchronize(ctx->stream));
-        std::vector<int32_t> valid;
-        for (int i = 0; i < num_pts; ++i)
-            if (sc[i] > min_score && am[i] < max_ambiguity) valid.push_back(i);
-        const uint32_t nv = (uint32_t)valid.size();
-        if (nv < 8) return SFM_OK;                                              // matching.cu:1037
-        // four distinct valid points per loop from the counter hash (replaces rand(), matching.cu:1038-1049)
-        pts.resize((size_t)4 * L);
-        for (int i = 0; i < L; ++i) {
-            const uint32_t base = hash32(hash32(seed ^ 0x48304D4Fu) + (uint32_t)i);
-            uint32_t pick[4]; int got = 0;
-            for (uint32_t k = 0; got < 4; ++k) {
-                const uint32_t c = mulhi32(hash32(base + k * 0x9E3779B9U), nv);
-                bool dup = false;
-                for (int j = 0; j < got; ++j) dup |= (pick[j] == c);
-                if (!dup) pick[got++] = c;
-            }
-            for (int k = 0; k < 4; ++k) pts[(size_t)k * L + i] = valid[pick[k]];
-        }
-        h_pts = pts.data();
-    } else {
+    if (h_pts) {
         for (size_t i = 0; i < (size_t)4 * L; ++i)
             SFM_REQUIRE(h_pts[i] >= 0 && h_pts[i] < num_pts, SFM_E_INVALID, "sample index %d out of range", h_pts[i]);
     }
-    return launch_homography(ctx, d_sift, num_pts, h_pts, L, thresh, h_H, num_matches, h_counts, h_homo);
+    // without an explicit sample the score / ambiguity gate (matching.cu:1030-1036) and the seeded sampler run on the device
+    int num_valid = 0;
+    return launch_homography(ctx, d_sift, num_pts, h_pts, L, thresh, min_score, max_ambiguity, seed, &num_valid, h_H, num_matches, h_counts, h_homo);
 }
 
 // ---- Image_pair ---------------------------------------------------------------------------------

@@ -127,6 +127,7 @@ int launch_extract_sift(sfm_ctx *ctx, sfm_sift_point *d_sift, int max_pts, const
                         int *num_pts, int *num_stored);
 // homography.hip
 int launch_homography(sfm_ctx *ctx, const sfm_sift_point *d_sift, int n, const int *h_pts, int L, float thresh,
+                      float min_score, float max_ambiguity, uint32_t seed, int *num_valid,
                       float h_H[9], int *num_matches, int *h_counts, float *h_homo);
 // match.hip
 int launch_match(sfm_ctx *ctx, const float *d1, int n1, int ld1, const float *d2, int n2, int ld2,

@@ -26,6 +26,68 @@ void homo_gather_kernel(const sfm_sift_point *__restrict__ s, int n, int ld, flo
     coord[3 * ld + j] = j < n ? s[j].match_ypos : qnan;
 }
 
+// score / ambiguity gate (matching.cu:1030-1036) as an order-preserving compaction: one block, every thread a
+// consecutive chunk, block scan of the chunk totals.  valid[0 .. nv) = indices of the gated points, ascending.
+__global__ __launch_bounds__(1024)
+void homo_gate_kernel(const sfm_sift_point *__restrict__ s, int n, float min_score, float max_ambiguity,
+                      int *__restrict__ valid, unsigned int *__restrict__ nv_out)
+{
+    __shared__ unsigned int wsum[17];
+    const int per = (n + 1023) / 1024;
+    const int lo = min(n, (int)threadIdx.x * per), hi = min(n, lo + per);
+    unsigned int mine = 0;
+    for (int i = lo; i < hi; ++i) mine += (s[i].score > min_score && s[i].ambiguity < max_ambiguity) ? 1u : 0u;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned int inc = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned int u = __shfl_up(inc, d);
+        if (lane >= d) inc += u;
+    }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned int acc = 0;
+        for (int i = 0; i < 16; ++i) { const unsigned int t = wsum[i]; wsum[i] = acc; acc += t; }
+        wsum[16] = acc;
+        *nv_out = acc;
+    }
+    __syncthreads();
+    unsigned int run = wsum[wave] + inc - mine;
+    for (int i = lo; i < hi; ++i)
+        if (s[i].score > min_score && s[i].ambiguity < max_ambiguity) valid[run++] = i;
+}
+
+// four distinct gated points per loop from the counter hash (replaces host rand(), matching.cu:1038-1049)
+__global__ __launch_bounds__(256)
+void homo_sample_kernel(const int *__restrict__ valid, const unsigned int *__restrict__ nv_in, uint32_t seed, int L, int *__restrict__ pts)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= L) return;
+    const uint32_t nv = *nv_in;
+    if (nv < 8u) {                                               // matching.cu:1037: the caller returns the identity
+#pragma unroll
+        for (int k = 0; k < 4; ++k) pts[(size_t)k * L + i] = 0;
+        return;
+    }
+    const uint32_t base = hash32(hash32(seed ^ 0x48304D4Fu) + (uint32_t)i);
+    uint32_t pick[4] = { 0, 0, 0, 0 };
+    int got = 0;
+    for (uint32_t k = 0; got < 4; ++k) {
+        const uint32_t c = mulhi32(hash32(base + k * 0x9E3779B9U), nv);
+        bool dup = false;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dup |= (j < got) & (pick[j] == c);
+        if (!dup) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (j == got) pick[j] = c;
+            ++got;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) pts[(size_t)k * L + i] = valid[pick[k]];
+}
+
 // 8x8 inverse: Crout LU with implicit (row-scaled) partial pivoting + eight back-substitutions
 // (the scheme of InvertMatrix<8>, matching.cu:821-905).  One matrix per thread, local arrays.
 __device__ void invert8(float (&e)[8][8], float (&res)[8][8])
@@ -108,36 +170,96 @@ void homo_solve_kernel(const float *__restrict__ coord, int ld, const int *__res
     }
 }
 
-// one hypothesis per wavefront (TestHomographies, matching.cu:953-996)
-__global__ __launch_bounds__(256)
-void homo_score_kernel(const float *__restrict__ coord, int ld, int n, const float *__restrict__ homo, int L,
-                       float thresh2, int *__restrict__ counts, unsigned long long *best_key)
+// ---- TestHomographies (matching.cu:953-996): one hypothesis per wavefront, points in LDS --------------------
+// The reference rounds every product of the test toward zero (__fmul_rz) and every sum to nearest.  hipcc turns each
+// __fmul_rz into a CALL of __ocml_mul_rtz_f32 (two mode-register writes per product); here the FP32 rounding mode
+// (MODE[1:0]) is switched once per GROUP of products, and a group is ONE asm statement -- mode switch, products, mode
+// switch back -- so neither the compiler nor the scheduler can move a product out of, or a sum into, the
+// round-toward-zero region.  Same results bit for bit (tests/test_gpu_homography.py runs the reference's own kernel).
+#define SFM_RZ_ON  "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3\n\ts_nop 0\n\t"
+#define SFM_RZ_OFF "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0\n\ts_nop 0"
+
+__device__ __forceinline__ bool homo_inlier(const float (&a)[8], float thresh2, float x1, float y1, float x2, float y2)
 {
+    float p0, p1, p2, p3, p4, p5;
+    asm volatile(SFM_RZ_ON
+                 "v_mul_f32 %0, %6, %12\n\tv_mul_f32 %1, %7, %13\n\tv_mul_f32 %2, %8, %12\n\t"
+                 "v_mul_f32 %3, %9, %13\n\tv_mul_f32 %4, %10, %12\n\tv_mul_f32 %5, %11, %13\n\t" SFM_RZ_OFF
+                 : "=&v"(p0), "=&v"(p1), "=&v"(p2), "=&v"(p3), "=&v"(p4), "=&v"(p5)
+                 : "s"(a[0]), "s"(a[1]), "s"(a[3]), "s"(a[4]), "s"(a[6]), "s"(a[7]), "v"(x1), "v"(y1));
+    const float nomx = (p0 + p1) + a[2];
+    const float nomy = (p2 + p3) + a[5];
+    const float deno = (p4 + p5) + 1.0f;
+    float q0, q1, q2;
+    asm volatile(SFM_RZ_ON "v_mul_f32 %0, %3, %5\n\tv_mul_f32 %1, %4, %5\n\tv_mul_f32 %2, %5, %5\n\t" SFM_RZ_OFF
+                 : "=&v"(q0), "=&v"(q1), "=&v"(q2) : "v"(x2), "v"(y2), "v"(deno));
+    const float errx = q0 - nomx, erry = q1 - nomy;
+    float r0, r1, r2;
+    asm volatile(SFM_RZ_ON "v_mul_f32 %0, %3, %3\n\tv_mul_f32 %1, %4, %4\n\tv_mul_f32 %2, %5, %6\n\t" SFM_RZ_OFF
+                 : "=&v"(r0), "=&v"(r1), "=&v"(r2) : "v"(errx), "v"(erry), "s"(thresh2), "v"(q2));
+    return (r0 + r1) < r2;
+}
+
+constexpr int kHomoTile = 8192;            // points per LDS tile: 16 B each, 128 KiB
+
+// Persistent blocks: a tile of points is staged once per block as (x1, y1, x2, y2) records, every hypothesis batch of
+// the block runs over it (the coordinates used to be re-read from L2 by every wavefront: latency-bound, 15x off).
+template <int WPB>
+__global__ __launch_bounds__(WPB * 64)
+void homo_score_kernel(const float *__restrict__ coord, int ld, int n, const float *__restrict__ homo, int L,
+                       float thresh2, int ntiles, int *__restrict__ counts, unsigned long long *best_key)
+{
+    extern __shared__ __attribute__((aligned(16))) float4 htile[];
     const int lane = threadIdx.x & 63;
-    const int l = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
-    if (l >= L) return;
-    float a[8];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nbatch = (L + WPB - 1) / WPB;
+    unsigned long long wbest = 0;
+    for (int t = 0; t < ntiles; ++t) {
+        if (t > 0) __syncthreads();
+        const int first = t * kHomoTile, len = min(kHomoTile, n - first);
+        for (int k = threadIdx.x; k < len; k += WPB * 64)
+            htile[k] = make_float4(coord[first + k], coord[ld + first + k], coord[2 * ld + first + k], coord[3 * ld + first + k]);
+        __syncthreads();
+        for (int batch = blockIdx.x; batch < nbatch; batch += gridDim.x) {
+            const int l = __builtin_amdgcn_readfirstlane(batch * WPB + wave);
+            if (l >= L) continue;
+            auto sreg = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); };
+            float a[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) a[k] = homo[k * L + l];
-    int cnt = 0;
-    for (int i0 = 0; i0 < n; i0 += 64) {
-        const int i = i0 + lane;
-        bool in = false;
-        if (i < n) {
-            const float x1 = coord[i], y1 = coord[i + ld], x2 = coord[i + 2 * ld], y2 = coord[i + 3 * ld];
-            const float nomx = (__fmul_rz(a[0], x1) + __fmul_rz(a[1], y1)) + a[2];
-            const float nomy = (__fmul_rz(a[3], x1) + __fmul_rz(a[4], y1)) + a[5];
-            const float deno = (__fmul_rz(a[6], x1) + __fmul_rz(a[7], y1)) + 1.0f;
-            const float errx = __fmul_rz(x2, deno) - nomx;
-            const float erry = __fmul_rz(y2, deno) - nomy;
-            const float err2 = __fmul_rz(errx, errx) + __fmul_rz(erry, erry);
-            in = err2 < __fmul_rz(thresh2, __fmul_rz(deno, deno));
+            for (int k = 0; k < 8; ++k) a[k] = sreg(homo[k * L + l]);
+            const float th = sreg(thresh2);
+            int cnt = 0;
+            for (int i0 = 0; i0 < len; i0 += 64) {
+                const int i = i0 + lane;
+                const float4 p = htile[min(i, len - 1)];
+                const bool in = homo_inlier(a, th, p.x, p.y, p.z, p.w) && i < len;
+                cnt += __builtin_popcountll(__ballot(in));
+            }
+            if (ntiles > 1) {
+                int total = cnt;
+                if (lane == 0) {
+                    if (t > 0) total += counts[l];
+                    counts[l] = total;
+                }
+                cnt = __builtin_amdgcn_readfirstlane(total);
+            } else if (lane == 0) {
+                counts[l] = cnt;
+            }
+            if (t == ntiles - 1) {
+                const unsigned long long key = pack_key((uint32_t)cnt, (uint32_t)l);      // first maximum wins (matching.cu:1066-1070)
+                wbest = key > wbest ? key : wbest;
+            }
         }
-        cnt += __builtin_popcountll(__ballot(in));
     }
-    if (lane == 0) {
-        counts[l] = cnt;
-        atomicMax(best_key, pack_key((uint32_t)cnt, (uint32_t)l));      // first maximum wins (matching.cu:1066-1070)
+    __syncthreads();
+    unsigned long long *sbest = reinterpret_cast<unsigned long long *>(htile);           // tile no longer needed
+    if (lane == 0) sbest[wave] = wbest;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long b = sbest[0];
+#pragma unroll
+        for (int w = 1; w < WPB; ++w) b = sbest[w] > b ? sbest[w] : b;
+        if (b) atomicMax(best_key, b);
     }
 }
 
@@ -152,12 +274,15 @@ __global__ void homo_finalize_kernel(const float *__restrict__ homo, int L, cons
     reinterpret_cast<int *>(out)[9] = (int)(k >> 32);
 }
 
+// h_pts == nullptr: gate (min_score, max_ambiguity) and seeded sample on the device; *num_valid receives the number of
+// gated points (< 8: the results are meaningless and the caller returns the identity, matching.cu:1037).
 int launch_homography(sfm_ctx *ctx, const sfm_sift_point *d_sift, int n, const int *h_pts, int L, float thresh,
+                      float min_score, float max_ambiguity, uint32_t seed, int *num_valid,
                       float h_H[9], int *num_matches, int *h_counts, float *h_homo)
 {
     hipStream_t st = ctx->stream;
     const int ld = round_up(n, 64);
-    const size_t need = (size_t)4 * ld * 4 + (size_t)4 * L * 4 + (size_t)8 * L * 4 + (size_t)L * 4 + 64;
+    const size_t need = (size_t)4 * ld * 4 + (size_t)4 * L * 4 + (size_t)8 * L * 4 + (size_t)L * 4 + (size_t)ld * 4 + 64;
     if (need > ctx->homo_ws_bytes) {
         SFM_HIP_TRY(hipStreamSynchronize(st));
         if (ctx->homo_ws) (void)hipFree(ctx->homo_ws);
@@ -172,19 +297,47 @@ int launch_homography(sfm_ctx *ctx, const sfm_sift_point *d_sift, int n, const i
     int *d_pts = reinterpret_cast<int *>(d_coord + (size_t)4 * ld);
     float *d_homo = reinterpret_cast<float *>(d_pts + (size_t)4 * L);
     int *d_counts = reinterpret_cast<int *>(d_homo + (size_t)8 * L);
+    int *d_valid = d_counts + L;
+    unsigned int *d_nv = reinterpret_cast<unsigned int *>(base + 8);
 
     SFM_HIP_TRY(hipMemsetAsync(d_key, 0, 8, st));
-    SFM_HIP_TRY(hipMemcpyAsync(d_pts, h_pts, (size_t)4 * L * sizeof(int), hipMemcpyHostToDevice, st));
+    if (h_pts) {
+        SFM_HIP_TRY(hipMemcpyAsync(d_pts, h_pts, (size_t)4 * L * sizeof(int), hipMemcpyHostToDevice, st));
+    } else {
+        hipLaunchKernelGGL(homo_gate_kernel, dim3(1), dim3(1024), 0, st, d_sift, n, min_score, max_ambiguity, d_valid, d_nv);
+        hipLaunchKernelGGL(homo_sample_kernel, dim3((L + 255) / 256), dim3(256), 0, st, d_valid, d_nv, seed, L, d_pts);
+    }
     hipLaunchKernelGGL(homo_gather_kernel, dim3((ld + 255) / 256), dim3(256), 0, st, d_sift, n, ld, d_coord);
     hipLaunchKernelGGL(homo_solve_kernel, dim3((L + 63) / 64), dim3(64), 0, st, d_coord, ld, d_pts, L, d_homo);
-    hipLaunchKernelGGL(homo_score_kernel, dim3((L + 3) / 4), dim3(256), 0, st, d_coord, ld, n, d_homo, L, thresh * thresh, d_counts, d_key);
+    {
+        constexpr int kWpb = 16;
+        const int tile = n < kHomoTile ? n : kHomoTile, ntiles = (n + kHomoTile - 1) / kHomoTile;
+        const size_t lds = (size_t)(tile > 64 ? tile : 64) * sizeof(float4);
+        if (lds > 64 * 1024) {
+            const int rc = allow_big_lds(ctx, reinterpret_cast<const void *>(&homo_score_kernel<kWpb>));
+            if (rc != SFM_OK) return rc;
+        }
+        const int nbatch = (L + kWpb - 1) / kWpb;
+        int per_cu = (int)((160 * 1024) / lds);
+        if (per_cu > 2) per_cu = 2;                              // 2048 threads per CU
+        if (per_cu < 1) per_cu = 1;
+        int blocks = nbatch / 8;                                 // as in launch_ransac_score: >= 8 batches per staged tile, finer grains beyond
+        if (blocks > 16 * ctx->num_cus) blocks = 16 * ctx->num_cus;
+        if (blocks < per_cu * ctx->num_cus) blocks = per_cu * ctx->num_cus;
+        if (blocks > nbatch) blocks = nbatch;
+        hipLaunchKernelGGL(homo_score_kernel<kWpb>, dim3(blocks), dim3(kWpb * 64), lds, st, d_coord, ld, n, d_homo, L, thresh * thresh, ntiles, d_counts, d_key);
+    }
     hipLaunchKernelGGL(homo_finalize_kernel, dim3(1), dim3(64), 0, st, d_homo, L, d_key, d_out);
     SFM_HIP_TRY(hipGetLastError());
     float out[10];
+    unsigned int nv = 0;
     SFM_HIP_TRY(hipMemcpyAsync(out, d_out, sizeof(out), hipMemcpyDeviceToHost, st));
+    if (!h_pts) SFM_HIP_TRY(hipMemcpyAsync(&nv, d_nv, sizeof(nv), hipMemcpyDeviceToHost, st));
     if (h_counts) SFM_HIP_TRY(hipMemcpyAsync(h_counts, d_counts, (size_t)L * sizeof(int), hipMemcpyDeviceToHost, st));
     if (h_homo) SFM_HIP_TRY(hipMemcpyAsync(h_homo, d_homo, (size_t)8 * L * sizeof(float), hipMemcpyDeviceToHost, st));
     SFM_HIP_TRY(hipStreamSynchronize(st));
+    if (num_valid) *num_valid = h_pts ? n : (int)nv;
+    if (!h_pts && nv < 8u) return SFM_OK;                                       // h_H / num_matches keep the caller's identity / 0
     for (int j = 0; j < 9; ++j) h_H[j] = out[j];
     *num_matches = __builtin_bit_cast(int, out[9]);
     return SFM_OK;
