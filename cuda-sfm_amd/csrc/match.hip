@@ -117,16 +117,19 @@ void match_mfma_kernel(const float *__restrict__ q, int nq, int ldq,
     {
         float4 regs[16 / W][2];
         constexpr int kChunks = CT * 32 * W / kRowsPerStage;
+        // chunks alternate between the two LDS buffers and the next chunk's global loads are in flight while this one is
+        // read back: one barrier per chunk, memory latency hidden behind the LDS reads
+        stage_load<W>(q, ldq, q0, nq, regs);
         for (int ch = 0; ch < kChunks; ++ch) {
-            stage_load<W>(q, ldq, q0 + ch * kRowsPerStage, nq, regs);
+            float *buf = lds[ch & 1];
+            stage_store<W>(buf, regs);
             __syncthreads();
-            stage_store<W>(lds[0], regs);
-            __syncthreads();
+            if (ch + 1 < kChunks) stage_load<W>(q, ldq, q0 + (ch + 1) * kRowsPerStage, nq, regs);
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) {
                 const int r = (wave * CT + ct) * 32 - ch * kRowsPerStage;     // first row of this column tile in the chunk
                 if (r >= 0 && r < kRowsPerStage) {
-                    const float *src = lds[0] + (r + col) * kLdsStride + 4 * half;
+                    const float *src = buf + (r + col) * kLdsStride + 4 * half;
 #pragma unroll
                     for (int m = 0; m < 16; ++m) {
                         const float4 v = *reinterpret_cast<const float4 *>(src + 8 * m);
