@@ -224,3 +224,18 @@ def test_rccl_comm_single_rank_equals_estimateE(gpu):
     assert pair.get_key() == ref[0] and same_bits(pair.get_E(), ref[1]) and np.array_equal(pair.get_inlier_mask(), ref[2])
     assert np.array_equal(pair.get_inlier_counts(H), ref[3])
     comm.close()
+
+
+@pytest.mark.parametrize("n,H", [(1000, 300000), (5000, 200000)])
+def test_many_hypotheses_oversubscribed_grid(gpu, n, H):
+    """Above 64k hypotheses the scoring grid is larger than what is co-resident (16 blocks per CU, each block running
+    several batches over its staged tile; with n > 4096 also over several tiles): every count against the oracle."""
+    scene = synth.two_view_scene(n, seed=300 + n)
+    pair, _ = make_pair(S, gpu, scene)
+    p = S.default_params(n, num_hypotheses=H, seed=12)
+    pair.estimateE(p)
+    assert pair.last_launch()["grid"] > 512
+    _, _, X0, X1 = oracle_xu(scene)
+    key, ocounts, _ = O.ransac_range(X0, X1, 0, H, p.threshold, p.jacobi_sweeps, seed=12)
+    assert np.array_equal(pair.get_inlier_counts(H), ocounts)
+    assert pair.get_key() == key
