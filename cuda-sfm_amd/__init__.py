@@ -47,9 +47,9 @@ assert SIFT_DTYPE.itemsize == 576
 
 EXPORTS = [
     "sfm_abi_version", "sfm_last_error", "sfm_ctx_create", "sfm_ctx_destroy", "sfm_ctx_set_stream",
-    "sfm_ctx_synchronize", "sfm_ctx_get_stream", "sfm_ctx_get_device", "sfm_ctx_timer_start", "sfm_ctx_timer_stop", "sfm_ctx_kernel_timing",
+    "sfm_ctx_synchronize", "sfm_ctx_own_stream", "sfm_ctx_get_stream", "sfm_ctx_get_device", "sfm_ctx_timer_start", "sfm_ctx_timer_stop", "sfm_ctx_kernel_timing",
     "sfm_ctx_kernel_timing_read", "sfm_device_alloc", "sfm_device_free", "sfm_copy_to_device", "sfm_copy_to_host",
-    "sfm_copy_to_host_2d", "sfm_copy_to_device_2d", "sfm_find_homography", "sfm_sift_temp_layout", "sfm_extract_sift", "sfm_match", "sfm_match_soa",
+    "sfm_copy_to_host_2d", "sfm_copy_to_device_2d", "sfm_find_homography", "sfm_sift_temp_layout", "sfm_extract_sift", "sfm_extract_sift_begin", "sfm_extract_sift_end", "sfm_match", "sfm_match_soa",
     "sfm_pair_create", "sfm_pair_destroy", "sfm_pair_reset", "sfm_get_result", "sfm_fill_xu", "sfm_set_points", "sfm_ransac_default_params",
     "sfm_ransac_permutation_indices", "sfm_estimate_E", "sfm_ransac_score", "sfm_ransac_finalize",
     "sfm_ransac_finalize_key", "sfm_ransac_export_key", "sfm_pose_candidates", "sfm_choose_pose", "sfm_triangulate",
@@ -89,6 +89,9 @@ class SiftLayout(C.Structure):
 _lib.sfm_sift_temp_layout.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(SiftLayout)]
 _lib.sfm_extract_sift.argtypes = [_vp, _vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_float, C.c_float,
                                   C.c_int, _vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+_lib.sfm_extract_sift_begin.argtypes = [_vp, _vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_float, C.c_float,
+                                        C.c_int, _vp]
+_lib.sfm_extract_sift_end.argtypes = [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
 _lib.sfm_copy_points_to_vbo.argtypes = [_vp, _vp, _vp, C.c_float]
 _lib.sfm_find_homography.argtypes = [_vp, _vp, C.c_int, _vp, C.POINTER(C.c_int), C.c_int, C.c_float, C.c_float,
                                      C.c_float, C.c_uint32, _vp, _vp, _vp]
@@ -203,6 +206,10 @@ class Context:
         """stream: raw hipStream_t value (e.g. torch.cuda.current_stream().cuda_stream) or None."""
         _check(_lib.sfm_ctx_set_stream(self._h, stream), "sfm_ctx_set_stream")
 
+    def own_stream(self):
+        """Give the context a non-blocking stream of its own (for a second context next to a torch-owned one)."""
+        _check(_lib.sfm_ctx_own_stream(self._h), "sfm_ctx_own_stream")
+
     def synchronize(self):
         _check(_lib.sfm_ctx_synchronize(self._h), "sfm_ctx_synchronize")
 
@@ -238,6 +245,19 @@ class Context:
         _check(_lib.sfm_extract_sift(self._h, _ptr(d_sift), int(max_pts), _ptr(d_image), int(width), int(height), int(pitch),
                                      int(num_octaves), float(init_blur), float(thresh), float(lowest_scale), int(bool(scale_up)),
                                      _ptr(d_temp), C.byref(n), C.byref(st)), "sfm_extract_sift")
+        return n.value, st.value
+
+    def extract_sift_begin(self, d_sift, max_pts, d_image, width, height, pitch, num_octaves=5, init_blur=1.0, thresh=3.0,
+                           lowest_scale=0.0, scale_up=False, d_temp=None):
+        """First half of extract_sift: everything enqueued on the context's stream, nothing waited for."""
+        _check(_lib.sfm_extract_sift_begin(self._h, _ptr(d_sift), int(max_pts), _ptr(d_image), int(width), int(height), int(pitch),
+                                           int(num_octaves), float(init_blur), float(thresh), float(lowest_scale), int(bool(scale_up)),
+                                           _ptr(d_temp)), "sfm_extract_sift_begin")
+
+    def extract_sift_end(self):
+        """Second half: waits for the extraction in flight -> (numPts, stored)."""
+        n, st = C.c_int(), C.c_int()
+        _check(_lib.sfm_extract_sift_end(self._h, C.byref(n), C.byref(st)), "sfm_extract_sift_end")
         return n.value, st.value
 
     def find_homography(self, d_sift, num_pts, num_loops=1000, min_score=0.85, max_ambiguity=0.95, thresh=5.0,

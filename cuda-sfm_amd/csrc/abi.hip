@@ -89,6 +89,8 @@ int sfm_ctx_destroy(sfm_ctx *ctx)
     if (ctx->homo_ws) (void)hipFree(ctx->homo_ws);
     if (ctx->sift_temp) (void)hipFree(ctx->sift_temp);
     if (ctx->sift_ws) (void)hipFree(ctx->sift_ws);
+    sift_job_free(ctx);
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     for (auto &t : ctx->tev) for (hipEvent_t e : t) if (e) (void)hipEventDestroy(e);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -99,7 +101,21 @@ int sfm_ctx_destroy(sfm_ctx *ctx)
 int sfm_ctx_set_stream(sfm_ctx *ctx, void *hip_stream)
 {
     SFM_REQUIRE(ctx, SFM_E_INVALID, "null context");
+    if (ctx->own_stream && ctx->stream) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamDestroy(ctx->stream); ctx->own_stream = false; }
     ctx->stream = static_cast<hipStream_t>(hip_stream);
+    return SFM_OK;
+}
+
+int sfm_ctx_own_stream(sfm_ctx *ctx)
+{
+    SFM_REQUIRE(ctx, SFM_E_INVALID, "null context");
+    if (ctx->own_stream) return SFM_OK;
+    SFM_HIP_TRY(hipSetDevice(ctx->device));
+    SFM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    hipStream_t st = nullptr;
+    SFM_HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    ctx->stream = st;
+    ctx->own_stream = true;
     return SFM_OK;
 }
 
@@ -278,6 +294,28 @@ int sfm_extract_sift(sfm_ctx *ctx, sfm_sift_point *d_sift, int max_pts, const fl
     SFM_HIP_TRY(hipSetDevice(ctx->device));
     return launch_extract_sift(ctx, d_sift, max_pts, d_image, width, height, pitch, num_octaves, init_blur, thresh, lowest_scale,
                                scale_up ? 1 : 0, d_temp, num_pts, num_stored);
+}
+
+int sfm_extract_sift_begin(sfm_ctx *ctx, sfm_sift_point *d_sift, int max_pts, const float *d_image, int width, int height,
+                           int pitch, int num_octaves, double init_blur, float thresh, float lowest_scale, int scale_up, float *d_temp)
+{
+    SFM_REQUIRE(ctx && d_sift && d_image, SFM_E_INVALID, "null argument");
+    SFM_REQUIRE(width > 0 && height > 0 && width <= 16384 && height <= 16384 && pitch >= width, SFM_E_INVALID,
+                "image %d x %d pitch %d", width, height, pitch);
+    SFM_REQUIRE(num_octaves >= 1 && num_octaves <= 7, SFM_E_INVALID, "num_octaves %d outside 1..7", num_octaves);
+    SFM_REQUIRE(max_pts > 0, SFM_E_INVALID, "max_pts %d", max_pts);
+    SFM_HIP_TRY(hipSetDevice(ctx->device));
+    return launch_extract_sift_begin(ctx, d_sift, max_pts, d_image, width, height, pitch, num_octaves, init_blur, thresh, lowest_scale,
+                                     scale_up ? 1 : 0, d_temp);
+}
+
+int sfm_extract_sift_end(sfm_ctx *ctx, int *num_pts, int *num_stored)
+{
+    SFM_REQUIRE(ctx && num_pts, SFM_E_INVALID, "null argument");
+    *num_pts = 0;
+    if (num_stored) *num_stored = 0;
+    SFM_HIP_TRY(hipSetDevice(ctx->device));
+    return launch_extract_sift_end(ctx, num_pts, num_stored);
 }
 
 // ---- FindHomography ------------------------------------------------------------------------------

@@ -31,6 +31,7 @@ inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 struct sfm_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    bool own_stream = false;           // created by sfm_ctx_own_stream, destroyed with the context
     int num_cus = 256;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // optional per-kernel stopwatch (sfm_ctx_kernel_timing): event triples around solve / score
@@ -47,6 +48,7 @@ struct sfm_ctx {
     size_t sift_temp_bytes = 0;
     void *sift_ws = nullptr;           // counters, candidates, secondary orientations
     size_t sift_ws_bytes = 0;
+    void *sift_job = nullptr;          // the extraction in flight (sift.hip: SiftJob), sfm_extract_sift_begin .. _end
     // kernels that already opted in to > 64 KiB of dynamic LDS on THIS context's device (function attributes are
     // per device; a context is used by one host thread at a time, so no process-wide flag)
     static constexpr int kBigLdsSlots = 16;
@@ -122,6 +124,10 @@ int launch_points_to_vbo(sfm_pair *pair, float *d_positions, float *d_velocities
 
 // sift.hip
 void sift_layout(int width, int height, int num_octaves, int scale_up, sfm_sift_layout *L);
+int launch_extract_sift_begin(sfm_ctx *ctx, sfm_sift_point *d_sift, int max_pts, const float *d_image, int width, int height, int pitch,
+                              int num_octaves, double init_blur, float thresh, float lowest_scale, int scale_up, float *d_temp);
+int launch_extract_sift_end(sfm_ctx *ctx, int *num_pts, int *num_stored);
+void sift_job_free(sfm_ctx *ctx);
 int launch_extract_sift(sfm_ctx *ctx, sfm_sift_point *d_sift, int max_pts, const float *d_image, int width, int height, int pitch,
                         int num_octaves, double init_blur, float thresh, float lowest_scale, int scale_up, float *d_temp,
                         int *num_pts, int *num_stored);

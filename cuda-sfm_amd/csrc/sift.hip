@@ -21,6 +21,7 @@
 #include "common.hpp"
 #include "sift_math.hpp"
 #include <cstring>
+#include <new>
 
 namespace sfm {
 using namespace sift;
@@ -789,11 +790,59 @@ static int grow(void **buf, size_t *have, size_t need, hipStream_t st)
     return SFM_OK;
 }
 
-int launch_extract_sift(sfm_ctx *ctx, sfm_sift_point *d_sift, int max_pts, const float *d_image, int width, int height, int pitch,
-                        int num_octaves, double init_blur, float thresh, float lowest_scale, int scale_up, float *d_temp,
-                        int *num_pts, int *num_stored)
+// One extraction in flight per context (sfm_extract_sift_begin .. sfm_extract_sift_end): everything the second half needs.
+struct SiftJob {
+    bool pending = false;
+    Levels LF;
+    Workspace W;
+    float *d_temp = nullptr;
+    sfm_sift_point *d_sift = nullptr;
+    char *ws = nullptr;
+    int n = 0, max_pts = 0, scale_up = 0, find_blocks = 0;
+    float thresh = 0.0f, lowest_scale = 0.0f;
+    size_t cap = 0;
+    LevelState *h_state = nullptr;        // pinned: the level totals come back asynchronously
+};
+
+static SiftJob *job_of(sfm_ctx *ctx)
+{
+    if (!ctx->sift_job) {
+        SiftJob *j = new (std::nothrow) SiftJob;
+        if (!j) return nullptr;
+        if (hipHostMalloc(reinterpret_cast<void **>(&j->h_state), 8 * sizeof(LevelState), hipHostMallocDefault) != hipSuccess) { delete j; return nullptr; }
+        ctx->sift_job = j;
+    }
+    return static_cast<SiftJob *>(ctx->sift_job);
+}
+
+void sift_job_free(sfm_ctx *ctx)
+{
+    SiftJob *j = static_cast<SiftJob *>(ctx->sift_job);
+    if (!j) return;
+    if (j->h_state) (void)hipHostFree(j->h_state);
+    delete j;
+    ctx->sift_job = nullptr;
+}
+
+// orientation -> output slots -> descriptors -> level totals on their way to the host (both passes end with this)
+static int enqueue_tail(sfm_ctx *ctx, SiftJob *j)
 {
     hipStream_t st = ctx->stream;
+    hipLaunchKernelGGL(sift_orient_kernel, dim3(2048), dim3(256), 0, st, j->d_temp, j->LF, j->W);
+    hipLaunchKernelGGL(sift_place_kernel, dim3(j->n), dim3(1024), 0, st, j->LF, j->W);
+    hipLaunchKernelGGL(sift_desc_kernel, dim3(4096), dim3(256), 0, st, j->d_temp, j->LF, j->W, j->d_sift, j->max_pts, j->scale_up);
+    SFM_HIP_TRY(hipGetLastError());
+    SFM_HIP_TRY(hipMemcpyAsync(j->h_state, j->W.state, 8 * sizeof(LevelState), hipMemcpyDeviceToHost, st));
+    return SFM_OK;
+}
+
+int launch_extract_sift_begin(sfm_ctx *ctx, sfm_sift_point *d_sift, int max_pts, const float *d_image, int width, int height, int pitch,
+                              int num_octaves, double init_blur, float thresh, float lowest_scale, int scale_up, float *d_temp)
+{
+    hipStream_t st = ctx->stream;
+    SiftJob *j = job_of(ctx);
+    SFM_REQUIRE(j, SFM_E_NOMEM, "host allocation failed");
+    SFM_REQUIRE(!j->pending, SFM_E_STATE, "an extraction is already in flight on this context (sfm_extract_sift_end it first)");
     sfm_sift_layout SL;
     sift_layout(width, height, num_octaves, scale_up, &SL);
     if (!d_temp) {
@@ -870,37 +919,60 @@ int launch_extract_sift(sfm_ctx *ctx, sfm_sift_point *d_sift, int max_pts, const
     for (int l = 1; l < n; ++l)
         hipLaunchKernelGGL(sift_scaledown_kernel, dim3((L.w[l] + kSdW - 1) / kSdW, (L.h[l] + kSdH - 1) / kSdH), dim3(256), 0, st,
                            d_temp + L.img[l - 1], L.p[l - 1], L.w[l - 1], L.h[l - 1], d_temp + L.img[l], L.p[l], sd);
-    unsigned int res[2] = { 0, 0 };
-    LevelState hs[8];
-    if (n > 0) hipLaunchKernelGGL(sift_laplace_kernel, dim3(lap_blocks), dim3(128), 0, st, d_temp, L, tabs);
-    for (int pass = 0; pass < 2 && n > 0; ++pass) {
+    j->LF = LF; j->W = W; j->d_temp = d_temp; j->d_sift = d_sift; j->ws = ws; j->n = n; j->max_pts = max_pts; j->scale_up = scale_up;
+    j->find_blocks = find_blocks; j->thresh = thresh; j->lowest_scale = lowest_scale; j->cap = cap;
+    std::memset(j->h_state, 0, 8 * sizeof(LevelState));
+    if (n > 0) {
         const float factor = 1.0f / kNumScales, edge_limit = 10.0f;
-        if (pass == 0) {
-            hipLaunchKernelGGL(sift_find_kernel, dim3(find_blocks), dim3(256), 0, st, d_temp, LF, W, thresh, lowest_scale, factor, edge_limit, 0);
-            hipLaunchKernelGGL(sift_scan_kernel, dim3(n), dim3(1024), 0, st, LF, W);
-        } else {
-            // some level found more raw extrema than its stash holds: count, scan, then store by rank (lowest ranks survive)
-            SFM_HIP_TRY(hipMemsetAsync(ws, 0, 256, st));
-            hipLaunchKernelGGL(sift_find_kernel, dim3(find_blocks), dim3(256), 0, st, d_temp, LF, W, thresh, lowest_scale, factor, edge_limit, 1);
-            hipLaunchKernelGGL(sift_scan_kernel, dim3(n), dim3(1024), 0, st, LF, W);
-            hipLaunchKernelGGL(sift_find_kernel, dim3(find_blocks), dim3(256), 0, st, d_temp, LF, W, thresh, lowest_scale, factor, edge_limit, 2);
-        }
-        hipLaunchKernelGGL(sift_orient_kernel, dim3(2048), dim3(256), 0, st, d_temp, LF, W);
-        hipLaunchKernelGGL(sift_place_kernel, dim3(n), dim3(1024), 0, st, LF, W);
-        hipLaunchKernelGGL(sift_desc_kernel, dim3(4096), dim3(256), 0, st, d_temp, LF, W, d_sift, max_pts, scale_up);
-        SFM_HIP_TRY(hipGetLastError());
-        SFM_HIP_TRY(hipMemcpyAsync(hs, W.state, sizeof(hs), hipMemcpyDeviceToHost, st));
-        SFM_HIP_TRY(hipStreamSynchronize(st));
-        unsigned int bases[8];
-        level_bases(hs, n, bases, res[0], res[1]);
-        bool overflow = false;
-        for (int l = 0; l < n; ++l) overflow = overflow || hs[l].found > (unsigned int)cap;
-        if (!overflow) break;
+        hipLaunchKernelGGL(sift_laplace_kernel, dim3(lap_blocks), dim3(128), 0, st, d_temp, L, tabs);
+        hipLaunchKernelGGL(sift_find_kernel, dim3(find_blocks), dim3(256), 0, st, d_temp, LF, W, thresh, lowest_scale, factor, edge_limit, 0);
+        hipLaunchKernelGGL(sift_scan_kernel, dim3(n), dim3(1024), 0, st, LF, W);
+        rc = enqueue_tail(ctx, j);
+        if (rc != SFM_OK) return rc;
     }
     SFM_HIP_TRY(hipGetLastError());
-    *num_pts = (int)(res[0] < (unsigned int)max_pts ? res[0] : (unsigned int)max_pts);      // cudaSiftH.cu:123-124
-    if (num_stored) *num_stored = (int)(res[1] < (unsigned int)max_pts ? res[1] : (unsigned int)max_pts);
+    j->pending = true;
     return SFM_OK;
+}
+
+int launch_extract_sift_end(sfm_ctx *ctx, int *num_pts, int *num_stored)
+{
+    hipStream_t st = ctx->stream;
+    SiftJob *j = static_cast<SiftJob *>(ctx->sift_job);
+    SFM_REQUIRE(j && j->pending, SFM_E_STATE, "no extraction in flight on this context");
+    j->pending = false;
+    unsigned int res[2] = { 0, 0 };
+    if (j->n > 0) {
+        SFM_HIP_TRY(hipStreamSynchronize(st));
+        bool overflow = false;
+        for (int l = 0; l < j->n; ++l) overflow = overflow || j->h_state[l].found > (unsigned int)j->cap;
+        if (overflow) {
+            // some level found more raw extrema than its stash holds: count, scan, then store by rank (lowest ranks survive)
+            const float factor = 1.0f / kNumScales, edge_limit = 10.0f;
+            SFM_HIP_TRY(hipMemsetAsync(j->ws, 0, 256, st));
+            hipLaunchKernelGGL(sift_find_kernel, dim3(j->find_blocks), dim3(256), 0, st, j->d_temp, j->LF, j->W, j->thresh, j->lowest_scale, factor, edge_limit, 1);
+            hipLaunchKernelGGL(sift_scan_kernel, dim3(j->n), dim3(1024), 0, st, j->LF, j->W);
+            hipLaunchKernelGGL(sift_find_kernel, dim3(j->find_blocks), dim3(256), 0, st, j->d_temp, j->LF, j->W, j->thresh, j->lowest_scale, factor, edge_limit, 2);
+            int rc = enqueue_tail(ctx, j);
+            if (rc != SFM_OK) return rc;
+            SFM_HIP_TRY(hipStreamSynchronize(st));
+        }
+        unsigned int bases[8];
+        level_bases(j->h_state, j->n, bases, res[0], res[1]);
+    }
+    SFM_HIP_TRY(hipGetLastError());
+    if (num_pts) *num_pts = (int)(res[0] < (unsigned int)j->max_pts ? res[0] : (unsigned int)j->max_pts);      // cudaSiftH.cu:123-124
+    if (num_stored) *num_stored = (int)(res[1] < (unsigned int)j->max_pts ? res[1] : (unsigned int)j->max_pts);
+    return SFM_OK;
+}
+
+int launch_extract_sift(sfm_ctx *ctx, sfm_sift_point *d_sift, int max_pts, const float *d_image, int width, int height, int pitch,
+                        int num_octaves, double init_blur, float thresh, float lowest_scale, int scale_up, float *d_temp,
+                        int *num_pts, int *num_stored)
+{
+    int rc = launch_extract_sift_begin(ctx, d_sift, max_pts, d_image, width, height, pitch, num_octaves, init_blur, thresh, lowest_scale, scale_up, d_temp);
+    if (rc != SFM_OK) return rc;
+    return launch_extract_sift_end(ctx, num_pts, num_stored);
 }
 
 } // namespace sfm

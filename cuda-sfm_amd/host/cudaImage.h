@@ -118,6 +118,30 @@ inline void ExtractSift(SiftData &siftData, CudaImage &img, int numOctaves, doub
     std::printf("Incl prefiltering & memcpy =  %.2f ms %d\n\n", ms + total, siftData.numPts);
 }
 
+// Two ExtractSift calls (src/main.cpp:273-274) issued together: the second image goes through a second context with its
+// own stream and its own temporary memory, so the two extractions overlap on the device (the per-level kernels of one
+// 720x576 image leave most of an MI355X idle).  Results are those of the two separate calls.
+inline void ExtractSiftPair(SiftData &siftData1, SiftData &siftData2, CudaImage &img1, CudaImage &img2, int numOctaves, double initBlur,
+                            float thresh, float lowestScale = 0.0f, bool scaleUp = false, float *tempMemory = 0)
+{
+    sfm_ctx *c1 = sfm_facade::context(), *c2 = sfm_facade::second_context();
+    float ms = 0.f;
+    int n1 = 0, n2 = 0;
+    SFM_FACADE_CALL(sfm_ctx_synchronize(c1));                              // the images were uploaded through the first context
+    SFM_FACADE_CALL(sfm_ctx_timer_start(c1));
+    SFM_FACADE_CALL(sfm_extract_sift_begin(c1, siftData1.d_data, siftData1.maxPts, img1.d_data, img1.width, img1.height, img1.pitch, numOctaves,
+                                           initBlur, thresh, lowestScale, scaleUp ? 1 : 0, tempMemory));
+    SFM_FACADE_CALL(sfm_extract_sift_begin(c2, siftData2.d_data, siftData2.maxPts, img2.d_data, img2.width, img2.height, img2.pitch, numOctaves,
+                                           initBlur, thresh, lowestScale, scaleUp ? 1 : 0, nullptr));
+    SFM_FACADE_CALL(sfm_extract_sift_end(c1, &n1, nullptr));
+    SFM_FACADE_CALL(sfm_extract_sift_end(c2, &n2, nullptr));
+    SFM_FACADE_CALL(sfm_ctx_timer_stop(c1, &ms));
+    siftData1.numPts = n1; siftData2.numPts = n2;
+    std::printf("SIFT extraction time (pair) = %.2f ms %d %d\n\n", ms, n1, n2);
+    if (siftData1.h_data && n1 > 0) SFM_FACADE_CALL(sfm_copy_to_host(c1, siftData1.h_data, siftData1.d_data, sizeof(SiftPoint) * (size_t)n1));
+    if (siftData2.h_data && n2 > 0) SFM_FACADE_CALL(sfm_copy_to_host(c1, siftData2.h_data, siftData2.d_data, sizeof(SiftPoint) * (size_t)n2));
+}
+
 // cudaSiftH.cu:265-305
 inline void PrintSiftData(SiftData &data)
 {

@@ -63,10 +63,29 @@ inline sfm_ctx *context()
     return global_ctx();
 }
 
+// a second context on the same device with a stream of its own: work issued through it overlaps with the first
+inline sfm_ctx *&second_ctx()
+{
+    static sfm_ctx *ctx = nullptr;
+    return ctx;
+}
+
+inline sfm_ctx *second_context()
+{
+    if (!second_ctx()) {
+        int dev = 0;
+        SFM_FACADE_CALL(sfm_ctx_get_device(context(), &dev));
+        SFM_FACADE_CALL(sfm_ctx_create(dev, &second_ctx()));
+        SFM_FACADE_CALL(sfm_ctx_own_stream(second_ctx()));
+    }
+    return second_ctx();
+}
+
 } // namespace sfm_facade
 
 inline void InitCuda(int devNum = 0)
 {
+    if (sfm_facade::second_ctx()) { sfm_ctx_destroy(sfm_facade::second_ctx()); sfm_facade::second_ctx() = nullptr; }
     if (sfm_facade::global_ctx()) { sfm_ctx_destroy(sfm_facade::global_ctx()); sfm_facade::global_ctx() = nullptr; }
     SFM_FACADE_CALL(sfm_ctx_create(devNum, &sfm_facade::global_ctx()));
 }

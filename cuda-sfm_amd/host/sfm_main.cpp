@@ -45,8 +45,8 @@ int main(int argc, char **argv)
     InitSiftData(siftData1, 32768, true, true);
     InitSiftData(siftData2, 32768, true, true);
     float *memoryTmp = AllocSiftTempMemory(w, h, 5, false);
-    ExtractSift(siftData1, img1, 5, initBlur, thresh, 0.0f, false, memoryTmp);
-    ExtractSift(siftData2, img2, 5, initBlur, thresh, 0.0f, false, memoryTmp);
+    // main.cpp:273-274 calls ExtractSift twice in a row; the pair form issues both at once (same results)
+    ExtractSiftPair(siftData1, siftData2, img1, img2, 5, initBlur, thresh, 0.0f, false, memoryTmp);
     FreeSiftTempMemory(memoryTmp);
 
     MatchSiftData(siftData1, siftData2);                                           // main.cpp:282

@@ -56,6 +56,9 @@ const char *sfm_last_error(void);
 int  sfm_ctx_create(int device_id, sfm_ctx **out);          /* replaces InitCuda + cuBLAS/cuSOLVER handle setup (sfm.cu:46-75) */
 int  sfm_ctx_destroy(sfm_ctx *ctx);
 int  sfm_ctx_set_stream(sfm_ctx *ctx, void *hip_stream);    /* NULL = default stream                                          */
+/* A stream of the context's own (hipStreamNonBlocking, destroyed with the context): callers without HIP headers get a
+ * second context that runs concurrently with the first (which sits on the default stream unless told otherwise). */
+int  sfm_ctx_own_stream(sfm_ctx *ctx);
 int  sfm_ctx_synchronize(sfm_ctx *ctx);
 int  sfm_ctx_get_stream(sfm_ctx *ctx, void **hip_stream);    /* the stream work is enqueued on (for callers that add their own, e.g. RCCL) */
 int  sfm_ctx_get_device(sfm_ctx *ctx, int *device_id);
@@ -117,6 +120,15 @@ int sfm_sift_temp_layout(int width, int height, int num_octaves, int scale_up, s
 int sfm_extract_sift(sfm_ctx *ctx, sfm_sift_point *d_sift, int max_pts, const float *d_image, int width, int height,
                      int pitch, int num_octaves, double init_blur, float thresh, float lowest_scale, int scale_up,
                      float *d_temp, int *num_pts, int *num_stored);
+/* ExtractSift in two halves: _begin enqueues the whole extraction on the context's stream and returns at once, _end waits
+ * for it and returns the counts (and runs the rare exact second pass when a level overflowed its candidate stash).
+ * The per-level kernels of one image do not fill an MI355X: two contexts (two streams) extract two images concurrently
+ * -- _begin on both, then _end on both (the dino pair of src/main.cpp:273-274: 0.25 -> 0.15 ms).  One extraction in
+ * flight per context; d_sift, d_image and d_temp must stay valid until _end. */
+int sfm_extract_sift_begin(sfm_ctx *ctx, sfm_sift_point *d_sift, int max_pts, const float *d_image, int width, int height,
+                           int pitch, int num_octaves, double init_blur, float thresh, float lowest_scale, int scale_up,
+                           float *d_temp);
+int sfm_extract_sift_end(sfm_ctx *ctx, int *num_pts, int *num_stored);
 
 /* ---- homography RANSAC pre-filter: FindHomography (matching.cu:1000-1087) -------------------------
  * 4-point DLT hypotheses from the matched records of d_sift (xpos, ypos -> match_xpos, match_ypos),

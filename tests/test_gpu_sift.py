@@ -274,3 +274,38 @@ def test_oracle_detector_matches_reference_findpointsmulti(gpu, R, w, h, octave,
     for f in ("xpos", "ypos", "sharpness", "edgeness", "subsampling"):
         assert same_bits(ref[f], opts[f]), f
     assert np.abs(ref["scale"] / opts["scale"] - 1.0).max() < 4e-7
+
+
+def test_begin_end_two_contexts_overlap_same_results(gpu):
+    """sfm_extract_sift_begin / _end: two contexts (the second on a stream of its own) extract two images at once; records
+    and counts are those of the plain calls; misuse is reported (end without begin, second begin)."""
+    torch, dev, ctx = gpu
+    w, h = 384, 288
+    imgs = [synth.image(w, h, seed=61, blobs=150), synth.image(w, h, seed=62, blobs=90)]
+    kw = dict(num_octaves=4, init_blur=1.0, thresh=2.0)
+    plain = [run_product(gpu, im, max_pts=4096, **kw) for im in imgs]
+    ctx2 = S.Context(0)
+    ctx2.own_stream()
+    p = align(w)
+    d_img = [torch.from_numpy(padded(im, p)).to(dev) for im in imgs]
+    d_out = [torch.zeros((4096, 576), dtype=torch.uint8, device=dev) for _ in imgs]
+    L = S.sift_temp_layout(w, h, 4, False)
+    d_tmp = [torch.zeros(L.total_floats, dtype=torch.float32, device=dev) for _ in imgs]
+    torch.cuda.synchronize()
+    with pytest.raises(S.SfmError) as e:
+        ctx2.extract_sift_end()
+    assert e.value.code == S.E_STATE
+    for _ in range(3):
+        ctx.extract_sift_begin(d_out[0], 4096, d_img[0], w, h, p, d_temp=d_tmp[0], **kw)
+        ctx2.extract_sift_begin(d_out[1], 4096, d_img[1], w, h, p, d_temp=d_tmp[1], **kw)
+        with pytest.raises(S.SfmError) as e:
+            ctx2.extract_sift_begin(d_out[1], 4096, d_img[1], w, h, p, d_temp=d_tmp[1], **kw)
+        assert e.value.code == S.E_STATE
+        got = [ctx.extract_sift_end(), ctx2.extract_sift_end()]
+        for k in (0, 1):
+            rec, n, stored = plain[k][0], plain[k][1], plain[k][2]
+            assert got[k] == (n, stored) and n > 30
+            mine = d_out[k].cpu().numpy().view(O.SIFT_DTYPE).reshape(-1)
+            for f in FIELDS:
+                assert same_bits(mine[f][:stored], rec[f][:stored]), (k, f)
+    ctx2.close()
