@@ -592,12 +592,31 @@ def process_views(ctx, images, K, Kinv, pairs=None, rank=0, world=1, max_pts=819
     block = torch.zeros((slots, rec_bytes + 64), dtype=torch.uint8, device=dev)       # records | int32 count in the tail
     L = sift_temp_layout(w, h, sift.get("num_octaves", 5), sift.get("scale_up", False))
     d_temp = torch.empty(L.total_floats, dtype=torch.float32, device=dev)
-    for slot, v in enumerate(range(rank, V, world)):
-        pad = np.zeros((h, p), np.float32)
-        pad[:, :w] = images[v]
-        d_img = torch.from_numpy(pad).to(dev)
-        n, _ = ctx.extract_sift(block[slot], max_pts, d_img, w, h, p, d_temp=d_temp, **sift)
-        block[slot, rec_bytes:rec_bytes + 4] = torch.from_numpy(np.array([n], np.int32).view(np.uint8)).to(dev)
+    # two views at a time: the second goes through an auxiliary context on its own stream, so the two extractions overlap
+    aux = getattr(ctx, "_aux", None)
+    if aux is None:
+        aux = ctx._aux = Context(ctx.device)
+        aux.own_stream()
+    d_temp2 = torch.empty(L.total_floats, dtype=torch.float32, device=dev)
+    mine_views = list(enumerate(range(rank, V, world)))
+    local_counts = {}
+    for i0 in range(0, len(mine_views), 2):
+        group = mine_views[i0:i0 + 2]
+        imgs = []
+        for slot, v in group:
+            pad = np.zeros((h, p), np.float32)
+            pad[:, :w] = images[v]
+            imgs.append(torch.from_numpy(pad).to(dev))
+        torch.cuda.synchronize(dev)                               # uploads done before the auxiliary stream reads them
+        for k, (slot, v) in enumerate(group):
+            (ctx, aux)[k].extract_sift_begin(block[slot], max_pts, imgs[k], w, h, p, d_temp=(d_temp, d_temp2)[k], **sift)
+        for k, (slot, v) in enumerate(group):
+            local_counts[slot] = (ctx, aux)[k].extract_sift_end()[0]
+    if local_counts:
+        cnt = np.zeros((slots, 4), np.uint8)
+        for slot, n in local_counts.items():
+            cnt[slot] = np.array([n], np.int32).view(np.uint8)
+        block[:, rec_bytes:rec_bytes + 4] = torch.from_numpy(cnt).to(dev)
     feats = gather_features(block) if (gather_features is not None and world > 1) else block
     feats = feats.reshape(-1, rec_bytes + 64)
 
