@@ -196,15 +196,18 @@ __device__ __forceinline__ void filter_pair(const Ess &E, const EssAddends &ad, 
 // TRACK_HI = false drops the upper range check of tp (one VALU instruction per pair of points).  The caller may
 // only do that when overflow is impossible: every |E_ij| <= 2 and every |coordinate| <= B < 1e5 give |a_i|, |b_j| <= 6B,
 // da, db <= 72 B^2, tp = thr * da * db <= 1e3 * 5184 B^4 < 5.2e26 < 1e30, and m = n^2 (da + db) <= 324 B^4 * 144 B^2 finite.
-template <bool UNITZ, bool TRACK_HI = true>
-__device__ __forceinline__ int score_tile(const Ess &E, const float *lds, int nvalid, const ThrBand &band, int lane)
+// NH hypotheses per wavefront share every point record read from LDS (NH = 2 halves the LDS traffic and the address
+// arithmetic per evaluated pair; the VALU work per hypothesis is unchanged).
+template <bool UNITZ, bool TRACK_HI, int NH>
+__device__ __forceinline__ void score_tile_n(const Ess (&E)[NH], const float *lds, int nvalid, const ThrBand &band, int lane, int (&cnt)[NH])
 {
     constexpr int kRec = UNITZ ? 1 : 3;         // float4 per pair record in the first array
     const float4 *rec0 = reinterpret_cast<const float4 *>(lds) + kRec * lane;
     const int full = nvalid >> 7;               // iterations with all 128 points real
-    int cnt = 0;
-    FilterAcc acc{ 0xFFFFFFFFu, 0xFFFFFFFFu, 0u };
-    const EssAddends ad = make_addends(E);
+    FilterAcc acc[NH];
+    EssAddends ad[NH];
+#pragma unroll
+    for (int h = 0; h < NH; ++h) { cnt[h] = 0; acc[h] = FilterAcc{ 0xFFFFFFFFu, 0xFFFFFFFFu, 0u }; ad[h] = make_addends(E[h]); }
     const float4 *rec = rec0;
     int it = 0;
     // four iterations per trip by hand (the ballots are convergent, so the compiler will not unroll a loop with a
@@ -212,46 +215,70 @@ __device__ __forceinline__ int score_tile(const Ess &E, const float *lds, int nv
     for (; it + 4 <= full; it += 4, rec += 4 * kRec * 64) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            unsigned long long in_a, in_b;
-            filter_pair<UNITZ, TRACK_HI>(E, ad, band.thr, load_pair<UNITZ>(rec + u * kRec * 64), in_a, in_b, acc);
-            cnt += __builtin_popcountll(in_a) + __builtin_popcountll(in_b);
+            const PairPts p = load_pair<UNITZ>(rec + u * kRec * 64);
+#pragma unroll
+            for (int h = 0; h < NH; ++h) {
+                unsigned long long in_a, in_b;
+                filter_pair<UNITZ, TRACK_HI>(E[h], ad[h], band.thr, p, in_a, in_b, acc[h]);
+                cnt[h] += __builtin_popcountll(in_a) + __builtin_popcountll(in_b);
+            }
         }
     }
     for (; it < full; ++it, rec += kRec * 64) {
-        unsigned long long in_a, in_b;
-        filter_pair<UNITZ, TRACK_HI>(E, ad, band.thr, load_pair<UNITZ>(rec), in_a, in_b, acc);
-        cnt += __builtin_popcountll(in_a) + __builtin_popcountll(in_b);
+        const PairPts p = load_pair<UNITZ>(rec);
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+            unsigned long long in_a, in_b;
+            filter_pair<UNITZ, TRACK_HI>(E[h], ad[h], band.thr, p, in_a, in_b, acc[h]);
+            cnt[h] += __builtin_popcountll(in_a) + __builtin_popcountll(in_b);
+        }
     }
     const int rest = nvalid - (full << 7);      // 0..127 real points in the ragged iteration
     if (rest > 0) {
         const unsigned long long va = __ballot(2 * lane < rest), vb = __ballot(2 * lane + 1 < rest);
-        unsigned long long in_a, in_b;
-        FilterAcc t{ 0xFFFFFFFFu, 0xFFFFFFFFu, 0u };
-        filter_pair<UNITZ>(E, ad, band.thr, load_pair<UNITZ>(rec), in_a, in_b, t);
-        // trackers of padding lanes are discarded; a lane holding one real and one padding point
-        // keeps them (NaN padding then reads as "undecided", which is merely conservative)
-        if (2 * lane < rest) {
-            acc.gap_min = min(acc.gap_min, t.gap_min);
-            acc.tb_min = min(acc.tb_min, t.tb_min);
-            acc.tb_max = max(acc.tb_max, t.tb_max);
-        }
-        cnt += __builtin_popcountll(in_a & va) + __builtin_popcountll(in_b & vb);
-    }
-    const bool und = (acc.gap_min < kBandUlps) || (acc.tb_min < band.lo_bits) || (acc.tb_max > band.hi_bits);
-    if (__builtin_expect(__any(und), 0)) {
-        // Some point of this tile was undecided (about 1 in 1e5; always for a degenerate E):
-        // recount the tile with the exact IEEE residual.  Wave-uniform, rare.
-        cnt = 0;
-        rec = rec0;
-        const int iters = (nvalid + 127) >> 7;
-        for (int it = 0; it < iters; ++it, rec += kRec * 64) {
-            const PairPts p = load_pair<UNITZ>(rec);
-            const bool ea = residual(E, p.x1x.x, p.x1y.x, p.x1z.x, p.x2x.x, p.x2y.x, p.x2z.x) < band.thr;   // NaN padding never counts
-            const bool eb = residual(E, p.x1x.y, p.x1y.y, p.x1z.y, p.x2x.y, p.x2y.y, p.x2z.y) < band.thr;
-            cnt += __builtin_popcountll(__ballot(ea)) + __builtin_popcountll(__ballot(eb));
+        const PairPts p = load_pair<UNITZ>(rec);
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+            unsigned long long in_a, in_b;
+            FilterAcc t{ 0xFFFFFFFFu, 0xFFFFFFFFu, 0u };
+            filter_pair<UNITZ>(E[h], ad[h], band.thr, p, in_a, in_b, t);
+            // trackers of padding lanes are discarded; a lane holding one real and one padding point
+            // keeps them (NaN padding then reads as "undecided", which is merely conservative)
+            if (2 * lane < rest) {
+                acc[h].gap_min = min(acc[h].gap_min, t.gap_min);
+                acc[h].tb_min = min(acc[h].tb_min, t.tb_min);
+                acc[h].tb_max = max(acc[h].tb_max, t.tb_max);
+            }
+            cnt[h] += __builtin_popcountll(in_a & va) + __builtin_popcountll(in_b & vb);
         }
     }
-    return cnt;
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+        const bool und = (acc[h].gap_min < kBandUlps) || (acc[h].tb_min < band.lo_bits) || (acc[h].tb_max > band.hi_bits);
+        if (__builtin_expect(__any(und), 0)) {
+            // Some point of this tile was undecided (about 1 in 1e5; always for a degenerate E):
+            // recount the tile with the exact IEEE residual.  Wave-uniform, rare.
+            int c = 0;
+            rec = rec0;
+            const int iters = (nvalid + 127) >> 7;
+            for (int k = 0; k < iters; ++k, rec += kRec * 64) {
+                const PairPts p = load_pair<UNITZ>(rec);
+                const bool ea = residual(E[h], p.x1x.x, p.x1y.x, p.x1z.x, p.x2x.x, p.x2y.x, p.x2z.x) < band.thr;   // NaN padding never counts
+                const bool eb = residual(E[h], p.x1x.y, p.x1y.y, p.x1z.y, p.x2x.y, p.x2y.y, p.x2z.y) < band.thr;
+                c += __builtin_popcountll(__ballot(ea)) + __builtin_popcountll(__ballot(eb));
+            }
+            cnt[h] = c;
+        }
+    }
+}
+
+template <bool UNITZ, bool TRACK_HI = true>
+__device__ __forceinline__ int score_tile(const Ess &E, const float *lds, int nvalid, const ThrBand &band, int lane)
+{
+    const Ess e1[1] = { E };
+    int c[1];
+    score_tile_n<UNITZ, TRACK_HI, 1>(e1, lds, nvalid, band, lane, c);
+    return c[0];
 }
 
 } // namespace sfm
