@@ -18,7 +18,6 @@
 //                         with S, V and the sampled points in per-wave LDS (see below).
 //
 // Work per (hypothesis, point): 38 FLOP; per hypothesis: 720 FLOP (A^T A) + solver.
-#include <cstdlib>
 #include "ransac_device.hpp"
 
 namespace sfm {
@@ -248,8 +247,8 @@ int launch_ransac_score(sfm_pair *pair, const sfm_ransac_params &p, uint32_t h0,
     while (wpb > 4 && (count + wpb - 1) / wpb < (uint32_t)ctx->num_cus) wpb >>= 1;
     // hypotheses per wavefront: with plenty of work two, which share every point record read from LDS (half the LDS
     // traffic and address arithmetic per evaluated pair: 1.98 -> 1.83 ms per 2^20 x 4096 on the same box)
-    int nh = (wpb == 16 && pair->unit_z && count >= 32768u) ? 2 : 1;
-    if (const char *e = getenv("SFM_DBG_NH")) nh = (wpb == 16 && pair->unit_z) ? atoi(e) : 1;
+    // (three or four per wavefront need > 64 VGPRs, i.e. half the occupancy: 2.01 / 1.91 ms)
+    const int nh = (wpb == 16 && pair->unit_z && count >= 32768u) ? 2 : 1;
     const uint32_t nbatch = (count + wpb * nh - 1) / (wpb * nh);
     // unit-z layout: fixed 64 KiB (two arrays of kTileMax/2 pair records); generic: 24 B per point
     const bool uz = pair->unit_z;
