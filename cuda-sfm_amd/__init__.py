@@ -51,7 +51,7 @@ EXPORTS = [
     "sfm_ctx_kernel_timing_read", "sfm_device_alloc", "sfm_device_free", "sfm_copy_to_device", "sfm_copy_to_host",
     "sfm_copy_to_host_2d", "sfm_copy_to_device_2d", "sfm_find_homography", "sfm_sift_temp_layout", "sfm_extract_sift", "sfm_extract_sift_begin", "sfm_extract_sift_end", "sfm_match", "sfm_match_soa",
     "sfm_pair_create", "sfm_pair_destroy", "sfm_pair_reset", "sfm_get_result", "sfm_fill_xu", "sfm_set_points", "sfm_ransac_default_params",
-    "sfm_ransac_permutation_indices", "sfm_estimate_E", "sfm_ransac_score", "sfm_ransac_finalize",
+    "sfm_ransac_permutation_indices", "sfm_estimate_E", "sfm_ransac_score", "sfm_ransac_score_into", "sfm_ransac_finalize",
     "sfm_ransac_finalize_key", "sfm_ransac_export_key", "sfm_pose_candidates", "sfm_choose_pose", "sfm_triangulate",
     "sfm_pair_device_ptr", "sfm_pair_ld", "sfm_pair_num_points", "sfm_get_XU", "sfm_get_E", "sfm_get_best",
     "sfm_get_key", "sfm_get_inlier_counts", "sfm_get_inlier_mask", "sfm_get_E_candidates",
@@ -106,6 +106,7 @@ _lib.sfm_ransac_default_params.restype = None
 _lib.sfm_ransac_permutation_indices.argtypes = [_vp, C.c_int, C.c_uint32, _vp]
 _lib.sfm_estimate_E.argtypes = [_vp, C.POINTER(RansacParams)]
 _lib.sfm_ransac_score.argtypes = [_vp, C.POINTER(RansacParams)]
+_lib.sfm_ransac_score_into.argtypes = [_vp, C.POINTER(RansacParams), _vp]
 _lib.sfm_ransac_finalize.argtypes = [_vp, C.POINTER(RansacParams), C.c_uint32]
 _lib.sfm_ransac_finalize_key.argtypes = [_vp, C.POINTER(RansacParams), _vp]
 _lib.sfm_ransac_export_key.argtypes = [_vp, _vp]
@@ -332,8 +333,12 @@ class ImagePair:
         p = params if params is not None else default_params(self.num_points)
         _check(_lib.sfm_estimate_E(self._h, C.byref(p)), "sfm_estimate_E")
 
-    def ransac_score(self, params):
-        _check(_lib.sfm_ransac_score(self._h, C.byref(params)), "sfm_ransac_score")
+    def ransac_score(self, params, key_out=None):
+        """Score the shard; with key_out (1-element int64 device tensor) its key is also left there for the all-reduce."""
+        if key_out is None:
+            _check(_lib.sfm_ransac_score(self._h, C.byref(params)), "sfm_ransac_score")
+        else:
+            _check(_lib.sfm_ransac_score_into(self._h, C.byref(params), _ptr(key_out)), "sfm_ransac_score_into")
 
     def ransac_finalize(self, params, hyp):
         _check(_lib.sfm_ransac_finalize(self._h, C.byref(params), int(hyp)), "sfm_ransac_finalize")
@@ -443,8 +448,7 @@ def estimate_E_distributed(pair, params, rank, world, key_tensor, all_reduce_max
     """
     begin, count = shard_range(params.num_hypotheses, rank, world)
     params.hyp_begin, params.hyp_count = begin, count     # count == 0 only when begin == H
-    pair.ransac_score(params)                             # empty shard -> key 0
-    pair.export_key(key_tensor)
+    pair.ransac_score(params, key_out=key_tensor)         # empty shard -> key 0; the key lands in key_tensor too (no export step)
     all_reduce_max(key_tensor)
     pair.ransac_finalize_key(params, key_tensor)
 

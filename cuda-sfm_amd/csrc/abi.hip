@@ -449,6 +449,16 @@ int sfm_ransac_score(sfm_pair *pair, const sfm_ransac_params *p)
     return launch_ransac_score(pair, *p, h0, count);
 }
 
+int sfm_ransac_score_into(sfm_pair *pair, const sfm_ransac_params *p, uint64_t *d_key_out)
+{
+    SFM_REQUIRE(d_key_out, SFM_E_INVALID, "null key pointer");
+    uint32_t h0, count;
+    int rc = resolve_shard(pair, p, &h0, &count);
+    if (rc != SFM_OK) return rc;
+    SFM_HIP_TRY(hipSetDevice(pair->ctx->device));
+    return launch_ransac_score(pair, *p, h0, count, reinterpret_cast<unsigned long long *>(d_key_out));
+}
+
 int sfm_ransac_finalize(sfm_pair *pair, const sfm_ransac_params *p, uint32_t hyp)
 {
     uint32_t h0, count;

@@ -25,11 +25,22 @@ namespace sfm {
 // ------------------------------------------------------------------------------------------
 // SPLIT step 1: one hypothesis per lane
 // ------------------------------------------------------------------------------------------
+// The solve kernel runs before the scoring kernel of the same call: its first thread clears the arg-max keys the scoring
+// blocks will atomicMax into (the pair's own and, if given, the caller's copy) -- no separate memset in the stream.
+__device__ __forceinline__ void reset_keys(unsigned long long *key, unsigned long long *key2)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        key[0] = 0ull; key[1] = 0ull;
+        if (key2) *key2 = 0ull;
+    }
+}
+
 __global__ __launch_bounds__(64)
 void ransac_solve_lanes(const float *__restrict__ X0, const float *__restrict__ X1, int ld, int n,
                         const int32_t *__restrict__ indices, uint32_t seed, uint32_t h0, uint32_t count,
-                        int sweeps, float *__restrict__ Ecand)
+                        int sweeps, float *__restrict__ Ecand, unsigned long long *zero_key, unsigned long long *zero_key2)
 {
+    reset_keys(zero_key, zero_key2);
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
     float E[9];
@@ -43,8 +54,9 @@ template <bool QR>
 __global__ __launch_bounds__(64)
 void ransac_solve_lanes2(const float *__restrict__ X0, const float *__restrict__ X1, int ld, int n,
                          const int32_t *__restrict__ indices, uint32_t seed, uint32_t h0, uint32_t count,
-                         int sweeps, float *__restrict__ Ecand)
+                         int sweeps, float *__restrict__ Ecand, unsigned long long *zero_key, unsigned long long *zero_key2)
 {
+    reset_keys(zero_key, zero_key2);
     const uint32_t i = 2u * (blockIdx.x * blockDim.x + threadIdx.x);
     if (i >= count) return;
     const uint32_t j = (i + 1 < count) ? i + 1 : i;         // odd count: the last lane solves its hypothesis twice
@@ -65,7 +77,7 @@ template <int WPB, bool UNITZ, int NH = 1>
 __global__ __launch_bounds__(WPB * 64, 8)
 void ransac_score_waves(const float *__restrict__ X0, const float *__restrict__ X1, int ld, int n,
                         const float *__restrict__ Ecand, uint32_t h0, uint32_t count, float thr,
-                        int tile, int ntiles, int *__restrict__ counts, unsigned long long *best_key)
+                        int tile, int ntiles, int *__restrict__ counts, unsigned long long *best_key, unsigned long long *best_key2)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     // bits of the largest |coordinate| in the staged tile, kept right behind the tile
@@ -146,7 +158,10 @@ void ransac_score_waves(const float *__restrict__ X0, const float *__restrict__ 
         unsigned long long b = sbest[0];
 #pragma unroll
         for (int w = 1; w < WPB; ++w) b = sbest[w] > b ? sbest[w] : b;
-        if (b) atomicMax(best_key, b);
+        if (b) {
+            atomicMax(best_key, b);
+            if (best_key2) atomicMax(best_key2, b);          // the caller's copy (sfm_ransac_score_into): no export step
+        }
     }
 }
 
@@ -189,22 +204,29 @@ static int ensure_hyp_capacity(sfm_pair *pair, size_t count)
 }
 
 template <int WPB, bool UNITZ, int NH = 1>
-static int launch_score_t(sfm_pair *pair, uint32_t h0, uint32_t count, float thr, int tile, int ntiles, int grid, size_t lds)
+static int launch_score_t(sfm_pair *pair, uint32_t h0, uint32_t count, float thr, int tile, int ntiles, int grid, size_t lds, unsigned long long *key2)
 {
     const int rc_lds = allow_big_lds(pair->ctx, reinterpret_cast<const void *>(&ransac_score_waves<WPB, UNITZ, NH>));
     if (rc_lds != SFM_OK) return rc_lds;
     hipLaunchKernelGGL((ransac_score_waves<WPB, UNITZ, NH>), dim3(grid), dim3(WPB * 64), lds, pair->ctx->stream,
                        pair->d_X[0], pair->d_X[1], pair->ld, pair->n, pair->d_Ecand, h0, count, thr, tile, ntiles,
-                       pair->d_counts, pair->d_key);
+                       pair->d_counts, pair->d_key, key2);
     SFM_HIP_TRY(hipGetLastError());
     pair->last_grid = grid; pair->last_block = WPB * 64; pair->last_lds = (int)lds;
     return SFM_OK;
 }
 
-int launch_ransac_score(sfm_pair *pair, const sfm_ransac_params &p, uint32_t h0, uint32_t count)
+int launch_ransac_score(sfm_pair *pair, const sfm_ransac_params &p, uint32_t h0, uint32_t count, unsigned long long *key2)
 {
     sfm_ctx *ctx = pair->ctx;
-    SFM_HIP_TRY(hipMemsetAsync(pair->d_key, 0, 2 * sizeof(unsigned long long), ctx->stream));
+    // which kernel family: decided first, because the lane-solve kernel of the SPLIT family clears the keys itself
+    const uint32_t fused_max_early = p.jacobi_sweeps > 0 ? 4096u : 1024u;
+    const int family = p.kernel == SFM_KERNEL_AUTO ? (count <= fused_max_early ? SFM_KERNEL_FUSED : SFM_KERNEL_SPLIT) : p.kernel;
+    const bool self_clearing = count > 0 && family == SFM_KERNEL_SPLIT;
+    if (!self_clearing) {
+        SFM_HIP_TRY(hipMemsetAsync(pair->d_key, 0, 2 * sizeof(unsigned long long), ctx->stream));
+        if (key2) SFM_HIP_TRY(hipMemsetAsync(key2, 0, sizeof(unsigned long long), ctx->stream));
+    }
     pair->last_count = count;
     pair->cand_h0 = h0; pair->cand_seed = p.seed; pair->cand_indices = p.d_indices; pair->cand_sweeps = p.jacobi_sweeps;
     if (count == 0) return SFM_OK;
@@ -219,7 +241,11 @@ int launch_ransac_score(sfm_pair *pair, const sfm_ransac_params &p, uint32_t h0,
     int kernel = p.kernel == SFM_KERNEL_AUTO ? (count <= fused_max ? SFM_KERNEL_FUSED : SFM_KERNEL_SPLIT) : p.kernel;
     if (kernel == SFM_KERNEL_MFMA && pair->n >= 65536) kernel = SFM_KERNEL_SPLIT;   // its packed counters are 16-bit
     pair->last_kernel = kernel;
-    if (kernel == SFM_KERNEL_FUSED) return launch_ransac_fused(pair, p, h0, count);
+    if (kernel == SFM_KERNEL_FUSED) {
+        rc = launch_ransac_fused(pair, p, h0, count);
+        if (rc == SFM_OK && key2) SFM_HIP_TRY(hipMemcpyAsync(key2, pair->d_key, sizeof(unsigned long long), hipMemcpyDeviceToDevice, ctx->stream));
+        return rc;
+    }
 
     const bool timed = ctx->timing && ctx->tcount < sfm_ctx::kTimingSlots;
     hipEvent_t *tev = timed ? ctx->tev[ctx->tcount] : nullptr;
@@ -227,15 +253,15 @@ int launch_ransac_score(sfm_pair *pair, const sfm_ransac_params &p, uint32_t h0,
     if (p.reserved[0] == 1)          // A/B switch: one hypothesis per lane (scalar math)
         hipLaunchKernelGGL(ransac_solve_lanes, dim3((count + 63) / 64), dim3(64), 0, ctx->stream,
                            pair->d_X[0], pair->d_X[1], pair->ld, pair->n, p.d_indices, p.seed, h0, count,
-                           p.jacobi_sweeps, pair->d_Ecand);
+                           p.jacobi_sweeps, pair->d_Ecand, pair->d_key, key2);
     else if (p.jacobi_sweeps <= 0)   // default: two hypotheses per lane (packed math), Householder instantiation
         hipLaunchKernelGGL(ransac_solve_lanes2<true>, dim3((count + 127) / 128), dim3(64), 0, ctx->stream,
                            pair->d_X[0], pair->d_X[1], pair->ld, pair->n, p.d_indices, p.seed, h0, count,
-                           p.jacobi_sweeps, pair->d_Ecand);
+                           p.jacobi_sweeps, pair->d_Ecand, pair->d_key, key2);
     else
         hipLaunchKernelGGL(ransac_solve_lanes2<false>, dim3((count + 127) / 128), dim3(64), 0, ctx->stream,
                            pair->d_X[0], pair->d_X[1], pair->ld, pair->n, p.d_indices, p.seed, h0, count,
-                           p.jacobi_sweeps, pair->d_Ecand);
+                           p.jacobi_sweeps, pair->d_Ecand, pair->d_key, key2);
     SFM_HIP_TRY(hipGetLastError());
     if (timed) SFM_HIP_TRY(hipEventRecord(tev[1], ctx->stream));
 
@@ -264,17 +290,20 @@ int launch_ransac_score(sfm_pair *pair, const sfm_ransac_params &p, uint32_t h0,
     if (blocks > 16u * (uint32_t)ctx->num_cus) blocks = 16u * (uint32_t)ctx->num_cus;
     if (blocks < resident) blocks = resident;
     const int grid = (int)(nbatch < blocks ? nbatch : blocks);
-    if (kernel == SFM_KERNEL_MFMA) rc = launch_score_mfma(pair, p, h0, count);
+    if (kernel == SFM_KERNEL_MFMA) {
+        rc = launch_score_mfma(pair, p, h0, count);
+        if (rc == SFM_OK && key2) SFM_HIP_TRY(hipMemcpyAsync(key2, pair->d_key, sizeof(unsigned long long), hipMemcpyDeviceToDevice, ctx->stream));
+    }
     else if (uz) switch (wpb) {
-    case 16: rc = nh == 2 ? launch_score_t<16, true, 2>(pair, h0, count, p.threshold, tile, ntiles, grid, lds)
-                          : launch_score_t<16, true>(pair, h0, count, p.threshold, tile, ntiles, grid, lds); break;
-    case 8:  rc = launch_score_t<8, true>(pair, h0, count, p.threshold, tile, ntiles, grid, lds); break;
-    default: rc = launch_score_t<4, true>(pair, h0, count, p.threshold, tile, ntiles, grid, lds); break;
+    case 16: rc = nh == 2 ? launch_score_t<16, true, 2>(pair, h0, count, p.threshold, tile, ntiles, grid, lds, key2)
+                          : launch_score_t<16, true>(pair, h0, count, p.threshold, tile, ntiles, grid, lds, key2); break;
+    case 8:  rc = launch_score_t<8, true>(pair, h0, count, p.threshold, tile, ntiles, grid, lds, key2); break;
+    default: rc = launch_score_t<4, true>(pair, h0, count, p.threshold, tile, ntiles, grid, lds, key2); break;
     }
     else switch (wpb) {
-    case 16: rc = launch_score_t<16, false>(pair, h0, count, p.threshold, tile, ntiles, grid, lds); break;
-    case 8:  rc = launch_score_t<8, false>(pair, h0, count, p.threshold, tile, ntiles, grid, lds); break;
-    default: rc = launch_score_t<4, false>(pair, h0, count, p.threshold, tile, ntiles, grid, lds); break;
+    case 16: rc = launch_score_t<16, false>(pair, h0, count, p.threshold, tile, ntiles, grid, lds, key2); break;
+    case 8:  rc = launch_score_t<8, false>(pair, h0, count, p.threshold, tile, ntiles, grid, lds, key2); break;
+    default: rc = launch_score_t<4, false>(pair, h0, count, p.threshold, tile, ntiles, grid, lds, key2); break;
     }
     if (rc == SFM_OK && timed) {
         SFM_HIP_TRY(hipEventRecord(tev[2], ctx->stream));

@@ -192,6 +192,9 @@ int sfm_ransac_finalize(sfm_pair *pair, const sfm_ransac_params *p, uint32_t hyp
 /* Device-resident variants: copy the local key into caller memory (e.g. the tensor handed to the
  * RCCL all-reduce) and finalize from a reduced key without any host round trip. */
 int sfm_ransac_export_key(sfm_pair *pair, uint64_t *d_key_out);
+/* sfm_ransac_score that also leaves the shard's key in caller memory (the 8 bytes handed to the all-reduce): the scoring
+ * blocks write both copies, so the multi-GPU step needs no export in between. */
+int sfm_ransac_score_into(sfm_pair *pair, const sfm_ransac_params *p, uint64_t *d_key_out);
 int sfm_ransac_finalize_key(sfm_pair *pair, const sfm_ransac_params *p, const uint64_t *d_key);
 
 /* Image_pair::computePosecandidates(), sfm.cu:238-252 + candidate_kernels kernels.h:357-385. */

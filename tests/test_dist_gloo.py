@@ -24,12 +24,14 @@ class OraclePair:
         self.key = 0
         self.final = None
 
-    def ransac_score(self, p):
+    def ransac_score(self, p, key_out=None):
         if p.hyp_count == 0:
             self.key = 0
-            return
-        self.key, _, _ = self.O.ransac_range(self.X0, self.X1, p.hyp_begin, p.hyp_count, p.threshold,
-                                             p.jacobi_sweeps, seed=p.seed, want_counts=False, nthreads=2)
+        else:
+            self.key, _, _ = self.O.ransac_range(self.X0, self.X1, p.hyp_begin, p.hyp_count, p.threshold,
+                                                 p.jacobi_sweeps, seed=p.seed, want_counts=False, nthreads=2)
+        if key_out is not None:                      # sfm_ransac_score_into: the key also lands in the caller's tensor
+            key_out[0] = self.key
 
     def export_key(self, t):
         t[0] = self.key

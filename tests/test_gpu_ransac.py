@@ -239,3 +239,31 @@ def test_many_hypotheses_oversubscribed_grid(gpu, n, H):
     key, ocounts, _ = O.ransac_range(X0, X1, 0, H, p.threshold, p.jacobi_sweeps, seed=12)
     assert np.array_equal(pair.get_inlier_counts(H), ocounts)
     assert pair.get_key() == key
+
+
+@pytest.mark.parametrize("kernel,H", [(S.KERNEL_SPLIT, 40000), (S.KERNEL_SPLIT, 3000), (S.KERNEL_FUSED, 500), (S.KERNEL_MFMA, 2000)])
+def test_score_into_leaves_the_key_in_caller_memory(gpu, kernel, H):
+    """sfm_ransac_score_into == sfm_ransac_score + sfm_ransac_export_key, for every kernel family, also on a buffer that
+    holds garbage before the call and across repeated calls (the keys are cleared inside the call)."""
+    torch, dev, ctx = gpu
+    n = 1200
+    scene = synth.two_view_scene(n, seed=71)
+    pair, _ = make_pair(S, gpu, scene)
+    p = S.default_params(n, num_hypotheses=H, seed=4, kernel=kernel)
+    pair.ransac_score(p)
+    ref = torch.zeros(1, dtype=torch.int64, device=dev)
+    pair.export_key(ref)
+    torch.cuda.synchronize()
+    for _ in range(3):
+        out = torch.full((1,), 0x7FFFFFFFFFFFFFFF, dtype=torch.int64, device=dev)
+        pair.ransac_score(p, key_out=out)
+        pair.ransac_finalize_key(p, out)
+        torch.cuda.synchronize()
+        assert int(out.item()) == int(ref.item()) == pair.get_key()
+        assert pair.get_best() == tuple(reversed(S.unpack_key(int(ref.item()))))
+    q = S.default_params(n, num_hypotheses=H, seed=4, kernel=kernel)
+    q.hyp_begin, q.hyp_count = H, 0                       # empty shard: key 0
+    out = torch.full((1,), 5, dtype=torch.int64, device=dev)
+    pair.ransac_score(q, key_out=out)
+    torch.cuda.synchronize()
+    assert int(out.item()) == 0
