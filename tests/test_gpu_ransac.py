@@ -267,3 +267,20 @@ def test_score_into_leaves_the_key_in_caller_memory(gpu, kernel, H):
     pair.ransac_score(q, key_out=out)
     torch.cuda.synchronize()
     assert int(out.item()) == 0
+
+
+def test_generic_z_two_hypotheses_per_wavefront(gpu):
+    """Homogeneous coordinates with z != 1 and enough hypotheses for the two-per-wavefront scoring kernel (generic 96 KiB
+    tile layout): every count against the oracle."""
+    torch, dev, ctx = gpu
+    n, H = 1300, 50001                                     # odd count: the last wavefront scores a single hypothesis
+    scene = synth.two_view_scene(n, seed=44)
+    _, _, X0, X1 = oracle_xu(scene)
+    X0s = np.ascontiguousarray(X0 * (0.5 + synth.uniform01(3, n)).astype(np.float32))
+    X1s = np.ascontiguousarray(X1 * (2.0 - synth.uniform01(4, n)).astype(np.float32))
+    pair = S.ImagePair(ctx, scene["K"], scene["Kinv"], 2, n)
+    pair.set_points(to_dev(torch, dev, X0s), to_dev(torch, dev, X1s))
+    p = S.default_params(n, num_hypotheses=H, seed=8)
+    pair.estimateE(p)
+    key, ocounts, _ = O.ransac_range(X0s, X1s, 0, H, p.threshold, p.jacobi_sweeps, seed=8)
+    assert np.array_equal(pair.get_inlier_counts(H), ocounts) and pair.get_key() == key
