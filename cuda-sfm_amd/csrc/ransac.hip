@@ -274,7 +274,7 @@ int launch_ransac_score(sfm_pair *pair, const sfm_ransac_params &p, uint32_t h0,
     // hypotheses per wavefront: with plenty of work two, which share every point record read from LDS (half the LDS
     // traffic and address arithmetic per evaluated pair: 1.98 -> 1.83 ms per 2^20 x 4096 on the same box)
     // (three or four per wavefront need > 64 VGPRs, i.e. half the occupancy: 2.01 / 1.91 ms)
-    const int nh = (wpb == 16 && count >= 32768u) ? 2 : 1;
+    const int nh = (wpb == 16 && count >= 8192u) ? 2 : 1;         // at 4096 hypotheses two per wavefront leave CUs without a block
     const uint32_t nbatch = (count + wpb * nh - 1) / (wpb * nh);
     // unit-z layout: fixed 64 KiB (two arrays of kTileMax/2 pair records); generic: 24 B per point
     const bool uz = pair->unit_z;

@@ -38,7 +38,7 @@ def main():
 
     def ransac_round():
         n = int(rng.choice([rng.integers(8, 200), rng.integers(200, 3000), rng.integers(3000, 9000)]))
-        H = int(rng.choice([rng.integers(1, 64), rng.integers(64, 1500), rng.integers(1500, 6000)]))
+        H = int(rng.choice([rng.integers(1, 64), rng.integers(64, 1500), rng.integers(1500, 6000), rng.integers(6000, 24000)]))
         kernel = int(rng.choice([S.KERNEL_AUTO, S.KERNEL_SPLIT, S.KERNEL_FUSED, S.KERNEL_MFMA]))
         sweeps = int(rng.choice([0, 0, 7, 3]))
         thr = float(np.float32(10.0 ** rng.uniform(-9, -2)))
