@@ -120,7 +120,7 @@ a, b, _, _ = synth.stereo_pair(720, 576, seed=5)
 whole_run(a, b, "whole_run_720x576", {"input": "synthetic stereo pair"})
 # the reference program's own input (src/main.cpp:250-251), kept as a fixture: the published 47.36 ms are for THIS pair
 dino = os.path.join(ROOT, "tests", "golden", "dino")
-if os.path.exists(os.path.join(dino, "viff.000.ppm")):
+if os.path.exists(os.path.join(dino, "dino_grey_000.pgm")):
     sys.path.insert(0, os.path.join(ROOT, "tests")); from helpers import read_pnm_grey
-    whole_run(read_pnm_grey(os.path.join(dino, "viff.000.ppm")), read_pnm_grey(os.path.join(dino, "viff.001.ppm")),
-              "whole_run_dino_pair", {"input": "data/dino/viff.000.ppm + viff.001.ppm (the reference program's input)"})
+    whole_run(read_pnm_grey(os.path.join(dino, "dino_grey_000.pgm")), read_pnm_grey(os.path.join(dino, "dino_grey_001.pgm")),
+              "whole_run_dino_pair", {"input": "data/dino/viff.000.ppm + viff.001.ppm (the reference program's input, as 8-bit grey)"})

@@ -10,7 +10,7 @@
   e2e_oracle.npz   seeded two-view scene -> oracle E / counts / mask / poses / points.  These are
                    ORACLE outputs (regression vectors for the HIP path and for oracle refactors),
                    not reference outputs: the reference's estimateE is not reproducible.
-  dino/, dino_oracle.npz   the reference program's own input images (data/dino/viff.000/001.ppm, frames 2-3 as grey
+  dino/, dino_oracle.npz   the reference program's own input images (data/dino/viff.000 .. 003.ppm, stored as 8-bit grey
                    PGM) and the oracle's results on that pair (ORACLE outputs, see gen_dino).
 Only data is written; no reference source text is stored."""
 import ctypes as C
@@ -110,19 +110,18 @@ def gen_e2e():
 
 def gen_dino():
     """The reference program's own input (src/main.cpp:250-251 reads data/dino/viff.000.ppm and viff.001.ppm):
-    the two frames are copied as data fixtures (plus frames 2 and 3 as grey PGM for the 4-view ring), and the
+    frames 0..3 are kept as 8-bit grey PGM data fixtures (0 and 1: the pair of main.cpp, 2 and 3: for the 4-view ring), and the
     oracle's results on the pair are frozen so that a drift of the oracle shows up in the CPU suite."""
-    import shutil
     from helpers import read_pnm_grey, DINO_KINV, DINO_SIFT
     src = "/root/reference/data/dino"
     dst = os.path.join(OUT, "dino"); os.makedirs(dst, exist_ok=True)
-    for k in (0, 1):
-        shutil.copyfile(f"{src}/viff.{k:03d}.ppm", f"{dst}/viff.{k:03d}.ppm"); os.chmod(f"{dst}/viff.{k:03d}.ppm", 0o644)
-    for k in (2, 3):
+    # stored as 8-bit grey (the conversion cv::imread(path, 0) applies before the reference program sees a pixel):
+    # derived data, a third of the size, and not a byte copy of the reference's files
+    for k in (0, 1, 2, 3):
         g = read_pnm_grey(f"{src}/viff.{k:03d}.ppm").astype(np.uint8)
-        with open(f"{dst}/viff.{k:03d}.pgm", "wb") as f:
+        with open(f"{dst}/dino_grey_{k:03d}.pgm", "wb") as f:
             f.write(b"P5\n%d %d\n255\n" % (g.shape[1], g.shape[0])); f.write(g.tobytes())
-    imgs = [read_pnm_grey(f"{dst}/viff.{k:03d}.ppm") for k in (0, 1)]
+    imgs = [read_pnm_grey(f"{dst}/dino_grey_{k:03d}.pgm") for k in (0, 1)]
     feats = [O.extract_sift(im, DINO_SIFT["num_octaves"], DINO_SIFT["init_blur"], DINO_SIFT["thresh"], 0.0, False, 32768) for im in imgs]
     n1 = feats[0][1]
     m = O.match_sift(feats[0][0][:n1].copy(), feats[1][0][:feats[1][1]])

@@ -1,5 +1,6 @@
 """BASELINE configs[1] on the REAL data: the two frames the reference program reads (src/main.cpp:250-251,
-data/dino/viff.000.ppm / viff.001.ppm, kept as fixtures under tests/golden/dino/), its own parameters
+data/dino/viff.000.ppm / viff.001.ppm, kept as 8-bit grey fixtures under tests/golden/dino/ -- the conversion
+cv::imread(path, 0) applies), its own parameters
 (initBlur 1.5, thresh 1.0, 5 octaves, 32768 points, K of main.cpp:292-297, H = N/8, threshold 1e-6):
 ExtractSift x2 -> MatchSiftData -> fillXU -> estimateE -> computePosecandidates -> choosePose ->
 linear_triangulation, every stage bit for bit against the oracle chain and the frozen oracle results; then the
@@ -21,8 +22,7 @@ FIELDS = ("xpos", "ypos", "scale", "sharpness", "edgeness", "orientation", "subs
 
 
 def frame(k):
-    ext = "ppm" if k < 2 else "pgm"
-    return os.path.join(DINO, f"viff.{k:03d}.{ext}")
+    return os.path.join(DINO, f"dino_grey_{k:03d}.pgm")
 
 
 def extract(gpu, img, max_pts=32768):

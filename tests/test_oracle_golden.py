@@ -122,7 +122,7 @@ def test_dino_pair_oracle_results_are_frozen():
     reproduces the committed results: features, matches, per-hypothesis counts, winner, E."""
     from helpers import DINO_KINV, DINO_SIFT, read_pnm_grey
     gold = np.load(os.path.join(G, "dino_oracle.npz"))
-    imgs = [read_pnm_grey(os.path.join(G, "dino", f"viff.{k:03d}.ppm")) for k in (0, 1)]
+    imgs = [read_pnm_grey(os.path.join(G, "dino", f"dino_grey_{k:03d}.pgm")) for k in (0, 1)]
     feats = [O.extract_sift(im, DINO_SIFT["num_octaves"], DINO_SIFT["init_blur"], DINO_SIFT["thresh"], 0.0, False, 32768) for im in imgs]
     assert [f[1] for f in feats] == gold["num_pts"].tolist() and [f[2] for f in feats] == gold["stored"].tolist()
     n1 = feats[0][1]
