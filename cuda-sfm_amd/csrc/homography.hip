@@ -89,61 +89,73 @@ void homo_sample_kernel(const int *__restrict__ valid, const unsigned int *__res
 }
 
 // 8x8 inverse: Crout LU with implicit (row-scaled) partial pivoting + eight back-substitutions
-// (the scheme of InvertMatrix<8>, matching.cu:821-905).  One matrix per thread, local arrays.
-__device__ void invert8(float (&e)[8][8], float (&res)[8][8])
+// (the scheme of InvertMatrix<8>, matching.cu:821-905).  One matrix per thread.  The pivot rows are data dependent, so
+// the matrices cannot live in registers; they sit in LDS, element-major ([element][thread]: every access of a wavefront
+// hits 64 different banks whatever row a lane picked) instead of per-thread scratch memory.
+struct LaneVec {                               // per-thread vector / matrix in LDS, element stride = threads per block
+    float *base;
+    __device__ __forceinline__ float &operator[](int k) const { return base[k * 64]; }
+};
+struct LaneMat {
+    float *base;
+    __device__ __forceinline__ float &operator()(int i, int j) const { return base[(i * 8 + j) * 64]; }
+};
+
+__device__ void invert8(const LaneMat &e, const LaneMat &res, const LaneVec &vv, const LaneVec &b, int (&indx)[8])
 {
-    int indx[8];
-    float vv[8], b[8];
     int imax = 0;
     for (int i = 0; i < 8; ++i) {
         float big = 0.0f;
-        for (int j = 0; j < 8; ++j) { const float t = fabsf(e[i][j]); if (t > big) big = t; }
+        for (int j = 0; j < 8; ++j) { const float t = fabsf(e(i, j)); if (t > big) big = t; }
         vv[i] = (big > 0.0f) ? (float)(1.0 / (double)big) : (float)1e16;
-        indx[i] = 0;
     }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) indx[i] = 0;
     for (int j = 0; j < 8; ++j) {
         for (int i = 0; i < j; ++i) {
-            float sum = e[i][j];
-            for (int k = 0; k < i; ++k) sum -= e[i][k] * e[k][j];
-            e[i][j] = sum;
+            float sum = e(i, j);
+            for (int k = 0; k < i; ++k) sum -= e(i, k) * e(k, j);
+            e(i, j) = sum;
         }
         float big = 0.0f;
         for (int i = j; i < 8; ++i) {
-            float sum = e[i][j];
-            for (int k = 0; k < j; ++k) sum -= e[i][k] * e[k][j];
-            e[i][j] = sum;
+            float sum = e(i, j);
+            for (int k = 0; k < j; ++k) sum -= e(i, k) * e(k, j);
+            e(i, j) = sum;
             const float dum = vv[i] * fabsf(sum);
             if (dum >= big) { big = dum; imax = i; }
         }
         if (j != imax) {
-            for (int k = 0; k < 8; ++k) { const float d = e[imax][k]; e[imax][k] = e[j][k]; e[j][k] = d; }
+            for (int k = 0; k < 8; ++k) { const float d = e(imax, k); e(imax, k) = e(j, k); e(j, k) = d; }
             vv[imax] = vv[j];
         }
-        indx[j] = imax;
-        if (e[j][j] == 0.0f) e[j][j] = (float)1e-16;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) if (q == j) indx[q] = imax;
+        if (e(j, j) == 0.0f) e(j, j) = (float)1e-16;
         if (j != 7) {
-            const float dum = (float)(1.0 / (double)e[j][j]);
-            for (int i = j + 1; i < 8; ++i) e[i][j] *= dum;
+            const float dum = (float)(1.0 / (double)e(j, j));
+            for (int i = j + 1; i < 8; ++i) e(i, j) *= dum;
         }
     }
     for (int j = 0; j < 8; ++j) {
         for (int k = 0; k < 8; ++k) b[k] = 0.0f;
         b[j] = 1.0f;
         int ii = -1;
+#pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int ip = indx[i];
             float sum = b[ip];
             b[ip] = b[i];
-            if (ii != -1) { for (int k = ii; k < i; ++k) sum -= e[i][k] * b[k]; }
+            if (ii != -1) { for (int k = ii; k < i; ++k) sum -= e(i, k) * b[k]; }
             else if (sum != 0.0f) ii = i;
             b[i] = sum;
         }
         for (int i = 7; i >= 0; --i) {
             float sum = b[i];
-            for (int k = i + 1; k < 8; ++k) sum -= e[i][k] * b[k];
-            b[i] = sum / e[i][i];
+            for (int k = i + 1; k < 8; ++k) sum -= e(i, k) * b[k];
+            b[i] = sum / e(i, i);
         }
-        for (int i = 0; i < 8; ++i) res[i][j] = b[i];
+        for (int i = 0; i < 8; ++i) res(i, j) = b[i];
     }
 }
 
@@ -151,21 +163,28 @@ __device__ void invert8(float (&e)[8][8], float (&res)[8][8])
 __global__ __launch_bounds__(64)
 void homo_solve_kernel(const float *__restrict__ coord, int ld, const int *__restrict__ pts, int L, float *__restrict__ homo)
 {
+    __shared__ float lds_a[64 * 64], lds_ia[64 * 64], lds_v[2 * 8 * 64];
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= L) return;
-    float a[8][8], ia[8][8], b[8];
+    const LaneMat a{ lds_a + threadIdx.x }, ia{ lds_ia + threadIdx.x };
+    const LaneVec vv{ lds_v + threadIdx.x }, bw{ lds_v + 8 * 64 + threadIdx.x };
+    float b[8];
+#pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int pt = pts[i * L + idx];
         const float x1 = coord[pt], y1 = coord[pt + ld], x2 = coord[pt + 2 * ld], y2 = coord[pt + 3 * ld];
-        float *r1 = a[2 * i], *r2 = a[2 * i + 1];
-        r1[0] = x1; r1[1] = y1; r1[2] = 1.0f; r1[3] = r1[4] = r1[5] = 0.0f; r1[6] = (-x2) * x1; r1[7] = (-x2) * y1;
-        r2[0] = r2[1] = r2[2] = 0.0f; r2[3] = x1; r2[4] = y1; r2[5] = 1.0f; r2[6] = (-y2) * x1; r2[7] = (-y2) * y1;
+        const int r1 = 2 * i, r2 = 2 * i + 1;
+        a(r1, 0) = x1; a(r1, 1) = y1; a(r1, 2) = 1.0f; a(r1, 3) = 0.0f; a(r1, 4) = 0.0f; a(r1, 5) = 0.0f; a(r1, 6) = (-x2) * x1; a(r1, 7) = (-x2) * y1;
+        a(r2, 0) = 0.0f; a(r2, 1) = 0.0f; a(r2, 2) = 0.0f; a(r2, 3) = x1; a(r2, 4) = y1; a(r2, 5) = 1.0f; a(r2, 6) = (-y2) * x1; a(r2, 7) = (-y2) * y1;
         b[2 * i] = x2; b[2 * i + 1] = y2;
     }
-    invert8(a, ia);
+    int indx[8];
+    invert8(a, ia, vv, bw, indx);
+#pragma unroll
     for (int j = 0; j < 8; ++j) {
         float sum = 0.0f;
-        for (int i = 0; i < 8; ++i) sum += ia[j][i] * b[i];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) sum += ia(j, i) * b[i];
         homo[j * L + idx] = sum;
     }
 }
