@@ -52,11 +52,11 @@ EXPORTS = [
     "sfm_copy_to_host_2d", "sfm_copy_to_device_2d", "sfm_find_homography", "sfm_sift_temp_layout", "sfm_extract_sift", "sfm_extract_sift_begin", "sfm_extract_sift_end", "sfm_match", "sfm_match_soa",
     "sfm_pair_create", "sfm_pair_destroy", "sfm_pair_reset", "sfm_get_result", "sfm_fill_xu", "sfm_set_points", "sfm_ransac_default_params",
     "sfm_ransac_permutation_indices", "sfm_estimate_E", "sfm_ransac_score", "sfm_ransac_score_into", "sfm_ransac_finalize",
-    "sfm_ransac_finalize_key", "sfm_ransac_export_key", "sfm_pose_candidates", "sfm_choose_pose", "sfm_triangulate",
+    "sfm_ransac_finalize_key", "sfm_ransac_finalize_key_on", "sfm_ransac_export_key", "sfm_pose_candidates", "sfm_choose_pose", "sfm_triangulate",
     "sfm_pair_device_ptr", "sfm_pair_ld", "sfm_pair_num_points", "sfm_get_XU", "sfm_get_E", "sfm_get_best",
     "sfm_get_key", "sfm_get_inlier_counts", "sfm_get_inlier_mask", "sfm_get_E_candidates",
     "sfm_get_pose_candidates", "sfm_get_pose_inverses", "sfm_get_pose_index", "sfm_get_points", "sfm_copy_points_to_vbo",
-    "sfm_ransac_last_launch",
+    "sfm_ransac_last_launch", "sfm_ransac_last_clock",
 ]
 
 
@@ -109,6 +109,7 @@ _lib.sfm_ransac_score.argtypes = [_vp, C.POINTER(RansacParams)]
 _lib.sfm_ransac_score_into.argtypes = [_vp, C.POINTER(RansacParams), _vp]
 _lib.sfm_ransac_finalize.argtypes = [_vp, C.POINTER(RansacParams), C.c_uint32]
 _lib.sfm_ransac_finalize_key.argtypes = [_vp, C.POINTER(RansacParams), _vp]
+_lib.sfm_ransac_finalize_key_on.argtypes = [_vp, C.POINTER(RansacParams), _vp, _vp]
 _lib.sfm_ransac_export_key.argtypes = [_vp, _vp]
 _lib.sfm_pose_candidates.argtypes = [_vp, C.c_int]
 _lib.sfm_choose_pose.argtypes = [_vp, C.c_int]
@@ -130,6 +131,7 @@ _lib.sfm_get_points.argtypes = [_vp, _vp]
 _lib.sfm_pair_reset.argtypes = [_vp, C.c_int]
 _lib.sfm_get_result.argtypes = [_vp, _vp]
 _lib.sfm_ransac_last_launch.argtypes = [_vp] + [C.POINTER(C.c_int)] * 4
+_lib.sfm_ransac_last_clock.argtypes = [_vp, C.POINTER(C.c_double)]
 
 
 class SfmError(RuntimeError):
@@ -349,6 +351,10 @@ class ImagePair:
     def ransac_finalize_key(self, params, d_key):
         _check(_lib.sfm_ransac_finalize_key(self._h, C.byref(params), _ptr(d_key)), "sfm_ransac_finalize_key")
 
+    def ransac_finalize_key_on(self, params, d_key, hip_stream=None):
+        """finalize on another stream of the device (None = the context's); E is re-derived from the hypothesis id."""
+        _check(_lib.sfm_ransac_finalize_key_on(self._h, C.byref(params), _ptr(d_key), _vp(hip_stream or 0)), "sfm_ransac_finalize_key_on")
+
     def computePosecandidates(self, mode=POSE_REFERENCE):
         _check(_lib.sfm_pose_candidates(self._h, int(mode)), "sfm_pose_candidates")
 
@@ -426,6 +432,11 @@ class ImagePair:
         _check(_lib.sfm_ransac_last_launch(self._h, *[C.byref(x) for x in v]), "sfm_ransac_last_launch")
         return {"kernel": v[0].value, "grid": v[1].value, "block": v[2].value, "lds_bytes": v[3].value}
 
+    def last_clock_mhz(self):
+        v = C.c_double()
+        _check(_lib.sfm_ransac_last_clock(self._h, C.byref(v)), "sfm_ransac_last_clock")
+        return v.value
+
     def close(self):
         if getattr(self, "_h", None):
             _lib.sfm_pair_destroy(self._h)
@@ -454,7 +465,8 @@ def estimate_E_distributed(pair, params, rank, world, key_tensor, all_reduce_max
 
 
 # ---- RCCL exchange step in C (include/sfm_amd_comm.h, libsfm_amd_rccl.so) ----------------------------
-COMM_EXPORTS = ["sfm_comm_unique_id", "sfm_comm_init", "sfm_comm_destroy", "sfm_comm_rank", "sfm_estimate_E_sharded"]
+COMM_EXPORTS = ["sfm_comm_unique_id", "sfm_comm_init", "sfm_comm_destroy", "sfm_comm_rank", "sfm_comm_nccl_ranks", "sfm_estimate_E_sharded",
+                "sfm_estimate_E_sharded_pipelined", "sfm_comm_flush"]
 COMM_LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), "libsfm_amd_rccl.so")
 COMM_ID_BYTES = 128
 _comm_lib = None
@@ -472,6 +484,9 @@ def comm_lib():
         L.sfm_comm_destroy.argtypes = [_vp]
         L.sfm_comm_rank.argtypes = [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.sfm_estimate_E_sharded.argtypes = [_vp, C.POINTER(RansacParams), _vp]
+        L.sfm_estimate_E_sharded_pipelined.argtypes = [_vp, C.POINTER(RansacParams), _vp]
+        L.sfm_comm_flush.argtypes = [_vp]
+        L.sfm_comm_nccl_ranks.argtypes = [_vp, C.POINTER(C.c_int)]
         _comm_lib = L
     return _comm_lib
 
@@ -498,6 +513,19 @@ class Comm:
     def estimate_E(self, pair, params):
         """estimateE over all ranks (params.num_hypotheses = global count): shard, ONE all-reduce(max), local finalize."""
         _check(comm_lib().sfm_estimate_E_sharded(pair._h, C.byref(params), self._h), "sfm_estimate_E_sharded")
+
+    def estimate_E_pipelined(self, pair, params):
+        """The same step with its exchange + finalize on the communicator's own stream, so that the next call's scoring
+        overlaps this call's all-reduce; flush() before reading results."""
+        _check(comm_lib().sfm_estimate_E_sharded_pipelined(pair._h, C.byref(params), self._h), "sfm_estimate_E_sharded_pipelined")
+
+    def flush(self):
+        _check(comm_lib().sfm_comm_flush(self._h), "sfm_comm_flush")
+
+    def nccl_ranks(self):
+        n = C.c_int()
+        _check(comm_lib().sfm_comm_nccl_ranks(self._h, C.byref(n)), "sfm_comm_nccl_ranks")
+        return n.value
 
     def close(self):
         if getattr(self, "_h", None):

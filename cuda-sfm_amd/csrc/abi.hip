@@ -362,12 +362,13 @@ int sfm_pair_create(sfm_ctx *ctx, const float h_K[9], const float h_Kinv[9], int
     A(&p->d_E, 9); A(&p->d_P, 64); A(&p->d_Pinv, 64); A(&p->d_Pind, 8);
     A(&p->d_points, (size_t)4 * num_points);
     A(&p->d_mask, (size_t)num_points);
-    A(&p->d_key, 2); A(&p->d_best, 2);
+    A(&p->d_key, 2); A(&p->d_best, 2); A(&p->d_clk, 2);
     if (rc != SFM_OK) { sfm_pair_destroy(p); return rc; }
     hipError_t e = hipMemcpyAsync(p->d_K, h_K, 9 * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(p->d_Kinv, h_Kinv, 9 * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipMemsetAsync(p->d_key, 0, 2 * sizeof(unsigned long long), ctx->stream);
     if (e == hipSuccess) e = hipMemsetAsync(p->d_best, 0, 2 * sizeof(uint32_t), ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(p->d_clk, 0, 2 * sizeof(unsigned long long), ctx->stream);
     if (e == hipSuccess) e = hipMemsetAsync(p->d_Pind, 0, 8 * sizeof(int), ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);       // host K arrays may go out of scope
     if (e != hipSuccess) { sfm_pair_destroy(p); set_error("pair init failed: %s", hipGetErrorString(e)); return SFM_E_HIP; }
@@ -382,7 +383,7 @@ int sfm_pair_reset(sfm_pair *pair, int num_points)
                 "num_points %d outside (0, %d] (the size the pair was created with)", num_points, pair->cap_points);
     pair->n = num_points;
     pair->ld = round_up(num_points, 128);
-    pair->have_points = pair->have_E = pair->have_P = pair->have_pose = false;
+    pair->have_points = pair->have_E = pair->have_P = pair->have_pose = pair->have_points3d = false;
     pair->last_count = 0;
     return SFM_OK;
 }
@@ -392,7 +393,7 @@ int sfm_pair_destroy(sfm_pair *p)
     if (!p) return SFM_OK;
     if (p->ctx) { (void)hipSetDevice(p->ctx->device); (void)hipStreamSynchronize(p->ctx->stream); }
     void *bufs[] = { p->d_K, p->d_Kinv, p->d_U[0], p->d_U[1], p->d_X[0], p->d_X[1], p->d_E, p->d_P, p->d_Pinv, p->d_Pind,
-                     p->d_points, p->d_mask, p->d_key, p->d_best, p->d_counts, p->d_Ecand };
+                     p->d_points, p->d_mask, p->d_key, p->d_best, p->d_counts, p->d_Ecand, p->d_clk };
     for (void *b : bufs) if (b) (void)hipFree(b);
     delete p;
     return SFM_OK;
@@ -404,7 +405,7 @@ int sfm_fill_xu(sfm_pair *pair, const sfm_sift_point *d_data)
     SFM_HIP_TRY(hipSetDevice(pair->ctx->device));
     int rc = launch_fill_xu(pair, d_data);
     if (rc == SFM_OK) {
-        pair->have_points = true; pair->have_E = pair->have_P = pair->have_pose = false; pair->last_count = 0;
+        pair->have_points = true; pair->have_E = pair->have_P = pair->have_pose = pair->have_points3d = false; pair->last_count = 0;
         // X_z = fma(Kinv[8], 1, fma(Kinv[7], y, Kinv[6] * x)) is exactly 1 for finite pixel coordinates when
         // the last row of K^-1 is (0 0 1): the scoring kernel may then drop z (ransac_device.hpp)
         pair->unit_z = pair->h_Kinv[6] == 0.0f && pair->h_Kinv[7] == 0.0f && pair->h_Kinv[8] == 1.0f;
@@ -417,7 +418,7 @@ int sfm_set_points(sfm_pair *pair, const float *d_X0, const float *d_X1)
     SFM_REQUIRE(pair && d_X0 && d_X1, SFM_E_INVALID, "null argument");
     SFM_HIP_TRY(hipSetDevice(pair->ctx->device));
     int rc = launch_set_points(pair, d_X0, d_X1);
-    if (rc == SFM_OK) { pair->have_points = true; pair->have_E = pair->have_P = pair->have_pose = false; pair->last_count = 0; pair->unit_z = false; }
+    if (rc == SFM_OK) { pair->have_points = true; pair->have_E = pair->have_P = pair->have_pose = pair->have_points3d = false; pair->last_count = 0; pair->unit_z = false; }
     return rc;
 }
 
@@ -467,7 +468,7 @@ int sfm_ransac_finalize(sfm_pair *pair, const sfm_ransac_params *p, uint32_t hyp
     SFM_REQUIRE(hyp < p->num_hypotheses, SFM_E_INVALID, "hypothesis id %u out of range", hyp);
     SFM_HIP_TRY(hipSetDevice(pair->ctx->device));
     rc = launch_ransac_finalize(pair, *p, nullptr, hyp, false);
-    if (rc == SFM_OK) { pair->have_E = true; pair->have_P = pair->have_pose = false; }
+    if (rc == SFM_OK) { pair->have_E = true; pair->have_P = pair->have_pose = pair->have_points3d = false; }
     return rc;
 }
 
@@ -487,7 +488,20 @@ int sfm_ransac_finalize_key(sfm_pair *pair, const sfm_ransac_params *p, const ui
     SFM_REQUIRE(d_key, SFM_E_INVALID, "null key pointer");
     SFM_HIP_TRY(hipSetDevice(pair->ctx->device));
     rc = launch_ransac_finalize(pair, *p, reinterpret_cast<const unsigned long long *>(d_key), 0, true);
-    if (rc == SFM_OK) { pair->have_E = true; pair->have_P = pair->have_pose = false; }
+    if (rc == SFM_OK) { pair->have_E = true; pair->have_P = pair->have_pose = pair->have_points3d = false; }
+    return rc;
+}
+
+int sfm_ransac_finalize_key_on(sfm_pair *pair, const sfm_ransac_params *p, const uint64_t *d_key, void *hip_stream)
+{
+    uint32_t h0, count;
+    int rc = resolve_shard(pair, p, &h0, &count);
+    if (rc != SFM_OK) return rc;
+    SFM_REQUIRE(d_key, SFM_E_INVALID, "null key pointer");
+    SFM_HIP_TRY(hipSetDevice(pair->ctx->device));
+    rc = launch_ransac_finalize(pair, *p, reinterpret_cast<const unsigned long long *>(d_key), 0, true,
+                                static_cast<hipStream_t>(hip_stream), true);
+    if (rc == SFM_OK) { pair->have_E = true; pair->have_P = pair->have_pose = pair->have_points3d = false; }
     return rc;
 }
 
@@ -501,7 +515,7 @@ int sfm_estimate_E(sfm_pair *pair, const sfm_ransac_params *p)
     rc = launch_ransac_score(pair, *p, h0, count);
     if (rc != SFM_OK) return rc;
     rc = launch_ransac_finalize(pair, *p, pair->d_key, 0, true);     // arg-max stays on the device
-    if (rc == SFM_OK) { pair->have_E = true; pair->have_P = pair->have_pose = false; }
+    if (rc == SFM_OK) { pair->have_E = true; pair->have_P = pair->have_pose = pair->have_points3d = false; }
     return rc;
 }
 
@@ -512,7 +526,7 @@ int sfm_pose_candidates(sfm_pair *pair, int mode)
     SFM_REQUIRE(pair->have_E, SFM_E_STATE, "computePosecandidates before estimateE");
     SFM_HIP_TRY(hipSetDevice(pair->ctx->device));
     int rc = launch_pose_candidates(pair, mode);
-    if (rc == SFM_OK) { pair->have_P = true; pair->have_pose = false; pair->pose_mode = mode; }
+    if (rc == SFM_OK) { pair->have_P = true; pair->have_pose = pair->have_points3d = false; pair->pose_mode = mode; }
     return rc;
 }
 
@@ -523,7 +537,7 @@ int sfm_choose_pose(sfm_pair *pair, int mode)
     SFM_REQUIRE(pair->have_P, SFM_E_STATE, "choosePose before computePosecandidates");
     SFM_HIP_TRY(hipSetDevice(pair->ctx->device));
     int rc = launch_choose_pose(pair, mode);
-    if (rc == SFM_OK) pair->have_pose = true;
+    if (rc == SFM_OK) { pair->have_pose = true; pair->have_points3d = false; }
     return rc;
 }
 
@@ -533,7 +547,9 @@ int sfm_triangulate(sfm_pair *pair, int mode)
     SFM_REQUIRE(mode == SFM_POSE_REFERENCE || mode == SFM_POSE_CORRECT, SFM_E_INVALID, "unknown pose mode %d", mode);
     SFM_REQUIRE(pair->have_pose, SFM_E_STATE, "linear_triangulation before choosePose");
     SFM_HIP_TRY(hipSetDevice(pair->ctx->device));
-    return launch_triangulate(pair, mode);
+    int rc = launch_triangulate(pair, mode);
+    if (rc == SFM_OK) pair->have_points3d = true;
+    return rc;
 }
 
 // ---- accessors ------------------------------------------------------------------------------------
@@ -593,6 +609,7 @@ int sfm_get_best(sfm_pair *pair, uint32_t *hyp, uint32_t *count)
     if (rc != SFM_OK) return rc;
     if (hyp) *hyp = b[0];
     if (count) *count = b[1];
+    SFM_REQUIRE(b[0] != 0xFFFFFFFFu, SFM_E_STATE, "the finalized key named no hypothesis (empty shards, uninitialised key or failed all-reduce)");
     return SFM_OK;
 }
 
@@ -665,6 +682,7 @@ int sfm_get_result(sfm_pair *pair, float h_record[28])
     const int ind = v[0] >= 0 && v[0] < 4 ? v[0] : 0;
     for (int k = 0; k < 16; ++k) h_record[9 + k] = P[16 * ind + k];
     h_record[25] = (float)v[0]; h_record[26] = (float)b[1]; h_record[27] = (float)b[0];
+    SFM_REQUIRE(b[0] != 0xFFFFFFFFu, SFM_E_STATE, "the finalized key named no hypothesis (empty shards, uninitialised key or failed all-reduce)");
     if (v[5] & (1 << ind)) { set_error("chosen pose candidate %d is singular", ind); return SFM_E_SINGULAR; }
     return SFM_OK;
 }
@@ -672,17 +690,27 @@ int sfm_get_result(sfm_pair *pair, float h_record[28])
 int sfm_get_points(sfm_pair *pair, float *h_points)
 {
     SFM_REQUIRE(pair && h_points, SFM_E_INVALID, "null argument");
-    SFM_REQUIRE(pair->have_pose, SFM_E_STATE, "linear_triangulation has not run");
+    SFM_REQUIRE(pair->have_points3d, SFM_E_STATE, "linear_triangulation has not run");
     return copy_out(pair, h_points, pair->d_points, (size_t)4 * pair->n * 4);
 }
 
 int sfm_copy_points_to_vbo(sfm_pair *pair, float *d_positions, float *d_velocities, float scale)
 {
     SFM_REQUIRE(pair, SFM_E_INVALID, "null pair");
-    SFM_REQUIRE(pair->have_pose, SFM_E_STATE, "linear_triangulation has not run");
+    SFM_REQUIRE(pair->have_points3d, SFM_E_STATE, "linear_triangulation has not run");
     SFM_REQUIRE((((uintptr_t)d_positions | (uintptr_t)d_velocities) & 15u) == 0, SFM_E_INVALID, "vertex buffers must be 16-byte aligned");
     SFM_HIP_TRY(hipSetDevice(pair->ctx->device));
     return launch_points_to_vbo(pair, d_positions, d_velocities, scale);
+}
+
+int sfm_ransac_last_clock(sfm_pair *pair, double *shader_mhz)
+{
+    SFM_REQUIRE(pair && shader_mhz, SFM_E_INVALID, "null argument");
+    unsigned long long c[2] = { 0, 0 };
+    int rc = copy_out(pair, c, pair->d_clk, sizeof(c));
+    if (rc != SFM_OK) return rc;
+    *shader_mhz = c[1] ? 100.0 * (double)c[0] / (double)c[1] : 0.0;
+    return SFM_OK;
 }
 
 int sfm_ransac_last_launch(sfm_pair *pair, int *kernel, int *grid, int *block, int *lds_bytes)

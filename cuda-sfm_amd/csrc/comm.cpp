@@ -13,6 +13,14 @@ struct sfm_comm {
     sfm_ctx *ctx = nullptr;
     ncclComm_t nccl = nullptr;
     int rank = 0, nranks = 1;
+    int nccl_ranks = 0;                 // what ncclCommCount reports (must equal nranks)
+    // pipelined exchange (sfm_estimate_E_sharded_pipelined): the all-reduce and the finalize of pair k run on `xstream`
+    // while the context stream already scores pair k+1; two key slots, one event pair per slot
+    hipStream_t xstream = nullptr;
+    uint64_t *d_keys = nullptr;         // 2 x 8 bytes
+    hipEvent_t ev_scored[2] = { nullptr, nullptr }, ev_final[2] = { nullptr, nullptr };
+    unsigned long long step = 0;
+    bool final_pending = false;
 };
 
 namespace {
@@ -49,7 +57,20 @@ extern "C" int sfm_comm_init(sfm_ctx *ctx, const void *id128, int rank, int nran
     ncclUniqueId id = *static_cast<const ncclUniqueId *>(id128);
     ncclResult_t r = ncclCommInitRank(&c->nccl, nranks, id, rank);
     if (r != ncclSuccess) { delete c; return fail("ncclCommInitRank", ncclGetErrorString(r)); }
+    (void)ncclCommCount(c->nccl, &c->nccl_ranks);
     *out = c;
+    return SFM_OK;
+}
+
+static int ensure_pipeline(sfm_comm *c)
+{
+    if (c->xstream) return SFM_OK;
+    COMM_HIP_TRY(hipStreamCreateWithFlags(&c->xstream, hipStreamNonBlocking));
+    COMM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&c->d_keys), 2 * sizeof(uint64_t)));
+    for (int i = 0; i < 2; ++i) {
+        COMM_HIP_TRY(hipEventCreateWithFlags(&c->ev_scored[i], hipEventDisableTiming));
+        COMM_HIP_TRY(hipEventCreateWithFlags(&c->ev_final[i], hipEventDisableTiming));
+    }
     return SFM_OK;
 }
 
@@ -57,7 +78,14 @@ extern "C" int sfm_comm_destroy(sfm_comm *c)
 {
     if (!c) return SFM_OK;
     (void)sfm_ctx_synchronize(c->ctx);
+    if (c->xstream) (void)hipStreamSynchronize(c->xstream);
     if (c->nccl) (void)ncclCommDestroy(c->nccl);
+    for (int i = 0; i < 2; ++i) {
+        if (c->ev_scored[i]) (void)hipEventDestroy(c->ev_scored[i]);
+        if (c->ev_final[i]) (void)hipEventDestroy(c->ev_final[i]);
+    }
+    if (c->d_keys) (void)hipFree(c->d_keys);
+    if (c->xstream) (void)hipStreamDestroy(c->xstream);
     delete c;
     return SFM_OK;
 }
@@ -70,14 +98,27 @@ extern "C" int sfm_comm_rank(const sfm_comm *c, int *rank, int *nranks)
     return SFM_OK;
 }
 
-extern "C" int sfm_estimate_E_sharded(sfm_pair *pair, sfm_ransac_params *p, sfm_comm *c)
+extern "C" int sfm_comm_nccl_ranks(const sfm_comm *c, int *nccl_ranks)
 {
-    if (!pair || !p || !c) return SFM_E_INVALID;
-    // contiguous shard of the global id range (the same split as cuda_sfm_amd.shard_range: the first H % G ranks own one more)
+    if (!c || !nccl_ranks) return SFM_E_INVALID;
+    *nccl_ranks = c->nccl_ranks;
+    return SFM_OK;
+}
+
+// contiguous shard of the global id range (the same split as cuda_sfm_amd.shard_range: the first H % G ranks own one more)
+static void set_shard(sfm_ransac_params *p, const sfm_comm *c)
+{
     const uint32_t H = p->num_hypotheses, G = (uint32_t)c->nranks, r = (uint32_t)c->rank;
     const uint32_t base = H / G, rem = H % G;
     p->hyp_begin = r * base + (r < rem ? r : rem);
     p->hyp_count = base + (r < rem ? 1u : 0u);        // 0 only when hyp_begin == H: "all of [H, H)" = empty shard, key 0
+}
+
+extern "C" int sfm_estimate_E_sharded(sfm_pair *pair, sfm_ransac_params *p, sfm_comm *c)
+{
+    if (!pair || !p || !c) return SFM_E_INVALID;
+    if (c->final_pending) { int rcf = sfm_comm_flush(c); if (rcf != SFM_OK) return rcf; }
+    set_shard(p, c);
     void *stream = nullptr;
     int rc = sfm_ctx_get_stream(c->ctx, &stream);
     if (rc != SFM_OK) return rc;
@@ -90,4 +131,50 @@ extern "C" int sfm_estimate_E_sharded(sfm_pair *pair, sfm_ransac_params *p, sfm_
     if (!d_key || bytes < sizeof(uint64_t)) return fail("sfm_pair_device_ptr", "no key buffer");
     COMM_NCCL_TRY(ncclAllReduce(d_key, d_key, 1, ncclUint64, ncclMax, c->nccl, static_cast<hipStream_t>(stream)));
     return sfm_ransac_finalize_key(pair, p, static_cast<const uint64_t *>(d_key));
+}
+
+// The same step, software-pipelined over consecutive calls: step k's scoring is enqueued on the context stream, its
+// all-reduce + finalize on the exchange stream behind an event, and the call returns; step k+1's scoring therefore starts
+// while step k's 8 bytes are still in flight (the all-reduce is pure latency, ~tens of microseconds, the kernels of a
+// shard take a few hundred).  Key slot k % 2 is re-used only after step k-2's finalize has read it (event).  The pair's
+// results (E, mask, best) belong to the LAST finished step; sfm_comm_flush orders them before the context stream.
+extern "C" int sfm_estimate_E_sharded_pipelined(sfm_pair *pair, sfm_ransac_params *p, sfm_comm *c)
+{
+    if (!pair || !p || !c) return SFM_E_INVALID;
+    int rc = ensure_pipeline(c);
+    if (rc != SFM_OK) return rc;
+    set_shard(p, c);
+    void *stream_v = nullptr;
+    rc = sfm_ctx_get_stream(c->ctx, &stream_v);
+    if (rc != SFM_OK) return rc;
+    hipStream_t stream = static_cast<hipStream_t>(stream_v);
+    const int slot = (int)(c->step & 1ull);
+    uint64_t *d_key = c->d_keys + slot;
+    if (c->step >= 2) COMM_HIP_TRY(hipStreamWaitEvent(stream, c->ev_final[slot], 0));      // slot free again
+    rc = sfm_ransac_score_into(pair, p, d_key);
+    if (rc != SFM_OK) return rc;
+    COMM_HIP_TRY(hipEventRecord(c->ev_scored[slot], stream));
+    COMM_HIP_TRY(hipStreamWaitEvent(c->xstream, c->ev_scored[slot], 0));
+    COMM_NCCL_TRY(ncclAllReduce(d_key, d_key, 1, ncclUint64, ncclMax, c->nccl, c->xstream));
+    rc = sfm_ransac_finalize_key_on(pair, p, d_key, c->xstream);
+    if (rc != SFM_OK) return rc;
+    COMM_HIP_TRY(hipEventRecord(c->ev_final[slot], c->xstream));
+    c->step++;
+    c->final_pending = true;
+    return SFM_OK;
+}
+
+// Makes the context stream wait for every finalize enqueued by sfm_estimate_E_sharded_pipelined: after this the usual
+// getters (which synchronise the context stream) see the last step's E / mask / best.
+extern "C" int sfm_comm_flush(sfm_comm *c)
+{
+    if (!c) return SFM_E_INVALID;
+    if (!c->final_pending) return SFM_OK;
+    void *stream_v = nullptr;
+    int rc = sfm_ctx_get_stream(c->ctx, &stream_v);
+    if (rc != SFM_OK) return rc;
+    const int last = (int)((c->step - 1) & 1ull);
+    COMM_HIP_TRY(hipStreamWaitEvent(static_cast<hipStream_t>(stream_v), c->ev_final[last], 0));
+    c->final_pending = false;
+    return SFM_OK;
 }

@@ -87,6 +87,7 @@ struct sfm_pair {
     uint8_t *d_mask = nullptr;         // n
     unsigned long long *d_key = nullptr;   // [0] packed best of last score, [1] scratch
     uint32_t *d_best = nullptr;        // [0] hyp, [1] count of the finalized hypothesis
+    unsigned long long *d_clk = nullptr;   // [0] shader-clock ticks, [1] 100 MHz ticks over block 0 of the last ransac_score_waves launch
     // per-shard buffers, grown on demand
     int   *d_counts = nullptr;
     float *d_Ecand = nullptr;
@@ -96,6 +97,7 @@ struct sfm_pair {
     const int32_t *cand_indices = nullptr;
     int cand_sweeps = 0;
     bool have_points = false, have_E = false, have_P = false, have_pose = false;
+    bool have_points3d = false;        // linear_triangulation ran for the current pose (sfm_get_points / VBO export need it)
     bool unit_z = false;               // every X z-coordinate is exactly 1 (fillXU with K^-1 last row (0 0 1))
     float h_Kinv[9] = {};
     int pose_mode = SFM_POSE_REFERENCE;
@@ -106,13 +108,15 @@ namespace sfm {
 
 // ransac.hip
 int launch_ransac_score(sfm_pair *pair, const sfm_ransac_params &p, uint32_t h0, uint32_t count, unsigned long long *key2 = nullptr);
-int launch_ransac_finalize(sfm_pair *pair, const sfm_ransac_params &p, const unsigned long long *d_key, uint32_t hyp_host, bool from_key);
+int launch_ransac_finalize(sfm_pair *pair, const sfm_ransac_params &p, const unsigned long long *d_key, uint32_t hyp_host, bool from_key,
+                           hipStream_t stream = nullptr, bool rederive = false);
 int launch_permutation_indices(sfm_ctx *ctx, int n, uint32_t seed, int32_t *d_indices);
 // ransac_mfma.hip
 int launch_score_mfma(sfm_pair *pair, const sfm_ransac_params &p, uint32_t h0, uint32_t count);
 // ransac_fused.hip
 int launch_ransac_fused(sfm_pair *pair, const sfm_ransac_params &p, uint32_t h0, uint32_t count);
-int launch_finalize_E_wave(sfm_pair *pair, const sfm_ransac_params &p, const unsigned long long *d_key, uint32_t hyp_host, bool from_key);
+int launch_finalize_E_wave(sfm_pair *pair, const sfm_ransac_params &p, const unsigned long long *d_key, uint32_t hyp_host, bool from_key,
+                           hipStream_t stream, bool rederive);
 
 // pose.hip
 int launch_fill_xu(sfm_pair *pair, const sfm_sift_point *d_data);

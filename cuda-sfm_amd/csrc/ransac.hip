@@ -38,11 +38,13 @@ __device__ __forceinline__ void reset_keys(unsigned long long *key, unsigned lon
 __global__ __launch_bounds__(64)
 void ransac_solve_lanes(const float *__restrict__ X0, const float *__restrict__ X1, int ld, int n,
                         const int32_t *__restrict__ indices, uint32_t seed, uint32_t h0, uint32_t count,
-                        int sweeps, float *__restrict__ Ecand, unsigned long long *zero_key, unsigned long long *zero_key2)
+                        int sweeps, float *__restrict__ Ecand, unsigned long long *zero_key, unsigned long long *zero_key2,
+                        int *__restrict__ zero_counts)
 {
     reset_keys(zero_key, zero_key2);
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
+    if (zero_counts) zero_counts[i] = 0;                    // tile-parallel scoring accumulates into counts[] with atomics
     float E[9];
     solve_one(X0, X1, ld, n, indices, seed, h0 + i, sweeps, E);
 #pragma unroll
@@ -54,12 +56,14 @@ template <bool QR>
 __global__ __launch_bounds__(64)
 void ransac_solve_lanes2(const float *__restrict__ X0, const float *__restrict__ X1, int ld, int n,
                          const int32_t *__restrict__ indices, uint32_t seed, uint32_t h0, uint32_t count,
-                         int sweeps, float *__restrict__ Ecand, unsigned long long *zero_key, unsigned long long *zero_key2)
+                         int sweeps, float *__restrict__ Ecand, unsigned long long *zero_key, unsigned long long *zero_key2,
+                         int *__restrict__ zero_counts)
 {
     reset_keys(zero_key, zero_key2);
     const uint32_t i = 2u * (blockIdx.x * blockDim.x + threadIdx.x);
     if (i >= count) return;
     const uint32_t j = (i + 1 < count) ? i + 1 : i;         // odd count: the last lane solves its hypothesis twice
+    if (zero_counts) { zero_counts[i] = 0; zero_counts[j] = 0; }   // tile-parallel scoring accumulates into counts[] with atomics
     v2f E[9];
     solve_two<QR>(X0, X1, ld, n, indices, seed, h0 + i, h0 + j, sweeps, E);
 #pragma unroll
@@ -73,13 +77,23 @@ void ransac_solve_lanes2(const float *__restrict__ X0, const float *__restrict__
 // ------------------------------------------------------------------------------------------
 // SPLIT step 2: one hypothesis per wavefront, points in LDS
 // ------------------------------------------------------------------------------------------
-template <int WPB, bool UNITZ, int NH = 1>
+// GRID2D (point sets of more than one tile): blockIdx.y names the ONE tile a block stages; it runs all its hypothesis
+// batches over that tile and adds the partial counts into counts[] (integer atomics: order-independent, so the result
+// is deterministic); ransac_argmax_counts then builds the keys.  No block ever re-stages, so there is no barrier
+// between tiles and a staged tile is amortised over ntiles times more batches than with the tile loop.
+template <int WPB, bool UNITZ, int NH = 1, bool GRID2D = false>
 __global__ __launch_bounds__(WPB * 64, 8)
 void ransac_score_waves(const float *__restrict__ X0, const float *__restrict__ X1, int ld, int n,
                         const float *__restrict__ Ecand, uint32_t h0, uint32_t count, float thr,
-                        int tile, int ntiles, int *__restrict__ counts, unsigned long long *best_key, unsigned long long *best_key2)
+                        int tile, int ntiles, int *__restrict__ counts, unsigned long long *best_key, unsigned long long *best_key2,
+                        unsigned long long *__restrict__ clk)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    // sustained shader clock of this launch: block 0 brackets its own lifetime with the shader-clock counter (s_memtime) and
+    // the constant 100 MHz counter (s_memrealtime); sfm_ransac_last_clock turns the ratio into MHz
+    const bool probe = clk && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0;
+    unsigned long long c0 = 0, w0 = 0;
+    if (probe) { c0 = clock64(); w0 = wall_clock64(); }
     // bits of the largest |coordinate| in the staged tile, kept right behind the tile
     unsigned int &tile_bound = *reinterpret_cast<unsigned int *>(lds + (UNITZ ? (size_t)(2 * kUnitZSecond / sizeof(float)) : 6 * (size_t)tile));
     const int lane = threadIdx.x & 63;
@@ -91,8 +105,9 @@ void ransac_score_waves(const float *__restrict__ X0, const float *__restrict__ 
     // Tile-outer order: a tile is staged ONCE per block and every hypothesis batch of the block runs over it before
     // the next tile comes in (with more than one tile the per-hypothesis partial counts live in counts[]; a
     // hypothesis is always scored by the same wavefront, lane 0 reads and writes its entry).
-    for (int t = 0; t < ntiles; ++t) {
-        if (t > 0) __syncthreads();                       // everyone done with the previous tile
+    const int t_first = GRID2D ? (int)blockIdx.y : 0, t_last = GRID2D ? (int)blockIdx.y + 1 : ntiles;
+    for (int t = t_first; t < t_last; ++t) {
+        if (t > t_first) __syncthreads();                 // everyone done with the previous tile
         if (threadIdx.x == 0) tile_bound = 0u;
         __syncthreads();
         const int first = t * tile;
@@ -132,6 +147,10 @@ void ransac_score_waves(const float *__restrict__ X0, const float *__restrict__ 
             for (int h = 0; h < NH; ++h) {
                 if (h >= nh) break;
                 int c = cnt[h];
+                if (GRID2D) {
+                    if (lane == 0 && c) atomicAdd(&counts[i + h], c);
+                    continue;
+                }
                 if (ntiles > 1) {
                     int total = c;
                     if (lane == 0) {
@@ -149,6 +168,8 @@ void ransac_score_waves(const float *__restrict__ X0, const float *__restrict__ 
             }
         }
     }
+    if (probe) { clk[0] = clock64() - c0; clk[1] = wall_clock64() - w0; }
+    if (GRID2D) return;                                   // keys come from ransac_argmax_counts
     // one atomic per block (first-maximum tie rule is encoded in the key)
     __syncthreads();
     unsigned long long *sbest = reinterpret_cast<unsigned long long *>(lds);       // tile no longer needed
@@ -165,6 +186,35 @@ void ransac_score_waves(const float *__restrict__ X0, const float *__restrict__ 
     }
 }
 
+// Keys of a shard whose counts[] are complete (GRID2D scoring): highest count, lowest id (thrust::max_element's
+// first maximum, sfm.cu:135-137, without its off-by-one).
+__global__ __launch_bounds__(256)
+void ransac_argmax_counts(const int *__restrict__ counts, uint32_t h0, uint32_t count,
+                          unsigned long long *best_key, unsigned long long *best_key2)
+{
+    __shared__ unsigned long long sbest[4];
+    unsigned long long b = 0;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
+        const unsigned long long key = pack_key((uint32_t)counts[i], h0 + i);
+        b = key > b ? key : b;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long o = __shfl_xor(b, off);
+        b = o > b ? o : b;
+    }
+    if ((threadIdx.x & 63) == 0) sbest[threadIdx.x >> 6] = b;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int w = 1; w < 4; ++w) b = sbest[w] > b ? sbest[w] : b;
+        if (b) {
+            atomicMax(best_key, b);
+            if (best_key2) atomicMax(best_key2, b);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // finalize: winner's E (recomputed from the hypothesis id -> bit-identical on every rank),
 // inlier mask and count.  Replaces thrust::max_element + the 9-float D2D copy (sfm.cu:135-140).
@@ -177,7 +227,9 @@ void ransac_finalize_mask(const float *__restrict__ X0, const float *__restrict_
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     const Ess E{ Eptr[0], Eptr[1], Eptr[2], Eptr[3], Eptr[4], Eptr[5], Eptr[6], Eptr[7], Eptr[8] };
     bool in = false;
-    if (j < n) {
+    if (best_out[0] == 0xFFFFFFFFu) {                      // no winner (ransac_finalize_E_wave): empty mask, count stays 0
+        if (j < n) mask[j] = 0;
+    } else if (j < n) {
         const float r = residual(E, X0[j], X0[(size_t)ld + j], X0[2 * (size_t)ld + j],
                                  X1[j], X1[(size_t)ld + j], X1[2 * (size_t)ld + j]);
         in = r < thr;
@@ -203,16 +255,22 @@ static int ensure_hyp_capacity(sfm_pair *pair, size_t count)
     return SFM_OK;
 }
 
-template <int WPB, bool UNITZ, int NH = 1>
+template <int WPB, bool UNITZ, int NH = 1, bool GRID2D = false>
 static int launch_score_t(sfm_pair *pair, uint32_t h0, uint32_t count, float thr, int tile, int ntiles, int grid, size_t lds, unsigned long long *key2)
 {
-    const int rc_lds = allow_big_lds(pair->ctx, reinterpret_cast<const void *>(&ransac_score_waves<WPB, UNITZ, NH>));
+    const int rc_lds = allow_big_lds(pair->ctx, reinterpret_cast<const void *>(&ransac_score_waves<WPB, UNITZ, NH, GRID2D>));
     if (rc_lds != SFM_OK) return rc_lds;
-    hipLaunchKernelGGL((ransac_score_waves<WPB, UNITZ, NH>), dim3(grid), dim3(WPB * 64), lds, pair->ctx->stream,
+    hipLaunchKernelGGL((ransac_score_waves<WPB, UNITZ, NH, GRID2D>), dim3(grid, GRID2D ? ntiles : 1), dim3(WPB * 64), lds, pair->ctx->stream,
                        pair->d_X[0], pair->d_X[1], pair->ld, pair->n, pair->d_Ecand, h0, count, thr, tile, ntiles,
-                       pair->d_counts, pair->d_key, key2);
+                       pair->d_counts, pair->d_key, key2, pair->d_clk);
     SFM_HIP_TRY(hipGetLastError());
-    pair->last_grid = grid; pair->last_block = WPB * 64; pair->last_lds = (int)lds;
+    if (GRID2D) {
+        const int ablocks = (int)((count + 4095u) / 4096u);
+        hipLaunchKernelGGL(ransac_argmax_counts, dim3(ablocks < 1024 ? ablocks : 1024), dim3(256), 0, pair->ctx->stream,
+                           pair->d_counts, h0, count, pair->d_key, key2);
+        SFM_HIP_TRY(hipGetLastError());
+    }
+    pair->last_grid = grid * (GRID2D ? ntiles : 1); pair->last_block = WPB * 64; pair->last_lds = (int)lds;
     return SFM_OK;
 }
 
@@ -247,24 +305,6 @@ int launch_ransac_score(sfm_pair *pair, const sfm_ransac_params &p, uint32_t h0,
         return rc;
     }
 
-    const bool timed = ctx->timing && ctx->tcount < sfm_ctx::kTimingSlots;
-    hipEvent_t *tev = timed ? ctx->tev[ctx->tcount] : nullptr;
-    if (timed) SFM_HIP_TRY(hipEventRecord(tev[0], ctx->stream));
-    if (p.reserved[0] == 1)          // A/B switch: one hypothesis per lane (scalar math)
-        hipLaunchKernelGGL(ransac_solve_lanes, dim3((count + 63) / 64), dim3(64), 0, ctx->stream,
-                           pair->d_X[0], pair->d_X[1], pair->ld, pair->n, p.d_indices, p.seed, h0, count,
-                           p.jacobi_sweeps, pair->d_Ecand, pair->d_key, key2);
-    else if (p.jacobi_sweeps <= 0)   // default: two hypotheses per lane (packed math), Householder instantiation
-        hipLaunchKernelGGL(ransac_solve_lanes2<true>, dim3((count + 127) / 128), dim3(64), 0, ctx->stream,
-                           pair->d_X[0], pair->d_X[1], pair->ld, pair->n, p.d_indices, p.seed, h0, count,
-                           p.jacobi_sweeps, pair->d_Ecand, pair->d_key, key2);
-    else
-        hipLaunchKernelGGL(ransac_solve_lanes2<false>, dim3((count + 127) / 128), dim3(64), 0, ctx->stream,
-                           pair->d_X[0], pair->d_X[1], pair->ld, pair->n, p.d_indices, p.seed, h0, count,
-                           p.jacobi_sweeps, pair->d_Ecand, pair->d_key, key2);
-    SFM_HIP_TRY(hipGetLastError());
-    if (timed) SFM_HIP_TRY(hipEventRecord(tev[1], ctx->stream));
-
     const int tile = pair->ld < kTileMax ? pair->ld : kTileMax;
     const int ntiles = (pair->ld + tile - 1) / tile;
     // waves per block: enough blocks to cover every CU when H is small, 16 waves sharing one
@@ -276,6 +316,29 @@ int launch_ransac_score(sfm_pair *pair, const sfm_ransac_params &p, uint32_t h0,
     // (three or four per wavefront need > 64 VGPRs, i.e. half the occupancy: 2.01 / 1.91 ms)
     const int nh = (wpb == 16 && count >= 8192u) ? 2 : 1;         // at 4096 hypotheses two per wavefront leave CUs without a block
     const uint32_t nbatch = (count + wpb * nh - 1) / (wpb * nh);
+    // more than one tile: one tile per block (blockIdx.y), partial counts through atomics, keys from ransac_argmax_counts
+    // (p.reserved[1] == 1 keeps the tile loop inside the block: the A/B switch of profiles/pipeline_bench.py)
+    const bool grid2d = ntiles > 1 && kernel == SFM_KERNEL_SPLIT && wpb == 16 && p.reserved[1] != 1;
+
+    const bool timed = ctx->timing && ctx->tcount < sfm_ctx::kTimingSlots;
+    hipEvent_t *tev = timed ? ctx->tev[ctx->tcount] : nullptr;
+    if (timed) SFM_HIP_TRY(hipEventRecord(tev[0], ctx->stream));
+    int *zero_counts = grid2d ? pair->d_counts : nullptr;
+    if (p.reserved[0] == 1)          // A/B switch: one hypothesis per lane (scalar math)
+        hipLaunchKernelGGL(ransac_solve_lanes, dim3((count + 63) / 64), dim3(64), 0, ctx->stream,
+                           pair->d_X[0], pair->d_X[1], pair->ld, pair->n, p.d_indices, p.seed, h0, count,
+                           p.jacobi_sweeps, pair->d_Ecand, pair->d_key, key2, zero_counts);
+    else if (p.jacobi_sweeps <= 0)   // default: two hypotheses per lane (packed math), Householder instantiation
+        hipLaunchKernelGGL(ransac_solve_lanes2<true>, dim3((count + 127) / 128), dim3(64), 0, ctx->stream,
+                           pair->d_X[0], pair->d_X[1], pair->ld, pair->n, p.d_indices, p.seed, h0, count,
+                           p.jacobi_sweeps, pair->d_Ecand, pair->d_key, key2, zero_counts);
+    else
+        hipLaunchKernelGGL(ransac_solve_lanes2<false>, dim3((count + 127) / 128), dim3(64), 0, ctx->stream,
+                           pair->d_X[0], pair->d_X[1], pair->ld, pair->n, p.d_indices, p.seed, h0, count,
+                           p.jacobi_sweeps, pair->d_Ecand, pair->d_key, key2, zero_counts);
+    SFM_HIP_TRY(hipGetLastError());
+    if (timed) SFM_HIP_TRY(hipEventRecord(tev[1], ctx->stream));
+
     // unit-z layout: fixed 64 KiB (two arrays of kTileMax/2 pair records); generic: 24 B per point
     const bool uz = pair->unit_z;
     const size_t lds = (uz ? (size_t)2 * kUnitZSecond : (size_t)6 * tile * sizeof(float)) + 16 * sizeof(unsigned long long);   // tile + bound / per-wave maxima
@@ -286,13 +349,24 @@ int launch_ransac_score(sfm_pair *pair, const sfm_ransac_params &p, uint32_t h0,
     if (per_cu > 2048 / (wpb * 64)) per_cu = 2048 / (wpb * 64);
     if (per_cu < 1) per_cu = 1;
     const uint32_t resident = (uint32_t)ctx->num_cus * (uint32_t)per_cu;
-    uint32_t blocks = nbatch / 8u;
+    const uint32_t min_batches = p.reserved[2] > 0 ? (uint32_t)p.reserved[2] : 8u;
+    uint32_t blocks = nbatch / min_batches;
     if (blocks > 16u * (uint32_t)ctx->num_cus) blocks = 16u * (uint32_t)ctx->num_cus;
     if (blocks < resident) blocks = resident;
-    const int grid = (int)(nbatch < blocks ? nbatch : blocks);
+    int grid = (int)(nbatch < blocks ? nbatch : blocks);
+    if (grid2d) {                        // `blocks` counts all tiles: columns x ntiles
+        grid = (int)((blocks + ntiles - 1) / ntiles);
+        if ((uint32_t)grid > nbatch) grid = (int)nbatch;
+    }
     if (kernel == SFM_KERNEL_MFMA) {
         rc = launch_score_mfma(pair, p, h0, count);
         if (rc == SFM_OK && key2) SFM_HIP_TRY(hipMemcpyAsync(key2, pair->d_key, sizeof(unsigned long long), hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    else if (grid2d) {
+        rc = uz ? (nh == 2 ? launch_score_t<16, true, 2, true>(pair, h0, count, p.threshold, tile, ntiles, grid, lds, key2)
+                           : launch_score_t<16, true, 1, true>(pair, h0, count, p.threshold, tile, ntiles, grid, lds, key2))
+                : (nh == 2 ? launch_score_t<16, false, 2, true>(pair, h0, count, p.threshold, tile, ntiles, grid, lds, key2)
+                           : launch_score_t<16, false, 1, true>(pair, h0, count, p.threshold, tile, ntiles, grid, lds, key2));
     }
     else if (uz) switch (wpb) {
     case 16: rc = nh == 2 ? launch_score_t<16, true, 2>(pair, h0, count, p.threshold, tile, ntiles, grid, lds, key2)
@@ -314,12 +388,13 @@ int launch_ransac_score(sfm_pair *pair, const sfm_ransac_params &p, uint32_t h0,
 }
 
 int launch_ransac_finalize(sfm_pair *pair, const sfm_ransac_params &p, const unsigned long long *d_key,
-                           uint32_t hyp_host, bool from_key)
+                           uint32_t hyp_host, bool from_key, hipStream_t stream, bool rederive)
 {
     sfm_ctx *ctx = pair->ctx;
-    int rc = launch_finalize_E_wave(pair, p, d_key, hyp_host, from_key);      // ransac_fused.hip
+    if (!stream) stream = ctx->stream;
+    int rc = launch_finalize_E_wave(pair, p, d_key, hyp_host, from_key, stream, rederive);      // ransac_fused.hip
     if (rc != SFM_OK) return rc;
-    hipLaunchKernelGGL(ransac_finalize_mask, dim3((pair->n + 255) / 256), dim3(256), 0, ctx->stream,
+    hipLaunchKernelGGL(ransac_finalize_mask, dim3((pair->n + 255) / 256), dim3(256), 0, stream,
                        pair->d_X[0], pair->d_X[1], pair->ld, pair->n, pair->d_E, p.threshold, pair->d_mask, pair->d_best);
     SFM_HIP_TRY(hipGetLastError());
     return SFM_OK;

@@ -254,7 +254,7 @@ __global__ __launch_bounds__(64)
 void ransac_finalize_E_wave(const float *__restrict__ X0, const float *__restrict__ X1, int ld, int n,
                             const int32_t *__restrict__ indices, uint32_t seed, int sweeps,
                             const unsigned long long *__restrict__ key, uint32_t hyp_host, int from_key,
-                            const float *__restrict__ Ecand, uint32_t h0, uint32_t count,
+                            const float *__restrict__ Ecand, uint32_t h0, uint32_t count, uint32_t num_hypotheses,
                             float *__restrict__ E_out, uint32_t *__restrict__ best_out)
 {
     __shared__ __attribute__((aligned(16))) float ws[kWaveScratch];
@@ -262,6 +262,14 @@ void ransac_finalize_E_wave(const float *__restrict__ X0, const float *__restric
     uint32_t hyp = hyp_host;
     if (from_key) hyp = 0xFFFFFFFFu - (uint32_t)(key[0] & 0xFFFFFFFFull);
     hyp = __builtin_amdgcn_readfirstlane(hyp);
+    if (hyp >= num_hypotheses) {
+        // no winner: a key of 0 (every shard empty), an uninitialised caller buffer or a failed all-reduce.  Defined
+        // result instead of reading the tuple table out of bounds: E = 0, best = {0xFFFFFFFF, 0}; the mask kernel
+        // sees the sentinel and clears the mask, sfm_get_best / sfm_get_result report SFM_E_STATE.
+        if (threadIdx.x < 9) E_out[threadIdx.x] = 0.0f;
+        if (threadIdx.x == 0) { best_out[0] = 0xFFFFFFFFu; best_out[1] = 0; }
+        return;
+    }
     if (Ecand && hyp >= h0 && hyp - h0 < count) {
         if (threadIdx.x < 9) E_out[threadIdx.x] = Ecand[9 * (size_t)(hyp - h0) + threadIdx.x];
     } else {
@@ -318,15 +326,16 @@ int launch_ransac_fused(sfm_pair *pair, const sfm_ransac_params &p, uint32_t h0,
 }
 
 int launch_finalize_E_wave(sfm_pair *pair, const sfm_ransac_params &p, const unsigned long long *d_key,
-                           uint32_t hyp_host, bool from_key)
+                           uint32_t hyp_host, bool from_key, hipStream_t stream, bool rederive)
 {
-    // Ecand is only trusted when it was produced by a score call with the same sampler settings
-    const bool cand_ok = pair->last_count > 0 && pair->cand_seed == p.seed && pair->cand_indices == p.d_indices &&
+    // Ecand is only trusted when it was produced by a score call with the same sampler settings (and when the caller
+    // does not overlap this finalize with the next score call, which rewrites it: rederive)
+    const bool cand_ok = !rederive && pair->last_count > 0 && pair->cand_seed == p.seed && pair->cand_indices == p.d_indices &&
                          pair->cand_sweeps == p.jacobi_sweeps;
-    hipLaunchKernelGGL(ransac_finalize_E_wave, dim3(1), dim3(64), 0, pair->ctx->stream,
+    hipLaunchKernelGGL(ransac_finalize_E_wave, dim3(1), dim3(64), 0, stream,
                        pair->d_X[0], pair->d_X[1], pair->ld, pair->n, p.d_indices, p.seed, p.jacobi_sweeps,
                        d_key, hyp_host, from_key ? 1 : 0,
-                       cand_ok ? pair->d_Ecand : nullptr, pair->cand_h0, pair->last_count, pair->d_E, pair->d_best);
+                       cand_ok ? pair->d_Ecand : nullptr, pair->cand_h0, pair->last_count, p.num_hypotheses, pair->d_E, pair->d_best);
     SFM_HIP_TRY(hipGetLastError());
     return SFM_OK;
 }

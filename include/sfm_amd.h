@@ -172,7 +172,9 @@ typedef struct sfm_ransac_params {
     int32_t  jacobi_sweeps;   /* null vector of the 8x9 system: 0 (default) = Householder QR of A^T;       */
                               /* k > 0 = normal equations A^T A + k sweeps of 9x9 Jacobi (7 converges)    */
     int32_t  kernel;          /* SFM_KERNEL_*                                                           */
-    int32_t  reserved[4];
+    int32_t  reserved[4];     /* 0 = defaults.  A/B switches of profiles/: [0] = 1 one hypothesis per lane in the solve kernel;   */
+                              /* [1] = 1 tile loop inside the scoring block instead of the tile-parallel grid (n > 4096);         */
+                              /* [2] = k > 0 minimum hypothesis batches per scoring block (default 8); [3] unused                 */
 } sfm_ransac_params;
 
 void sfm_ransac_default_params(sfm_ransac_params *p, int num_points);
@@ -196,6 +198,12 @@ int sfm_ransac_export_key(sfm_pair *pair, uint64_t *d_key_out);
  * blocks write both copies, so the multi-GPU step needs no export in between. */
 int sfm_ransac_score_into(sfm_pair *pair, const sfm_ransac_params *p, uint64_t *d_key_out);
 int sfm_ransac_finalize_key(sfm_pair *pair, const sfm_ransac_params *p, const uint64_t *d_key);
+/* sfm_ransac_finalize_key enqueued on ANOTHER stream of the same device (NULL = the context's): for callers that overlap
+ * pair k's exchange + finalize with pair k+1's scoring (sfm_amd_comm.h, sfm_estimate_E_sharded_pipelined).  The winner's E
+ * is always re-derived from the hypothesis id (bit-identical to the scored candidate), never read from the candidate
+ * buffer the next score call is rewriting.  The caller orders the streams (events); the getters synchronise the context
+ * stream only. */
+int sfm_ransac_finalize_key_on(sfm_pair *pair, const sfm_ransac_params *p, const uint64_t *d_key, void *hip_stream);
 
 /* Image_pair::computePosecandidates(), sfm.cu:238-252 + candidate_kernels kernels.h:357-385. */
 #define SFM_POSE_REFERENCE 0   /* as written in the reference (quirks Q7, Q8, Q9, Q11 of SURVEY.md) */
@@ -243,6 +251,9 @@ int sfm_get_result(sfm_pair *pair, float h_record[28]);
 int sfm_copy_points_to_vbo(sfm_pair *pair, float *d_positions, float *d_velocities, float scale);
 /* Name and launch geometry of the RANSAC scoring kernel used by the last call (for profiling). */
 int sfm_ransac_last_launch(sfm_pair *pair, int *kernel, int *grid, int *block, int *lds_bytes);
+/* Sustained shader clock (MHz) during the last wavefront-scoring launch (SFM_KERNEL_SPLIT): shader-clock ticks over
+ * 100 MHz ticks across the lifetime of its first block; 0 if that kernel has not run.  Synchronises. */
+int sfm_ransac_last_clock(sfm_pair *pair, double *shader_mhz);
 
 #ifdef __cplusplus
 }

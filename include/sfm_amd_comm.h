@@ -27,11 +27,21 @@ int sfm_comm_unique_id(void *id128);          /* rank 0: ncclGetUniqueId        
 int sfm_comm_init(sfm_ctx *ctx, const void *id128, int rank, int nranks, sfm_comm **out);   /* ncclCommInitRank */
 int sfm_comm_destroy(sfm_comm *comm);
 int sfm_comm_rank(const sfm_comm *comm, int *rank, int *nranks);
+int sfm_comm_nccl_ranks(const sfm_comm *comm, int *nccl_ranks);      /* ncclCommCount: the rank count RCCL itself sees */
 
 /* Image_pair::estimateE over all ranks: p->num_hypotheses is the GLOBAL count; the call overrides
  * p->hyp_begin / p->hyp_count with this rank's shard, scores it, all-reduces the key and finalizes the winner.
  * Asynchronous (context stream) like sfm_estimate_E; every rank must call it with the same arguments. */
 int sfm_estimate_E_sharded(sfm_pair *pair, sfm_ransac_params *p, sfm_comm *comm);
+
+/* The same step software-pipelined over consecutive calls (a stream of pairs, or bench.py's repeated steps): the shard is
+ * scored on the context stream, the all-reduce and the finalize run on the communicator's own exchange stream behind an
+ * event, so the NEXT call's scoring overlaps this call's 8-byte exchange.  Two key slots; the finalize re-derives the
+ * winner's E from its id (sfm_ransac_finalize_key_on) because the next scoring call rewrites the candidate buffer.
+ * sfm_comm_flush makes the context stream wait for the last finalize; call it before reading results (sfm_get_*), before
+ * the pose stages, and before re-using the pair's point set for something else.  sfm_estimate_E_sharded flushes by itself. */
+int sfm_estimate_E_sharded_pipelined(sfm_pair *pair, sfm_ransac_params *p, sfm_comm *comm);
+int sfm_comm_flush(sfm_comm *comm);
 
 #ifdef __cplusplus
 }

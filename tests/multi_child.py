@@ -1,0 +1,51 @@
+"""One rank of tests/test_gpu_multi.py::test_two_ranks_rccl (started by bench.launch_ranks, one process per GPU):
+sfm_estimate_E_sharded and its pipelined form over a real RCCL communicator against the single-GPU sfm_estimate_E.
+Rank 0 prints one JSON line."""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import torch.distributed as dist
+import cuda_sfm_amd as S
+from cuda_sfm_amd import synth
+
+rank, world, local = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ["LOCAL_RANK"])
+torch.cuda.set_device(local)
+dev = torch.device("cuda", local)
+dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+n, H = 3000, 40001
+scene = synth.two_view_scene(n, seed=77)
+d_sift = torch.from_numpy(scene["sift"].view(np.uint8).reshape(n, 576)).to(dev)
+ctx = S.Context(local, torch.cuda.current_stream().cuda_stream)
+pair = S.ImagePair(ctx, scene["K"], scene["Kinv"], 2, n)
+pair.fillXU(d_sift)
+p = S.default_params(n, num_hypotheses=H, seed=9)
+pair.estimateE(p)                                               # every rank: the whole range on its own GPU
+ref = (pair.get_key(), pair.get_E().copy(), pair.get_inlier_mask().copy(), pair.get_best())
+uid = [S.Comm.unique_id() if rank == 0 else None]
+dist.broadcast_object_list(uid, src=0)
+comm = S.Comm(ctx, uid[0], rank, world)
+ok = comm.nccl_ranks() == world
+q = S.default_params(n, num_hypotheses=H, seed=9)
+comm.estimate_E(pair, q)
+ok = ok and (q.hyp_begin, q.hyp_count) == S.shard_range(H, rank, world)
+ok = ok and pair.get_best() == ref[3] and np.array_equal(pair.get_E().view(np.uint32), ref[1].view(np.uint32)) and np.array_equal(pair.get_inlier_mask(), ref[2])
+for _ in range(5):                                              # pipelined: the next step's scoring overlaps this step's exchange
+    comm.estimate_E_pipelined(pair, q)
+comm.flush()
+ok = ok and pair.get_best() == ref[3] and np.array_equal(pair.get_E().view(np.uint32), ref[1].view(np.uint32)) and np.array_equal(pair.get_inlier_mask(), ref[2])
+t = torch.tensor([1 if ok else 0], dtype=torch.int64, device=dev)
+dist.all_reduce(t, op=dist.ReduceOp.MIN)
+if rank == 0:
+    import ctypes
+    ctypes.CDLL(None).fflush(None)
+    print(json.dumps({"ok": bool(t.item()), "world": world, "nccl_ranks": comm.nccl_ranks(), "best": list(ref[3])}), flush=True)
+comm.close()
+dist.barrier()
+dist.destroy_process_group()
+sys.exit(0 if ok else 1)

@@ -1,0 +1,89 @@
+"""GPU: the multi-GPU estimateE protocol through the C ABI (include/sfm_amd_comm.h).  On a 1-GPU box: the 1-rank
+communicator (serial and pipelined step) and the shard protocol with every 'rank' played one after the other on the
+same device; with >= 2 GPUs: two real ranks over RCCL (one process per GPU, started by bench.py's launcher)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import cuda_sfm_amd as S
+from cuda_sfm_amd import synth
+from helpers import same_bits, make_pair
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_pipelined_step_single_rank_equals_estimateE(gpu):
+    """sfm_estimate_E_sharded_pipelined: scoring on the context stream, all-reduce + finalize on the exchange stream, two
+    key slots.  Repeated steps (so that slots and events are re-used), then a flush: E / mask / best must equal
+    sfm_estimate_E; a different seed in between must not leak into the next result."""
+    torch, dev, ctx = gpu
+    n, H = 3000, 50000
+    scene = synth.two_view_scene(n, seed=77)
+    pair, _ = make_pair(S, gpu, scene)
+    refs = {}
+    for seed in (9, 10):
+        p = S.default_params(n, num_hypotheses=H, seed=seed)
+        pair.estimateE(p)
+        refs[seed] = (pair.get_best(), pair.get_E().copy(), pair.get_inlier_mask().copy())
+    assert refs[9][0] != refs[10][0]
+    comm = S.Comm(ctx, S.Comm.unique_id(), 0, 1)
+    assert comm.nccl_ranks() == 1
+    for seed in (9, 10, 10, 9, 9, 9, 10):
+        q = S.default_params(n, num_hypotheses=H, seed=seed)
+        comm.estimate_E_pipelined(pair, q)
+    comm.flush()
+    assert pair.get_best() == refs[10][0] and same_bits(pair.get_E(), refs[10][1]) and np.array_equal(pair.get_inlier_mask(), refs[10][2])
+    q = S.default_params(n, num_hypotheses=H, seed=9)
+    comm.estimate_E_pipelined(pair, q)
+    comm.estimate_E(pair, q)                                   # the serial form flushes pending pipelined work by itself
+    assert pair.get_best() == refs[9][0] and same_bits(pair.get_E(), refs[9][1])
+    comm.close()
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+@pytest.mark.parametrize("sweeps", [0, 7])
+def test_estimate_E_distributed_shard_cuts_on_one_gpu(gpu, world, sweeps):
+    """estimate_E_distributed with the ranks played one after the other on this GPU (score shard r -> key r; the
+    'all-reduce' is max over the recorded keys; every rank finalizes from the reduced key): keys, E and mask must not
+    depend on how the id range is cut."""
+    torch, dev, ctx = gpu
+    n, H = 2000, 20011
+    scene = synth.two_view_scene(n, seed=31)
+    pair, _ = make_pair(S, gpu, scene)
+    p = S.default_params(n, num_hypotheses=H, seed=6, jacobi_sweeps=sweeps)
+    pair.estimateE(p)
+    ref = (pair.get_key(), pair.get_E().copy(), pair.get_inlier_mask().copy(), pair.get_best())
+    keys = []
+    for r in range(world):                                     # pass 1: every rank's local key
+        q = S.default_params(n, num_hypotheses=H, seed=6, jacobi_sweeps=sweeps)
+        t = torch.zeros(1, dtype=torch.int64, device=dev)
+        S.estimate_E_distributed(pair, q, r, world, t, lambda x: None)
+        torch.cuda.synchronize()
+        keys.append(int(t.item()))
+    assert max(keys) == ref[0]
+    for r in range(world):                                     # pass 2: the same step with the reduced key injected
+        q = S.default_params(n, num_hypotheses=H, seed=6, jacobi_sweeps=sweeps)
+        t = torch.zeros(1, dtype=torch.int64, device=dev)
+
+        def reduce_max(x):
+            x[0] = max(keys)
+        S.estimate_E_distributed(pair, q, r, world, t, reduce_max)
+        assert pair.get_best() == ref[3] and same_bits(pair.get_E(), ref[1]) and np.array_equal(pair.get_inlier_mask(), ref[2]), f"rank {r}"
+
+
+def test_two_ranks_rccl():
+    """Two processes, two GPUs, one RCCL communicator: sfm_estimate_E_sharded (+ pipelined) == the single-GPU call."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs on the node (the driver's SCALE run exercises the same path through bench.py)")
+    code = ("import sys, bench; sys.exit(bench.launch_ranks(2, [], command=[sys.executable, %r], timeout=600))"
+            % os.path.join(ROOT, "tests", "multi_child.py"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rec = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert rec["ok"] and rec["world"] == 2 and rec["nccl_ranks"] == 2

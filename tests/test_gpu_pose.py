@@ -116,3 +116,25 @@ def test_pair_reset_reuses_buffers_and_result_record(gpu):
     assert e.value.code == S.E_INVALID
     with pytest.raises(S.SfmError):
         pool.reset(0)
+
+
+def test_points_need_a_triangulation_of_the_current_pose(gpu):
+    """sfm_get_points / sfm_copy_points_to_vbo are valid only after linear_triangulation ran for the current pose:
+    not after choosePose alone, and not with the previous pair's points after sfm_pair_reset."""
+    torch, dev, ctx = gpu
+    n = 600
+    scene = synth.two_view_scene(n, seed=31)
+    pair, d_sift = make_pair(S, gpu, scene)
+    pair.estimateE(S.default_params(n, num_hypotheses=64))
+    pair.computePosecandidates(); pair.choosePose()
+    for call in (pair.get_points, lambda: pair.copy_points_to_vbo(torch.empty(4 * n, device=dev), None)):
+        with pytest.raises(S.SfmError) as e:
+            call()
+        assert e.value.code == S.E_STATE
+    pair.linear_triangulation()
+    assert np.isfinite(pair.get_points()).all()
+    pair.reset(n); pair.fillXU(d_sift)
+    pair.estimateE(S.default_params(n, num_hypotheses=64))
+    pair.computePosecandidates(); pair.choosePose()
+    with pytest.raises(S.SfmError):
+        pair.get_points()

@@ -284,3 +284,111 @@ def test_generic_z_two_hypotheses_per_wavefront(gpu):
     pair.estimateE(p)
     key, ocounts, _ = O.ransac_range(X0s, X1s, 0, H, p.threshold, p.jacobi_sweeps, seed=8)
     assert np.array_equal(pair.get_inlier_counts(H), ocounts) and pair.get_key() == key
+
+
+def _oracle_sample_check(X0, X1, p, counts, hyps, n, base=0):
+    for h in hyps:
+        E = O.hypothesis_E(X0, X1, O.sample8(p.seed, int(h), n), p.jacobi_sweeps)
+        c, _ = O.count_inliers(E, X0, X1, p.threshold, want_mask=False)
+        assert c == counts[int(h) - base], f"hypothesis {h}: gpu {counts[int(h) - base]} oracle {c}"
+
+
+def test_c4_full_size_single_gpu(gpu):
+    """BASELINE configs[3] on ONE GPU: 16384 matches x 2^20 hypotheses (four 4096-point tiles -> tile-parallel grid,
+    partial counts through integer atomics, keys from ransac_argmax_counts).  The oracle needs ~1.5 ms per hypothesis at
+    this size, so: sampled counts against the oracle, winner = first arg-max of ALL counts, mask sum = count, and the
+    tile loop inside the block (reserved[1] = 1, the pre-round-2 arrangement) gives the same counts and key."""
+    n, H = 16384, 1 << 20
+    scene = synth.two_view_scene(n)
+    pair, _ = make_pair(S, gpu, scene)
+    p = S.default_params(n, num_hypotheses=H)
+    pair.estimateE(p)
+    assert pair.last_launch()["kernel"] == S.KERNEL_SPLIT
+    counts = pair.get_inlier_counts(H).copy()
+    key = pair.get_key()
+    hyp, cnt = pair.get_best()
+    assert cnt == counts.max() and hyp == int(np.argmax(counts))
+    assert key == S.pack_key(cnt, hyp)
+    mask = pair.get_inlier_mask()
+    assert mask.sum() == cnt
+    _, _, X0, X1 = oracle_xu(scene)
+    rng = np.random.default_rng(4)
+    top = np.argsort(counts)[-8:]                                 # the best few and a random sample
+    _oracle_sample_check(X0, X1, p, counts, [hyp] + top.tolist() + rng.integers(0, H, 48).tolist(), n)
+    E = O.hypothesis_E(X0, X1, O.sample8(p.seed, hyp, n), p.jacobi_sweeps)
+    assert same_bits(pair.get_E(), E.reshape(3, 3))
+    assert np.array_equal(mask, O.count_inliers(E, X0, X1, p.threshold)[1])
+    q = S.default_params(n, num_hypotheses=H)
+    q.reserved[1] = 1
+    pair.estimateE(q)
+    assert np.array_equal(pair.get_inlier_counts(H), counts) and pair.get_key() == key
+
+
+def test_c4_eight_shards_equal_the_single_call(gpu):
+    """BASELINE configs[3] as the 8 ranks see it: shards hyp_begin = r * 2^17 of the same 16384-match scene, scored one
+    after the other on this GPU.  Concatenated counts == the single call's counts, max of the shard keys == its key,
+    and finalizing from the reduced key reproduces E / mask / best bit for bit."""
+    torch, dev, ctx = gpu
+    n, H, G = 16384, 1 << 20, 8
+    scene = synth.two_view_scene(n)
+    pair, _ = make_pair(S, gpu, scene)
+    p = S.default_params(n, num_hypotheses=H)
+    pair.estimateE(p)
+    full = pair.get_inlier_counts(H).copy()
+    ref = (pair.get_key(), pair.get_E().copy(), pair.get_inlier_mask().copy(), pair.get_best())
+    keys = []
+    key_t = torch.zeros(1, dtype=torch.int64, device=dev)
+    for r in range(G):
+        b, c = S.shard_range(H, r, G)
+        assert (b, c) == (r << 17, 1 << 17)
+        q = S.default_params(n, num_hypotheses=H, hyp_begin=b, hyp_count=c)
+        pair.ransac_score(q, key_out=key_t)
+        torch.cuda.synchronize()
+        assert np.array_equal(pair.get_inlier_counts(c), full[b:b + c]), f"shard {r}"
+        assert int(key_t.item()) == pair.get_key()
+        keys.append(pair.get_key())
+    assert max(keys) == ref[0]
+    key_t[0] = max(keys)                                     # what the all-reduce(max) leaves on every rank
+    pair.ransac_finalize_key(q, key_t)                       # the last rank's shard does not hold the winner's E: re-derived
+    assert pair.get_best() == ref[3] and same_bits(pair.get_E(), ref[1]) and np.array_equal(pair.get_inlier_mask(), ref[2])
+
+
+@pytest.mark.parametrize("n,H", [(4097, 9000), (8192, 20000), (12345, 8192), (16384, 65536)])
+def test_tile_parallel_grid_equals_tile_loop(gpu, n, H):
+    """n > 4096: tile-parallel scoring (default) against the in-block tile loop (reserved[1] = 1) and the oracle."""
+    scene = synth.two_view_scene(n, seed=n)
+    pair, _ = make_pair(S, gpu, scene)
+    p = S.default_params(n, num_hypotheses=H, seed=3, kernel=S.KERNEL_SPLIT)
+    pair.estimateE(p)
+    a = (pair.get_inlier_counts(H).copy(), pair.get_key(), pair.get_inlier_mask().copy())
+    q = S.default_params(n, num_hypotheses=H, seed=3, kernel=S.KERNEL_SPLIT)
+    q.reserved[1] = 1
+    pair.estimateE(q)
+    assert np.array_equal(pair.get_inlier_counts(H), a[0]) and pair.get_key() == a[1] and np.array_equal(pair.get_inlier_mask(), a[2])
+    _, _, X0, X1 = oracle_xu(scene)
+    rng = np.random.default_rng(n)
+    _oracle_sample_check(X0, X1, p, a[0], rng.integers(0, H, 30).tolist(), n)
+
+
+def test_finalize_from_a_key_that_names_no_hypothesis(gpu):
+    """A key of 0 (every shard empty / uninitialised buffer / failed all-reduce) decodes to hypothesis 0xFFFFFFFF: the
+    finalize step must not index the tuple table with it; result is defined (E = 0, empty mask) and reported."""
+    torch, dev, ctx = gpu
+    n = 500
+    scene = synth.two_view_scene(n, seed=2)
+    pair, _ = make_pair(S, gpu, scene)
+    d_idx = torch.zeros(8 * 10, dtype=torch.int32, device=dev)
+    d_idx[:] = torch.arange(80, dtype=torch.int32, device=dev) % n
+    p = S.default_params(n, num_hypotheses=10, d_indices=d_idx)
+    key_t = torch.zeros(1, dtype=torch.int64, device=dev)
+    pair.ransac_finalize_key(p, key_t)
+    with pytest.raises(S.SfmError) as e:
+        pair.get_best()
+    assert e.value.code == S.E_STATE
+    assert pair.get_inlier_mask().sum() == 0 and not pair.get_E().any()
+    key_t[0] = S.pack_key(3, 10)                              # id == num_hypotheses: out of range too
+    pair.ransac_finalize_key(p, key_t)
+    with pytest.raises(S.SfmError):
+        pair.get_best()
+    pair.estimateE(p)                                          # and the pair is still usable
+    assert pair.get_best()[0] < 10
