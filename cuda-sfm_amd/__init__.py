@@ -32,7 +32,7 @@ _lib = C.CDLL(LIB_PATH)
 
 # ---- constants (include/sfm_amd.h) --------------------------------------------------------------
 OK, E_INVALID, E_HIP, E_NOMEM, E_STATE, E_SINGULAR = 0, -1, -2, -3, -4, -5
-KERNEL_AUTO, KERNEL_SPLIT, KERNEL_FUSED, KERNEL_MFMA = 0, 1, 2, 3
+KERNEL_AUTO, KERNEL_SPLIT, KERNEL_FUSED, KERNEL_MFMA, KERNEL_PREFILTER = 0, 1, 2, 3, 4
 POSE_REFERENCE, POSE_CORRECT = 0, 1
 (BUF_X0, BUF_X1, BUF_U0, BUF_U1, BUF_E, BUF_P, BUF_PINV, BUF_POINTS, BUF_COUNTS, BUF_MASK, BUF_KEY,
  BUF_ECAND, BUF_PIND) = range(13)

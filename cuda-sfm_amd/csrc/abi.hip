@@ -34,7 +34,7 @@ static int resolve_shard(const sfm_pair *pair, const sfm_ransac_params *p, uint3
     SFM_REQUIRE(p->num_hypotheses > 0, SFM_E_INVALID, "num_hypotheses must be > 0");
     SFM_REQUIRE(p->hyp_begin <= p->num_hypotheses, SFM_E_INVALID, "hyp_begin %u beyond num_hypotheses %u", p->hyp_begin, p->num_hypotheses);
     SFM_REQUIRE(p->jacobi_sweeps >= 0 && p->jacobi_sweeps <= 64, SFM_E_INVALID, "jacobi_sweeps out of range (0 = Householder solver)");
-    SFM_REQUIRE(p->kernel >= SFM_KERNEL_AUTO && p->kernel <= SFM_KERNEL_MFMA, SFM_E_INVALID, "unknown kernel id %d", p->kernel);
+    SFM_REQUIRE(p->kernel >= SFM_KERNEL_AUTO && p->kernel <= SFM_KERNEL_PREFILTER, SFM_E_INVALID, "unknown kernel id %d", p->kernel);
     uint32_t c = p->hyp_count ? p->hyp_count : p->num_hypotheses - p->hyp_begin;
     SFM_REQUIRE((uint64_t)p->hyp_begin + c <= p->num_hypotheses, SFM_E_INVALID, "shard [%u, %u) exceeds num_hypotheses %u",
                 p->hyp_begin, p->hyp_begin + c, p->num_hypotheses);

@@ -111,6 +111,9 @@ int launch_ransac_score(sfm_pair *pair, const sfm_ransac_params &p, uint32_t h0,
 int launch_ransac_finalize(sfm_pair *pair, const sfm_ransac_params &p, const unsigned long long *d_key, uint32_t hyp_host, bool from_key,
                            hipStream_t stream = nullptr, bool rederive = false);
 int launch_permutation_indices(sfm_ctx *ctx, int n, uint32_t seed, int32_t *d_indices);
+// ransac_prefilter.hip
+bool prefilter_usable(const sfm_pair *pair, const sfm_ransac_params &p, uint32_t count);
+int launch_score_prefilter(sfm_pair *pair, const sfm_ransac_params &p, uint32_t count);
 // ransac_mfma.hip
 int launch_score_mfma(sfm_pair *pair, const sfm_ransac_params &p, uint32_t h0, uint32_t count);
 // ransac_fused.hip

@@ -1,0 +1,178 @@
+// prefilter_math.hpp -- operands and decision rule of the matrix-core pre-filter in front of the exact inlier test
+// (ransac_prefilter.hip).  __host__ __device__ like device_math.hpp, so tests/hostcheck can run the very same code on
+// the CPU and check the rule against the oracle without a GPU.
+//
+// What it replaces: nothing in the reference -- calculateInliers (SfM/sfm.cu:155-236) evaluates the residual of every
+// (hypothesis, point) pair in full (six batched GEMMs + eight element-wise passes).  The product's exact test is
+// residual() / inlier_filter() (device_math.hpp); this file only decides which pairs may SKIP it.
+//
+// Idea.  Of ~1e9 .. 1e10 pairs per call only ~0.5 % are inliers.  A pair can be an inlier only if its one-sided
+// residual n^2 / da is below the threshold (r = n^2/da + n^2/db >= n^2/da), and both sides of that test are
+// contractions of per-hypothesis coefficients with per-point features:
+//     n  = x1^T E x2          = sum_k E_k phi_k(x1, x2)       (9 terms: 4 bilinear, 4 linear, 1 constant; z = 1)
+//     da = |(E x2)_{0,1}|^2   = sum_j M_j(E) psi_j(x2)        (6 terms: x^2, xy, y^2, x, y, 1)
+// so a 32 x 32 block of pairs costs a few v_mfma_f32_32x32x16_f16 instead of 1024 x 40 vector operations.  fp16 has 11
+// significant bits; every coefficient and feature is split into two fp16 values (hi + lo, 22 bits) and the products
+// hi*hi, hi*lo, lo*hi are separate k-slots (fp16 x fp16 products are exact in the fp32 accumulator), the constants get
+// three parts.  The vector unit then needs two instructions per pair (one fma with clamp, one integer compare) to
+// reject it; the ~1 % that survive go through the exact test, which alone decides what is counted.
+//
+// The rule must never reject a pair the exact test would count.  Notation for one pair: nn_c, da_c the floats
+// residual() computes; n*, da* the same expressions in real arithmetic; nt, G what the matrix cores return (scaled by
+// 2^a and 2^2a, undone here in the text).  Per hypothesis, with B >= |coordinate| of the tile:
+//     sabs   = |e8| + B (|e2|+|e5|+|e6|+|e7|) + B^2 (|e0|+|e1|+|e3|+|e4|)          (sum of |terms| of n)
+//     dn     = 3 * 2^-20 sabs + 2^-22 (1 + B^2)   >=  |nt - nn_c|
+//              (split truncation <= 3 * 2^-22 per term, fp32 accumulation measured 1.2 * 2^-24 per instruction and
+//               budgeted 8 * 2^-24, fp32 feature products, fp16 subnormal floor, the 6 roundings of the fma chains)
+//     s      = c1 thr,  c1 = (1 + rho)(1 + 2^-20)(1 + 2^-6),  rho = 1/8
+//     T''    = s da~ + c2  with da~ the contraction and c2 = 1.25 terr + 264 s eta^2 + (1 + 1/rho) dn^2
+//              terr >= s |da~ - da*|,   eta >= |a_i,c - a_i*|
+//   (1) nt^2 >= T''  =>  |nt| >= sqrt((1 + rho) T + (1 + 1/rho) dn^2) >= sqrt(T) + dn   (T = thr' da_up, AM-GM)
+//                    =>  |nn_c| >= sqrt(T)  =>  fl(nn_c^2) >= thr (1 + 2^-23) da_c.
+//   (2) If moreover da_c > 0: t1 = fl(n2 / da_c) >= thr, and r = fl(t1 + t2) >= t1 >= thr for every t2 >= 0 (or NaN, or
+//       inf): not an inlier.  db_c = 0 zeroes t2, which changes nothing.
+//   (3) da_c = 0 zeroes t1 (the reference's element_wise_div guard), so such a pair must never be rejected: da_c = 0
+//       needs |a_0*|, |a_1*| <= eta, i.e. da* <= 2 eta^2.  G = T'' - tmin with tmin = c2 + 1.25 terr + 8 s eta^2, so
+//       G >= 0 => s da~ >= 1.25 terr + 8 s eta^2 => da* >= 8 eta^2 - ... > 2 eta^2 => da_c > 0.
+//   Rule: reject  <=>  0 <= G  and  G + tmin_w < nt^2   (tmin_w = largest tmin of the wavefront's hypotheses), evaluated
+//   as  bits(G) <u bits(clamp01(nt^2 - tmin_w))  -- one v_fma_f32 ... clamp and one v_cmp_lt_u32: a negative or NaN G has
+//   bits above every clamped value, NaN nt clamps to 0 (never rejects), and G >= 1 is simply not rejected (T'' is scaled
+//   to stay below ~0.4).  Degenerate or non-finite E: all coefficients 0 and G = -inf, every pair survives.
+#pragma once
+#include "device_math.hpp"
+
+namespace sfm {
+
+constexpr int kPfSlots = 32;             // k-slots of the n contraction (two v_mfma_f32_32x32x16_f16)
+constexpr int kPfSlotsT = 16;            // k-slots of the G contraction (one)
+constexpr float kPfRho = 0.125f;
+constexpr float kPfFeatScale = 16.0f;    // sigF: features of n are stored times 16 (fp16 low parts stay normal)
+constexpr float kPfPadValue = 256.0f;    // k-slot 27 of a padding point: nt = 256 -> clamp(nt^2 - tmin) = 1 > G = 0: rejected
+
+struct PfScales { int a; float sigE, sigF, sig2a; };
+
+// Power-of-two scaling: nt is carried as 2^a n, G as 2^2a (T'' - tmin); a is chosen from the threshold so that 2^2a T''
+// stays below 1 (T'' <= ~12 thr for |E_ij| <= 1.5, |coordinates| <= 1).  Returns false when the threshold is outside
+// the range the fp16 operands cover -- the caller then uses the plain vector kernel.
+SFM_HD bool prefilter_scales(float thr, PfScales &sc)
+{
+    if (!(thr >= 1e-9f && thr <= 1e-2f)) return false;
+    int e = 0;
+    (void)frexpf(1.0f / (32.0f * thr), &e);          // 1 / (32 thr) = m 2^e, m in [0.5, 1)  ->  floor(log2) = e - 1
+    const int a = (e - 1) >> 1;                       // floor(0.5 log2(1 / (32 thr)))   (arithmetic shift: floor)
+    sc.a = a;
+    sc.sigE = ldexpf(1.0f, a - 4);
+    sc.sigF = kPfFeatScale;
+    sc.sig2a = ldexpf(1.0f, 2 * a);
+    return true;
+}
+
+SFM_HD void pf_split2(float x, _Float16 &h, _Float16 &m)
+{
+    h = (_Float16)x;
+    m = (_Float16)(x - (float)h);
+}
+
+SFM_HD void pf_split3(float x, _Float16 &h, _Float16 &m, _Float16 &l)
+{
+    h = (_Float16)x;
+    const float r = x - (float)h;
+    m = (_Float16)r;
+    l = (_Float16)(r - (float)m);
+}
+
+// k-slot order shared by the two operands.  n: term i of (e0 ux, e1 uy, e3 vx, e4 vy, e2 u, e5 v, e6 x, e7 y) with
+// (u, v) = x1, (x, y) = x2 occupies slots 3i..3i+2 = (E_hi f_hi, E_hi f_lo, E_lo f_hi); e8 = slots 24..26 (hi, mid, lo
+// times the constant feature sigF); slot 27 = 1 x (0 for a real point, kPfPadValue for padding).
+// G: term j of (x^2, xy, y^2, x, y) occupies 3j..3j+2 the same way; slot 15 the constant (one fp16: its rounding error,
+// 2^-11 of s (e2^2 + e5^2), is part of terr) x 1.
+// Returns tmin (unscaled); ns / ts are the hypothesis' coefficient slots.
+SFM_HD float prefilter_hyp_slots(const float e[9], float thr, float B, const PfScales &sc, _Float16 ns[kPfSlots], _Float16 ts[kPfSlotsT])
+{
+#pragma unroll
+    for (int k = 0; k < kPfSlots; ++k) ns[k] = (_Float16)0.0f;
+#pragma unroll
+    for (int k = 0; k < kPfSlotsT; ++k) ts[k] = (_Float16)0.0f;
+    float ae[9];
+    bool tame = B <= 48.0f;                           // features up to 16 B^2 must stay inside fp16 (inf B: not tame)
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { ae[k] = fabsf(e[k]); tame = tame && (ae[k] <= 2.0f); }      // NaN compares false
+    ns[27] = (_Float16)1.0f;
+    if (!tame) {                                      // every pair of this hypothesis survives (G = -2^-10 < 0 for real points)
+        ts[15] = (_Float16)(-0.0009765625f);
+        return 0.0f;
+    }
+    const int order[8] = { 0, 1, 3, 4, 2, 5, 6, 7 };
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        _Float16 h, m;
+        pf_split2(e[order[i]] * sc.sigE, h, m);
+        ns[3 * i] = h; ns[3 * i + 1] = h; ns[3 * i + 2] = m;
+    }
+    pf_split3(e[8] * sc.sigE, ns[24], ns[25], ns[26]);
+
+    const float sabs = ae[8] + B * (ae[2] + ae[5] + ae[6] + ae[7]) + B * B * (ae[0] + ae[1] + ae[3] + ae[4]);
+    const float dn = 2.8610229e-06f * sabs + 2.3841858e-07f * (1.0f + B * B);           // 3 * 2^-20, 2^-22
+    const float c1 = (1.0f + kPfRho) * (1.0f + 9.5367432e-07f) * (1.0f + 0.015625f) * 1.0001f;
+    const float s = c1 * thr;
+    const float mq[5] = { e[0] * e[0] + e[3] * e[3], 2.0f * (e[0] * e[1] + e[3] * e[4]), e[1] * e[1] + e[4] * e[4],
+                          2.0f * (e[0] * e[2] + e[3] * e[5]), 2.0f * (e[1] * e[2] + e[4] * e[5]) };
+    const float C = e[2] * e[2] + e[5] * e[5];
+    const float aq = (ae[0] * ae[0] + ae[3] * ae[3]) + 2.0f * (ae[0] * ae[1] + ae[3] * ae[4]) + (ae[1] * ae[1] + ae[4] * ae[4]);
+    const float al = 2.0f * (ae[0] * ae[2] + ae[3] * ae[5]) + 2.0f * (ae[1] * ae[2] + ae[4] * ae[5]);
+    const float sabsT = aq * B * B + al * B + C;
+    const float terr = s * 2.8610229e-06f * sabsT + 4.7683716e-07f * (B * B + B + 1.0f + 4.0f * s * sc.sig2a) / sc.sig2a   // 16 * 2^-25
+                     + 4.9e-04f * s * C;                                                                                   // 2^-11: the one-part constant
+    const float eta = 2.3841858e-07f * (ae[2] + ae[5] + B * (ae[0] + ae[1] + ae[3] + ae[4]));                                 // 4 * 2^-24
+    const float c2 = 1.25f * terr + s * 262.6f * eta * eta + (1.0f + 1.0f / kPfRho) * 1.01f * dn * dn + 1e-37f;
+    const float gsub = 1.25f * terr + s * 8.0f * eta * eta + 1e-36f;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        _Float16 h, m;
+        pf_split2((s * mq[j]) * sc.sig2a, h, m);
+        ts[3 * j] = h; ts[3 * j + 1] = h; ts[3 * j + 2] = m;
+    }
+    ts[15] = (_Float16)((s * C - gsub) * sc.sig2a);
+    return c2 + gsub;
+}
+
+// Feature slots of one point (u, v) = x1, (x, y) = x2.  Padding points (beyond num_points) get all-zero features and the
+// pad marker: nt = 256, G = 0 -> always rejected.  A real point with a non-finite coordinate, or one whose features leave
+// the fp16 range, gets all-zero features WITHOUT the marker: nt = 0 -> clamp(0 - tmin) = 0 -> never rejected, the exact
+// test sees it (no NaN or inf ever enters a matrix-core operand, so G and nt are always finite).
+SFM_HD void prefilter_point_slots(float u, float v, float x, float y, bool real, _Float16 bn[kPfSlots], _Float16 bt[kPfSlotsT])
+{
+#pragma unroll
+    for (int k = 0; k < kPfSlots; ++k) bn[k] = (_Float16)0.0f;
+#pragma unroll
+    for (int k = 0; k < kPfSlotsT; ++k) bt[k] = (_Float16)0.0f;
+    if (!real) { bn[27] = (_Float16)kPfPadValue; return; }
+    const float big = fmaxf(fmaxf(fabsf(u), fabsf(v)), fmaxf(fabsf(x), fabsf(y)));
+    if (!(big <= 48.0f) || u != u || v != v || x != x || y != y) return;           // 16 * 48^2 < 65504
+    const float fn[8] = { u * x, u * y, v * x, v * y, u, v, x, y };
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        _Float16 h, m;
+        pf_split2(fn[i] * kPfFeatScale, h, m);
+        bn[3 * i] = h; bn[3 * i + 1] = m; bn[3 * i + 2] = h;
+    }
+    bn[24] = bn[25] = bn[26] = (_Float16)kPfFeatScale;
+    const float ft[5] = { x * x, x * y, y * y, x, y };
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        _Float16 h, m;
+        pf_split2(ft[j], h, m);
+        bt[3 * j] = h; bt[3 * j + 1] = m; bt[3 * j + 2] = h;
+    }
+    bt[15] = (_Float16)1.0f;
+}
+
+// The rule on the host (tests): the kernel evaluates the same thing as v_fma_f32 ... clamp + v_cmp_lt_u32.
+SFM_HD bool prefilter_reject(float nt, float G, float tminw_scaled)
+{
+    float w = fmaf(nt, nt, -tminw_scaled);
+    w = (w != w) ? 0.0f : fminf(fmaxf(w, 0.0f), 1.0f);
+    return f32_bits(G) < f32_bits(w);
+}
+
+} // namespace sfm

@@ -280,7 +280,7 @@ int launch_ransac_score(sfm_pair *pair, const sfm_ransac_params &p, uint32_t h0,
     // which kernel family: decided first, because the lane-solve kernel of the SPLIT family clears the keys itself
     const uint32_t fused_max_early = p.jacobi_sweeps > 0 ? 4096u : 1024u;
     const int family = p.kernel == SFM_KERNEL_AUTO ? (count <= fused_max_early ? SFM_KERNEL_FUSED : SFM_KERNEL_SPLIT) : p.kernel;
-    const bool self_clearing = count > 0 && family == SFM_KERNEL_SPLIT;
+    const bool self_clearing = count > 0 && (family == SFM_KERNEL_SPLIT || family == SFM_KERNEL_PREFILTER);
     if (!self_clearing) {
         SFM_HIP_TRY(hipMemsetAsync(pair->d_key, 0, 2 * sizeof(unsigned long long), ctx->stream));
         if (key2) SFM_HIP_TRY(hipMemsetAsync(key2, 0, sizeof(unsigned long long), ctx->stream));
@@ -298,6 +298,11 @@ int launch_ransac_score(sfm_pair *pair, const sfm_ransac_params &p, uint32_t h0,
     const uint32_t fused_max = p.jacobi_sweeps > 0 ? 4096u : 1024u;
     int kernel = p.kernel == SFM_KERNEL_AUTO ? (count <= fused_max ? SFM_KERNEL_FUSED : SFM_KERNEL_SPLIT) : p.kernel;
     if (kernel == SFM_KERNEL_MFMA && pair->n >= 65536) kernel = SFM_KERNEL_SPLIT;   // its packed counters are 16-bit
+    // matrix-core pre-filter in front of the exact test (ransac_prefilter.hip): AUTO takes it whenever it applies
+    // (unit-z points, threshold inside the fp16 scaling range, enough hypotheses); asked for explicitly where it does
+    // not apply, the call runs the plain wavefront kernel instead (sfm_ransac_last_launch reports which one ran)
+    if (kernel == SFM_KERNEL_PREFILTER && !prefilter_usable(pair, p, count >= 16384u ? count : 16384u)) kernel = SFM_KERNEL_SPLIT;
+    if (p.kernel == SFM_KERNEL_AUTO && kernel == SFM_KERNEL_SPLIT && prefilter_usable(pair, p, count) && p.reserved[3] != 1) kernel = SFM_KERNEL_PREFILTER;
     pair->last_kernel = kernel;
     if (kernel == SFM_KERNEL_FUSED) {
         rc = launch_ransac_fused(pair, p, h0, count);
@@ -319,11 +324,12 @@ int launch_ransac_score(sfm_pair *pair, const sfm_ransac_params &p, uint32_t h0,
     // more than one tile: one tile per block (blockIdx.y), partial counts through atomics, keys from ransac_argmax_counts
     // (p.reserved[1] == 1 keeps the tile loop inside the block: the A/B switch of profiles/pipeline_bench.py)
     const bool grid2d = ntiles > 1 && kernel == SFM_KERNEL_SPLIT && wpb == 16 && p.reserved[1] != 1;
+    const bool prefilter = kernel == SFM_KERNEL_PREFILTER;
 
     const bool timed = ctx->timing && ctx->tcount < sfm_ctx::kTimingSlots;
     hipEvent_t *tev = timed ? ctx->tev[ctx->tcount] : nullptr;
     if (timed) SFM_HIP_TRY(hipEventRecord(tev[0], ctx->stream));
-    int *zero_counts = grid2d ? pair->d_counts : nullptr;
+    int *zero_counts = (grid2d || prefilter) ? pair->d_counts : nullptr;
     if (p.reserved[0] == 1)          // A/B switch: one hypothesis per lane (scalar math)
         hipLaunchKernelGGL(ransac_solve_lanes, dim3((count + 63) / 64), dim3(64), 0, ctx->stream,
                            pair->d_X[0], pair->d_X[1], pair->ld, pair->n, p.d_indices, p.seed, h0, count,
@@ -358,7 +364,16 @@ int launch_ransac_score(sfm_pair *pair, const sfm_ransac_params &p, uint32_t h0,
         grid = (int)((blocks + ntiles - 1) / ntiles);
         if ((uint32_t)grid > nbatch) grid = (int)nbatch;
     }
-    if (kernel == SFM_KERNEL_MFMA) {
+    if (prefilter) {
+        rc = launch_score_prefilter(pair, p, count);
+        if (rc == SFM_OK) {
+            const int ablocks = (int)((count + 4095u) / 4096u);
+            hipLaunchKernelGGL(ransac_argmax_counts, dim3(ablocks < 1024 ? ablocks : 1024), dim3(256), 0, ctx->stream,
+                               pair->d_counts, h0, count, pair->d_key, key2);
+            SFM_HIP_TRY(hipGetLastError());
+        }
+    }
+    else if (kernel == SFM_KERNEL_MFMA) {
         rc = launch_score_mfma(pair, p, h0, count);
         if (rc == SFM_OK && key2) SFM_HIP_TRY(hipMemcpyAsync(key2, pair->d_key, sizeof(unsigned long long), hipMemcpyDeviceToDevice, ctx->stream));
     }

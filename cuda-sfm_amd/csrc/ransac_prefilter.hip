@@ -1,0 +1,274 @@
+// ransac_prefilter.hip -- inlier counting with a matrix-core pre-filter in front of the exact test (gfx950).
+//
+// Replaces Image_pair::calculateInliers (SfM/sfm.cu:155-236: 6 strided-batched GEMMs + 8 element-wise passes that
+// materialise 6 x 3NR + 4 x NR floats) like ransac_score_waves does, with the same exact decision per pair
+// (device_math.hpp residual / inlier_filter) -- but only for the ~1 % of the pairs that a conservative test on the
+// matrix cores cannot rule out.  prefilter_math.hpp has the rule and its proof obligations.
+//
+// One block = 16 wavefronts sharing one tile of 1024 points, staged ONCE in LDS: fp16 feature fragments (the B operands
+// of v_mfma_f32_32x32x16_f16, 96 bytes per point) and the plain coordinates for the exact test (16 bytes per point).
+// A wavefront prepares the coefficient fragments (A operands) of 64 hypotheses at a time, one hypothesis per lane, and
+// hands them to the two 32-row blocks through a half-wave exchange; for each 32-row block it walks the tile in 32-point
+// steps:
+//     3 x ds_read_b128 -> 3 MFMAs (G: 1, nt: 2) -> per accumulator v_fma ... clamp, v_cmp_lt_u32, v_addc (no branch)
+// which leaves every lane with a 16-bit "rejected" mask of its 16 pairs.  Lanes with a surviving pair append one word to
+// the wavefront's ring in LDS; 64 entries at a time go through the exact filter, one entry per lane, and inliers bump the
+// hypothesis' counter in LDS.  Tiles are spread over blockIdx.y; partial counts reach counts[] through integer atomics
+// (order-independent, so the result is deterministic) and ransac_argmax_counts (ransac.hip) builds the keys.
+#include "ransac_device.hpp"
+#include "prefilter_math.hpp"
+
+namespace sfm {
+
+constexpr int kPfTile = 1024;            // points per tile
+constexpr int kPfWaves = 16;
+constexpr int kPfRing = 128;             // survivor ring entries per wavefront (at most 64 are appended per step)
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+typedef int i4v __attribute__((ext_vector_type(4)));
+
+// LDS map
+constexpr int kPfLdsBn = 0;                                   // [32-point block][k-step 0..1][lane][8 fp16]
+constexpr int kPfLdsBt = kPfLdsBn + kPfTile * 64;             // [32-point block][lane][8 fp16]
+constexpr int kPfLdsPts = kPfLdsBt + kPfTile * 32;            // float4 (x1x, x1y, x2x, x2y) per point
+constexpr int kPfLdsWave = kPfLdsPts + kPfTile * 16;          // per wavefront: E table 32 x 9 floats, 32 counters, ring
+constexpr int kPfWaveBytes = 32 * 9 * 4 + 32 * 4 + kPfRing * 4;
+constexpr int kPfLdsBound = kPfLdsWave + kPfWaves * kPfWaveBytes;
+constexpr int kPfLdsBytes = kPfLdsBound + 16;
+
+// clamp01(a * b + c) with NaN -> 0: the compiler folds the med3 into the fma's clamp modifier (the kernel descriptor has
+// DX10_CLAMP set).  Deliberately NOT inline assembly: the result registers of an MFMA need software wait states before a
+// vector instruction may read them, and the hazard recognizer does not look into asm statements.
+__device__ __forceinline__ float fma_clamp(float a, float b, float c)
+{
+    return __builtin_amdgcn_fmed3f(fmaf(a, b, c), 0.0f, 1.0f);
+}
+
+// rejected = (rejected << 1) | (bits(G) <u bits(w)): one compare into VCC and one add-with-carry (the compiler's own
+// selection for the C++ form is v_cmp + v_cndmask + or-tree, 3.5 instructions per pair and 20 more registers).
+// G comes straight out of an MFMA, whose result registers need software wait states before a vector instruction may read
+// them, and the hazard recognizer does not look into asm statements: FIRST = true (the first read after the MFMAs) carries
+// 20 wait states of its own, more than the 19 a 16-pass matrix instruction asks for on gfx950.
+template <bool FIRST>
+__device__ __forceinline__ uint32_t shift_in_reject(uint32_t rejected, float G, float w)
+{
+    if (FIRST)
+        asm volatile("s_nop 15\n\ts_nop 3\n\tv_cmp_lt_u32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(rejected) : "v"(G), "v"(w) : "vcc");
+    else
+        asm volatile("v_cmp_lt_u32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(rejected) : "v"(G), "v"(w) : "vcc");
+    return rejected;
+}
+
+// The fragment of hypothesis row `src` for this lane's k-half: every lane offers both halves of the row it prepared, the
+// reader keeps the one its MFMA lane position asks for (ds_bpermute through __shfl; no LDS storage involved).
+__device__ __forceinline__ h8 fetch_fragment(const h8 &xs, const h8 &ys, int src, int half)
+{
+    const i4v xi = __builtin_bit_cast(i4v, xs), yi = __builtin_bit_cast(i4v, ys);
+    i4v o;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        const int fx = __shfl(xi[d], src), fy = __shfl(yi[d], src);
+        o[d] = half ? fy : fx;
+    }
+    return __builtin_bit_cast(h8, o);
+}
+
+// Exact decision for up to 64 ring entries starting at `head`, one entry per lane.
+// entry = (point block << 22) | (lane << 16) | 16-bit mask of surviving accumulators (bit 15 - r = accumulator r).
+__device__ __noinline__ void pf_flush(const uint32_t *ring, int head, int nent, int lane, const float *etab, int *cnt,
+                                      const float4 *pts, int nvalid_hyp, float thr)
+{
+    if (lane >= nent) return;
+    const ThrBand band = make_band(thr);
+    const uint32_t ent = ring[(head + lane) & (kPfRing - 1)];
+    const int l = (ent >> 16) & 63, pb = ent >> 22;
+    uint32_t surv = ent & 0xFFFFu;
+    const float4 q = pts[pb * 32 + (l & 31)];
+    while (surv) {
+        const int bit = __builtin_ctz(surv);
+        surv &= surv - 1;
+        const int r = 15 - bit;
+        const int hl = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);               // accumulator row = local hypothesis
+        if (hl < nvalid_hyp) {
+            const float *e = etab + 9 * hl;
+            const Ess E{ e[0], e[1], e[2], e[3], e[4], e[5], e[6], e[7], e[8] };
+            bool und;
+            bool in = inlier_filter(E, band, q.x, q.y, 1.0f, q.z, q.w, 1.0f, und);
+            if (und) in = residual(E, q.x, q.y, 1.0f, q.z, q.w, 1.0f) < band.thr;
+            if (in) atomicAdd(&cnt[hl], 1);
+        }
+    }
+}
+
+__global__ __launch_bounds__(kPfWaves * 64)
+void ransac_score_prefilter(const float *__restrict__ X0, const float *__restrict__ X1, int ld, int n,
+                            const float *__restrict__ Ecand, uint32_t count, float thr, PfScales sc,
+                            int *__restrict__ counts, unsigned long long *__restrict__ clk)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool probe = clk && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0;
+    unsigned long long c0 = 0, w0 = 0;
+    if (probe) { c0 = clock64(); w0 = wall_clock64(); }
+
+    // ---- stage the tile: one point per thread -> 48 fp16 feature slots in MFMA B-fragment order + its coordinates
+    unsigned int &tile_bound = *reinterpret_cast<unsigned int *>(smem + kPfLdsBound);
+    if (threadIdx.x == 0) tile_bound = 0u;
+    __syncthreads();
+    const int tile_first = blockIdx.y * kPfTile;
+    {
+        const int t = threadIdx.x;
+        const int p = tile_first + t;
+        float u = 0.f, v = 0.f, x = 0.f, y = 0.f;
+        const bool real = p < n;
+        if (real) { u = X0[p]; v = X0[(size_t)ld + p]; x = X1[p]; y = X1[(size_t)ld + p]; }
+        _Float16 bn[kPfSlots], bt[kPfSlotsT];
+        prefilter_point_slots(u, v, x, y, real, bn, bt);
+        const float big = fmaxf(fmaxf(fabsf(u), fabsf(v)), fmaxf(fabsf(x), fabsf(y)));
+        if (big <= 48.0f) atomicMax(&tile_bound, __float_as_uint(big));       // points beyond that carry no features (prefilter_point_slots)
+        // padding reads as NaN in the exact test (it is always rejected before; NaN never counts)
+        reinterpret_cast<float4 *>(smem + kPfLdsPts)[t] = real ? make_float4(u, v, x, y) : make_float4(NAN, NAN, NAN, NAN);
+        const int pb = t >> 5, col = t & 31;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                h8 c;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) c[j] = bn[ks * 16 + half * 8 + j];
+                *reinterpret_cast<h8 *>(smem + kPfLdsBn + (((pb * 2 + ks) * 2 + half) * 32 + col) * 16) = c;
+            }
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            h8 c;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) c[j] = bt[half * 8 + j];
+            *reinterpret_cast<h8 *>(smem + kPfLdsBt + ((pb * 2 + half) * 32 + col) * 16) = c;
+        }
+    }
+    __syncthreads();
+    const float B = __uint_as_float(tile_bound);
+    const int npb = (min(kPfTile, ld - tile_first) + 31) >> 5;           // 32-point blocks that hold points or padding
+    float *etab = reinterpret_cast<float *>(smem + kPfLdsWave + wave * kPfWaveBytes);
+    int *cnt = reinterpret_cast<int *>(etab + 32 * 9);
+    uint32_t *ring = reinterpret_cast<uint32_t *>(cnt + 32);
+    const float4 *pts = reinterpret_cast<const float4 *>(smem + kPfLdsPts);
+    const h8 *bn_l = reinterpret_cast<const h8 *>(smem + kPfLdsBn) + lane;
+    const h8 *bt_l = reinterpret_cast<const h8 *>(smem + kPfLdsBt) + lane;
+    const int half = lane >> 5, row = lane & 31;
+
+    // ---- 64 hypotheses per pass of this wavefront (no block-level synchronisation from here on)
+    const uint32_t npass = (count + 63u) / 64u;
+    for (uint32_t ps = blockIdx.x * kPfWaves + wave; ps < npass; ps += gridDim.x * kPfWaves) {
+        const uint32_t h_first = ps * 64u;
+        const int nvalid64 = (int)min(64u, count - h_first);
+        // coefficient slots: lane l prepares hypothesis h_first + l (lanes beyond the range repeat the last one)
+        float e[9];
+        {
+            const float *src = Ecand + 9 * (size_t)(h_first + (uint32_t)min(lane, nvalid64 - 1));
+#pragma unroll
+            for (int k = 0; k < 9; ++k) e[k] = src[k];
+        }
+        _Float16 ns[kPfSlots], ts[kPfSlotsT];
+        const float tmin_own = prefilter_hyp_slots(e, thr, B, sc, ns, ts);
+        // X* = k-slots 0..7 of each 16-slot step (the fragment of MFMA lanes 0..31), Y* = k-slots 8..15 (lanes 32..63)
+        h8 xn0, yn0, xn1, yn1, xt, yt;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            xn0[j] = ns[j];      yn0[j] = ns[8 + j];
+            xn1[j] = ns[16 + j]; yn1[j] = ns[24 + j];
+            xt[j] = ts[j];       yt[j] = ts[8 + j];
+        }
+        for (int blk = 0; blk < 2; ++blk) {
+            const int nvalid = min(32, nvalid64 - 32 * blk);
+            if (nvalid <= 0) break;
+            // rows of this block were prepared by lanes 32 blk .. 32 blk + 31; MFMA lane l needs row l % 32, k-half l / 32
+            const int src = 32 * blk + row;
+            const h8 an0 = fetch_fragment(xn0, yn0, src, half), an1 = fetch_fragment(xn1, yn1, src, half);
+            const h8 at = fetch_fragment(xt, yt, src, half);
+            float tmin = __shfl(tmin_own, src);
+            // E table and counters of this block (the previous block's ring is drained, its counters are flushed)
+            if (half == blk) {
+#pragma unroll
+                for (int k = 0; k < 9; ++k) etab[9 * row + k] = e[k];
+                cnt[row] = 0;
+            }
+            if (row >= nvalid) tmin = 0.0f;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) tmin = fmaxf(tmin, __shfl_xor(tmin, off));
+            const float neg_tminw = -(tmin * sc.sig2a);
+
+            int head = 0, nq = 0;                       // ring state (wave-uniform)
+            for (int pb = 0; pb < npb; ++pb) {
+                const h8 bt0 = bt_l[pb * 64];
+                const h8 bn0 = bn_l[(pb * 2 + 0) * 64], bn1 = bn_l[(pb * 2 + 1) * 64];
+                f16v accg = {}, accn = {};
+                accg = __builtin_amdgcn_mfma_f32_32x32x16_f16(at, bt0, accg, 0, 0, 0);
+                accn = __builtin_amdgcn_mfma_f32_32x32x16_f16(an0, bn0, accn, 0, 0, 0);
+                accn = __builtin_amdgcn_mfma_f32_32x32x16_f16(an1, bn1, accn, 0, 0, 0);
+                uint32_t rejected = 0;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float w = fma_clamp(accn[r], accn[r], neg_tminw);
+                    rejected = r == 0 ? shift_in_reject<true>(rejected, accg[r], w) : shift_in_reject<false>(rejected, accg[r], w);
+                }
+                const uint32_t surv = ~rejected & 0xFFFFu;              // bit 15 - r: accumulator r survived
+                const unsigned long long any = __ballot(surv != 0u);
+                if (any) {
+                    if (nq >= 64) {                     // make room first: at most 64 entries are appended below
+                        pf_flush(ring, head, 64, lane, etab, cnt, pts, nvalid, thr);
+                        head = (head + 64) & (kPfRing - 1); nq -= 64;
+                    }
+                    const int slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(any >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)any, 0u));
+                    if (surv) ring[(head + nq + slot) & (kPfRing - 1)] = ((uint32_t)pb << 22) | ((uint32_t)lane << 16) | surv;
+                    nq += __builtin_popcountll(any);
+                }
+            }
+            while (nq > 0) {
+                const int m = min(nq, 64);
+                pf_flush(ring, head, m, lane, etab, cnt, pts, nvalid, thr);
+                head = (head + m) & (kPfRing - 1); nq -= m;
+            }
+            // LDS counters -> counts[] (zeroed by the solve kernel); a wavefront's LDS operations complete in order
+            if (lane < nvalid) {
+                const int c = cnt[lane];
+                if (c) atomicAdd(&counts[h_first + 32u * blk + lane], c);
+            }
+        }
+    }
+    if (probe) { clk[0] = clock64() - c0; clk[1] = wall_clock64() - w0; }
+}
+
+// Conditions under which launch_ransac_score may pick this kernel: the unit-z layout (every z exactly 1), a threshold the
+// fp16 scaling covers, and enough hypotheses to fill the chip with 1024-hypothesis block iterations.
+bool prefilter_usable(const sfm_pair *pair, const sfm_ransac_params &p, uint32_t count)
+{
+    PfScales sc;
+    return pair->unit_z && count >= 16384u && prefilter_scales(p.threshold, sc);
+}
+
+int launch_score_prefilter(sfm_pair *pair, const sfm_ransac_params &p, uint32_t count)
+{
+    sfm_ctx *ctx = pair->ctx;
+    PfScales sc;
+    if (!prefilter_scales(p.threshold, sc)) { set_error("threshold %g outside the pre-filter's range", (double)p.threshold); return SFM_E_INVALID; }
+    const int rc_lds = allow_big_lds(ctx, reinterpret_cast<const void *>(&ransac_score_prefilter));
+    if (rc_lds != SFM_OK) return rc_lds;
+    const int ntiles = (pair->ld + kPfTile - 1) / kPfTile;
+    const uint32_t iters = (count + 64u * kPfWaves - 1) / (64u * kPfWaves);       // 1024-hypothesis block iterations per tile
+    // one block per CU is resident (140 KiB of LDS) and staging a tile is not overlapped with anything, so few, long
+    // blocks: about two per CU (measured on 2^20 x 4096: 1.39 ms with 256 blocks, 1.41 with 512, 1.47 with 1024, 1.63 with 4096)
+    uint32_t cols = (uint32_t)(2 * ctx->num_cus + ntiles - 1) / (uint32_t)ntiles;
+    if (p.reserved[2] > 0) cols = (uint32_t)p.reserved[2];
+    if (cols > iters) cols = iters;
+    if (cols < 1) cols = 1;
+    hipLaunchKernelGGL(ransac_score_prefilter, dim3(cols, ntiles), dim3(kPfWaves * 64), kPfLdsBytes, ctx->stream,
+                       pair->d_X[0], pair->d_X[1], pair->ld, pair->n, pair->d_Ecand, count, p.threshold, sc,
+                       pair->d_counts, pair->d_clk);
+    SFM_HIP_TRY(hipGetLastError());
+    pair->last_grid = (int)cols * ntiles; pair->last_block = kPfWaves * 64; pair->last_lds = kPfLdsBytes;
+    return SFM_OK;
+}
+
+} // namespace sfm

@@ -161,6 +161,9 @@ int sfm_set_points(sfm_pair *pair, const float *d_X0, const float *d_X1);
 #define SFM_KERNEL_SPLIT  1   /* solve: one hypothesis per lane; score: one hypothesis per wavefront */
 #define SFM_KERNEL_FUSED  2   /* everything one hypothesis per wavefront in LDS                      */
 #define SFM_KERNEL_MFMA   3   /* lane solve; scoring: 32 hypotheses per wavefront, E.X on the matrix cores */
+#define SFM_KERNEL_PREFILTER 4 /* lane solve; scoring: fp16-split matrix-core pre-filter (32 hypotheses x 32 points per  */
+                              /* MFMA tile) rejects the pairs that cannot be inliers, the exact test runs on the rest; */
+                              /* needs z == 1 points (fillXU) and 1e-9 <= threshold <= 1e-2, else SFM_KERNEL_SPLIT runs */
 
 typedef struct sfm_ransac_params {
     uint32_t num_hypotheses;  /* H: global hypothesis count (reference: N/8, sfm.cu:95)                 */
@@ -174,7 +177,8 @@ typedef struct sfm_ransac_params {
     int32_t  kernel;          /* SFM_KERNEL_*                                                           */
     int32_t  reserved[4];     /* 0 = defaults.  A/B switches of profiles/: [0] = 1 one hypothesis per lane in the solve kernel;   */
                               /* [1] = 1 tile loop inside the scoring block instead of the tile-parallel grid (n > 4096);         */
-                              /* [2] = k > 0 minimum hypothesis batches per scoring block (default 8); [3] unused                 */
+                              /* [2] = k > 0 minimum hypothesis batches per scoring block (default 8; pre-filter: grid columns);   */
+                              /* [3] = 1 AUTO never picks SFM_KERNEL_PREFILTER                                                    */
 } sfm_ransac_params;
 
 void sfm_ransac_default_params(sfm_ransac_params *p, int num_points);

@@ -1,0 +1,94 @@
+"""GPU parity of the matrix-core pre-filter scoring kernel (SFM_KERNEL_PREFILTER, csrc/ransac_prefilter.hip) against the
+CPU oracle: every inlier count, the key, the winner's E and mask -- bit for bit, like every other kernel family.  The
+pre-filter may only skip work; any pair it rejects wrongly shows up here as a count that is too small."""
+import numpy as np
+import pytest
+
+import cuda_sfm_amd as S
+from cuda_sfm_amd import synth
+import oracle as O
+from helpers import same_bits, to_dev, make_pair
+
+pytestmark = pytest.mark.gpu
+
+
+def check_all(pair, scene, p, H, n):
+    _, _, X0, X1 = O.fill_xu(scene["sift"], scene["Kinv"])
+    key, ocounts, oE = O.ransac_range(X0, X1, 0, H, p.threshold, p.jacobi_sweeps, seed=p.seed, want_E=True)
+    counts = pair.get_inlier_counts(H)
+    bad = np.flatnonzero(counts != ocounts)
+    assert bad.size == 0, f"{bad.size} counts differ, first: hyp {bad[:5]} gpu {counts[bad[:5]]} oracle {ocounts[bad[:5]]}"
+    assert pair.get_key() == key
+    ocnt, ohyp = O.unpack_key(key)
+    assert pair.get_best() == (ohyp, ocnt)
+    assert same_bits(pair.get_E(), oE[ohyp].reshape(3, 3))
+    assert np.array_equal(pair.get_inlier_mask(), O.count_inliers(oE[ohyp], X0, X1, p.threshold)[1])
+
+
+@pytest.mark.parametrize("n,H", [(1024, 16384), (1000, 20000), (4096, 32768), (4500, 17000), (700, 16385), (2048, 65536)])
+def test_prefilter_counts_equal_oracle(gpu, n, H):
+    scene = synth.two_view_scene(n, seed=200 + n)
+    pair, _ = make_pair(S, gpu, scene)
+    p = S.default_params(n, num_hypotheses=H, seed=n + 1, kernel=S.KERNEL_PREFILTER)
+    pair.estimateE(p)
+    assert pair.last_launch()["kernel"] == S.KERNEL_PREFILTER
+    check_all(pair, scene, p, H, n)
+
+
+@pytest.mark.parametrize("thr", [1e-8, 1e-7, 1e-5, 1e-4, 1e-3])
+def test_prefilter_thresholds(gpu, thr):
+    n, H = 2000, 20000
+    scene = synth.two_view_scene(n, seed=17)
+    pair, _ = make_pair(S, gpu, scene)
+    p = S.default_params(n, num_hypotheses=H, seed=5, kernel=S.KERNEL_PREFILTER, threshold=thr)
+    pair.estimateE(p)
+    assert pair.last_launch()["kernel"] == S.KERNEL_PREFILTER
+    check_all(pair, scene, p, H, n)
+
+
+@pytest.mark.parametrize("focal,noise", [(300.0, 0.5), (1200.0, 0.1), (2360.0, 0.0), (8000.0, 1.0)])
+def test_prefilter_fields_of_view(gpu, focal, noise):
+    """Wide to narrow fields of view change the coordinate bound B (and with it every error bound of the rule)."""
+    n, H = 3000, 16384
+    scene = synth.two_view_scene(n, seed=23, focal=focal, noise_px=noise)
+    pair, _ = make_pair(S, gpu, scene)
+    p = S.default_params(n, num_hypotheses=H, seed=9, kernel=S.KERNEL_PREFILTER)
+    pair.estimateE(p)
+    check_all(pair, scene, p, H, n)
+
+
+def test_prefilter_equals_split_at_bench_size(gpu):
+    """The bench configuration: every one of the 2^20 counts equal to the plain wavefront kernel's (which the other tests
+    pin to the oracle), same key, same E, same mask."""
+    n, H = 4096, 1 << 20
+    scene = synth.two_view_scene(n)
+    pair, _ = make_pair(S, gpu, scene)
+    p = S.default_params(n, num_hypotheses=H, kernel=S.KERNEL_SPLIT)
+    pair.estimateE(p)
+    ref = (pair.get_inlier_counts(H).copy(), pair.get_key(), pair.get_E().copy(), pair.get_inlier_mask().copy())
+    q = S.default_params(n, num_hypotheses=H, kernel=S.KERNEL_PREFILTER)
+    pair.estimateE(q)
+    assert pair.last_launch()["kernel"] == S.KERNEL_PREFILTER
+    counts = pair.get_inlier_counts(H)
+    bad = np.flatnonzero(counts != ref[0])
+    assert bad.size == 0, f"{bad.size} counts differ, first {bad[:5]}: {counts[bad[:5]]} vs {ref[0][bad[:5]]}"
+    assert pair.get_key() == ref[1] and same_bits(pair.get_E(), ref[2]) and np.array_equal(pair.get_inlier_mask(), ref[3])
+
+
+def test_prefilter_falls_back_where_it_does_not_apply(gpu):
+    """z != 1 (sfm_set_points) or a threshold outside the fp16 scaling range: the plain wavefront kernel runs."""
+    torch, dev, ctx = gpu
+    n, H = 1200, 20000
+    scene = synth.two_view_scene(n, seed=4)
+    _, _, X0, X1 = O.fill_xu(scene["sift"], scene["Kinv"])
+    pair = S.ImagePair(ctx, scene["K"], scene["Kinv"], 2, n)
+    pair.set_points(to_dev(torch, dev, np.ascontiguousarray(X0 * 2)), to_dev(torch, dev, np.ascontiguousarray(X1 * 3)))
+    p = S.default_params(n, num_hypotheses=H, kernel=S.KERNEL_PREFILTER)
+    pair.estimateE(p)
+    assert pair.last_launch()["kernel"] == S.KERNEL_SPLIT
+    pair2, _ = make_pair(S, gpu, scene)
+    q = S.default_params(n, num_hypotheses=H, kernel=S.KERNEL_PREFILTER, threshold=1e-11)
+    pair2.estimateE(q)
+    assert pair2.last_launch()["kernel"] == S.KERNEL_SPLIT
+    key, ocounts, _ = O.ransac_range(X0, X1, 0, H, q.threshold, q.jacobi_sweeps, seed=q.seed)
+    assert np.array_equal(pair2.get_inlier_counts(H), ocounts)
