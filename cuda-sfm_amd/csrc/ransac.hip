@@ -301,7 +301,7 @@ int launch_ransac_score(sfm_pair *pair, const sfm_ransac_params &p, uint32_t h0,
     // matrix-core pre-filter in front of the exact test (ransac_prefilter.hip): AUTO takes it whenever it applies
     // (unit-z points, threshold inside the fp16 scaling range, enough hypotheses); asked for explicitly where it does
     // not apply, the call runs the plain wavefront kernel instead (sfm_ransac_last_launch reports which one ran)
-    if (kernel == SFM_KERNEL_PREFILTER && !prefilter_usable(pair, p, count >= 16384u ? count : 16384u)) kernel = SFM_KERNEL_SPLIT;
+    if (kernel == SFM_KERNEL_PREFILTER && !prefilter_usable(pair, p, 0x40000000u)) kernel = SFM_KERNEL_SPLIT;     // asked for explicitly: any size
     if (p.kernel == SFM_KERNEL_AUTO && kernel == SFM_KERNEL_SPLIT && prefilter_usable(pair, p, count) && p.reserved[3] != 1) kernel = SFM_KERNEL_PREFILTER;
     pair->last_kernel = kernel;
     if (kernel == SFM_KERNEL_FUSED) {

@@ -22,7 +22,7 @@ namespace sfm {
 
 constexpr int kPfTile = 1024;            // points per tile
 constexpr int kPfWaves = 16;
-constexpr int kPfRing = 128;             // survivor ring entries per wavefront (at most 64 are appended per step)
+constexpr int kPfRing = 256;             // survivor ring entries per wavefront: < 64 waiting + 64 appended per step + 64 re-queued by a flush
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef float f16v __attribute__((ext_vector_type(16)));
 typedef int i4v __attribute__((ext_vector_type(4)));
@@ -46,17 +46,33 @@ __device__ __forceinline__ float fma_clamp(float a, float b, float c)
 
 // rejected = (rejected << 1) | (bits(G) <u bits(w)): one compare into VCC and one add-with-carry (the compiler's own
 // selection for the C++ form is v_cmp + v_cndmask + or-tree, 3.5 instructions per pair and 20 more registers).
-// G comes straight out of an MFMA, whose result registers need software wait states before a vector instruction may read
-// them, and the hazard recognizer does not look into asm statements: FIRST = true (the first read after the MFMAs) carries
-// 20 wait states of its own, more than the 19 a 16-pass matrix instruction asks for on gfx950.
-template <bool FIRST>
+// G and nt come straight out of MFMAs, whose result registers need software wait states before a vector instruction may
+// read them, and the hazard recognizer does not look into asm statements.  mfma_fence() is the compiler-visible read that
+// gets those wait states; its result is an input of the first asm statement of a step (and asm volatile statements keep
+// their order), so no asm statement can be scheduled in front of it.
 __device__ __forceinline__ uint32_t shift_in_reject(uint32_t rejected, float G, float w)
 {
-    if (FIRST)
-        asm volatile("s_nop 15\n\ts_nop 3\n\tv_cmp_lt_u32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(rejected) : "v"(G), "v"(w) : "vcc");
-    else
-        asm volatile("v_cmp_lt_u32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(rejected) : "v"(G), "v"(w) : "vcc");
+    asm volatile("v_cmp_lt_u32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(rejected) : "v"(G), "v"(w) : "vcc");
     return rejected;
+}
+
+__device__ __forceinline__ uint32_t mfma_fence(const f16v &a, const f16v &b)
+{
+    const uint32_t d = __float_as_uint(a[15]) | __float_as_uint(b[15]);     // one v_or_b32 reading the last register of both results
+    uint32_t zero;
+    asm volatile("v_mov_b32 %0, 0 ; after %1" : "=v"(zero) : "v"(d));
+    return zero;
+}
+
+// Two pairs per instruction: (w0, w1) = clamp01((n0, n1)^2 + c) as v_pk_fma_f32 ... clamp (NaN -> 0), then the two
+// compare / add-with-carry steps.
+typedef float v2f32 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t shift_in_reject2(uint32_t rejected, v2f32 nt, v2f32 G, v2f32 c)
+{
+    v2f32 w;
+    asm volatile("v_pk_fma_f32 %0, %1, %1, %2 clamp" : "=v"(w) : "v"(nt), "v"(c));
+    rejected = shift_in_reject(rejected, G.x, w.x);
+    return shift_in_reject(rejected, G.y, w.y);
 }
 
 // The fragment of hypothesis row `src` for this lane's k-half: every lane offers both halves of the row it prepared, the
@@ -73,23 +89,24 @@ __device__ __forceinline__ h8 fetch_fragment(const h8 &xs, const h8 &ys, int src
     return __builtin_bit_cast(h8, o);
 }
 
-// Exact decision for up to 64 ring entries starting at `head`, one entry per lane.
+// Exact decision for up to 64 ring entries starting at `head`, one entry per lane: the lane evaluates the FIRST surviving
+// pair of its entry; an entry that holds more (one in fifteen) goes back to the tail of the ring with the rest of its
+// mask, so that every pass of the exact filter runs on (nearly) 64 busy lanes.  Returns the number of re-queued entries.
 // entry = (point block << 22) | (lane << 16) | 16-bit mask of surviving accumulators (bit 15 - r = accumulator r).
-__device__ __noinline__ void pf_flush(const uint32_t *ring, int head, int nent, int lane, const float *etab, int *cnt,
-                                      const float4 *pts, int nvalid_hyp, float thr)
+__device__ __noinline__ int pf_flush(uint32_t *ring, int head, int nent, int tail, int lane, const float *etab, int *cnt,
+                                     const float4 *pts, int nvalid_hyp, float thr)
 {
-    if (lane >= nent) return;
-    const ThrBand band = make_band(thr);
-    const uint32_t ent = ring[(head + lane) & (kPfRing - 1)];
-    const int l = (ent >> 16) & 63, pb = ent >> 22;
-    uint32_t surv = ent & 0xFFFFu;
-    const float4 q = pts[pb * 32 + (l & 31)];
-    while (surv) {
-        const int bit = __builtin_ctz(surv);
-        surv &= surv - 1;
-        const int r = 15 - bit;
+    uint32_t rest = 0, ent = 0;
+    if (lane < nent) {
+        const ThrBand band = make_band(thr);
+        ent = ring[(head + lane) & (kPfRing - 1)];
+        const int l = (ent >> 16) & 63, pb = ent >> 22;
+        const uint32_t surv = ent & 0xFFFFu;
+        rest = surv & (surv - 1);
+        const int r = 15 - __builtin_ctz(surv);
         const int hl = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);               // accumulator row = local hypothesis
         if (hl < nvalid_hyp) {
+            const float4 q = pts[pb * 32 + (l & 31)];
             const float *e = etab + 9 * hl;
             const Ess E{ e[0], e[1], e[2], e[3], e[4], e[5], e[6], e[7], e[8] };
             bool und;
@@ -98,8 +115,15 @@ __device__ __noinline__ void pf_flush(const uint32_t *ring, int head, int nent, 
             if (in) atomicAdd(&cnt[hl], 1);
         }
     }
+    const unsigned long long more = __ballot(rest != 0u);
+    if (more) {
+        const int slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(more >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)more, 0u));
+        if (rest) ring[(tail + slot) & (kPfRing - 1)] = (ent & 0xFFFF0000u) | rest;
+    }
+    return __builtin_popcountll(more);
 }
 
+template <bool PACKED>
 __global__ __launch_bounds__(kPfWaves * 64)
 void ransac_score_prefilter(const float *__restrict__ X0, const float *__restrict__ X1, int ld, int n,
                             const float *__restrict__ Ecand, uint32_t count, float thr, PfScales sc,
@@ -172,22 +196,33 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
         }
         _Float16 ns[kPfSlots], ts[kPfSlotsT];
         const float tmin_own = prefilter_hyp_slots(e, thr, B, sc, ns, ts);
-        // X* = k-slots 0..7 of each 16-slot step (the fragment of MFMA lanes 0..31), Y* = k-slots 8..15 (lanes 32..63)
-        h8 xn0, yn0, xn1, yn1, xt, yt;
+        // X* = k-slots 0..7 of each 16-slot step (the fragment of MFMA lanes 0..31), Y* = k-slots 8..15 (lanes 32..63).
+        // Rows of block b were prepared by lanes 32 b .. 32 b + 31; MFMA lane l needs row l % 32, k-half l / 32.
+        h8 fn0[2], fn1[2], ft[2];
+        float ftmin[2];
+        {
+            h8 xn0, yn0, xn1, yn1, xt, yt;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            xn0[j] = ns[j];      yn0[j] = ns[8 + j];
-            xn1[j] = ns[16 + j]; yn1[j] = ns[24 + j];
-            xt[j] = ts[j];       yt[j] = ts[8 + j];
+            for (int j = 0; j < 8; ++j) {
+                xn0[j] = ns[j];      yn0[j] = ns[8 + j];
+                xn1[j] = ns[16 + j]; yn1[j] = ns[24 + j];
+                xt[j] = ts[j];       yt[j] = ts[8 + j];
+            }
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk) {
+                const int src = 32 * blk + row;
+                fn0[blk] = fetch_fragment(xn0, yn0, src, half);
+                fn1[blk] = fetch_fragment(xn1, yn1, src, half);
+                ft[blk] = fetch_fragment(xt, yt, src, half);
+                ftmin[blk] = __shfl(tmin_own, src);
+            }
         }
+#pragma unroll
         for (int blk = 0; blk < 2; ++blk) {
             const int nvalid = min(32, nvalid64 - 32 * blk);
             if (nvalid <= 0) break;
-            // rows of this block were prepared by lanes 32 blk .. 32 blk + 31; MFMA lane l needs row l % 32, k-half l / 32
-            const int src = 32 * blk + row;
-            const h8 an0 = fetch_fragment(xn0, yn0, src, half), an1 = fetch_fragment(xn1, yn1, src, half);
-            const h8 at = fetch_fragment(xt, yt, src, half);
-            float tmin = __shfl(tmin_own, src);
+            const h8 an0 = fn0[blk], an1 = fn1[blk], at = ft[blk];
+            float tmin = ftmin[blk];
             // E table and counters of this block (the previous block's ring is drained, its counters are flushed)
             if (half == blk) {
 #pragma unroll
@@ -207,18 +242,27 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
                 accg = __builtin_amdgcn_mfma_f32_32x32x16_f16(at, bt0, accg, 0, 0, 0);
                 accn = __builtin_amdgcn_mfma_f32_32x32x16_f16(an0, bn0, accn, 0, 0, 0);
                 accn = __builtin_amdgcn_mfma_f32_32x32x16_f16(an1, bn1, accn, 0, 0, 0);
-                uint32_t rejected = 0;
+                uint32_t rejected = mfma_fence(accg, accn);           // 0, available once all three MFMAs have written back
+                if (PACKED) {
+                    const v2f32 c2v = { neg_tminw, neg_tminw };
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float w = fma_clamp(accn[r], accn[r], neg_tminw);
-                    rejected = r == 0 ? shift_in_reject<true>(rejected, accg[r], w) : shift_in_reject<false>(rejected, accg[r], w);
+                    for (int r = 0; r < 16; r += 2) {
+                        const v2f32 n2 = { accn[r], accn[r + 1] }, g2 = { accg[r], accg[r + 1] };
+                        rejected = shift_in_reject2(rejected, n2, g2, c2v);
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float w = fma_clamp(accn[r], accn[r], neg_tminw);
+                        rejected = shift_in_reject(rejected, accg[r], w);
+                    }
                 }
                 const uint32_t surv = ~rejected & 0xFFFFu;              // bit 15 - r: accumulator r survived
                 const unsigned long long any = __ballot(surv != 0u);
                 if (any) {
-                    if (nq >= 64) {                     // make room first: at most 64 entries are appended below
-                        pf_flush(ring, head, 64, lane, etab, cnt, pts, nvalid, thr);
-                        head = (head + 64) & (kPfRing - 1); nq -= 64;
+                    while (nq >= 64) {                  // make room first (< 64 waiting + 64 appended + 64 re-queued < ring size)
+                        const int back = pf_flush(ring, head, 64, head + nq, lane, etab, cnt, pts, nvalid, thr);
+                        head = (head + 64) & (kPfRing - 1); nq += back - 64;
                     }
                     const int slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(any >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)any, 0u));
                     if (surv) ring[(head + nq + slot) & (kPfRing - 1)] = ((uint32_t)pb << 22) | ((uint32_t)lane << 16) | surv;
@@ -227,8 +271,8 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
             }
             while (nq > 0) {
                 const int m = min(nq, 64);
-                pf_flush(ring, head, m, lane, etab, cnt, pts, nvalid, thr);
-                head = (head + m) & (kPfRing - 1); nq -= m;
+                const int back = pf_flush(ring, head, m, head + nq, lane, etab, cnt, pts, nvalid, thr);
+                head = (head + m) & (kPfRing - 1); nq += back - m;
             }
             // LDS counters -> counts[] (zeroed by the solve kernel); a wavefront's LDS operations complete in order
             if (lane < nvalid) {
@@ -241,11 +285,13 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
 }
 
 // Conditions under which launch_ransac_score may pick this kernel: the unit-z layout (every z exactly 1), a threshold the
-// fp16 scaling covers, and enough hypotheses to fill the chip with 1024-hypothesis block iterations.
+// fp16 scaling covers, and enough work to fill the chip with 1024-hypothesis x 1024-point block iterations (measured
+// crossover against the plain wavefront kernel at 4096 points: between 16k and 32k hypotheses, profiles/r02_prefilter_ab.txt).
 bool prefilter_usable(const sfm_pair *pair, const sfm_ransac_params &p, uint32_t count)
 {
     PfScales sc;
-    return pair->unit_z && count >= 16384u && prefilter_scales(p.threshold, sc);
+    const uint64_t ntiles = (uint64_t)((pair->ld + kPfTile - 1) / kPfTile);
+    return pair->unit_z && count >= 16384u && (uint64_t)count * ntiles >= 131072u && prefilter_scales(p.threshold, sc);
 }
 
 int launch_score_prefilter(sfm_pair *pair, const sfm_ransac_params &p, uint32_t count)
@@ -253,7 +299,11 @@ int launch_score_prefilter(sfm_pair *pair, const sfm_ransac_params &p, uint32_t 
     sfm_ctx *ctx = pair->ctx;
     PfScales sc;
     if (!prefilter_scales(p.threshold, sc)) { set_error("threshold %g outside the pre-filter's range", (double)p.threshold); return SFM_E_INVALID; }
-    const int rc_lds = allow_big_lds(ctx, reinterpret_cast<const void *>(&ransac_score_prefilter));
+    // A/B switch: reserved[0] = 2 -> two pairs per v_pk_fma_f32 ... clamp.  Measured SLOWER (0.789 vs 0.743 ms per 2^20 x 4096):
+    // packed FP32 instructions issued next to MFMAs stall the matrix pipe (MI355X_MICROARCH.md), so the default is one pair per v_fma_f32
+    const bool packed = p.reserved[0] == 2;
+    const int rc_lds = allow_big_lds(ctx, packed ? reinterpret_cast<const void *>(&ransac_score_prefilter<true>)
+                                                 : reinterpret_cast<const void *>(&ransac_score_prefilter<false>));
     if (rc_lds != SFM_OK) return rc_lds;
     const int ntiles = (pair->ld + kPfTile - 1) / kPfTile;
     const uint32_t iters = (count + 64u * kPfWaves - 1) / (64u * kPfWaves);       // 1024-hypothesis block iterations per tile
@@ -263,9 +313,14 @@ int launch_score_prefilter(sfm_pair *pair, const sfm_ransac_params &p, uint32_t 
     if (p.reserved[2] > 0) cols = (uint32_t)p.reserved[2];
     if (cols > iters) cols = iters;
     if (cols < 1) cols = 1;
-    hipLaunchKernelGGL(ransac_score_prefilter, dim3(cols, ntiles), dim3(kPfWaves * 64), kPfLdsBytes, ctx->stream,
-                       pair->d_X[0], pair->d_X[1], pair->ld, pair->n, pair->d_Ecand, count, p.threshold, sc,
-                       pair->d_counts, pair->d_clk);
+    if (packed)
+        hipLaunchKernelGGL(ransac_score_prefilter<true>, dim3(cols, ntiles), dim3(kPfWaves * 64), kPfLdsBytes, ctx->stream,
+                           pair->d_X[0], pair->d_X[1], pair->ld, pair->n, pair->d_Ecand, count, p.threshold, sc,
+                           pair->d_counts, pair->d_clk);
+    else
+        hipLaunchKernelGGL(ransac_score_prefilter<false>, dim3(cols, ntiles), dim3(kPfWaves * 64), kPfLdsBytes, ctx->stream,
+                           pair->d_X[0], pair->d_X[1], pair->ld, pair->n, pair->d_Ecand, count, p.threshold, sc,
+                           pair->d_counts, pair->d_clk);
     SFM_HIP_TRY(hipGetLastError());
     pair->last_grid = (int)cols * ntiles; pair->last_block = kPfWaves * 64; pair->last_lds = kPfLdsBytes;
     return SFM_OK;

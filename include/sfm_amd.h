@@ -175,7 +175,8 @@ typedef struct sfm_ransac_params {
     int32_t  jacobi_sweeps;   /* null vector of the 8x9 system: 0 (default) = Householder QR of A^T;       */
                               /* k > 0 = normal equations A^T A + k sweeps of 9x9 Jacobi (7 converges)    */
     int32_t  kernel;          /* SFM_KERNEL_*                                                           */
-    int32_t  reserved[4];     /* 0 = defaults.  A/B switches of profiles/: [0] = 1 one hypothesis per lane in the solve kernel;   */
+    int32_t  reserved[4];     /* 0 = defaults.  A/B switches of profiles/: [0] = 1 one hypothesis per lane in the solve kernel,   */
+                              /* = 2 packed FP32 in the pre-filter scan;                                                          */
                               /* [1] = 1 tile loop inside the scoring block instead of the tile-parallel grid (n > 4096);         */
                               /* [2] = k > 0 minimum hypothesis batches per scoring block (default 8; pre-filter: grid columns);   */
                               /* [3] = 1 AUTO never picks SFM_KERNEL_PREFILTER                                                    */

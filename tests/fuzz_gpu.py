@@ -39,13 +39,23 @@ def main():
     def ransac_round():
         n = int(rng.choice([rng.integers(8, 200), rng.integers(200, 3000), rng.integers(3000, 9000)]))
         H = int(rng.choice([rng.integers(1, 64), rng.integers(64, 1500), rng.integers(1500, 6000), rng.integers(6000, 24000)]))
-        kernel = int(rng.choice([S.KERNEL_AUTO, S.KERNEL_SPLIT, S.KERNEL_FUSED, S.KERNEL_MFMA]))
+        kernel = int(rng.choice([S.KERNEL_AUTO, S.KERNEL_SPLIT, S.KERNEL_FUSED, S.KERNEL_MFMA, S.KERNEL_PREFILTER, S.KERNEL_PREFILTER]))
         sweeps = int(rng.choice([0, 0, 7, 3]))
         thr = float(np.float32(10.0 ** rng.uniform(-9, -2)))
         flavour = str(rng.choice(["plain", "plain", "clean", "dup", "epipole", "genericz", "huge", "nan"]))
+        if kernel == S.KERNEL_PREFILTER:              # the matrix-core pre-filter needs fillXU points (z == 1): wide / narrow
+            flavour = str(rng.choice(["plain", "clean", "dup", "nan", "forward", "wide"]))       # fields of view, forward motion (epipole in the image)
+            H = int(rng.choice([H, rng.integers(64, 3000)]))
         sseed = int(rng.integers(1, 1 << 30))
         scene = synth.two_view_scene(n, seed=sseed, noise_px=float(rng.choice([0.0, 0.3, 2.0])),
-                                     outlier_frac=float(rng.choice([0.0, 0.3, 0.8])) if flavour != "clean" else 0.0)
+                                     outlier_frac=float(rng.choice([0.0, 0.3, 0.8])) if flavour != "clean" else 0.0,
+                                     focal=float(rng.choice([150.0, 600.0, 9000.0])) if flavour == "wide" else 2360.0)
+        if flavour == "forward":                      # matches that move radially from the principal point: epipoles inside the image,
+            c = np.array([360.0, 288.0]); s1 = scene["sift"]          # some correspondences exactly on it (zero divisors in the residual)
+            d = np.stack([s1["xpos"], s1["ypos"]], 1) - c
+            s1["match_xpos"], s1["match_ypos"] = (c + 1.07 * d).T.astype(np.float32)
+            on = rng.integers(0, n, max(1, n // 40))
+            s1["xpos"][on] = 360.0; s1["ypos"][on] = 288.0; s1["match_xpos"][on] = 360.0; s1["match_ypos"][on] = 288.0
         cfg = dict(path="ransac", n=n, H=H, kernel=kernel, sweeps=sweeps, thr=thr, flavour=flavour, scene_seed=sseed)
         sift = scene["sift"]
         if flavour == "dup":                          # repeated correspondences -> rank-deficient samples

@@ -4,9 +4,41 @@
 // product loads this library; it is not a CPU fallback.
 #include "../../cuda-sfm_amd/csrc/device_math.hpp"
 #include "../../cuda-sfm_amd/csrc/sift_math.hpp"
+#include "../../cuda-sfm_amd/csrc/prefilter_math.hpp"
 #include <string.h>
 
 extern "C" {
+
+// ---- matrix-core pre-filter (prefilter_math.hpp): operands and rule, for tests/test_hostcheck_prefilter.py
+int hc_pf_scales(float thr, int *a, float *sigE, float *sigF, float *sig2a)
+{
+    sfm::PfScales sc{};
+    const bool ok = sfm::prefilter_scales(thr, sc);
+    *a = sc.a; *sigE = sc.sigE; *sigF = sc.sigF; *sig2a = sc.sig2a;
+    return ok ? 1 : 0;
+}
+
+// coefficient slots of one hypothesis as floats (the fp16 values, widened); returns tmin
+float hc_pf_hyp_slots(const float *e, float thr, float B, float *ns /*32*/, float *ts /*16*/)
+{
+    sfm::PfScales sc{};
+    if (!sfm::prefilter_scales(thr, sc)) return -1.0f;
+    _Float16 n16[sfm::kPfSlots], t16[sfm::kPfSlotsT];
+    const float tmin = sfm::prefilter_hyp_slots(e, thr, B, sc, n16, t16);
+    for (int k = 0; k < sfm::kPfSlots; ++k) ns[k] = (float)n16[k];
+    for (int k = 0; k < sfm::kPfSlotsT; ++k) ts[k] = (float)t16[k];
+    return tmin;
+}
+
+void hc_pf_point_slots(float u, float v, float x, float y, int real, float *bn /*32*/, float *bt /*16*/)
+{
+    _Float16 n16[sfm::kPfSlots], t16[sfm::kPfSlotsT];
+    sfm::prefilter_point_slots(u, v, x, y, real != 0, n16, t16);
+    for (int k = 0; k < sfm::kPfSlots; ++k) bn[k] = (float)n16[k];
+    for (int k = 0; k < sfm::kPfSlotsT; ++k) bt[k] = (float)t16[k];
+}
+
+int hc_pf_reject(float nt, float G, float tminw_scaled) { return sfm::prefilter_reject(nt, G, tminw_scaled) ? 1 : 0; }
 
 void hc_sample8(uint32_t seed, uint32_t hyp, int n, int *idx) { sfm::sample8(seed, hyp, n, idx); }
 

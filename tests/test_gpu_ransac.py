@@ -232,7 +232,7 @@ def test_many_hypotheses_oversubscribed_grid(gpu, n, H):
     several batches over its staged tile; with n > 4096 also over several tiles): every count against the oracle."""
     scene = synth.two_view_scene(n, seed=300 + n)
     pair, _ = make_pair(S, gpu, scene)
-    p = S.default_params(n, num_hypotheses=H, seed=12)
+    p = S.default_params(n, num_hypotheses=H, seed=12, kernel=S.KERNEL_SPLIT)
     pair.estimateE(p)
     assert pair.last_launch()["grid"] > 512
     _, _, X0, X1 = oracle_xu(scene)
@@ -294,16 +294,16 @@ def _oracle_sample_check(X0, X1, p, counts, hyps, n, base=0):
 
 
 def test_c4_full_size_single_gpu(gpu):
-    """BASELINE configs[3] on ONE GPU: 16384 matches x 2^20 hypotheses (four 4096-point tiles -> tile-parallel grid,
-    partial counts through integer atomics, keys from ransac_argmax_counts).  The oracle needs ~1.5 ms per hypothesis at
-    this size, so: sampled counts against the oracle, winner = first arg-max of ALL counts, mask sum = count, and the
-    tile loop inside the block (reserved[1] = 1, the pre-round-2 arrangement) gives the same counts and key."""
+    """BASELINE configs[3] on ONE GPU: 16384 matches x 2^20 hypotheses.  The oracle needs ~1.5 ms per hypothesis at this
+    size, so: sampled counts against the oracle, winner = first arg-max of ALL counts, mask sum = count, and all three
+    scoring arrangements (matrix-core pre-filter = AUTO; plain wavefront kernel with the tile-parallel grid; the same with
+    the tile loop inside the block, the pre-round-2 arrangement) give the same 2^20 counts and the same key."""
     n, H = 16384, 1 << 20
     scene = synth.two_view_scene(n)
     pair, _ = make_pair(S, gpu, scene)
     p = S.default_params(n, num_hypotheses=H)
     pair.estimateE(p)
-    assert pair.last_launch()["kernel"] == S.KERNEL_SPLIT
+    assert pair.last_launch()["kernel"] == S.KERNEL_PREFILTER          # what AUTO picks at this size (matrix-core pre-filter)
     counts = pair.get_inlier_counts(H).copy()
     key = pair.get_key()
     hyp, cnt = pair.get_best()
@@ -318,10 +318,12 @@ def test_c4_full_size_single_gpu(gpu):
     E = O.hypothesis_E(X0, X1, O.sample8(p.seed, hyp, n), p.jacobi_sweeps)
     assert same_bits(pair.get_E(), E.reshape(3, 3))
     assert np.array_equal(mask, O.count_inliers(E, X0, X1, p.threshold)[1])
-    q = S.default_params(n, num_hypotheses=H)
-    q.reserved[1] = 1
-    pair.estimateE(q)
-    assert np.array_equal(pair.get_inlier_counts(H), counts) and pair.get_key() == key
+    for tile_loop in (0, 1):                                           # the plain wavefront kernel: tile-parallel grid, then the in-block tile loop
+        q = S.default_params(n, num_hypotheses=H, kernel=S.KERNEL_SPLIT)
+        q.reserved[1] = tile_loop
+        pair.estimateE(q)
+        assert pair.last_launch()["kernel"] == S.KERNEL_SPLIT
+        assert np.array_equal(pair.get_inlier_counts(H), counts) and pair.get_key() == key
 
 
 def test_c4_eight_shards_equal_the_single_call(gpu):

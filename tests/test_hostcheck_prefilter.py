@@ -1,0 +1,187 @@
+"""CPU: the matrix-core pre-filter's operands and decision rule (cuda-sfm_amd/csrc/prefilter_math.hpp, compiled as HIP host
+code by tests/hostcheck) against the oracle.  The rule may only REJECT pairs the exact test would not count; here the two
+fp16 contractions are evaluated in float64 and then pushed by the full accumulation-error budget in every direction that
+favours a rejection -- a single rejected oracle inlier fails the test.  (The GPU twin is tests/test_gpu_prefilter.py:
+counts bit for bit.)"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import oracle as O
+from cuda_sfm_amd_synth import synth
+
+LIB = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hostcheck", "libhostcheck.so")
+pytestmark = pytest.mark.skipif(not os.path.exists(LIB), reason="tests/hostcheck not built (make hostcheck)")
+f32p = O.f32p
+ACC = 8 * 2.0 ** -24            # budget per contraction; measured on MI355X: 1.2 * 2^-24 per instruction (profiles/probes/mfma_f16_probe.hip)
+
+
+@pytest.fixture(scope="module")
+def H():
+    h = C.CDLL(LIB)
+    h.hc_pf_scales.argtypes = [C.c_float, C.POINTER(C.c_int), f32p, f32p, f32p]
+    h.hc_pf_hyp_slots.restype = C.c_float
+    h.hc_pf_hyp_slots.argtypes = [f32p, C.c_float, C.c_float, f32p, f32p]
+    h.hc_pf_point_slots.argtypes = [C.c_float] * 4 + [C.c_int, f32p, f32p]
+    h.hc_pf_reject.argtypes = [C.c_float] * 3
+    return h
+
+
+def fp(a):
+    return a.ctypes.data_as(f32p)
+
+
+def scales(H, thr):
+    a = C.c_int(); s = [C.c_float() for _ in range(3)]
+    ok = H.hc_pf_scales(thr, C.byref(a), *[C.byref(x) for x in s])
+    return ok, a.value, [x.value for x in s]
+
+
+def point_slots(H, X0, X1, n_real=None):
+    n = X0.shape[1]
+    Bn = np.zeros((n, 32), np.float32); Bt = np.zeros((n, 16), np.float32)
+    for j in range(n):
+        real = 1 if (n_real is None or j < n_real) else 0
+        H.hc_pf_point_slots(float(X0[0, j]), float(X0[1, j]), float(X1[0, j]), float(X1[1, j]), real, fp(Bn[j]), fp(Bt[j]))
+    return Bn.astype(np.float64), Bt.astype(np.float64)
+
+
+def hyp_slots(H, E, thr, B):
+    e = np.ascontiguousarray(E, np.float32).reshape(9)
+    ns = np.zeros(32, np.float32); ts = np.zeros(16, np.float32)
+    tmin = H.hc_pf_hyp_slots(fp(e), thr, B, fp(ns), fp(ts))
+    return ns.astype(np.float64), ts.astype(np.float64), float(tmin)
+
+
+def rejected(H, ns, ts, tminw_scaled, Bn, Bt):
+    """The rule under the worst accumulation error: returns a bool array, True where ANY admissible perturbation rejects."""
+    nt = Bn @ ns; G = Bt @ ts
+    en = ACC * (np.abs(Bn) @ np.abs(ns)); eg = ACC * (np.abs(Bt) @ np.abs(ts))
+    out = np.zeros(nt.shape, bool)
+    for sn in (1.0, -1.0, 0.0):
+        for sg in (1.0, -1.0, 0.0):
+            n32 = (np.sign(nt) * (np.abs(nt) + sn * en)).astype(np.float32)
+            g32 = (G + sg * eg).astype(np.float32)
+            with np.errstate(invalid="ignore", over="ignore"):
+                w = (n32.astype(np.float64) * n32.astype(np.float64) - np.float64(np.float32(tminw_scaled))).astype(np.float32)   # fma: one rounding
+            w = np.where(np.isnan(w), 0.0, np.clip(w, 0.0, 1.0)).astype(np.float32)
+            out |= g32.view(np.uint32) < w.view(np.uint32)
+    return out
+
+
+def check_scene(H, X0, X1, Es, thr, n_real=None, max_survivors=None):
+    ok, a, (sigE, sigF, sig2a) = scales(H, thr)
+    assert ok
+    n = X0.shape[1] if n_real is None else n_real
+    with np.errstate(invalid="ignore"):
+        c = np.abs(np.concatenate([X0[:2, :n].ravel(), X1[:2, :n].ravel()]))
+        B = float(np.max(c[c <= 48.0], initial=0.0))
+    Bn, Bt = point_slots(H, X0, X1, n_real)
+    surv = 0
+    prepared = [hyp_slots(H, E, thr, B) for E in Es]
+    for w0 in range(0, len(Es), 32):
+        grp = prepared[w0:w0 + 32]
+        tminw_scaled = max(g[2] for g in grp) * sig2a               # what the wavefront of these 32 rows uses
+        for E, (ns, ts, tmin) in zip(Es[w0:w0 + 32], grp):
+            rej = rejected(H, ns, ts, tminw_scaled, Bn, Bt)
+            _, mask = O.count_inliers(np.ascontiguousarray(E, np.float32).reshape(3, 3), X0[:, :n], X1[:, :n], thr)
+            inl = np.zeros(rej.shape, bool); inl[:n] = mask.astype(bool)
+            assert not (rej & inl).any(), f"rejected {int((rej & inl).sum())} oracle inliers"
+            if n_real is not None:
+                assert rej[n:].all(), "padding must always be rejected"
+            surv += int((~rej[:n]).sum())
+    rate = surv / (len(Es) * n)
+    if max_survivors is not None:
+        assert rate < max_survivors, f"survivor rate {rate:.4f}"
+    return rate
+
+
+@pytest.mark.parametrize("thr", [1e-8, 1e-6, 1e-4, 1e-3])
+@pytest.mark.parametrize("focal", [600.0, 2360.0])
+def test_no_oracle_inlier_is_rejected(H, thr, focal):
+    n = 1024
+    sc = synth.two_view_scene(n, seed=7, focal=focal)
+    _, _, X0, X1 = O.fill_xu(sc["sift"], sc["Kinv"])
+    Es = [O.hypothesis_E(X0, X1, O.sample8(99, h, n), 0) for h in range(96)]
+    rate = check_scene(H, X0, X1, Es, np.float32(thr))
+    if thr == 1e-6 and focal == 2360.0:
+        assert rate < 0.03                                          # and it still filters: ~1 % survive at the reference threshold
+
+
+def test_padding_and_ragged_tile(H):
+    n = 300
+    sc = synth.two_view_scene(384, seed=3)
+    _, _, X0, X1 = O.fill_xu(sc["sift"], sc["Kinv"])
+    X0[:, n:] = np.nan; X1[:, n:] = np.nan                          # what the tail of a padded row looks like
+    Es = [O.hypothesis_E(X0[:, :n], X1[:, :n], O.sample8(5, h, n), 0) for h in range(40)]
+    check_scene(H, X0, X1, Es, np.float32(1e-6), n_real=n)
+
+
+def test_zero_divisor_pairs_survive(H):
+    """da_c == 0 zeroes the first term of the residual (the reference's element_wise_div guard): forward motion with a
+    correspondence whose x2 sits exactly on the epipole has r = n^2 / db, possibly an inlier, although n^2 / da is 'infinite'."""
+    E = np.array([[0, -1, 0], [1, 0, 0], [0, 0, 0]], np.float32)            # t = (0, 0, 1), R = I; singular values (1, 1, 0)
+    rng = np.random.default_rng(0)
+    n = 64
+    X0 = np.ones((3, n), np.float32); X1 = np.ones((3, n), np.float32)
+    X0[:2] = rng.uniform(-0.3, 0.3, (2, n)).astype(np.float32)
+    X1[:2] = (X0[:2] * np.float32(1.05)).astype(np.float32)                  # forward motion: points move radially -> inliers
+    X1[:2, 0] = 0.0                                                          # x2 on the epipole: a0 = a1 = 0 exactly
+    X1[:2, 1] = 0.0; X0[:2, 1] = 0.0                                         # both epipoles: da = db = 0, r = 0
+    X1[:2, 2] = np.float32(1e-30)                                            # da underflows
+    cnt, mask = O.count_inliers(E, X0, X1, np.float32(1e-6))
+    assert mask[0] == 1 and mask[1] == 1
+    check_scene(H, X0, X1, [E, -E, (E * np.float32(0.5)).astype(np.float32)], np.float32(1e-6))
+    # the same with n != 0: rows 0 and 1 parallel (rank 2), x2 orthogonal to them but not to row 2 -> a0 = a1 = 0 exactly,
+    # n = a2 = x2y, r = n^2 / db: an inlier for |x2y| < 1e-3 that the one-sided bound n^2 / da = inf would throw away
+    E2 = np.array([[1, 0, -0.125], [2, 0, -0.25], [0, 1, 0]], np.float32)
+    Y0 = np.ones((3, 8), np.float32); Y1 = np.ones((3, 8), np.float32)
+    Y0[:2] = rng.uniform(-0.3, 0.3, (2, 8)).astype(np.float32)
+    Y1[0] = 0.125
+    Y1[1] = np.array([5e-4, -9e-4, 2e-3, 0.0, 1e-5, 0.3, -0.3, 9.9e-4], np.float32)
+    cnt, mask = O.count_inliers(E2, Y0, Y1, np.float32(1e-6))
+    assert mask[0] == 1 and mask[1] == 1 and mask[2] == 0 and mask[5] == 0
+    check_scene(H, Y0, Y1, [E2], np.float32(1e-6))
+    # the test is live: without the zero-divisor guard (G pushed positive) the rule WOULD reject those inliers
+    ns, ts, tmin = hyp_slots(H, E2, np.float32(1e-6), 0.3)
+    Bn, Bt = point_slots(H, Y0, Y1)
+    ts_bad = ts.copy(); ts_bad[15] += 1e-3
+    assert rejected(H, ts=ts_bad, ns=ns, tminw_scaled=tmin * scales(H, 1e-6)[2][2], Bn=Bn, Bt=Bt)[:2].all()
+
+
+def test_degenerate_hypotheses_and_points(H):
+    sc = synth.two_view_scene(256, seed=11)
+    _, _, X0, X1 = O.fill_xu(sc["sift"], sc["Kinv"])
+    X0 = X0.copy(); X1 = X1.copy()
+    X1[0, 5] = np.nan; X0[1, 6] = np.inf; X1[0, 7] = 100.0; X0[0, 8] = -60.0          # non-finite / beyond the fp16 feature range
+    good = O.hypothesis_E(X0, X1, O.sample8(1, 3, 256), 0)
+    Es = [np.zeros((3, 3), np.float32),                                                # E = 0: every finite pair has r = 0 -> inlier
+          np.full((3, 3), np.nan, np.float32), good * np.float32(3.0),                 # non-finite, and entries above the tame bound
+          good, np.diag([1, 1, 0]).astype(np.float32), np.array([[0, 0, 0], [0, 0, -1], [0, 1, 0]], np.float32)]
+    with np.errstate(invalid="ignore"):
+        check_scene(H, X0, X1, Es, np.float32(1e-6))
+
+
+def test_random_matrices_and_scales(H):
+    rng = np.random.default_rng(5)
+    n = 512
+    for scale in (0.05, 0.5, 3.0, 20.0):
+        X0 = np.ones((3, n), np.float32); X1 = np.ones((3, n), np.float32)
+        X0[:2] = (scale * rng.uniform(-1, 1, (2, n))).astype(np.float32)
+        X1[:2] = (X0[:2] + 0.02 * scale * rng.normal(size=(2, n))).astype(np.float32)
+        Es = []
+        for _ in range(24):
+            M = rng.normal(size=(3, 3)) * rng.choice([1e-3, 0.1, 1.0], size=(3, 3))
+            M /= max(1e-9, np.abs(M).max())
+            Es.append((M * rng.uniform(0.2, 1.9)).astype(np.float32))
+        for thr in (1e-7, 1e-5, 1e-3):
+            t = np.float32(min(max(thr * scale * scale, 1e-9), 1e-2))            # inside the range the fp16 scaling covers
+            check_scene(H, X0, X1, Es, t)
+
+
+def test_threshold_range(H):
+    for thr, ok in ((1e-10, 0), (1e-9, 1), (1e-6, 1), (1e-2, 1), (0.02, 0), (float("nan"), 0)):
+        assert scales(H, thr)[0] == ok
+    assert scales(H, 1e-6)[1] == 7 and scales(H, 1e-6)[2] == [8.0, 16.0, 16384.0]
