@@ -393,7 +393,7 @@ int sfm_pair_destroy(sfm_pair *p)
     if (!p) return SFM_OK;
     if (p->ctx) { (void)hipSetDevice(p->ctx->device); (void)hipStreamSynchronize(p->ctx->stream); }
     void *bufs[] = { p->d_K, p->d_Kinv, p->d_U[0], p->d_U[1], p->d_X[0], p->d_X[1], p->d_E, p->d_P, p->d_Pinv, p->d_Pind,
-                     p->d_points, p->d_mask, p->d_key, p->d_best, p->d_counts, p->d_Ecand, p->d_clk };
+                     p->d_points, p->d_mask, p->d_key, p->d_best, p->d_counts, p->d_Ecand, p->d_clk, p->d_tick };
     for (void *b : bufs) if (b) (void)hipFree(b);
     delete p;
     return SFM_OK;

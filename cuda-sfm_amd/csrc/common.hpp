@@ -90,6 +90,7 @@ struct sfm_pair {
     unsigned long long *d_clk = nullptr;   // [0] shader-clock ticks, [1] 100 MHz ticks over block 0 of the last ransac_score_waves launch
     // per-shard buffers, grown on demand
     int   *d_counts = nullptr;
+    uint32_t *d_tick = nullptr;        // pre-filter kernel: per 64-hypothesis group, how many tiles have been added
     float *d_Ecand = nullptr;
     size_t cap_hyps = 0;
     uint32_t last_count = 0;           // hyp_count of the last score call
@@ -113,13 +114,13 @@ int launch_ransac_finalize(sfm_pair *pair, const sfm_ransac_params &p, const uns
 int launch_permutation_indices(sfm_ctx *ctx, int n, uint32_t seed, int32_t *d_indices);
 // ransac_prefilter.hip
 bool prefilter_usable(const sfm_pair *pair, const sfm_ransac_params &p, uint32_t count);
-int launch_score_prefilter(sfm_pair *pair, const sfm_ransac_params &p, uint32_t count);
+int launch_score_prefilter(sfm_pair *pair, const sfm_ransac_params &p, uint32_t h0, uint32_t count, unsigned long long *key2);
 // ransac_mfma.hip
 int launch_score_mfma(sfm_pair *pair, const sfm_ransac_params &p, uint32_t h0, uint32_t count);
 // ransac_fused.hip
 int launch_ransac_fused(sfm_pair *pair, const sfm_ransac_params &p, uint32_t h0, uint32_t count);
-int launch_finalize_E_wave(sfm_pair *pair, const sfm_ransac_params &p, const unsigned long long *d_key, uint32_t hyp_host, bool from_key,
-                           hipStream_t stream, bool rederive);
+int launch_finalize_block(sfm_pair *pair, const sfm_ransac_params &p, const unsigned long long *d_key, uint32_t hyp_host, bool from_key,
+                          hipStream_t stream, bool rederive);
 
 // pose.hip
 int launch_fill_xu(sfm_pair *pair, const sfm_sift_point *d_data);

@@ -39,10 +39,11 @@ __global__ __launch_bounds__(64)
 void ransac_solve_lanes(const float *__restrict__ X0, const float *__restrict__ X1, int ld, int n,
                         const int32_t *__restrict__ indices, uint32_t seed, uint32_t h0, uint32_t count,
                         int sweeps, float *__restrict__ Ecand, unsigned long long *zero_key, unsigned long long *zero_key2,
-                        int *__restrict__ zero_counts)
+                        int *__restrict__ zero_counts, uint32_t *__restrict__ zero_ticks)
 {
     reset_keys(zero_key, zero_key2);
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (zero_ticks && i < (count + 63u) / 64u) zero_ticks[i] = 0u;
     if (i >= count) return;
     if (zero_counts) zero_counts[i] = 0;                    // tile-parallel scoring accumulates into counts[] with atomics
     float E[9];
@@ -57,10 +58,11 @@ __global__ __launch_bounds__(64)
 void ransac_solve_lanes2(const float *__restrict__ X0, const float *__restrict__ X1, int ld, int n,
                          const int32_t *__restrict__ indices, uint32_t seed, uint32_t h0, uint32_t count,
                          int sweeps, float *__restrict__ Ecand, unsigned long long *zero_key, unsigned long long *zero_key2,
-                         int *__restrict__ zero_counts)
+                         int *__restrict__ zero_counts, uint32_t *__restrict__ zero_ticks)
 {
     reset_keys(zero_key, zero_key2);
     const uint32_t i = 2u * (blockIdx.x * blockDim.x + threadIdx.x);
+    if (zero_ticks && (i >> 1) < (count + 63u) / 64u) zero_ticks[i >> 1] = 0u;          // the pre-filter kernel's per-group tickets
     if (i >= count) return;
     const uint32_t j = (i + 1 < count) ? i + 1 : i;         // odd count: the last lane solves its hypothesis twice
     if (zero_counts) { zero_counts[i] = 0; zero_counts[j] = 0; }   // tile-parallel scoring accumulates into counts[] with atomics
@@ -216,30 +218,6 @@ void ransac_argmax_counts(const int *__restrict__ counts, uint32_t h0, uint32_t 
 }
 
 // ------------------------------------------------------------------------------------------
-// finalize: winner's E (recomputed from the hypothesis id -> bit-identical on every rank),
-// inlier mask and count.  Replaces thrust::max_element + the 9-float D2D copy (sfm.cu:135-140).
-// ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256)
-void ransac_finalize_mask(const float *__restrict__ X0, const float *__restrict__ X1, int ld, int n,
-                          const float *__restrict__ Eptr, float thr, uint8_t *__restrict__ mask,
-                          uint32_t *__restrict__ best_out)
-{
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    const Ess E{ Eptr[0], Eptr[1], Eptr[2], Eptr[3], Eptr[4], Eptr[5], Eptr[6], Eptr[7], Eptr[8] };
-    bool in = false;
-    if (best_out[0] == 0xFFFFFFFFu) {                      // no winner (ransac_finalize_E_wave): empty mask, count stays 0
-        if (j < n) mask[j] = 0;
-    } else if (j < n) {
-        const float r = residual(E, X0[j], X0[(size_t)ld + j], X0[2 * (size_t)ld + j],
-                                 X1[j], X1[(size_t)ld + j], X1[2 * (size_t)ld + j]);
-        in = r < thr;
-        mask[j] = in ? 1 : 0;
-    }
-    const int c = __builtin_popcountll(__ballot(in));
-    if ((threadIdx.x & 63) == 0 && c) atomicAdd(&best_out[1], (uint32_t)c);
-}
-
-// ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
 static int ensure_hyp_capacity(sfm_pair *pair, size_t count)
@@ -248,7 +226,9 @@ static int ensure_hyp_capacity(sfm_pair *pair, size_t count)
     SFM_HIP_TRY(hipStreamSynchronize(pair->ctx->stream));
     if (pair->d_counts) (void)hipFree(pair->d_counts);
     if (pair->d_Ecand) (void)hipFree(pair->d_Ecand);
-    pair->d_counts = nullptr; pair->d_Ecand = nullptr; pair->cap_hyps = 0;
+    if (pair->d_tick) (void)hipFree(pair->d_tick);
+    pair->d_counts = nullptr; pair->d_Ecand = nullptr; pair->d_tick = nullptr; pair->cap_hyps = 0;
+    SFM_HIP_TRY(hipMalloc(&pair->d_tick, (count / 64 + 2) * sizeof(uint32_t)));
     SFM_HIP_TRY(hipMalloc(&pair->d_counts, count * sizeof(int)));
     SFM_HIP_TRY(hipMalloc(&pair->d_Ecand, count * 9 * sizeof(float)));
     pair->cap_hyps = count;
@@ -333,15 +313,15 @@ int launch_ransac_score(sfm_pair *pair, const sfm_ransac_params &p, uint32_t h0,
     if (p.reserved[0] == 1)          // A/B switch: one hypothesis per lane (scalar math)
         hipLaunchKernelGGL(ransac_solve_lanes, dim3((count + 63) / 64), dim3(64), 0, ctx->stream,
                            pair->d_X[0], pair->d_X[1], pair->ld, pair->n, p.d_indices, p.seed, h0, count,
-                           p.jacobi_sweeps, pair->d_Ecand, pair->d_key, key2, zero_counts);
+                           p.jacobi_sweeps, pair->d_Ecand, pair->d_key, key2, zero_counts, prefilter ? pair->d_tick : nullptr);
     else if (p.jacobi_sweeps <= 0)   // default: two hypotheses per lane (packed math), Householder instantiation
         hipLaunchKernelGGL(ransac_solve_lanes2<true>, dim3((count + 127) / 128), dim3(64), 0, ctx->stream,
                            pair->d_X[0], pair->d_X[1], pair->ld, pair->n, p.d_indices, p.seed, h0, count,
-                           p.jacobi_sweeps, pair->d_Ecand, pair->d_key, key2, zero_counts);
+                           p.jacobi_sweeps, pair->d_Ecand, pair->d_key, key2, zero_counts, prefilter ? pair->d_tick : nullptr);
     else
         hipLaunchKernelGGL(ransac_solve_lanes2<false>, dim3((count + 127) / 128), dim3(64), 0, ctx->stream,
                            pair->d_X[0], pair->d_X[1], pair->ld, pair->n, p.d_indices, p.seed, h0, count,
-                           p.jacobi_sweeps, pair->d_Ecand, pair->d_key, key2, zero_counts);
+                           p.jacobi_sweeps, pair->d_Ecand, pair->d_key, key2, zero_counts, prefilter ? pair->d_tick : nullptr);
     SFM_HIP_TRY(hipGetLastError());
     if (timed) SFM_HIP_TRY(hipEventRecord(tev[1], ctx->stream));
 
@@ -365,13 +345,7 @@ int launch_ransac_score(sfm_pair *pair, const sfm_ransac_params &p, uint32_t h0,
         if ((uint32_t)grid > nbatch) grid = (int)nbatch;
     }
     if (prefilter) {
-        rc = launch_score_prefilter(pair, p, count);
-        if (rc == SFM_OK) {
-            const int ablocks = (int)((count + 4095u) / 4096u);
-            hipLaunchKernelGGL(ransac_argmax_counts, dim3(ablocks < 1024 ? ablocks : 1024), dim3(256), 0, ctx->stream,
-                               pair->d_counts, h0, count, pair->d_key, key2);
-            SFM_HIP_TRY(hipGetLastError());
-        }
+        rc = launch_score_prefilter(pair, p, h0, count, key2);      // arg-max included (per-group tickets)
     }
     else if (kernel == SFM_KERNEL_MFMA) {
         rc = launch_score_mfma(pair, p, h0, count);
@@ -407,12 +381,10 @@ int launch_ransac_finalize(sfm_pair *pair, const sfm_ransac_params &p, const uns
 {
     sfm_ctx *ctx = pair->ctx;
     if (!stream) stream = ctx->stream;
-    int rc = launch_finalize_E_wave(pair, p, d_key, hyp_host, from_key, stream, rederive);      // ransac_fused.hip
-    if (rc != SFM_OK) return rc;
-    hipLaunchKernelGGL(ransac_finalize_mask, dim3((pair->n + 255) / 256), dim3(256), 0, stream,
-                       pair->d_X[0], pair->d_X[1], pair->ld, pair->n, pair->d_E, p.threshold, pair->d_mask, pair->d_best);
-    SFM_HIP_TRY(hipGetLastError());
-    return SFM_OK;
+    (void)ctx;
+    // winner's E (taken from the candidates or re-derived from the hypothesis id: bit-identical on every rank), inlier
+    // mask and count: replaces thrust::max_element + the 9-float D2D copy (sfm.cu:135-140).  One launch (ransac_fused.hip).
+    return launch_finalize_block(pair, p, d_key, hyp_host, from_key, stream, rederive);
 }
 
 // Reference-mode tuples (sfm.cu:97-106, kernels.h:247): disjoint consecutive slices of one

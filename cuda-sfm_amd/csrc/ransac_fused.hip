@@ -247,44 +247,70 @@ void ransac_fused_waves(const float *__restrict__ X0, const float *__restrict__ 
     }
 }
 
-// Winner's E, one wavefront.  When the winner belongs to the shard this rank just scored, its E is
-// already in Ecand (same bits); otherwise (multi-GPU: another rank owns it) it is re-derived from the
-// hypothesis id with the wave-cooperative solver.
-__global__ __launch_bounds__(64)
-void ransac_finalize_E_wave(const float *__restrict__ X0, const float *__restrict__ X1, int ld, int n,
-                            const int32_t *__restrict__ indices, uint32_t seed, int sweeps,
-                            const unsigned long long *__restrict__ key, uint32_t hyp_host, int from_key,
-                            const float *__restrict__ Ecand, uint32_t h0, uint32_t count, uint32_t num_hypotheses,
-                            float *__restrict__ E_out, uint32_t *__restrict__ best_out)
+// Winner's E, inlier mask and count in ONE launch of one 1024-thread block (the two launches it replaces cost ~14 us of a
+// 180 us multi-GPU step, most of it the gap between them).  Wavefront 0: when the winner belongs to the shard this rank
+// just scored, its E is already in Ecand (same bits); otherwise (multi-GPU: another rank owns it) it is re-derived from
+// the hypothesis id with the wave-cooperative solver.  Then every thread walks the points (n / 1024 iterations).
+__global__ __launch_bounds__(1024)
+void ransac_finalize_block(const float *__restrict__ X0, const float *__restrict__ X1, int ld, int n,
+                           const int32_t *__restrict__ indices, uint32_t seed, int sweeps,
+                           const unsigned long long *__restrict__ key, uint32_t hyp_host, int from_key,
+                           const float *__restrict__ Ecand, uint32_t h0, uint32_t count, uint32_t num_hypotheses,
+                           float thr, float *__restrict__ E_out, uint8_t *__restrict__ mask, uint32_t *__restrict__ best_out)
 {
     __shared__ __attribute__((aligned(16))) float ws[kWaveScratch];
     __shared__ uint2 sched[9][64];
+    __shared__ float sE[9];
+    __shared__ int scount[16];
     uint32_t hyp = hyp_host;
     if (from_key) hyp = 0xFFFFFFFFu - (uint32_t)(key[0] & 0xFFFFFFFFull);
     hyp = __builtin_amdgcn_readfirstlane(hyp);
     if (hyp >= num_hypotheses) {
         // no winner: a key of 0 (every shard empty), an uninitialised caller buffer or a failed all-reduce.  Defined
-        // result instead of reading the tuple table out of bounds: E = 0, best = {0xFFFFFFFF, 0}; the mask kernel
-        // sees the sentinel and clears the mask, sfm_get_best / sfm_get_result report SFM_E_STATE.
+        // result instead of reading the tuple table out of bounds: E = 0, empty mask, best = {0xFFFFFFFF, 0};
+        // sfm_get_best / sfm_get_result report SFM_E_STATE.
         if (threadIdx.x < 9) E_out[threadIdx.x] = 0.0f;
         if (threadIdx.x == 0) { best_out[0] = 0xFFFFFFFFu; best_out[1] = 0; }
+        for (int j = threadIdx.x; j < n; j += blockDim.x) mask[j] = 0;
         return;
     }
-    if (Ecand && hyp >= h0 && hyp - h0 < count) {
-        if (threadIdx.x < 9) E_out[threadIdx.x] = Ecand[9 * (size_t)(hyp - h0) + threadIdx.x];
-    } else {
-        float E[9];
-        build_jacobi_schedule(sched, threadIdx.x);
-        wave_sync();
-        solve_wave(X0, X1, ld, n, indices, seed, hyp, sweeps, ws, sched, threadIdx.x, E);
-        if (threadIdx.x == 0) {
+    if (threadIdx.x < 64) {
+        if (Ecand && hyp >= h0 && hyp - h0 < count) {
+            if (threadIdx.x < 9) sE[threadIdx.x] = Ecand[9 * (size_t)(hyp - h0) + threadIdx.x];
+        } else {
+            float E[9];
+            build_jacobi_schedule(sched, threadIdx.x);
+            wave_sync();
+            solve_wave(X0, X1, ld, n, indices, seed, hyp, sweeps, ws, sched, threadIdx.x, E);
+            if (threadIdx.x == 0) {
 #pragma unroll
-            for (int k = 0; k < 9; ++k) E_out[k] = E[k];
+                for (int k = 0; k < 9; ++k) sE[k] = E[k];
+            }
         }
     }
+    __syncthreads();
+    if (threadIdx.x < 9) E_out[threadIdx.x] = sE[threadIdx.x];
+    const Ess E{ sE[0], sE[1], sE[2], sE[3], sE[4], sE[5], sE[6], sE[7], sE[8] };
+    int c = 0;
+    for (int j0 = 0; j0 < n; j0 += blockDim.x) {
+        const int j = j0 + threadIdx.x;
+        bool in = false;
+        if (j < n) {
+            const float r = residual(E, X0[j], X0[(size_t)ld + j], X0[2 * (size_t)ld + j],
+                                     X1[j], X1[(size_t)ld + j], X1[2 * (size_t)ld + j]);
+            in = r < thr;
+            mask[j] = in ? 1 : 0;
+        }
+        c += __builtin_popcountll(__ballot(in));
+    }
+    if ((threadIdx.x & 63) == 0) scount[threadIdx.x >> 6] = c;
+    __syncthreads();
     if (threadIdx.x == 0) {
+        int total = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) total += scount[w];
         best_out[0] = hyp;
-        best_out[1] = 0;        // filled by ransac_finalize_mask
+        best_out[1] = (uint32_t)total;
     }
 }
 
@@ -325,17 +351,18 @@ int launch_ransac_fused(sfm_pair *pair, const sfm_ransac_params &p, uint32_t h0,
     return rc;
 }
 
-int launch_finalize_E_wave(sfm_pair *pair, const sfm_ransac_params &p, const unsigned long long *d_key,
-                           uint32_t hyp_host, bool from_key, hipStream_t stream, bool rederive)
+int launch_finalize_block(sfm_pair *pair, const sfm_ransac_params &p, const unsigned long long *d_key,
+                          uint32_t hyp_host, bool from_key, hipStream_t stream, bool rederive)
 {
     // Ecand is only trusted when it was produced by a score call with the same sampler settings (and when the caller
     // does not overlap this finalize with the next score call, which rewrites it: rederive)
     const bool cand_ok = !rederive && pair->last_count > 0 && pair->cand_seed == p.seed && pair->cand_indices == p.d_indices &&
                          pair->cand_sweeps == p.jacobi_sweeps;
-    hipLaunchKernelGGL(ransac_finalize_E_wave, dim3(1), dim3(64), 0, stream,
+    hipLaunchKernelGGL(ransac_finalize_block, dim3(1), dim3(1024), 0, stream,
                        pair->d_X[0], pair->d_X[1], pair->ld, pair->n, p.d_indices, p.seed, p.jacobi_sweeps,
                        d_key, hyp_host, from_key ? 1 : 0,
-                       cand_ok ? pair->d_Ecand : nullptr, pair->cand_h0, pair->last_count, p.num_hypotheses, pair->d_E, pair->d_best);
+                       cand_ok ? pair->d_Ecand : nullptr, pair->cand_h0, pair->last_count, p.num_hypotheses,
+                       p.threshold, pair->d_E, pair->d_mask, pair->d_best);
     SFM_HIP_TRY(hipGetLastError());
     return SFM_OK;
 }

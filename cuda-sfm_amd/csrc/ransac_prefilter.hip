@@ -14,7 +14,8 @@
 // which leaves every lane with a 16-bit "rejected" mask of its 16 pairs.  Lanes with a surviving pair append one word to
 // the wavefront's ring in LDS; 64 entries at a time go through the exact filter, one entry per lane, and inliers bump the
 // hypothesis' counter in LDS.  Tiles are spread over blockIdx.y; partial counts reach counts[] through integer atomics
-// (order-independent, so the result is deterministic) and ransac_argmax_counts (ransac.hip) builds the keys.
+// (order-independent, so the result is deterministic); the wavefront that adds the last tile of a hypothesis group folds its
+// keys into the shard's arg-max key.
 #include "ransac_device.hpp"
 #include "prefilter_math.hpp"
 
@@ -126,8 +127,9 @@ __device__ __noinline__ int pf_flush(uint32_t *ring, int head, int nent, int tai
 template <bool PACKED>
 __global__ __launch_bounds__(kPfWaves * 64)
 void ransac_score_prefilter(const float *__restrict__ X0, const float *__restrict__ X1, int ld, int n,
-                            const float *__restrict__ Ecand, uint32_t count, float thr, PfScales sc,
-                            int *__restrict__ counts, unsigned long long *__restrict__ clk)
+                            const float *__restrict__ Ecand, uint32_t h0, uint32_t count, float thr, PfScales sc,
+                            int *__restrict__ counts, uint32_t *__restrict__ tick, unsigned long long *best_key,
+                            unsigned long long *best_key2, unsigned long long *__restrict__ clk)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
@@ -280,6 +282,32 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
                 if (c) atomicAdd(&counts[h_first + 32u * blk + lane], c);
             }
         }
+        // arg-max without a kernel of its own: the wavefront that contributes the LAST tile of these 64 hypotheses (ticket)
+        // reads their final counts and folds the best key into the shard's key (first maximum: highest count, lowest id)
+        // Ordering without __threadfence() (an agent-scope release fence writes this XCD's L2 back: 119 -> 190 us per
+        // launch): every datum involved is touched by device-scope atomics only, so it is enough that the count atomics
+        // have been acknowledged (vmcnt, which also tracks atomics without return on gfx9) before the ticket is issued;
+        // the reader's agent-scope atomic loads are issued after its ticket came back.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        uint32_t t = 0;
+        if (lane == 0) t = atomicAdd(&tick[ps], 1u);
+        t = __builtin_amdgcn_readfirstlane(t);
+        if (t == gridDim.y - 1) {
+            unsigned long long k = 0;
+            if (lane < nvalid64) {
+                const int c = __hip_atomic_load(&counts[h_first + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                k = pack_key((uint32_t)c, h0 + h_first + (uint32_t)lane);
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const unsigned long long o = __shfl_xor(k, off);
+                k = o > k ? o : k;
+            }
+            if (lane == 0 && k) {
+                atomicMax(best_key, k);
+                if (best_key2) atomicMax(best_key2, k);
+            }
+        }
     }
     if (probe) { clk[0] = clock64() - c0; clk[1] = wall_clock64() - w0; }
 }
@@ -294,7 +322,7 @@ bool prefilter_usable(const sfm_pair *pair, const sfm_ransac_params &p, uint32_t
     return pair->unit_z && count >= 16384u && (uint64_t)count * ntiles >= 131072u && prefilter_scales(p.threshold, sc);
 }
 
-int launch_score_prefilter(sfm_pair *pair, const sfm_ransac_params &p, uint32_t count)
+int launch_score_prefilter(sfm_pair *pair, const sfm_ransac_params &p, uint32_t h0, uint32_t count, unsigned long long *key2)
 {
     sfm_ctx *ctx = pair->ctx;
     PfScales sc;
@@ -315,12 +343,12 @@ int launch_score_prefilter(sfm_pair *pair, const sfm_ransac_params &p, uint32_t 
     if (cols < 1) cols = 1;
     if (packed)
         hipLaunchKernelGGL(ransac_score_prefilter<true>, dim3(cols, ntiles), dim3(kPfWaves * 64), kPfLdsBytes, ctx->stream,
-                           pair->d_X[0], pair->d_X[1], pair->ld, pair->n, pair->d_Ecand, count, p.threshold, sc,
-                           pair->d_counts, pair->d_clk);
+                           pair->d_X[0], pair->d_X[1], pair->ld, pair->n, pair->d_Ecand, h0, count, p.threshold, sc,
+                           pair->d_counts, pair->d_tick, pair->d_key, key2, pair->d_clk);
     else
         hipLaunchKernelGGL(ransac_score_prefilter<false>, dim3(cols, ntiles), dim3(kPfWaves * 64), kPfLdsBytes, ctx->stream,
-                           pair->d_X[0], pair->d_X[1], pair->ld, pair->n, pair->d_Ecand, count, p.threshold, sc,
-                           pair->d_counts, pair->d_clk);
+                           pair->d_X[0], pair->d_X[1], pair->ld, pair->n, pair->d_Ecand, h0, count, p.threshold, sc,
+                           pair->d_counts, pair->d_tick, pair->d_key, key2, pair->d_clk);
     SFM_HIP_TRY(hipGetLastError());
     pair->last_grid = (int)cols * ntiles; pair->last_block = kPfWaves * 64; pair->last_lds = kPfLdsBytes;
     return SFM_OK;
