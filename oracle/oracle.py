@@ -55,6 +55,10 @@ def _load():
     L.orc_ransac_range.restype = C.c_uint64
     L.orc_ransac_range.argtypes = [f32p, f32p, C.c_int, C.c_uint32, C.c_uint32, i32p, C.c_uint32,
                                    C.c_float, C.c_int, i32p, f32p, C.c_int]
+    L.orc_ransac_range_fast.restype = C.c_uint64
+    L.orc_ransac_range_fast.argtypes = L.orc_ransac_range.argtypes
+    L.orc_count_inliers_fast.restype = C.c_int
+    L.orc_count_inliers_fast.argtypes = [f32p, f32p, f32p, C.c_int, C.c_float]
     L.orc_count_inliers.restype = C.c_int
     L.orc_count_inliers.argtypes = [f32p, f32p, f32p, C.c_int, C.c_float, u8p]
     L.orc_choose_pose.restype = C.c_int
@@ -188,6 +192,28 @@ def ransac_range(X0, X1, h0, count, thr, sweeps, seed=0, indices=None, want_coun
                               _ip(counts) if want_counts else None,
                               _fp(Ec) if want_E else None, nthreads)
     return int(key), counts, Ec
+
+
+def ransac_range_fast(X0, X1, h0, count, thr, sweeps, seed=0, indices=None, want_counts=True,
+                      want_E=False, nthreads=0):
+    """ransac_range through the vectorised scoring loop of sfm_oracle_fast.c (bench.py's cpu_baseline): same results."""
+    X0 = _f32(X0); X1 = _f32(X1)
+    n = X0.shape[1]
+    counts = np.empty(count, np.int32) if want_counts else None
+    Ec = np.empty((count, 9), np.float32) if want_E else None
+    ind = None
+    if indices is not None:
+        indices = np.ascontiguousarray(indices, np.int32)
+        ind = _ip(indices)
+    key = _L.orc_ransac_range_fast(_fp(X0), _fp(X1), n, h0, count, ind, seed, thr, sweeps,
+                                   _ip(counts) if want_counts else None,
+                                   _fp(Ec) if want_E else None, nthreads)
+    return int(key), counts, Ec
+
+
+def count_inliers_fast(E, X0, X1, thr):
+    E = _f32(E).reshape(9); X0 = _f32(X0); X1 = _f32(X1)
+    return int(_L.orc_count_inliers_fast(_fp(E), _fp(X0), _fp(X1), X0.shape[1], thr))
 
 
 def pose_candidates(E, mode=POSE_REFERENCE):

@@ -76,6 +76,11 @@ void orc_hypothesis_E(const float *X0, const float *X1, int n, const int idx[8],
 uint64_t orc_ransac_range(const float *X0, const float *X1, int n,
                           uint32_t h0, uint32_t count, const int *indices, uint32_t seed,
                           float thr, int sweeps, int *counts, float *Ecand, int nthreads);
+/* sfm_oracle_fast.c: the same results through the vectorised division-free filter + exact fallback (cpu_baseline) */
+int  orc_count_inliers_fast(const float E[9], const float *X0, const float *X1, int n, float thr);
+uint64_t orc_ransac_range_fast(const float *X0, const float *X1, int n,
+                               uint32_t h0, uint32_t count, const int *indices, uint32_t seed,
+                               float thr, int sweeps, int *counts, float *Ecand, int nthreads);
 uint64_t orc_pack_key(uint32_t count, uint32_t hyp);
 void     orc_unpack_key(uint64_t key, uint32_t *count, uint32_t *hyp);
 
