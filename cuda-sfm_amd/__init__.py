@@ -56,7 +56,7 @@ EXPORTS = [
     "sfm_pair_device_ptr", "sfm_pair_ld", "sfm_pair_num_points", "sfm_get_XU", "sfm_get_E", "sfm_get_best",
     "sfm_get_key", "sfm_get_inlier_counts", "sfm_get_inlier_mask", "sfm_get_E_candidates",
     "sfm_get_pose_candidates", "sfm_get_pose_inverses", "sfm_get_pose_index", "sfm_get_points", "sfm_copy_points_to_vbo",
-    "sfm_ransac_last_launch", "sfm_ransac_last_clock",
+    "sfm_ransac_last_launch", "sfm_ransac_last_clock", "sfm_process_pairs",
 ]
 
 
@@ -548,47 +548,63 @@ def pair_schedule(num_pairs, rank, world):
     return list(range(int(rank), int(num_pairs), int(world)))
 
 
-def _two_view(ip, d_sift, n, num_hypotheses, pose_mode):
-    """fillXU -> estimateE -> pose candidates -> choosePose -> linear triangulation on a pooled Image_pair -> record."""
-    ip.reset(n)
-    ip.fillXU(d_sift)
-    p = default_params(n) if num_hypotheses is None else default_params(n, num_hypotheses=num_hypotheses)
-    ip.estimateE(p)
-    ip.computePosecandidates(pose_mode)
-    ip.choosePose(pose_mode)
-    ip.linear_triangulation(pose_mode)
-    return ip.get_result()
+class PairDesc(C.Structure):
+    """sfm_pair_desc (include/sfm_amd.h)."""
+    _fields_ = [("d_sift1", C.c_void_p), ("n1", C.c_int), ("d_sift2", C.c_void_p), ("n2", C.c_int)]
+
+
+_lib.sfm_process_pairs.argtypes = [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(PairDesc), C.c_int, C.c_int, C.c_int,
+                                   C.c_uint32, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int)]
+
+
+def process_pairs_local(ctx, descs, K, Kinv, rank=0, world=1, num_hypotheses=None, pose_mode=POSE_REFERENCE):
+    """sfm_process_pairs: the pairs rank, rank + world, ... of `descs` through the C library -- per pair MatchSiftData
+    (when a second view is given), fillXU, estimateE, pose candidates, choosePose, linear triangulation, enqueued back to
+    back, ONE read-back.  descs: sequence of (d_sift1, n1) [already matched] or (d_sift1, n1, d_sift2, n2).
+    Returns (records [owned, 28] float32, status [owned] int32) in list order of the owned pairs."""
+    arr = (PairDesc * max(1, len(descs)))()
+    for i, d in enumerate(descs):
+        arr[i].d_sift1 = _ptr(d[0]); arr[i].n1 = int(d[1])
+        arr[i].d_sift2 = _ptr(d[2]) if len(d) > 2 and d[2] is not None else None
+        arr[i].n2 = int(d[3]) if len(d) > 3 else 0
+    owned = len(range(int(rank), len(descs), int(world)))
+    rec = np.full((max(owned, 1), 28), -1.0, np.float32)
+    status = np.zeros(max(owned, 1), np.int32)
+    k = np.ascontiguousarray(K, np.float32).reshape(9); ki = np.ascontiguousarray(Kinv, np.float32).reshape(9)
+    _check(_lib.sfm_process_pairs(ctx._h, k.ctypes.data_as(C.POINTER(C.c_float)), ki.ctypes.data_as(C.POINTER(C.c_float)), arr, len(descs),
+                                  int(rank), int(world), int(num_hypotheses or 0), int(pose_mode),
+                                  rec.ctypes.data_as(C.POINTER(C.c_float)), status.ctypes.data_as(C.POINTER(C.c_int))), "sfm_process_pairs")
+    return rec[:owned], status[:owned]
 
 
 def process_pairs(ctx, pairs, K, Kinv, rank=0, world=1, num_hypotheses=None, pose_mode=POSE_REFERENCE,
                   all_gather=None, device=None):
     """Task-parallel two-view estimation over many view pairs: each rank runs the whole per-pair
     pipeline (fillXU -> estimateE -> pose candidates -> choosePose -> linear triangulation) for the
-    pairs it owns; NO per-pair collective.  Results are fixed-size records
-    [E(9) | P(16) | pose_index, inliers, best_hypothesis] gathered ONCE at the end.
+    pairs it owns through sfm_process_pairs (C, no per-pair host work); NO per-pair collective.  Results are fixed-size
+    records [E(9) | P(16) | pose_index, inliers, best_hypothesis] gathered ONCE at the end.
 
-    pairs: sequence of (d_sift, n) device SiftPoint arrays (already matched: match_xpos/ypos filled);
+    pairs: sequence of (d_sift, n) device SiftPoint arrays (already matched: match_xpos/ypos filled) or
+    (d_sift1, n1, d_sift2, n2) to have MatchSiftData run first;
     all_gather(local_tensor) -> gathered tensor [world * max_local, RESULT_FLOATS] (torch.distributed
     all_gather_into_tensor over RCCL; identity for world == 1).  Returns {pair_id: record ndarray}.
     """
     import torch
     mine = pair_schedule(len(pairs), rank, world)
     max_local = (len(pairs) + world - 1) // world
-    rec = np.full((max_local, RESULT_FLOATS + 1), -1.0, np.float32)     # last column: pair id (-1 = empty slot)
-    # ONE Image_pair at the largest size, reset per pair (the reference builds one per pair: ~20 allocations each)
-    ip = ImagePair(ctx, K, Kinv, 2, max(pairs[pid][1] for pid in mine)) if mine else None
-    for slot, pid in enumerate(mine):
-        d_sift, n = pairs[pid]
-        rec[slot, :RESULT_FLOATS] = _two_view(ip, d_sift, n, num_hypotheses, pose_mode)
-        rec[slot, 28] = pid
-    if ip is not None:
-        ip.close()
+    rec = np.full((max(max_local, 1), RESULT_FLOATS + 1), -1.0, np.float32)     # last column: pair id (-1 = empty slot)
+    if mine:
+        r, status = process_pairs_local(ctx, pairs, K, Kinv, rank, world, num_hypotheses, pose_mode)
+        for slot, pid in enumerate(mine):
+            if status[slot] == 0 or status[slot] == E_SINGULAR:
+                rec[slot, :RESULT_FLOATS] = r[slot]
+                rec[slot, RESULT_FLOATS] = pid
     local = torch.from_numpy(rec)
     if device is not None:
         local = local.to(device)
     gathered = all_gather(local) if (all_gather is not None and world > 1) else local
     g = gathered.cpu().numpy().reshape(-1, RESULT_FLOATS + 1)
-    return {int(r[28]): r[:RESULT_FLOATS].copy() for r in g if r[28] >= 0}
+    return {int(r[RESULT_FLOATS]): r[:RESULT_FLOATS].copy() for r in g if r[RESULT_FLOATS] >= 0}
 
 
 def ring_pairs(num_views):
@@ -661,17 +677,19 @@ def process_views(ctx, images, K, Kinv, pairs=None, rank=0, world=1, max_pts=819
 
     mine = pair_schedule(len(pairs), rank, world)
     max_local = (len(pairs) + world - 1) // world
-    rec = np.full((max_local, RESULT_FLOATS + 1), -1.0, np.float32)
-    usable = [pid for pid in mine if counts[pairs[pid][0]] >= 8 and counts[pairs[pid][1]] >= 1]
-    ip = ImagePair(ctx, K, Kinv, 2, max(counts[pairs[pid][0]] for pid in usable)) if usable else None
-    for slot, pid in enumerate(usable):
-        i, j = pairs[pid]
+    rec = np.full((max(max_local, 1), RESULT_FLOATS + 1), -1.0, np.float32)
+    # per pair MatchSiftData + the two-view pipeline, all inside sfm_process_pairs (C): MatchSiftData writes its result
+    # fields (score .. match_ypos) straight into the first view's records -- nothing else of a record changes, so no copy
+    descs = []
+    for (i, j) in pairs:
         (s1, n1), (s2, n2) = view(i), view(j)
-        ctx.match(s1, n1, s2, n2)
-        rec[slot, :RESULT_FLOATS] = _two_view(ip, s1, n1, num_hypotheses, pose_mode)
-        rec[slot, RESULT_FLOATS] = pid
-    if ip is not None:
-        ip.close()
+        descs.append((s1, n1, s2, n2))
+    if mine:
+        r, status = process_pairs_local(ctx, descs, K, Kinv, rank, world, num_hypotheses, pose_mode)
+        for slot, pid in enumerate(mine):
+            if status[slot] == 0 or status[slot] == E_SINGULAR:
+                rec[slot, :RESULT_FLOATS] = r[slot]
+                rec[slot, RESULT_FLOATS] = pid
     local = torch.from_numpy(rec).to(dev)
     gathered = gather_results(local) if (gather_results is not None and world > 1) else local
     g = gathered.cpu().numpy().reshape(-1, RESULT_FLOATS + 1)

@@ -89,6 +89,8 @@ int sfm_ctx_destroy(sfm_ctx *ctx)
     if (ctx->homo_ws) (void)hipFree(ctx->homo_ws);
     if (ctx->sift_temp) (void)hipFree(ctx->sift_temp);
     if (ctx->sift_ws) (void)hipFree(ctx->sift_ws);
+    if (ctx->pool_pair) (void)sfm_pair_destroy(ctx->pool_pair);
+    if (ctx->pool_records) (void)hipFree(ctx->pool_records);
     sift_job_free(ctx);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     for (auto &t : ctx->tev) for (hipEvent_t e : t) if (e) (void)hipEventDestroy(e);
@@ -701,6 +703,85 @@ int sfm_copy_points_to_vbo(sfm_pair *pair, float *d_positions, float *d_velociti
     SFM_REQUIRE((((uintptr_t)d_positions | (uintptr_t)d_velocities) & 15u) == 0, SFM_E_INVALID, "vertex buffers must be 16-byte aligned");
     SFM_HIP_TRY(hipSetDevice(pair->ctx->device));
     return launch_points_to_vbo(pair, d_positions, d_velocities, scale);
+}
+
+// ---- many view pairs --------------------------------------------------------------------------------
+int sfm_process_pairs(sfm_ctx *ctx, const float h_K[9], const float h_Kinv[9], const sfm_pair_desc *pairs, int num_pairs,
+                      int first, int stride, uint32_t num_hypotheses, int pose_mode, float *h_records, int *h_status)
+{
+    SFM_REQUIRE(ctx && h_K && h_Kinv && h_records, SFM_E_INVALID, "null argument");
+    SFM_REQUIRE(num_pairs >= 0 && first >= 0 && stride >= 1, SFM_E_INVALID, "bad pair range (%d pairs, first %d, stride %d)", num_pairs, first, stride);
+    SFM_REQUIRE(pose_mode == SFM_POSE_REFERENCE || pose_mode == SFM_POSE_CORRECT, SFM_E_INVALID, "unknown pose mode %d", pose_mode);
+    SFM_REQUIRE(num_pairs == 0 || pairs, SFM_E_INVALID, "null pair list");
+    SFM_HIP_TRY(hipSetDevice(ctx->device));
+    int owned = 0, max_n = 0;
+    for (int i = first; i < num_pairs; i += stride) {
+        SFM_REQUIRE(pairs[i].n1 >= 0 && pairs[i].n2 >= 0, SFM_E_INVALID, "pair %d: negative feature count", i);
+        SFM_REQUIRE(pairs[i].n1 == 0 || pairs[i].d_sift1, SFM_E_INVALID, "pair %d: null feature pointer", i);
+        if (pairs[i].n1 > max_n) max_n = pairs[i].n1;
+        ++owned;
+    }
+    if (owned == 0) return SFM_OK;
+    // ONE pooled Image_pair at the largest size (the reference constructs one per pair: ~20 cudaMalloc / cudaFree each)
+    int rc = SFM_OK;
+    if (max_n >= 8) {
+        if (ctx->pool_pair && (ctx->pool_pair->cap_points < max_n || memcmp(ctx->pool_K, h_K, 36) != 0 || memcmp(ctx->pool_Kinv, h_Kinv, 36) != 0)) {
+            (void)sfm_pair_destroy(ctx->pool_pair);
+            ctx->pool_pair = nullptr;
+        }
+        if (!ctx->pool_pair) {
+            rc = sfm_pair_create(ctx, h_K, h_Kinv, 2, max_n, &ctx->pool_pair);
+            if (rc != SFM_OK) return rc;
+            memcpy(ctx->pool_K, h_K, 36); memcpy(ctx->pool_Kinv, h_Kinv, 36);
+        }
+    }
+    if (ctx->pool_records_cap < (size_t)owned) {
+        SFM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if (ctx->pool_records) (void)hipFree(ctx->pool_records);
+        ctx->pool_records = nullptr; ctx->pool_records_cap = 0;
+        SFM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->pool_records), (size_t)owned * SFM_RECORD_FLOATS * sizeof(float)));
+        ctx->pool_records_cap = (size_t)owned;
+    }
+    sfm_pair *ip = ctx->pool_pair;
+    // per pair: MatchSiftData (optional) -> fillXU -> estimateE -> pose candidates -> choosePose -> linear triangulation
+    // (src/main.cpp:282-307), everything enqueued back to back, no host synchronisation, the record stays on the device
+    int slot = 0;
+    for (int i = first; i < num_pairs; i += stride, ++slot) {
+        const sfm_pair_desc &d = pairs[i];
+        const bool usable = d.n1 >= 8 && (!d.d_sift2 || d.n2 >= 1);
+        if (h_status) h_status[slot] = usable ? SFM_OK : SFM_E_INVALID;
+        if (!usable) continue;
+        if (d.d_sift2) { rc = sfm_match(ctx, d.d_sift1, d.n1, d.d_sift2, d.n2); if (rc != SFM_OK) return rc; }
+        rc = sfm_pair_reset(ip, d.n1);                                  if (rc != SFM_OK) return rc;
+        rc = sfm_fill_xu(ip, d.d_sift1);                                if (rc != SFM_OK) return rc;
+        sfm_ransac_params p;
+        sfm_ransac_default_params(&p, d.n1);
+        if (num_hypotheses) p.num_hypotheses = num_hypotheses;
+        rc = sfm_estimate_E(ip, &p);                                    if (rc != SFM_OK) return rc;
+        rc = sfm_pose_candidates(ip, pose_mode);                        if (rc != SFM_OK) return rc;
+        rc = sfm_choose_pose(ip, pose_mode);                            if (rc != SFM_OK) return rc;
+        rc = sfm_triangulate(ip, pose_mode);                            if (rc != SFM_OK) return rc;
+        rc = launch_pair_record(ip, pose_mode, ctx->pool_records + (size_t)slot * SFM_RECORD_FLOATS);
+        if (rc != SFM_OK) return rc;
+    }
+    // ONE read-back for all pairs of this rank
+    std::vector<float> rec((size_t)owned * SFM_RECORD_FLOATS);
+    SFM_HIP_TRY(hipMemcpyAsync(rec.data(), ctx->pool_records, rec.size() * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    SFM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    slot = 0;
+    int worst = SFM_OK;
+    for (int i = first; i < num_pairs; i += stride, ++slot) {
+        float *out = h_records + (size_t)slot * 28;
+        const bool usable = pairs[i].n1 >= 8 && (!pairs[i].d_sift2 || pairs[i].n2 >= 1);
+        if (!usable) { for (int k = 0; k < 28; ++k) out[k] = -1.0f; continue; }
+        memcpy(out, rec.data() + (size_t)slot * SFM_RECORD_FLOATS, 28 * sizeof(float));
+        if (rec[(size_t)slot * SFM_RECORD_FLOATS + 28] != 0.0f) {
+            if (h_status) h_status[slot] = SFM_E_SINGULAR;
+            set_error("pair %d: chosen pose candidate is singular", i);
+            worst = SFM_E_SINGULAR;
+        }
+    }
+    return h_status ? SFM_OK : worst;
 }
 
 int sfm_ransac_last_clock(sfm_pair *pair, double *shader_mhz)

@@ -48,6 +48,11 @@ struct sfm_ctx {
     size_t sift_temp_bytes = 0;
     void *sift_ws = nullptr;           // counters, candidates, secondary orientations
     size_t sift_ws_bytes = 0;
+    // many-pairs driver (sfm_process_pairs): pooled Image_pair and device-side result records
+    sfm_pair *pool_pair = nullptr;
+    float pool_K[9] = {}, pool_Kinv[9] = {};
+    float *pool_records = nullptr;
+    size_t pool_records_cap = 0;
     void *sift_job = nullptr;          // the extraction in flight (sift.hip: SiftJob), sfm_extract_sift_begin .. _end
     // kernels that already opted in to > 64 KiB of dynamic LDS on THIS context's device (function attributes are
     // per device; a context is used by one host thread at a time, so no process-wide flag)
@@ -129,6 +134,7 @@ int launch_pose_candidates(sfm_pair *pair, int mode);
 int launch_choose_pose(sfm_pair *pair, int mode);
 int launch_triangulate(sfm_pair *pair, int mode);
 int launch_points_to_vbo(sfm_pair *pair, float *d_positions, float *d_velocities, float scale);
+int launch_pair_record(sfm_pair *pair, int mode, float *d_record);
 
 // sift.hip
 void sift_layout(int width, int height, int num_octaves, int scale_up, sfm_sift_layout *L);

@@ -234,6 +234,32 @@ void points_to_vbo_kernel(int n, int ld, const float *__restrict__ pts, float *_
     if (vel) reinterpret_cast<float4 *>(vel)[i] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
 }
 
+// The record a many-pairs driver keeps of one pair (sfm_get_result's layout), assembled on the device so that a batch of
+// pairs needs ONE read-back: [E (9) | chosen pose 4x4 (16) | pose index, inlier count, best hypothesis | singular flag].
+__global__ __launch_bounds__(64)
+void pair_record_kernel(const float *__restrict__ E, const float *__restrict__ P, const float *__restrict__ Pinv,
+                        const int *__restrict__ pind, const uint32_t *__restrict__ best, int mode, float *__restrict__ out)
+{
+    const int t = threadIdx.x;
+    const int raw = pind[0];
+    const int ind = raw >= 0 && raw < 4 ? raw : 0;
+    const float *Pset = (mode == SFM_POSE_REFERENCE) ? Pinv : P;
+    if (t < 9) out[t] = E[t];
+    else if (t < 25) out[t] = Pset[16 * ind + (t - 9)];
+    else if (t == 25) out[25] = (float)raw;
+    else if (t == 26) out[26] = (float)best[1];
+    else if (t == 27) out[27] = (float)best[0];
+    else if (t == 28) out[28] = (pind[5] & (1 << ind)) ? 1.0f : 0.0f;
+}
+
+int launch_pair_record(sfm_pair *pair, int mode, float *d_record)
+{
+    hipLaunchKernelGGL(pair_record_kernel, dim3(1), dim3(64), 0, pair->ctx->stream,
+                       pair->d_E, pair->d_P, pair->d_Pinv, pair->d_Pind, pair->d_best, mode, d_record);
+    SFM_HIP_TRY(hipGetLastError());
+    return SFM_OK;
+}
+
 int launch_points_to_vbo(sfm_pair *pair, float *d_positions, float *d_velocities, float scale)
 {
     hipLaunchKernelGGL(points_to_vbo_kernel, dim3((pair->n + 255) / 256), dim3(256), 0, pair->ctx->stream, pair->n, pair->n, pair->d_points,

@@ -250,6 +250,24 @@ int sfm_get_points(sfm_pair *pair, float *h_points /* 4 x num_points */);
 /* Everything a many-pairs driver keeps of one pair, with ONE synchronisation:
  * [E (9) | chosen pose 4x4 (16): P^-1 in SFM_POSE_REFERENCE, P in SFM_POSE_CORRECT | pose index, inlier count, best hypothesis]. */
 int sfm_get_result(sfm_pair *pair, float h_record[28]);
+/* Many view pairs (BASELINE configs[4]): the per-pair sequence of src/main.cpp:282-307 -- MatchSiftData (when d_sift2 is
+ * given; it fills the match fields of d_sift1's records), fillXU, estimateE (num_hypotheses = 0: the reference's n1 / 8),
+ * computePosecandidates, choosePose, linear_triangulation -- for the pairs first, first + stride, first + 2 stride, ... of
+ * the list (rank r of G owns r, r + G, ...: no per-pair collective), enqueued back to back on the context's stream through
+ * one pooled Image_pair, the result records assembled on the device and read back ONCE at the end.
+ * h_records: 28 floats per owned pair in list order (layout of sfm_get_result; all -1 for a pair with fewer than 8
+ * features); h_status (optional): SFM_OK / SFM_E_INVALID (too few features) / SFM_E_SINGULAR per owned pair -- when it
+ * is NULL a singular pose makes the call return SFM_E_SINGULAR.  Synchronous at the end. */
+typedef struct sfm_pair_desc {
+    sfm_sift_point *d_sift1;        /* features of the first view (match fields are written when d_sift2 != NULL) */
+    int n1;
+    const sfm_sift_point *d_sift2;  /* features of the second view, or NULL when d_sift1 is already matched        */
+    int n2;
+} sfm_pair_desc;
+#define SFM_RECORD_FLOATS 32        /* device-side record stride: 28 floats of sfm_get_result + singular flag + pad */
+int sfm_process_pairs(sfm_ctx *ctx, const float h_K[9], const float h_Kinv[9], const sfm_pair_desc *pairs, int num_pairs,
+                      int first, int stride, uint32_t num_hypotheses, int pose_mode, float *h_records, int *h_status);
+
 /* Image_pair::copyBoidsToVBO (sfm.cu:374-383; kernCopyPositionsToVBO / kernCopyVelocitiesToVBO kernels.h:471-494):
  * interleaved (x, y, z, 1) * scale vertices and the constant (1, 1, 1, 1) colour buffer, written to DEVICE
  * buffers of 4 * num_points floats each (in the reference: the mapped GL buffer objects).  Either may be NULL. */

@@ -99,6 +99,45 @@ def test_dino_ring_of_four_views(gpu):
         assert same_bits(r[:9], Ec[ohyp]) and (int(r[26]), int(r[27])) == (ocnt, ohyp)
 
 
+def test_dino_ring_batched_equals_per_pair(gpu):
+    """sfm_process_pairs (every pair enqueued back to back inside the C library, records assembled on the device, one
+    read-back) against the same pairs taken one at a time through the Image_pair calls: records bit for bit, for both
+    pose modes, a second pass over the pooled Image_pair included; ranks 0 / 1 of 2 split the list without overlap."""
+    torch, dev, ctx = gpu
+    views = [read_pnm_grey(frame(k)) for k in range(4)]
+    h, w = views[0].shape
+    p = (w + 127) // 128 * 128
+    feats = []
+    for v in views:
+        pad = np.zeros((h, p), np.float32); pad[:, :w] = v
+        d_sift = torch.zeros((32768, 576), dtype=torch.uint8, device=dev)
+        n, _ = ctx.extract_sift(d_sift, 32768, torch.from_numpy(pad).to(dev), w, h, p, **DINO_SIFT)
+        feats.append((d_sift, n))
+    ring = S.ring_pairs(4)
+    for mode in (S.POSE_REFERENCE, S.POSE_CORRECT):
+        single = []
+        for (i, j) in ring:                                         # one at a time: match, then the Image_pair sequence
+            (s1, n1), (s2, n2) = feats[i], feats[j]
+            ctx.match(s1, n1, s2, n2)
+            pair = S.ImagePair(ctx, DINO_K, DINO_KINV, 2, n1)
+            pair.fillXU(s1); pair.estimateE(S.default_params(n1))
+            pair.computePosecandidates(mode); pair.choosePose(mode); pair.linear_triangulation(mode)
+            single.append(pair.get_result().copy())
+            pair.close()
+        descs = [(feats[i][0], feats[i][1], feats[j][0], feats[j][1]) for (i, j) in ring]
+        for _ in range(2):
+            rec, status = S.process_pairs_local(ctx, descs, DINO_K, DINO_KINV, pose_mode=mode)
+            assert status.tolist() == [0, 0, 0, 0]
+            for k in range(4):
+                assert same_bits(rec[k], single[k]), f"pair {k} mode {mode}"
+        r0, _ = S.process_pairs_local(ctx, descs, DINO_K, DINO_KINV, rank=0, world=2, pose_mode=mode)
+        r1, _ = S.process_pairs_local(ctx, descs, DINO_K, DINO_KINV, rank=1, world=2, pose_mode=mode)
+        assert same_bits(r0[0], single[0]) and same_bits(r0[1], single[2]) and same_bits(r1[0], single[1]) and same_bits(r1[1], single[3])
+    # a pair with too few features is reported, not run
+    rec, status = S.process_pairs_local(ctx, [(feats[0][0], 5, feats[1][0], feats[1][1]), descs[0]], DINO_K, DINO_KINV, pose_mode=S.POSE_CORRECT)
+    assert status.tolist() == [S.E_INVALID, 0] and (rec[0] == -1).all() and same_bits(rec[1], single[0])
+
+
 def test_dino_main_program(tmp_path):
     """host/sfm_main (src/main.cpp:249-307 re-hosted) on the reference's own two files with its own defaults."""
     app = os.path.join(ROOT, "cuda-sfm_amd", "host", "sfm_main")
