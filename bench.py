@@ -305,17 +305,21 @@ def rank_main(args):
                     "rccl": "ncclAllReduce(max, u64) + finalize on the communicator's exchange stream, overlapped with the next step's scoring (libsfm_amd_rccl.so, sfm_estimate_E_sharded_pipelined)",
                     "rccl-serial": "ncclAllReduce(max, u64) on the compute stream (libsfm_amd_rccl.so, sfm_estimate_E_sharded)",
                     "torch": "torch.distributed all_reduce(MAX), 8 bytes"}[mode]
+        launch = pair.last_launch()
+        kname = {1: "ransac_score_waves", 2: "ransac_fused_waves", 3: "ransac_score_mfma", 4: "ransac_score_prefilter"}.get(launch["kernel"], "?")
         traffic_profiled = None                       # HBM bytes per launch from the committed rocprofv3 PMC passes: quoted, NOT measured by this run
-        for name in ("r02_traffic.json", "r01_traffic.json"):
-            try:
-                with open(os.path.join(ROOT, "profiles", name)) as f:
-                    t = json.load(f)["ransac_score_waves"]
-                if t["matches"] == n and t["hypotheses"] == local_hyps:
-                    traffic_profiled = {"bytes_per_launch": 1024.0 * (t["fetch_kb"] + t["write_kb"]),
-                                        "source": f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; quoted, not collected by this run)"}
-                    break
-            except (OSError, KeyError, ValueError):
-                pass
+        profiled = None                               # issue-slot occupancy of the kernel from the committed PMC pass: quoted as well
+        try:
+            with open(os.path.join(ROOT, "profiles", "r02_traffic.json")) as f:
+                t = json.load(f).get(kname)
+            if t and t["matches"] == n and t["hypotheses"] == local_hyps:
+                src = f"profiles/r02_traffic.json (rocprofv3 --pmc passes of this command on the final code; quoted, not collected by this run)"
+                traffic_profiled = {"bytes_per_launch": 1024.0 * (t["fetch_kb"] + t["write_kb"]), "source": src}
+                profiled = {k: t[k] for k in ("valu_busy_frac", "mfma_busy_frac", "valu_insts_per_launch", "lds_bank_conflict_frac") if k in t}
+                profiled["source"] = src
+        except (OSError, KeyError, ValueError):
+            pass
+        prefilter = launch["kernel"] == 4
         out = {
             "metric": "RANSAC E-matrix hypotheses/sec (8-point, fused scoring), inlier-mask parity vs CPU oracle",
             "value": H * args.steps / elapsed,
@@ -337,13 +341,18 @@ def rank_main(args):
                        "matches": n, "hypotheses_per_step": H, "threshold": params.threshold,
                        "jacobi_sweeps": params.jacobi_sweeps,
                        "solver": "householder QR of the 8x9 system" if params.jacobi_sweeps == 0 else f"normal equations + {params.jacobi_sweeps} Jacobi sweeps",
-                       "kernel": pair.last_launch(), "exchange": exchange,
+                       "kernel": dict(launch, name=kname), "exchange": exchange,
                        "nccl_ranks": comm.nccl_ranks() if comm is not None else (world if mode == "torch" else 1),
                        "per_rank_kernel_ms": [{"rank": r, "solve": v[0], "score": v[1], "shader_clock_mhz": v[2]} for r, v in enumerate(per_rank)]},
             "roofline": {"bound": "valu_fp32",
-                         "bound_detail": "FP32 vector ALU issue (v_pk_fma_f32 and friends); 157.3 TFLOP/s = 256 CU x 256 FLOP/clk x 2.4 GHz, "
-                                         "numerically the dense f32 MFMA peak the bench contract prices compute against",
-                         "kernel": "ransac_score_waves", "achieved": achieved,
+                         "bound_detail": ("vector-ALU issue: the kernel rejects ~99 % of the (hypothesis, point) pairs with 3 fp16 MFMAs per 32 x 32 pairs + "
+                                          "3 vector instructions per pair and runs the exact 38-FLOP test on the rest, so `achieved` -- the ALGORITHMIC FLOP of "
+                                          "SURVEY 8d over the launch time -- may exceed the FP32 peak it is priced against; `issue_profiled` has the occupancy "
+                                          "of the vector and matrix pipes from the committed counter pass"
+                                          if prefilter else
+                                          "FP32 vector ALU issue (v_pk_fma_f32 and friends); 157.3 TFLOP/s = 256 CU x 256 FLOP/clk x 2.4 GHz, "
+                                          "numerically the dense f32 MFMA peak the bench contract prices compute against"),
+                         "kernel": kname, "achieved": achieved, "issue_profiled": profiled,
                          "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_PEAK_TFLOPS,
                          "traffic": None, "traffic_profiled": traffic_profiled,
                          "flop_per_launch": flops, "avg_launch_ms": 1e3 * score_s,

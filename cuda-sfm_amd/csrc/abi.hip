@@ -90,6 +90,8 @@ int sfm_ctx_destroy(sfm_ctx *ctx)
     if (ctx->sift_temp) (void)hipFree(ctx->sift_temp);
     if (ctx->sift_ws) (void)hipFree(ctx->sift_ws);
     if (ctx->pool_pair) (void)sfm_pair_destroy(ctx->pool_pair);
+    for (sfm_ctx *l : ctx->lane) if (l) (void)sfm_ctx_destroy(l);
+    for (hipEvent_t e : ctx->lane_ev) if (e) (void)hipEventDestroy(e);
     if (ctx->pool_records) (void)hipFree(ctx->pool_records);
     sift_job_free(ctx);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -722,17 +724,35 @@ int sfm_process_pairs(sfm_ctx *ctx, const float h_K[9], const float h_Kinv[9], c
         ++owned;
     }
     if (owned == 0) return SFM_OK;
-    // ONE pooled Image_pair at the largest size (the reference constructs one per pair: ~20 cudaMalloc / cudaFree each)
     int rc = SFM_OK;
-    if (max_n >= 8) {
-        if (ctx->pool_pair && (ctx->pool_pair->cap_points < max_n || memcmp(ctx->pool_K, h_K, 36) != 0 || memcmp(ctx->pool_Kinv, h_Kinv, 36) != 0)) {
-            (void)sfm_pair_destroy(ctx->pool_pair);
-            ctx->pool_pair = nullptr;
-        }
-        if (!ctx->pool_pair) {
-            rc = sfm_pair_create(ctx, h_K, h_Kinv, 2, max_n, &ctx->pool_pair);
+    // lanes: the context itself + up to three auxiliary contexts on streams of their own.  Pairs that share their FIRST view
+    // stay on one lane in list order (MatchSiftData writes that view's match fields, fillXU reads them); everything else
+    // of a record is only read, so different lanes may work on pairs that share views.
+    const int nlanes = owned >= 8 ? sfm_ctx::kPairLanes : 1;
+    sfm_ctx *lanes[sfm_ctx::kPairLanes] = { ctx, nullptr, nullptr, nullptr };
+    for (int l = 1; l < nlanes; ++l) {
+        if (!ctx->lane[l - 1]) {
+            rc = sfm_ctx_create(ctx->device, &ctx->lane[l - 1]);
+            if (rc == SFM_OK) rc = sfm_ctx_own_stream(ctx->lane[l - 1]);
             if (rc != SFM_OK) return rc;
-            memcpy(ctx->pool_K, h_K, 36); memcpy(ctx->pool_Kinv, h_Kinv, 36);
+        }
+        lanes[l] = ctx->lane[l - 1];
+    }
+    for (int l = 0; l < nlanes; ++l)
+        if (!ctx->lane_ev[l]) SFM_HIP_TRY(hipEventCreateWithFlags(&ctx->lane_ev[l], hipEventDisableTiming));
+    // ONE pooled Image_pair per lane at the largest size (the reference constructs one per pair: ~20 cudaMalloc / cudaFree each)
+    if (max_n >= 8) {
+        for (int l = 0; l < nlanes; ++l) {
+            sfm_ctx *c = lanes[l];
+            if (c->pool_pair && (c->pool_pair->cap_points < max_n || memcmp(c->pool_K, h_K, 36) != 0 || memcmp(c->pool_Kinv, h_Kinv, 36) != 0)) {
+                (void)sfm_pair_destroy(c->pool_pair);
+                c->pool_pair = nullptr;
+            }
+            if (!c->pool_pair) {
+                rc = sfm_pair_create(c, h_K, h_Kinv, 2, max_n, &c->pool_pair);
+                if (rc != SFM_OK) return rc;
+                memcpy(c->pool_K, h_K, 36); memcpy(c->pool_Kinv, h_Kinv, 36);
+            }
         }
     }
     if (ctx->pool_records_cap < (size_t)owned) {
@@ -742,16 +762,26 @@ int sfm_process_pairs(sfm_ctx *ctx, const float h_K[9], const float h_Kinv[9], c
         SFM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->pool_records), (size_t)owned * SFM_RECORD_FLOATS * sizeof(float)));
         ctx->pool_records_cap = (size_t)owned;
     }
-    sfm_pair *ip = ctx->pool_pair;
+    // the auxiliary streams start after everything already enqueued on the caller's stream (the features, typically)
+    if (nlanes > 1) {
+        SFM_HIP_TRY(hipEventRecord(ctx->lane_ev[0], ctx->stream));
+        for (int l = 1; l < nlanes; ++l) SFM_HIP_TRY(hipStreamWaitEvent(lanes[l]->stream, ctx->lane_ev[0], 0));
+    }
     // per pair: MatchSiftData (optional) -> fillXU -> estimateE -> pose candidates -> choosePose -> linear triangulation
     // (src/main.cpp:282-307), everything enqueued back to back, no host synchronisation, the record stays on the device
+    std::vector<const void *> first_views;
     int slot = 0;
     for (int i = first; i < num_pairs; i += stride, ++slot) {
         const sfm_pair_desc &d = pairs[i];
         const bool usable = d.n1 >= 8 && (!d.d_sift2 || d.n2 >= 1);
         if (h_status) h_status[slot] = usable ? SFM_OK : SFM_E_INVALID;
         if (!usable) continue;
-        if (d.d_sift2) { rc = sfm_match(ctx, d.d_sift1, d.n1, d.d_sift2, d.n2); if (rc != SFM_OK) return rc; }
+        size_t v = 0;
+        while (v < first_views.size() && first_views[v] != d.d_sift1) ++v;
+        if (v == first_views.size()) first_views.push_back(d.d_sift1);
+        sfm_ctx *c = lanes[v % (size_t)nlanes];
+        sfm_pair *ip = c->pool_pair;
+        if (d.d_sift2) { rc = sfm_match(c, d.d_sift1, d.n1, d.d_sift2, d.n2); if (rc != SFM_OK) return rc; }
         rc = sfm_pair_reset(ip, d.n1);                                  if (rc != SFM_OK) return rc;
         rc = sfm_fill_xu(ip, d.d_sift1);                                if (rc != SFM_OK) return rc;
         sfm_ransac_params p;
@@ -763,6 +793,10 @@ int sfm_process_pairs(sfm_ctx *ctx, const float h_K[9], const float h_Kinv[9], c
         rc = sfm_triangulate(ip, pose_mode);                            if (rc != SFM_OK) return rc;
         rc = launch_pair_record(ip, pose_mode, ctx->pool_records + (size_t)slot * SFM_RECORD_FLOATS);
         if (rc != SFM_OK) return rc;
+    }
+    for (int l = 1; l < nlanes; ++l) {
+        SFM_HIP_TRY(hipEventRecord(ctx->lane_ev[l], lanes[l]->stream));
+        SFM_HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->lane_ev[l], 0));
     }
     // ONE read-back for all pairs of this rank
     std::vector<float> rec((size_t)owned * SFM_RECORD_FLOATS);

@@ -48,7 +48,11 @@ struct sfm_ctx {
     size_t sift_temp_bytes = 0;
     void *sift_ws = nullptr;           // counters, candidates, secondary orientations
     size_t sift_ws_bytes = 0;
-    // many-pairs driver (sfm_process_pairs): pooled Image_pair and device-side result records
+    // many-pairs driver (sfm_process_pairs): pooled Image_pair and device-side result records; up to three auxiliary
+    // contexts with streams of their own, so that the small single-wave stages of one pair overlap another pair's matcher
+    static constexpr int kPairLanes = 4;
+    sfm_ctx *lane[kPairLanes - 1] = {};
+    hipEvent_t lane_ev[kPairLanes] = {};
     sfm_pair *pool_pair = nullptr;
     float pool_K[9] = {}, pool_Kinv[9] = {};
     float *pool_records = nullptr;

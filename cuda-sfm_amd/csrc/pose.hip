@@ -102,6 +102,7 @@ void choose_pose_reference_kernel(const float *__restrict__ X0, const float *__r
     if (threadIdx.x == 0) {
         pind[0] = m ? (63 - __builtin_clzll(m)) : 0;      // last passing candidate wins (sfm.cu:295-296)
         pind[5] = (int)sing;
+        pind[6] = 0; pind[7] = 0;
     }
 }
 
@@ -200,11 +201,11 @@ int launch_pose_candidates(sfm_pair *pair, int mode)
 int launch_choose_pose(sfm_pair *pair, int mode)
 {
     hipStream_t st = pair->ctx->stream;
-    SFM_HIP_TRY(hipMemsetAsync(pair->d_Pind, 0, 8 * sizeof(int), st));
-    if (mode == SFM_POSE_REFERENCE) {
+    if (mode == SFM_POSE_REFERENCE) {                        // the single-wave kernel writes every field itself: no memset
         hipLaunchKernelGGL(choose_pose_reference_kernel, dim3(1), dim3(64), 0, st,
                            pair->d_X[0], pair->d_X[1], pair->ld, pair->d_P, kSweeps4, pair->d_Pinv, pair->d_Pind);
     } else {
+        SFM_HIP_TRY(hipMemsetAsync(pair->d_Pind, 0, 8 * sizeof(int), st));     // vote counters
         hipLaunchKernelGGL(choose_pose_vote_kernel, dim3((pair->n + 255) / 256), dim3(256), 0, st,
                            pair->d_X[0], pair->d_X[1], pair->ld, pair->n, pair->d_P, kSweeps4, pair->d_Pind);
         SFM_HIP_TRY(hipGetLastError());
