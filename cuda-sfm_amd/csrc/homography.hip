@@ -88,105 +88,127 @@ void homo_sample_kernel(const int *__restrict__ valid, const unsigned int *__res
     for (int k = 0; k < 4; ++k) pts[(size_t)k * L + i] = valid[pick[k]];
 }
 
-// 8x8 inverse: Crout LU with implicit (row-scaled) partial pivoting + eight back-substitutions
-// (the scheme of InvertMatrix<8>, matching.cu:821-905).  One matrix per thread.  The pivot rows are data dependent, so
-// the matrices cannot live in registers; they sit in LDS, element-major ([element][thread]: every access of a wavefront
-// hits 64 different banks whatever row a lane picked) instead of per-thread scratch memory.
-struct LaneVec {                               // per-thread vector / matrix in LDS, element stride = threads per block
-    float *base;
-    __device__ __forceinline__ float &operator[](int k) const { return base[k * 64]; }
-};
-struct LaneMat {
-    float *base;
-    __device__ __forceinline__ float &operator()(int i, int j) const { return base[(i * 8 + j) * 64]; }
-};
+// ---- 4-point DLT (ComputeHomographies + InvertMatrix<8>, matching.cu:821-948) ----------------------------------------
+// The arithmetic is the contract here: the reference inverts the 8x8 system by LU decomposition with implicit (row-scaled)
+// partial pivoting and eight back-substitutions, then multiplies the inverse with the right-hand side, and the product
+// must reproduce every coefficient bit for bit (tests/test_gpu_homography.py runs the reference's kernel on the GPU).
+// So every sum keeps its order, every product its own rounding, the pivot rule its tie-break -- but the work is laid out
+// for the wavefront instead of one matrix per thread: EIGHT LANES OWN ONE MATRIX, lane r holds row r in registers.
+//   column j of the decomposition = j broadcast steps (row k's finished entry goes to the rows below it) instead of a
+//       triangular loop nest over a matrix in memory; a row's partial sums still grow in k order
+//   pivot search = a three-step exchange inside the 8-lane group on (scaled magnitude, row) with "later row wins ties",
+//       which is what the sequential scan with >= amounts to; a column of NaNs leaves the previous pivot row in place
+//   row interchange = one lane-pair exchange of the eight registers (data-dependent rows need no addressable storage)
+//   the eight unit right-hand sides are solved at once, lane c takes column c of the inverse, L / U entries arrive by
+//       broadcast; the final inverse x rhs product is accumulated over the lanes in index order
+// No LDS, no scratch; a wavefront finishes eight systems in ~30 dependent exchange steps instead of one lane walking ~400
+// dependent memory operations per system.
+__device__ __forceinline__ float grp_get(float v, int lane_in_group) { return __shfl(v, lane_in_group, 8); }
+__device__ __forceinline__ int grp_get(int v, int lane_in_group) { return __shfl(v, lane_in_group, 8); }
 
-__device__ void invert8(const LaneMat &e, const LaneMat &res, const LaneVec &vv, const LaneVec &b, int (&indx)[8])
-{
-    int imax = 0;
-    for (int i = 0; i < 8; ++i) {
-        float big = 0.0f;
-        for (int j = 0; j < 8; ++j) { const float t = fabsf(e(i, j)); if (t > big) big = t; }
-        vv[i] = (big > 0.0f) ? (float)(1.0 / (double)big) : (float)1e16;
-    }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) indx[i] = 0;
-    for (int j = 0; j < 8; ++j) {
-        for (int i = 0; i < j; ++i) {
-            float sum = e(i, j);
-            for (int k = 0; k < i; ++k) sum -= e(i, k) * e(k, j);
-            e(i, j) = sum;
-        }
-        float big = 0.0f;
-        for (int i = j; i < 8; ++i) {
-            float sum = e(i, j);
-            for (int k = 0; k < j; ++k) sum -= e(i, k) * e(k, j);
-            e(i, j) = sum;
-            const float dum = vv[i] * fabsf(sum);
-            if (dum >= big) { big = dum; imax = i; }
-        }
-        if (j != imax) {
-            for (int k = 0; k < 8; ++k) { const float d = e(imax, k); e(imax, k) = e(j, k); e(j, k) = d; }
-            vv[imax] = vv[j];
-        }
-#pragma unroll
-        for (int q = 0; q < 8; ++q) if (q == j) indx[q] = imax;
-        if (e(j, j) == 0.0f) e(j, j) = (float)1e-16;
-        if (j != 7) {
-            const float dum = (float)(1.0 / (double)e(j, j));
-            for (int i = j + 1; i < 8; ++i) e(i, j) *= dum;
-        }
-    }
-    for (int j = 0; j < 8; ++j) {
-        for (int k = 0; k < 8; ++k) b[k] = 0.0f;
-        b[j] = 1.0f;
-        int ii = -1;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int ip = indx[i];
-            float sum = b[ip];
-            b[ip] = b[i];
-            if (ii != -1) { for (int k = ii; k < i; ++k) sum -= e(i, k) * b[k]; }
-            else if (sum != 0.0f) ii = i;
-            b[i] = sum;
-        }
-        for (int i = 7; i >= 0; --i) {
-            float sum = b[i];
-            for (int k = i + 1; k < 8; ++k) sum -= e(i, k) * b[k];
-            b[i] = sum / e(i, i);
-        }
-        for (int i = 0; i < 8; ++i) res(i, j) = b[i];
-    }
-}
-
-// one 4-point DLT per thread (matching.cu:907-948); pts: 4 x L, homo: 8 x L
 __global__ __launch_bounds__(64)
 void homo_solve_kernel(const float *__restrict__ coord, int ld, const int *__restrict__ pts, int L, float *__restrict__ homo)
 {
-    __shared__ float lds_a[64 * 64], lds_ia[64 * 64], lds_v[2 * 8 * 64];
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= L) return;
-    const LaneMat a{ lds_a + threadIdx.x }, ia{ lds_ia + threadIdx.x };
-    const LaneVec vv{ lds_v + threadIdx.x }, bw{ lds_v + 8 * 64 + threadIdx.x };
-    float b[8];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int pt = pts[i * L + idx];
+    const int r = threadIdx.x & 7;                                        // my row
+    const int m = (blockIdx.x * blockDim.x + threadIdx.x) >> 3;           // my matrix
+    const int mm = m < L ? m : L - 1;                                     // whole groups past the end repeat the last system
+    float e[8], rhs;
+    {
+        const int pt = pts[(r >> 1) * L + mm];
         const float x1 = coord[pt], y1 = coord[pt + ld], x2 = coord[pt + 2 * ld], y2 = coord[pt + 3 * ld];
-        const int r1 = 2 * i, r2 = 2 * i + 1;
-        a(r1, 0) = x1; a(r1, 1) = y1; a(r1, 2) = 1.0f; a(r1, 3) = 0.0f; a(r1, 4) = 0.0f; a(r1, 5) = 0.0f; a(r1, 6) = (-x2) * x1; a(r1, 7) = (-x2) * y1;
-        a(r2, 0) = 0.0f; a(r2, 1) = 0.0f; a(r2, 2) = 0.0f; a(r2, 3) = x1; a(r2, 4) = y1; a(r2, 5) = 1.0f; a(r2, 6) = (-y2) * x1; a(r2, 7) = (-y2) * y1;
-        b[2 * i] = x2; b[2 * i + 1] = y2;
+        const bool odd = r & 1;                                           // matching.cu:918-936: rows 2i (x) and 2i + 1 (y) of point i
+        const float w = odd ? y2 : x2;
+        e[0] = odd ? 0.0f : x1; e[1] = odd ? 0.0f : y1; e[2] = odd ? 0.0f : 1.0f;
+        e[3] = odd ? x1 : 0.0f; e[4] = odd ? y1 : 0.0f; e[5] = odd ? 1.0f : 0.0f;
+        e[6] = (-w) * x1; e[7] = (-w) * y1;
+        rhs = w;
     }
-    int indx[8];
-    invert8(a, ia, vv, bw, indx);
+    // row scale: 1 / largest magnitude of the row (double-precision reciprocal, matching.cu:828-838)
+    float vv;
+    {
+        float big = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float t = fabsf(e[j]); big = (t > big) ? t : big; }
+        vv = (big > 0.0f) ? (float)(1.0 / (double)big) : (float)1e16;
+    }
+    int imax = 0, perm = 0;                                               // perm: pivot row of column j in bits 3j .. 3j + 2
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
+        // rows above the diagonal finish their entry of column j one after the other; the rows below collect all j terms
+#pragma unroll
+        for (int k = 0; k < j; ++k) {
+            const float ekj = grp_get(e[j], k);
+            const float prod = e[k] * ekj;
+            if (r > k) e[j] = e[j] - prod;
+        }
+        // pivot: largest vv * |entry| among rows >= j, the later row on ties; NaN never wins
+        {
+            const float dum = vv * fabsf(e[j]);
+            float best = (r >= j && dum == dum) ? dum : -1.0f;
+            int row = r;
+#pragma unroll
+            for (int off = 1; off < 8; off <<= 1) {
+                const float ob = __shfl_xor(best, off, 8);
+                const int orow = __shfl_xor(row, off, 8);
+                const bool take = (ob > best) || (ob == best && orow > row);
+                best = take ? ob : best; row = take ? orow : row;
+            }
+            if (best >= 0.0f) imax = row;
+        }
+        if (imax != j) {                                                  // group-uniform
+            const int partner = (r == j) ? imax : (r == imax ? j : r);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) e[k] = grp_get(e[k], partner);
+            const float vj = grp_get(vv, j);
+            if (r == imax) vv = vj;                                       // only this direction (matching.cu:866)
+        }
+        perm |= imax << (3 * j);
+        if (r == j && e[j] == 0.0f) e[j] = (float)1e-16;
+        if (j != 7) {
+            const float piv = grp_get(e[j], j);
+            const float dum = (float)(1.0 / (double)piv);
+            if (r > j) e[j] *= dum;
+        }
+    }
+    // inverse: lane c solves L U x = P e_c
+    float b[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) b[i] = (i == r) ? 1.0f : 0.0f;
+    int ii = -1;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int ip = (perm >> (3 * i)) & 7;
         float sum = 0.0f;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) sum += ia(j, i) * b[i];
-        homo[j * L + idx] = sum;
+        for (int q = 0; q < 8; ++q) sum = (q == ip) ? b[q] : sum;         // sum = b[ip]; b[ip] = b[i]
+#pragma unroll
+        for (int q = 0; q < 8; ++q) b[q] = (q == ip) ? b[i] : b[q];
+#pragma unroll
+        for (int k = 0; k < i; ++k) {
+            const float eik = grp_get(e[k], i);
+            if (ii != -1 && k >= ii) sum -= eik * b[k];
+        }
+        if (ii == -1 && sum != 0.0f) ii = i;
+        b[i] = sum;
     }
+#pragma unroll
+    for (int i = 7; i >= 0; --i) {
+        float sum = b[i];
+#pragma unroll
+        for (int k = i + 1; k < 8; ++k) sum -= grp_get(e[k], i) * b[k];
+        b[i] = sum / grp_get(e[i], i);
+    }
+    // homography coefficient j = sum over i of inverse(j, i) * rhs(i): lane i holds column i, accumulate in lane order
+    float out = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float term = b[j] * rhs;
+        float sum = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) sum += grp_get(term, i);
+        if (r == j) out = sum;
+    }
+    if (m < L) homo[r * L + m] = out;
 }
 
 // ---- TestHomographies (matching.cu:953-996): one hypothesis per wavefront, points in LDS --------------------
@@ -327,7 +349,7 @@ int launch_homography(sfm_ctx *ctx, const sfm_sift_point *d_sift, int n, const i
         hipLaunchKernelGGL(homo_sample_kernel, dim3((L + 255) / 256), dim3(256), 0, st, d_valid, d_nv, seed, L, d_pts);
     }
     hipLaunchKernelGGL(homo_gather_kernel, dim3((ld + 255) / 256), dim3(256), 0, st, d_sift, n, ld, d_coord);
-    hipLaunchKernelGGL(homo_solve_kernel, dim3((L + 63) / 64), dim3(64), 0, st, d_coord, ld, d_pts, L, d_homo);
+    hipLaunchKernelGGL(homo_solve_kernel, dim3((L + 7) / 8), dim3(64), 0, st, d_coord, ld, d_pts, L, d_homo);       // 8 lanes per system
     {
         constexpr int kWpb = 16;
         const int tile = n < kHomoTile ? n : kHomoTile, ntiles = (n + kHomoTile - 1) / kHomoTile;
