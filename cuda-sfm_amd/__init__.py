@@ -33,6 +33,7 @@ _lib = C.CDLL(LIB_PATH)
 # ---- constants (include/sfm_amd.h) --------------------------------------------------------------
 OK, E_INVALID, E_HIP, E_NOMEM, E_STATE, E_SINGULAR = 0, -1, -2, -3, -4, -5
 KERNEL_AUTO, KERNEL_SPLIT, KERNEL_FUSED, KERNEL_MFMA, KERNEL_PREFILTER = 0, 1, 2, 3, 4
+QUIRK_MATCH_TAIL = 1
 POSE_REFERENCE, POSE_CORRECT = 0, 1
 (BUF_X0, BUF_X1, BUF_U0, BUF_U1, BUF_E, BUF_P, BUF_PINV, BUF_POINTS, BUF_COUNTS, BUF_MASK, BUF_KEY,
  BUF_ECAND, BUF_PIND) = range(13)
@@ -46,7 +47,7 @@ SIFT_DTYPE = np.dtype([
 assert SIFT_DTYPE.itemsize == 576
 
 EXPORTS = [
-    "sfm_abi_version", "sfm_last_error", "sfm_ctx_create", "sfm_ctx_destroy", "sfm_ctx_set_stream",
+    "sfm_abi_version", "sfm_last_error", "sfm_ctx_create", "sfm_ctx_destroy", "sfm_ctx_set_stream", "sfm_ctx_set_quirks",
     "sfm_ctx_synchronize", "sfm_ctx_own_stream", "sfm_ctx_get_stream", "sfm_ctx_get_device", "sfm_ctx_timer_start", "sfm_ctx_timer_stop", "sfm_ctx_kernel_timing",
     "sfm_ctx_kernel_timing_read", "sfm_device_alloc", "sfm_device_free", "sfm_copy_to_device", "sfm_copy_to_host",
     "sfm_copy_to_host_2d", "sfm_copy_to_device_2d", "sfm_find_homography", "sfm_sift_temp_layout", "sfm_extract_sift", "sfm_extract_sift_begin", "sfm_extract_sift_end", "sfm_match", "sfm_match_soa",
@@ -208,6 +209,10 @@ class Context:
     def set_stream(self, stream):
         """stream: raw hipStream_t value (e.g. torch.cuda.current_stream().cuda_stream) or None."""
         _check(_lib.sfm_ctx_set_stream(self._h, stream), "sfm_ctx_set_stream")
+
+    def set_quirks(self, flags):
+        """SFM_QUIRK_* behaviours of the reference for A/B runs (QUIRK_MATCH_TAIL: skip the last num_pts2 % 32 points)."""
+        _check(_lib.sfm_ctx_set_quirks(self._h, C.c_uint(int(flags))), "sfm_ctx_set_quirks")
 
     def own_stream(self):
         """Give the context a non-blocking stream of its own (for a second context next to a torch-owned one)."""
@@ -617,6 +622,22 @@ def view_slot(v, world, slots):
     return (int(v) % int(world)) * int(slots) + int(v) // int(world)
 
 
+def exchange_view_features(block, num_views, world, max_pts, gather_features=None):
+    """The one collective of the many-views front end.  block: this rank's uint8 tensor [slots, max_pts * 576 + 64]
+    (slot s = view rank + s * world: its SiftPoint records, then its int32 feature count in the tail).
+    gather_features(block) -> all ranks' blocks concatenated in rank order (torch.distributed.all_gather_into_tensor over
+    RCCL; gloo in the CPU tests; None / world == 1: identity).  Returns (gathered [world * slots, ...] tensor, counts per
+    view); view v sits in row view_slot(v, world, slots)."""
+    rec_bytes = int(max_pts) * 576
+    slots = block.shape[0]
+    feats = gather_features(block) if (gather_features is not None and world > 1) else block
+    feats = feats.reshape(-1, rec_bytes + 64)
+    assert feats.shape[0] == world * slots, f"gathered {feats.shape[0]} slots, expected {world * slots}"
+    tail = feats[:, rec_bytes:rec_bytes + 4].cpu().numpy().view(np.int32).reshape(-1)
+    counts = [int(tail[view_slot(v, world, slots)]) for v in range(int(num_views))]
+    return feats, counts
+
+
 def process_views(ctx, images, K, Kinv, pairs=None, rank=0, world=1, max_pts=8192, sift=None, num_hypotheses=None,
                   pose_mode=POSE_REFERENCE, gather_features=None, gather_results=None, device=None):
     """Many-view front end of process_pairs: images -> ExtractSift per view (views round-robin over the ranks) ->
@@ -665,12 +686,8 @@ def process_views(ctx, images, K, Kinv, pairs=None, rank=0, world=1, max_pts=819
         for slot, n in local_counts.items():
             cnt[slot] = np.array([n], np.int32).view(np.uint8)
         block[:, rec_bytes:rec_bytes + 4] = torch.from_numpy(cnt).to(dev)
-    feats = gather_features(block) if (gather_features is not None and world > 1) else block
-    feats = feats.reshape(-1, rec_bytes + 64)
-
-    # feature counts of all views with ONE read-back; MatchSiftData then writes its result fields (score .. match_ypos)
-    # straight into the first view's records -- nothing else of a record changes, so no per-pair copy is needed
-    counts = [int(c) for c in feats[:, rec_bytes:rec_bytes + 4].cpu().numpy().view(np.int32).reshape(-1)[[view_slot(v, world, slots) for v in range(V)]]]
+    # ONE exchange of the fixed-size feature blocks; feature counts of all views with ONE read-back
+    feats, counts = exchange_view_features(block, V, world, max_pts, gather_features)
 
     def view(v):
         return feats[view_slot(v, world, slots)][:rec_bytes].reshape(max_pts, 576), counts[v]

@@ -110,6 +110,14 @@ int sfm_ctx_set_stream(sfm_ctx *ctx, void *hip_stream)
     return SFM_OK;
 }
 
+int sfm_ctx_set_quirks(sfm_ctx *ctx, unsigned int flags)
+{
+    SFM_REQUIRE(ctx, SFM_E_INVALID, "null context");
+    SFM_REQUIRE((flags & ~SFM_QUIRK_MATCH_TAIL) == 0, SFM_E_INVALID, "unknown quirk flags 0x%x", flags);
+    ctx->quirks = flags;
+    return SFM_OK;
+}
+
 int sfm_ctx_own_stream(sfm_ctx *ctx)
 {
     SFM_REQUIRE(ctx, SFM_E_INVALID, "null context");
@@ -257,6 +265,10 @@ int sfm_match(sfm_ctx *ctx, sfm_sift_point *d_sift1, int n1, const sfm_sift_poin
     SFM_REQUIRE(n1 >= 0 && n2 >= 0, SFM_E_INVALID, "negative point count");
     if (n1 == 0 || n2 == 0 || !d_sift1 || !d_sift2) return SFM_OK;      // matching.cu:1095-1102
     SFM_HIP_TRY(hipSetDevice(ctx->device));
+    if (ctx->quirks & SFM_QUIRK_MATCH_TAIL) {                           // matching.cu:325: the tile loop stops 32 points short
+        n2 -= n2 % 32;
+        if (n2 == 0) return launch_match_none(ctx, n1, d_sift1);
+    }
     const int ld = (int)(sizeof(sfm_sift_point) / sizeof(float));
     return launch_match(ctx, d_sift1->data, n1, ld, d_sift2->data, n2, ld, nullptr, nullptr, nullptr, d_sift1, d_sift2);
 }

@@ -33,6 +33,7 @@ struct sfm_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;           // created by sfm_ctx_own_stream, destroyed with the context
     int num_cus = 256;
+    unsigned int quirks = 0;           // SFM_QUIRK_* (sfm_ctx_set_quirks)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // optional per-kernel stopwatch (sfm_ctx_kernel_timing): event triples around solve / score
     bool timing = false;
@@ -154,6 +155,7 @@ int launch_homography(sfm_ctx *ctx, const sfm_sift_point *d_sift, int n, const i
                       float min_score, float max_ambiguity, uint32_t seed, int *num_valid,
                       float h_H[9], int *num_matches, int *h_counts, float *h_homo);
 // match.hip
+int launch_match_none(sfm_ctx *ctx, int n1, sfm_sift_point *sift1);
 int launch_match(sfm_ctx *ctx, const float *d1, int n1, int ld1, const float *d2, int n2, int ld2,
                  float *d_best, float *d_second, int32_t *d_index,
                  sfm_sift_point *sift1, const sfm_sift_point *sift2);

@@ -100,7 +100,9 @@ __global__ __launch_bounds__(W * 64)
 void match_mfma_kernel(const float *__restrict__ q, int nq, int ldq,
                        const float *__restrict__ db, int ndb, int lddb,
                        int rows_per_split,
-                       float *__restrict__ ws_best, float *__restrict__ ws_second, int *__restrict__ ws_idx)
+                       float *__restrict__ ws_best, float *__restrict__ ws_second, int *__restrict__ ws_idx,
+                       unsigned int *__restrict__ tickets, float *__restrict__ out_best, float *__restrict__ out_second,
+                       int *__restrict__ out_idx, sfm_sift_point *__restrict__ sift1, const sfm_sift_point *__restrict__ sift2)
 {
     __shared__ __attribute__((aligned(16))) float lds[2][kRowsPerStage * kLdsStride];
     const int lane = threadIdx.x & 63;
@@ -208,37 +210,70 @@ void match_mfma_kernel(const float *__restrict__ q, int nq, int ldq,
         const Top2 mrg = top2_merge(top[ct], o);
         const int p1 = q0 + (wave * CT + ct) * 32 + col;
         if (half == 0 && p1 < nq) {
+            // agent-scope stores (written through this XCD's L2): the block that merges may sit on another XCD
             const size_t w = (size_t)split * nq + p1;
-            ws_best[w] = mrg.best; ws_second[w] = mrg.second; ws_idx[w] = mrg.idx;
+            __hip_atomic_store(&ws_best[w], mrg.best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&ws_second[w], mrg.second, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&ws_idx[w], mrg.idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    // ---- the LAST split block of this query block merges the partials (ascending database ranges) and writes the results,
+    // either to plain arrays or into the SiftPoint fields MatchSiftData updates (matching.cu:391-395): no merge launch.
+    // Ordering without a fence: the partials are agent-scope stores, acknowledged (vmcnt) before the block's ticket is drawn;
+    // the merging block reads them with agent-scope loads after its own ticket came back.
+    __shared__ int s_last;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned int t = atomicAdd(&tickets[blockIdx.x], 1u);
+        s_last = (t == gridDim.y - 1) ? 1 : 0;
+        if (s_last) __hip_atomic_store(&tickets[blockIdx.x], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // ready for the next call
+    }
+    __syncthreads();
+    if (!s_last) return;
+    const int nsplit = gridDim.y;
+    for (int k = threadIdx.x; k < CT * 32 * W; k += blockDim.x) {
+        const int p1 = q0 + k;
+        if (p1 >= nq) break;
+        Top2 t{ __hip_atomic_load(&ws_best[p1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                __hip_atomic_load(&ws_second[p1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                __hip_atomic_load(&ws_idx[p1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) };
+        for (int sp = 1; sp < nsplit; ++sp) {
+            const size_t w = (size_t)sp * nq + p1;
+            t = top2_merge(t, Top2{ __hip_atomic_load(&ws_best[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                                    __hip_atomic_load(&ws_second[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                                    __hip_atomic_load(&ws_idx[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) });
+        }
+        if (out_best) out_best[p1] = t.best;
+        if (out_second) out_second[p1] = t.second;
+        if (out_idx) out_idx[p1] = t.idx;
+        if (sift1) {
+            sfm_sift_point *o = sift1 + p1;
+            o->score = t.best;
+            o->match = t.idx;
+            o->match_xpos = t.idx >= 0 ? sift2[t.idx].xpos : 0.0f;
+            o->match_ypos = t.idx >= 0 ? sift2[t.idx].ypos : 0.0f;
+            o->ambiguity = t.second / (t.best + 1e-6f);
         }
     }
 }
 
-// Merge the per-split partials (ascending database ranges) and write the results either to
-// plain arrays or into the SiftPoint fields MatchSiftData updates (matching.cu:391-395).
+// SFM_QUIRK_MATCH_TAIL with fewer than 32 points in the second set: nothing is searched, every query keeps the initial
+// values of FindMaxCorr10 (score 0, index -1; the reference then reads sift2[-1], matching.cu:393-394 -- here positions 0)
 __global__ __launch_bounds__(256)
-void match_merge_kernel(int nq, int nsplit, const float *__restrict__ ws_best, const float *__restrict__ ws_second,
-                        const int *__restrict__ ws_idx, float *__restrict__ out_best, float *__restrict__ out_second,
-                        int *__restrict__ out_idx, sfm_sift_point *__restrict__ sift1, const sfm_sift_point *__restrict__ sift2)
+void match_none_kernel(int nq, sfm_sift_point *__restrict__ sift1)
 {
     const int p1 = blockIdx.x * blockDim.x + threadIdx.x;
     if (p1 >= nq) return;
-    Top2 t{ ws_best[p1], ws_second[p1], ws_idx[p1] };
-    for (int s = 1; s < nsplit; ++s) {
-        const size_t w = (size_t)s * nq + p1;
-        t = top2_merge(t, Top2{ ws_best[w], ws_second[w], ws_idx[w] });
-    }
-    if (out_best) out_best[p1] = t.best;
-    if (out_second) out_second[p1] = t.second;
-    if (out_idx) out_idx[p1] = t.idx;
-    if (sift1) {
-        sfm_sift_point *o = sift1 + p1;
-        o->score = t.best;
-        o->match = t.idx;
-        o->match_xpos = t.idx >= 0 ? sift2[t.idx].xpos : 0.0f;
-        o->match_ypos = t.idx >= 0 ? sift2[t.idx].ypos : 0.0f;
-        o->ambiguity = t.second / (t.best + 1e-6f);
-    }
+    sfm_sift_point *o = sift1 + p1;
+    o->score = 0.0f; o->match = -1; o->match_xpos = 0.0f; o->match_ypos = 0.0f; o->ambiguity = 0.0f;
+}
+
+int launch_match_none(sfm_ctx *ctx, int n1, sfm_sift_point *sift1)
+{
+    hipLaunchKernelGGL(match_none_kernel, dim3((n1 + 255) / 256), dim3(256), 0, ctx->stream, n1, sift1);
+    SFM_HIP_TRY(hipGetLastError());
+    return SFM_OK;
 }
 
 int launch_match(sfm_ctx *ctx, const float *d1, int n1, int ld1, const float *d2, int n2, int ld2,
@@ -262,28 +297,30 @@ int launch_match(sfm_ctx *ctx, const float *d1, int n1, int ld1, const float *d2
     rows_per_split = round_up(rows_per_split, kRowsPerStage);
     nsplit = (n2 + rows_per_split - 1) / rows_per_split;
 
-    const size_t need = (size_t)nsplit * n1 * 12;
+    // scratch: one ticket per query block (zero between calls: the merging block resets its own) + the per-split partials
+    constexpr size_t kTicketBytes = 4096;
+    const size_t need = kTicketBytes + (size_t)nsplit * n1 * 12;
+    if (qblocks > (int)(kTicketBytes / 4)) { set_error("too many query blocks (%d)", qblocks); return SFM_E_INVALID; }
     if (need > ctx->match_ws_bytes) {
         SFM_HIP_TRY(hipStreamSynchronize(ctx->stream));
         if (ctx->match_ws) (void)hipFree(ctx->match_ws);
         ctx->match_ws = nullptr; ctx->match_ws_bytes = 0;
         SFM_HIP_TRY(hipMalloc(&ctx->match_ws, need));
+        SFM_HIP_TRY(hipMemsetAsync(ctx->match_ws, 0, kTicketBytes, ctx->stream));
         ctx->match_ws_bytes = need;
     }
-    float *wb = static_cast<float *>(ctx->match_ws);
+    unsigned int *tickets = static_cast<unsigned int *>(ctx->match_ws);
+    float *wb = reinterpret_cast<float *>(static_cast<char *>(ctx->match_ws) + kTicketBytes);
     float *wsnd = wb + (size_t)nsplit * n1;
     int *wi = reinterpret_cast<int *>(wsnd + (size_t)nsplit * n1);
 
     const dim3 grid(qblocks, nsplit);
     if (ct == 2)
         hipLaunchKernelGGL((match_mfma_kernel<2, 8>), grid, dim3(512), 0, ctx->stream,
-                           d1, n1, ld1, d2, n2, ld2, rows_per_split, wb, wsnd, wi);
+                           d1, n1, ld1, d2, n2, ld2, rows_per_split, wb, wsnd, wi, tickets, d_best, d_second, d_index, sift1, sift2);
     else
         hipLaunchKernelGGL((match_mfma_kernel<1, 4>), grid, dim3(256), 0, ctx->stream,
-                           d1, n1, ld1, d2, n2, ld2, rows_per_split, wb, wsnd, wi);
-    SFM_HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(match_merge_kernel, dim3((n1 + 255) / 256), dim3(256), 0, ctx->stream,
-                       n1, nsplit, wb, wsnd, wi, d_best, d_second, d_index, sift1, sift2);
+                           d1, n1, ld1, d2, n2, ld2, rows_per_split, wb, wsnd, wi, tickets, d_best, d_second, d_index, sift1, sift2);
     SFM_HIP_TRY(hipGetLastError());
     return SFM_OK;
 }

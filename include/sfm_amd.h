@@ -56,6 +56,11 @@ const char *sfm_last_error(void);
 int  sfm_ctx_create(int device_id, sfm_ctx **out);          /* replaces InitCuda + cuBLAS/cuSOLVER handle setup (sfm.cu:46-75) */
 int  sfm_ctx_destroy(sfm_ctx *ctx);
 int  sfm_ctx_set_stream(sfm_ctx *ctx, void *hip_stream);    /* NULL = default stream                                          */
+/* Behaviours of the reference that the product fixes, selectable for A/B runs against it (SURVEY.md, quirk list):
+ * SFM_QUIRK_MATCH_TAIL -- FindMaxCorr10's tile loop (matching.cu:325) never visits the last num_pts2 % 32 points of the
+ * second set; with the flag sfm_match searches only the first num_pts2 - num_pts2 % 32 (none: match = -1, score = 0). */
+#define SFM_QUIRK_MATCH_TAIL 1u
+int  sfm_ctx_set_quirks(sfm_ctx *ctx, unsigned int flags);
 /* A stream of the context's own (hipStreamNonBlocking, destroyed with the context): callers without HIP headers get a
  * second context that runs concurrently with the first (which sits on the default stream unless told otherwise). */
 int  sfm_ctx_own_stream(sfm_ctx *ctx);

@@ -210,3 +210,21 @@ def test_findmaxcorr10_tail_quirk_q1(R, gpu):
     assert np.array_equal(full["match"][:13], np.arange(n2 - 13, n2)) and (full["score"][:13] > 0.999).all()
     rest = full["match"] < n2 - 13                          # wherever no skipped point wins the two agree
     assert rest[13:].mean() > 0.9 and np.array_equal(full["match"][rest], ref["match"][rest]) and same_bits(full["score"][rest], ref["score"][rest])
+    # SFM_QUIRK_MATCH_TAIL: the product emulates the skipped tail itself, for A/B runs against the reference
+    qctx = S.Context(0, torch.cuda.current_stream().cuda_stream)
+    qctx.set_quirks(S.QUIRK_MATCH_TAIL)
+    t1 = to_dev(torch, dev, s1)
+    qctx.match(t1, n1, t2, n2)
+    torch.cuda.synchronize()
+    quirk = t1.cpu().numpy().reshape(-1).view(synth.SIFT_DTYPE)
+    assert np.array_equal(quirk["match"], ref["match"]) and same_bits(quirk["score"], ref["score"])
+    for f in ("match_xpos", "match_ypos"):
+        assert same_bits(quirk[f], ref[f])
+    t1 = to_dev(torch, dev, s1)
+    qctx.match(t1, n1, t2, 20)                               # fewer than 32 points: nothing is searched
+    torch.cuda.synchronize()
+    none = t1.cpu().numpy().reshape(-1).view(synth.SIFT_DTYPE)
+    assert (none["match"] == -1).all() and not none["score"].any()
+    qctx.set_quirks(0)
+    with pytest.raises(S.SfmError):
+        qctx.set_quirks(8)

@@ -133,3 +133,54 @@ def test_process_views_ring_from_images(gpu):
         if pid < 3:                                               # neighbouring views: pure +x translation, no rotation
             P = r[9:25].reshape(4, 4)
             assert np.abs(P[:3, :3] - np.eye(3)).max() < 0.03 and abs(abs(P[0, 3]) - 1.0) < 0.03
+
+
+def _views_worker(rank, world, port, V, max_pts, q):
+    import sys
+    sys.path.insert(0, ROOT)
+    import cuda_sfm_amd as S
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    slots = (V + world - 1) // world
+    rec_bytes = max_pts * 576
+    block = torch.zeros((slots, rec_bytes + 64), dtype=torch.uint8)
+    for slot, v in enumerate(range(rank, V, world)):                       # what process_views leaves in the local block
+        n = 10 + 3 * v                                                     # feature count of view v
+        body = (np.arange(rec_bytes, dtype=np.int64) * (v + 1) % 251).astype(np.uint8)
+        block[slot, :rec_bytes] = torch.from_numpy(body)
+        block[slot, rec_bytes:rec_bytes + 4] = torch.from_numpy(np.array([n], np.int32).view(np.uint8))
+
+    def gather(b):
+        out = torch.empty((world * b.shape[0],) + tuple(b.shape[1:]), dtype=b.dtype)
+        dist.all_gather_into_tensor(out, b)
+        return out
+
+    feats, counts = S.exchange_view_features(block, V, world, max_pts, gather)
+    ok = counts == [10 + 3 * v for v in range(V)]
+    for v in range(V):
+        row = feats[S.view_slot(v, world, slots)]
+        want = (np.arange(rec_bytes, dtype=np.int64) * (v + 1) % 251).astype(np.uint8)
+        ok = ok and np.array_equal(row[:rec_bytes].numpy(), want)
+    # the pair schedule on top of it: every pair owned by exactly one rank, both of its views present on that rank
+    pairs = S.ring_pairs(V)
+    mine = S.pair_schedule(len(pairs), rank, world)
+    q.put((rank, bool(ok), mine, counts))
+    dist.barrier(); dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("V", [5, 8])
+def test_two_rank_feature_exchange_of_process_views(V):
+    """The ONE collective between extraction and pairing (exchange_view_features) with real slot contents, world 2, gloo:
+    after the all-gather every rank finds every view's records and feature count at view_slot(), also when the views do
+    not divide evenly over the ranks (the spare slot stays empty); the ring pairs are dealt without overlap."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_views_worker, args=(r, 2, port, V, 4, q)) for r in range(2)]
+    for p in procs: p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60); assert p.exitcode == 0
+    assert all(r[1] for r in res)
+    assert sorted(res[0][2] + res[1][2]) == list(range(V)) and not set(res[0][2]) & set(res[1][2])
+    assert res[0][3] == res[1][3]
