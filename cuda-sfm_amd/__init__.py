@@ -57,7 +57,7 @@ EXPORTS = [
     "sfm_pair_device_ptr", "sfm_pair_ld", "sfm_pair_num_points", "sfm_get_XU", "sfm_get_E", "sfm_get_best",
     "sfm_get_key", "sfm_get_inlier_counts", "sfm_get_inlier_mask", "sfm_get_E_candidates",
     "sfm_get_pose_candidates", "sfm_get_pose_inverses", "sfm_get_pose_index", "sfm_get_points", "sfm_copy_points_to_vbo",
-    "sfm_ransac_last_launch", "sfm_ransac_last_clock", "sfm_process_pairs",
+    "sfm_ransac_last_launch", "sfm_ransac_last_clock", "sfm_process_pairs", "sfm_extract_views",
 ]
 
 
@@ -558,6 +558,8 @@ class PairDesc(C.Structure):
     _fields_ = [("d_sift1", C.c_void_p), ("n1", C.c_int), ("d_sift2", C.c_void_p), ("n2", C.c_int)]
 
 
+_lib.sfm_extract_views.argtypes = [_vp, C.POINTER(C.POINTER(C.c_float)), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_size_t, C.c_int,
+                                   C.c_int, C.c_double, C.c_float, C.c_float, C.c_int, C.POINTER(C.c_int)]
 _lib.sfm_process_pairs.argtypes = [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(PairDesc), C.c_int, C.c_int, C.c_int,
                                    C.c_uint32, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int)]
 
@@ -659,33 +661,16 @@ def process_views(ctx, images, K, Kinv, pairs=None, rank=0, world=1, max_pts=819
     slots = (V + world - 1) // world
     rec_bytes = max_pts * 576
     block = torch.zeros((slots, rec_bytes + 64), dtype=torch.uint8, device=dev)       # records | int32 count in the tail
-    L = sift_temp_layout(w, h, sift.get("num_octaves", 5), sift.get("scale_up", False))
-    d_temp = torch.empty(L.total_floats, dtype=torch.float32, device=dev)
-    # two views at a time: the second goes through an auxiliary context on its own stream, so the two extractions overlap
-    aux = getattr(ctx, "_aux", None)
-    if aux is None:
-        aux = ctx._aux = Context(ctx.device)
-        aux.own_stream()
-    d_temp2 = torch.empty(L.total_floats, dtype=torch.float32, device=dev)
-    mine_views = list(enumerate(range(rank, V, world)))
-    local_counts = {}
-    for i0 in range(0, len(mine_views), 2):
-        group = mine_views[i0:i0 + 2]
-        imgs = []
-        for slot, v in group:
-            pad = np.zeros((h, p), np.float32)
-            pad[:, :w] = images[v]
-            imgs.append(torch.from_numpy(pad).to(dev))
-        torch.cuda.synchronize(dev)                               # uploads done before the auxiliary stream reads them
-        for k, (slot, v) in enumerate(group):
-            (ctx, aux)[k].extract_sift_begin(block[slot], max_pts, imgs[k], w, h, p, d_temp=(d_temp, d_temp2)[k], **sift)
-        for k, (slot, v) in enumerate(group):
-            local_counts[slot] = (ctx, aux)[k].extract_sift_end()[0]
-    if local_counts:
-        cnt = np.zeros((slots, 4), np.uint8)
-        for slot, n in local_counts.items():
-            cnt[slot] = np.array([n], np.int32).view(np.uint8)
-        block[:, rec_bytes:rec_bytes + 4] = torch.from_numpy(cnt).to(dev)
+    # ExtractSift for this rank's views inside the C library (sfm_extract_views: pinned staging, two streams)
+    mine_views = list(range(rank, V, world))
+    if mine_views:
+        imgs = [np.ascontiguousarray(images[v], np.float32) for v in range(V)]
+        assert all(im.shape == (h, w) for im in imgs), "process_views needs equally sized images"
+        ptrs = (C.POINTER(C.c_float) * V)(*[im.ctypes.data_as(C.POINTER(C.c_float)) for im in imgs])
+        cnts = (C.c_int * len(mine_views))()
+        _check(_lib.sfm_extract_views(ctx._h, ptrs, V, w, h, int(rank), int(world), _ptr(block), rec_bytes + 64, int(max_pts),
+                                      int(sift.get("num_octaves", 5)), float(sift.get("init_blur", 1.0)), float(sift.get("thresh", 3.0)),
+                                      float(sift.get("lowest_scale", 0.0)), int(bool(sift.get("scale_up", False))), cnts), "sfm_extract_views")
     # ONE exchange of the fixed-size feature blocks; feature counts of all views with ONE read-back
     feats, counts = exchange_view_features(block, V, world, max_pts, gather_features)
 

@@ -93,6 +93,9 @@ int sfm_ctx_destroy(sfm_ctx *ctx)
     for (sfm_ctx *l : ctx->lane) if (l) (void)sfm_ctx_destroy(l);
     for (hipEvent_t e : ctx->lane_ev) if (e) (void)hipEventDestroy(e);
     if (ctx->pool_records) (void)hipFree(ctx->pool_records);
+    if (ctx->views_pinned) (void)hipHostFree(ctx->views_pinned);
+    if (ctx->views_image) (void)hipFree(ctx->views_image);
+    if (ctx->views_ev) (void)hipEventDestroy(ctx->views_ev);
     sift_job_free(ctx);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     for (auto &t : ctx->tev) for (hipEvent_t e : t) if (e) (void)hipEventDestroy(e);
@@ -717,6 +720,80 @@ int sfm_copy_points_to_vbo(sfm_pair *pair, float *d_positions, float *d_velociti
     SFM_REQUIRE((((uintptr_t)d_positions | (uintptr_t)d_velocities) & 15u) == 0, SFM_E_INVALID, "vertex buffers must be 16-byte aligned");
     SFM_HIP_TRY(hipSetDevice(pair->ctx->device));
     return launch_points_to_vbo(pair, d_positions, d_velocities, scale);
+}
+
+// ---- many views: ExtractSift for a rank's share of the images --------------------------------------------------------
+static int views_buffers(sfm_ctx *c, size_t floats)
+{
+    if (!c->views_ev) SFM_HIP_TRY(hipEventCreateWithFlags(&c->views_ev, hipEventDisableTiming));
+    if (c->views_floats >= floats) return SFM_OK;
+    SFM_HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->views_pinned) (void)hipHostFree(c->views_pinned);
+    if (c->views_image) (void)hipFree(c->views_image);
+    c->views_pinned = nullptr; c->views_image = nullptr; c->views_floats = 0;
+    SFM_HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c->views_pinned), floats * sizeof(float), hipHostMallocDefault));
+    SFM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&c->views_image), floats * sizeof(float)));
+    c->views_floats = floats;
+    return SFM_OK;
+}
+
+int sfm_extract_views(sfm_ctx *ctx, const float *const *h_images, int num_views, int width, int height, int first, int stride,
+                      void *d_block, size_t slot_bytes, int max_pts, int num_octaves, double init_blur, float thresh,
+                      float lowest_scale, int scale_up, int *h_counts)
+{
+    SFM_REQUIRE(ctx && h_images && d_block, SFM_E_INVALID, "null argument");
+    SFM_REQUIRE(num_views >= 0 && first >= 0 && stride >= 1, SFM_E_INVALID, "bad view range");
+    SFM_REQUIRE(width > 0 && height > 0 && width <= 16384 && height <= 16384, SFM_E_INVALID, "image size %d x %d", width, height);
+    SFM_REQUIRE(num_octaves >= 1 && num_octaves <= 7 && max_pts > 0, SFM_E_INVALID, "bad extraction parameters");
+    SFM_REQUIRE(slot_bytes >= (size_t)max_pts * sizeof(sfm_sift_point) + 4 && slot_bytes % 16 == 0, SFM_E_INVALID,
+                "slot_bytes %zu: need max_pts records + the count, a multiple of 16", slot_bytes);
+    SFM_HIP_TRY(hipSetDevice(ctx->device));
+    // two contexts (the caller's + the first auxiliary lane): while one image is being extracted the next one is copied
+    // into pinned memory, uploaded and started on the other stream -- one image's per-level kernels leave most CUs idle
+    if (!ctx->lane[0]) {
+        int rc = sfm_ctx_create(ctx->device, &ctx->lane[0]);
+        if (rc == SFM_OK) rc = sfm_ctx_own_stream(ctx->lane[0]);
+        if (rc != SFM_OK) return rc;
+    }
+    sfm_ctx *cs[2] = { ctx, ctx->lane[0] };
+    const int pitch = round_up(width, 128);
+    const size_t floats = (size_t)pitch * height;
+    for (sfm_ctx *c : cs) { int rc = views_buffers(c, floats); if (rc != SFM_OK) return rc; }
+    SFM_HIP_TRY(hipEventRecord(ctx->views_ev, ctx->stream));                 // the lane starts after what the caller enqueued
+    SFM_HIP_TRY(hipStreamWaitEvent(cs[1]->stream, ctx->views_ev, 0));
+    char *block = static_cast<char *>(d_block);
+    int pending_slot[2] = { -1, -1 };
+    auto finish = [&](int k) -> int {
+        if (pending_slot[k] < 0) return SFM_OK;
+        int n = 0, stored = 0;
+        int rc = launch_extract_sift_end(cs[k], &n, &stored);                  // waits for this context's stream
+        if (rc != SFM_OK) return rc;
+        if (h_counts) h_counts[pending_slot[k]] = n;
+        SFM_HIP_TRY(hipMemcpyAsync(block + (size_t)pending_slot[k] * slot_bytes + (size_t)max_pts * sizeof(sfm_sift_point), &n, sizeof(int),
+                                   hipMemcpyHostToDevice, cs[k]->stream));
+        SFM_HIP_TRY(hipStreamSynchronize(cs[k]->stream));                      // `n` lives on this frame
+        pending_slot[k] = -1;
+        return SFM_OK;
+    };
+    int slot = 0;
+    for (int v = first; v < num_views; v += stride, ++slot) {
+        const int k = slot & 1;
+        int rc = finish(k);                                                    // this context's previous image (also frees its staging)
+        if (rc != SFM_OK) return rc;
+        SFM_REQUIRE(h_images[v], SFM_E_INVALID, "view %d: null image", v);
+        float *pin = cs[k]->views_pinned;
+        for (int y = 0; y < height; ++y) {
+            memcpy(pin + (size_t)y * pitch, h_images[v] + (size_t)y * width, (size_t)width * sizeof(float));
+            if (pitch > width) memset(pin + (size_t)y * pitch + width, 0, (size_t)(pitch - width) * sizeof(float));
+        }
+        SFM_HIP_TRY(hipMemcpyAsync(cs[k]->views_image, pin, floats * sizeof(float), hipMemcpyHostToDevice, cs[k]->stream));
+        rc = launch_extract_sift_begin(cs[k], reinterpret_cast<sfm_sift_point *>(block + (size_t)slot * slot_bytes), max_pts, cs[k]->views_image,
+                                       width, height, pitch, num_octaves, init_blur, thresh, lowest_scale, scale_up ? 1 : 0, nullptr);
+        if (rc != SFM_OK) return rc;
+        pending_slot[k] = slot;
+    }
+    for (int k = 0; k < 2; ++k) { int rc = finish(k); if (rc != SFM_OK) return rc; }
+    return SFM_OK;
 }
 
 // ---- many view pairs --------------------------------------------------------------------------------

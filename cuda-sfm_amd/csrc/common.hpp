@@ -55,6 +55,10 @@ struct sfm_ctx {
     sfm_ctx *lane[kPairLanes - 1] = {};
     hipEvent_t lane_ev[kPairLanes] = {};
     sfm_pair *pool_pair = nullptr;
+    // many-views front end (sfm_extract_views): pinned staging + device image, one per context
+    float *views_pinned = nullptr, *views_image = nullptr;
+    size_t views_floats = 0;
+    hipEvent_t views_ev = nullptr;
     float pool_K[9] = {}, pool_Kinv[9] = {};
     float *pool_records = nullptr;
     size_t pool_records_cap = 0;

@@ -255,6 +255,16 @@ int sfm_get_points(sfm_pair *pair, float *h_points /* 4 x num_points */);
 /* Everything a many-pairs driver keeps of one pair, with ONE synchronisation:
  * [E (9) | chosen pose 4x4 (16): P^-1 in SFM_POSE_REFERENCE, P in SFM_POSE_CORRECT | pose index, inlier count, best hypothesis]. */
 int sfm_get_result(sfm_pair *pair, float h_record[28]);
+/* Many views (BASELINE configs[4]), front end: ExtractSift (src/main.cpp:258-279 per image) for the views first,
+ * first + stride, ... of h_images (HOST images, width x height floats, tightly packed rows, grey values 0..255) into the
+ * slots 0, 1, ... of d_block: slot s = max_pts SiftPoint records followed by the int32 feature count, slot_bytes apart.
+ * Images go through pinned staging and two streams, so that upload and extraction of consecutive views overlap.
+ * h_counts (optional): feature count per owned view.  A multi-GPU caller all-gathers the blocks afterwards (one
+ * collective) and hands views to sfm_process_pairs.  Synchronous at the end. */
+int sfm_extract_views(sfm_ctx *ctx, const float *const *h_images, int num_views, int width, int height, int first, int stride,
+                      void *d_block, size_t slot_bytes, int max_pts, int num_octaves, double init_blur, float thresh,
+                      float lowest_scale, int scale_up, int *h_counts);
+
 /* Many view pairs (BASELINE configs[4]): the per-pair sequence of src/main.cpp:282-307 -- MatchSiftData (when d_sift2 is
  * given; it fills the match fields of d_sift1's records), fillXU, estimateE (num_hypotheses = 0: the reference's n1 / 8),
  * computePosecandidates, choosePose, linear_triangulation -- for the pairs first, first + stride, first + 2 stride, ... of
