@@ -57,6 +57,40 @@ def test_prefilter_fields_of_view(gpu, focal, noise):
     check_all(pair, scene, p, H, n)
 
 
+@pytest.mark.parametrize("focal", [4.0, 9.0])
+def test_prefilter_coordinates_beyond_the_fp16_feature_range(gpu, focal):
+    """A 4-pixel focal length puts normalised coordinates near +-90 (beyond the +-48 the fp16 features cover; 9 px: some
+    points in, some out): out-of-range points carry no features, so every pair with them survives and the exact test
+    alone decides -- slow, but the counts must not change."""
+    n, H = 1500, 16384
+    scene = synth.two_view_scene(n, seed=3, focal=focal, noise_px=0.01)
+    pair, _ = make_pair(S, gpu, scene)
+    p = S.default_params(n, num_hypotheses=H, seed=2, kernel=S.KERNEL_PREFILTER, threshold=1e-3)
+    pair.estimateE(p)
+    assert pair.last_launch()["kernel"] == S.KERNEL_PREFILTER
+    check_all(pair, scene, p, H, n)
+
+
+def test_prefilter_with_the_jacobi_solver_and_explicit_tuples(gpu):
+    """The scoring kernel is independent of where the candidates come from: normal equations + Jacobi, and the
+    reference-mode sampler (explicit 8-tuples, repeated to fill the range)."""
+    torch, dev, ctx = gpu
+    n, H = 2048, 16384
+    scene = synth.two_view_scene(n, seed=12)
+    pair, _ = make_pair(S, gpu, scene)
+    p = S.default_params(n, num_hypotheses=H, seed=4, kernel=S.KERNEL_PREFILTER, jacobi_sweeps=7)
+    pair.estimateE(p)
+    check_all(pair, scene, p, H, n)
+    rng = np.random.default_rng(1)
+    idx = np.stack([rng.choice(n, 8, replace=False) for _ in range(H)]).astype(np.int32).reshape(-1)
+    d_idx = torch.from_numpy(idx).to(dev)
+    q = S.default_params(n, num_hypotheses=H, kernel=S.KERNEL_PREFILTER, d_indices=d_idx)
+    pair.estimateE(q)
+    _, _, X0, X1 = O.fill_xu(scene["sift"], scene["Kinv"])
+    key, ocounts, _ = O.ransac_range(X0, X1, 0, H, q.threshold, q.jacobi_sweeps, indices=idx)
+    assert np.array_equal(pair.get_inlier_counts(H), ocounts) and pair.get_key() == key
+
+
 def test_prefilter_equals_split_at_bench_size(gpu):
     """The bench configuration: every one of the 2^20 counts equal to the plain wavefront kernel's (which the other tests
     pin to the oracle), same key, same E, same mask."""
