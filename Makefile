@@ -30,7 +30,7 @@ $(BUILD)/%.o: $(CSRC)/%.hip $(HDRS)
 
 $(LIB): $(OBJS)
 	@mkdir -p $(PKG)/lib
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS) -lpthread
 
 # the RCCL exchange step lives in its own library: libsfm_amd.so itself has no RCCL dependency
 $(COMMLIB): $(CSRC)/comm.cpp include/sfm_amd_comm.h include/sfm_amd.h $(LIB)

@@ -5,6 +5,8 @@
 #include <stdio.h>
 #include <string.h>
 #include <new>
+#include <atomic>
+#include <thread>
 #include <vector>
 
 namespace sfm {
@@ -758,45 +760,68 @@ int sfm_extract_views(sfm_ctx *ctx, const float *const *h_images, int num_views,
     sfm_ctx *cs[2] = { ctx, ctx->lane[0] };
     const int pitch = round_up(width, 128);
     const size_t floats = (size_t)pitch * height;
-    for (sfm_ctx *c : cs) { int rc = views_buffers(c, floats); if (rc != SFM_OK) return rc; }
+    // device image per context; FOUR pinned staging buffers (two per context) filled by a helper thread that runs ahead of
+    // the enqueueing thread: the row-by-row copy into pinned memory is the host-side cost of a view (~0.1 ms for 720 x 576,
+    // about what its extraction takes), so it must not sit between two enqueues
+    for (sfm_ctx *c : cs) { int rc = views_buffers(c, 2 * floats); if (rc != SFM_OK) return rc; }
+    float *ring[4] = { cs[0]->views_pinned, cs[1]->views_pinned, cs[0]->views_pinned + floats, cs[1]->views_pinned + floats };
+    float *image[2] = { cs[0]->views_image, cs[1]->views_image };
     SFM_HIP_TRY(hipEventRecord(ctx->views_ev, ctx->stream));                 // the lane starts after what the caller enqueued
     SFM_HIP_TRY(hipStreamWaitEvent(cs[1]->stream, ctx->views_ev, 0));
+    int nown = 0;
+    for (int v = first; v < num_views; v += stride) { SFM_REQUIRE(h_images[v], SFM_E_INVALID, "view %d: null image", v); ++nown; }
+    if (nown == 0) return SFM_OK;
+    std::atomic<int> staged(0), consumed(0), stop(0);
+    std::thread stager([&]() {
+        for (int i = 0; i < nown && !stop.load(std::memory_order_relaxed); ++i) {
+            while (i - consumed.load(std::memory_order_acquire) >= 4 && !stop.load(std::memory_order_relaxed)) std::this_thread::yield();
+            float *pin = ring[i & 3];
+            const float *src = h_images[first + i * stride];
+            for (int y = 0; y < height; ++y) {
+                memcpy(pin + (size_t)y * pitch, src + (size_t)y * width, (size_t)width * sizeof(float));
+                if (pitch > width) memset(pin + (size_t)y * pitch + width, 0, (size_t)(pitch - width) * sizeof(float));
+            }
+            staged.store(i + 1, std::memory_order_release);
+        }
+    });
     char *block = static_cast<char *>(d_block);
+    std::vector<int> counts((size_t)nown, 0);
     int pending_slot[2] = { -1, -1 };
     auto finish = [&](int k) -> int {
         if (pending_slot[k] < 0) return SFM_OK;
         int n = 0, stored = 0;
-        int rc = launch_extract_sift_end(cs[k], &n, &stored);                  // waits for this context's stream
+        int rc = launch_extract_sift_end(cs[k], &n, &stored);                  // waits for this context's stream: its upload is done too
         if (rc != SFM_OK) return rc;
-        if (h_counts) h_counts[pending_slot[k]] = n;
-        SFM_HIP_TRY(hipMemcpyAsync(block + (size_t)pending_slot[k] * slot_bytes + (size_t)max_pts * sizeof(sfm_sift_point), &n, sizeof(int),
-                                   hipMemcpyHostToDevice, cs[k]->stream));
-        SFM_HIP_TRY(hipStreamSynchronize(cs[k]->stream));                      // `n` lives on this frame
+        counts[(size_t)pending_slot[k]] = n;
+        consumed.store(pending_slot[k] + 1, std::memory_order_release);        // staging buffer pending_slot % 4 may be refilled
         pending_slot[k] = -1;
         return SFM_OK;
     };
-    int slot = 0;
-    for (int v = first; v < num_views; v += stride, ++slot) {
-        const int k = slot & 1;
-        int rc = finish(k);                                                    // this context's previous image (also frees its staging)
-        if (rc != SFM_OK) return rc;
-        SFM_REQUIRE(h_images[v], SFM_E_INVALID, "view %d: null image", v);
-        float *pin = cs[k]->views_pinned;
-        const float *src = h_images[v];
-        auto stage_rows = [=](int y0, int y1) {
-            for (int y = y0; y < y1; ++y) {
-                memcpy(pin + (size_t)y * pitch, src + (size_t)y * width, (size_t)width * sizeof(float));
-                if (pitch > width) memset(pin + (size_t)y * pitch + width, 0, (size_t)(pitch - width) * sizeof(float));
-            }
-        };
-        stage_rows(0, height);        // (three helper threads for this copy measured slower: 10.2 vs 8.6-9.1 ms per ring of 36)
-        SFM_HIP_TRY(hipMemcpyAsync(cs[k]->views_image, pin, floats * sizeof(float), hipMemcpyHostToDevice, cs[k]->stream));
-        rc = launch_extract_sift_begin(cs[k], reinterpret_cast<sfm_sift_point *>(block + (size_t)slot * slot_bytes), max_pts, cs[k]->views_image,
+    int rc = SFM_OK;
+    for (int i = 0; i < nown && rc == SFM_OK; ++i) {
+        const int k = i & 1;
+        rc = finish(k);                                                        // this context's previous view
+        if (rc != SFM_OK) break;
+        while (staged.load(std::memory_order_acquire) <= i) std::this_thread::yield();
+        hipError_t e = hipMemcpyAsync(image[k], ring[i & 3], floats * sizeof(float), hipMemcpyHostToDevice, cs[k]->stream);
+        if (e != hipSuccess) { set_error("view upload failed: %s", hipGetErrorString(e)); rc = SFM_E_HIP; break; }
+        rc = launch_extract_sift_begin(cs[k], reinterpret_cast<sfm_sift_point *>(block + (size_t)i * slot_bytes), max_pts, image[k],
                                        width, height, pitch, num_octaves, init_blur, thresh, lowest_scale, scale_up ? 1 : 0, nullptr);
-        if (rc != SFM_OK) return rc;
-        pending_slot[k] = slot;
+        if (rc == SFM_OK) pending_slot[k] = i;
     }
-    for (int k = 0; k < 2; ++k) { int rc = finish(k); if (rc != SFM_OK) return rc; }
+    for (int k = 0; k < 2 && rc == SFM_OK; ++k) rc = finish(k);
+    stop.store(1, std::memory_order_relaxed);
+    consumed.store(nown, std::memory_order_release);
+    stager.join();
+    if (rc != SFM_OK) {
+        for (int k = 0; k < 2; ++k) if (pending_slot[k] >= 0) { int n = 0; (void)launch_extract_sift_end(cs[k], &n, nullptr); }
+        return rc;
+    }
+    // the feature counts of all slots with ONE strided copy
+    SFM_HIP_TRY(hipMemcpy2DAsync(block + (size_t)max_pts * sizeof(sfm_sift_point), slot_bytes, counts.data(), sizeof(int), sizeof(int), (size_t)nown,
+                                 hipMemcpyHostToDevice, ctx->stream));
+    SFM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (h_counts) memcpy(h_counts, counts.data(), (size_t)nown * sizeof(int));
     return SFM_OK;
 }
 
