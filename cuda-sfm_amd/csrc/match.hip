@@ -281,9 +281,15 @@ int launch_match(sfm_ctx *ctx, const float *d1, int n1, int ld1, const float *d2
                  sfm_sift_point *sift1, const sfm_sift_point *sift2)
 {
     if (n1 <= 0 || n2 <= 0) return SFM_OK;                 // matching.cu:1095-1096
-    const int big = 5000;                                   // measured crossover of the two configurations (4500: 0.065 vs 0.074 ms, 5500: 0.105 vs 0.091)
-    const int ct = n1 > big ? 2 : 1;
-    const int wv = n1 > big ? 8 : 4;                       // wavefronts per block
+    // three configurations (column tiles per wavefront, wavefronts per block), crossovers measured with profiles/match_cfg_probe.py
+    // (TFLOP/s at n x n):  n      3000   4500   5500   7000   9000   10000  12000  14000  16384
+    //                      (1,4)  64     79     72     79     81
+    //                      (1,8)  58     78     91     98     105    104    110    106    123
+    //                      (2,8)  42     70     84     91     103    102    112    118    127
+    static const char *cfg_env = getenv("SFM_MATCH_CFG");    // profiling only: "ct,wv"
+    int ct = n1 > 11000 ? 2 : 1;
+    int wv = n1 > 4500 ? 8 : 4;                      // wavefronts per block
+    if (cfg_env && cfg_env[0] && cfg_env[1] && cfg_env[2]) { ct = cfg_env[0] == '2' ? 2 : 1; wv = cfg_env[2] == '8' ? 8 : 4; }
     const int qper = ct * 32 * wv;                          // queries per block
     const int qblocks = (n1 + qper - 1) / qper;
     // (query block, database split) pairs: as many as fit in ONE round over the CUs, not more -- rounding the split
@@ -317,6 +323,9 @@ int launch_match(sfm_ctx *ctx, const float *d1, int n1, int ld1, const float *d2
     const dim3 grid(qblocks, nsplit);
     if (ct == 2)
         hipLaunchKernelGGL((match_mfma_kernel<2, 8>), grid, dim3(512), 0, ctx->stream,
+                           d1, n1, ld1, d2, n2, ld2, rows_per_split, wb, wsnd, wi, tickets, d_best, d_second, d_index, sift1, sift2);
+    else if (wv == 8)
+        hipLaunchKernelGGL((match_mfma_kernel<1, 8>), grid, dim3(512), 0, ctx->stream,
                            d1, n1, ld1, d2, n2, ld2, rows_per_split, wb, wsnd, wi, tickets, d_best, d_second, d_index, sift1, sift2);
     else
         hipLaunchKernelGGL((match_mfma_kernel<1, 4>), grid, dim3(256), 0, ctx->stream,
