@@ -55,6 +55,9 @@ def parse_args(argv=None):
                          "ncclAllReduce(max, u64) + finalize on the communicator's exchange stream, overlapped with the next "
                          "step's scoring); rccl-serial = sfm_estimate_E_sharded (everything on ONE stream, no overlap); "
                          "torch = torch.distributed.all_reduce")
+    ap.add_argument("--serial", action="store_true",
+                    help="one estimateE at a time (sfm_estimate_E / sfm_estimate_E_sharded) instead of the two-slot pipelined calls "
+                         "(sfm_estimate_E_pipelined / sfm_estimate_E_sharded_pipelined) in which consecutive steps overlap on the device")
     ap.add_argument("--reserved", type=int, nargs="*", default=[], help="sfm_ransac_params.reserved[] A/B switches (profiles/)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-variants", action="store_true", help="skip the short run with the other null-vector solver")
@@ -220,6 +223,9 @@ def rank_main(args):
 
     comm = None
     mode = args.comm if world > 1 else "none"
+    if args.serial and mode == "rccl":
+        mode = "rccl-serial"
+    pipelined = (mode == "rccl") or (mode == "none" and not args.serial)
     if mode in ("rccl", "rccl-serial"):
         uid = [S.Comm.unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)            # the out-of-band hand-over of the ncclUniqueId
@@ -232,12 +238,16 @@ def rank_main(args):
             comm.estimate_E(pair, params)
         elif mode == "torch":
             S.estimate_E_distributed(pair, params, rank, world, key_t, reduce_max)
+        elif pipelined:
+            pair.estimateE_pipelined(params)              # two slots: consecutive steps overlap on the device
         else:
             pair.estimateE(params)
 
     def fence():
         if comm is not None:
             comm.flush()                                  # the context stream waits for the exchange stream's last finalize
+        elif pipelined:
+            pair.flush()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -301,8 +311,11 @@ def rank_main(args):
         solve_s = solve_ms / 1e3 / max(calls, 1)
         flops = float(local_hyps) * FLOP_PER_POINT * n
         achieved = flops / score_s / 1e12 if score_s > 0 else 0.0
+        step_mode = ("two-slot pipelined calls: step k + 1 is solved and scored on a second stream and buffer set while step k is still "
+                     "running (sfm_estimate_E_pipelined / sfm_estimate_E_sharded_pipelined); --serial times one call at a time"
+                     if pipelined else "serial: one estimateE at a time")
         exchange = {"none": "none",
-                    "rccl": "ncclAllReduce(max, u64) + finalize on the communicator's exchange stream, overlapped with the next step's scoring (libsfm_amd_rccl.so, sfm_estimate_E_sharded_pipelined)",
+                    "rccl": "ncclAllReduce(max, u64) + finalize on the communicator's exchange stream, overlapped with the next step's solve + scoring (libsfm_amd_rccl.so, sfm_estimate_E_sharded_pipelined)",
                     "rccl-serial": "ncclAllReduce(max, u64) on the compute stream (libsfm_amd_rccl.so, sfm_estimate_E_sharded)",
                     "torch": "torch.distributed all_reduce(MAX), 8 bytes"}[mode]
         launch = pair.last_launch()
@@ -341,7 +354,7 @@ def rank_main(args):
                        "matches": n, "hypotheses_per_step": H, "threshold": params.threshold,
                        "jacobi_sweeps": params.jacobi_sweeps,
                        "solver": "householder QR of the 8x9 system" if params.jacobi_sweeps == 0 else f"normal equations + {params.jacobi_sweeps} Jacobi sweeps",
-                       "kernel": dict(launch, name=kname), "exchange": exchange,
+                       "kernel": dict(launch, name=kname), "step_mode": step_mode, "exchange": exchange,
                        "nccl_ranks": comm.nccl_ranks() if comm is not None else (world if mode == "torch" else 1),
                        "per_rank_kernel_ms": [{"rank": r, "solve": v[0], "score": v[1], "shader_clock_mhz": v[2]} for r, v in enumerate(per_rank)]},
             "roofline": {"bound": "valu_fp32",

@@ -53,7 +53,7 @@ EXPORTS = [
     "sfm_copy_to_host_2d", "sfm_copy_to_device_2d", "sfm_find_homography", "sfm_sift_temp_layout", "sfm_extract_sift", "sfm_extract_sift_begin", "sfm_extract_sift_end", "sfm_match", "sfm_match_soa",
     "sfm_pair_create", "sfm_pair_destroy", "sfm_pair_reset", "sfm_get_result", "sfm_fill_xu", "sfm_set_points", "sfm_ransac_default_params",
     "sfm_ransac_permutation_indices", "sfm_estimate_E", "sfm_ransac_score", "sfm_ransac_score_into", "sfm_ransac_finalize",
-    "sfm_ransac_finalize_key", "sfm_ransac_finalize_key_on", "sfm_ransac_export_key", "sfm_pose_candidates", "sfm_choose_pose", "sfm_triangulate",
+    "sfm_ransac_finalize_key", "sfm_ransac_finalize_key_on", "sfm_ransac_score_into_slot", "sfm_estimate_E_pipelined", "sfm_pair_flush", "sfm_ransac_export_key", "sfm_pose_candidates", "sfm_choose_pose", "sfm_triangulate",
     "sfm_pair_device_ptr", "sfm_pair_ld", "sfm_pair_num_points", "sfm_get_XU", "sfm_get_E", "sfm_get_best",
     "sfm_get_key", "sfm_get_inlier_counts", "sfm_get_inlier_mask", "sfm_get_E_candidates",
     "sfm_get_pose_candidates", "sfm_get_pose_inverses", "sfm_get_pose_index", "sfm_get_points", "sfm_copy_points_to_vbo",
@@ -111,6 +111,8 @@ _lib.sfm_ransac_score_into.argtypes = [_vp, C.POINTER(RansacParams), _vp]
 _lib.sfm_ransac_finalize.argtypes = [_vp, C.POINTER(RansacParams), C.c_uint32]
 _lib.sfm_ransac_finalize_key.argtypes = [_vp, C.POINTER(RansacParams), _vp]
 _lib.sfm_ransac_finalize_key_on.argtypes = [_vp, C.POINTER(RansacParams), _vp, _vp]
+_lib.sfm_estimate_E_pipelined.argtypes = [_vp, C.POINTER(RansacParams)]
+_lib.sfm_pair_flush.argtypes = [_vp]
 _lib.sfm_ransac_export_key.argtypes = [_vp, _vp]
 _lib.sfm_pose_candidates.argtypes = [_vp, C.c_int]
 _lib.sfm_choose_pose.argtypes = [_vp, C.c_int]
@@ -355,6 +357,13 @@ class ImagePair:
 
     def ransac_finalize_key(self, params, d_key):
         _check(_lib.sfm_ransac_finalize_key(self._h, C.byref(params), _ptr(d_key)), "sfm_ransac_finalize_key")
+
+    def estimateE_pipelined(self, params):
+        """estimateE for a stream of calls: consecutive calls overlap on the device (two slots); flush() before the pose stages."""
+        _check(_lib.sfm_estimate_E_pipelined(self._h, C.byref(params)), "sfm_estimate_E_pipelined")
+
+    def flush(self):
+        _check(_lib.sfm_pair_flush(self._h), "sfm_pair_flush")
 
     def ransac_finalize_key_on(self, params, d_key, hip_stream=None):
         """finalize on another stream of the device (None = the context's); E is re-derived from the hypothesis id."""

@@ -6,6 +6,7 @@
 #include <string.h>
 #include <new>
 #include <atomic>
+#include <utility>
 #include <thread>
 #include <vector>
 
@@ -47,6 +48,7 @@ static int resolve_shard(const sfm_pair *pair, const sfm_ransac_params *p, uint3
 
 static int copy_out(sfm_pair *pair, void *h_dst, const void *d_src, size_t bytes)
 {
+    if (pair->pipe_pending) { int rcf = sfm_pair_flush(pair); if (rcf != SFM_OK) return rcf; }
     SFM_HIP_TRY(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, pair->ctx->stream));
     SFM_HIP_TRY(hipStreamSynchronize(pair->ctx->stream));
     return SFM_OK;
@@ -400,6 +402,7 @@ int sfm_pair_create(sfm_ctx *ctx, const float h_K[9], const float h_Kinv[9], int
 int sfm_pair_reset(sfm_pair *pair, int num_points)
 {
     SFM_REQUIRE(pair, SFM_E_INVALID, "null pair");
+    if (pair->pipe_pending) { const int rcf = sfm_pair_flush(pair); if (rcf != SFM_OK) return rcf; }
     SFM_REQUIRE(num_points > 0 && num_points <= pair->cap_points, SFM_E_INVALID,
                 "num_points %d outside (0, %d] (the size the pair was created with)", num_points, pair->cap_points);
     pair->n = num_points;
@@ -414,8 +417,13 @@ int sfm_pair_destroy(sfm_pair *p)
     if (!p) return SFM_OK;
     if (p->ctx) { (void)hipSetDevice(p->ctx->device); (void)hipStreamSynchronize(p->ctx->stream); }
     void *bufs[] = { p->d_K, p->d_Kinv, p->d_U[0], p->d_U[1], p->d_X[0], p->d_X[1], p->d_E, p->d_P, p->d_Pinv, p->d_Pind,
-                     p->d_points, p->d_mask, p->d_key, p->d_best, p->d_counts, p->d_Ecand, p->d_clk, p->d_tick };
+                     p->d_points, p->d_mask, p->d_key, p->d_best, p->d_counts, p->d_Ecand, p->d_clk, p->d_tick,
+                     p->alt_counts, p->alt_Ecand, p->alt_tick, p->alt_key };
     for (void *b : bufs) if (b) (void)hipFree(b);
+    if (p->pipe_stream) { (void)hipStreamSynchronize(p->pipe_stream); (void)hipStreamDestroy(p->pipe_stream); }
+    for (hipEvent_t e : p->pipe_final) if (e) (void)hipEventDestroy(e);
+    if (p->pipe_call) (void)hipEventDestroy(p->pipe_call);
+    if (p->pipe_keys) (void)hipFree(p->pipe_keys);
     delete p;
     return SFM_OK;
 }
@@ -423,6 +431,7 @@ int sfm_pair_destroy(sfm_pair *p)
 int sfm_fill_xu(sfm_pair *pair, const sfm_sift_point *d_data)
 {
     SFM_REQUIRE(pair && d_data, SFM_E_INVALID, "null argument");
+    if (pair->pipe_pending) { const int rcf = sfm_pair_flush(pair); if (rcf != SFM_OK) return rcf; }
     SFM_HIP_TRY(hipSetDevice(pair->ctx->device));
     int rc = launch_fill_xu(pair, d_data);
     if (rc == SFM_OK) {
@@ -437,6 +446,7 @@ int sfm_fill_xu(sfm_pair *pair, const sfm_sift_point *d_data)
 int sfm_set_points(sfm_pair *pair, const float *d_X0, const float *d_X1)
 {
     SFM_REQUIRE(pair && d_X0 && d_X1, SFM_E_INVALID, "null argument");
+    if (pair->pipe_pending) { const int rcf = sfm_pair_flush(pair); if (rcf != SFM_OK) return rcf; }
     SFM_HIP_TRY(hipSetDevice(pair->ctx->device));
     int rc = launch_set_points(pair, d_X0, d_X1);
     if (rc == SFM_OK) { pair->have_points = true; pair->have_E = pair->have_P = pair->have_pose = pair->have_points3d = false; pair->last_count = 0; pair->unit_z = false; }
@@ -467,6 +477,7 @@ int sfm_ransac_score(sfm_pair *pair, const sfm_ransac_params *p)
     uint32_t h0, count;
     int rc = resolve_shard(pair, p, &h0, &count);
     if (rc != SFM_OK) return rc;
+    if (pair->pipe_pending) { const int rcf = sfm_pair_flush(pair); if (rcf != SFM_OK) return rcf; }
     SFM_HIP_TRY(hipSetDevice(pair->ctx->device));
     return launch_ransac_score(pair, *p, h0, count);
 }
@@ -477,8 +488,85 @@ int sfm_ransac_score_into(sfm_pair *pair, const sfm_ransac_params *p, uint64_t *
     uint32_t h0, count;
     int rc = resolve_shard(pair, p, &h0, &count);
     if (rc != SFM_OK) return rc;
+    if (pair->pipe_pending) { const int rcf = sfm_pair_flush(pair); if (rcf != SFM_OK) return rcf; }
     SFM_HIP_TRY(hipSetDevice(pair->ctx->device));
     return launch_ransac_score(pair, *p, h0, count, reinterpret_cast<unsigned long long *>(d_key_out));
+}
+
+int sfm_ransac_score_into_slot(sfm_pair *pair, const sfm_ransac_params *p, uint64_t *d_key_out, int slot, void *hip_stream)
+{
+    SFM_REQUIRE(d_key_out, SFM_E_INVALID, "null key pointer");
+    SFM_REQUIRE(slot == 0 || slot == 1, SFM_E_INVALID, "slot must be 0 or 1");
+    uint32_t h0, count;
+    int rc = resolve_shard(pair, p, &h0, &count);
+    if (rc != SFM_OK) return rc;
+    SFM_HIP_TRY(hipSetDevice(pair->ctx->device));
+    // the launchers work on the pair's current per-shard buffers and the context's stream: lend them slot 1's buffers and
+    // the caller's stream for the duration of the (asynchronous) launches -- kernel arguments are captured at launch
+    if (slot == 1 && !pair->alt_key) {
+        SFM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&pair->alt_key), 2 * sizeof(unsigned long long)));
+        SFM_HIP_TRY(hipMemset(pair->alt_key, 0, 2 * sizeof(unsigned long long)));
+    }
+    auto swap_slot = [&]() {
+        std::swap(pair->d_counts, pair->alt_counts); std::swap(pair->d_tick, pair->alt_tick);
+        std::swap(pair->d_Ecand, pair->alt_Ecand); std::swap(pair->cap_hyps, pair->alt_cap_hyps);
+        std::swap(pair->d_key, pair->alt_key);
+    };
+    hipStream_t keep = pair->ctx->stream;
+    if (slot == 1) swap_slot();
+    if (hip_stream) pair->ctx->stream = static_cast<hipStream_t>(hip_stream);
+    rc = launch_ransac_score(pair, *p, h0, count, reinterpret_cast<unsigned long long *>(d_key_out));
+    pair->ctx->stream = keep;
+    if (slot == 1) swap_slot();
+    pair->last_count = 0;                         // the candidates / counts of a slot are not what the plain getters describe
+    return rc;
+}
+
+// Image_pair::estimateE for a STREAM of calls: step k runs on slot k % 2 (its own stream and per-shard buffers), so that
+// consecutive calls overlap -- the next call's lane-solve kernel and launch gaps fill what this call's scoring kernel
+// leaves idle.  Results (E, mask, best) are those of the last call once sfm_pair_flush has run.
+int sfm_estimate_E_pipelined(sfm_pair *pair, const sfm_ransac_params *p)
+{
+    uint32_t h0, count;
+    int rc = resolve_shard(pair, p, &h0, &count);
+    if (rc != SFM_OK) return rc;
+    SFM_REQUIRE(count > 0, SFM_E_INVALID, "empty hypothesis range");
+    sfm_ctx *ctx = pair->ctx;
+    SFM_HIP_TRY(hipSetDevice(ctx->device));
+    if (!pair->pipe_stream) {
+        SFM_HIP_TRY(hipStreamCreateWithFlags(&pair->pipe_stream, hipStreamNonBlocking));
+        for (hipEvent_t &e : pair->pipe_final) SFM_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        SFM_HIP_TRY(hipEventCreateWithFlags(&pair->pipe_call, hipEventDisableTiming));
+        SFM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&pair->pipe_keys), 2 * sizeof(uint64_t)));
+    }
+    const int slot = (int)(pair->pipe_step & 1ull);
+    hipStream_t st = slot ? pair->pipe_stream : ctx->stream;
+    // What the caller enqueued on the context stream BEFORE this burst of pipelined calls (the points) must come first on
+    // the second stream too -- marked once, when the burst starts: an event recorded later would sit behind the previous
+    // step's kernels and serialise the two slots.
+    if (!pair->pipe_pending) SFM_HIP_TRY(hipEventRecord(pair->pipe_call, ctx->stream));
+    if (slot) SFM_HIP_TRY(hipStreamWaitEvent(st, pair->pipe_call, 0));
+    rc = sfm_ransac_score_into_slot(pair, p, pair->pipe_keys + slot, slot, st);
+    if (rc != SFM_OK) return rc;
+    // E, mask and best exist once: the finalizes of consecutive steps keep their order across the two streams
+    if (pair->pipe_step >= 1) SFM_HIP_TRY(hipStreamWaitEvent(st, pair->pipe_final[slot ^ 1], 0));
+    rc = launch_ransac_finalize(pair, *p, reinterpret_cast<const unsigned long long *>(pair->pipe_keys + slot), 0, true, st, true);
+    if (rc != SFM_OK) return rc;
+    SFM_HIP_TRY(hipEventRecord(pair->pipe_final[slot], st));
+    pair->pipe_step++;
+    pair->pipe_pending = true;
+    pair->have_E = true; pair->have_P = pair->have_pose = pair->have_points3d = false;
+    return SFM_OK;
+}
+
+int sfm_pair_flush(sfm_pair *pair)
+{
+    SFM_REQUIRE(pair, SFM_E_INVALID, "null pair");
+    if (!pair->pipe_pending) return SFM_OK;
+    const int last = (int)((pair->pipe_step - 1) & 1ull);
+    SFM_HIP_TRY(hipStreamWaitEvent(pair->ctx->stream, pair->pipe_final[last], 0));     // the finalizes are ordered: the last one covers all
+    pair->pipe_pending = false;
+    return SFM_OK;
 }
 
 int sfm_ransac_finalize(sfm_pair *pair, const sfm_ransac_params *p, uint32_t hyp)
@@ -486,6 +574,7 @@ int sfm_ransac_finalize(sfm_pair *pair, const sfm_ransac_params *p, uint32_t hyp
     uint32_t h0, count;
     int rc = resolve_shard(pair, p, &h0, &count);
     if (rc != SFM_OK) return rc;
+    if (pair->pipe_pending) { const int rcf = sfm_pair_flush(pair); if (rcf != SFM_OK) return rcf; }
     SFM_REQUIRE(hyp < p->num_hypotheses, SFM_E_INVALID, "hypothesis id %u out of range", hyp);
     SFM_HIP_TRY(hipSetDevice(pair->ctx->device));
     rc = launch_ransac_finalize(pair, *p, nullptr, hyp, false);
@@ -506,6 +595,7 @@ int sfm_ransac_finalize_key(sfm_pair *pair, const sfm_ransac_params *p, const ui
     uint32_t h0, count;
     int rc = resolve_shard(pair, p, &h0, &count);
     if (rc != SFM_OK) return rc;
+    if (pair->pipe_pending) { const int rcf = sfm_pair_flush(pair); if (rcf != SFM_OK) return rcf; }
     SFM_REQUIRE(d_key, SFM_E_INVALID, "null key pointer");
     SFM_HIP_TRY(hipSetDevice(pair->ctx->device));
     rc = launch_ransac_finalize(pair, *p, reinterpret_cast<const unsigned long long *>(d_key), 0, true);
@@ -531,6 +621,7 @@ int sfm_estimate_E(sfm_pair *pair, const sfm_ransac_params *p)
     uint32_t h0, count;
     int rc = resolve_shard(pair, p, &h0, &count);
     if (rc != SFM_OK) return rc;
+    if (pair->pipe_pending) { const int rcf = sfm_pair_flush(pair); if (rcf != SFM_OK) return rcf; }
     SFM_REQUIRE(count > 0, SFM_E_INVALID, "empty hypothesis range");
     SFM_HIP_TRY(hipSetDevice(pair->ctx->device));
     rc = launch_ransac_score(pair, *p, h0, count);
@@ -543,6 +634,7 @@ int sfm_estimate_E(sfm_pair *pair, const sfm_ransac_params *p)
 int sfm_pose_candidates(sfm_pair *pair, int mode)
 {
     SFM_REQUIRE(pair, SFM_E_INVALID, "null pair");
+    if (pair->pipe_pending) { const int rcf = sfm_pair_flush(pair); if (rcf != SFM_OK) return rcf; }
     SFM_REQUIRE(mode == SFM_POSE_REFERENCE || mode == SFM_POSE_CORRECT, SFM_E_INVALID, "unknown pose mode %d", mode);
     SFM_REQUIRE(pair->have_E, SFM_E_STATE, "computePosecandidates before estimateE");
     SFM_HIP_TRY(hipSetDevice(pair->ctx->device));

@@ -17,8 +17,9 @@ struct sfm_comm {
     // pipelined exchange (sfm_estimate_E_sharded_pipelined): the all-reduce and the finalize of pair k run on `xstream`
     // while the context stream already scores pair k+1; two key slots, one event pair per slot
     hipStream_t xstream = nullptr;
+    hipStream_t sstream = nullptr;      // odd steps are scored here, even steps on the context stream
     uint64_t *d_keys = nullptr;         // 2 x 8 bytes
-    hipEvent_t ev_scored[2] = { nullptr, nullptr }, ev_final[2] = { nullptr, nullptr };
+    hipEvent_t ev_scored[2] = { nullptr, nullptr }, ev_final[2] = { nullptr, nullptr }, ev_call = nullptr;
     unsigned long long step = 0;
     bool final_pending = false;
 };
@@ -66,6 +67,8 @@ static int ensure_pipeline(sfm_comm *c)
 {
     if (c->xstream) return SFM_OK;
     COMM_HIP_TRY(hipStreamCreateWithFlags(&c->xstream, hipStreamNonBlocking));
+    COMM_HIP_TRY(hipStreamCreateWithFlags(&c->sstream, hipStreamNonBlocking));
+    COMM_HIP_TRY(hipEventCreateWithFlags(&c->ev_call, hipEventDisableTiming));
     COMM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&c->d_keys), 2 * sizeof(uint64_t)));
     for (int i = 0; i < 2; ++i) {
         COMM_HIP_TRY(hipEventCreateWithFlags(&c->ev_scored[i], hipEventDisableTiming));
@@ -79,6 +82,7 @@ extern "C" int sfm_comm_destroy(sfm_comm *c)
     if (!c) return SFM_OK;
     (void)sfm_ctx_synchronize(c->ctx);
     if (c->xstream) (void)hipStreamSynchronize(c->xstream);
+    if (c->sstream) (void)hipStreamSynchronize(c->sstream);
     if (c->nccl) (void)ncclCommDestroy(c->nccl);
     for (int i = 0; i < 2; ++i) {
         if (c->ev_scored[i]) (void)hipEventDestroy(c->ev_scored[i]);
@@ -86,6 +90,8 @@ extern "C" int sfm_comm_destroy(sfm_comm *c)
     }
     if (c->d_keys) (void)hipFree(c->d_keys);
     if (c->xstream) (void)hipStreamDestroy(c->xstream);
+    if (c->sstream) (void)hipStreamDestroy(c->sstream);
+    if (c->ev_call) (void)hipEventDestroy(c->ev_call);
     delete c;
     return SFM_OK;
 }
@@ -133,11 +139,13 @@ extern "C" int sfm_estimate_E_sharded(sfm_pair *pair, sfm_ransac_params *p, sfm_
     return sfm_ransac_finalize_key(pair, p, static_cast<const uint64_t *>(d_key));
 }
 
-// The same step, software-pipelined over consecutive calls: step k's scoring is enqueued on the context stream, its
-// all-reduce + finalize on the exchange stream behind an event, and the call returns; step k+1's scoring therefore starts
-// while step k's 8 bytes are still in flight (the all-reduce is pure latency, ~tens of microseconds, the kernels of a
-// shard take a few hundred).  Key slot k % 2 is re-used only after step k-2's finalize has read it (event).  The pair's
-// results (E, mask, best) belong to the LAST finished step; sfm_comm_flush orders them before the context stream.
+// The same step, software-pipelined over consecutive calls.  Step k uses slot k % 2: its shard is solved and scored on the
+// slot's stream (slot 0: the context stream, slot 1: a stream of the communicator) into the slot's buffers, its all-reduce
+// and finalize follow on the exchange stream behind an event, and the call returns.  Step k+1 therefore runs next to step
+// k: its lane-solve kernel and launch gaps fill what step k's scoring kernel leaves idle (155 -> 119 us per
+// 131072-hypothesis shard on one GPU, profiles/overlap_probe.py) and step k's 8 bytes travel meanwhile.  A slot is
+// re-used only after its previous finalize has read the key (event).  The pair's results (E, mask, best) belong to the
+// LAST finished step; sfm_comm_flush orders everything before the context stream.
 extern "C" int sfm_estimate_E_sharded_pipelined(sfm_pair *pair, sfm_ransac_params *p, sfm_comm *c)
 {
     if (!pair || !p || !c) return SFM_E_INVALID;
@@ -147,13 +155,18 @@ extern "C" int sfm_estimate_E_sharded_pipelined(sfm_pair *pair, sfm_ransac_param
     void *stream_v = nullptr;
     rc = sfm_ctx_get_stream(c->ctx, &stream_v);
     if (rc != SFM_OK) return rc;
-    hipStream_t stream = static_cast<hipStream_t>(stream_v);
+    hipStream_t cstream = static_cast<hipStream_t>(stream_v);
     const int slot = (int)(c->step & 1ull);
+    hipStream_t sstream = slot ? c->sstream : cstream;
     uint64_t *d_key = c->d_keys + slot;
-    if (c->step >= 2) COMM_HIP_TRY(hipStreamWaitEvent(stream, c->ev_final[slot], 0));      // slot free again
-    rc = sfm_ransac_score_into(pair, p, d_key);
+    // what the caller enqueued on the context stream BEFORE this burst of pipelined calls (the points) comes first on the
+    // second scoring stream too; marked once per burst -- an event recorded later would sit behind the previous step's kernels
+    if (!c->final_pending) COMM_HIP_TRY(hipEventRecord(c->ev_call, cstream));
+    if (slot) COMM_HIP_TRY(hipStreamWaitEvent(sstream, c->ev_call, 0));
+    if (c->step >= 2) COMM_HIP_TRY(hipStreamWaitEvent(sstream, c->ev_final[slot], 0));      // slot (key + buffers) free again
+    rc = sfm_ransac_score_into_slot(pair, p, d_key, slot, sstream);
     if (rc != SFM_OK) return rc;
-    COMM_HIP_TRY(hipEventRecord(c->ev_scored[slot], stream));
+    COMM_HIP_TRY(hipEventRecord(c->ev_scored[slot], sstream));
     COMM_HIP_TRY(hipStreamWaitEvent(c->xstream, c->ev_scored[slot], 0));
     COMM_NCCL_TRY(ncclAllReduce(d_key, d_key, 1, ncclUint64, ncclMax, c->nccl, c->xstream));
     rc = sfm_ransac_finalize_key_on(pair, p, d_key, c->xstream);
@@ -173,8 +186,11 @@ extern "C" int sfm_comm_flush(sfm_comm *c)
     void *stream_v = nullptr;
     int rc = sfm_ctx_get_stream(c->ctx, &stream_v);
     if (rc != SFM_OK) return rc;
+    // both slots: the finalizes run in order on the exchange stream, but the OTHER slot's scoring stream must be idle too
+    // before the caller touches the pair again
     const int last = (int)((c->step - 1) & 1ull);
     COMM_HIP_TRY(hipStreamWaitEvent(static_cast<hipStream_t>(stream_v), c->ev_final[last], 0));
+    if (c->step >= 2) COMM_HIP_TRY(hipStreamWaitEvent(static_cast<hipStream_t>(stream_v), c->ev_final[last ^ 1], 0));
     c->final_pending = false;
     return SFM_OK;
 }

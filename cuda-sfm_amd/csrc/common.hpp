@@ -111,6 +111,18 @@ struct sfm_pair {
     uint32_t cand_h0 = 0, cand_seed = 0;   // what d_Ecand currently holds: shard start, sampler settings
     const int32_t *cand_indices = nullptr;
     int cand_sweeps = 0;
+    // second set of the per-shard buffers (sfm_ransac_score_into_slot, slot 1): two shards in flight on two streams
+    int   *alt_counts = nullptr;
+    uint32_t *alt_tick = nullptr;
+    float *alt_Ecand = nullptr;
+    unsigned long long *alt_key = nullptr;   // slot 1's internal key (the fused / MFMA families reduce into the pair's key, then copy)
+    size_t alt_cap_hyps = 0;
+    // sfm_estimate_E_pipelined: odd steps run on this stream, even steps on the context's; one event per slot
+    hipStream_t pipe_stream = nullptr;
+    hipEvent_t pipe_final[2] = { nullptr, nullptr }, pipe_call = nullptr;
+    uint64_t *pipe_keys = nullptr;
+    unsigned long long pipe_step = 0;
+    bool pipe_pending = false;
     bool have_points = false, have_E = false, have_P = false, have_pose = false;
     bool have_points3d = false;        // linear_triangulation ran for the current pose (sfm_get_points / VBO export need it)
     bool unit_z = false;               // every X z-coordinate is exactly 1 (fillXU with K^-1 last row (0 0 1))

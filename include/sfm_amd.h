@@ -196,6 +196,14 @@ int sfm_ransac_permutation_indices(sfm_ctx *ctx, int num_points, uint32_t seed, 
  * maximum, thrust::max_element semantics without the off-by-one of sfm.cu:137), winner's E and
  * inlier mask.  No host synchronisation. */
 int sfm_estimate_E(sfm_pair *pair, const sfm_ransac_params *p);
+/* estimateE for a STREAM of calls (many pairs, repeated estimates): step k runs on slot k % 2 -- a stream and a set of
+ * per-shard buffers of its own -- so consecutive calls overlap on the device (the lane-solve kernel and the launch gaps
+ * of one call fill what the scoring kernel of the other leaves idle: 851 -> 815 us per call at 2^20 hypotheses,
+ * 155 -> 119 us at 131072; profiles/overlap_probe.py).  E, mask and best are those of the last call once
+ * sfm_pair_flush has made the context stream wait for it; the sfm_get_* readers flush by themselves, the pose stages
+ * and sfm_fill_xu need an explicit sfm_pair_flush first. */
+int sfm_estimate_E_pipelined(sfm_pair *pair, const sfm_ransac_params *p);
+int sfm_pair_flush(sfm_pair *pair);
 /* The same in two steps for multi-GPU use: score the local shard (device key = (count << 32) |
  * (0xFFFFFFFF - hyp), 0 if the shard is empty), exchange keys with one all-reduce(max), then
  * finalize the winning hypothesis id on every rank. */
@@ -208,6 +216,13 @@ int sfm_ransac_export_key(sfm_pair *pair, uint64_t *d_key_out);
  * blocks write both copies, so the multi-GPU step needs no export in between. */
 int sfm_ransac_score_into(sfm_pair *pair, const sfm_ransac_params *p, uint64_t *d_key_out);
 int sfm_ransac_finalize_key(sfm_pair *pair, const sfm_ransac_params *p, const uint64_t *d_key);
+/* sfm_ransac_score_into on one of TWO sets of per-shard buffers (slot 0 = the pair's usual ones, slot 1 = a second set,
+ * allocated on first use) and on the given stream of the same device (NULL = the context's): consecutive shards -- of the
+ * same pair or of a stream of calls -- can then be in flight together (one's lane-solve kernel fills the tail and the
+ * launch gaps of the other's scoring kernel: 155 -> 119 us per 131072-hypothesis shard, profiles/overlap_probe.py).
+ * The caller orders the streams and re-uses a slot only after its key has been consumed; sfm_get_inlier_counts /
+ * sfm_get_E_candidates do not describe slot shards. */
+int sfm_ransac_score_into_slot(sfm_pair *pair, const sfm_ransac_params *p, uint64_t *d_key_out, int slot, void *hip_stream);
 /* sfm_ransac_finalize_key enqueued on ANOTHER stream of the same device (NULL = the context's): for callers that overlap
  * pair k's exchange + finalize with pair k+1's scoring (sfm_amd_comm.h, sfm_estimate_E_sharded_pipelined).  The winner's E
  * is always re-derived from the hypothesis id (bit-identical to the scored candidate), never read from the candidate

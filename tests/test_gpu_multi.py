@@ -87,3 +87,33 @@ def test_two_ranks_rccl():
     assert r.returncode == 0, r.stderr[-2000:]
     rec = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert rec["ok"] and rec["world"] == 2 and rec["nccl_ranks"] == 2
+
+
+def test_estimate_E_pipelined_equals_estimateE(gpu):
+    """sfm_estimate_E_pipelined: consecutive calls alternate between two slots (stream + per-shard buffers) and overlap on
+    the device.  Interleaved seeds and sizes, readers flush by themselves: the result is always the LAST call's, equal to
+    sfm_estimate_E bit for bit; the pose stages after an explicit flush; fillXU after pipelined calls flushes too."""
+    torch, dev, ctx = gpu
+    n = 3000
+    scene = synth.two_view_scene(n, seed=41)
+    pair, d_sift = make_pair(S, gpu, scene)
+    refs = {}
+    for seed, H in ((9, 50000), (10, 50000), (11, 300), (12, 140000)):
+        p = S.default_params(n, num_hypotheses=H, seed=seed)
+        pair.estimateE(p)
+        refs[(seed, H)] = (pair.get_best(), pair.get_E().copy(), pair.get_inlier_mask().copy())
+    order = [(9, 50000), (10, 50000), (12, 140000), (11, 300), (10, 50000), (9, 50000), (12, 140000)]
+    for upto in range(1, len(order) + 1):
+        for seed, H in order[:upto]:
+            pair.estimateE_pipelined(S.default_params(n, num_hypotheses=H, seed=seed))
+        want = refs[order[upto - 1]]
+        assert pair.get_best() == want[0] and same_bits(pair.get_E(), want[1]) and np.array_equal(pair.get_inlier_mask(), want[2]), upto
+    pair.estimateE_pipelined(S.default_params(n, num_hypotheses=50000, seed=9))
+    pair.flush()
+    pair.computePosecandidates(); pair.choosePose(); pair.linear_triangulation()
+    assert np.isfinite(pair.get_points()).all()
+    for _ in range(3):
+        pair.estimateE_pipelined(S.default_params(n, num_hypotheses=50000, seed=10))
+    pair.fillXU(d_sift)                                       # flushes the pending steps before it rewrites the points
+    pair.estimateE(S.default_params(n, num_hypotheses=50000, seed=9))
+    assert pair.get_best() == refs[(9, 50000)][0]
