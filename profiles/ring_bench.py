@@ -22,7 +22,14 @@ base = np.array([5.0, 8.0, 12.0, 16.0, 7.0, 10.0], np.float32)
 views = [synth.stereo_pair(w, h, seed=9, disparities=tuple((0.1 * k) * base))[1] if k else synth.stereo_pair(w, h, seed=9)[0] for k in range(V)]
 K, Kinv = synth.camera(w, h)
 sift = dict(num_octaves=5, init_blur=1.5, thresh=1.0)          # src/main.cpp:267-277
-for name, pairs in (("ring_36_pairs", S.ring_pairs(V)), ("all_630_pairs", [(i, j) for i in range(V) for j in range(i + 1, V)])):
+runs_todo = [("ring_36_pairs", views, S.ring_pairs(V)), ("all_630_pairs", views, [(i, j) for i in range(V) for j in range(i + 1, V)])]
+# the reference's own sequence (data/dino/viff.000-035.ppm as 8-bit grey fixtures): BASELINE configs[4] literally
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from helpers import read_pnm_grey, dino_frame
+if os.path.exists(dino_frame(35)):
+    dino = [read_pnm_grey(dino_frame(k)) for k in range(36)]
+    runs_todo += [("dino_ring_36_pairs", dino, S.ring_pairs(36)), ("dino_all_630_pairs", dino, [(i, j) for i in range(36) for j in range(i + 1, 36)])]
+for name, views, pairs in runs_todo:
     S.process_views(ctx, views[:9], K, Kinv, max_pts=8192, sift=sift, device=dev)      # warm-up (buffers, lanes, clocks)
     runs = []
     for _ in range(3):                                   # the first run still grows buffers (pooled pairs, records, allocator)

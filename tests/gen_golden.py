@@ -110,7 +110,7 @@ def gen_e2e():
 
 def gen_dino():
     """The reference program's own input (src/main.cpp:250-251 reads data/dino/viff.000.ppm and viff.001.ppm):
-    frames 0..3 are kept as 8-bit grey PGM data fixtures (0 and 1: the pair of main.cpp, 2 and 3: for the 4-view ring), and the
+    all 36 frames are kept as 8-bit grey PGM data fixtures (0 and 1: the pair of main.cpp, 0..3: the 4-view ring, 0..35: the ring of BASELINE configs[4]), and the
     oracle's results on the pair are frozen so that a drift of the oracle shows up in the CPU suite."""
     from helpers import read_pnm_grey, DINO_KINV, DINO_SIFT
     src = "/root/reference/data/dino"
@@ -121,6 +121,12 @@ def gen_dino():
         g = read_pnm_grey(f"{src}/viff.{k:03d}.ppm").astype(np.uint8)
         with open(f"{dst}/dino_grey_{k:03d}.pgm", "wb") as f:
             f.write(b"P5\n%d %d\n255\n" % (g.shape[1], g.shape[0])); f.write(g.tobytes())
+    # frames 4..35 complete the 36-view ring of BASELINE configs[4]; same conversion, bzip2 (tests/helpers.py reads them)
+    import bz2
+    for k in range(4, 36):
+        g = read_pnm_grey(f"{src}/viff.{k:03d}.ppm").astype(np.uint8)
+        with open(f"{dst}/dino_grey_{k:03d}.pgm.bz2", "wb") as f:
+            f.write(bz2.compress(b"P5\n%d %d\n255\n" % (g.shape[1], g.shape[0]) + g.tobytes(), 9))
     imgs = [read_pnm_grey(f"{dst}/dino_grey_{k:03d}.pgm") for k in (0, 1)]
     feats = [O.extract_sift(im, DINO_SIFT["num_octaves"], DINO_SIFT["init_blur"], DINO_SIFT["thresh"], 0.0, False, 32768) for im in imgs]
     n1 = feats[0][1]

@@ -33,7 +33,11 @@ def read_pnm_grey(path):
     """Binary PGM / PPM -> float32 grey image exactly as cv::imread(path, 0).convertTo(CV_32FC1) delivers it to the
     reference program (src/main.cpp:249-252): 8-bit fixed-point RGB -> grey (4899 R + 9617 G + 1868 B + 8192) >> 14.
     Python twin of ReadPNM in cuda-sfm_amd/host/sfm_io.h."""
-    b = open(path, "rb").read()
+    if path.endswith(".bz2"):                      # frames 4..35 of the dino ring are kept compressed
+        import bz2
+        b = bz2.decompress(open(path, "rb").read())
+    else:
+        b = open(path, "rb").read()
     toks, i = [], 0
     while len(toks) < 4:
         while b[i:i + 1].isspace():
@@ -53,6 +57,15 @@ def read_pnm_grey(path):
         return np.frombuffer(b, np.uint8, w * h, i).reshape(h, w).astype(np.float32)
     c = np.frombuffer(b, np.uint8, w * h * 3, i).reshape(h, w, 3).astype(np.int64)
     return ((c[..., 0] * 4899 + c[..., 1] * 9617 + c[..., 2] * 1868 + 8192) >> 14).astype(np.float32)
+
+
+def dino_frame(k):
+    """Path of frame k of the reference's data/dino sequence as kept under tests/golden/dino (8-bit grey, 0..3 plain PGM,
+    4..35 bzip2)."""
+    import os
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dino")
+    plain = os.path.join(d, f"dino_grey_{k:03d}.pgm")
+    return plain if os.path.exists(plain) else plain + ".bz2"
 
 
 DINO_K = np.array([[2360.0, 0.0, 360.0], [0.0, 2360.0, 288.0], [0.0, 0.0, 1.0]], np.float32)          # src/main.cpp:292-297

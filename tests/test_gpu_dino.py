@@ -99,6 +99,38 @@ def test_dino_ring_of_four_views(gpu):
         assert same_bits(r[:9], Ec[ohyp]) and (int(r[26]), int(r[27])) == (ocnt, ohyp)
 
 
+def test_dino_ring_of_36_views(gpu):
+    """BASELINE configs[4] on the reference's own data: all 36 frames of data/dino (8-bit grey fixtures), ExtractSift per
+    view, the 36 ring pairs through sfm_extract_views + sfm_process_pairs.  Every view's feature count against the oracle
+    extractor, six pairs (among them the closing pair 35-0) against the whole oracle chain, every pair a valid estimate."""
+    torch, dev, ctx = gpu
+    from helpers import dino_frame
+    views = [read_pnm_grey(dino_frame(k)) for k in range(36)]
+    res, counts = S.process_views(ctx, views, DINO_K, DINO_KINV, max_pts=32768, sift=DINO_SIFT, device=dev)
+    assert sorted(res) == list(range(36)) and min(counts) > 1000
+    ring = S.ring_pairs(36)
+    check = [0, 1, 7, 18, 29, 35]
+    need = sorted({v for pid in check for v in ring[pid]})
+    feats = {v: oracle_features(views[v]) for v in need}
+    for v in need:
+        assert counts[v] == feats[v][1], f"view {v}"
+    for pid in check:
+        i, j = ring[pid]
+        ni = feats[i][1]
+        m = O.match_sift(feats[i][0][:ni].copy(), feats[j][0][:feats[j][1]])
+        _, _, X0, X1 = O.fill_xu(m, DINO_KINV)
+        p = S.default_params(ni)
+        key, _, Ec = O.ransac_range(X0, X1, 0, p.num_hypotheses, p.threshold, p.jacobi_sweeps, seed=p.seed, want_E=True)
+        ocnt, ohyp = O.unpack_key(key)
+        r = res[pid]
+        assert same_bits(r[:9], Ec[ohyp]) and (int(r[26]), int(r[27])) == (ocnt, ohyp), f"pair {pid}"
+        oP = O.pose_candidates(Ec[ohyp], S.POSE_REFERENCE)
+        oind, oPinv, _, _ = O.choose_pose(X0, X1, oP, S.POSE_REFERENCE, 8)
+        assert int(r[25]) == oind and same_bits(r[9:25], oPinv[oind].reshape(16))
+    for pid in range(36):
+        assert res[pid][26] >= 8 and np.isfinite(res[pid][:25]).all()
+
+
 def test_dino_ring_batched_equals_per_pair(gpu):
     """sfm_process_pairs (every pair enqueued back to back inside the C library, records assembled on the device, one
     read-back) against the same pairs taken one at a time through the Image_pair calls: records bit for bit, for both
