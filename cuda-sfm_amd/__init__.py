@@ -52,7 +52,7 @@ EXPORTS = [
     "sfm_ctx_kernel_timing_read", "sfm_device_alloc", "sfm_device_free", "sfm_copy_to_device", "sfm_copy_to_host",
     "sfm_copy_to_host_2d", "sfm_copy_to_device_2d", "sfm_find_homography", "sfm_sift_temp_layout", "sfm_extract_sift", "sfm_extract_sift_begin", "sfm_extract_sift_end", "sfm_match", "sfm_match_soa",
     "sfm_pair_create", "sfm_pair_destroy", "sfm_pair_reset", "sfm_get_result", "sfm_fill_xu", "sfm_set_points", "sfm_ransac_default_params",
-    "sfm_ransac_permutation_indices", "sfm_estimate_E", "sfm_ransac_score", "sfm_ransac_score_into", "sfm_ransac_finalize",
+    "sfm_ransac_permutation_indices", "sfm_estimate_E", "sfm_ransac_score", "sfm_ransac_score_candidates", "sfm_ransac_score_into", "sfm_ransac_finalize",
     "sfm_ransac_finalize_key", "sfm_ransac_finalize_key_on", "sfm_ransac_score_into_slot", "sfm_estimate_E_pipelined", "sfm_pair_flush", "sfm_ransac_export_key", "sfm_pose_candidates", "sfm_choose_pose", "sfm_triangulate",
     "sfm_pair_device_ptr", "sfm_pair_ld", "sfm_pair_num_points", "sfm_get_XU", "sfm_get_E", "sfm_get_best",
     "sfm_get_key", "sfm_get_inlier_counts", "sfm_get_inlier_mask", "sfm_get_E_candidates",
@@ -108,6 +108,7 @@ _lib.sfm_ransac_permutation_indices.argtypes = [_vp, C.c_int, C.c_uint32, _vp]
 _lib.sfm_estimate_E.argtypes = [_vp, C.POINTER(RansacParams)]
 _lib.sfm_ransac_score.argtypes = [_vp, C.POINTER(RansacParams)]
 _lib.sfm_ransac_score_into.argtypes = [_vp, C.POINTER(RansacParams), _vp]
+_lib.sfm_ransac_score_candidates.argtypes = [_vp, C.POINTER(RansacParams), _vp]
 _lib.sfm_ransac_finalize.argtypes = [_vp, C.POINTER(RansacParams), C.c_uint32]
 _lib.sfm_ransac_finalize_key.argtypes = [_vp, C.POINTER(RansacParams), _vp]
 _lib.sfm_ransac_finalize_key_on.argtypes = [_vp, C.POINTER(RansacParams), _vp, _vp]
@@ -349,6 +350,10 @@ class ImagePair:
         else:
             _check(_lib.sfm_ransac_score_into(self._h, C.byref(params), _ptr(key_out)), "sfm_ransac_score_into")
 
+    def ransac_score_candidates(self, params, d_E):
+        """calculateInliers on its own: score caller-supplied candidates (float32 device tensor, 9 x hyp_count)."""
+        _check(_lib.sfm_ransac_score_candidates(self._h, C.byref(params), _ptr(d_E)), "sfm_ransac_score_candidates")
+
     def ransac_finalize(self, params, hyp):
         _check(_lib.sfm_ransac_finalize(self._h, C.byref(params), int(hyp)), "sfm_ransac_finalize")
 
@@ -480,7 +485,7 @@ def estimate_E_distributed(pair, params, rank, world, key_tensor, all_reduce_max
 
 # ---- RCCL exchange step in C (include/sfm_amd_comm.h, libsfm_amd_rccl.so) ----------------------------
 COMM_EXPORTS = ["sfm_comm_unique_id", "sfm_comm_init", "sfm_comm_destroy", "sfm_comm_rank", "sfm_comm_nccl_ranks", "sfm_estimate_E_sharded",
-                "sfm_estimate_E_sharded_pipelined", "sfm_comm_flush"]
+                "sfm_estimate_E_sharded_pipelined", "sfm_comm_flush", "sfm_process_views_sharded"]
 COMM_LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), "libsfm_amd_rccl.so")
 COMM_ID_BYTES = 128
 _comm_lib = None
@@ -501,6 +506,9 @@ def comm_lib():
         L.sfm_estimate_E_sharded_pipelined.argtypes = [_vp, C.POINTER(RansacParams), _vp]
         L.sfm_comm_flush.argtypes = [_vp]
         L.sfm_comm_nccl_ranks.argtypes = [_vp, C.POINTER(C.c_int)]
+        L.sfm_process_views_sharded.argtypes = [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.POINTER(C.c_float)), C.c_int, C.c_int, C.c_int,
+                                                C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.c_double, C.c_float, C.c_float, C.c_int, C.c_uint32,
+                                                C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int)]
         _comm_lib = L
     return _comm_lib
 
@@ -535,6 +543,26 @@ class Comm:
 
     def flush(self):
         _check(comm_lib().sfm_comm_flush(self._h), "sfm_comm_flush")
+
+    def process_views(self, images, K, Kinv, pairs=None, max_pts=8192, sift=None, num_hypotheses=None, pose_mode=POSE_REFERENCE):
+        """sfm_process_views_sharded: BASELINE configs[4] over all ranks inside the C libraries (two ncclAllGathers).
+        Returns ({pair_id: record}, counts) like process_views; every rank gets every record."""
+        sift = dict(sift or {})
+        V = len(images)
+        pairs = ring_pairs(V) if pairs is None else list(pairs)
+        imgs = [np.ascontiguousarray(im, np.float32) for im in images]
+        h, w = imgs[0].shape
+        ptrs = (C.POINTER(C.c_float) * V)(*[im.ctypes.data_as(C.POINTER(C.c_float)) for im in imgs])
+        pij = np.ascontiguousarray(np.array(pairs, np.int32).reshape(-1))
+        rec = np.empty((max(len(pairs), 1), 28), np.float32)
+        counts = (C.c_int * V)()
+        k = np.ascontiguousarray(K, np.float32).reshape(9); ki = np.ascontiguousarray(Kinv, np.float32).reshape(9)
+        _check(comm_lib().sfm_process_views_sharded(self._h, k.ctypes.data_as(C.POINTER(C.c_float)), ki.ctypes.data_as(C.POINTER(C.c_float)), ptrs, V, w, h,
+                                                    pij.ctypes.data_as(C.POINTER(C.c_int)), len(pairs), int(max_pts), int(sift.get("num_octaves", 5)),
+                                                    float(sift.get("init_blur", 1.0)), float(sift.get("thresh", 3.0)), float(sift.get("lowest_scale", 0.0)),
+                                                    int(bool(sift.get("scale_up", False))), int(num_hypotheses or 0), int(pose_mode),
+                                                    rec.ctypes.data_as(C.POINTER(C.c_float)), counts), "sfm_process_views_sharded")
+        return {pid: rec[pid].copy() for pid in range(len(pairs)) if rec[pid][26] >= 0}, list(counts)
 
     def nccl_ranks(self):
         n = C.c_int()

@@ -482,6 +482,17 @@ int sfm_ransac_score(sfm_pair *pair, const sfm_ransac_params *p)
     return launch_ransac_score(pair, *p, h0, count);
 }
 
+int sfm_ransac_score_candidates(sfm_pair *pair, const sfm_ransac_params *p, const float *d_E)
+{
+    SFM_REQUIRE(d_E, SFM_E_INVALID, "null candidate pointer");
+    uint32_t h0, count;
+    int rc = resolve_shard(pair, p, &h0, &count);
+    if (rc != SFM_OK) return rc;
+    if (pair->pipe_pending) { const int rcf = sfm_pair_flush(pair); if (rcf != SFM_OK) return rcf; }
+    SFM_HIP_TRY(hipSetDevice(pair->ctx->device));
+    return launch_ransac_score(pair, *p, h0, count, nullptr, d_E);
+}
+
 int sfm_ransac_score_into(sfm_pair *pair, const sfm_ransac_params *p, uint64_t *d_key_out)
 {
     SFM_REQUIRE(d_key_out, SFM_E_INVALID, "null key pointer");

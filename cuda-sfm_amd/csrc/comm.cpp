@@ -5,7 +5,9 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <cstring>
 #include <new>
+#include <vector>
 
 #include "sfm_amd_comm.h"
 
@@ -22,6 +24,8 @@ struct sfm_comm {
     hipEvent_t ev_scored[2] = { nullptr, nullptr }, ev_final[2] = { nullptr, nullptr }, ev_call = nullptr;
     unsigned long long step = 0;
     bool final_pending = false;
+    void *d_views = nullptr;            // sfm_process_views_sharded: feature slots + result records, mine and everybody's
+    size_t views_bytes = 0;
 };
 
 namespace {
@@ -89,6 +93,7 @@ extern "C" int sfm_comm_destroy(sfm_comm *c)
         if (c->ev_final[i]) (void)hipEventDestroy(c->ev_final[i]);
     }
     if (c->d_keys) (void)hipFree(c->d_keys);
+    if (c->d_views) (void)sfm_device_free(c->ctx, c->d_views);
     if (c->xstream) (void)hipStreamDestroy(c->xstream);
     if (c->sstream) (void)hipStreamDestroy(c->sstream);
     if (c->ev_call) (void)hipEventDestroy(c->ev_call);
@@ -192,5 +197,83 @@ extern "C" int sfm_comm_flush(sfm_comm *c)
     COMM_HIP_TRY(hipStreamWaitEvent(static_cast<hipStream_t>(stream_v), c->ev_final[last], 0));
     if (c->step >= 2) COMM_HIP_TRY(hipStreamWaitEvent(static_cast<hipStream_t>(stream_v), c->ev_final[last ^ 1], 0));
     c->final_pending = false;
+    return SFM_OK;
+}
+
+// BASELINE configs[4] over all ranks without leaving C: views and pairs are dealt round-robin, two collectives in total.
+extern "C" int sfm_process_views_sharded(sfm_comm *c, const float h_K[9], const float h_Kinv[9], const float *const *h_images, int num_views,
+                                         int width, int height, const int *h_pairs, int num_pairs, int max_pts, int num_octaves,
+                                         double init_blur, float thresh, float lowest_scale, int scale_up, uint32_t num_hypotheses,
+                                         int pose_mode, float *h_records, int *h_counts)
+{
+    if (!c || !h_K || !h_Kinv || !h_images || !h_records || num_views < 1 || num_pairs < 0 || (num_pairs > 0 && !h_pairs) || max_pts < 1)
+        return fail("sfm_process_views_sharded", "bad argument");
+    if (c->final_pending) { int rcf = sfm_comm_flush(c); if (rcf != SFM_OK) return rcf; }
+    void *stream_v = nullptr;
+    int rc = sfm_ctx_get_stream(c->ctx, &stream_v);
+    if (rc != SFM_OK) return rc;
+    hipStream_t stream = static_cast<hipStream_t>(stream_v);
+    const int G = c->nranks, r = c->rank;
+    const int slots = (num_views + G - 1) / G;
+    const size_t rec_bytes = (size_t)max_pts * sizeof(sfm_sift_point), slot_bytes = rec_bytes + 64;
+    const int max_local = (num_pairs + G - 1) / G > 0 ? (num_pairs + G - 1) / G : 1;
+    const size_t local_bytes = (size_t)slots * slot_bytes, recs_local = (size_t)max_local * SFM_RECORD_FLOATS * sizeof(float);
+    // one allocation: [my feature slots][everybody's feature slots][my records][everybody's records]
+    const size_t need = local_bytes * (size_t)(1 + G) + recs_local * (size_t)(1 + G);
+    if (need > c->views_bytes) {
+        (void)sfm_ctx_synchronize(c->ctx);
+        if (c->d_views) (void)sfm_device_free(c->ctx, c->d_views);
+        c->d_views = nullptr; c->views_bytes = 0;
+        rc = sfm_device_alloc(c->ctx, need, &c->d_views);
+        if (rc != SFM_OK) return rc;
+        c->views_bytes = need;
+    }
+    char *d_local = static_cast<char *>(c->d_views), *d_all = d_local + local_bytes;
+    char *d_rec_local = d_all + local_bytes * (size_t)G, *d_rec_all = d_rec_local + recs_local;
+    COMM_HIP_TRY(hipMemsetAsync(d_local, 0, local_bytes, stream));                       // spare slots: zero features
+    COMM_HIP_TRY(hipStreamSynchronize(stream));                                          // extraction runs on its own streams
+    // 1. ExtractSift for my views, 2. ONE all-gather of the fixed-size feature slots (rank-major: view v sits in slot
+    //    (v % G) * slots + v / G), 3. the pairs I own, 4. ONE all-gather of the fixed-size result records
+    rc = sfm_extract_views(c->ctx, h_images, num_views, width, height, r, G, d_local, slot_bytes, max_pts, num_octaves, init_blur, thresh,
+                           lowest_scale, scale_up, nullptr);
+    if (rc != SFM_OK) return rc;
+    COMM_NCCL_TRY(ncclAllGather(d_local, d_all, local_bytes, ncclChar, c->nccl, stream));
+    std::vector<int> tails((size_t)slots * G);
+    COMM_HIP_TRY(hipMemcpy2DAsync(tails.data(), sizeof(int), d_all + rec_bytes, slot_bytes, sizeof(int), (size_t)slots * G, hipMemcpyDeviceToHost, stream));
+    COMM_HIP_TRY(hipStreamSynchronize(stream));
+    auto slot_of = [&](int v) { return (size_t)(v % G) * slots + (size_t)(v / G); };
+    std::vector<int> counts((size_t)num_views);
+    for (int v = 0; v < num_views; ++v) counts[(size_t)v] = tails[slot_of(v)];
+    if (h_counts) std::memcpy(h_counts, counts.data(), counts.size() * sizeof(int));
+    std::vector<sfm_pair_desc> descs((size_t)(num_pairs > 0 ? num_pairs : 1));
+    for (int k = 0; k < num_pairs; ++k) {
+        const int i = h_pairs[2 * k], j = h_pairs[2 * k + 1];
+        if (i < 0 || i >= num_views || j < 0 || j >= num_views) return fail("sfm_process_views_sharded", "pair names a view out of range");
+        descs[(size_t)k].d_sift1 = reinterpret_cast<sfm_sift_point *>(d_all + slot_of(i) * slot_bytes); descs[(size_t)k].n1 = counts[(size_t)i];
+        descs[(size_t)k].d_sift2 = reinterpret_cast<const sfm_sift_point *>(d_all + slot_of(j) * slot_bytes); descs[(size_t)k].n2 = counts[(size_t)j];
+    }
+    const int owned = num_pairs > r ? (num_pairs - r + G - 1) / G : 0;
+    std::vector<float> mine((size_t)max_local * SFM_RECORD_FLOATS, -1.0f), all((size_t)max_local * SFM_RECORD_FLOATS * (size_t)G);
+    std::vector<float> rec28((size_t)(owned > 0 ? owned : 1) * 28);
+    std::vector<int> status((size_t)(owned > 0 ? owned : 1));
+    if (owned > 0) {
+        rc = sfm_process_pairs(c->ctx, h_K, h_Kinv, descs.data(), num_pairs, r, G, num_hypotheses, pose_mode, rec28.data(), status.data());
+        if (rc != SFM_OK) return rc;
+        for (int s = 0; s < owned; ++s) {
+            std::memcpy(&mine[(size_t)s * SFM_RECORD_FLOATS], &rec28[(size_t)s * 28], 28 * sizeof(float));
+            mine[(size_t)s * SFM_RECORD_FLOATS + 28] = (float)status[(size_t)s];
+            mine[(size_t)s * SFM_RECORD_FLOATS + 29] = (float)(r + s * G);                 // pair id
+        }
+    }
+    COMM_HIP_TRY(hipMemcpyAsync(d_rec_local, mine.data(), recs_local, hipMemcpyHostToDevice, stream));
+    COMM_NCCL_TRY(ncclAllGather(d_rec_local, d_rec_all, recs_local, ncclChar, c->nccl, stream));
+    COMM_HIP_TRY(hipMemcpyAsync(all.data(), d_rec_all, recs_local * (size_t)G, hipMemcpyDeviceToHost, stream));
+    COMM_HIP_TRY(hipStreamSynchronize(stream));
+    for (int k = 0; k < num_pairs; ++k) for (int q = 0; q < 28; ++q) h_records[(size_t)k * 28 + q] = -1.0f;
+    for (size_t s = 0; s < (size_t)max_local * (size_t)G; ++s) {
+        const float *rec = &all[s * SFM_RECORD_FLOATS];
+        const int pid = (int)rec[29];
+        if (rec[29] >= 0.0f && pid < num_pairs && rec[28] != (float)SFM_E_INVALID) std::memcpy(&h_records[(size_t)pid * 28], rec, 28 * sizeof(float));
+    }
     return SFM_OK;
 }

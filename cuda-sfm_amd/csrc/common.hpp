@@ -134,7 +134,8 @@ struct sfm_pair {
 namespace sfm {
 
 // ransac.hip
-int launch_ransac_score(sfm_pair *pair, const sfm_ransac_params &p, uint32_t h0, uint32_t count, unsigned long long *key2 = nullptr);
+int launch_ransac_score(sfm_pair *pair, const sfm_ransac_params &p, uint32_t h0, uint32_t count, unsigned long long *key2 = nullptr,
+                        const float *d_E_given = nullptr);
 int launch_ransac_finalize(sfm_pair *pair, const sfm_ransac_params &p, const unsigned long long *d_key, uint32_t hyp_host, bool from_key,
                            hipStream_t stream = nullptr, bool rederive = false);
 int launch_permutation_indices(sfm_ctx *ctx, int n, uint32_t seed, int32_t *d_indices);

@@ -14,8 +14,8 @@
 // so a 32 x 32 block of pairs costs a few v_mfma_f32_32x32x16_f16 instead of 1024 x 40 vector operations.  fp16 has 11
 // significant bits; every coefficient and feature is split into two fp16 values (hi + lo, 22 bits) and the products
 // hi*hi, hi*lo, lo*hi are separate k-slots (fp16 x fp16 products are exact in the fp32 accumulator), the constants get
-// three parts.  The vector unit then needs two instructions per pair (one fma with clamp, one integer compare) to
-// reject it; the ~1 % that survive go through the exact test, which alone decides what is counted.
+// three parts.  The vector unit then needs two instructions per pair (one fma, one v_alignbit that shifts its sign bit
+// into the lane's mask) to reject it; the ~1 % that survive go through the exact test, which alone decides what is counted.
 //
 // The rule must never reject a pair the exact test would count.  Notation for one pair: nn_c, da_c the floats
 // residual() computes; n*, da* the same expressions in real arithmetic; nt, G what the matrix cores return (scaled by
@@ -25,19 +25,27 @@
 //              (split truncation <= 3 * 2^-22 per term, fp32 accumulation measured 1.2 * 2^-24 per instruction and
 //               budgeted 8 * 2^-24, fp32 feature products, fp16 subnormal floor, the 6 roundings of the fma chains)
 //     s      = c1 thr,  c1 = (1 + rho)(1 + 2^-20)(1 + 2^-6),  rho = 1/8
-//     T''    = s da~ + c2  with da~ the contraction and c2 = 1.25 terr + 264 s eta^2 + (1 + 1/rho) dn^2
+//     G      = s da~ + c2  with da~ the contraction and c2 = 1.25 terr + 264 s eta^2 + (1 + 1/rho) dn^2
 //              terr >= s |da~ - da*|,   eta >= |a_i,c - a_i*|
-//   (1) nt^2 >= T''  =>  |nt| >= sqrt((1 + rho) T + (1 + 1/rho) dn^2) >= sqrt(T) + dn   (T = thr' da_up, AM-GM)
-//                    =>  |nn_c| >= sqrt(T)  =>  fl(nn_c^2) >= thr (1 + 2^-23) da_c.
+//              (the constant k-slot holds s (e2^2 + e5^2) + c2 rounded UP to fp16)
+//   (1) nt^2 > G  =>  |nt| >= sqrt((1 + rho) T + (1 + 1/rho) dn^2) >= sqrt(T) + dn   (T = thr' da_up, AM-GM)
+//                 =>  |nn_c| >= sqrt(T)  =>  fl(nn_c^2) >= thr (1 + 2^-23) da_c.
 //   (2) If moreover da_c > 0: t1 = fl(n2 / da_c) >= thr, and r = fl(t1 + t2) >= t1 >= thr for every t2 >= 0 (or NaN, or
 //       inf): not an inlier.  db_c = 0 zeroes t2, which changes nothing.
-//   (3) da_c = 0 zeroes t1 (the reference's element_wise_div guard), so such a pair must never be rejected: da_c = 0
-//       needs |a_0*|, |a_1*| <= eta, i.e. da* <= 2 eta^2.  G = T'' - tmin with tmin = c2 + 1.25 terr + 8 s eta^2, so
-//       G >= 0 => s da~ >= 1.25 terr + 8 s eta^2 => da* >= 8 eta^2 - ... > 2 eta^2 => da_c > 0.
-//   Rule: reject  <=>  0 <= G  and  G + tmin_w < nt^2   (tmin_w = largest tmin of the wavefront's hypotheses), evaluated
-//   as  bits(G) <u bits(clamp01(nt^2 - tmin_w))  -- one v_fma_f32 ... clamp and one v_cmp_lt_u32: a negative or NaN G has
-//   bits above every clamped value, NaN nt clamps to 0 (never rejects), and G >= 1 is simply not rejected (T'' is scaled
-//   to stay below ~0.4).  Degenerate or non-finite E: all coefficients 0 and G = -inf, every pair survives.
+//   (3) da_c = 0 zeroes t1 (the reference's element_wise_div guard), so such a pair must never be rejected.  That is
+//       decided per (hypothesis, tile), not per pair: da_c = 0 needs |a_0,c|, |a_1,c| <= 2^-74, hence
+//       |a_0*(x2)|, |a_1*(x2)| <= eta + 2^-74 with a* = A x2 + b, A = (e0 e1; e3 e4), b = (e2, e5) -- x2 lies within
+//           rad = |A^-1|_inf (eta' + R),   R >= |A xc + b|_inf
+//       of ANY centre xc (prefilter_zero_divisor_cells takes the float solution of A xc = -b and bounds R and
+//       |A^-1|_inf = (|e0|+|e1|+|e3|+|e4|) / |det| from above in float arithmetic).  The points of the tile are hashed by
+//       their cell on a grid of pitch g (a power of two >= 2^-11 B); a hypothesis whose disc fits 2 x 2 cells and meets no
+//       occupied cell has no zero-divisor pair in the tile.  Every other hypothesis (disc too large to tell, singular A,
+//       or an occupied cell: ~0.5 % of them) is checked against all points of the tile with the very expression
+//       residual() evaluates (prefilter_zero_divisor); only if a zero divisor really exists, the hypothesis gets
+//       all-zero coefficients for this tile (nt = 0, G > 0) and all its pairs survive.
+//   Rule: reject  <=>  nt^2 > G, evaluated as the sign bit of fma(-nt, nt, G) (one rounding, so the sign is exact; nt and
+//   G are always finite because no NaN or inf ever enters a matrix-core operand).  Degenerate or non-finite E: all
+//   coefficients 0 and G = 2^-10, every pair survives.
 #pragma once
 #include "device_math.hpp"
 
@@ -47,11 +55,11 @@ constexpr int kPfSlots = 32;             // k-slots of the n contraction (two v_
 constexpr int kPfSlotsT = 16;            // k-slots of the G contraction (one)
 constexpr float kPfRho = 0.125f;
 constexpr float kPfFeatScale = 16.0f;    // sigF: features of n are stored times 16 (fp16 low parts stay normal)
-constexpr float kPfPadValue = 256.0f;    // k-slot 27 of a padding point: nt = 256 -> clamp(nt^2 - tmin) = 1 > G = 0: rejected
+constexpr float kPfPadValue = 256.0f;    // k-slot 27 of a padding point: nt = 256, G = 0 (or 2^-10) -> nt^2 > G: rejected
 
 struct PfScales { int a; float sigE, sigF, sig2a; };
 
-// Power-of-two scaling: nt is carried as 2^a n, G as 2^2a (T'' - tmin); a is chosen from the threshold so that 2^2a T''
+// Power-of-two scaling: nt is carried as 2^a n, G as 2^2a T''; a is chosen from the threshold so that 2^2a T''
 // stays below 1 (T'' <= ~12 thr for |E_ij| <= 1.5, |coordinates| <= 1).  Returns false when the threshold is outside
 // the range the fp16 operands cover -- the caller then uses the plain vector kernel.
 SFM_HD bool prefilter_scales(float thr, PfScales &sc)
@@ -86,8 +94,10 @@ SFM_HD void pf_split3(float x, _Float16 &h, _Float16 &m, _Float16 &l)
 // times the constant feature sigF); slot 27 = 1 x (0 for a real point, kPfPadValue for padding).
 // G: term j of (x^2, xy, y^2, x, y) occupies 3j..3j+2 the same way; slot 15 the constant (one fp16: its rounding error,
 // 2^-11 of s (e2^2 + e5^2), is part of terr) x 1.
-// Returns tmin (unscaled); ns / ts are the hypothesis' coefficient slots.
-SFM_HD float prefilter_hyp_slots(const float e[9], float thr, float B, const PfScales &sc, _Float16 ns[kPfSlots], _Float16 ts[kPfSlotsT])
+// ns / ts are the hypothesis' coefficient slots; survive_all = this hypothesis has a zero-divisor pair in the tile (3).
+// Returns c2 (unscaled; diagnostics).
+SFM_HD float prefilter_hyp_slots(const float e[9], float thr, float B, const PfScales &sc, _Float16 ns[kPfSlots], _Float16 ts[kPfSlotsT],
+                                 bool survive_all = false)
 {
 #pragma unroll
     for (int k = 0; k < kPfSlots; ++k) ns[k] = (_Float16)0.0f;
@@ -98,8 +108,8 @@ SFM_HD float prefilter_hyp_slots(const float e[9], float thr, float B, const PfS
 #pragma unroll
     for (int k = 0; k < 9; ++k) { ae[k] = fabsf(e[k]); tame = tame && (ae[k] <= 2.0f); }      // NaN compares false
     ns[27] = (_Float16)1.0f;
-    if (!tame) {                                      // every pair of this hypothesis survives (G = -2^-10 < 0 for real points)
-        ts[15] = (_Float16)(-0.0009765625f);
+    if (!tame || survive_all) {                       // every pair of this hypothesis survives (nt = 0, G = 2^-10 for real points)
+        ts[15] = (_Float16)0.0009765625f;
         return 0.0f;
     }
     const int order[8] = { 0, 1, 3, 4, 2, 5, 6, 7 };
@@ -125,20 +135,95 @@ SFM_HD float prefilter_hyp_slots(const float e[9], float thr, float B, const PfS
                      + 4.9e-04f * s * C;                                                                                   // 2^-11: the one-part constant
     const float eta = 2.3841858e-07f * (ae[2] + ae[5] + B * (ae[0] + ae[1] + ae[3] + ae[4]));                                 // 4 * 2^-24
     const float c2 = 1.25f * terr + s * 262.6f * eta * eta + (1.0f + 1.0f / kPfRho) * 1.01f * dn * dn + 1e-37f;
-    const float gsub = 1.25f * terr + s * 8.0f * eta * eta + 1e-36f;
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
         _Float16 h, m;
         pf_split2((s * mq[j]) * sc.sig2a, h, m);
         ts[3 * j] = h; ts[3 * j + 1] = h; ts[3 * j + 2] = m;
     }
-    ts[15] = (_Float16)((s * C - gsub) * sc.sig2a);
-    return c2 + gsub;
+    // the constant slot, rounded UP to fp16 (2^-10 of it more threshold at most: far inside the (1 + rho) slack)
+    const float cst = ((s * C + c2) * sc.sig2a) * 1.0000005f;
+    _Float16 ch = (_Float16)cst;
+    if ((float)ch < cst) ch = (_Float16)((float)ch * 1.001f + 6e-8f);               // next fp16 up (ulp >= 2^-11 relative, 2^-24 absolute)
+    ts[15] = ch;
+    return c2;
+}
+
+// ---- (3): which points of a tile can make da_c == 0 for this hypothesis
+struct PfGrid { float g, ginv; };
+
+// Grid pitch for a tile whose coordinates are bounded by B: 2^-11 of the next power of two above B.
+SFM_HD PfGrid prefilter_grid(float B)
+{
+    int ex = 0;
+    (void)frexpf(B, &ex);                              // B = m 2^ex, m in [0.5, 1)
+    if (!(B > 0.0f) || ex < -20) ex = -20;
+    if (ex > 6) ex = 6;                                // B <= 48
+    PfGrid gr;
+    gr.g = ldexpf(1.0f, ex - 11);
+    gr.ginv = ldexpf(1.0f, 11 - ex);
+    return gr;
+}
+
+// Cell index of a coordinate (exact: a power-of-two scaling and a floor), clamped far outside the range of any point.
+SFM_HD int pf_cell(float c, const PfGrid &gr)
+{
+    const float f = floorf(c * gr.ginv);
+    return (int)fminf(fmaxf(f, -5.0e8f), 5.0e8f);
+}
+
+// Non-zero hash of a cell (equal cells -> equal keys; different cells may collide, which only costs a tile scan).
+SFM_HD uint32_t pf_cell_key(int ix, int iy)
+{
+    return hash32((uint32_t)ix * 0x9E3779B1u ^ hash32((uint32_t)iy + 0x7F4A7C15u)) | 1u;
+}
+
+// The divisor of the first residual term exactly as residual() / inlier_filter() compute it (z = 1).
+SFM_HD bool prefilter_zero_divisor(const float e[9], float x2x, float x2y)
+{
+    const float a0 = fmaf(e[1], x2y, fmaf(e[0], x2x, e[2]));
+    const float a1 = fmaf(e[4], x2y, fmaf(e[3], x2x, e[5]));
+    return fmaf(a1, a1, a0 * a0) == 0.0f;
+}
+
+// 0: no point with |coordinates| <= B has da_c == 0;  1: only points in the cells [cx0, cx1] x [cy0, cy1] (at most 2 x 2)
+// can;  2: cannot tell -- check every point of the tile.  Every comparison is written so that a NaN lands in 2.
+SFM_HD int prefilter_zero_divisor_cells(const float e[9], float B, const PfGrid &gr, int &cx0, int &cx1, int &cy0, int &cy1)
+{
+    cx0 = cx1 = cy0 = cy1 = 0;
+    const float a0 = fabsf(e[0]), a1 = fabsf(e[1]), a3 = fabsf(e[3]), a4 = fabsf(e[4]);
+    const float sumA = (a0 + a1) + (a3 + a4);
+    const float det = fmaf(-e[1], e[3], e[0] * e[4]);
+    const float detlo = fabsf(det) - 2.3841858e-07f * (a0 * a4 + a1 * a3);            // 2^-22 (|e0 e4| + |e1 e3|) >= 2 x the rounding of det
+    if (!(detlo > 1e-30f) || !(sumA <= 8.0f)) return 2;
+    const float inv = 1.0f / det;
+    const float xc = fmaf(e[1], e[5], -(e[2] * e[4])) * inv, yc = fmaf(e[2], e[3], -(e[0] * e[5])) * inv;   // any accuracy will do
+    if (!(fabsf(xc) <= 1e6f) || !(fabsf(yc) <= 1e6f)) {
+        // the solution is far outside the tile; A x + b cannot vanish on |x| <= B if |b| dominates: |a_i*| >= |b_i| - B (|A_i0| + |A_i1|)
+        const float eta_far = 2.3841858e-07f * (fabsf(e[2]) + fabsf(e[5]) + B * sumA) * 1.001f + 1e-18f;
+        const float m0 = fabsf(e[2]) - B * (a0 + a1) * 1.000001f, m1 = fabsf(e[5]) - B * (a3 + a4) * 1.000001f;
+        return (m0 > eta_far || m1 > eta_far) ? 0 : 2;
+    }
+    // residual of the centre and its own rounding: |A xc + b|_inf <= R
+    const float r0 = fmaf(e[1], yc, fmaf(e[0], xc, e[2])), r1 = fmaf(e[4], yc, fmaf(e[3], xc, e[5]));
+    const float ax = fabsf(xc), ay = fabsf(yc);
+    const float m0 = a0 * ax + a1 * ay + fabsf(e[2]), m1 = a3 * ax + a4 * ay + fabsf(e[5]);
+    const float R = fmaxf(fabsf(r0), fabsf(r1)) + 2.3841858e-07f * fmaxf(m0, m1);     // 2^-22 (sum of |terms|) >= 2 x two fma roundings
+    const float eta = 2.3841858e-07f * (fabsf(e[2]) + fabsf(e[5]) + B * sumA) * 1.001f + 1e-18f;   // 4 * 2^-24 (...) as in prefilter_hyp_slots, + the 2^-75 below which a square vanishes (2^-63 were denormals flushed)
+    float rad = (sumA / detlo) * (eta + R) * 1.001f;
+    rad = rad + 4.7683716e-07f * (fmaxf(ax, ay) + rad);                                // the roundings of xc -+ rad below
+    if (!(rad <= 0.5f * gr.g)) return 2;
+    const float lx = xc - rad, hx = xc + rad, ly = yc - rad, hy = yc + rad;
+    const float Bu = B * 1.000001f;
+    if (lx > Bu || hx < -Bu || ly > Bu || hy < -Bu) return 0;                          // the disc misses every point of the tile
+    cx0 = pf_cell(lx, gr); cx1 = pf_cell(hx, gr); cy0 = pf_cell(ly, gr); cy1 = pf_cell(hy, gr);
+    if (cx1 - cx0 > 1 || cy1 - cy0 > 1) return 2;
+    return 1;
 }
 
 // Feature slots of one point (u, v) = x1, (x, y) = x2.  Padding points (beyond num_points) get all-zero features and the
 // pad marker: nt = 256, G = 0 -> always rejected.  A real point with a non-finite coordinate, or one whose features leave
-// the fp16 range, gets all-zero features WITHOUT the marker: nt = 0 -> clamp(0 - tmin) = 0 -> never rejected, the exact
+// the fp16 range, gets all-zero features WITHOUT the marker: nt = 0, G = 0 -> fma(-0, 0, 0) = +0 -> never rejected, the exact
 // test sees it (no NaN or inf ever enters a matrix-core operand, so G and nt are always finite).
 SFM_HD void prefilter_point_slots(float u, float v, float x, float y, bool real, _Float16 bn[kPfSlots], _Float16 bt[kPfSlotsT])
 {
@@ -167,12 +252,10 @@ SFM_HD void prefilter_point_slots(float u, float v, float x, float y, bool real,
     bt[15] = (_Float16)1.0f;
 }
 
-// The rule on the host (tests): the kernel evaluates the same thing as v_fma_f32 ... clamp + v_cmp_lt_u32.
-SFM_HD bool prefilter_reject(float nt, float G, float tminw_scaled)
+// The rule: the sign bit of G - nt^2 (one fma; the kernel shifts that bit into the lane's mask with v_alignbit_b32).
+SFM_HD bool prefilter_reject(float nt, float G)
 {
-    float w = fmaf(nt, nt, -tminw_scaled);
-    w = (w != w) ? 0.0f : fminf(fmaxf(w, 0.0f), 1.0f);
-    return f32_bits(G) < f32_bits(w);
+    return (f32_bits(fmaf(-nt, nt, G)) >> 31) != 0u;
 }
 
 } // namespace sfm

@@ -254,13 +254,14 @@ static int launch_score_t(sfm_pair *pair, uint32_t h0, uint32_t count, float thr
     return SFM_OK;
 }
 
-int launch_ransac_score(sfm_pair *pair, const sfm_ransac_params &p, uint32_t h0, uint32_t count, unsigned long long *key2)
+int launch_ransac_score(sfm_pair *pair, const sfm_ransac_params &p, uint32_t h0, uint32_t count, unsigned long long *key2, const float *d_E_given)
 {
     sfm_ctx *ctx = pair->ctx;
     // which kernel family: decided first, because the lane-solve kernel of the SPLIT family clears the keys itself
     const uint32_t fused_max_early = p.jacobi_sweeps > 0 ? 4096u : 1024u;
-    const int family = p.kernel == SFM_KERNEL_AUTO ? (count <= fused_max_early ? SFM_KERNEL_FUSED : SFM_KERNEL_SPLIT) : p.kernel;
-    const bool self_clearing = count > 0 && (family == SFM_KERNEL_SPLIT || family == SFM_KERNEL_PREFILTER);
+    int family = p.kernel == SFM_KERNEL_AUTO ? (count <= fused_max_early ? SFM_KERNEL_FUSED : SFM_KERNEL_SPLIT) : p.kernel;
+    if (d_E_given && family == SFM_KERNEL_FUSED) family = SFM_KERNEL_SPLIT;      // the fused kernel solves its own candidates
+    const bool self_clearing = !d_E_given && count > 0 && (family == SFM_KERNEL_SPLIT || family == SFM_KERNEL_PREFILTER);
     if (!self_clearing) {
         SFM_HIP_TRY(hipMemsetAsync(pair->d_key, 0, 2 * sizeof(unsigned long long), ctx->stream));
         if (key2) SFM_HIP_TRY(hipMemsetAsync(key2, 0, sizeof(unsigned long long), ctx->stream));
@@ -277,6 +278,7 @@ int launch_ransac_score(sfm_pair *pair, const sfm_ransac_params &p, uint32_t h0,
     // between 1k and 4k with the (much cheaper) Householder solver.
     const uint32_t fused_max = p.jacobi_sweeps > 0 ? 4096u : 1024u;
     int kernel = p.kernel == SFM_KERNEL_AUTO ? (count <= fused_max ? SFM_KERNEL_FUSED : SFM_KERNEL_SPLIT) : p.kernel;
+    if (d_E_given && kernel == SFM_KERNEL_FUSED) kernel = SFM_KERNEL_SPLIT;
     if (kernel == SFM_KERNEL_MFMA && pair->n >= 65536) kernel = SFM_KERNEL_SPLIT;   // its packed counters are 16-bit
     // matrix-core pre-filter in front of the exact test (ransac_prefilter.hip): AUTO takes it whenever it applies
     // (unit-z points, threshold inside the fp16 scaling range, enough hypotheses); asked for explicitly where it does
@@ -310,7 +312,12 @@ int launch_ransac_score(sfm_pair *pair, const sfm_ransac_params &p, uint32_t h0,
     hipEvent_t *tev = timed ? ctx->tev[ctx->tcount] : nullptr;
     if (timed) SFM_HIP_TRY(hipEventRecord(tev[0], ctx->stream));
     int *zero_counts = (grid2d || prefilter) ? pair->d_counts : nullptr;
-    if (p.reserved[0] == 1)          // A/B switch: one hypothesis per lane (scalar math)
+    if (d_E_given) {                 // caller-supplied candidates (sfm_ransac_score_candidates): no solve, clear what it would have cleared
+        SFM_HIP_TRY(hipMemcpyAsync(pair->d_Ecand, d_E_given, (size_t)count * 9 * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+        if (zero_counts) SFM_HIP_TRY(hipMemsetAsync(pair->d_counts, 0, (size_t)count * sizeof(int), ctx->stream));
+        if (prefilter) SFM_HIP_TRY(hipMemsetAsync(pair->d_tick, 0, ((size_t)count / 64 + 2) * sizeof(uint32_t), ctx->stream));
+    }
+    else if (p.reserved[0] == 1)     // A/B switch: one hypothesis per lane (scalar math)
         hipLaunchKernelGGL(ransac_solve_lanes, dim3((count + 63) / 64), dim3(64), 0, ctx->stream,
                            pair->d_X[0], pair->d_X[1], pair->ld, pair->n, p.d_indices, p.seed, h0, count,
                            p.jacobi_sweeps, pair->d_Ecand, pair->d_key, key2, zero_counts, prefilter ? pair->d_tick : nullptr);

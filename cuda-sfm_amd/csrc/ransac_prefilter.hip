@@ -10,7 +10,7 @@
 // A wavefront prepares the coefficient fragments (A operands) of 64 hypotheses at a time, one hypothesis per lane, and
 // hands them to the two 32-row blocks through a half-wave exchange; for each 32-row block it walks the tile in 32-point
 // steps:
-//     3 x ds_read_b128 -> 3 MFMAs (G: 1, nt: 2) -> per accumulator v_fma ... clamp, v_cmp_lt_u32, v_addc (no branch)
+//     3 x ds_read_b128 -> 3 MFMAs (G: 1, nt: 2) -> per accumulator v_fma (G - nt^2), v_alignbit (its sign bit) (no branch)
 // which leaves every lane with a 16-bit "rejected" mask of its 16 pairs.  Lanes with a surviving pair append one word to
 // the wavefront's ring in LDS; 64 entries at a time go through the exact filter, one entry per lane, and inliers bump the
 // hypothesis' counter in LDS.  Tiles are spread over blockIdx.y; partial counts reach counts[] through integer atomics
@@ -35,45 +35,16 @@ constexpr int kPfLdsPts = kPfLdsBt + kPfTile * 32;            // float4 (x1x, x1
 constexpr int kPfLdsWave = kPfLdsPts + kPfTile * 16;          // per wavefront: E table 32 x 9 floats, 32 counters, ring
 constexpr int kPfWaveBytes = 32 * 9 * 4 + 32 * 4 + kPfRing * 4;
 constexpr int kPfLdsBound = kPfLdsWave + kPfWaves * kPfWaveBytes;
-constexpr int kPfLdsBytes = kPfLdsBound + 16;
+constexpr int kPfHashSlots = 2048;                             // occupied grid cells of the tile (<= 1024 keys): open addressing, 0 = empty
+constexpr int kPfLdsHash = kPfLdsBound + 16;
+constexpr int kPfLdsBytes = kPfLdsHash + kPfHashSlots * 4;
+static_assert(kPfLdsBytes <= 160 * 1024, "one block must fit the CU's LDS");
 
-// clamp01(a * b + c) with NaN -> 0: the compiler folds the med3 into the fma's clamp modifier (the kernel descriptor has
-// DX10_CLAMP set).  Deliberately NOT inline assembly: the result registers of an MFMA need software wait states before a
-// vector instruction may read them, and the hazard recognizer does not look into asm statements.
-__device__ __forceinline__ float fma_clamp(float a, float b, float c)
+// rejected = (rejected << 1) | sign(G - nt^2): v_fma_f32 with a negated operand and v_alignbit_b32.  Plain C++ (no inline
+// assembly), so the compiler inserts the wait states the MFMA result registers need before a vector instruction reads them.
+__device__ __forceinline__ uint32_t shift_in_reject(uint32_t rejected, float nt, float G)
 {
-    return __builtin_amdgcn_fmed3f(fmaf(a, b, c), 0.0f, 1.0f);
-}
-
-// rejected = (rejected << 1) | (bits(G) <u bits(w)): one compare into VCC and one add-with-carry (the compiler's own
-// selection for the C++ form is v_cmp + v_cndmask + or-tree, 3.5 instructions per pair and 20 more registers).
-// G and nt come straight out of MFMAs, whose result registers need software wait states before a vector instruction may
-// read them, and the hazard recognizer does not look into asm statements.  mfma_fence() is the compiler-visible read that
-// gets those wait states; its result is an input of the first asm statement of a step (and asm volatile statements keep
-// their order), so no asm statement can be scheduled in front of it.
-__device__ __forceinline__ uint32_t shift_in_reject(uint32_t rejected, float G, float w)
-{
-    asm volatile("v_cmp_lt_u32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(rejected) : "v"(G), "v"(w) : "vcc");
-    return rejected;
-}
-
-__device__ __forceinline__ uint32_t mfma_fence(const f16v &a, const f16v &b)
-{
-    const uint32_t d = __float_as_uint(a[15]) | __float_as_uint(b[15]);     // one v_or_b32 reading the last register of both results
-    uint32_t zero;
-    asm volatile("v_mov_b32 %0, 0 ; after %1" : "=v"(zero) : "v"(d));
-    return zero;
-}
-
-// Two pairs per instruction: (w0, w1) = clamp01((n0, n1)^2 + c) as v_pk_fma_f32 ... clamp (NaN -> 0), then the two
-// compare / add-with-carry steps.
-typedef float v2f32 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ uint32_t shift_in_reject2(uint32_t rejected, v2f32 nt, v2f32 G, v2f32 c)
-{
-    v2f32 w;
-    asm volatile("v_pk_fma_f32 %0, %1, %1, %2 clamp" : "=v"(w) : "v"(nt), "v"(c));
-    rejected = shift_in_reject(rejected, G.x, w.x);
-    return shift_in_reject(rejected, G.y, w.y);
+    return __builtin_amdgcn_alignbit(rejected, __float_as_uint(fmaf(-nt, nt, G)), 31);
 }
 
 // The fragment of hypothesis row `src` for this lane's k-half: every lane offers both halves of the row it prepared, the
@@ -124,7 +95,6 @@ __device__ __noinline__ int pf_flush(uint32_t *ring, int head, int nent, int tai
     return __builtin_popcountll(more);
 }
 
-template <bool PACKED>
 __global__ __launch_bounds__(kPfWaves * 64)
 void ransac_score_prefilter(const float *__restrict__ X0, const float *__restrict__ X1, int ld, int n,
                             const float *__restrict__ Ecand, uint32_t h0, uint32_t count, float thr, PfScales sc,
@@ -140,9 +110,13 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
 
     // ---- stage the tile: one point per thread -> 48 fp16 feature slots in MFMA B-fragment order + its coordinates
     unsigned int &tile_bound = *reinterpret_cast<unsigned int *>(smem + kPfLdsBound);
+    uint32_t *cells = reinterpret_cast<uint32_t *>(smem + kPfLdsHash);
     if (threadIdx.x == 0) tile_bound = 0u;
+    for (int k = threadIdx.x; k < kPfHashSlots; k += kPfWaves * 64) cells[k] = 0u;
     __syncthreads();
     const int tile_first = blockIdx.y * kPfTile;
+    float px = 0.f, py = 0.f;
+    bool hashed = false;
     {
         const int t = threadIdx.x;
         const int p = tile_first + t;
@@ -153,6 +127,8 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
         prefilter_point_slots(u, v, x, y, real, bn, bt);
         const float big = fmaxf(fmaxf(fabsf(u), fabsf(v)), fmaxf(fabsf(x), fabsf(y)));
         if (big <= 48.0f) atomicMax(&tile_bound, __float_as_uint(big));       // points beyond that carry no features (prefilter_point_slots)
+        hashed = real && big <= 48.0f && u == u && v == v && x == x && y == y;     // the points the pre-filter can reject at all
+        px = x; py = y;
         // padding reads as NaN in the exact test (it is always rejected before; NaN never counts)
         reinterpret_cast<float4 *>(smem + kPfLdsPts)[t] = real ? make_float4(u, v, x, y) : make_float4(NAN, NAN, NAN, NAN);
         const int pb = t >> 5, col = t & 31;
@@ -175,6 +151,18 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
     }
     __syncthreads();
     const float B = __uint_as_float(tile_bound);
+    // the occupied cells of the zero-divisor grid (prefilter_math.hpp (3)); its pitch follows the tile's bound
+    const PfGrid grid = prefilter_grid(B);
+    if (hashed) {
+        const uint32_t key = pf_cell_key(pf_cell(px, grid), pf_cell(py, grid));
+        uint32_t sl = (key >> 8) & (kPfHashSlots - 1);
+        for (;;) {
+            const uint32_t old = atomicCAS(&cells[sl], 0u, key);
+            if (old == 0u || old == key) break;
+            sl = (sl + 1) & (kPfHashSlots - 1);
+        }
+    }
+    __syncthreads();
     const int npb = (min(kPfTile, ld - tile_first) + 31) >> 5;           // 32-point blocks that hold points or padding
     float *etab = reinterpret_cast<float *>(smem + kPfLdsWave + wave * kPfWaveBytes);
     int *cnt = reinterpret_cast<int *>(etab + 32 * 9);
@@ -196,12 +184,46 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
 #pragma unroll
             for (int k = 0; k < 9; ++k) e[k] = src[k];
         }
+        // zero divisors (prefilter_math.hpp (3)): nearly every hypothesis is cleared by its 2 x 2 cells; the rest
+        // (~0.5 %) is checked against every point of the tile, one hypothesis at a time by the whole wavefront
+        bool survive_all = false;
+        {
+            int cx0, cx1, cy0, cy1;
+            int zs = prefilter_zero_divisor_cells(e, B, grid, cx0, cx1, cy0, cy1);
+            if (zs == 1) {
+                zs = 0;
+                for (int cy = cy0; cy <= cy1; ++cy)
+                    for (int cx = cx0; cx <= cx1; ++cx) {
+                        const uint32_t key = pf_cell_key(cx, cy);
+                        uint32_t sl = (key >> 8) & (kPfHashSlots - 1);
+                        for (;;) {
+                            const uint32_t got = cells[sl];
+                            if (got == key) zs = 2;
+                            if (got == key || got == 0u) break;
+                            sl = (sl + 1) & (kPfHashSlots - 1);
+                        }
+                    }
+            }
+            unsigned long long todo = __ballot(zs == 2);
+            while (todo) {
+                const int l = __builtin_ctzll(todo);
+                todo &= todo - 1;
+                float se[9];
+#pragma unroll
+                for (int k = 0; k < 6; ++k) se[k] = __shfl(e[k], l);
+                bool z = false;
+                for (int j = 0; j < kPfTile / 64; ++j) {
+                    const float4 q = pts[j * 64 + lane];
+                    z = z || prefilter_zero_divisor(se, q.z, q.w);              // NaN padding never compares equal to 0
+                }
+                if (__ballot(z) != 0ull && lane == l) survive_all = true;
+            }
+        }
         _Float16 ns[kPfSlots], ts[kPfSlotsT];
-        const float tmin_own = prefilter_hyp_slots(e, thr, B, sc, ns, ts);
+        (void)prefilter_hyp_slots(e, thr, B, sc, ns, ts, survive_all);
         // X* = k-slots 0..7 of each 16-slot step (the fragment of MFMA lanes 0..31), Y* = k-slots 8..15 (lanes 32..63).
         // Rows of block b were prepared by lanes 32 b .. 32 b + 31; MFMA lane l needs row l % 32, k-half l / 32.
         h8 fn0[2], fn1[2], ft[2];
-        float ftmin[2];
         {
             h8 xn0, yn0, xn1, yn1, xt, yt;
 #pragma unroll
@@ -216,7 +238,6 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
                 fn0[blk] = fetch_fragment(xn0, yn0, src, half);
                 fn1[blk] = fetch_fragment(xn1, yn1, src, half);
                 ft[blk] = fetch_fragment(xt, yt, src, half);
-                ftmin[blk] = __shfl(tmin_own, src);
             }
         }
 #pragma unroll
@@ -224,17 +245,12 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
             const int nvalid = min(32, nvalid64 - 32 * blk);
             if (nvalid <= 0) break;
             const h8 an0 = fn0[blk], an1 = fn1[blk], at = ft[blk];
-            float tmin = ftmin[blk];
             // E table and counters of this block (the previous block's ring is drained, its counters are flushed)
             if (half == blk) {
 #pragma unroll
                 for (int k = 0; k < 9; ++k) etab[9 * row + k] = e[k];
                 cnt[row] = 0;
             }
-            if (row >= nvalid) tmin = 0.0f;
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) tmin = fmaxf(tmin, __shfl_xor(tmin, off));
-            const float neg_tminw = -(tmin * sc.sig2a);
 
             int head = 0, nq = 0;                       // ring state (wave-uniform)
             for (int pb = 0; pb < npb; ++pb) {
@@ -244,21 +260,9 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
                 accg = __builtin_amdgcn_mfma_f32_32x32x16_f16(at, bt0, accg, 0, 0, 0);
                 accn = __builtin_amdgcn_mfma_f32_32x32x16_f16(an0, bn0, accn, 0, 0, 0);
                 accn = __builtin_amdgcn_mfma_f32_32x32x16_f16(an1, bn1, accn, 0, 0, 0);
-                uint32_t rejected = mfma_fence(accg, accn);           // 0, available once all three MFMAs have written back
-                if (PACKED) {
-                    const v2f32 c2v = { neg_tminw, neg_tminw };
+                uint32_t rejected = 0u;
 #pragma unroll
-                    for (int r = 0; r < 16; r += 2) {
-                        const v2f32 n2 = { accn[r], accn[r + 1] }, g2 = { accg[r], accg[r + 1] };
-                        rejected = shift_in_reject2(rejected, n2, g2, c2v);
-                    }
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float w = fma_clamp(accn[r], accn[r], neg_tminw);
-                        rejected = shift_in_reject(rejected, accg[r], w);
-                    }
-                }
+                for (int r = 0; r < 16; ++r) rejected = shift_in_reject(rejected, accn[r], accg[r]);
                 const uint32_t surv = ~rejected & 0xFFFFu;              // bit 15 - r: accumulator r survived
                 const unsigned long long any = __ballot(surv != 0u);
                 if (any) {
@@ -327,28 +331,19 @@ int launch_score_prefilter(sfm_pair *pair, const sfm_ransac_params &p, uint32_t 
     sfm_ctx *ctx = pair->ctx;
     PfScales sc;
     if (!prefilter_scales(p.threshold, sc)) { set_error("threshold %g outside the pre-filter's range", (double)p.threshold); return SFM_E_INVALID; }
-    // A/B switch: reserved[0] = 2 -> two pairs per v_pk_fma_f32 ... clamp.  Measured SLOWER (0.789 vs 0.743 ms per 2^20 x 4096):
-    // packed FP32 instructions issued next to MFMAs stall the matrix pipe (MI355X_MICROARCH.md), so the default is one pair per v_fma_f32
-    const bool packed = p.reserved[0] == 2;
-    const int rc_lds = allow_big_lds(ctx, packed ? reinterpret_cast<const void *>(&ransac_score_prefilter<true>)
-                                                 : reinterpret_cast<const void *>(&ransac_score_prefilter<false>));
+    const int rc_lds = allow_big_lds(ctx, reinterpret_cast<const void *>(&ransac_score_prefilter));
     if (rc_lds != SFM_OK) return rc_lds;
     const int ntiles = (pair->ld + kPfTile - 1) / kPfTile;
     const uint32_t iters = (count + 64u * kPfWaves - 1) / (64u * kPfWaves);       // 1024-hypothesis block iterations per tile
-    // one block per CU is resident (140 KiB of LDS) and staging a tile is not overlapped with anything, so few, long
+    // one block per CU is resident (156 KiB of LDS) and staging a tile is not overlapped with anything, so few, long
     // blocks: about two per CU (measured on 2^20 x 4096: 1.39 ms with 256 blocks, 1.41 with 512, 1.47 with 1024, 1.63 with 4096)
     uint32_t cols = (uint32_t)(2 * ctx->num_cus + ntiles - 1) / (uint32_t)ntiles;
     if (p.reserved[2] > 0) cols = (uint32_t)p.reserved[2];
     if (cols > iters) cols = iters;
     if (cols < 1) cols = 1;
-    if (packed)
-        hipLaunchKernelGGL(ransac_score_prefilter<true>, dim3(cols, ntiles), dim3(kPfWaves * 64), kPfLdsBytes, ctx->stream,
-                           pair->d_X[0], pair->d_X[1], pair->ld, pair->n, pair->d_Ecand, h0, count, p.threshold, sc,
-                           pair->d_counts, pair->d_tick, pair->d_key, key2, pair->d_clk);
-    else
-        hipLaunchKernelGGL(ransac_score_prefilter<false>, dim3(cols, ntiles), dim3(kPfWaves * 64), kPfLdsBytes, ctx->stream,
-                           pair->d_X[0], pair->d_X[1], pair->ld, pair->n, pair->d_Ecand, h0, count, p.threshold, sc,
-                           pair->d_counts, pair->d_tick, pair->d_key, key2, pair->d_clk);
+    hipLaunchKernelGGL(ransac_score_prefilter, dim3(cols, ntiles), dim3(kPfWaves * 64), kPfLdsBytes, ctx->stream,
+                       pair->d_X[0], pair->d_X[1], pair->ld, pair->n, pair->d_Ecand, h0, count, p.threshold, sc,
+                       pair->d_counts, pair->d_tick, pair->d_key, key2, pair->d_clk);
     SFM_HIP_TRY(hipGetLastError());
     pair->last_grid = (int)cols * ntiles; pair->last_block = kPfWaves * 64; pair->last_lds = kPfLdsBytes;
     return SFM_OK;

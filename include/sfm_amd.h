@@ -209,6 +209,12 @@ int sfm_pair_flush(sfm_pair *pair);
  * finalize the winning hypothesis id on every rank. */
 int sfm_ransac_score(sfm_pair *pair, const sfm_ransac_params *p);
 int sfm_ransac_finalize(sfm_pair *pair, const sfm_ransac_params *p, uint32_t hyp);
+/* calculateInliers on its own (sfm.cu:155-236 takes the E candidates as its input): scores hyp_count caller-supplied
+ * candidates (d_E: 9 floats each, row-major, DEVICE memory; candidate k has hypothesis id hyp_begin + k) instead of
+ * solving them from 8-tuples.  Leaves the counts (sfm_get_inlier_counts), the candidates (sfm_get_E_candidates) and
+ * the packed key (sfm_get_key).  sfm_ransac_finalize re-derives E from the hypothesis' tuple, so it does not apply
+ * to candidates that did not come from one. */
+int sfm_ransac_score_candidates(sfm_pair *pair, const sfm_ransac_params *p, const float *d_E);
 /* Device-resident variants: copy the local key into caller memory (e.g. the tensor handed to the
  * RCCL all-reduce) and finalize from a reduced key without any host round trip. */
 int sfm_ransac_export_key(sfm_pair *pair, uint64_t *d_key_out);

@@ -43,6 +43,17 @@ int sfm_estimate_E_sharded(sfm_pair *pair, sfm_ransac_params *p, sfm_comm *comm)
 int sfm_estimate_E_sharded_pipelined(sfm_pair *pair, sfm_ransac_params *p, sfm_comm *comm);
 int sfm_comm_flush(sfm_comm *comm);
 
+/* BASELINE configs[4] over all ranks: many views -> ExtractSift (views dealt round-robin: rank r extracts r, r + G, ...) ->
+ * ONE ncclAllGather of fixed-size feature slots -> per pair MatchSiftData + the Image_pair sequence on the rank that owns
+ * it (pairs r, r + G, ... of the list; sfm_process_pairs) -> ONE ncclAllGather of fixed-size result records.
+ * h_images: num_views host images (width x height floats, grey 0..255); h_pairs: num_pairs x 2 view indices;
+ * h_records: num_pairs x 28 floats on EVERY rank (layout of sfm_get_result; all -1 for a pair with too few features);
+ * h_counts (optional): features per view.  Synchronous; every rank calls it with the same arguments. */
+int sfm_process_views_sharded(sfm_comm *comm, const float h_K[9], const float h_Kinv[9], const float *const *h_images, int num_views,
+                              int width, int height, const int *h_pairs, int num_pairs, int max_pts, int num_octaves,
+                              double init_blur, float thresh, float lowest_scale, int scale_up, uint32_t num_hypotheses,
+                              int pose_mode, float *h_records, int *h_counts);
+
 #ifdef __cplusplus
 }
 #endif

@@ -17,9 +17,6 @@ for cfg in headline c3 c4; do for k in 4 1; do
 import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']
 print(json.dumps({'config':'$cfg','kernel':d['config']['kernel']['name'],'ms_per_step':round(d['ms_per_step'],4),'score_ms':round(r['avg_launch_ms'],4),'frac':round(r['frac'],4),'clock_mhz':round(r['shader_clock_mhz']),'grid':d['config']['kernel']['grid'],'result':d['result']}))" >> $O/${TAG}_prefilter_ab.txt
 done; done
-python3 bench.py --serial --steps 30 --warmup 5 --no-cpu --no-variants --kernel 4 --reserved 2 2>/dev/null | python3 -c "
-import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']
-print(json.dumps({'config':'headline, packed FP32 scan (reserved[0]=2)','score_ms':round(r['avg_launch_ms'],4),'frac':round(r['frac'],4)}))" >> $O/${TAG}_prefilter_ab.txt
 for h in 16384 32768 65536 131072 262144; do for k in 4 1; do
   python3 bench.py --serial --hyps $h --steps 50 --warmup 5 --no-cpu --no-variants --kernel $k 2>/dev/null | python3 -c "
 import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']

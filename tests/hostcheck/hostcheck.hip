@@ -18,16 +18,42 @@ int hc_pf_scales(float thr, int *a, float *sigE, float *sigF, float *sig2a)
     return ok ? 1 : 0;
 }
 
-// coefficient slots of one hypothesis as floats (the fp16 values, widened); returns tmin
-float hc_pf_hyp_slots(const float *e, float thr, float B, float *ns /*32*/, float *ts /*16*/)
+// coefficient slots of one hypothesis as floats (the fp16 values, widened); returns c2
+float hc_pf_hyp_slots(const float *e, float thr, float B, int survive_all, float *ns /*32*/, float *ts /*16*/)
 {
     sfm::PfScales sc{};
     if (!sfm::prefilter_scales(thr, sc)) return -1.0f;
     _Float16 n16[sfm::kPfSlots], t16[sfm::kPfSlotsT];
-    const float tmin = sfm::prefilter_hyp_slots(e, thr, B, sc, n16, t16);
+    const float c2 = sfm::prefilter_hyp_slots(e, thr, B, sc, n16, t16, survive_all != 0);
     for (int k = 0; k < sfm::kPfSlots; ++k) ns[k] = (float)n16[k];
     for (int k = 0; k < sfm::kPfSlotsT; ++k) ts[k] = (float)t16[k];
-    return tmin;
+    return c2;
+}
+
+// zero-divisor guard: state (0 none / 1 cells / 2 scan) and the cell range; cell index and key of a coordinate pair
+int hc_pf_zero_divisor_cells(const float *e, float B, int *cells /*4: cx0 cx1 cy0 cy1*/, float *g)
+{
+    const sfm::PfGrid gr = sfm::prefilter_grid(B);
+    *g = gr.g;
+    return sfm::prefilter_zero_divisor_cells(e, B, gr, cells[0], cells[1], cells[2], cells[3]);
+}
+
+void hc_pf_point_cell(float x, float y, float B, int *cell /*2*/, uint32_t *key)
+{
+    const sfm::PfGrid gr = sfm::prefilter_grid(B);
+    cell[0] = sfm::pf_cell(x, gr); cell[1] = sfm::pf_cell(y, gr);
+    *key = sfm::pf_cell_key(cell[0], cell[1]);
+}
+
+uint32_t hc_pf_cell_key(int ix, int iy) { return sfm::pf_cell_key(ix, iy); }
+
+int hc_pf_zero_divisor(const float *e, float x, float y) { return sfm::prefilter_zero_divisor(e, x, y) ? 1 : 0; }
+
+int hc_pf_zero_divisor_any(const float *e, const float *x, const float *y, int n)
+{
+    int c = 0;
+    for (int k = 0; k < n; ++k) c += sfm::prefilter_zero_divisor(e, x[k], y[k]) ? 1 : 0;
+    return c;
 }
 
 void hc_pf_point_slots(float u, float v, float x, float y, int real, float *bn /*32*/, float *bt /*16*/)
@@ -38,7 +64,7 @@ void hc_pf_point_slots(float u, float v, float x, float y, int real, float *bn /
     for (int k = 0; k < sfm::kPfSlotsT; ++k) bt[k] = (float)t16[k];
 }
 
-int hc_pf_reject(float nt, float G, float tminw_scaled) { return sfm::prefilter_reject(nt, G, tminw_scaled) ? 1 : 0; }
+int hc_pf_reject(float nt, float G) { return sfm::prefilter_reject(nt, G) ? 1 : 0; }
 
 void hc_sample8(uint32_t seed, uint32_t hyp, int n, int *idx) { sfm::sample8(seed, hyp, n, idx); }
 

@@ -39,6 +39,17 @@ for _ in range(5):                                              # pipelined: the
     comm.estimate_E_pipelined(pair, q)
 comm.flush()
 ok = ok and pair.get_best() == ref[3] and np.array_equal(pair.get_E().view(np.uint32), ref[1].view(np.uint32)) and np.array_equal(pair.get_inlier_mask(), ref[2])
+# configs[4] inside the C libraries: 5 views (spare slot on the last rank), 5 pairs, against the single-GPU path
+w, h = 384, 288
+base_d = np.array([5.0, 8.0, 12.0, 16.0, 7.0, 10.0], np.float32)
+views = [synth.stereo_pair(w, h, seed=9, disparities=tuple(0.6 * k * base_d))[1] if k else synth.stereo_pair(w, h, seed=9)[0] for k in range(5)]
+K, Kinv = synth.camera(w, h)
+pairs = [(0, 1), (1, 2), (4, 0), (2, 4), (3, 1)]
+sift = dict(num_octaves=4, thresh=2.0)
+vref, vcounts = S.process_views(ctx, views, K, Kinv, pairs=pairs, max_pts=4096, sift=sift, device=dev)
+vres, counts = comm.process_views(views, K, Kinv, pairs=pairs, max_pts=4096, sift=sift)
+ok = ok and counts == vcounts and sorted(vres) == sorted(vref) and len(vref) == len(pairs)
+ok = ok and all(np.array_equal(vres[k].view(np.uint32), vref[k].view(np.uint32)) for k in vref)
 t = torch.tensor([1 if ok else 0], dtype=torch.int64, device=dev)
 dist.all_reduce(t, op=dist.ReduceOp.MIN)
 if rank == 0:

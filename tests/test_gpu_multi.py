@@ -45,6 +45,29 @@ def test_pipelined_step_single_rank_equals_estimateE(gpu):
     comm.close()
 
 
+def test_process_views_sharded_single_rank(gpu):
+    """sfm_process_views_sharded (configs[4] inside the C libraries: extract -> ncclAllGather of feature slots -> owned
+    pairs -> ncclAllGather of records) with a 1-rank communicator against process_views on the same synthetic views;
+    a pair list that is not the ring, and a second call with fewer views through the cached buffers."""
+    torch, dev, ctx = gpu
+    w, h = 384, 288
+    base_d = np.array([5.0, 8.0, 12.0, 16.0, 7.0, 10.0], np.float32)
+    views = [synth.stereo_pair(w, h, seed=9, disparities=tuple(0.6 * k * base_d))[1] if k else synth.stereo_pair(w, h, seed=9)[0] for k in range(5)]
+    K, Kinv = synth.camera(w, h)
+    pairs = [(0, 1), (1, 2), (4, 0), (2, 4), (3, 1)]
+    sift = dict(num_octaves=4, thresh=2.0)
+    ref, rcounts = S.process_views(ctx, views, K, Kinv, pairs=pairs, max_pts=4096, sift=sift, device=dev)
+    comm = S.Comm(ctx, S.Comm.unique_id(), 0, 1)
+    res, counts = comm.process_views(views, K, Kinv, pairs=pairs, max_pts=4096, sift=sift)
+    assert counts == rcounts and sorted(res) == sorted(ref) and len(ref) == len(pairs)
+    for pid in ref:
+        assert same_bits(res[pid], ref[pid]), f"pair {pid}"
+    res2, counts2 = comm.process_views(views[:3], K, Kinv, max_pts=4096, sift=sift)
+    ref2, _ = S.process_views(ctx, views[:3], K, Kinv, max_pts=4096, sift=sift, device=dev)
+    assert counts2 == rcounts[:3] and all(same_bits(res2[k], ref2[k]) for k in ref2) and sorted(res2) == sorted(ref2)
+    comm.close()
+
+
 @pytest.mark.parametrize("world", [2, 3, 8])
 @pytest.mark.parametrize("sweeps", [0, 7])
 def test_estimate_E_distributed_shard_cuts_on_one_gpu(gpu, world, sweeps):

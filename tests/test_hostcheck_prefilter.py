@@ -23,9 +23,14 @@ def H():
     h = C.CDLL(LIB)
     h.hc_pf_scales.argtypes = [C.c_float, C.POINTER(C.c_int), f32p, f32p, f32p]
     h.hc_pf_hyp_slots.restype = C.c_float
-    h.hc_pf_hyp_slots.argtypes = [f32p, C.c_float, C.c_float, f32p, f32p]
+    h.hc_pf_hyp_slots.argtypes = [f32p, C.c_float, C.c_float, C.c_int, f32p, f32p]
     h.hc_pf_point_slots.argtypes = [C.c_float] * 4 + [C.c_int, f32p, f32p]
-    h.hc_pf_reject.argtypes = [C.c_float] * 3
+    h.hc_pf_reject.argtypes = [C.c_float] * 2
+    h.hc_pf_zero_divisor_cells.argtypes = [f32p, C.c_float, C.POINTER(C.c_int), f32p]
+    h.hc_pf_point_cell.argtypes = [C.c_float, C.c_float, C.c_float, C.POINTER(C.c_int), C.POINTER(C.c_uint32)]
+    h.hc_pf_cell_key.restype = C.c_uint32
+    h.hc_pf_cell_key.argtypes = [C.c_int, C.c_int]
+    h.hc_pf_zero_divisor_any.argtypes = [f32p, f32p, f32p, C.c_int]
     return h
 
 
@@ -48,30 +53,64 @@ def point_slots(H, X0, X1, n_real=None):
     return Bn.astype(np.float64), Bt.astype(np.float64)
 
 
-def hyp_slots(H, E, thr, B):
+def hyp_slots(H, E, thr, B, survive_all=False):
     e = np.ascontiguousarray(E, np.float32).reshape(9)
     ns = np.zeros(32, np.float32); ts = np.zeros(16, np.float32)
-    tmin = H.hc_pf_hyp_slots(fp(e), thr, B, fp(ns), fp(ts))
-    return ns.astype(np.float64), ts.astype(np.float64), float(tmin)
+    c2 = H.hc_pf_hyp_slots(fp(e), thr, B, int(survive_all), fp(ns), fp(ts))
+    return ns.astype(np.float64), ts.astype(np.float64), float(c2)
 
 
-def rejected(H, ns, ts, tminw_scaled, Bn, Bt):
-    """The rule under the worst accumulation error: returns a bool array, True where ANY admissible perturbation rejects."""
+def rejected(H, ns, ts, Bn, Bt):
+    """The rule (sign of fma(-nt, nt, G)) under the worst accumulation error: returns a bool array, True where ANY
+    admissible perturbation rejects."""
     nt = Bn @ ns; G = Bt @ ts
     en = ACC * (np.abs(Bn) @ np.abs(ns)); eg = ACC * (np.abs(Bt) @ np.abs(ts))
     out = np.zeros(nt.shape, bool)
     for sn in (1.0, -1.0, 0.0):
         for sg in (1.0, -1.0, 0.0):
-            n32 = (np.sign(nt) * (np.abs(nt) + sn * en)).astype(np.float32)
-            g32 = (G + sg * eg).astype(np.float32)
-            with np.errstate(invalid="ignore", over="ignore"):
-                w = (n32.astype(np.float64) * n32.astype(np.float64) - np.float64(np.float32(tminw_scaled))).astype(np.float32)   # fma: one rounding
-            w = np.where(np.isnan(w), 0.0, np.clip(w, 0.0, 1.0)).astype(np.float32)
-            out |= g32.view(np.uint32) < w.view(np.uint32)
+            n32 = (np.sign(nt) * (np.abs(nt) + sn * en)).astype(np.float32).astype(np.float64)
+            g32 = (G + sg * eg).astype(np.float32).astype(np.float64)
+            out |= (g32 - n32 * n32) < 0.0                       # exact in float64 (24 + 48 bits): the sign a single-rounding fma returns
     return out
 
 
-def check_scene(H, X0, X1, Es, thr, n_real=None, max_survivors=None):
+class ZeroDivisorGuard:
+    """prefilter_math.hpp (3) as the kernel stages it: occupied cells of the tile's points, per hypothesis the 2 x 2 cell
+    test, and the scan of the whole tile for those it cannot clear.  decide() also checks the guard's own claim -- a
+    hypothesis it clears must not have a zero-divisor point (brute force over the tile)."""
+
+    def __init__(self, H, X1, n, B):
+        self.H, self.B = H, float(B)
+        ok = np.isfinite(X1[:2, :n]).all(axis=0)
+        self.x = np.ascontiguousarray(X1[0, :n], np.float32); self.y = np.ascontiguousarray(X1[1, :n], np.float32)
+        self.n = n
+        self.keys = set()
+        cell = (C.c_int * 2)(); key = C.c_uint32()
+        for j in np.nonzero(ok)[0]:
+            H.hc_pf_point_cell(float(self.x[j]), float(self.y[j]), self.B, cell, C.byref(key))
+            self.keys.add(key.value)
+        self.states = [0, 0, 0]
+        self.scans = 0
+
+    def decide(self, E):
+        e = np.ascontiguousarray(E, np.float32).reshape(9)
+        cells = (C.c_int * 4)(); g = C.c_float()
+        st = self.H.hc_pf_zero_divisor_cells(fp(e), self.B, cells, C.byref(g))
+        self.states[st] += 1
+        with np.errstate(invalid="ignore"):
+            truth = self.H.hc_pf_zero_divisor_any(fp(e), fp(self.x), fp(self.y), self.n) > 0
+        if st == 1:
+            assert 0 <= cells[1] - cells[0] <= 1 and 0 <= cells[3] - cells[2] <= 1
+            hit = any(self.H.hc_pf_cell_key(cx, cy) in self.keys for cx in range(cells[0], cells[1] + 1) for cy in range(cells[2], cells[3] + 1))
+            st = 2 if hit else 0
+        if st == 0:
+            assert not truth, "the guard cleared a hypothesis that has a zero-divisor point in the tile"
+            return False
+        self.scans += 1
+        return truth
+
+
+def check_scene(H, X0, X1, Es, thr, n_real=None, max_survivors=None, scans_below=None):
     ok, a, (sigE, sigF, sig2a) = scales(H, thr)
     assert ok
     n = X0.shape[1] if n_real is None else n_real
@@ -80,21 +119,21 @@ def check_scene(H, X0, X1, Es, thr, n_real=None, max_survivors=None):
         B = float(np.max(c[c <= 48.0], initial=0.0))
     Bn, Bt = point_slots(H, X0, X1, n_real)
     surv = 0
-    prepared = [hyp_slots(H, E, thr, B) for E in Es]
-    for w0 in range(0, len(Es), 32):
-        grp = prepared[w0:w0 + 32]
-        tminw_scaled = max(g[2] for g in grp) * sig2a               # what the wavefront of these 32 rows uses
-        for E, (ns, ts, tmin) in zip(Es[w0:w0 + 32], grp):
-            rej = rejected(H, ns, ts, tminw_scaled, Bn, Bt)
-            _, mask = O.count_inliers(np.ascontiguousarray(E, np.float32).reshape(3, 3), X0[:, :n], X1[:, :n], thr)
-            inl = np.zeros(rej.shape, bool); inl[:n] = mask.astype(bool)
-            assert not (rej & inl).any(), f"rejected {int((rej & inl).sum())} oracle inliers"
-            if n_real is not None:
-                assert rej[n:].all(), "padding must always be rejected"
-            surv += int((~rej[:n]).sum())
+    guard = ZeroDivisorGuard(H, X1, n, B)
+    for E in Es:
+        ns, ts, _ = hyp_slots(H, E, thr, B, guard.decide(E))
+        rej = rejected(H, ns, ts, Bn, Bt)
+        _, mask = O.count_inliers(np.ascontiguousarray(E, np.float32).reshape(3, 3), X0[:, :n], X1[:, :n], thr)
+        inl = np.zeros(rej.shape, bool); inl[:n] = mask.astype(bool)
+        assert not (rej & inl).any(), f"rejected {int((rej & inl).sum())} oracle inliers"
+        if n_real is not None:
+            assert rej[n:].all(), "padding must always be rejected"
+        surv += int((~rej[:n]).sum())
     rate = surv / (len(Es) * n)
     if max_survivors is not None:
         assert rate < max_survivors, f"survivor rate {rate:.4f}"
+    if scans_below is not None:
+        assert guard.scans <= scans_below * len(Es), f"{guard.scans} of {len(Es)} hypotheses needed a tile scan"
     return rate
 
 
@@ -105,7 +144,7 @@ def test_no_oracle_inlier_is_rejected(H, thr, focal):
     sc = synth.two_view_scene(n, seed=7, focal=focal)
     _, _, X0, X1 = O.fill_xu(sc["sift"], sc["Kinv"])
     Es = [O.hypothesis_E(X0, X1, O.sample8(99, h, n), 0) for h in range(96)]
-    rate = check_scene(H, X0, X1, Es, np.float32(thr))
+    rate = check_scene(H, X0, X1, Es, np.float32(thr), scans_below=0.05)
     if thr == 1e-6 and focal == 2360.0:
         assert rate < 0.03                                          # and it still filters: ~1 % survive at the reference threshold
 
@@ -144,11 +183,26 @@ def test_zero_divisor_pairs_survive(H):
     cnt, mask = O.count_inliers(E2, Y0, Y1, np.float32(1e-6))
     assert mask[0] == 1 and mask[1] == 1 and mask[2] == 0 and mask[5] == 0
     check_scene(H, Y0, Y1, [E2], np.float32(1e-6))
-    # the test is live: without the zero-divisor guard (G pushed positive) the rule WOULD reject those inliers
-    ns, ts, tmin = hyp_slots(H, E2, np.float32(1e-6), 0.3)
+    # the test is live: without the zero-divisor guard the rule WOULD reject those inliers
+    ns, ts, _ = hyp_slots(H, E2, np.float32(1e-6), 0.3, survive_all=False)
     Bn, Bt = point_slots(H, Y0, Y1)
-    ts_bad = ts.copy(); ts_bad[15] += 1e-3
-    assert rejected(H, ts=ts_bad, ns=ns, tminw_scaled=tmin * scales(H, 1e-6)[2][2], Bn=Bn, Bt=Bt)[:2].all()
+    assert rejected(H, ns, ts, Bn, Bt)[:2].all()
+    g = ZeroDivisorGuard(H, Y1, 8, 0.3)
+    assert g.decide(E2) and g.scans == 1
+
+
+@pytest.mark.parametrize("scale,thr", [(0.3, 1e-6), (5.0, 1e-3)])
+def test_crafted_candidates_of_the_gpu_test(H, scale, thr):
+    """The candidate set of tests/test_gpu_prefilter.py::test_prefilter_supplied_candidates_and_zero_divisors through the
+    host model of the rule (one tile of it)."""
+    from helpers import crafted_candidates, lattice_points
+    rng = np.random.default_rng(3)
+    X0, X1 = lattice_points(rng, 1024, scale)
+    Es = crafted_candidates(rng, X1, 1024, 512)
+    kept = sum(O.count_inliers(Es[h], X0, X1, np.float32(thr))[0] for h in range(10, 512, 16))
+    assert kept > 0
+    with np.errstate(invalid="ignore", over="ignore"):
+        check_scene(H, X0, X1, list(Es), np.float32(thr))
 
 
 def test_degenerate_hypotheses_and_points(H):
@@ -185,3 +239,71 @@ def test_threshold_range(H):
     for thr, ok in ((1e-10, 0), (1e-9, 1), (1e-6, 1), (1e-2, 1), (0.02, 0), (float("nan"), 0)):
         assert scales(H, thr)[0] == ok
     assert scales(H, 1e-6)[1] == 7 and scales(H, 1e-6)[2] == [8.0, 16.0, 16384.0]
+
+
+def exact_zero_family(rng, pts, count):
+    """Matrices whose first two rows vanish EXACTLY (in float arithmetic) at one of the given points: coefficients with few
+    mantissa bits and points on a 2^-12 lattice make every product and sum exact.  Well and ill conditioned 2 x 2 parts."""
+    out = []
+    coef = np.array([-1.5, -1.0, -0.75, -0.5, -0.25, 0.25, 0.5, 0.75, 1.0, 1.5])
+    while len(out) < count:
+        px, py = pts[rng.integers(len(pts))]
+        a, b = rng.choice(coef, 2)
+        kind = rng.integers(4)
+        if kind == 0:
+            c, d = rng.choice(coef, 2)
+        elif kind == 1:
+            c, d = a + 2.0 ** -rng.integers(4, 12), b                      # nearly parallel rows
+        elif kind == 2:
+            c, d = 2.0 * a, 2.0 * b                                        # parallel rows: singular, a whole line of zeros
+            if abs(c) > 2 or abs(d) > 2:
+                c, d = 0.5 * a, 0.5 * b
+        else:
+            c, d = 0.0, 0.0                                                # second row vanishes identically with b1 = 0
+        e2 = -(a * px + b * py); e5 = -(c * px + d * py)
+        E = np.array([[a, b, e2], [c, d, e5], rng.uniform(-1, 1, 3)], np.float64)
+        if np.abs(E).max() > 2.0:
+            continue
+        E32 = E.astype(np.float32)
+        assert np.array_equal(E32.astype(np.float64)[:2], E[:2])
+        out.append(E32)
+    return out
+
+
+def test_zero_divisor_guard_claims(H):
+    """The per-(hypothesis, tile) guard on its own: whenever it clears a hypothesis (no cell hit), brute force must find no
+    point with da_c == 0 (asserted inside decide); crafted exact zeros must be found; random matrices hardly ever scan."""
+    rng = np.random.default_rng(12)
+    n = 1024
+    for scale in (0.3, 1.0, 7.0, 40.0):
+        lattice = 2.0 ** -12 * 2.0 ** np.ceil(np.log2(scale))
+        X1 = np.ones((3, n), np.float32)
+        X1[:2] = (np.round(rng.uniform(-scale, scale, (2, n)) / lattice) * lattice).astype(np.float32)
+        X1[0, 5] = np.nan; X1[1, 6] = np.inf
+        B = float(np.abs(X1[:2][np.isfinite(X1[:2])]).max())
+        guard = ZeroDivisorGuard(H, X1, n, B)
+        pts = [(float(X1[0, j]), float(X1[1, j])) for j in range(8, 200)]
+        found = 0
+        fam = exact_zero_family(rng, pts, 300)
+        for E in fam:
+            found += bool(guard.decide(E))
+        assert found == len(fam), "every crafted matrix has an exact zero divisor in the tile"
+        # the same matrices moved off the lattice: the zero is (almost always) gone, the claim still has to hold
+        for E in fam[:150]:
+            E2 = E.copy(); E2[0, 2] = np.nextafter(E2[0, 2], np.float32(9), dtype=np.float32)
+            guard.decide(E2)
+        scans0 = guard.scans
+        for _ in range(1500):
+            M = rng.normal(size=(3, 3)) * rng.choice([1e-3, 0.05, 1.0], size=(3, 3))
+            M *= rng.uniform(0.1, 1.9) / max(1e-9, np.abs(M).max())
+            assert not guard.decide(M.astype(np.float32)) or True
+        assert guard.scans - scans0 < 0.6 * 1500                          # badly scaled on purpose; real hypotheses: test_no_oracle_inlier_is_rejected (< 5 %)
+    # degenerate inputs: all-zero, zero 2 x 2 part with and without a constant, non-finite entries
+    X1 = np.ones((3, 64), np.float32); X1[:2] = rng.uniform(-0.3, 0.3, (2, 64)).astype(np.float32)
+    guard = ZeroDivisorGuard(H, X1, 64, 0.3)
+    assert guard.decide(np.zeros((3, 3), np.float32))
+    assert not guard.decide(np.array([[0, 0, 0.5], [0, 0, 0], [1, 0, 0]], np.float32))
+    assert guard.decide(np.array([[0, 0, 0], [0, 0, 0], [1, 0, 0]], np.float32))
+    assert guard.decide(np.array([[0, 0, 1e-30], [0, 0, 1e-30], [1, 0, 0]], np.float32))       # the squares underflow
+    with np.errstate(invalid="ignore"):
+        assert not guard.decide(np.full((3, 3), np.nan, np.float32))
