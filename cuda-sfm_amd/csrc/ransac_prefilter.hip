@@ -12,7 +12,7 @@
 // steps:
 //     3 x ds_read_b128 -> 3 MFMAs (G: 1, nt: 2) -> per accumulator v_fma (G - nt^2), v_alignbit (its sign bit) (no branch)
 // which leaves every lane with a 16-bit "rejected" mask of its 16 pairs.  Lanes with a surviving pair append one word to
-// the wavefront's ring in LDS; 64 entries at a time go through the exact filter, one entry per lane, and inliers bump the
+// the wavefront's ring in LDS (two 32-point steps share one append); 64 entries at a time go through the exact filter, one entry per lane, and inliers bump the
 // hypothesis' counter in LDS.  Tiles are spread over blockIdx.y; partial counts reach counts[] through integer atomics
 // (order-independent, so the result is deterministic); the wavefront that adds the last tile of a hypothesis group folds its
 // keys into the shard's arg-max key.
@@ -23,7 +23,8 @@ namespace sfm {
 
 constexpr int kPfTile = 1024;            // points per tile
 constexpr int kPfWaves = 16;
-constexpr int kPfRing = 256;             // survivor ring entries per wavefront: < 64 waiting + 64 appended per step + 64 re-queued by a flush
+constexpr int kPfRing = 128;             // survivor ring entries (8 bytes) per wavefront: < 64 waiting + 64 appended per step;
+                                         // a flush re-queues at most 64 more, onto slots its own 64 entries have just left
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef float f16v __attribute__((ext_vector_type(16)));
 typedef int i4v __attribute__((ext_vector_type(4)));
@@ -33,7 +34,7 @@ constexpr int kPfLdsBn = 0;                                   // [32-point block
 constexpr int kPfLdsBt = kPfLdsBn + kPfTile * 64;             // [32-point block][lane][8 fp16]
 constexpr int kPfLdsPts = kPfLdsBt + kPfTile * 32;            // float4 (x1x, x1y, x2x, x2y) per point
 constexpr int kPfLdsWave = kPfLdsPts + kPfTile * 16;          // per wavefront: E table 32 x 9 floats, 32 counters, ring
-constexpr int kPfWaveBytes = 32 * 9 * 4 + 32 * 4 + kPfRing * 4;
+constexpr int kPfWaveBytes = 32 * 9 * 4 + 32 * 4 + kPfRing * 8;
 constexpr int kPfLdsBound = kPfLdsWave + kPfWaves * kPfWaveBytes;
 constexpr int kPfHashSlots = 2048;                             // occupied grid cells of the tile (<= 1024 keys): open addressing, 0 = empty
 constexpr int kPfLdsHash = kPfLdsBound + 16;
@@ -61,36 +62,47 @@ __device__ __forceinline__ h8 fetch_fragment(const h8 &xs, const h8 &ys, int src
     return __builtin_bit_cast(h8, o);
 }
 
+// LDS through address-space-3 pointers: pf_flush is a real call (three sites), and plain pointers passed into it would be
+// generic ones -- flat loads / stores / atomics instead of ds_* instructions.
+typedef uint32_t u2v __attribute__((ext_vector_type(2)));
+typedef float f4v __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) u2v lds_u2;
+typedef __attribute__((address_space(3))) const f4v lds_cf4;
+typedef __attribute__((address_space(3))) const float lds_cf;
+typedef __attribute__((address_space(3))) int lds_i;
+
 // Exact decision for up to 64 ring entries starting at `head`, one entry per lane: the lane evaluates the FIRST surviving
-// pair of its entry; an entry that holds more (one in fifteen) goes back to the tail of the ring with the rest of its
-// mask, so that every pass of the exact filter runs on (nearly) 64 busy lanes.  Returns the number of re-queued entries.
-// entry = (point block << 22) | (lane << 16) | 16-bit mask of surviving accumulators (bit 15 - r = accumulator r).
-__device__ __noinline__ int pf_flush(uint32_t *ring, int head, int nent, int tail, int lane, const float *etab, int *cnt,
-                                     const float4 *pts, int nvalid_hyp, float thr)
+// pair of its entry; an entry that holds more goes back to the tail of the ring with the rest of its mask, so that every
+// pass of the exact filter runs on (nearly) 64 busy lanes.  Returns the number of re-queued entries.
+// entry = { 32-bit mask of surviving accumulators (bit 31 - r: accumulator r of the pair's first point block, bit 15 - r:
+// of its second), (point-block pair << 6) | lane }.
+__device__ __noinline__ int pf_flush(lds_u2 *ring, int head, int nent, int tail, int lane, lds_cf *etab, lds_i *cnt,
+                                     lds_cf4 *pts, int nvalid_hyp, ThrBand band)
 {
-    uint32_t rest = 0, ent = 0;
+    uint32_t rest = 0, tag = 0;
     if (lane < nent) {
-        const ThrBand band = make_band(thr);
-        ent = ring[(head + lane) & (kPfRing - 1)];
-        const int l = (ent >> 16) & 63, pb = ent >> 22;
-        const uint32_t surv = ent & 0xFFFFu;
+        const u2v ent = ring[(head + lane) & (kPfRing - 1)];
+        tag = ent.y;
+        const uint32_t surv = ent.x;
         rest = surv & (surv - 1);
-        const int r = 15 - __builtin_ctz(surv);
+        const int b = __builtin_ctz(surv);
+        const int r = 15 - (b & 15);
+        const int l = tag & 63, pb = 2 * (int)(tag >> 6) + ((b >> 4) ^ 1);
         const int hl = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);               // accumulator row = local hypothesis
         if (hl < nvalid_hyp) {
-            const float4 q = pts[pb * 32 + (l & 31)];
-            const float *e = etab + 9 * hl;
+            const f4v q = pts[pb * 32 + (l & 31)];
+            lds_cf *e = etab + 9 * hl;
             const Ess E{ e[0], e[1], e[2], e[3], e[4], e[5], e[6], e[7], e[8] };
             bool und;
             bool in = inlier_filter(E, band, q.x, q.y, 1.0f, q.z, q.w, 1.0f, und);
             if (und) in = residual(E, q.x, q.y, 1.0f, q.z, q.w, 1.0f) < band.thr;
-            if (in) atomicAdd(&cnt[hl], 1);
+            if (in) __hip_atomic_fetch_add(cnt + hl, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     }
     const unsigned long long more = __ballot(rest != 0u);
     if (more) {
         const int slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(more >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)more, 0u));
-        if (rest) ring[(tail + slot) & (kPfRing - 1)] = (ent & 0xFFFF0000u) | rest;
+        if (rest) ring[(tail + slot) & (kPfRing - 1)] = u2v{ rest, tag };
     }
     return __builtin_popcountll(more);
 }
@@ -166,8 +178,12 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
     const int npb = (min(kPfTile, ld - tile_first) + 31) >> 5;           // 32-point blocks that hold points or padding
     float *etab = reinterpret_cast<float *>(smem + kPfLdsWave + wave * kPfWaveBytes);
     int *cnt = reinterpret_cast<int *>(etab + 32 * 9);
-    uint32_t *ring = reinterpret_cast<uint32_t *>(cnt + 32);
     const float4 *pts = reinterpret_cast<const float4 *>(smem + kPfLdsPts);
+    lds_cf *etab_l = (lds_cf *)etab;
+    lds_i *cnt_l = (lds_i *)cnt;
+    lds_u2 *ring = (lds_u2 *)(cnt + 32);
+    lds_cf4 *pts_l = (lds_cf4 *)pts;
+    const ThrBand band = make_band(thr);
     const h8 *bn_l = reinterpret_cast<const h8 *>(smem + kPfLdsBn) + lane;
     const h8 *bt_l = reinterpret_cast<const h8 *>(smem + kPfLdsBt) + lane;
     const int half = lane >> 5, row = lane & 31;
@@ -253,31 +269,39 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
             }
 
             int head = 0, nq = 0;                       // ring state (wave-uniform)
-            for (int pb = 0; pb < npb; ++pb) {
-                const h8 bt0 = bt_l[pb * 64];
-                const h8 bn0 = bn_l[(pb * 2 + 0) * 64], bn1 = bn_l[(pb * 2 + 1) * 64];
-                f16v accg = {}, accn = {};
-                accg = __builtin_amdgcn_mfma_f32_32x32x16_f16(at, bt0, accg, 0, 0, 0);
-                accn = __builtin_amdgcn_mfma_f32_32x32x16_f16(an0, bn0, accn, 0, 0, 0);
-                accn = __builtin_amdgcn_mfma_f32_32x32x16_f16(an1, bn1, accn, 0, 0, 0);
-                uint32_t rejected = 0u;
+            const int npp = (npb + 1) >> 1;             // two 32-point blocks per iteration (a block beyond npb holds padding only: all rejected)
+            for (int pp = 0; pp < npp; ++pp) {
+                uint32_t rej[2];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) rejected = shift_in_reject(rejected, accn[r], accg[r]);
-                const uint32_t surv = ~rejected & 0xFFFFu;              // bit 15 - r: accumulator r survived
-                const unsigned long long any = __ballot(surv != 0u);
+                for (int sub = 0; sub < 2; ++sub) {
+                    const int pb = 2 * pp + sub;
+                    const h8 bt0 = bt_l[pb * 64];
+                    const h8 bn0 = bn_l[(pb * 2 + 0) * 64], bn1 = bn_l[(pb * 2 + 1) * 64];
+                    f16v accg = {}, accn = {};
+                    accg = __builtin_amdgcn_mfma_f32_32x32x16_f16(at, bt0, accg, 0, 0, 0);
+                    accn = __builtin_amdgcn_mfma_f32_32x32x16_f16(an0, bn0, accn, 0, 0, 0);
+                    accn = __builtin_amdgcn_mfma_f32_32x32x16_f16(an1, bn1, accn, 0, 0, 0);
+                    uint32_t rejected = 0u;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) rejected = shift_in_reject(rejected, accn[r], accg[r]);
+                    rej[sub] = rejected;                    // < 2^16: sixteen bits shifted into 0
+                }
+                const uint32_t rej32 = (rej[0] << 16) | rej[1];
+                const bool mine = rej32 != 0xFFFFFFFFu;
+                const unsigned long long any = __ballot(mine);
                 if (any) {
-                    while (nq >= 64) {                  // make room first (< 64 waiting + 64 appended + 64 re-queued < ring size)
-                        const int back = pf_flush(ring, head, 64, head + nq, lane, etab, cnt, pts, nvalid, thr);
+                    while (nq >= 64) {                  // make room first
+                        const int back = pf_flush(ring, head, 64, head + nq, lane, etab_l, cnt_l, pts_l, nvalid, band);
                         head = (head + 64) & (kPfRing - 1); nq += back - 64;
                     }
                     const int slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(any >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)any, 0u));
-                    if (surv) ring[(head + nq + slot) & (kPfRing - 1)] = ((uint32_t)pb << 22) | ((uint32_t)lane << 16) | surv;
+                    if (mine) ring[(head + nq + slot) & (kPfRing - 1)] = u2v{ ~rej32, ((uint32_t)pp << 6) | (uint32_t)lane };
                     nq += __builtin_popcountll(any);
                 }
             }
             while (nq > 0) {
                 const int m = min(nq, 64);
-                const int back = pf_flush(ring, head, m, head + nq, lane, etab, cnt, pts, nvalid, thr);
+                const int back = pf_flush(ring, head, m, head + nq, lane, etab_l, cnt_l, pts_l, nvalid, band);
                 head = (head + m) & (kPfRing - 1); nq += back - m;
             }
             // LDS counters -> counts[] (zeroed by the solve kernel); a wavefront's LDS operations complete in order
