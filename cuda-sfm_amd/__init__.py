@@ -57,7 +57,7 @@ EXPORTS = [
     "sfm_pair_device_ptr", "sfm_pair_ld", "sfm_pair_num_points", "sfm_get_XU", "sfm_get_E", "sfm_get_best",
     "sfm_get_key", "sfm_get_inlier_counts", "sfm_get_inlier_mask", "sfm_get_E_candidates",
     "sfm_get_pose_candidates", "sfm_get_pose_inverses", "sfm_get_pose_index", "sfm_get_points", "sfm_copy_points_to_vbo",
-    "sfm_ransac_last_launch", "sfm_ransac_last_clock", "sfm_process_pairs", "sfm_extract_views",
+    "sfm_ransac_last_launch", "sfm_ransac_last_clock", "sfm_ransac_last_phases", "sfm_process_pairs", "sfm_extract_views",
 ]
 
 
@@ -109,6 +109,7 @@ _lib.sfm_estimate_E.argtypes = [_vp, C.POINTER(RansacParams)]
 _lib.sfm_ransac_score.argtypes = [_vp, C.POINTER(RansacParams)]
 _lib.sfm_ransac_score_into.argtypes = [_vp, C.POINTER(RansacParams), _vp]
 _lib.sfm_ransac_score_candidates.argtypes = [_vp, C.POINTER(RansacParams), _vp]
+_lib.sfm_ransac_last_phases.argtypes = [_vp, C.POINTER(C.c_uint64)]
 _lib.sfm_ransac_finalize.argtypes = [_vp, C.POINTER(RansacParams), C.c_uint32]
 _lib.sfm_ransac_finalize_key.argtypes = [_vp, C.POINTER(RansacParams), _vp]
 _lib.sfm_ransac_finalize_key_on.argtypes = [_vp, C.POINTER(RansacParams), _vp, _vp]
@@ -349,6 +350,12 @@ class ImagePair:
             _check(_lib.sfm_ransac_score(self._h, C.byref(params)), "sfm_ransac_score")
         else:
             _check(_lib.sfm_ransac_score_into(self._h, C.byref(params), _ptr(key_out)), "sfm_ransac_score_into")
+
+    def last_phases(self):
+        """sfm_ransac_last_phases: 8 tick values of block 0 of the last pre-filter scoring launch."""
+        t = (C.c_uint64 * 8)()
+        _check(_lib.sfm_ransac_last_phases(self._h, t), "sfm_ransac_last_phases")
+        return list(t)
 
     def ransac_score_candidates(self, params, d_E):
         """calculateInliers on its own: score caller-supplied candidates (float32 device tensor, 9 x hyp_count)."""

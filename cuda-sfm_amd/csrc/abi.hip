@@ -385,13 +385,13 @@ int sfm_pair_create(sfm_ctx *ctx, const float h_K[9], const float h_Kinv[9], int
     A(&p->d_E, 9); A(&p->d_P, 64); A(&p->d_Pinv, 64); A(&p->d_Pind, 8);
     A(&p->d_points, (size_t)4 * num_points);
     A(&p->d_mask, (size_t)num_points);
-    A(&p->d_key, 2); A(&p->d_best, 2); A(&p->d_clk, 2);
+    A(&p->d_key, 2); A(&p->d_best, 2); A(&p->d_clk, 8);
     if (rc != SFM_OK) { sfm_pair_destroy(p); return rc; }
     hipError_t e = hipMemcpyAsync(p->d_K, h_K, 9 * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(p->d_Kinv, h_Kinv, 9 * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipMemsetAsync(p->d_key, 0, 2 * sizeof(unsigned long long), ctx->stream);
     if (e == hipSuccess) e = hipMemsetAsync(p->d_best, 0, 2 * sizeof(uint32_t), ctx->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(p->d_clk, 0, 2 * sizeof(unsigned long long), ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(p->d_clk, 0, 8 * sizeof(unsigned long long), ctx->stream);
     if (e == hipSuccess) e = hipMemsetAsync(p->d_Pind, 0, 8 * sizeof(int), ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);       // host K arrays may go out of scope
     if (e != hipSuccess) { sfm_pair_destroy(p); set_error("pair init failed: %s", hipGetErrorString(e)); return SFM_E_HIP; }
@@ -1046,6 +1046,16 @@ int sfm_ransac_last_clock(sfm_pair *pair, double *shader_mhz)
     int rc = copy_out(pair, c, pair->d_clk, sizeof(c));
     if (rc != SFM_OK) return rc;
     *shader_mhz = c[1] ? 100.0 * (double)c[0] / (double)c[1] : 0.0;
+    return SFM_OK;
+}
+
+int sfm_ransac_last_phases(sfm_pair *pair, uint64_t ticks[8])
+{
+    SFM_REQUIRE(pair && ticks, SFM_E_INVALID, "null argument");
+    unsigned long long c[8] = { 0 };
+    int rc = copy_out(pair, c, pair->d_clk, sizeof(c));
+    if (rc != SFM_OK) return rc;
+    for (int k = 0; k < 8; ++k) ticks[k] = c[k];
     return SFM_OK;
 }
 

@@ -57,7 +57,7 @@ constexpr float kPfRho = 0.125f;
 constexpr float kPfFeatScale = 16.0f;    // sigF: features of n are stored times 16 (fp16 low parts stay normal)
 constexpr float kPfPadValue = 256.0f;    // k-slot 27 of a padding point: nt = 256, G = 0 (or 2^-10) -> nt^2 > G: rejected
 
-struct PfScales { int a; float sigE, sigF, sig2a; };
+struct PfScales { int a; float sigE, sigF, sig2a, inv_sig2a; };
 
 // Power-of-two scaling: nt is carried as 2^a n, G as 2^2a T''; a is chosen from the threshold so that 2^2a T''
 // stays below 1 (T'' <= ~12 thr for |E_ij| <= 1.5, |coordinates| <= 1).  Returns false when the threshold is outside
@@ -72,6 +72,7 @@ SFM_HD bool prefilter_scales(float thr, PfScales &sc)
     sc.sigE = ldexpf(1.0f, a - 4);
     sc.sigF = kPfFeatScale;
     sc.sig2a = ldexpf(1.0f, 2 * a);
+    sc.inv_sig2a = ldexpf(1.0f, -2 * a);
     return true;
 }
 
@@ -131,7 +132,7 @@ SFM_HD float prefilter_hyp_slots(const float e[9], float thr, float B, const PfS
     const float aq = (ae[0] * ae[0] + ae[3] * ae[3]) + 2.0f * (ae[0] * ae[1] + ae[3] * ae[4]) + (ae[1] * ae[1] + ae[4] * ae[4]);
     const float al = 2.0f * (ae[0] * ae[2] + ae[3] * ae[5]) + 2.0f * (ae[1] * ae[2] + ae[4] * ae[5]);
     const float sabsT = aq * B * B + al * B + C;
-    const float terr = s * 2.8610229e-06f * sabsT + 4.7683716e-07f * (B * B + B + 1.0f + 4.0f * s * sc.sig2a) / sc.sig2a   // 16 * 2^-25
+    const float terr = s * 2.8610229e-06f * sabsT + 4.7683716e-07f * (B * B + B + 1.0f + 4.0f * s * sc.sig2a) * sc.inv_sig2a   // 16 * 2^-25
                      + 4.9e-04f * s * C;                                                                                   // 2^-11: the one-part constant
     const float eta = 2.3841858e-07f * (ae[2] + ae[5] + B * (ae[0] + ae[1] + ae[3] + ae[4]));                                 // 4 * 2^-24
     const float c2 = 1.25f * terr + s * 262.6f * eta * eta + (1.0f + 1.0f / kPfRho) * 1.01f * dn * dn + 1e-37f;
@@ -151,6 +152,16 @@ SFM_HD float prefilter_hyp_slots(const float e[9], float thr, float B, const PfS
 
 // ---- (3): which points of a tile can make da_c == 0 for this hypothesis
 struct PfGrid { float g, ginv; };
+
+// 1 / x to within 1 ulp on the device (v_rcp_f32), correctly rounded on the host: every use below carries a 1.001 slack.
+SFM_HD float pf_rcp(float x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rcpf(x);
+#else
+    return 1.0f / x;
+#endif
+}
 
 // Grid pitch for a tile whose coordinates are bounded by B: 2^-11 of the next power of two above B.
 SFM_HD PfGrid prefilter_grid(float B)
@@ -175,7 +186,9 @@ SFM_HD int pf_cell(float c, const PfGrid &gr)
 // Non-zero hash of a cell (equal cells -> equal keys; different cells may collide, which only costs a tile scan).
 SFM_HD uint32_t pf_cell_key(int ix, int iy)
 {
-    return hash32((uint32_t)ix * 0x9E3779B1u ^ hash32((uint32_t)iy + 0x7F4A7C15u)) | 1u;
+    uint32_t k = (uint32_t)ix * 0x9E3779B1u ^ (uint32_t)iy * 0x85EBCA6Bu;
+    k ^= k >> 15;
+    return (k * 0x2C1B3C6Du) | 1u;
 }
 
 // The divisor of the first residual term exactly as residual() / inlier_filter() compute it (z = 1).
@@ -196,7 +209,7 @@ SFM_HD int prefilter_zero_divisor_cells(const float e[9], float B, const PfGrid 
     const float det = fmaf(-e[1], e[3], e[0] * e[4]);
     const float detlo = fabsf(det) - 2.3841858e-07f * (a0 * a4 + a1 * a3);            // 2^-22 (|e0 e4| + |e1 e3|) >= 2 x the rounding of det
     if (!(detlo > 1e-30f) || !(sumA <= 8.0f)) return 2;
-    const float inv = 1.0f / det;
+    const float inv = pf_rcp(det);
     const float xc = fmaf(e[1], e[5], -(e[2] * e[4])) * inv, yc = fmaf(e[2], e[3], -(e[0] * e[5])) * inv;   // any accuracy will do
     if (!(fabsf(xc) <= 1e6f) || !(fabsf(yc) <= 1e6f)) {
         // the solution is far outside the tile; A x + b cannot vanish on |x| <= B if |b| dominates: |a_i*| >= |b_i| - B (|A_i0| + |A_i1|)
@@ -210,7 +223,7 @@ SFM_HD int prefilter_zero_divisor_cells(const float e[9], float B, const PfGrid 
     const float m0 = a0 * ax + a1 * ay + fabsf(e[2]), m1 = a3 * ax + a4 * ay + fabsf(e[5]);
     const float R = fmaxf(fabsf(r0), fabsf(r1)) + 2.3841858e-07f * fmaxf(m0, m1);     // 2^-22 (sum of |terms|) >= 2 x two fma roundings
     const float eta = 2.3841858e-07f * (fabsf(e[2]) + fabsf(e[5]) + B * sumA) * 1.001f + 1e-18f;   // 4 * 2^-24 (...) as in prefilter_hyp_slots, + the 2^-75 below which a square vanishes (2^-63 were denormals flushed)
-    float rad = (sumA / detlo) * (eta + R) * 1.001f;
+    float rad = (sumA * pf_rcp(detlo)) * (eta + R) * 1.001f;
     rad = rad + 4.7683716e-07f * (fmaxf(ax, ay) + rad);                                // the roundings of xc -+ rad below
     if (!(rad <= 0.5f * gr.g)) return 2;
     const float lx = xc - rad, hx = xc + rad, ly = yc - rad, hy = yc + rad;

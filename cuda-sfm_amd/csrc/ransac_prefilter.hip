@@ -8,7 +8,7 @@
 // One block = 16 wavefronts sharing one tile of 1024 points, staged ONCE in LDS: fp16 feature fragments (the B operands
 // of v_mfma_f32_32x32x16_f16, 96 bytes per point) and the plain coordinates for the exact test (16 bytes per point).
 // A wavefront prepares the coefficient fragments (A operands) of 64 hypotheses at a time, one hypothesis per lane, and
-// hands them to the two 32-row blocks through a half-wave exchange; for each 32-row block it walks the tile in 32-point
+// hands them to the two 32-row blocks through a half-wave exchange (v_permlane32_swap); for each 32-row block it walks the tile in 32-point
 // steps:
 //     3 x ds_read_b128 -> 3 MFMAs (G: 1, nt: 2) -> per accumulator v_fma (G - nt^2), v_alignbit (its sign bit) (no branch)
 // which leaves every lane with a 16-bit "rejected" mask of its 16 pairs.  Lanes with a surviving pair append one word to
@@ -48,18 +48,21 @@ __device__ __forceinline__ uint32_t shift_in_reject(uint32_t rejected, float nt,
     return __builtin_amdgcn_alignbit(rejected, __float_as_uint(fmaf(-nt, nt, G)), 31);
 }
 
-// The fragment of hypothesis row `src` for this lane's k-half: every lane offers both halves of the row it prepared, the
-// reader keeps the one its MFMA lane position asks for (ds_bpermute through __shfl; no LDS storage involved).
-__device__ __forceinline__ h8 fetch_fragment(const h8 &xs, const h8 &ys, int src, int half)
+// Coefficient fragments of both 32-row blocks from what every lane prepared for ITS hypothesis: xs = k-slots 0..7 (what
+// MFMA lanes 0..31 hold), ys = k-slots 8..15 (lanes 32..63).  v_permlane32_swap exchanges lanes 32..63 of its first
+// operand with lanes 0..31 of its second: afterwards the first holds { x of hypotheses 0..31 | y of hypotheses 0..31 } --
+// the A fragment of block 0 -- and the second { x of 32..63 | y of 32..63 } -- block 1.  One instruction per dword.
+__device__ __forceinline__ void fetch_fragments(const h8 &xs, const h8 &ys, h8 &f0, h8 &f1)
 {
     const i4v xi = __builtin_bit_cast(i4v, xs), yi = __builtin_bit_cast(i4v, ys);
-    i4v o;
+    i4v o0, o1;
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
-        const int fx = __shfl(xi[d], src), fy = __shfl(yi[d], src);
-        o[d] = half ? fy : fx;
+        const auto r = __builtin_amdgcn_permlane32_swap((unsigned int)xi[d], (unsigned int)yi[d], false, false);
+        o0[d] = (int)r[0]; o1[d] = (int)r[1];
     }
-    return __builtin_bit_cast(h8, o);
+    f0 = __builtin_bit_cast(h8, o0);
+    f1 = __builtin_bit_cast(h8, o1);
 }
 
 // LDS through address-space-3 pointers: pf_flush is a real call (three sites), and plain pointers passed into it would be
@@ -119,7 +122,21 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
     const bool probe = clk && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0;
     unsigned long long c0 = 0, w0 = 0;
     if (probe) { c0 = clock64(); w0 = wall_clock64(); }
-
+    // the candidates of this wavefront's first pass: requested before the tile is staged, so that their way through the
+    // memory system overlaps the staging instead of the first coefficient preparation
+    const uint32_t npass = (count + 63u) / 64u;
+    const uint32_t ps_first = blockIdx.x * kPfWaves + wave;
+    float e_first[9];
+    {
+        const uint32_t hf = min(ps_first, npass - 1u) * 64u;
+        const float *src = Ecand + 9 * (size_t)(hf + (uint32_t)min(lane, (int)min(64u, count - hf) - 1));
+#pragma unroll
+        for (int k = 0; k < 9; ++k) e_first[k] = src[k];
+    }
+    // ... and parked in the wavefront's own LDS area (64 x 9 floats = exactly the E table + counters + ring, all unused
+    // until the first pass starts) so that they do not occupy registers while the tile is staged
+    float *park = reinterpret_cast<float *>(smem + kPfLdsWave + wave * kPfWaveBytes);
+    static_assert(kPfWaveBytes >= 64 * 9 * 4, "the first pass' candidates are parked in the wavefront's LDS area");
     // ---- stage the tile: one point per thread -> 48 fp16 feature slots in MFMA B-fragment order + its coordinates
     unsigned int &tile_bound = *reinterpret_cast<unsigned int *>(smem + kPfLdsBound);
     uint32_t *cells = reinterpret_cast<uint32_t *>(smem + kPfLdsHash);
@@ -135,6 +152,8 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
         float u = 0.f, v = 0.f, x = 0.f, y = 0.f;
         const bool real = p < n;
         if (real) { u = X0[p]; v = X0[(size_t)ld + p]; x = X1[p]; y = X1[(size_t)ld + p]; }
+#pragma unroll
+        for (int k = 0; k < 9; ++k) park[k * 64 + lane] = e_first[k];           // (issued before the coordinates: arrives first)
         _Float16 bn[kPfSlots], bt[kPfSlotsT];
         prefilter_point_slots(u, v, x, y, real, bn, bt);
         const float big = fmaxf(fmaxf(fabsf(u), fabsf(v)), fmaxf(fabsf(x), fabsf(y)));
@@ -163,6 +182,7 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
     }
     __syncthreads();
     const float B = __uint_as_float(tile_bound);
+    if (probe) clk[2] = wall_clock64() - w0;
     // the occupied cells of the zero-divisor grid (prefilter_math.hpp (3)); its pitch follows the tile's bound
     const PfGrid grid = prefilter_grid(B);
     if (hashed) {
@@ -189,13 +209,15 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
     const int half = lane >> 5, row = lane & 31;
 
     // ---- 64 hypotheses per pass of this wavefront (no block-level synchronisation from here on)
-    const uint32_t npass = (count + 63u) / 64u;
-    for (uint32_t ps = blockIdx.x * kPfWaves + wave; ps < npass; ps += gridDim.x * kPfWaves) {
+    for (uint32_t ps = ps_first; ps < npass; ps += gridDim.x * kPfWaves) {
         const uint32_t h_first = ps * 64u;
         const int nvalid64 = (int)min(64u, count - h_first);
         // coefficient slots: lane l prepares hypothesis h_first + l (lanes beyond the range repeat the last one)
         float e[9];
-        {
+        if (ps == ps_first) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) e[k] = park[k * 64 + lane];
+        } else {
             const float *src = Ecand + 9 * (size_t)(h_first + (uint32_t)min(lane, nvalid64 - 1));
 #pragma unroll
             for (int k = 0; k < 9; ++k) e[k] = src[k];
@@ -237,6 +259,7 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
         }
         _Float16 ns[kPfSlots], ts[kPfSlotsT];
         (void)prefilter_hyp_slots(e, thr, B, sc, ns, ts, survive_all);
+        const bool probe1 = probe && ps == 0u;
         // X* = k-slots 0..7 of each 16-slot step (the fragment of MFMA lanes 0..31), Y* = k-slots 8..15 (lanes 32..63).
         // Rows of block b were prepared by lanes 32 b .. 32 b + 31; MFMA lane l needs row l % 32, k-half l / 32.
         h8 fn0[2], fn1[2], ft[2];
@@ -248,18 +271,15 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
                 xn1[j] = ns[16 + j]; yn1[j] = ns[24 + j];
                 xt[j] = ts[j];       yt[j] = ts[8 + j];
             }
-#pragma unroll
-            for (int blk = 0; blk < 2; ++blk) {
-                const int src = 32 * blk + row;
-                fn0[blk] = fetch_fragment(xn0, yn0, src, half);
-                fn1[blk] = fetch_fragment(xn1, yn1, src, half);
-                ft[blk] = fetch_fragment(xt, yt, src, half);
-            }
+            fetch_fragments(xn0, yn0, fn0[0], fn0[1]);
+            fetch_fragments(xn1, yn1, fn1[0], fn1[1]);
+            fetch_fragments(xt, yt, ft[0], ft[1]);
         }
 #pragma unroll
         for (int blk = 0; blk < 2; ++blk) {
             const int nvalid = min(32, nvalid64 - 32 * blk);
             if (nvalid <= 0) break;
+            if (probe1 && blk == 0) clk[3] = wall_clock64() - w0;
             const h8 an0 = fn0[blk], an1 = fn1[blk], at = ft[blk];
             // E table and counters of this block (the previous block's ring is drained, its counters are flushed)
             if (half == blk) {
@@ -304,6 +324,7 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
                 const int back = pf_flush(ring, head, m, head + nq, lane, etab_l, cnt_l, pts_l, nvalid, band);
                 head = (head + m) & (kPfRing - 1); nq += back - m;
             }
+            if (probe1 && blk == 0) clk[4] = wall_clock64() - w0;
             // LDS counters -> counts[] (zeroed by the solve kernel); a wavefront's LDS operations complete in order
             if (lane < nvalid) {
                 const int c = cnt[lane];
@@ -336,6 +357,8 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
                 if (best_key2) atomicMax(best_key2, k);
             }
         }
+        if (probe1) clk[5] = wall_clock64() - w0;
+        if (probe) clk[6] = (unsigned long long)((ps - blockIdx.x * kPfWaves) / (gridDim.x * kPfWaves) + 1u);
     }
     if (probe) { clk[0] = clock64() - c0; clk[1] = wall_clock64() - w0; }
 }

@@ -313,6 +313,11 @@ int sfm_ransac_last_launch(sfm_pair *pair, int *kernel, int *grid, int *block, i
 /* Sustained shader clock (MHz) during the last wavefront-scoring launch (SFM_KERNEL_SPLIT): shader-clock ticks over
  * 100 MHz ticks across the lifetime of its first block; 0 if that kernel has not run.  Synchronises. */
 int sfm_ransac_last_clock(sfm_pair *pair, double *shader_mhz);
+/* Where block 0 of the last pre-filter scoring launch (SFM_KERNEL_PREFILTER) spent its time: ticks[0] shader-clock ticks and
+ * ticks[1] 100 MHz ticks over its lifetime (as above); 100 MHz ticks since its start at: [2] tile staged, [3] first pass'
+ * coefficients prepared, [4] first 32-hypothesis block scanned and drained, [5] first pass done (counts and ticket out),
+ * [6] number of passes wavefront 0 ran.  Zero where the kernel that ran has no such probe.  Synchronises. */
+int sfm_ransac_last_phases(sfm_pair *pair, uint64_t ticks[8]);
 
 #ifdef __cplusplus
 }
