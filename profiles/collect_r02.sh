@@ -31,7 +31,11 @@ python3 profiles/sift_bench.py > $O/${TAG}_sift_bench.txt 2>/dev/null
 python3 profiles/small_h_bench.py > $O/${TAG}_small_h_bench.txt 2>/dev/null
 ./profiles/probes/mfma_f16_probe.bin > $O/${TAG}_mfma_f16_probe.txt 2>&1
 ./profiles/probes/pk_clamp_probe.bin > $O/${TAG}_pk_clamp_probe.txt 2>&1
-python3 tests/fuzz_gpu.py 120 21 > $O/${TAG}_fuzz_last.txt 2>/dev/null
+python3 tests/fuzz_gpu.py 300 99 > $O/${TAG}_fuzz.txt 2>/dev/null
+python3 profiles/prefilter_soak.py 420 7 > $O/${TAG}_prefilter_soak.txt 2>/dev/null
+python3 profiles/phase_probe.py 2>/dev/null | grep hypotheses > $O/${TAG}_phase_probe.txt
+python3 profiles/enqueue_probe.py 2>/dev/null | grep hypotheses > $O/${TAG}_enqueue_probe.txt
+sh profiles/small_shard_ab.sh 2>/dev/null | grep hyps > $O/${TAG}_small_shard_ab.txt
 # 3. rocprof: kernel stats of the bench command (headline, c3, c4) and one multi-GPU-sized step (131072 hypotheses: what one of 8 ranks runs)
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_stats -o bench -- python3 $R/bench.py --serial --steps 100 --warmup 20 --no-cpu --no-variants > /dev/null 2>&1
@@ -65,4 +69,4 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_${TAG}_$
 python3 $R/profiles/pmc_summary.py $O/pmc_${TAG}_${cfg}_1 $O/pmc_${TAG}_${cfg}_2 $O/pmc_${TAG}_${cfg}_3 $O/pmc_${TAG}_${cfg}_f $O/pmc_${TAG}_${cfg}_w > $O/pmc_${TAG}_${cfg}_summary.txt
 done
 python3 $R/profiles/make_traffic_json.py $O/pmc_${TAG}_headline_summary.txt > $O/${TAG}_traffic.json
-cat $O/${TAG}_prefilter_ab.txt | head -8; head -5 $O/${TAG}_bench_kernel_stats.csv | cut -c1-200; cat $O/${TAG}_rank8_step_timeline.txt; cat $O/${TAG}_traffic.json | head -30; tail -3 $O/${TAG}_ring_bench.txt | cut -c1-300; cat $O/${TAG}_fuzz_last.txt | tail -1
+cat $O/${TAG}_prefilter_ab.txt | head -8; head -5 $O/${TAG}_bench_kernel_stats.csv | cut -c1-200; cat $O/${TAG}_rank8_step_timeline.txt; cat $O/${TAG}_traffic.json | head -30; tail -3 $O/${TAG}_ring_bench.txt | cut -c1-300; tail -1 $O/${TAG}_fuzz.txt; tail -1 $O/${TAG}_prefilter_soak.txt

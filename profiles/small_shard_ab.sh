@@ -1,9 +1,7 @@
 R=${GRAFT_REPO_ROOT:-$(pwd)}; cd $R
-tail -3 gpurun_out/quick_pytest.txt 2>/dev/null
 run() { python bench.py "$@" --no-cpu --no-variants 2>/dev/null | tail -1 | python -c "
 import json,sys; d=json.loads(sys.stdin.read()); r=d['roofline']
 print('%-50s ms_per_step %.4f score %.4f solve %.4f grid %s' % ('$*', d['ms_per_step'], r['avg_launch_ms'], r['solve_kernel_avg_ms'], d['config']['kernel']['grid']))"; }
-python -m pytest tests/test_gpu_prefilter.py tests/test_gpu_ransac.py -x -q 2>&1 | tail -2
 for h in 131072 262144; do
 run --hyps $h --serial
 run --hyps $h --serial --reserved 1
