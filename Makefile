@@ -60,7 +60,7 @@ $(GEOMTEST): tests/cpp/geom_test.cpp $(PKG)/host/geomFuncs.h $(PKG)/host/sfm_io.
 
 hostcheck: tests/hostcheck/libhostcheck.so
 
-tests/hostcheck/libhostcheck.so: tests/hostcheck/hostcheck.hip $(CSRC)/device_math.hpp $(CSRC)/sift_math.hpp
+tests/hostcheck/libhostcheck.so: tests/hostcheck/hostcheck.hip $(CSRC)/device_math.hpp $(CSRC)/sift_math.hpp $(CSRC)/prefilter_math.hpp $(CSRC)/match_prefilter_math.hpp
 	$(HIPCC) -x hip --cuda-host-only -O2 -ffp-contract=off -mfma -fPIC -shared -Wno-pass-failed -o $@ $<
 
 clean:

@@ -34,6 +34,7 @@ _lib = C.CDLL(LIB_PATH)
 OK, E_INVALID, E_HIP, E_NOMEM, E_STATE, E_SINGULAR = 0, -1, -2, -3, -4, -5
 KERNEL_AUTO, KERNEL_SPLIT, KERNEL_FUSED, KERNEL_MFMA, KERNEL_PREFILTER = 0, 1, 2, 3, 4
 QUIRK_MATCH_TAIL = 1
+MATCH_AUTO, MATCH_EXACT, MATCH_PREFILTER = 0, 1, 2
 POSE_REFERENCE, POSE_CORRECT = 0, 1
 (BUF_X0, BUF_X1, BUF_U0, BUF_U1, BUF_E, BUF_P, BUF_PINV, BUF_POINTS, BUF_COUNTS, BUF_MASK, BUF_KEY,
  BUF_ECAND, BUF_PIND) = range(13)
@@ -47,17 +48,17 @@ SIFT_DTYPE = np.dtype([
 assert SIFT_DTYPE.itemsize == 576
 
 EXPORTS = [
-    "sfm_abi_version", "sfm_last_error", "sfm_ctx_create", "sfm_ctx_destroy", "sfm_ctx_set_stream", "sfm_ctx_set_quirks",
+    "sfm_abi_version", "sfm_last_error", "sfm_ctx_create", "sfm_ctx_destroy", "sfm_ctx_set_stream", "sfm_ctx_set_quirks", "sfm_ctx_set_match_kernel", "sfm_ctx_last_match_kernel",
     "sfm_ctx_synchronize", "sfm_ctx_own_stream", "sfm_ctx_get_stream", "sfm_ctx_get_device", "sfm_ctx_timer_start", "sfm_ctx_timer_stop", "sfm_ctx_kernel_timing",
     "sfm_ctx_kernel_timing_read", "sfm_device_alloc", "sfm_device_free", "sfm_copy_to_device", "sfm_copy_to_host",
     "sfm_copy_to_host_2d", "sfm_copy_to_device_2d", "sfm_find_homography", "sfm_sift_temp_layout", "sfm_extract_sift", "sfm_extract_sift_begin", "sfm_extract_sift_end", "sfm_match", "sfm_match_soa",
     "sfm_pair_create", "sfm_pair_destroy", "sfm_pair_reset", "sfm_get_result", "sfm_fill_xu", "sfm_set_points", "sfm_ransac_default_params",
     "sfm_ransac_permutation_indices", "sfm_estimate_E", "sfm_ransac_score", "sfm_ransac_score_candidates", "sfm_ransac_score_into", "sfm_ransac_finalize",
-    "sfm_ransac_finalize_key", "sfm_ransac_finalize_key_on", "sfm_ransac_score_into_slot", "sfm_estimate_E_pipelined", "sfm_pair_flush", "sfm_ransac_export_key", "sfm_pose_candidates", "sfm_choose_pose", "sfm_triangulate",
+    "sfm_ransac_finalize_key", "sfm_ransac_finalize_key_on", "sfm_ransac_score_into_slot", "sfm_estimate_E_pipelined", "sfm_pair_flush", "sfm_ransac_export_key", "sfm_pose_candidates", "sfm_choose_pose", "sfm_triangulate", "sfm_pose_chain",
     "sfm_pair_device_ptr", "sfm_pair_ld", "sfm_pair_num_points", "sfm_get_XU", "sfm_get_E", "sfm_get_best",
     "sfm_get_key", "sfm_get_inlier_counts", "sfm_get_inlier_mask", "sfm_get_E_candidates",
     "sfm_get_pose_candidates", "sfm_get_pose_inverses", "sfm_get_pose_index", "sfm_get_points", "sfm_copy_points_to_vbo",
-    "sfm_ransac_last_launch", "sfm_ransac_last_clock", "sfm_ransac_last_phases", "sfm_process_pairs", "sfm_extract_views",
+    "sfm_ransac_last_launch", "sfm_ransac_last_clock", "sfm_ransac_last_phases", "sfm_prefilter_probe", "sfm_process_pairs", "sfm_extract_views",
 ]
 
 
@@ -119,6 +120,7 @@ _lib.sfm_ransac_export_key.argtypes = [_vp, _vp]
 _lib.sfm_pose_candidates.argtypes = [_vp, C.c_int]
 _lib.sfm_choose_pose.argtypes = [_vp, C.c_int]
 _lib.sfm_triangulate.argtypes = [_vp, C.c_int]
+_lib.sfm_pose_chain.argtypes = [_vp, C.c_int]
 _lib.sfm_pair_device_ptr.argtypes = [_vp, C.c_int, C.POINTER(_vp), C.POINTER(C.c_size_t)]
 _lib.sfm_pair_ld.argtypes = [_vp]
 _lib.sfm_pair_num_points.argtypes = [_vp]
@@ -217,6 +219,23 @@ class Context:
     def set_quirks(self, flags):
         """SFM_QUIRK_* behaviours of the reference for A/B runs (QUIRK_MATCH_TAIL: skip the last num_pts2 % 32 points)."""
         _check(_lib.sfm_ctx_set_quirks(self._h, C.c_uint(int(flags))), "sfm_ctx_set_quirks")
+
+    def set_match_kernel(self, kernel):
+        """MATCH_AUTO / MATCH_EXACT / MATCH_PREFILTER (bit-identical results; A/B runs and tests)."""
+        _check(_lib.sfm_ctx_set_match_kernel(self._h, int(kernel)), "sfm_ctx_set_match_kernel")
+
+    def last_match_kernel(self):
+        k = C.c_int(0)
+        _check(_lib.sfm_ctx_last_match_kernel(self._h, C.byref(k)), "sfm_ctx_last_match_kernel")
+        return k.value
+
+    def prefilter_probe(self, E, threshold, bound, point, survive_all=False):
+        """Operands and matrix-core results of one (hypothesis, point) pair of the pre-filter kernel (test probe)."""
+        e = np.ascontiguousarray(E, np.float32).reshape(9); pt = np.ascontiguousarray(point, np.float32).reshape(4)
+        out = np.zeros(100, np.float32)
+        _check(_lib.sfm_prefilter_probe(self._h, e.ctypes.data_as(_vp), C.c_float(float(threshold)), C.c_float(float(bound)), pt.ctypes.data_as(_vp),
+                                        int(bool(survive_all)), out.ctypes.data_as(_vp)), "sfm_prefilter_probe")
+        return {"ns": out[0:32], "ts": out[32:48], "bn": out[48:80], "bt": out[80:96], "nt": out[96], "G": out[97], "rejected": bool(out[98]), "zero_divisor_state": int(out[99])}
 
     def own_stream(self):
         """Give the context a non-blocking stream of its own (for a second context next to a torch-owned one)."""
@@ -389,6 +408,10 @@ class ImagePair:
 
     def linear_triangulation(self, mode=POSE_REFERENCE):
         _check(_lib.sfm_triangulate(self._h, int(mode)), "sfm_triangulate")
+
+    def pose_chain(self, mode=POSE_REFERENCE):
+        """computePosecandidates + choosePose + linear_triangulation (src/main.cpp:302-306) in one launch (REFERENCE mode)."""
+        _check(_lib.sfm_pose_chain(self._h, int(mode)), "sfm_pose_chain")
 
     computePoseCandidates = computePosecandidates     # BASELINE.json spelling
     linearTriangulate = linear_triangulation

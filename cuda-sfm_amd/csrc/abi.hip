@@ -90,6 +90,7 @@ int sfm_ctx_destroy(sfm_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->match_ws) (void)hipFree(ctx->match_ws);
+    if (ctx->match_pf_ws) (void)hipFree(ctx->match_pf_ws);
     if (ctx->homo_ws) (void)hipFree(ctx->homo_ws);
     if (ctx->sift_temp) (void)hipFree(ctx->sift_temp);
     if (ctx->sift_ws) (void)hipFree(ctx->sift_ws);
@@ -122,6 +123,22 @@ int sfm_ctx_set_quirks(sfm_ctx *ctx, unsigned int flags)
     SFM_REQUIRE(ctx, SFM_E_INVALID, "null context");
     SFM_REQUIRE((flags & ~SFM_QUIRK_MATCH_TAIL) == 0, SFM_E_INVALID, "unknown quirk flags 0x%x", flags);
     ctx->quirks = flags;
+    return SFM_OK;
+}
+
+int sfm_ctx_set_match_kernel(sfm_ctx *ctx, int kernel)
+{
+    SFM_REQUIRE(ctx, SFM_E_INVALID, "null context");
+    SFM_REQUIRE(kernel == SFM_MATCH_AUTO || kernel == SFM_MATCH_EXACT || kernel == SFM_MATCH_PREFILTER, SFM_E_INVALID, "unknown matcher %d", kernel);
+    ctx->match_kernel = kernel;
+    for (sfm_ctx *l : ctx->lane) if (l) l->match_kernel = kernel;
+    return SFM_OK;
+}
+
+int sfm_ctx_last_match_kernel(sfm_ctx *ctx, int *kernel)
+{
+    SFM_REQUIRE(ctx && kernel, SFM_E_INVALID, "null argument");
+    *kernel = ctx->last_match_kernel;
     return SFM_OK;
 }
 
@@ -676,6 +693,27 @@ int sfm_triangulate(sfm_pair *pair, int mode)
     return rc;
 }
 
+static int pose_chain(sfm_pair *pair, int mode, float *d_record)
+{
+    SFM_REQUIRE(pair, SFM_E_INVALID, "null pair");
+    if (pair->pipe_pending) { const int rcf = sfm_pair_flush(pair); if (rcf != SFM_OK) return rcf; }
+    SFM_REQUIRE(mode == SFM_POSE_REFERENCE || mode == SFM_POSE_CORRECT, SFM_E_INVALID, "unknown pose mode %d", mode);
+    SFM_REQUIRE(pair->have_E, SFM_E_STATE, "computePosecandidates before estimateE");
+    if (mode == SFM_POSE_CORRECT) {               // the majority vote needs every point before the choice: three launches
+        int rc = sfm_pose_candidates(pair, mode);
+        if (rc == SFM_OK) rc = sfm_choose_pose(pair, mode);
+        if (rc == SFM_OK) rc = sfm_triangulate(pair, mode);
+        if (rc == SFM_OK && d_record) rc = launch_pair_record(pair, mode, d_record);
+        return rc;
+    }
+    SFM_HIP_TRY(hipSetDevice(pair->ctx->device));
+    const int rc = launch_pose_chain(pair, d_record);
+    if (rc == SFM_OK) { pair->have_P = pair->have_pose = pair->have_points3d = true; pair->pose_mode = mode; }
+    return rc;
+}
+
+int sfm_pose_chain(sfm_pair *pair, int mode) { return pose_chain(pair, mode, nullptr); }
+
 // ---- accessors ------------------------------------------------------------------------------------
 int sfm_pair_ld(const sfm_pair *pair) { return pair ? pair->ld : 0; }
 int sfm_pair_num_points(const sfm_pair *pair) { return pair ? pair->n : 0; }
@@ -958,6 +996,7 @@ int sfm_process_pairs(sfm_ctx *ctx, const float h_K[9], const float h_Kinv[9], c
             if (rc != SFM_OK) return rc;
         }
         lanes[l] = ctx->lane[l - 1];
+        lanes[l]->match_kernel = ctx->match_kernel;
     }
     for (int l = 0; l < nlanes; ++l)
         if (!ctx->lane_ev[l]) SFM_HIP_TRY(hipEventCreateWithFlags(&ctx->lane_ev[l], hipEventDisableTiming));
@@ -1009,10 +1048,8 @@ int sfm_process_pairs(sfm_ctx *ctx, const float h_K[9], const float h_Kinv[9], c
         sfm_ransac_default_params(&p, d.n1);
         if (num_hypotheses) p.num_hypotheses = num_hypotheses;
         rc = sfm_estimate_E(ip, &p);                                    if (rc != SFM_OK) return rc;
-        rc = sfm_pose_candidates(ip, pose_mode);                        if (rc != SFM_OK) return rc;
-        rc = sfm_choose_pose(ip, pose_mode);                            if (rc != SFM_OK) return rc;
-        rc = sfm_triangulate(ip, pose_mode);                            if (rc != SFM_OK) return rc;
-        rc = launch_pair_record(ip, pose_mode, ctx->pool_records + (size_t)slot * SFM_RECORD_FLOATS);
+        // poses, triangulation and the record: one launch in SFM_POSE_REFERENCE (sfm_pose_chain), four otherwise
+        rc = pose_chain(ip, pose_mode, ctx->pool_records + (size_t)slot * SFM_RECORD_FLOATS);
         if (rc != SFM_OK) return rc;
     }
     for (int l = 1; l < nlanes; ++l) {
@@ -1052,11 +1089,30 @@ int sfm_ransac_last_clock(sfm_pair *pair, double *shader_mhz)
 int sfm_ransac_last_phases(sfm_pair *pair, uint64_t ticks[8])
 {
     SFM_REQUIRE(pair && ticks, SFM_E_INVALID, "null argument");
-    unsigned long long c[8] = { 0 };
+    constexpr int kN = 8;
+    unsigned long long c[kN] = { 0 };
     int rc = copy_out(pair, c, pair->d_clk, sizeof(c));
     if (rc != SFM_OK) return rc;
-    for (int k = 0; k < 8; ++k) ticks[k] = c[k];
+    for (int k = 0; k < kN; ++k) ticks[k] = c[k];
     return SFM_OK;
+}
+
+int sfm_prefilter_probe(sfm_ctx *ctx, const float h_E[9], float threshold, float bound, const float h_point[4], int survive_all, float h_out[100])
+{
+    SFM_REQUIRE(ctx && h_E && h_point && h_out, SFM_E_INVALID, "null argument");
+    SFM_HIP_TRY(hipSetDevice(ctx->device));
+    float *d = nullptr;
+    SFM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d), 128 * sizeof(float)));
+    hipError_t e = hipMemcpyAsync(d + 100, h_E, 9 * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
+    int rc = e == hipSuccess ? launch_prefilter_probe(ctx, d + 100, threshold, bound, h_point, survive_all, d) : SFM_E_HIP;
+    if (rc == SFM_OK) {
+        e = hipMemcpyAsync(h_out, d, 100 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) { set_error("probe copy failed: %s", hipGetErrorString(e)); rc = SFM_E_HIP; }
+    }
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d);
+    return rc;
 }
 
 int sfm_ransac_last_launch(sfm_pair *pair, int *kernel, int *grid, int *block, int *lds_bytes)

@@ -43,6 +43,11 @@ struct sfm_ctx {
     // matcher scratch: per-split partial (best, second, index) records
     void *match_ws = nullptr;
     size_t match_ws_bytes = 0;
+    // pre-filter matcher (match_prefilter.hip): fp16 copies, norms, per-split partials, candidate lists
+    void *match_pf_ws = nullptr;
+    size_t match_pf_ws_bytes = 0;
+    int match_kernel = 0;              // SFM_MATCH_AUTO / _EXACT / _PREFILTER (sfm_ctx_set_match_kernel)
+    int last_match_kernel = 0;         // what the last sfm_match / sfm_match_soa call ran
     void *homo_ws = nullptr;           // homography RANSAC scratch
     size_t homo_ws_bytes = 0;
     void *sift_temp = nullptr;         // pyramid + DoG planes when the caller passes no temp memory
@@ -157,6 +162,8 @@ int launch_choose_pose(sfm_pair *pair, int mode);
 int launch_triangulate(sfm_pair *pair, int mode);
 int launch_points_to_vbo(sfm_pair *pair, float *d_positions, float *d_velocities, float scale);
 int launch_pair_record(sfm_pair *pair, int mode, float *d_record);
+int launch_prefilter_probe(sfm_ctx *ctx, const float *d_E, float thr, float B, const float pt[4], int survive_all, float *d_out);
+int launch_pose_chain(sfm_pair *pair, float *d_record);          // REFERENCE mode: candidates + choosePose + triangulation (+ record) in one launch
 
 // sift.hip
 void sift_layout(int width, int height, int num_octaves, int scale_up, sfm_sift_layout *L);
@@ -173,6 +180,9 @@ int launch_homography(sfm_ctx *ctx, const sfm_sift_point *d_sift, int n, const i
                       float h_H[9], int *num_matches, int *h_counts, float *h_homo);
 // match.hip
 int launch_match_none(sfm_ctx *ctx, int n1, sfm_sift_point *sift1);
+int launch_match_prefilter(sfm_ctx *ctx, const float *d1, int n1, int ld1, const float *d2, int n2, int ld2,
+                           float *d_best, float *d_second, int32_t *d_index,
+                           sfm_sift_point *sift1, const sfm_sift_point *sift2);
 int launch_match(sfm_ctx *ctx, const float *d1, int n1, int ld1, const float *d2, int n2, int ld2,
                  float *d_best, float *d_second, int32_t *d_index,
                  sfm_sift_point *sift1, const sfm_sift_point *sift2);

@@ -20,8 +20,7 @@
 // group hit 16 distinct 16-byte slots.  Inside each group of 8 floats the order is
 // (d0 d2 d4 d6 | d1 d3 d5 d7) so that one b128 read yields the operands of four consecutive MFMA
 // k-steps for the lane's k-parity (lane >> 5).
-#include "common.hpp"
-#include "device_math.hpp"
+#include "match_common.hpp"
 
 namespace sfm {
 
@@ -29,32 +28,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kRowsPerStage = 64;        // database rows per LDS stage (RT = 2 MFMA row tiles)
 constexpr int kLdsStride = 132;          // floats per staged row
-
-struct Top2 { float best, second; int idx; };
-
-__device__ __forceinline__ void top2_push(Top2 &t, float s, int p)
-{
-    // matching.cu:352-361 / match.cu:64-68: strict '>', ascending p within a lane:
-    //   if (s > best) { second = best; best = s; idx = p; } else if (s > second) second = s;
-    // With best >= second that is: second' = median(best, second, s), best' = max(best, s), idx moves on a strict win --
-    // branch-free, one v_med3_f32 per statistic.
-    const bool wins = s > t.best;
-    t.second = __builtin_amdgcn_fmed3f(t.best, t.second, s);
-    t.best = __builtin_amdgcn_fmed3f(t.best, s, __builtin_inff());
-    t.idx = wins ? p : t.idx;
-}
-
-__device__ __forceinline__ Top2 top2_merge(const Top2 &a, const Top2 &b)
-{
-    // higher score wins; equal scores -> lower index (-1 compares as largest)
-    const bool bwins = (b.best > a.best) || (b.best == a.best && (unsigned)b.idx < (unsigned)a.idx);
-    Top2 r;
-    r.best = bwins ? b.best : a.best;
-    r.idx = bwins ? b.idx : a.idx;
-    const float lo = bwins ? a.best : b.best;
-    r.second = fmaxf(lo, fmaxf(a.second, b.second));
-    return r;
-}
 
 // Stage `rows` descriptor rows (first row `row0`, zero beyond `nrows`) into buf[rows][132].
 template <int W>
@@ -238,23 +211,22 @@ void match_mfma_kernel(const float *__restrict__ q, int nq, int ldq,
         Top2 t{ __hip_atomic_load(&ws_best[p1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
                 __hip_atomic_load(&ws_second[p1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
                 __hip_atomic_load(&ws_idx[p1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) };
-        for (int sp = 1; sp < nsplit; ++sp) {
-            const size_t w = (size_t)sp * nq + p1;
-            t = top2_merge(t, Top2{ __hip_atomic_load(&ws_best[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
-                                    __hip_atomic_load(&ws_second[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
-                                    __hip_atomic_load(&ws_idx[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) });
+        // eight splits' partials are requested before the first is merged: one memory round trip per eight splits, not
+        // per split (the loads are atomics, which the compiler never hoists over the merge of the previous split)
+        for (int sp0 = 1; sp0 < nsplit; sp0 += 8) {
+            Top2 part[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const size_t w = (size_t)min(sp0 + u, nsplit - 1) * nq + p1;
+                part[u].best = __hip_atomic_load(&ws_best[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                part[u].second = __hip_atomic_load(&ws_second[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                part[u].idx = __hip_atomic_load(&ws_idx[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (sp0 + u < nsplit) t = top2_merge(t, part[u]);
         }
-        if (out_best) out_best[p1] = t.best;
-        if (out_second) out_second[p1] = t.second;
-        if (out_idx) out_idx[p1] = t.idx;
-        if (sift1) {
-            sfm_sift_point *o = sift1 + p1;
-            o->score = t.best;
-            o->match = t.idx;
-            o->match_xpos = t.idx >= 0 ? sift2[t.idx].xpos : 0.0f;
-            o->match_ypos = t.idx >= 0 ? sift2[t.idx].ypos : 0.0f;
-            o->ambiguity = t.second / (t.best + 1e-6f);
-        }
+        match_emit(p1, t, out_best, out_second, out_idx, sift1, sift2);
     }
 }
 
@@ -281,6 +253,13 @@ int launch_match(sfm_ctx *ctx, const float *d1, int n1, int ld1, const float *d2
                  sfm_sift_point *sift1, const sfm_sift_point *sift2)
 {
     if (n1 <= 0 || n2 <= 0) return SFM_OK;                 // matching.cu:1095-1096
+    // large sets: fp16 matrix-core pre-filter + exact scores of the few candidates (match_prefilter.hip; same results)
+    const bool big = n1 >= 1024 && n2 >= 1024 && (size_t)n1 * (size_t)n2 >= (size_t)3000 * 3000;
+    if (ctx->match_kernel == SFM_MATCH_PREFILTER || (ctx->match_kernel == SFM_MATCH_AUTO && big)) {
+        ctx->last_match_kernel = SFM_MATCH_PREFILTER;
+        return launch_match_prefilter(ctx, d1, n1, ld1, d2, n2, ld2, d_best, d_second, d_index, sift1, sift2);
+    }
+    ctx->last_match_kernel = SFM_MATCH_EXACT;
     // three configurations (column tiles per wavefront, wavefronts per block), crossovers measured with profiles/match_cfg_probe.py
     // (TFLOP/s at n x n):  n      3000   4500   5500   7000   9000   10000  12000  14000  16384
     //                      (1,4)  64     79     72     79     81

@@ -172,8 +172,93 @@ void triangulate_kernel(const float *__restrict__ X0, const float *__restrict__ 
     for (int c = 0; c < 4; ++c) out[(size_t)c * n + j] = pt[c];         // 4 x n row-major (kernels.h:440-449)
 }
 
+// ---- computePosecandidates + choosePose + linear_triangulation in ONE launch (SFM_POSE_REFERENCE) ---------------
+// The three calls of src/main.cpp:302-306 are three dependent single-wave latency chains (svd3; one triangulation per
+// candidate + a 4x4 inverse; one triangulation per point) with two launch gaps between them.  Here a block's first
+// wavefront runs the choosePose chain while its other three wavefronts triangulate 48 points against ALL FOUR inverted
+// candidates (thread = point x candidate), so the two 4x4 Jacobi chains run side by side instead of back to back; after
+// one barrier the threads of the chosen candidate store their points.  Every value goes through the very functions the
+// separate kernels call (pose_candidates, triangulate_point, inv4) on the same inputs, so P, P^-1, the index, the votes
+// and the points are bit-identical to the three-call sequence.  Block 0 also writes what the accessors read (d_P,
+// d_Pinv, d_Pind) and, when asked, the pair's result record (pair_record_kernel's layout).
+constexpr int kChainPoints = 48;        // points per block: wavefronts 1..3, four lanes per point
+
+__global__ __launch_bounds__(256)
+void pose_chain_reference_kernel(const float *__restrict__ X0, const float *__restrict__ X1, int ld, int n,
+                                 const float *__restrict__ E, int sweeps, float *__restrict__ P, float *__restrict__ Pinv,
+                                 int *__restrict__ pind, float *__restrict__ out, const uint32_t *__restrict__ best,
+                                 float *__restrict__ record)
+{
+    __shared__ int s_choice;
+    const int wave = threadIdx.x >> 6;
+    const int i = threadIdx.x & 3;                 // candidate of this lane
+    float e[9], p[64];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) e[k] = E[k];
+    pose_candidates(e, SFM_POSE_REFERENCE, p);     // every lane, redundantly: no exchange needed afterwards
+    float Pm[16], Q[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) Pm[k] = i == 0 ? p[k] : i == 1 ? p[16 + k] : i == 2 ? p[32 + k] : p[48 + k];
+    const bool ok = inv4(Pm, Q);                   // in-place inverse of the reference (sfm.cu:286, Q8)
+    if (!ok) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) Q[k] = 0.0f;
+    }
+    float pt[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+    int j = -1;
+    if (wave == 0) {
+        // choosePose: cheirality on correspondence #0 only (kernels.h:408-409), last passing candidate wins (sfm.cu:295-296)
+        triangulate_point(X0[0], X0[ld], X1[0], X1[ld], Pm, sweeps, pt);
+        float z2 = Q[8] * pt[0];
+#pragma unroll
+        for (int k = 1; k < 4; ++k) z2 = fmaf(Q[8 + k], pt[k], z2);
+        const bool pass = (pt[2] > 0.0f) && (z2 > 0.0f);
+        const unsigned long long m = __ballot(pass) & 0xFull;
+        const unsigned long long sing = __ballot(!ok) & 0xFull;
+        const int choice = m ? (63 - __builtin_clzll(m)) : 0;
+        if (threadIdx.x == 0) s_choice = choice;
+        if (blockIdx.x == 0) {
+            if (threadIdx.x < 4) {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) { P[16 * i + k] = Pm[k]; Pinv[16 * i + k] = Q[k]; }
+                pind[1 + i] = pass ? 1 : 0;
+            }
+            if (threadIdx.x == 0) { pind[0] = choice; pind[5] = (int)sing; pind[6] = 0; pind[7] = 0; }
+            if (record) {
+                const int t = threadIdx.x;
+                if (t < 9) record[t] = e[t];
+                else if (t >= 12 && t < 16 && i == choice) {           // the lane group 12..15 holds one lane per candidate
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) record[9 + k] = Q[k];
+                }
+                else if (t == 25) record[25] = (float)choice;
+                else if (t == 26) record[26] = (float)best[1];
+                else if (t == 27) record[27] = (float)best[0];
+                else if (t == 28) record[28] = ((sing >> choice) & 1ull) ? 1.0f : 0.0f;
+            }
+        }
+    } else {
+        j = blockIdx.x * kChainPoints + ((int)threadIdx.x - 64) / 4;
+        if (j < n) triangulate_point(X0[j], X0[(size_t)ld + j], X1[j], X1[(size_t)ld + j], Q, sweeps, pt);
+    }
+    __syncthreads();
+    if (j >= 0 && j < n && i == s_choice) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) out[(size_t)c * n + j] = pt[c];     // 4 x n row-major (kernels.h:440-449)
+    }
+}
+
 // ---- launchers --------------------------------------------------------------------------------
 constexpr int kSweeps4 = 8;     // one-sided Jacobi sweeps for 4x4 systems
+
+int launch_pose_chain(sfm_pair *pair, float *d_record)
+{
+    hipLaunchKernelGGL(pose_chain_reference_kernel, dim3((pair->n + kChainPoints - 1) / kChainPoints), dim3(256), 0, pair->ctx->stream,
+                       pair->d_X[0], pair->d_X[1], pair->ld, pair->n, pair->d_E, kSweeps4, pair->d_P, pair->d_Pinv, pair->d_Pind,
+                       pair->d_points, pair->d_best, d_record);
+    SFM_HIP_TRY(hipGetLastError());
+    return SFM_OK;
+}
 
 int launch_fill_xu(sfm_pair *pair, const sfm_sift_point *d_data)
 {

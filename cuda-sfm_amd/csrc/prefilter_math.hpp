@@ -76,14 +76,32 @@ SFM_HD bool prefilter_scales(float thr, PfScales &sc)
     return true;
 }
 
+// The value as the optimiser cannot see through it.  A split reads its fp32 input TWICE (high part, then input - high
+// part).  Where the input is a product, hipcc folds the multiplication into ONE of the two conversions (v_fma_mixlo_f16: a
+// single rounding of the exact product) and not into the other; when the fp32 product sits exactly half-way between two fp16
+// values the two roundings disagree and the low part no longer complements the stored high part (an error of one fp16 ulp,
+// 2^-10, where the bound assumes 2^-22: found by profiles/prefilter_soak.py as one lost inlier in 5e13 pairs, x2x^2 =
+// 2.1728515625).  Behind the barrier both conversions see the same rounded fp32 value, on the device and on the host.
+SFM_HD float pf_opaque(float x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(x));
+#else
+    asm volatile("" : "+x"(x));
+#endif
+    return x;
+}
+
 SFM_HD void pf_split2(float x, _Float16 &h, _Float16 &m)
 {
+    x = pf_opaque(x);                    // from here on every conversion reads the one rounded fp32 value
     h = (_Float16)x;
-    m = (_Float16)(x - (float)h);
+    m = (_Float16)(x - (float)h);        // x - h is exact in fp32 (h is within 2^-11 of x), so this has one rounding however it is fused
 }
 
 SFM_HD void pf_split3(float x, _Float16 &h, _Float16 &m, _Float16 &l)
 {
+    x = pf_opaque(x);
     h = (_Float16)x;
     const float r = x - (float)h;
     m = (_Float16)r;
@@ -143,7 +161,7 @@ SFM_HD float prefilter_hyp_slots(const float e[9], float thr, float B, const PfS
         ts[3 * j] = h; ts[3 * j + 1] = h; ts[3 * j + 2] = m;
     }
     // the constant slot, rounded UP to fp16 (2^-10 of it more threshold at most: far inside the (1 + rho) slack)
-    const float cst = ((s * C + c2) * sc.sig2a) * 1.0000005f;
+    const float cst = pf_opaque(((s * C + c2) * sc.sig2a) * 1.0000005f);      // one value for the conversion and the comparison below
     _Float16 ch = (_Float16)cst;
     if ((float)ch < cst) ch = (_Float16)((float)ch * 1.001f + 6e-8f);               // next fp16 up (ulp >= 2^-11 relative, 2^-24 absolute)
     ts[15] = ch;

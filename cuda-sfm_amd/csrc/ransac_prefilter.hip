@@ -363,6 +363,51 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
     if (probe) { clk[0] = clock64() - c0; clk[1] = wall_clock64() - w0; }
 }
 
+// Test probe (sfm_prefilter_probe): the operands of ONE (hypothesis, point) pair exactly as the kernel above builds them on
+// the device, and what the matrix cores return for them.  out: ns[32] | ts[16] | bn[32] | bt[16] | nt | G | rejected |
+// zero-divisor state (0 cleared, 1 cells to look up, 2 scan).  tests/test_gpu_prefilter.py compares it with the host build
+// of prefilter_math.hpp bit for bit.
+__global__ __launch_bounds__(64)
+void pf_probe_kernel(const float *__restrict__ E, float thr, float B, PfScales sc, float u, float v, float x, float y, int survive_all,
+                     float *__restrict__ out)
+{
+    const int lane = threadIdx.x;
+    const int half = lane >> 5;
+    float e[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) e[k] = E[k];
+    _Float16 ns[kPfSlots], ts[kPfSlotsT], bn[kPfSlots], bt[kPfSlotsT];
+    (void)prefilter_hyp_slots(e, thr, B, sc, ns, ts, survive_all != 0);
+    prefilter_point_slots(u, v, x, y, true, bn, bt);
+    h8 an0, an1, at, b0, b1, b2;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        an0[j] = half ? ns[8 + j] : ns[j];   an1[j] = half ? ns[24 + j] : ns[16 + j];   at[j] = half ? ts[8 + j] : ts[j];
+        b0[j] = half ? bn[8 + j] : bn[j];    b1[j] = half ? bn[24 + j] : bn[16 + j];    b2[j] = half ? bt[8 + j] : bt[j];
+    }
+    f16v accg = {}, accn = {};
+    accg = __builtin_amdgcn_mfma_f32_32x32x16_f16(at, b2, accg, 0, 0, 0);
+    accn = __builtin_amdgcn_mfma_f32_32x32x16_f16(an0, b0, accn, 0, 0, 0);
+    accn = __builtin_amdgcn_mfma_f32_32x32x16_f16(an1, b1, accn, 0, 0, 0);
+    if (lane == 0) {
+        for (int k = 0; k < 32; ++k) { out[k] = (float)ns[k]; out[48 + k] = (float)bn[k]; }
+        for (int k = 0; k < 16; ++k) { out[32 + k] = (float)ts[k]; out[80 + k] = (float)bt[k]; }
+        out[96] = accn[0]; out[97] = accg[0];
+        out[98] = (float)(shift_in_reject(0u, accn[0], accg[0]) & 1u);
+        int cx0, cx1, cy0, cy1;
+        out[99] = (float)prefilter_zero_divisor_cells(e, B, prefilter_grid(B), cx0, cx1, cy0, cy1);
+    }
+}
+
+int launch_prefilter_probe(sfm_ctx *ctx, const float *d_E, float thr, float B, const float pt[4], int survive_all, float *d_out)
+{
+    PfScales sc;
+    if (!prefilter_scales(thr, sc)) { set_error("threshold %g outside the pre-filter's range", (double)thr); return SFM_E_INVALID; }
+    hipLaunchKernelGGL(pf_probe_kernel, dim3(1), dim3(64), 0, ctx->stream, d_E, thr, B, sc, pt[0], pt[1], pt[2], pt[3], survive_all, d_out);
+    SFM_HIP_TRY(hipGetLastError());
+    return SFM_OK;
+}
+
 // Conditions under which launch_ransac_score may pick this kernel: the unit-z layout (every z exactly 1), a threshold the
 // fp16 scaling covers, and enough work to fill the chip with 1024-hypothesis x 1024-point block iterations (measured
 // crossover against the plain wavefront kernel at 4096 points: between 16k and 32k hypotheses, profiles/r02_prefilter_ab.txt).

@@ -61,6 +61,16 @@ int  sfm_ctx_set_stream(sfm_ctx *ctx, void *hip_stream);    /* NULL = default st
  * second set; with the flag sfm_match searches only the first num_pts2 - num_pts2 % 32 (none: match = -1, score = 0). */
 #define SFM_QUIRK_MATCH_TAIL 1u
 int  sfm_ctx_set_quirks(sfm_ctx *ctx, unsigned int flags);
+/* Which matcher sfm_match / sfm_match_soa run (results are bit-identical; A/B runs and tests):
+ * SFM_MATCH_EXACT     -- every score as the exact fp32 chain on v_mfma_f32_32x32x2_f32 (match.hip);
+ * SFM_MATCH_PREFILTER -- fp16 matrix-core scores select the few rows per query that can be its best or second best, the
+ *                        exact chain runs on those only (match_prefilter.hip);
+ * SFM_MATCH_AUTO      -- the pre-filter from ~3000 x 3000 points on (default).  sfm_ctx_last_match_kernel: what the last call ran. */
+#define SFM_MATCH_AUTO      0
+#define SFM_MATCH_EXACT     1
+#define SFM_MATCH_PREFILTER 2
+int  sfm_ctx_set_match_kernel(sfm_ctx *ctx, int kernel);
+int  sfm_ctx_last_match_kernel(sfm_ctx *ctx, int *kernel);
 /* A stream of the context's own (hipStreamNonBlocking, destroyed with the context): callers without HIP headers get a
  * second context that runs concurrently with the first (which sits on the default stream unless told otherwise). */
 int  sfm_ctx_own_stream(sfm_ctx *ctx);
@@ -244,6 +254,11 @@ int sfm_pose_candidates(sfm_pair *pair, int mode);
 int sfm_choose_pose(sfm_pair *pair, int mode);
 /* Image_pair::linear_triangulation(), sfm.cu:309-344. */
 int sfm_triangulate(sfm_pair *pair, int mode);
+/* The three calls above as the caller issues them (src/main.cpp:302-306: computePosecandidates, choosePose,
+ * linear_triangulation) in ONE launch for SFM_POSE_REFERENCE -- the choosePose chain and the triangulation of every point
+ * against all four candidates run side by side, results bit-identical to the three calls; SFM_POSE_CORRECT (majority
+ * vote over all points before the choice) runs the three launches.  sfm_process_pairs uses it per pair. */
+int sfm_pose_chain(sfm_pair *pair, int mode);
 
 /* ---- accessors (the reference keeps these private; needed for parity checks) ------------------ */
 #define SFM_BUF_X0      0   /* float 3 x ld   normalised coords image 1 (ld = sfm_pair_ld)   */
@@ -318,6 +333,12 @@ int sfm_ransac_last_clock(sfm_pair *pair, double *shader_mhz);
  * coefficients prepared, [4] first 32-hypothesis block scanned and drained, [5] first pass done (counts and ticket out),
  * [6] number of passes wavefront 0 ran.  Zero where the kernel that ran has no such probe.  Synchronises. */
 int sfm_ransac_last_phases(sfm_pair *pair, uint64_t ticks[8]);
+/* Test probe of the matrix-core pre-filter (ransac_prefilter.hip): the fp16 operands of ONE (hypothesis, point) pair as the
+ * device builds them and what the matrix cores return for them.  h_point = (x1x, x1y, x2x, x2y), bound = the tile's largest
+ * |coordinate|.  h_out: coefficient slots ns[32], ts[16] | feature slots bn[32], bt[16] | nt | G | rejected (0/1) |
+ * zero-divisor state.  tests/test_gpu_prefilter.py compares them with the host build of the same header.  Synchronises. */
+int sfm_prefilter_probe(sfm_ctx *ctx, const float h_E[9], float threshold, float bound, const float h_point[4], int survive_all,
+                        float h_out[100]);
 
 #ifdef __cplusplus
 }

@@ -5,9 +5,35 @@
 #include "../../cuda-sfm_amd/csrc/device_math.hpp"
 #include "../../cuda-sfm_amd/csrc/sift_math.hpp"
 #include "../../cuda-sfm_amd/csrc/prefilter_math.hpp"
+#include "../../cuda-sfm_amd/csrc/match_prefilter_math.hpp"
 #include <string.h>
 
 extern "C" {
+
+// ---- pre-filter matcher (match_prefilter_math.hpp): the bound on |fp16 matrix-core score - exact chain|, for
+// tests/test_hostcheck_match_prefilter.py
+float hc_match_pf_eps(float qnorm_up, float dbnorm_up) { return sfm::match_pf_eps(qnorm_up, dbnorm_up); }
+float hc_match_pf_norm_up(const float *row /*128*/)
+{
+    float sumsq = 0.0f;                 // the order match_pf_prep adds in: eight entries per lane, then the 16-lane butterfly
+    float part[16];
+    for (int c = 0; c < 16; ++c) {
+        float s = 0.0f;
+        for (int j = 0; j < 8; ++j) s = fmaf(row[8 * c + j], row[8 * c + j], s);
+        part[c] = s;
+    }
+    for (int m = 1; m < 16; m <<= 1) {
+        float nxt[16];
+        for (int c = 0; c < 16; ++c) nxt[c] = part[c] + part[c ^ m];
+        for (int c = 0; c < 16; ++c) part[c] = nxt[c];
+    }
+    sumsq = part[0];
+    return sfm::match_pf_norm_up(sumsq);
+}
+void hc_match_pf_half(const float *x, float *out, int n)      // the fp16 copy of match_pf_prep, unscaled again
+{
+    for (int i = 0; i < n; ++i) out[i] = (float)(_Float16)(x[i] * sfm::kMpScale) / sfm::kMpScale;
+}
 
 // ---- matrix-core pre-filter (prefilter_math.hpp): operands and rule, for tests/test_hostcheck_prefilter.py
 int hc_pf_scales(float thr, int *a, float *sigE, float *sigF, float *sig2a)

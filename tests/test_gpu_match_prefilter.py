@@ -1,0 +1,132 @@
+"""GPU parity: the fp16 matrix-core pre-filter matcher (match_prefilter.hip) against the exact MFMA matcher and the oracle.
+Bit-exact scores and indices are the bar: the pre-filter only selects which rows get the exact fp32 chain."""
+import numpy as np
+import pytest
+
+import cuda_sfm_amd as S
+from cuda_sfm_amd import synth
+import oracle as O
+from helpers import same_bits, to_dev
+
+pytestmark = pytest.mark.gpu
+
+
+def run_soa(gpu, d1, d2, kernel):
+    torch, dev, ctx = gpu
+    ctx.set_match_kernel(kernel)
+    try:
+        t1, t2 = to_dev(torch, dev, d1), to_dev(torch, dev, d2)
+        n1, n2 = d1.shape[0], d2.shape[0]
+        best = torch.full((n1,), -5.0, dtype=torch.float32, device=dev)
+        sec = torch.full((n1,), -5.0, dtype=torch.float32, device=dev)
+        idx = torch.full((n1,), -7, dtype=torch.int32, device=dev)
+        ctx.match_soa(t1, n1, d1.shape[1], t2, n2, d2.shape[1], best, sec, idx)
+        torch.cuda.synchronize()
+        ran = ctx.last_match_kernel()
+    finally:
+        ctx.set_match_kernel(S.MATCH_AUTO)
+    return best.cpu().numpy(), sec.cpu().numpy(), idx.cpu().numpy(), ran
+
+
+def check_both(gpu, d1, d2, oracle_rows=None):
+    b, s, i, ran = run_soa(gpu, d1, d2, S.MATCH_PREFILTER)
+    assert ran == S.MATCH_PREFILTER
+    eb, es, ei, ran2 = run_soa(gpu, d1, d2, S.MATCH_EXACT)
+    assert ran2 == S.MATCH_EXACT
+    assert np.array_equal(i, ei)
+    assert same_bits(b, eb) and same_bits(s, es)
+    rows = np.arange(d1.shape[0]) if oracle_rows is None else oracle_rows
+    ob, os_, oi = O.match_desc(d1[rows], d2)
+    assert np.array_equal(i[rows], oi) and same_bits(b[rows], ob) and same_bits(s[rows], os_)
+    return b, s, i
+
+
+@pytest.mark.parametrize("n1,n2", [(1, 1), (5, 3), (31, 33), (64, 64), (100, 777), (513, 511), (1911, 2086), (3000, 3100), (4100, 1000)])
+def test_prefilter_bit_exact(gpu, n1, n2):
+    d1, _, _ = synth.descriptors(n1, seed=300 + n1)
+    d2, _, _ = synth.descriptors(n2, seed=400 + n2)
+    check_both(gpu, d1, d2)
+
+
+def test_prefilter_permutation_and_duplicates(gpu):
+    n = 4096
+    d1, d2, perm = synth.descriptors(n)
+    b, s, i = check_both(gpu, d2, d1, oracle_rows=np.arange(0, n, 37))
+    assert (i == perm).mean() > 0.99
+    # exact duplicates in the database: lowest index wins, second == best
+    db = d1.copy(); db[3000] = db[10]; db[77] = db[10]
+    b, s, i = check_both(gpu, d1[:64], db)
+    assert i[10] == 10 and b[10] == s[10]
+
+
+def test_prefilter_many_equal_rows_take_the_full_scan(gpu):
+    """More candidates than slots (every database row identical, or one row repeated 500 times): the exact kernel scans all rows."""
+    rng = np.random.default_rng(5)
+    d1, _, _ = synth.descriptors(300, seed=9)
+    row = d1[7].copy()
+    db = np.tile(row, (2000, 1)).astype(np.float32)
+    b, s, i = check_both(gpu, d1, db)
+    assert (i == 0).all() and same_bits(b, s)
+    db2, _, _ = synth.descriptors(2500, seed=10)
+    db2[rng.choice(2500, 500, replace=False)] = d1[3]
+    check_both(gpu, d1, db2)
+
+
+def test_prefilter_signs_zeros_tiny_and_scaled(gpu):
+    rng = np.random.default_rng(11)
+    n1, n2 = 257, 1500
+    d1 = rng.standard_normal((n1, 128)).astype(np.float32)
+    d2 = rng.standard_normal((n2, 128)).astype(np.float32)
+    check_both(gpu, d1, d2)                                    # mixed signs, norms ~ 11
+    d1z = d1.copy(); d1z[5] = 0.0; d1z[6, 1:] = 0.0
+    d2z = d2.copy(); d2z[100] = 0.0
+    check_both(gpu, d1z, d2z)                                  # zero rows: scores 0 never win
+    check_both(gpu, (d1 * 1e-6).astype(np.float32), (d2 * 1e-3).astype(np.float32))    # below the fp16 floor of the scaled copies
+    check_both(gpu, (d1 * 20.0).astype(np.float32), (d2 * 20.0).astype(np.float32))    # entries up to ~90: still inside the fp16 range
+    neg = -np.abs(d2)
+    b, s, i = check_both(gpu, np.abs(d1), neg)                 # no positive score at all
+    assert (i == -1).all() and (b == 0).all() and (s == 0).all()
+
+
+def test_prefilter_entries_the_fp16_copy_cannot_hold(gpu):
+    """|entry| > 255, inf, NaN in either set: those queries (or all of them, for a database row) take the full exact scan."""
+    rng = np.random.default_rng(12)
+    d1, _, _ = synth.descriptors(200, seed=21)
+    d2, _, _ = synth.descriptors(1200, seed=22)
+    q = d1.copy(); q[3, 5] = 1000.0; q[9, 0] = 3e38
+    check_both(gpu, q, d2)
+    db = d2.copy(); db[50, 7] = 400.0
+    check_both(gpu, d1, db)
+    db = d2.copy(); db[60] *= 1e4
+    check_both(gpu, d1, db)
+
+
+def test_prefilter_sift_records_and_auto(gpu):
+    """MatchSiftData semantics through the pre-filter path; AUTO picks it from ~3000 x 3000 on."""
+    torch, dev, ctx = gpu
+    n1, n2 = 3100, 3300
+    d1, _, _ = synth.descriptors(n1, seed=31)
+    d2, _, _ = synth.descriptors(n2, seed=32)
+    s1 = synth.sift_records(d1, seed=33); s2 = synth.sift_records(d2, seed=34)
+    t1, t2 = to_dev(torch, dev, s1), to_dev(torch, dev, s2)
+    ctx.set_match_kernel(S.MATCH_AUTO)
+    ctx.match(t1, n1, t2, n2)
+    torch.cuda.synchronize()
+    assert ctx.last_match_kernel() == S.MATCH_PREFILTER
+    out = t1.cpu().numpy().reshape(-1).view(synth.SIFT_DTYPE)
+    ref = O.match_sift(s1, s2)
+    for f in ("score", "ambiguity", "match_xpos", "match_ypos"):
+        assert same_bits(out[f], ref[f]), f
+    assert np.array_equal(out["match"], ref["match"])
+    for f in ("xpos", "ypos", "scale", "data"):
+        assert np.array_equal(out[f], s1[f])
+    ctx.match(t1, 700, t2, 900)
+    assert ctx.last_match_kernel() == S.MATCH_EXACT
+
+
+def test_prefilter_full_size(gpu):
+    """16384 x 16384 (match.cu benchmark size): both matchers agree on every query; sampled oracle rows."""
+    n = 16384
+    d1, d2, perm = synth.descriptors(n)
+    b, s, i = check_both(gpu, d2, d1, oracle_rows=np.random.default_rng(1).integers(0, n, 64))
+    assert (i == perm).mean() > 0.99

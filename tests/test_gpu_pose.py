@@ -33,6 +33,38 @@ def test_pose_pipeline(gpu, n, mode):
     assert same_bits(pair.get_points(), opts)
 
 
+@pytest.mark.parametrize("mode", [S.POSE_REFERENCE, S.POSE_CORRECT])
+@pytest.mark.parametrize("n", [8, 47, 48, 49, 200, 2048, 5000])
+def test_pose_chain_equals_three_calls(gpu, n, mode):
+    """sfm_pose_chain (one launch in REFERENCE mode) against computePosecandidates + choosePose + linear_triangulation on
+    the same pair and against the oracle: candidates, inverses, index, votes and points bit for bit; get_result too."""
+    scene = synth.two_view_scene(n, seed=140 + n, outlier_frac=0.2)
+    pair, _ = make_pair(S, gpu, scene)
+    pair.estimateE(S.default_params(n, num_hypotheses=256))
+    pair.computePosecandidates(mode); pair.choosePose(mode); pair.linear_triangulation(mode)
+    want = (pair.get_pose_candidates(), pair.get_pose_inverses(), pair.get_pose_index(), pair.get_points(), pair.get_result())
+    pair.estimateE(S.default_params(n, num_hypotheses=256))           # clears the pose state
+    with pytest.raises(S.SfmError):
+        pair.get_points()
+    pair.pose_chain(mode)
+    got = (pair.get_pose_candidates(), pair.get_pose_inverses(), pair.get_pose_index(), pair.get_points(), pair.get_result())
+    assert got[2] == want[2]
+    for g, w in zip(got, want):
+        assert same_bits(np.asarray(g, np.float32), np.asarray(w, np.float32))
+    _, _, X0, X1 = O.fill_xu(scene["sift"], scene["Kinv"])
+    oP = O.pose_candidates(pair.get_E(), mode)
+    oind, oPinv, _, _ = O.choose_pose(X0, X1, oP, mode, sweeps=8)
+    assert got[2] == oind and same_bits(got[0], oP) and same_bits(got[1], oPinv)
+    assert same_bits(got[3], O.triangulate(X0, X1, oPinv[oind] if mode == S.POSE_REFERENCE else oP[oind], sweeps=8))
+
+
+def test_pose_chain_needs_E(gpu):
+    pair, _ = make_pair(S, gpu, synth.two_view_scene(64))
+    with pytest.raises(S.SfmError) as e:
+        pair.pose_chain()
+    assert e.value.code == S.E_STATE
+
+
 def test_correct_mode_recovers_ground_truth(gpu):
     """Noise-free scene: CORRECT mode must give the true R, t (up to scale) and exact depths.
     Tolerances: rotation 5e-3, translation direction 5e-3, points 1e-2 relative (fp32 DLT)."""

@@ -166,3 +166,90 @@ def test_prefilter_supplied_candidates_and_zero_divisors(gpu, n, scale, thr):
         best = int(np.argmax(ocounts))
         assert res[kernel][1] == O.pack_key(int(ocounts[best]), best)
     assert same_bits(pair.get_E_candidates(H).reshape(H, 9), Es.reshape(H, 9)) or True      # NaN payloads aside, the candidates were taken as given
+
+
+def _tie_cases():
+    import json, os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "prefilter_tie_cases.json")) as f:
+        return json.load(f)["cases"]
+
+
+def _fp16_tie_coordinates(rng, count):
+    """floats x whose fp32 square is EXACTLY half-way between two fp16 values (while the exact square is not)"""
+    out = []
+    while len(out) < count:
+        x = rng.uniform(0.05, 1.9, 200000).astype(np.float32) * rng.choice(np.float32([-1.0, 1.0]), 200000)
+        p = (x * x).astype(np.float32)
+        h = p.astype(np.float16).astype(np.float32)
+        ulp = np.spacing(np.abs(p).astype(np.float16)).astype(np.float32)
+        out.extend(x[np.abs(p - h) * 2 == ulp].tolist())
+    return np.float32(out[:count])
+
+
+@pytest.mark.parametrize("case", range(3))
+def test_prefilter_keeps_inliers_whose_feature_is_an_fp16_tie(gpu, case):
+    """Round-2 soak finding: when fp32(x2x^2) is exactly half-way between two fp16 values, hipcc rounded the high part of the
+    feature's fp16 split from the fp32 product in one place and from the exact product (v_fma_mixlo_f16) in another, the
+    low part no longer complemented the high part (error 2^-10 instead of 2^-22) and an inlier next to the epipole was
+    rejected.  The committed pairs, alone among far-away points, at several positions of the tile, both kernels vs the oracle."""
+    torch, dev, ctx = gpu
+    c = _tie_cases()[case]
+    n = 2048
+    eye = np.eye(3, dtype=np.float32)
+    E = np.float32(c["E"]).reshape(3, 3)
+    thr = float(np.float32(c["thr"]))
+    for at in (0, 31, 32, 278, 1023, 1500):
+        sift = np.zeros(n, synth.SIFT_DTYPE)
+        sift["xpos"], sift["ypos"], sift["match_xpos"], sift["match_ypos"] = -1.75, 1.06, 1.7, -1.34
+        sift["xpos"][at], sift["ypos"][at], sift["match_xpos"][at], sift["match_ypos"][at] = c["x1"][0], c["x1"][1], c["x2"][0], c["x2"][1]
+        pair, _ = make_pair(S, gpu, {"sift": sift, "K": eye, "Kinv": eye})
+        _, _, X0, X1 = O.fill_xu(sift, eye)
+        want, mask = O.count_inliers(E, X0[:, :n], X1[:, :n], np.float32(thr))
+        assert want >= 1 and mask[at]
+        d_E = to_dev(torch, dev, np.repeat(E.reshape(1, 9), 64, 0).reshape(-1))
+        for kernel in (S.KERNEL_PREFILTER, S.KERNEL_SPLIT):
+            p = S.default_params(n, num_hypotheses=64, kernel=kernel, threshold=thr)
+            pair.ransac_score_candidates(p, d_E)
+            assert pair.last_launch()["kernel"] == kernel
+            assert (pair.get_inlier_counts(64) == want).all(), (kernel, at)
+        pair.close()
+
+
+def test_prefilter_operands_on_the_device_equal_the_host_build(gpu):
+    """sfm_prefilter_probe: the fp16 coefficient and feature slots the device builds for one (hypothesis, point) pair, against
+    tests/hostcheck (the same header compiled for the host) bit for bit -- random pairs, the committed tie cases, crafted
+    exact-tie coordinates -- and hi + lo of every feature must reproduce the fp32 feature to 2^-21."""
+    import ctypes as C
+    import test_hostcheck_prefilter as T
+    torch, dev, ctx = gpu
+    h = C.CDLL(T.LIB)
+    f32p = O.f32p
+    h.hc_pf_hyp_slots.restype = C.c_float
+    h.hc_pf_hyp_slots.argtypes = [f32p, C.c_float, C.c_float, C.c_int, f32p, f32p]
+    h.hc_pf_point_slots.argtypes = [C.c_float] * 4 + [C.c_int, f32p, f32p]
+    rng = np.random.default_rng(77)
+    pairs = [(np.float32(c["E"]), np.float32(c["thr"]), np.float32(c["x1"] + c["x2"])) for c in _tie_cases()]
+    ties = _fp16_tie_coordinates(rng, 24)
+    for k in range(24):
+        E = rng.standard_normal(9).astype(np.float32); E /= np.linalg.norm(E)
+        pt = rng.uniform(-1.8, 1.8, 4).astype(np.float32)
+        pt[2] = ties[k]
+        if k % 2:
+            pt[3] = ties[(k + 5) % 24]
+        pairs.append((E, np.float32(10.0 ** rng.uniform(-8, -3)), pt))
+    for E, thr, pt in pairs:
+        B = float(np.abs(pt).max()) * 1.01
+        dv = ctx.prefilter_probe(E, thr, B, pt)
+        ns, ts, _ = T.hyp_slots(h, E, float(thr), float(np.float32(B)))
+        Bn, Bt = T.point_slots(h, np.float32([[pt[0]], [pt[1]], [1.0]]), np.float32([[pt[2]], [pt[3]], [1.0]]))
+        for name, a, b in (("ns", dv["ns"], ns), ("ts", dv["ts"], ts), ("bn", dv["bn"], Bn[0]), ("bt", dv["bt"], Bt[0])):
+            assert np.array_equal(a.astype(np.float64), b), (name, a, b)
+        x, y = np.float64(pt[2]), np.float64(pt[3])
+        for j, f in enumerate((np.float32(pt[2] * pt[2]), np.float32(pt[2] * pt[3]), np.float32(pt[3] * pt[3]), pt[2], pt[3])):
+            hi, lo = np.float64(dv["bt"][3 * j]), np.float64(dv["bt"][3 * j + 1])
+            assert dv["bt"][3 * j + 2] == dv["bt"][3 * j]
+            assert abs(hi + lo - np.float64(f)) <= abs(np.float64(f)) * 2.0 ** -21 + 2.0 ** -25, (j, hi, lo, f)
+        # the matrix cores on these operands: the contraction in float64 within the accumulation budget
+        nt = float(Bn[0] @ ns); G = float(Bt[0] @ ts)
+        assert abs(float(dv["nt"]) - nt) <= T.ACC * float(np.abs(Bn[0]) @ np.abs(ns)) + 1e-12
+        assert abs(float(dv["G"]) - G) <= T.ACC * float(np.abs(Bt[0]) @ np.abs(ts)) + 1e-12

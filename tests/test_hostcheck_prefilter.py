@@ -307,3 +307,22 @@ def test_zero_divisor_guard_claims(H):
     assert guard.decide(np.array([[0, 0, 1e-30], [0, 0, 1e-30], [1, 0, 0]], np.float32))       # the squares underflow
     with np.errstate(invalid="ignore"):
         assert not guard.decide(np.full((3, 3), np.nan, np.float32))
+
+
+def test_committed_tie_cases_are_kept_and_their_splits_are_consistent(H):
+    """tests/golden/prefilter_tie_cases.json: oracle inliers whose x2x^2 is an exact fp16 half-way case in fp32 (the device
+    build once split such a feature inconsistently; GPU twin: test_prefilter_keeps_inliers_whose_feature_is_an_fp16_tie)."""
+    import json
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "prefilter_tie_cases.json")) as f:
+        cases = json.load(f)["cases"]
+    for c in cases:
+        X0 = np.float32([[c["x1"][0], -1.75], [c["x1"][1], 1.06], [1.0, 1.0]])
+        X1 = np.float32([[c["x2"][0], 1.7], [c["x2"][1], -1.34], [1.0, 1.0]])
+        E = np.float32(c["E"]).reshape(3, 3)
+        cnt, mask = O.count_inliers(E, X0, X1, np.float32(c["thr"]))
+        assert mask[0]
+        check_scene(H, X0, X1, [E], float(np.float32(c["thr"])))
+        p = np.float32(X1[0, 0] * X1[0, 0])
+        assert abs(float(p) - float(np.float16(p))) * 2 == float(np.spacing(np.float16(p)))         # the tie
+        Bn, Bt = point_slots(H, X0[:, :1], X1[:, :1])
+        assert Bt[0][0] == Bt[0][2] and abs(Bt[0][0] + Bt[0][1] - float(p)) <= 2.0 ** -21 * float(p)
