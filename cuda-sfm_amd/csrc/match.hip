@@ -254,7 +254,8 @@ int launch_match(sfm_ctx *ctx, const float *d1, int n1, int ld1, const float *d2
 {
     if (n1 <= 0 || n2 <= 0) return SFM_OK;                 // matching.cu:1095-1096
     // large sets: fp16 matrix-core pre-filter + exact scores of the few candidates (match_prefilter.hip; same results)
-    const bool big = n1 >= 1024 && n2 >= 1024 && (size_t)n1 * (size_t)n2 >= (size_t)3000 * 3000;
+    // (measured crossover, profiles/r02_match_bench.txt: 3000^2 0.043 vs 0.034 ms, 4096^2 0.043 vs 0.050, 5500^2 0.057 vs 0.083, 16384^2 0.15 vs 0.55)
+    const bool big = n1 >= 1024 && n2 >= 1024 && (size_t)n1 * (size_t)n2 >= (size_t)4096 * 4096;
     if (ctx->match_kernel == SFM_MATCH_PREFILTER || (ctx->match_kernel == SFM_MATCH_AUTO && big)) {
         ctx->last_match_kernel = SFM_MATCH_PREFILTER;
         return launch_match_prefilter(ctx, d1, n1, ld1, d2, n2, ld2, d_best, d_second, d_index, sift1, sift2);

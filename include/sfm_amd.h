@@ -65,7 +65,7 @@ int  sfm_ctx_set_quirks(sfm_ctx *ctx, unsigned int flags);
  * SFM_MATCH_EXACT     -- every score as the exact fp32 chain on v_mfma_f32_32x32x2_f32 (match.hip);
  * SFM_MATCH_PREFILTER -- fp16 matrix-core scores select the few rows per query that can be its best or second best, the
  *                        exact chain runs on those only (match_prefilter.hip);
- * SFM_MATCH_AUTO      -- the pre-filter from ~3000 x 3000 points on (default).  sfm_ctx_last_match_kernel: what the last call ran. */
+ * SFM_MATCH_AUTO      -- the pre-filter from 4096 x 4096 points on (default).  sfm_ctx_last_match_kernel: what the last call ran. */
 #define SFM_MATCH_AUTO      0
 #define SFM_MATCH_EXACT     1
 #define SFM_MATCH_PREFILTER 2

@@ -9,7 +9,7 @@ for d in sys.argv[1:]:
             acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
             calls[(k, r["Counter_Name"])].add(r["Dispatch_Id"])
 for k in sorted(acc):
-    if "sfm::" not in k:
+    if "sfm::" not in k and "3sfm" not in k:
         continue
     print(k)
     for c in sorted(acc[k]):

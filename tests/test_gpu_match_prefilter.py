@@ -99,12 +99,18 @@ def test_prefilter_entries_the_fp16_copy_cannot_hold(gpu):
     check_both(gpu, d1, db)
     db = d2.copy(); db[60] *= 1e4
     check_both(gpu, d1, db)
+    # the offending entry anywhere in the row (the row's sixteen lanes must all learn of it), several rows at once
+    q = d1.copy(); q[4, 77] = 1000.0; q[5, 127] = -2000.0; q[6, 8] = 300.0
+    db = d2.copy(); db[70, 127] = 500.0; db[71, 64] = -256.5
+    check_both(gpu, q, d2)
+    check_both(gpu, d1, db)
+    check_both(gpu, q, db)
 
 
 def test_prefilter_sift_records_and_auto(gpu):
-    """MatchSiftData semantics through the pre-filter path; AUTO picks it from ~3000 x 3000 on."""
+    """MatchSiftData semantics through the pre-filter path; AUTO picks it from 4096 x 4096 on."""
     torch, dev, ctx = gpu
-    n1, n2 = 3100, 3300
+    n1, n2 = 4200, 4100
     d1, _, _ = synth.descriptors(n1, seed=31)
     d2, _, _ = synth.descriptors(n2, seed=32)
     s1 = synth.sift_records(d1, seed=33); s2 = synth.sift_records(d2, seed=34)
