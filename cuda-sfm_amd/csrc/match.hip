@@ -29,7 +29,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int kRowsPerStage = 64;        // database rows per LDS stage (RT = 2 MFMA row tiles)
 constexpr int kLdsStride = 132;          // floats per staged row
 
-// Stage `rows` descriptor rows (first row `row0`, zero beyond `nrows`) into buf[rows][132].
+// Stage `rows` descriptor rows (first row `row0`, zero beyond `nrows`) into buf[rows][132].  The loads are unconditional
+// (from a clamped row; the zeros are selected when the values are stored): with branches around them the compiler cannot
+// count the loads in flight and waits for ALL of them -- the prefetch it has just issued -- before the stage's first MFMA.
 template <int W>
 __device__ __forceinline__ void stage_load(const float *__restrict__ base, int ld, int row0, int nrows,
                                            float4 (&regs)[16 / W][2])
@@ -38,27 +40,24 @@ __device__ __forceinline__ void stage_load(const float *__restrict__ base, int l
     const int rr = threadIdx.x >> 4;             // 4*W rows per pass
 #pragma unroll
     for (int pass = 0; pass < 16 / W; ++pass) {
-        const int row = row0 + pass * (4 * W) + rr;
-        if (row < nrows) {
-            const float4 *src = reinterpret_cast<const float4 *>(base + (size_t)row * ld + 8 * c8);
-            regs[pass][0] = src[0];
-            regs[pass][1] = src[1];
-        } else {
-            regs[pass][0] = make_float4(0.f, 0.f, 0.f, 0.f);
-            regs[pass][1] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+        const int row = min(row0 + pass * (4 * W) + rr, nrows - 1);
+        const float4 *src = reinterpret_cast<const float4 *>(base + (size_t)row * ld + 8 * c8);
+        regs[pass][0] = src[0];
+        regs[pass][1] = src[1];
     }
 }
 
 template <int W>
-__device__ __forceinline__ void stage_store(float *buf, const float4 (&regs)[16 / W][2])
+__device__ __forceinline__ void stage_store(float *buf, const float4 (&regs)[16 / W][2], int row0, int nrows)
 {
     const int c8 = threadIdx.x & 15;
     const int rr = threadIdx.x >> 4;
 #pragma unroll
     for (int pass = 0; pass < 16 / W; ++pass) {
         float4 *dst = reinterpret_cast<float4 *>(buf + (pass * (4 * W) + rr) * kLdsStride + 8 * c8);
-        const float4 a = regs[pass][0], b = regs[pass][1];
+        const bool real = row0 + pass * (4 * W) + rr < nrows;
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 a = real ? regs[pass][0] : z, b = real ? regs[pass][1] : z;
         dst[0] = make_float4(a.x, a.z, b.x, b.z);      // even d: k-parity 0
         dst[1] = make_float4(a.y, a.w, b.y, b.w);      // odd d : k-parity 1
     }
@@ -97,7 +96,7 @@ void match_mfma_kernel(const float *__restrict__ q, int nq, int ldq,
         stage_load<W>(q, ldq, q0, nq, regs);
         for (int ch = 0; ch < kChunks; ++ch) {
             float *buf = lds[ch & 1];
-            stage_store<W>(buf, regs);
+            stage_store<W>(buf, regs, q0 + ch * kRowsPerStage, nq);
             __syncthreads();
             if (ch + 1 < kChunks) stage_load<W>(q, ldq, q0 + (ch + 1) * kRowsPerStage, nq, regs);
 #pragma unroll
@@ -126,7 +125,7 @@ void match_mfma_kernel(const float *__restrict__ q, int nq, int ldq,
     float4 regs[16 / W][2];
     if (nstage > 0) {
         stage_load<W>(db, lddb, row_begin, row_end, regs);
-        stage_store<W>(lds[0], regs);
+        stage_store<W>(lds[0], regs, row_begin, row_end);
     }
     __syncthreads();
     for (int s = 0; s < nstage; ++s) {
@@ -169,7 +168,7 @@ void match_mfma_kernel(const float *__restrict__ q, int nq, int ldq,
                 for (int ct = 0; ct < CT; ++ct) top2_push(top[ct], acc[rt][ct][r], p2);
             }
 
-        if (s + 1 < nstage) stage_store<W>(lds[(s + 1) & 1], regs);
+        if (s + 1 < nstage) stage_store<W>(lds[(s + 1) & 1], regs, row_begin + (s + 1) * kRowsPerStage, row_end);
         __syncthreads();
     }
 

@@ -85,9 +85,9 @@ SFM_HD bool prefilter_scales(float thr, PfScales &sc)
 SFM_HD float pf_opaque(float x)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-    asm volatile("" : "+v"(x));
+    asm("" : "+v"(x));
 #else
-    asm volatile("" : "+x"(x));
+    asm("" : "+x"(x));
 #endif
     return x;
 }

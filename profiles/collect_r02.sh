@@ -25,14 +25,15 @@ done; done
 # 2. stand-alone benches
 python3 profiles/pipeline_bench.py > $O/${TAG}_pipeline_bench.txt 2>/dev/null
 python3 profiles/ring_bench.py > $O/${TAG}_ring_bench.txt 2>/dev/null
-python3 profiles/match_bench.py > $O/${TAG}_match_bench.txt 2>/dev/null
+MATCH_SIZES=1200,2048,3000,4096,5500,8192,16384 python3 profiles/match_bench.py > $O/${TAG}_match_bench.txt 2>/dev/null
 python3 profiles/homography_bench.py > $O/${TAG}_homography_bench.txt 2>/dev/null
 python3 profiles/sift_bench.py > $O/${TAG}_sift_bench.txt 2>/dev/null
 python3 profiles/small_h_bench.py > $O/${TAG}_small_h_bench.txt 2>/dev/null
 ./profiles/probes/mfma_f16_probe.bin > $O/${TAG}_mfma_f16_probe.txt 2>&1
 ./profiles/probes/pk_clamp_probe.bin > $O/${TAG}_pk_clamp_probe.txt 2>&1
 python3 tests/fuzz_gpu.py 300 99 > $O/${TAG}_fuzz.txt 2>/dev/null
-python3 profiles/prefilter_soak.py 420 7 > $O/${TAG}_prefilter_soak.txt 2>/dev/null
+python3 profiles/prefilter_soak.py 420 31 > $O/${TAG}_prefilter_soak.txt 2>/dev/null
+python3 profiles/soak_repro.py "$(cat profiles/soak_cases_r02.json)" $O/${TAG}_soak_repro.npz 2>/dev/null | tail -1 > $O/${TAG}_soak_repro_after_fix.txt
 python3 profiles/phase_probe.py 2>/dev/null | grep hypotheses > $O/${TAG}_phase_probe.txt
 python3 profiles/enqueue_probe.py 2>/dev/null | grep hypotheses > $O/${TAG}_enqueue_probe.txt
 sh profiles/small_shard_ab.sh 2>/dev/null | grep hyps > $O/${TAG}_small_shard_ab.txt
@@ -59,6 +60,11 @@ for r in rows[i0:i0+4]:
 PY
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_stats_pipe -o bench -- python3 $R/bench.py --steps 100 --warmup 20 --no-cpu --no-variants > /dev/null 2>&1
 cp $O/${TAG}_stats_pipe/bench_kernel_stats.csv $O/${TAG}_bench_pipelined_kernel_stats.csv
+# 3b. the matchers: per-kernel durations and counters at 16384 x 16384
+sh $R/profiles/match_kernels.sh 5500,16384 > $O/${TAG}_match_kernels.txt 2>/dev/null
+sh $R/profiles/pmc_match.sh 16384 > /dev/null 2>&1
+grep -A18 "match_pf\|match_mfma" $O/pmc_match_summary.txt > $O/pmc_${TAG}_match_summary.txt
+cd /tmp
 # 4. counters (separate passes): SQ / LDS, matrix pipe, HBM traffic -- bench command, headline and c4
 for cfg in headline c4; do
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $O/pmc_${TAG}_${cfg}_1 -o p -- python3 $R/bench.py --serial --config $cfg --steps 3 --warmup 1 --no-cpu --no-variants > /dev/null 2>&1
