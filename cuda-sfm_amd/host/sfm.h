@@ -58,6 +58,8 @@ public:
         params_.hyp_begin = 0; params_.hyp_count = 0;
     }
     void setPoseMode(int mode) { pose_mode_ = mode; }
+    // computePosecandidates + choosePose + linear_triangulation (src/main.cpp:302-306) as one launch; same results
+    void poseChain() { SFM_FACADE_CALL(sfm_pose_chain(pair_, pose_mode_)); }
     // another correspondence set of at most the constructor's num_points, without re-allocating anything
     void reset(int num_points)
     {

@@ -61,9 +61,13 @@ int main(int argc, char **argv)
     if (argc > 6) sfm.setPoseMode(std::atoi(argv[6]));
     sfm.fillXU(siftData1.d_data);                           // main.cpp:299
     sfm.estimateE();                                        // main.cpp:301
-    sfm.computePosecandidates();                            // main.cpp:303
-    sfm.choosePose();                                       // main.cpp:305
-    sfm.linear_triangulation();                             // main.cpp:307
+    if (std::getenv("SFM_DEMO_POSE_CHAIN")) {               // the same three calls as ONE launch (additive; tests/test_gpu_facade.py)
+        sfm.poseChain();
+    } else {
+        sfm.computePosecandidates();                        // main.cpp:303
+        sfm.choosePose();                                   // main.cpp:305
+        sfm.linear_triangulation();                         // main.cpp:307
+    }
 
     float E[9], P[64], Pinv[64];
     uint32_t hyp = 0, cnt = 0;

@@ -30,13 +30,16 @@ def make_feature_sets(n, seed):
     return s1, np.concatenate([s2, extra]), sc
 
 
-@pytest.mark.parametrize("n,H,mode", [(500, 200, 0), (2048, 1024, 0), (2048, 1024, 1)])
-def test_cpp_facade_end_to_end(tmp_path, n, H, mode):
+@pytest.mark.parametrize("n,H,mode,chain", [(500, 200, 0, False), (2048, 1024, 0, False), (2048, 1024, 1, False), (2048, 1024, 0, True), (777, 300, 1, True)])
+def test_cpp_facade_end_to_end(tmp_path, n, H, mode, chain):
     assert os.path.exists(DEMO), "two_view_demo not built (make)"
     s1, s2, sc = make_feature_sets(n, seed=70 + n)
     f1, f2, out = (str(tmp_path / x) for x in ("s1.bin", "s2.bin", "out.bin"))
     s1.tofile(f1); s2.tofile(f2)
-    r = subprocess.run([DEMO, f1, f2, out, str(H), "0x1234", str(mode)], capture_output=True, text=True, timeout=300)
+    env = dict(os.environ)
+    if chain:
+        env["SFM_DEMO_POSE_CHAIN"] = "1"                           # Image_pair::poseChain() instead of the three pose calls
+    r = subprocess.run([DEMO, f1, f2, out, str(H), "0x1234", str(mode)], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "MatchSiftData time" in r.stdout                      # reference prints this (matching.cu:1203)
 
