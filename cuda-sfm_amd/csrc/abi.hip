@@ -407,6 +407,7 @@ int sfm_pair_create(sfm_ctx *ctx, const float h_K[9], const float h_Kinv[9], int
     hipError_t e = hipMemcpyAsync(p->d_K, h_K, 9 * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(p->d_Kinv, h_Kinv, 9 * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipMemsetAsync(p->d_key, 0, 2 * sizeof(unsigned long long), ctx->stream);
+    p->key_clean = true;
     if (e == hipSuccess) e = hipMemsetAsync(p->d_best, 0, 2 * sizeof(uint32_t), ctx->stream);
     if (e == hipSuccess) e = hipMemsetAsync(p->d_clk, 0, 8 * sizeof(unsigned long long), ctx->stream);
     if (e == hipSuccess) e = hipMemsetAsync(p->d_Pind, 0, 8 * sizeof(int), ctx->stream);
@@ -453,6 +454,7 @@ int sfm_fill_xu(sfm_pair *pair, const sfm_sift_point *d_data)
     int rc = launch_fill_xu(pair, d_data);
     if (rc == SFM_OK) {
         pair->have_points = true; pair->have_E = pair->have_P = pair->have_pose = pair->have_points3d = false; pair->last_count = 0;
+        pair->key_clean = true;             // fill_xu_kernel zeroes d_key
         // X_z = fma(Kinv[8], 1, fma(Kinv[7], y, Kinv[6] * x)) is exactly 1 for finite pixel coordinates when
         // the last row of K^-1 is (0 0 1): the scoring kernel may then drop z (ransac_device.hpp)
         pair->unit_z = pair->h_Kinv[6] == 0.0f && pair->h_Kinv[7] == 0.0f && pair->h_Kinv[8] == 1.0f;
@@ -538,6 +540,7 @@ int sfm_ransac_score_into_slot(sfm_pair *pair, const sfm_ransac_params *p, uint6
     auto swap_slot = [&]() {
         std::swap(pair->d_counts, pair->alt_counts); std::swap(pair->d_tick, pair->alt_tick);
         std::swap(pair->d_Ecand, pair->alt_Ecand); std::swap(pair->cap_hyps, pair->alt_cap_hyps);
+        pair->key_clean = false;            // (the flag describes the pair's own key buffer, not the slot's)
         std::swap(pair->d_key, pair->alt_key);
     };
     hipStream_t keep = pair->ctx->stream;

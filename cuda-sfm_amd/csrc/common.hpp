@@ -105,6 +105,7 @@ struct sfm_pair {
     float *d_points = nullptr;         // 4 x n
     uint8_t *d_mask = nullptr;         // n
     unsigned long long *d_key = nullptr;   // [0] packed best of last score, [1] scratch
+    bool key_clean = false;                // d_key is known to be zero (pair creation, fillXU): the next score launch needs no memset
     uint32_t *d_best = nullptr;        // [0] hyp, [1] count of the finalized hypothesis
     unsigned long long *d_clk = nullptr;   // [0] shader-clock ticks, [1] 100 MHz ticks over block 0 of the last ransac_score_waves launch
     // per-shard buffers, grown on demand

@@ -16,9 +16,11 @@ namespace sfm {
 // NaN so that padded points can never be inliers, the U tail is 0.
 __global__ __launch_bounds__(256)
 void fill_xu_kernel(const sfm_sift_point *__restrict__ data, int n, int ld, const float *__restrict__ kinv,
-                    float *__restrict__ U0, float *__restrict__ U1, float *__restrict__ X0, float *__restrict__ X1)
+                    float *__restrict__ U0, float *__restrict__ U1, float *__restrict__ X0, float *__restrict__ X1,
+                    unsigned long long *__restrict__ key)
 {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j == 0) { key[0] = 0ull; key[1] = 0ull; }           // the estimateE that follows finds its arg-max key cleared: no memset launch
     if (j >= ld) return;
     const float qnan = __builtin_nanf("");
     float u0[3] = { 0.0f, 0.0f, 0.0f }, u1[3] = { 0.0f, 0.0f, 0.0f };
@@ -263,7 +265,7 @@ int launch_pose_chain(sfm_pair *pair, float *d_record)
 int launch_fill_xu(sfm_pair *pair, const sfm_sift_point *d_data)
 {
     hipLaunchKernelGGL(fill_xu_kernel, dim3((pair->ld + 255) / 256), dim3(256), 0, pair->ctx->stream,
-                       d_data, pair->n, pair->ld, pair->d_Kinv, pair->d_U[0], pair->d_U[1], pair->d_X[0], pair->d_X[1]);
+                       d_data, pair->n, pair->ld, pair->d_Kinv, pair->d_U[0], pair->d_U[1], pair->d_X[0], pair->d_X[1], pair->d_key);
     SFM_HIP_TRY(hipGetLastError());
     return SFM_OK;
 }

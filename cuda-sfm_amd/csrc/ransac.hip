@@ -263,9 +263,10 @@ int launch_ransac_score(sfm_pair *pair, const sfm_ransac_params &p, uint32_t h0,
     if (d_E_given && family == SFM_KERNEL_FUSED) family = SFM_KERNEL_SPLIT;      // the fused kernel solves its own candidates
     const bool self_clearing = !d_E_given && count > 0 && (family == SFM_KERNEL_SPLIT || family == SFM_KERNEL_PREFILTER);
     if (!self_clearing) {
-        SFM_HIP_TRY(hipMemsetAsync(pair->d_key, 0, 2 * sizeof(unsigned long long), ctx->stream));
+        if (!pair->key_clean) SFM_HIP_TRY(hipMemsetAsync(pair->d_key, 0, 2 * sizeof(unsigned long long), ctx->stream));    // (fillXU leaves it cleared)
         if (key2) SFM_HIP_TRY(hipMemsetAsync(key2, 0, sizeof(unsigned long long), ctx->stream));
     }
+    pair->key_clean = false;
     pair->last_count = count;
     pair->cand_h0 = h0; pair->cand_seed = p.seed; pair->cand_indices = p.d_indices; pair->cand_sweeps = p.jacobi_sweeps;
     if (count == 0) return SFM_OK;
