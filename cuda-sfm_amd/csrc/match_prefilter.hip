@@ -28,7 +28,6 @@ typedef float f16v __attribute__((ext_vector_type(16)));
 constexpr int kMpRows = 128;             // database rows per LDS stage: two sub-stages of two 32-row MFMA tiles, one barrier
 constexpr int kMpSub = 64;               // rows per sub-stage (what one set of accumulators covers)
 constexpr int kMpStride = 272;           // bytes per staged row: 256 + 16, so that the 16 lanes of a ds_read_b128 group hit 64 distinct banks
-constexpr int kMpWaves = 8;
 constexpr int kMpCap = 8;                // candidate slots per (query, database split); more than that: the query scans that split in full
 
 // ---- prep: rows [0, nq) = queries, [nq, nq + ndb) = database; sixteen lanes per row, eight entries each
@@ -71,14 +70,15 @@ void match_pf_prep(const float *__restrict__ q, int nq, int ldq, const float *__
     }
 }
 
-// ---- passes 1 and 2: W = 8 wavefronts x CT column tiles = 256 CT queries against the database rows of one split
-template <int CT, int PASS>
-__global__ __launch_bounds__(kMpWaves * 64)
+// ---- passes 1 and 2: W wavefronts x CT column tiles = 32 W CT queries against the database rows of one split
+template <int CT, int W, int PASS>
+__global__ __launch_bounds__(W * 64)
 void match_pf_pass(const _Float16 *__restrict__ qh, int nq, const _Float16 *__restrict__ dbh, int ndb, int rows_per_split,
                    float *__restrict__ ws_t1, float *__restrict__ ws_t2, float *__restrict__ ws_bmax,
                    const float *__restrict__ qnorm, const float *__restrict__ dbnorm, int *__restrict__ cnt, int *__restrict__ cand)
 {
     __shared__ __attribute__((aligned(16))) unsigned char lds[2][kMpRows * kMpStride];
+    constexpr int kMpWaves = W;
     __shared__ float s_red[kMpWaves];
     __shared__ int s_cnt[CT * 32 * kMpWaves];             // PASS 2: candidates of this split per query of the block
     const int lane = threadIdx.x & 63;
@@ -171,7 +171,7 @@ void match_pf_pass(const _Float16 *__restrict__ qh, int nq, const _Float16 *__re
     auto stage_load = [&](int s) {
 #pragma unroll
         for (int u = 0; u < kLd; ++u) {
-            const int idx = (int)threadIdx.x + 512 * u;
+            const int idx = (int)threadIdx.x + kMpWaves * 64 * u;
             const int row = row_begin + s * kMpRows + (idx >> 4);
             regs[u] = *reinterpret_cast<const h8 *>(dbh + (size_t)min(row, row_end - 1) * 128 + 8 * (idx & 15));
         }
@@ -179,7 +179,7 @@ void match_pf_pass(const _Float16 *__restrict__ qh, int nq, const _Float16 *__re
     auto stage_store = [&](unsigned char *buf, int s) {          // (the select sits here, where the loaded values are needed anyway)
 #pragma unroll
         for (int u = 0; u < kLd; ++u) {
-            const int idx = (int)threadIdx.x + 512 * u;
+            const int idx = (int)threadIdx.x + kMpWaves * 64 * u;
             const int row = row_begin + s * kMpRows + (idx >> 4);
             h8 z = {};
             *reinterpret_cast<h8 *>(buf + (idx >> 4) * kMpStride + 16 * (idx & 15)) = row < row_end ? regs[u] : z;
@@ -194,16 +194,17 @@ void match_pf_pass(const _Float16 *__restrict__ qh, int nq, const _Float16 *__re
         // The sixteen A fragments of a sub-stage are requested in one go (16 ds_read_b128 in flight: the LDS latency is paid
         // once per sub-stage, not once per k-step), and those of the NEXT sub-stage straight after this one's MFMAs have been
         // issued, so that they travel while the accumulators are folded.
-        h8 af[2][8];
-        auto load_frags = [&](int sub) {
-            const unsigned char *a0p = lds[s & 1] + sub * kMpSub * kMpStride + col * kMpStride + 16 * half;
+        constexpr int KB = W > 8 ? 4 : 8;      // k-steps per batch of A fragments (four wavefronts per SIMD have 128 VGPRs each)
+        h8 af[2][KB];
+        auto load_frags = [&](int sub, int kk0) {
+            const unsigned char *a0p = lds[s & 1] + sub * kMpSub * kMpStride + col * kMpStride + 16 * half + 32 * kk0;
 #pragma unroll
-            for (int kk = 0; kk < 8; ++kk) {
+            for (int kk = 0; kk < KB; ++kk) {
                 af[0][kk] = *reinterpret_cast<const h8 *>(a0p + 32 * kk);
                 af[1][kk] = *reinterpret_cast<const h8 *>(a0p + 32 * kMpStride + 32 * kk);
             }
         };
-        load_frags(0);
+        load_frags(0, 0);
 #pragma unroll
       for (int sub = 0; sub < kSubs; ++sub) {
         if (row_begin + s * kMpRows + sub * kMpSub >= row_end) break;          // nothing but padding left (block-uniform)
@@ -215,17 +216,21 @@ void match_pf_pass(const _Float16 *__restrict__ qh, int nq, const _Float16 *__re
             for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[rt][ct][r] = 0.0f;
-        __builtin_amdgcn_sched_barrier(0);      // keeps the scheduler from sinking the reads back next to their MFMAs
 #pragma unroll
-        for (int kk = 0; kk < 8; ++kk) {
+        for (int kk0 = 0; kk0 < 8; kk0 += KB) {
+            __builtin_amdgcn_sched_barrier(0);      // keeps the scheduler from sinking the reads back next to their MFMAs
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct) {
-                acc[0][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][kk], bq[ct][kk], acc[0][ct], 0, 0, 0);
-                acc[1][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[1][kk], bq[ct][kk], acc[1][ct], 0, 0, 0);
+            for (int kk = 0; kk < KB; ++kk) {
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+                    acc[0][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][kk], bq[ct][kk0 + kk], acc[0][ct], 0, 0, 0);
+                    acc[1][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[1][kk], bq[ct][kk0 + kk], acc[1][ct], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);      // independent accumulators round-robin: the compiler would pair k-steps of one
             }
-            __builtin_amdgcn_sched_barrier(0);      // four independent accumulators round-robin: the compiler would pair k-steps of one
+            if (kk0 + KB < 8) load_frags(sub, kk0 + KB);
+            else if (sub + 1 < kSubs) load_frags(sub + 1, 0);
         }
-        if (sub + 1 < kSubs) load_frags(sub + 1);
         __builtin_amdgcn_sched_barrier(0);
 
         if (PASS == 1) {
@@ -374,12 +379,11 @@ static int match_pf_workspace(sfm_ctx *ctx, size_t need)
     return SFM_OK;
 }
 
-int launch_match_prefilter(sfm_ctx *ctx, const float *d1, int n1, int ld1, const float *d2, int n2, int ld2,
-                           float *d_best, float *d_second, int32_t *d_index,
-                           sfm_sift_point *sift1, const sfm_sift_point *sift2)
+template <int CT, int kMpWaves>
+static int launch_match_prefilter_cfg(sfm_ctx *ctx, const float *d1, int n1, int ld1, const float *d2, int n2, int ld2,
+                                      float *d_best, float *d_second, int32_t *d_index,
+                                      sfm_sift_point *sift1, const sfm_sift_point *sift2)
 {
-    if (n1 <= 0 || n2 <= 0) return SFM_OK;
-    constexpr int CT = 2;
     const int qper = CT * 32 * kMpWaves;
     const int qblocks = (n1 + qper - 1) / qper;
     int nsplit = ctx->num_cus / qblocks;                 // one round over the CUs (see launch_match)
@@ -405,12 +409,26 @@ int launch_match_prefilter(sfm_ctx *ctx, const float *d1, int n1, int ld1, const
     hipLaunchKernelGGL(match_pf_prep, dim3((unsigned)(((size_t)(n1 + n2) * 16 + 255) / 256)), dim3(256), 0, st,
                        d1, n1, ld1, d2, n2, ld2, qh, dbh, qn, dbn);
     const dim3 grid(qblocks, nsplit);
-    hipLaunchKernelGGL((match_pf_pass<CT, 1>), grid, dim3(kMpWaves * 64), 0, st, qh, n1, dbh, n2, rows_per_split, t1, t2, bm, qn, dbn, cnt, cand);
-    hipLaunchKernelGGL((match_pf_pass<CT, 2>), grid, dim3(kMpWaves * 64), 0, st, qh, n1, dbh, n2, rows_per_split, t1, t2, bm, qn, dbn, cnt, cand);
+    hipLaunchKernelGGL((match_pf_pass<CT, kMpWaves, 1>), grid, dim3(kMpWaves * 64), 0, st, qh, n1, dbh, n2, rows_per_split, t1, t2, bm, qn, dbn, cnt, cand);
+    hipLaunchKernelGGL((match_pf_pass<CT, kMpWaves, 2>), grid, dim3(kMpWaves * 64), 0, st, qh, n1, dbh, n2, rows_per_split, t1, t2, bm, qn, dbn, cnt, cand);
     hipLaunchKernelGGL(match_pf_exact, dim3((unsigned)(((size_t)n1 * 16 + 255) / 256)), dim3(256), 0, st,
                        d1, n1, ld1, d2, n2, ld2, cnt, cand, nsplit, rows_per_split, d_best, d_second, d_index, sift1, sift2);
     SFM_HIP_TRY(hipGetLastError());
     return SFM_OK;
+}
+
+int launch_match_prefilter(sfm_ctx *ctx, const float *d1, int n1, int ld1, const float *d2, int n2, int ld2,
+                           float *d_best, float *d_second, int32_t *d_index,
+                           sfm_sift_point *sift1, const sfm_sift_point *sift2)
+{
+    if (n1 <= 0 || n2 <= 0) return SFM_OK;
+    // two configurations: 16 wavefronts x 1 column tile (four per SIMD: more phases in flight behind the stage barrier; the
+    // default -- passes 1 + 2 at 4096^2 / 5500^2 / 16384^2: 23.6 / 30.7 / 124 us against 26.4 / 34.3 / 128) and 8 wavefronts x 2
+    // column tiles (two per SIMD, every A fragment feeds two MFMAs)
+    static const char *cfg_env = getenv("SFM_MATCH_PF_CFG");      // profiling only: "1,16" or "2,8"
+    const bool wide = cfg_env ? cfg_env[0] == '1' : true;
+    if (wide) return launch_match_prefilter_cfg<1, 16>(ctx, d1, n1, ld1, d2, n2, ld2, d_best, d_second, d_index, sift1, sift2);
+    return launch_match_prefilter_cfg<2, 8>(ctx, d1, n1, ld1, d2, n2, ld2, d_best, d_second, d_index, sift1, sift2);
 }
 
 } // namespace sfm
