@@ -226,10 +226,25 @@ def rank_main(args):
     if args.serial and mode == "rccl":
         mode = "rccl-serial"
     pipelined = (mode == "rccl") or (mode == "none" and not args.serial)
+    comm_note = None
     if mode in ("rccl", "rccl-serial"):
-        uid = [S.Comm.unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)            # the out-of-band hand-over of the ncclUniqueId
-        comm = S.Comm(ctx, uid[0], rank, world)
+        # the C-level exchange (libsfm_amd_rccl.so).  Should its communicator fail to come up on ANY rank, every rank falls
+        # back to torch.distributed's all-reduce for the same 8-byte key (agreed through one collective), and the line says so.
+        err = ""
+        try:
+            uid = [S.Comm.unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0)        # the out-of-band hand-over of the ncclUniqueId
+            comm = S.Comm(ctx, uid[0], rank, world)
+        except Exception as e:                            # noqa: BLE001 -- any failure means "use the other exchange"
+            err = f"{type(e).__name__}: {e}"
+        ok = torch.tensor([0 if err else 1], dtype=torch.int32, device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            comm = None
+            comm_note = f"libsfm_amd_rccl communicator unavailable on some rank ({err or 'another rank'}): torch.distributed all-reduce instead"
+            print("bench.py: " + comm_note, file=sys.stderr)
+            mode = "torch"
+            pipelined = False
 
     def step():
         if mode == "rccl":
@@ -336,6 +351,8 @@ def rank_main(args):
                     "rccl": "ncclAllReduce(max, u64) + finalize on the communicator's exchange stream, overlapped with the next step's solve + scoring (libsfm_amd_rccl.so, sfm_estimate_E_sharded_pipelined)",
                     "rccl-serial": "ncclAllReduce(max, u64) on the compute stream (libsfm_amd_rccl.so, sfm_estimate_E_sharded)",
                     "torch": "torch.distributed all_reduce(MAX), 8 bytes"}[mode]
+        if comm_note:
+            exchange += " -- " + comm_note
         launch = pair.last_launch()
         kname = {1: "ransac_score_waves", 2: "ransac_fused_waves", 3: "ransac_score_mfma", 4: "ransac_score_prefilter"}.get(launch["kernel"], "?")
         traffic_profiled = None                       # HBM bytes per launch from the committed rocprofv3 PMC passes: quoted, NOT measured by this run
