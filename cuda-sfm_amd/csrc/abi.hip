@@ -894,71 +894,91 @@ int sfm_extract_views(sfm_ctx *ctx, const float *const *h_images, int num_views,
     SFM_REQUIRE(slot_bytes >= (size_t)max_pts * sizeof(sfm_sift_point) + 4 && slot_bytes % 16 == 0, SFM_E_INVALID,
                 "slot_bytes %zu: need max_pts records + the count, a multiple of 16", slot_bytes);
     SFM_HIP_TRY(hipSetDevice(ctx->device));
-    // two contexts (the caller's + the first auxiliary lane): while one image is being extracted the next one is copied
-    // into pinned memory, uploaded and started on the other stream -- one image's per-level kernels leave most CUs idle
-    if (!ctx->lane[0]) {
-        int rc = sfm_ctx_create(ctx->device, &ctx->lane[0]);
-        if (rc == SFM_OK) rc = sfm_ctx_own_stream(ctx->lane[0]);
-        if (rc != SFM_OK) return rc;
+    // FOUR contexts (the caller's + the auxiliary lanes): one image's per-level kernels leave most CUs idle, and every view
+    // ends with a host synchronisation (its feature count), so four views are in flight on four streams.
+    constexpr int NC = sfm_ctx::kPairLanes;           // contexts
+    constexpr int NR = 2 * NC;                        // pinned staging buffers (two per context)
+    constexpr int NT = 3;                             // helper threads that fill them
+    sfm_ctx *cs[NC] = { ctx };
+    for (int l = 1; l < NC; ++l) {
+        if (!ctx->lane[l - 1]) {
+            int rc = sfm_ctx_create(ctx->device, &ctx->lane[l - 1]);
+            if (rc == SFM_OK) rc = sfm_ctx_own_stream(ctx->lane[l - 1]);
+            if (rc != SFM_OK) return rc;
+            ctx->lane[l - 1]->match_kernel = ctx->match_kernel;
+        }
+        cs[l] = ctx->lane[l - 1];
     }
-    sfm_ctx *cs[2] = { ctx, ctx->lane[0] };
     const int pitch = round_up(width, 128);
     const size_t floats = (size_t)pitch * height;
-    // device image per context; FOUR pinned staging buffers (two per context) filled by a helper thread that runs ahead of
-    // the enqueueing thread: the row-by-row copy into pinned memory is the host-side cost of a view (~0.1 ms for 720 x 576,
-    // about what its extraction takes), so it must not sit between two enqueues
+    // device image per context; pinned staging buffers filled by helper threads that run ahead of the enqueueing thread:
+    // the row-by-row copy into pinned memory is the host-side cost of a view (~0.1 ms for 720 x 576, about what its
+    // extraction takes and more than its upload), so it must neither sit between two enqueues nor be done by ONE thread
     for (sfm_ctx *c : cs) { int rc = views_buffers(c, 2 * floats); if (rc != SFM_OK) return rc; }
-    float *ring[4] = { cs[0]->views_pinned, cs[1]->views_pinned, cs[0]->views_pinned + floats, cs[1]->views_pinned + floats };
-    float *image[2] = { cs[0]->views_image, cs[1]->views_image };
-    SFM_HIP_TRY(hipEventRecord(ctx->views_ev, ctx->stream));                 // the lane starts after what the caller enqueued
-    SFM_HIP_TRY(hipStreamWaitEvent(cs[1]->stream, ctx->views_ev, 0));
+    float *ring[NR], *image[NC];
+    for (int k = 0; k < NC; ++k) { ring[k] = cs[k]->views_pinned; ring[NC + k] = cs[k]->views_pinned + floats; image[k] = cs[k]->views_image; }
+    SFM_HIP_TRY(hipEventRecord(ctx->views_ev, ctx->stream));                 // the lanes start after what the caller enqueued
+    for (int k = 1; k < NC; ++k) SFM_HIP_TRY(hipStreamWaitEvent(cs[k]->stream, ctx->views_ev, 0));
     int nown = 0;
     for (int v = first; v < num_views; v += stride) { SFM_REQUIRE(h_images[v], SFM_E_INVALID, "view %d: null image", v); ++nown; }
     if (nown == 0) return SFM_OK;
-    std::atomic<int> staged(0), consumed(0), stop(0);
-    std::thread stager([&]() {
-        for (int i = 0; i < nown && !stop.load(std::memory_order_relaxed); ++i) {
-            while (i - consumed.load(std::memory_order_acquire) >= 4 && !stop.load(std::memory_order_relaxed)) std::this_thread::yield();
-            float *pin = ring[i & 3];
+    std::vector<std::atomic<int>> staged((size_t)nown);
+    for (auto &f : staged) f.store(0, std::memory_order_relaxed);
+    std::atomic<int> consumed(0), stop(0);
+    auto stage = [&](int t) {
+        for (int i = t; i < nown && !stop.load(std::memory_order_relaxed); i += NT) {
+            while (i - consumed.load(std::memory_order_acquire) >= NR && !stop.load(std::memory_order_relaxed)) std::this_thread::yield();
+            float *pin = ring[i % NR];
             const float *src = h_images[first + i * stride];
             for (int y = 0; y < height; ++y) {
                 memcpy(pin + (size_t)y * pitch, src + (size_t)y * width, (size_t)width * sizeof(float));
                 if (pitch > width) memset(pin + (size_t)y * pitch + width, 0, (size_t)(pitch - width) * sizeof(float));
             }
-            staged.store(i + 1, std::memory_order_release);
+            staged[(size_t)i].store(1, std::memory_order_release);
         }
-    });
+    };
+    std::vector<std::thread> stagers;
+    for (int t = 0; t < NT && t < nown; ++t) stagers.emplace_back(stage, t);
     char *block = static_cast<char *>(d_block);
     std::vector<int> counts((size_t)nown, 0);
-    int pending_slot[2] = { -1, -1 };
+    int pending_slot[NC];
+    for (int k = 0; k < NC; ++k) pending_slot[k] = -1;
+    int done_upto = 0;                                // views 0 .. done_upto - 1 have been read back (in order: contexts take turns)
     auto finish = [&](int k) -> int {
         if (pending_slot[k] < 0) return SFM_OK;
         int n = 0, stored = 0;
         int rc = launch_extract_sift_end(cs[k], &n, &stored);                  // waits for this context's stream: its upload is done too
         if (rc != SFM_OK) return rc;
         counts[(size_t)pending_slot[k]] = n;
-        consumed.store(pending_slot[k] + 1, std::memory_order_release);        // staging buffer pending_slot % 4 may be refilled
+        done_upto = pending_slot[k] + 1;
+        consumed.store(done_upto, std::memory_order_release);                  // staging buffer pending_slot % NR may be refilled
         pending_slot[k] = -1;
         return SFM_OK;
     };
     int rc = SFM_OK;
     for (int i = 0; i < nown && rc == SFM_OK; ++i) {
-        const int k = i & 1;
+        const int k = i % NC;
         rc = finish(k);                                                        // this context's previous view
         if (rc != SFM_OK) break;
-        while (staged.load(std::memory_order_acquire) <= i) std::this_thread::yield();
-        hipError_t e = hipMemcpyAsync(image[k], ring[i & 3], floats * sizeof(float), hipMemcpyHostToDevice, cs[k]->stream);
+        while (staged[(size_t)i].load(std::memory_order_acquire) == 0) std::this_thread::yield();
+        hipError_t e = hipMemcpyAsync(image[k], ring[i % NR], floats * sizeof(float), hipMemcpyHostToDevice, cs[k]->stream);
         if (e != hipSuccess) { set_error("view upload failed: %s", hipGetErrorString(e)); rc = SFM_E_HIP; break; }
         rc = launch_extract_sift_begin(cs[k], reinterpret_cast<sfm_sift_point *>(block + (size_t)i * slot_bytes), max_pts, image[k],
                                        width, height, pitch, num_octaves, init_blur, thresh, lowest_scale, scale_up ? 1 : 0, nullptr);
         if (rc == SFM_OK) pending_slot[k] = i;
     }
-    for (int k = 0; k < 2 && rc == SFM_OK; ++k) rc = finish(k);
+    // the remaining views, oldest first (the staging ring is released in view order)
+    for (int left = 0; left < NC && rc == SFM_OK; ++left) {
+        int oldest = -1;
+        for (int k = 0; k < NC; ++k) if (pending_slot[k] >= 0 && (oldest < 0 || pending_slot[k] < pending_slot[oldest])) oldest = k;
+        if (oldest < 0) break;
+        rc = finish(oldest);
+    }
     stop.store(1, std::memory_order_relaxed);
     consumed.store(nown, std::memory_order_release);
-    stager.join();
+    for (std::thread &t : stagers) t.join();
     if (rc != SFM_OK) {
-        for (int k = 0; k < 2; ++k) if (pending_slot[k] >= 0) { int n = 0; (void)launch_extract_sift_end(cs[k], &n, nullptr); }
+        for (int k = 0; k < NC; ++k) if (pending_slot[k] >= 0) { int n = 0; (void)launch_extract_sift_end(cs[k], &n, nullptr); }
         return rc;
     }
     // the feature counts of all slots with ONE strided copy
