@@ -399,6 +399,7 @@ int sfm_pair_create(sfm_ctx *ctx, const float h_K[9], const float h_Kinv[9], int
     auto A = [&](auto **ptr, size_t count) { if (rc == SFM_OK) rc = dev_alloc(ptr, count); };
     A(&p->d_K, 9); A(&p->d_Kinv, 9);
     for (int i = 0; i < 2; ++i) { A(&p->d_U[i], (size_t)3 * p->ld); A(&p->d_X[i], (size_t)3 * p->ld); }
+    A(&p->d_pts4, (size_t)p->ld);
     A(&p->d_E, 9); A(&p->d_P, 64); A(&p->d_Pinv, 64); A(&p->d_Pind, 8);
     A(&p->d_points, (size_t)4 * num_points);
     A(&p->d_mask, (size_t)num_points);
@@ -434,7 +435,7 @@ int sfm_pair_destroy(sfm_pair *p)
 {
     if (!p) return SFM_OK;
     if (p->ctx) { (void)hipSetDevice(p->ctx->device); (void)hipStreamSynchronize(p->ctx->stream); }
-    void *bufs[] = { p->d_K, p->d_Kinv, p->d_U[0], p->d_U[1], p->d_X[0], p->d_X[1], p->d_E, p->d_P, p->d_Pinv, p->d_Pind,
+    void *bufs[] = { p->d_K, p->d_Kinv, p->d_U[0], p->d_U[1], p->d_X[0], p->d_X[1], p->d_pts4, p->d_E, p->d_P, p->d_Pinv, p->d_Pind,
                      p->d_points, p->d_mask, p->d_key, p->d_best, p->d_counts, p->d_Ecand, p->d_clk, p->d_tick,
                      p->alt_counts, p->alt_Ecand, p->alt_tick, p->alt_key };
     for (void *b : bufs) if (b) (void)hipFree(b);
@@ -458,6 +459,7 @@ int sfm_fill_xu(sfm_pair *pair, const sfm_sift_point *d_data)
         // X_z = fma(Kinv[8], 1, fma(Kinv[7], y, Kinv[6] * x)) is exactly 1 for finite pixel coordinates when
         // the last row of K^-1 is (0 0 1): the scoring kernel may then drop z (ransac_device.hpp)
         pair->unit_z = pair->h_Kinv[6] == 0.0f && pair->h_Kinv[7] == 0.0f && pair->h_Kinv[8] == 1.0f;
+        pair->have_pts4 = pair->unit_z;     // fill_xu_kernel wrote the (x1x, x1y, x2x, x2y) records; they stand for the points when every z is 1
     }
     return rc;
 }
@@ -468,7 +470,7 @@ int sfm_set_points(sfm_pair *pair, const float *d_X0, const float *d_X1)
     if (pair->pipe_pending) { const int rcf = sfm_pair_flush(pair); if (rcf != SFM_OK) return rcf; }
     SFM_HIP_TRY(hipSetDevice(pair->ctx->device));
     int rc = launch_set_points(pair, d_X0, d_X1);
-    if (rc == SFM_OK) { pair->have_points = true; pair->have_E = pair->have_P = pair->have_pose = pair->have_points3d = false; pair->last_count = 0; pair->unit_z = false; }
+    if (rc == SFM_OK) { pair->have_points = true; pair->have_E = pair->have_P = pair->have_pose = pair->have_points3d = false; pair->last_count = 0; pair->unit_z = false; pair->have_pts4 = false; }
     return rc;
 }
 

@@ -98,6 +98,8 @@ struct sfm_pair {
     float *d_K = nullptr, *d_Kinv = nullptr;
     float *d_U[2] = { nullptr, nullptr };
     float *d_X[2] = { nullptr, nullptr };
+    float4 *d_pts4 = nullptr;          // (x1x, x1y, x2x, x2y) per correspondence, written by fillXU: ONE 16-byte gather per sampled point
+    bool have_pts4 = false;            // d_pts4 describes the current points (fillXU with the unit-z layout)
     float *d_E = nullptr;              // 9
     float *d_P = nullptr;              // 4 x 16 candidates
     float *d_Pinv = nullptr;           // 4 x 16 inverses

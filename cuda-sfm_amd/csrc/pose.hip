@@ -17,7 +17,7 @@ namespace sfm {
 __global__ __launch_bounds__(256)
 void fill_xu_kernel(const sfm_sift_point *__restrict__ data, int n, int ld, const float *__restrict__ kinv,
                     float *__restrict__ U0, float *__restrict__ U1, float *__restrict__ X0, float *__restrict__ X1,
-                    unsigned long long *__restrict__ key)
+                    unsigned long long *__restrict__ key, float4 *__restrict__ pts4)
 {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j == 0) { key[0] = 0ull; key[1] = 0ull; }           // the estimateE that follows finds its arg-max key cleared: no memset launch
@@ -42,6 +42,7 @@ void fill_xu_kernel(const sfm_sift_point *__restrict__ data, int n, int ld, cons
         X0[(size_t)r * ld + j] = x0[r];
         X1[(size_t)r * ld + j] = x1[r];
     }
+    pts4[j] = make_float4(x0[0], x0[1], x1[0], x1[1]);        // the sampler's view of a correspondence: one 16-byte gather (ransac.hip)
 }
 
 __global__ __launch_bounds__(256)
@@ -265,7 +266,7 @@ int launch_pose_chain(sfm_pair *pair, float *d_record)
 int launch_fill_xu(sfm_pair *pair, const sfm_sift_point *d_data)
 {
     hipLaunchKernelGGL(fill_xu_kernel, dim3((pair->ld + 255) / 256), dim3(256), 0, pair->ctx->stream,
-                       d_data, pair->n, pair->ld, pair->d_Kinv, pair->d_U[0], pair->d_U[1], pair->d_X[0], pair->d_X[1], pair->d_key);
+                       d_data, pair->n, pair->ld, pair->d_Kinv, pair->d_U[0], pair->d_U[1], pair->d_X[0], pair->d_X[1], pair->d_key, pair->d_pts4);
     SFM_HIP_TRY(hipGetLastError());
     return SFM_OK;
 }

@@ -52,13 +52,54 @@ void ransac_solve_lanes(const float *__restrict__ X0, const float *__restrict__ 
     for (int k = 0; k < 9; ++k) Ecand[9 * (size_t)i + k] = E[k];
 }
 
+// One hypothesis per lane, Householder solver only (the scalar instantiation of the same templates: bit-identical).  Half the
+// registers of the packed kernel below, so twice the hypotheses are in flight per SIMD and every wavefront walks a chain of plain
+// (not packed) instructions: the latency-bound regime -- shards of up to a few hundred thousand hypotheses, where the packed
+// kernel is one wavefront per SIMD stepping through ~4900 dependent instructions.
+__global__ __launch_bounds__(64)
+void ransac_solve_lanes1_qr(const float *__restrict__ X0, const float *__restrict__ X1, int ld, int n,
+                            const int32_t *__restrict__ indices, uint32_t seed, uint32_t h0, uint32_t count,
+                            int sweeps, float *__restrict__ Ecand, unsigned long long *zero_key, unsigned long long *zero_key2,
+                            int *__restrict__ zero_counts, uint32_t *__restrict__ zero_ticks, const float4 *__restrict__ pts4)
+{
+    reset_keys(zero_key, zero_key2);
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (zero_ticks && i < (count + 63u) / 64u) zero_ticks[i] = 0u;
+    if (i >= count) return;
+    if (zero_counts) zero_counts[i] = 0;
+    int idx[8];
+    load_tuple(indices, seed, h0 + i, n, idx);
+    float x1[8][3], x2[8][3];
+    if (pts4) {                                             // unit-z points as 16-byte records: 8 gathers instead of 48
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float4 q = pts4[idx[k]];
+            x1[k][0] = q.x; x1[k][1] = q.y; x1[k][2] = 1.0f;
+            x2[k][0] = q.z; x2[k][1] = q.w; x2[k][2] = 1.0f;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                x1[k][a] = X0[(size_t)a * ld + idx[k]];
+                x2[k][a] = X1[(size_t)a * ld + idx[k]];
+            }
+    }
+    float E[9];
+    nullvec9_householder(x1, x2, E);
+    normalize_E(E);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) Ecand[9 * (size_t)i + k] = E[k];
+}
+
 // Two hypotheses per lane (2i, 2i+1): every mul / add / fma of the solver is a v_pk_*_f32.
 template <bool QR>
 __global__ __launch_bounds__(64)
 void ransac_solve_lanes2(const float *__restrict__ X0, const float *__restrict__ X1, int ld, int n,
                          const int32_t *__restrict__ indices, uint32_t seed, uint32_t h0, uint32_t count,
                          int sweeps, float *__restrict__ Ecand, unsigned long long *zero_key, unsigned long long *zero_key2,
-                         int *__restrict__ zero_counts, uint32_t *__restrict__ zero_ticks)
+                         int *__restrict__ zero_counts, uint32_t *__restrict__ zero_ticks, const float4 *__restrict__ pts4)
 {
     reset_keys(zero_key, zero_key2);
     const uint32_t i = 2u * (blockIdx.x * blockDim.x + threadIdx.x);
@@ -67,7 +108,7 @@ void ransac_solve_lanes2(const float *__restrict__ X0, const float *__restrict__
     const uint32_t j = (i + 1 < count) ? i + 1 : i;         // odd count: the last lane solves its hypothesis twice
     if (zero_counts) { zero_counts[i] = 0; zero_counts[j] = 0; }   // tile-parallel scoring accumulates into counts[] with atomics
     v2f E[9];
-    solve_two<QR>(X0, X1, ld, n, indices, seed, h0 + i, h0 + j, sweeps, E);
+    solve_two<QR>(X0, X1, ld, n, indices, seed, h0 + i, h0 + j, sweeps, E, pts4);
 #pragma unroll
     for (int k = 0; k < 9; ++k) Ecand[9 * (size_t)i + k] = E[k].x;
     if (j != i) {
@@ -254,6 +295,13 @@ static int launch_score_t(sfm_pair *pair, uint32_t h0, uint32_t count, float thr
     return SFM_OK;
 }
 
+// Householder solve: one hypothesis per lane (64 VGPRs, eight wavefronts per SIMD) whenever the points are available as 16-byte
+// records, and up to this many hypotheses otherwise; two per lane (packed) for large generic-z shards.  Measured
+// (profiles/r02_solve_lanes_ab.txt, 4096 points, us per launch at 4096 / 131072 / 2^20 hypotheses): packed + scattered gathers
+// 18.7 / 33.8 / 139, packed + records 17.5 / 27.2 / 96.8, scalar + records 12.5 / 23.2 / 93.7.  reserved[0]: 2 = packed,
+// 3 = scalar, 4 = scattered gathers (A/B).
+constexpr uint32_t kScalarSolveMax = 262144u;
+
 int launch_ransac_score(sfm_pair *pair, const sfm_ransac_params &p, uint32_t h0, uint32_t count, unsigned long long *key2, const float *d_E_given)
 {
     sfm_ctx *ctx = pair->ctx;
@@ -313,6 +361,7 @@ int launch_ransac_score(sfm_pair *pair, const sfm_ransac_params &p, uint32_t h0,
     hipEvent_t *tev = timed ? ctx->tev[ctx->tcount] : nullptr;
     if (timed) SFM_HIP_TRY(hipEventRecord(tev[0], ctx->stream));
     int *zero_counts = (grid2d || prefilter) ? pair->d_counts : nullptr;
+    const float4 *pts4 = (pair->have_pts4 && p.reserved[0] != 4) ? pair->d_pts4 : nullptr;      // (reserved[0] == 4: scattered gathers, A/B)
     if (d_E_given) {                 // caller-supplied candidates (sfm_ransac_score_candidates): no solve, clear what it would have cleared
         SFM_HIP_TRY(hipMemcpyAsync(pair->d_Ecand, d_E_given, (size_t)count * 9 * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
         if (zero_counts) SFM_HIP_TRY(hipMemsetAsync(pair->d_counts, 0, (size_t)count * sizeof(int), ctx->stream));
@@ -322,14 +371,18 @@ int launch_ransac_score(sfm_pair *pair, const sfm_ransac_params &p, uint32_t h0,
         hipLaunchKernelGGL(ransac_solve_lanes, dim3((count + 63) / 64), dim3(64), 0, ctx->stream,
                            pair->d_X[0], pair->d_X[1], pair->ld, pair->n, p.d_indices, p.seed, h0, count,
                            p.jacobi_sweeps, pair->d_Ecand, pair->d_key, key2, zero_counts, prefilter ? pair->d_tick : nullptr);
+    else if (p.jacobi_sweeps <= 0 && (p.reserved[0] == 3 || (p.reserved[0] == 0 && (pts4 != nullptr || count <= kScalarSolveMax))))     // one hypothesis per lane
+        hipLaunchKernelGGL(ransac_solve_lanes1_qr, dim3((count + 63) / 64), dim3(64), 0, ctx->stream,
+                           pair->d_X[0], pair->d_X[1], pair->ld, pair->n, p.d_indices, p.seed, h0, count,
+                           p.jacobi_sweeps, pair->d_Ecand, pair->d_key, key2, zero_counts, prefilter ? pair->d_tick : nullptr, pts4);
     else if (p.jacobi_sweeps <= 0)   // default: two hypotheses per lane (packed math), Householder instantiation
         hipLaunchKernelGGL(ransac_solve_lanes2<true>, dim3((count + 127) / 128), dim3(64), 0, ctx->stream,
                            pair->d_X[0], pair->d_X[1], pair->ld, pair->n, p.d_indices, p.seed, h0, count,
-                           p.jacobi_sweeps, pair->d_Ecand, pair->d_key, key2, zero_counts, prefilter ? pair->d_tick : nullptr);
+                           p.jacobi_sweeps, pair->d_Ecand, pair->d_key, key2, zero_counts, prefilter ? pair->d_tick : nullptr, pts4);
     else
         hipLaunchKernelGGL(ransac_solve_lanes2<false>, dim3((count + 127) / 128), dim3(64), 0, ctx->stream,
                            pair->d_X[0], pair->d_X[1], pair->ld, pair->n, p.d_indices, p.seed, h0, count,
-                           p.jacobi_sweeps, pair->d_Ecand, pair->d_key, key2, zero_counts, prefilter ? pair->d_tick : nullptr);
+                           p.jacobi_sweeps, pair->d_Ecand, pair->d_key, key2, zero_counts, prefilter ? pair->d_tick : nullptr, pts4);
     SFM_HIP_TRY(hipGetLastError());
     if (timed) SFM_HIP_TRY(hipEventRecord(tev[1], ctx->stream));
 

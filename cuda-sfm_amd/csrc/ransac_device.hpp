@@ -48,12 +48,22 @@ __device__ __forceinline__ void solve_one(const float *__restrict__ X0, const fl
 template <bool QR = false>
 __device__ __forceinline__ void solve_two(const float *__restrict__ X0, const float *__restrict__ X1, int ld, int n,
                                           const int32_t *__restrict__ indices, uint32_t seed, uint32_t hypA, uint32_t hypB,
-                                          int sweeps, v2f E[9])
+                                          int sweeps, v2f E[9], const float4 *__restrict__ pts4 = nullptr)
 {
     int ia[8], ib[8];
     load_tuple(indices, seed, hypA, n, ia);
     load_tuple(indices, seed, hypB, n, ib);
     v2f x1[8][3], x2[8][3];
+    if (pts4) {
+        // unit-z points as 16-byte records: 16 gathers per pair of hypotheses instead of 96 scattered dwords (the texture
+        // addresser handles one address per lane and instruction: 2^20 hypotheses were 84 us of it per CU)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float4 qa = pts4[ia[k]], qb = pts4[ib[k]];
+            x1[k][0] = v2f{ qa.x, qb.x }; x1[k][1] = v2f{ qa.y, qb.y }; x1[k][2] = v2f{ 1.0f, 1.0f };
+            x2[k][0] = v2f{ qa.z, qb.z }; x2[k][1] = v2f{ qa.w, qb.w }; x2[k][2] = v2f{ 1.0f, 1.0f };
+        }
+    } else {
 #pragma unroll
     for (int k = 0; k < 8; ++k)
 #pragma unroll
@@ -61,6 +71,7 @@ __device__ __forceinline__ void solve_two(const float *__restrict__ X0, const fl
             x1[k][a] = v2f{ X0[(size_t)a * ld + ia[k]], X0[(size_t)a * ld + ib[k]] };
             x2[k][a] = v2f{ X1[(size_t)a * ld + ia[k]], X1[(size_t)a * ld + ib[k]] };
         }
+    }
     if (QR) nullvec9_householder(x1, x2, E);
     else nullvec9(x1, x2, sweeps, E);
     normalize_E(E);
