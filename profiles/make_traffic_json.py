@@ -13,7 +13,7 @@ for block in re.split(r"\n(?=sfm::)", text):
         continue
     vals = {m.group(1): float(m.group(2)) for m in re.finditer(r"^\s+(\w+)\s+(\d+) per launch", block, re.M)}
     key = name.split("<")[0]
-    if key not in ("ransac_score_prefilter", "ransac_solve_lanes2", "ransac_score_waves"):
+    if key not in ("ransac_score_prefilter", "ransac_solve_lanes2", "ransac_solve_lanes1_qr", "ransac_score_waves"):
         continue
     e = {"matches": 4096, "hypotheses": 1 << 20, "fetch_kb": vals.get("FETCH_SIZE"), "write_kb": vals.get("WRITE_SIZE"),
          "valu_insts_per_launch": vals.get("SQ_INSTS_VALU")}
