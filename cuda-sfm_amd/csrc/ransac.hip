@@ -48,7 +48,8 @@ void ransac_solve_lanes(const float *__restrict__ X0, const float *__restrict__ 
     if (zero_counts) zero_counts[i] = 0;                    // tile-parallel scoring accumulates into counts[] with atomics
     float E[9];
     solve_one(X0, X1, ld, n, indices, seed, h0 + i, sweeps, E);
-    store_E9(Ecand + 9 * (size_t)i, E);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) Ecand[9 * (size_t)i + k] = E[k];
 }
 
 // One hypothesis per lane, Householder solver only (the scalar instantiation of the same templates: bit-identical).  Half the
@@ -88,7 +89,8 @@ void ransac_solve_lanes1_qr(const float *__restrict__ X0, const float *__restric
     float E[9];
     nullvec9_householder(x1, x2, E);
     normalize_E(E);
-    store_E9(Ecand + 9 * (size_t)i, E);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) Ecand[9 * (size_t)i + k] = E[k];
 }
 
 // Two hypotheses per lane (2i, 2i+1): every mul / add / fma of the solver is a v_pk_*_f32.
@@ -107,11 +109,12 @@ void ransac_solve_lanes2(const float *__restrict__ X0, const float *__restrict__
     if (zero_counts) { zero_counts[i] = 0; zero_counts[j] = 0; }   // tile-parallel scoring accumulates into counts[] with atomics
     v2f E[9];
     solve_two<QR>(X0, X1, ld, n, indices, seed, h0 + i, h0 + j, sweeps, E, pts4);
-    float Ea[9], Eb[9];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) { Ea[k] = E[k].x; Eb[k] = E[k].y; }
-    store_E9(Ecand + 9 * (size_t)i, Ea);
-    if (j != i) store_E9(Ecand + 9 * (size_t)j, Eb);
+    for (int k = 0; k < 9; ++k) Ecand[9 * (size_t)i + k] = E[k].x;
+    if (j != i) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) Ecand[9 * (size_t)j + k] = E[k].y;
+    }
 }
 
 // ------------------------------------------------------------------------------------------

@@ -42,21 +42,6 @@ __device__ __forceinline__ void solve_one(const float *__restrict__ X0, const fl
     normalize_E(E);
 }
 
-// A candidate matrix is nine floats at a 36-byte stride: as three 12-byte accesses (global_load / store_dwordx3, 4-byte
-// aligned) instead of nine dwords -- a third of the addresses the texture addresser has to walk per wavefront.
-struct __attribute__((packed, aligned(4))) Tri { float a, b, c; };
-__device__ __forceinline__ void store_E9(float *__restrict__ dst, const float (&E)[9])
-{
-    reinterpret_cast<Tri *>(dst)[0] = Tri{ E[0], E[1], E[2] };
-    reinterpret_cast<Tri *>(dst)[1] = Tri{ E[3], E[4], E[5] };
-    reinterpret_cast<Tri *>(dst)[2] = Tri{ E[6], E[7], E[8] };
-}
-__device__ __forceinline__ void load_E9(const float *__restrict__ src, float (&e)[9])
-{
-    const Tri t0 = reinterpret_cast<const Tri *>(src)[0], t1 = reinterpret_cast<const Tri *>(src)[1], t2 = reinterpret_cast<const Tri *>(src)[2];
-    e[0] = t0.a; e[1] = t0.b; e[2] = t0.c; e[3] = t1.a; e[4] = t1.b; e[5] = t1.c; e[6] = t2.a; e[7] = t2.b; e[8] = t2.c;
-}
-
 // Two hypotheses per lane through the packed (v2f) instantiation of the solver: element 0 = hypA,
 // element 1 = hypB.  Bit-identical per hypothesis to solve_one.
 // QR = true instantiates the Householder solver only (no Jacobi code, a third of its registers); false dispatches on sweeps.

@@ -129,7 +129,9 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
     float e_first[9];
     {
         const uint32_t hf = min(ps_first, npass - 1u) * 64u;
-        load_E9(Ecand + 9 * (size_t)(hf + (uint32_t)min(lane, (int)min(64u, count - hf) - 1)), e_first);
+        const float *src = Ecand + 9 * (size_t)(hf + (uint32_t)min(lane, (int)min(64u, count - hf) - 1));
+#pragma unroll
+        for (int k = 0; k < 9; ++k) e_first[k] = src[k];
     }
     // ... and parked in the wavefront's own LDS area (64 x 9 floats = exactly the E table + counters + ring, all unused
     // until the first pass starts) so that they do not occupy registers while the tile is staged
@@ -216,7 +218,9 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
 #pragma unroll
             for (int k = 0; k < 9; ++k) e[k] = park[k * 64 + lane];
         } else {
-            load_E9(Ecand + 9 * (size_t)(h_first + (uint32_t)min(lane, nvalid64 - 1)), e);
+            const float *src = Ecand + 9 * (size_t)(h_first + (uint32_t)min(lane, nvalid64 - 1));
+#pragma unroll
+            for (int k = 0; k < 9; ++k) e[k] = src[k];
         }
         // zero divisors (prefilter_math.hpp (3)): nearly every hypothesis is cleared by its 2 x 2 cells; the rest
         // (~0.5 %) is checked against every point of the tile, one hypothesis at a time by the whole wavefront
