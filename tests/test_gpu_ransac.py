@@ -394,3 +394,34 @@ def test_finalize_from_a_key_that_names_no_hypothesis(gpu):
         pair.get_best()
     pair.estimateE(p)                                          # and the pair is still usable
     assert pair.get_best()[0] < 10
+
+
+@pytest.mark.parametrize("n,H", [(1000, 3000), (4096, 20000), (700, 300001)])
+def test_lane_solve_variants_give_the_oracle_candidates(gpu, n, H):
+    """The lane-solve kernel's arrangements -- one hypothesis per lane with the sampled points gathered as 16-byte records (the
+    default after fillXU), two per lane (packed), scattered dword gathers, the solver-agnostic scalar kernel; with fillXU's
+    unit-z points and with sfm_set_points (no records) -- must all produce the oracle's E for every hypothesis, bit for bit."""
+    torch, dev, ctx = gpu
+    scene = synth.two_view_scene(n, seed=300 + n)
+    pair, _ = make_pair(S, gpu, scene)
+    _, _, X0, X1 = O.fill_xu(scene["sift"], scene["Kinv"])
+    Hs = min(H, 2048)                                           # oracle candidates for the head and the tail of the range
+    _, _, e_head = O.ransac_range(X0, X1, 0, Hs, 1e-6, 0, seed=9, want_E=True)
+    _, _, e_tail = O.ransac_range(X0, X1, H - Hs, Hs, 1e-6, 0, seed=9, want_E=True)
+    cands = {}
+    for variant in (0, 2, 3, 4, 1):
+        p = S.default_params(n, num_hypotheses=H, seed=9, kernel=S.KERNEL_SPLIT)
+        p.reserved[0] = variant
+        pair.ransac_score(p)
+        cands[variant] = pair.get_E_candidates(H).reshape(H, 9).copy()
+        assert same_bits(cands[variant][:Hs], e_head.reshape(Hs, 9)) and same_bits(cands[variant][H - Hs:], e_tail.reshape(Hs, 9)), variant
+    for variant in (2, 3, 4, 1):
+        assert same_bits(cands[variant], cands[0]), variant
+    # no records: pre-normalised points through sfm_set_points (generic z), same coordinates
+    d0, d1 = to_dev(torch, dev, np.ascontiguousarray(X0[:, :n])), to_dev(torch, dev, np.ascontiguousarray(X1[:, :n]))
+    pair.set_points(d0, d1)
+    for variant in (0, 2, 3):
+        p = S.default_params(n, num_hypotheses=H, seed=9, kernel=S.KERNEL_SPLIT)
+        p.reserved[0] = variant
+        pair.ransac_score(p)
+        assert same_bits(pair.get_E_candidates(H).reshape(H, 9), cands[0]), ("set_points", variant)
