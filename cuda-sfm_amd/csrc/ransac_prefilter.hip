@@ -427,9 +427,11 @@ int launch_score_prefilter(sfm_pair *pair, const sfm_ransac_params &p, uint32_t 
     if (rc_lds != SFM_OK) return rc_lds;
     const int ntiles = (pair->ld + kPfTile - 1) / kPfTile;
     const uint32_t iters = (count + 64u * kPfWaves - 1) / (64u * kPfWaves);       // 1024-hypothesis block iterations per tile
-    // one block per CU is resident (156 KiB of LDS) and staging a tile is not overlapped with anything, so few, long
-    // blocks: about two per CU (measured on 2^20 x 4096: 1.39 ms with 256 blocks, 1.41 with 512, 1.47 with 1024, 1.63 with 4096)
-    uint32_t cols = (uint32_t)(2 * ctx->num_cus + ntiles - 1) / (uint32_t)ntiles;
+    // one block per CU is resident (148 KiB of LDS) and staging a tile is not overlapped with anything, so few, long blocks:
+    // ONE per CU up to four tiles (2^20 x 4096: 0.586 ms against 0.595 with two per CU, 131072 x 4096: 0.097 against 0.105),
+    // two per CU above (16 tiles, 16384 points: 2.27 against 2.31 ms at 2^20 hypotheses) -- profiles/r02_grid_ab.txt
+    const uint32_t per_cu = ntiles <= 4 ? 1u : 2u;
+    uint32_t cols = (per_cu * (uint32_t)ctx->num_cus + (uint32_t)ntiles - 1) / (uint32_t)ntiles;
     if (p.reserved[2] > 0) cols = (uint32_t)p.reserved[2];
     if (cols > iters) cols = iters;
     if (cols < 1) cols = 1;
