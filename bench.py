@@ -12,14 +12,31 @@ invocations (--warmup 3) do not time the clock ramp; the timed region is exactly
 
 `python bench.py --gpus N` with N > 1 and no RANK in the environment launches the N ranks itself: the parent process
 (which never imports torch and never touches HIP) starts one child per GPU with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*
-set, relays rank 0's JSON line and exits non-zero if any child fails.
+set, relays rank 0's JSON line and exits non-zero as soon as any child fails.
+
+What the line carries besides the contract's keys:
+  result.parity_vs_oracle   N = 1: EVERY inlier count of the step's H hypotheses, the arg-max key (first maximum), the winner's
+                            E (bit for bit) and the inlier mask against the CPU oracle (oracle/ is the checker, never the path).
+                            N > 1: every rank must report nccl_ranks == N and the same (key, E, mask) -- else exit code 1.
+  roofline                  for the kernel that ran.  The matrix-core pre-filter kernel is priced against its own issue floor
+                            (frac <= 1 by construction); the SURVEY 8(d) figure (38 FLOP per pair) stays as
+                            `algorithmic_equiv_tflops`.  Counter figures are QUOTED from profiles/<round>_traffic.json and only
+                            when the hash of the kernel sources recorded there equals the hash of the sources in this tree.
+  cpu_baseline              the oracle's vectorised port on the host cores, bounded sample (its first H hypotheses double as
+                            the parity check above).
+  extra                     N = 1 only, short runs of the other BASELINE configurations so that each has a clock from the same
+                            invocation: c3, c4 (one GPU), the share of one of eight ranks, the descriptor matcher at 2048^2 and
+                            16384^2, the dino pair end to end (configs[1]) and the 36-view dino ring / all 630 pairs
+                            (configs[4]), each with its own parity boolean.  --no-extra skips them.
 """
 import argparse
+import hashlib
 import json
 import os
 import socket
 import subprocess
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -28,22 +45,32 @@ sys.path.insert(0, ROOT)
 N_MATCHES = 4096              # "4k matches" of the BASELINE metric
 TOTAL_HYPS = 1 << 20          # hypotheses per step over the whole job (BASELINE configs[3] count)
 FP32_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: 256 CU x 256 FLOP/clk x 2.4 GHz
+FP16_MFMA_PEAK_TFLOPS = 2516.6  # dense fp16 MFMA: 256 CU x 4096 FLOP/clk x 2.4 GHz (MI355X_MICROARCH.md, no sparsity)
 PEAK_CLOCK_MHZ = 2400.0
+NUM_SIMDS = 1024              # 256 CU x 4
 FLOP_PER_POINT = 38           # residual of one (hypothesis, point)
 FLOP_PER_HYP = 720            # A^T A normal equations
+# ransac_score_prefilter, per (hypothesis, point) pair, what cannot be removed from this formulation:
+PF_SCAN_VALU_PER_PAIR = 2     # v_fma_f32 (G - nt^2) + v_alignbit_b32 (its sign bit into the lane's mask)
+PF_MFMA_PER_1024_PAIRS = 3    # v_mfma_f32_32x32x16_f16: G (16 k-slots) + nt (32 k-slots)
+PF_MFMA_CYCLES = 32           # issue interval of one 32x32x16 f16 MFMA on a SIMD (8 passes x 4 cycles; profiles/r02_mfma_rate_probe.txt)
+PF_SOURCES = ("ransac_prefilter.hip", "prefilter_math.hpp", "ransac.hip", "ransac_device.hpp", "device_math.hpp")
+TRAFFIC_JSON = os.path.join("profiles", "r03_traffic.json")
+PUBLISHED_ESTIMATE_E_MS = 24.12     # img/data.xlsx B5 / README.md:54 of the reference: estimateE on the dino pair, GTX 1080 Ti
 
-# BASELINE.json configs that are RANSAC workloads (configs[1] and [4] are pipelines: profiles/pipeline_bench.py, ring_bench.py)
+# BASELINE.json configs that are RANSAC workloads (configs[1] and [4] are pipelines: see `extra`)
 CONFIGS = {
     "headline": (N_MATCHES, TOTAL_HYPS, "the metric's '4k matches' configuration"),
     "c3": (16384, 65536, "BASELINE configs[2]: synthetic 16k-match pair, 65k hypotheses"),
     "c4": (16384, 1 << 20, "BASELINE configs[3]: synthetic 16k matches, 1M hypotheses (sharded over --gpus)"),
 }
+KERNEL_NAMES = {1: "ransac_score_waves", 2: "ransac_fused_waves", 3: "ransac_score_mfma", 4: "ransac_score_prefilter"}
 
 
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)     # 100 x 2 ms: long enough for the clocks to settle (20 steps read 4 % slower)
+    ap.add_argument("--steps", type=int, default=100)     # 100 x 0.6 ms: long enough for the clocks to settle (20 steps read 4 % slower)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", choices=sorted(CONFIGS), default="headline")
     ap.add_argument("--matches", type=int, default=None, help="overrides the preset's match count")
@@ -59,8 +86,10 @@ def parse_args(argv=None):
                     help="one estimateE at a time (sfm_estimate_E / sfm_estimate_E_sharded) instead of the two-slot pipelined calls "
                          "(sfm_estimate_E_pipelined / sfm_estimate_E_sharded_pipelined) in which consecutive steps overlap on the device")
     ap.add_argument("--reserved", type=int, nargs="*", default=[], help="sfm_ransac_params.reserved[] A/B switches (profiles/)")
-    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg (and with it the full-oracle parity check)")
     ap.add_argument("--no-variants", action="store_true", help="skip the short run with the other null-vector solver")
+    ap.add_argument("--no-extra", action="store_true", help="skip the short runs of the other BASELINE configurations")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU time budget of the cpu_baseline sample")
     return ap.parse_args(argv)
 
 
@@ -87,7 +116,9 @@ def free_port():
 
 def launch_ranks(n, argv, env_extra=None, command=None, timeout=3600.0):
     """Starts n child processes of this script (or of `command`), one per rank, and relays rank 0's stdout.
-    Returns the exit code for the parent: 0 only if every rank exited 0."""
+    Returns the exit code for the parent: 0 only if every rank exited 0.  The children are polled: the first rank that
+    exits non-zero ends the job at once (the others, possibly blocked in a collective that can no longer complete, are
+    terminated) instead of leaving the launcher waiting for the time-out."""
     port = free_port()
     procs = []
     for r in range(n):
@@ -99,25 +130,38 @@ def launch_ranks(n, argv, env_extra=None, command=None, timeout=3600.0):
             env.update(env_extra)
         cmd = command if command is not None else [sys.executable, os.path.abspath(__file__)] + list(argv)
         procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0)))
+    out0 = []
+    drain = threading.Thread(target=lambda: out0.extend(procs[0].stdout.readlines()), daemon=True)   # keeps rank 0's pipe from filling up
+    drain.start()
     deadline = time.time() + timeout
     rc = 0
-    out0 = ""
-    try:
-        out0, _ = procs[0].communicate(timeout=max(1.0, deadline - time.time()))
-        for p in procs[1:]:
-            p.wait(timeout=max(1.0, deadline - time.time()))
-    except subprocess.TimeoutExpired:
-        rc = 124
+    while True:
+        codes = [p.poll() for p in procs]
+        failed = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+        if failed:
+            r, c = failed[0]
+            print(f"bench.py: rank {r} exited with code {c}; stopping the other ranks", file=sys.stderr)
+            rc = c if c > 0 else 1
+            break
+        if all(c == 0 for c in codes):
+            break
+        if time.time() > deadline:
+            print(f"bench.py: time-out after {timeout:.0f} s", file=sys.stderr)
+            rc = 124
+            break
+        time.sleep(0.2)
     for r, p in enumerate(procs):
-        if p.poll() is None:                      # still running: a rank hung after another one failed / timed out
-            p.kill()                              # exactly the PIDs started above
-            p.wait()
+        if p.poll() is None:                      # exactly the PIDs started above
+            p.terminate()
+            try:
+                p.wait(timeout=5)
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
             rc = rc or 125
-        elif p.returncode != 0:
-            print(f"bench.py: rank {r} exited with code {p.returncode}", file=sys.stderr)
-            rc = rc or (p.returncode if p.returncode > 0 else 1)
-    for line in (out0 or "").splitlines():        # library banners (gloo / RCCL print to stdout) go to stderr: stdout carries the JSON line only
-        (sys.stdout if line.lstrip().startswith("{") else sys.stderr).write(line + "\n")
+    drain.join(timeout=5)
+    for line in out0:                             # library banners (gloo / RCCL print to stdout) go to stderr: stdout carries the JSON line only
+        (sys.stdout if line.lstrip().startswith("{") else sys.stderr).write(line if line.endswith("\n") else line + "\n")
     sys.stdout.flush()
     return rc
 
@@ -131,18 +175,20 @@ def launcher_main(args, argv):
 
 
 # ------------------------------------------------------------------------------------------------------------------
-# CPU baseline (rank 0, N = 1 only)
+# CPU oracle (rank 0, N = 1 only): the baseline leg and the parity check share one sweep
 # ------------------------------------------------------------------------------------------------------------------
-def cpu_baseline(scene, params, n_matches, seconds=15.0):
-    """CPU port of the same algorithm on a bounded sample (oracle/: OpenMP over hypotheses; the scoring loop is the
-    vectorised division-free filter + exact fallback when the oracle exports it, else the scalar restatement)."""
-    import numpy as np
+def load_oracle():
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle as O
+    return O
+
+
+def cpu_baseline(O, X0, X1, params, n_matches, H, seconds):
+    """CPU port of the same algorithm on a bounded sample (oracle/: OpenMP over hypotheses; the scoring loop is the
+    vectorised division-free filter + exact fallback).  The sample STARTS with hypotheses 0..H-1, counts kept: that sweep
+    is also what the GPU's counts and arg-max key are compared with.  Returns (baseline dict, oracle key, oracle counts)."""
     avail = len(os.sched_getaffinity(0))
-    _, _, X0, X1 = O.fill_xu(scene["sift"], scene["Kinv"])
-    fast = hasattr(O, "ransac_range_fast")
-    run = O.ransac_range_fast if fast else O.ransac_range
+    run = O.ransac_range_fast
 
     def rate_of(threads, hyps):
         t0 = time.perf_counter()
@@ -157,25 +203,314 @@ def cpu_baseline(scene, params, n_matches, seconds=15.0):
         r = rate_of(threads, max(256, int(2000 * threads)))
         if r > rate:
             cores, rate = threads, r
-    sample = int(max(4096, min(256 * TOTAL_HYPS, rate * seconds)))    # ids beyond H are further hypotheses of the same scene
     t0 = time.perf_counter()
-    run(X0, X1, 0, sample, params.threshold, params.jacobi_sweeps, seed=params.seed, want_counts=False, nthreads=cores)
+    key, counts, _ = run(X0, X1, 0, H, params.threshold, params.jacobi_sweeps, seed=params.seed, want_counts=True, nthreads=cores)
     dt = time.perf_counter() - t0
+    sample = H
+    more = int(min(256 * TOTAL_HYPS, H / dt * max(0.0, seconds - dt)))      # ids beyond H are further hypotheses of the same scene
+    if more >= 4096:
+        t0 = time.perf_counter()
+        run(X0, X1, H, more, params.threshold, params.jacobi_sweeps, seed=params.seed, want_counts=False, nthreads=cores)
+        dt += time.perf_counter() - t0
+        sample += more
     out = {"value": sample / dt, "unit": "hypotheses/s", "cores": cores, "cpus_in_affinity_mask": avail, "kind": "port",
            "impl": ("oracle/sfm_oracle_fast.c: compiler-vectorised (AVX-512 / AVX2 by CPU) division-free filter + exact fallback, "
-                    "count-exact vs the scalar restatement (tests/test_oracle_fast.py)" if fast else "oracle/sfm_oracle.c: scalar restatement"),
-           "sample": f"hypotheses 0..{sample - 1} of the same {n_matches}-match scene, {dt:.1f} s, OpenMP x{cores}"}
-    # north_star also asks for OpenCV's cv::findEssentialMat (a 5-point solver: wall-time sanity, not a parity target)
+                    "count-exact vs the scalar restatement (tests/test_oracle_fast.py)"),
+           "sample": f"hypotheses 0..{sample - 1} of the same {n_matches}-match scene ({H} of them with counts kept for the parity check), "
+                     f"{dt:.1f} s, OpenMP x{cores}",
+           # north_star also names OpenCV's cv::findEssentialMat (a 5-point solver: wall-time sanity, not a parity target)
+           "opencv_findEssentialMat": "unavailable: OpenCV (cv2) is not installed in this image"}
     try:
-        import cv2
-        p1 = np.stack([scene["sift"]["xpos"], scene["sift"]["ypos"]], 1).astype(np.float64)
-        p2 = np.stack([scene["sift"]["match_xpos"], scene["sift"]["match_ypos"]], 1).astype(np.float64)
-        t0 = time.perf_counter()
-        _, m = cv2.findEssentialMat(p1, p2, scene["K"].astype(np.float64), cv2.RANSAC, 0.999, 1.0)
-        out["opencv_findEssentialMat"] = {"ms": 1e3 * (time.perf_counter() - t0), "inliers": int(m.sum()), "threads": cv2.getNumThreads()}
+        import cv2                                   # noqa: F401
+        out["opencv_findEssentialMat"] = "cv2 importable but not timed by this script"
     except ImportError:
-        out["opencv_findEssentialMat"] = "unavailable: OpenCV (cv2) is not installed in this image"
-    return out, (O, X0, X1)
+        pass
+    return out, key, counts
+
+
+def full_parity(O, X0, X1, params, n, okey, ocounts, gpu):
+    """gpu = (counts[H], key, E 3x3, mask) of ONE estimateE; okey / ocounts = the oracle's sweep of the same H hypotheses.
+    True iff every count, the key (arg-max, first maximum), the winner's E bit for bit and the mask agree."""
+    import numpy as np
+    counts, key, E, mask = gpu
+    ocnt, ohyp = O.unpack_key(okey)
+    if not (np.array_equal(counts, ocounts) and int(key) == int(okey)):
+        return False
+    if ocnt != int(ocounts.max()) or ohyp != int(np.argmax(ocounts)):       # the oracle's own key must be the first maximum
+        return False
+    oE = O.hypothesis_E(X0, X1, O.sample8(params.seed, ohyp, n), params.jacobi_sweeps)
+    c2, omask = O.count_inliers(oE, X0, X1, params.threshold)                # scalar restatement for the winner
+    return bool(c2 == ocnt and np.array_equal(omask, mask) and np.array_equal(oE.reshape(-1).view(np.uint32), np.ascontiguousarray(E, np.float32).reshape(-1).view(np.uint32)))
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# roofline of the scoring kernel
+# ------------------------------------------------------------------------------------------------------------------
+def source_hash():
+    h = hashlib.sha256()
+    for name in PF_SOURCES:
+        with open(os.path.join(ROOT, "cuda-sfm_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def quoted_counters(kname, n, local_hyps):
+    """Counter figures of the committed rocprofv3 --pmc passes -- quoted, not collected by this run, and only if they were
+    collected on the kernel sources of this tree (hash of PF_SOURCES recorded by profiles/make_traffic_json.py)."""
+    try:
+        with open(os.path.join(ROOT, TRAFFIC_JSON)) as f:
+            doc = json.load(f)
+        t = doc.get(kname)
+        if not t or t["matches"] != n or t["hypotheses"] != local_hyps:
+            return None, f"{TRAFFIC_JSON} has no entry for {kname} at {n} x {local_hyps}"
+        have = source_hash()
+        if doc.get("code_sha256_16") != have:
+            return None, (f"{TRAFFIC_JSON} was collected on kernel sources {doc.get('code_sha256_16')}, this tree has {have}: "
+                          "not quoted (re-run profiles/collect_r03.sh)")
+        t = dict(t)
+        t["source"] = f"{TRAFFIC_JSON} (rocprofv3 --pmc passes of this command on sources {have}; quoted, not collected by this run)"
+        return t, None
+    except (OSError, KeyError, ValueError) as e:
+        return None, f"{TRAFFIC_JSON}: {type(e).__name__}"
+
+
+def roofline_block(kernel_id, n, local_hyps, score_s, solve_s, clock_mhz, measured_in):
+    kname = KERNEL_NAMES.get(kernel_id, "?")
+    pairs = float(local_hyps) * n
+    alg_flops = pairs * FLOP_PER_POINT
+    alg_tflops = alg_flops / score_s / 1e12 if score_s > 0 else 0.0
+    quoted, why_not = quoted_counters(kname, n, local_hyps)
+    common = {"kernel": kname, "avg_launch_ms": 1e3 * score_s, "solve_kernel_avg_ms": 1e3 * solve_s, "measured_in": measured_in,
+              "shader_clock_mhz": clock_mhz, "pairs_per_launch": pairs,
+              "algorithmic_equiv_tflops": alg_tflops,
+              "algorithmic_equiv_note": "SURVEY 8(d): 38 FLOP per (hypothesis, point) pair over the launch time; the FP32 peak is 157.3 TFLOP/s",
+              "pipeline_algorithmic_equiv_tflops": (float(local_hyps) * (FLOP_PER_HYP + FLOP_PER_POINT * n)) / max(score_s + solve_s, 1e-12) / 1e12}
+    if kernel_id == 4:
+        clock = PEAK_CLOCK_MHZ * 1e6
+        valu_floor = pairs * PF_SCAN_VALU_PER_PAIR / 64.0 / NUM_SIMDS * 4.0 / clock
+        mfma_floor = pairs / 1024.0 * PF_MFMA_PER_1024_PAIRS * PF_MFMA_CYCLES / NUM_SIMDS / clock
+        floor = max(valu_floor, mfma_floor)
+        if valu_floor >= mfma_floor:
+            # one vector instruction-lane priced as one FMA slot (2 FLOP) of the plain (non-packed) FP32 vector rate
+            bound, peak = "valu_issue", FP32_PEAK_TFLOPS / 2.0
+            achieved = pairs * PF_SCAN_VALU_PER_PAIR * 2.0 / score_s / 1e12 if score_s > 0 else 0.0
+            detail = (f"vector-ALU issue: the irreducible scan is {PF_SCAN_VALU_PER_PAIR} vector instructions per pair (v_fma_f32 G - nt^2, v_alignbit_b32), "
+                      "each priced as one FMA lane-slot = 2 FLOP against the plain FP32 vector rate 78.65 TFLOP/s (1024 SIMDs x 16 lanes x 2 FLOP x 2.4 GHz); "
+                      "the three fp16 MFMAs per 1024 pairs issue next to it (mfma_floor_ms)")
+        else:
+            bound, peak = "mfma", FP16_MFMA_PEAK_TFLOPS
+            achieved = pairs / 1024.0 * PF_MFMA_PER_1024_PAIRS * 32768.0 / score_s / 1e12 if score_s > 0 else 0.0
+            detail = "fp16 MFMA issue: three v_mfma_f32_32x32x16_f16 (32768 FLOP each) per 1024 pairs"
+        out = {"bound": bound, "bound_detail": detail, "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+               "frac": (floor / score_s) if score_s > 0 else 0.0,
+               "valu_floor_ms": 1e3 * valu_floor, "mfma_floor_ms": 1e3 * mfma_floor,
+               "frac_at_sustained_clock": (floor / score_s * PEAK_CLOCK_MHZ / clock_mhz) if (score_s > 0 and clock_mhz > 0) else None}
+    else:
+        out = {"bound": "valu_fp32",
+               "bound_detail": ("FP32 vector ALU issue (v_pk_fma_f32 and friends); 157.3 TFLOP/s = 256 CU x 256 FLOP/clk x 2.4 GHz, "
+                                "numerically the dense f32 MFMA peak the bench contract prices compute against"),
+               "achieved": alg_tflops, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": alg_tflops / FP32_PEAK_TFLOPS,
+               "frac_at_sustained_clock": (alg_tflops / (FP32_PEAK_TFLOPS * clock_mhz / PEAK_CLOCK_MHZ)) if clock_mhz > 0 else None}
+    out.update(common)
+    if quoted:
+        out["traffic"] = 1024.0 * (quoted["fetch_kb"] + quoted["write_kb"])
+        out["traffic_source"] = quoted["source"]
+        out["traffic_algorithmic_bytes"] = float(local_hyps) * 36.0 * ((n + 1023) // 1024 if kernel_id == 4 else 1) + 4.0 * local_hyps
+        out["issue_profiled"] = {k: quoted[k] for k in ("valu_busy_frac", "mfma_busy_frac", "valu_insts_per_launch", "lds_bank_conflict_frac", "kernel_cycles") if k in quoted}
+    else:
+        out["traffic"] = None
+        out["traffic_source"] = why_not
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# extra: the other BASELINE configurations, short runs (rank 0, N = 1)
+# ------------------------------------------------------------------------------------------------------------------
+def extra_ransac(S, synth, O, ctx, dev, torch, np, name, n, H, steps, hyp_count=None):
+    """A short pipelined run of another RANSAC configuration + the full-oracle parity check of one call."""
+    scene = synth.two_view_scene(n)
+    d_sift = torch.from_numpy(scene["sift"].view(np.uint8).reshape(n, 576)).to(dev)
+    pair = S.ImagePair(ctx, scene["K"], scene["Kinv"], 2, n)
+    pair.fillXU(d_sift)
+    p = S.default_params(n, num_hypotheses=H)
+    if hyp_count is not None:
+        p.hyp_begin, p.hyp_count = 0, hyp_count
+    local = hyp_count if hyp_count is not None else H
+    for _ in range(5):
+        pair.estimateE_pipelined(p)
+    pair.flush(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        pair.estimateE_pipelined(p)
+    pair.flush(); torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    for _ in range(2):
+        pair.ransac_score(p)
+    ctx.synchronize()
+    ctx.kernel_timing(True)
+    for _ in range(5):
+        pair.ransac_score(p)
+    solve_ms, score_ms, calls = ctx.kernel_timing_read()
+    ctx.kernel_timing(False)
+    pair.estimateE(p)
+    launch = pair.last_launch()
+    got = (pair.get_inlier_counts(local).copy(), pair.get_key(), pair.get_E().copy(), pair.get_inlier_mask().copy())
+    hyp, cnt = pair.get_best()
+    out = {"matches": n, "hypotheses_per_step": local, "ms_per_step": 1e3 * dt, "hypotheses_per_s": local / dt, "steps": steps,
+           "kernel": KERNEL_NAMES.get(launch["kernel"], "?"), "score_kernel_ms": score_ms / max(calls, 1), "solve_kernel_ms": solve_ms / max(calls, 1),
+           "best_hypothesis": hyp, "inliers": cnt}
+    if launch["kernel"] == 4 and score_ms > 0:
+        r = roofline_block(4, n, local, score_ms / 1e3 / calls, solve_ms / 1e3 / calls, pair.last_clock_mhz(), "5 serial launches")
+        out["roofline_frac"] = r["frac"]
+    if O is not None:
+        _, _, X0, X1 = O.fill_xu(scene["sift"], scene["Kinv"])
+        t0 = time.perf_counter()
+        okey, ocounts, _ = O.ransac_range_fast(X0, X1, 0, local, p.threshold, p.jacobi_sweeps, seed=p.seed)
+        out["oracle_sweep_s"] = time.perf_counter() - t0
+        out["parity_vs_oracle"] = full_parity(O, X0, X1, p, n, okey, ocounts, got)
+    pair.close()
+    return out
+
+
+def extra_match(S, synth, O, ctx, dev, torch, np, n, reps):
+    d1, d2, perm = synth.descriptors(n)
+    t1, t2 = torch.from_numpy(d1).to(dev), torch.from_numpy(d2).to(dev)
+    best = torch.empty(n, dtype=torch.float32, device=dev); sec = torch.empty_like(best)
+    idx = torch.empty(n, dtype=torch.int32, device=dev)
+    ctx.set_match_kernel(S.MATCH_AUTO)
+    for _ in range(3):
+        ctx.match_soa(t2, n, 128, t1, n, 128, best, sec, idx)
+    torch.cuda.synchronize()
+    ctx.timer_start()
+    for _ in range(reps):
+        ctx.match_soa(t2, n, 128, t1, n, 128, best, sec, idx)
+    ms = ctx.timer_stop() / reps
+    ran = ctx.last_match_kernel()
+    res = (best.cpu().numpy().copy(), sec.cpu().numpy().copy(), idx.cpu().numpy().copy())
+    flops = 2.0 * n * n * 128
+    out = {"n": n, "ms": ms, "kernel": {S.MATCH_EXACT: "exact fp32 MFMA", S.MATCH_PREFILTER: "fp16 MFMA pre-filter + exact candidates"}.get(ran, str(ran)),
+           "algorithmic_tflops": flops / ms / 1e9, "perm_recovered": float((res[2] == perm).mean())}
+    if ran == S.MATCH_EXACT:
+        out["frac_of_fp32_mfma_peak"] = flops / ms / 1e9 / FP32_PEAK_TFLOPS
+    if O is not None:
+        # the CPU matcher restates MatchC1 (CudaSift/match.cu:57-71): all queries at 2048, the first 1024 queries at 16384
+        q = n if n <= 4096 else 1024
+        cb, cs, ci = O.match_desc(d2[:q], d1, nthreads=len(os.sched_getaffinity(0)))
+        out["parity_vs_oracle"] = bool(np.array_equal(ci, res[2][:q]) and np.array_equal(cb.view(np.uint32), res[0][:q].view(np.uint32)))
+        out["parity_queries_checked"] = q
+    return out
+
+
+def extra_dino(S, O, ctx, dev, torch, np):
+    """BASELINE configs[1] (dino pair: match + estimateE end to end, 1024 hypotheses) and configs[4] (36-view ring / all 630
+    pairs) on the reference's own frames (8-bit grey fixtures under tests/golden/dino)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import read_pnm_grey, dino_frame, DINO_K, DINO_KINV, DINO_SIFT
+    if not os.path.exists(dino_frame(35)):
+        return {"skipped": "tests/golden/dino fixtures not present"}
+    views = [read_pnm_grey(dino_frame(k)) for k in range(36)]
+    h, w = views[0].shape
+    pitch = (w + 127) // 128 * 128
+    out = {}
+
+    def extract(img):
+        pad = np.zeros((h, pitch), np.float32); pad[:, :w] = img
+        d_sift = torch.zeros((32768, 576), dtype=torch.uint8, device=dev)
+        n, _ = ctx.extract_sift(d_sift, 32768, torch.from_numpy(pad).to(dev), w, h, pitch, **DINO_SIFT)
+        return d_sift, n
+
+    def timed(fn, reps=50):
+        for _ in range(5):
+            fn()
+        ctx.synchronize()
+        ctx.timer_start()
+        for _ in range(reps):
+            fn()
+        return ctx.timer_stop() / reps
+
+    (s1, n1), (s2, n2) = extract(views[0]), extract(views[1])
+    pair = S.ImagePair(ctx, DINO_K, DINO_KINV, 2, n1)
+    p = S.default_params(n1, num_hypotheses=1024)               # configs[1]: "~2k matches, 1024 RANSAC hypotheses"
+    stage = {"match": timed(lambda: ctx.match(s1, n1, s2, n2)), "fillXU": timed(lambda: pair.fillXU(s1)),
+             "estimateE": timed(lambda: pair.estimateE(p)), "pose_chain": timed(lambda: pair.pose_chain())}
+
+    def end_to_end():
+        ctx.match(s1, n1, s2, n2); pair.fillXU(s1); pair.estimateE(p); pair.pose_chain()
+    stage["match_fillXU_estimateE_pose_chain"] = timed(end_to_end)
+    hyp, cnt = pair.get_best()
+    c1 = {"features": [n1, n2], "hypotheses": 1024, "ms": stage, "inliers": cnt, "best_hypothesis": hyp,
+          "published_estimateE_ms_gtx1080ti": PUBLISHED_ESTIMATE_E_MS, "estimateE_speedup_vs_published": PUBLISHED_ESTIMATE_E_MS / stage["estimateE"],
+          "note": "the published 24.12 ms are for H = N/8 = 269 hypotheses; this run does 1024"}
+    if O is not None:
+        m = s1.cpu().numpy().view(O.SIFT_DTYPE).reshape(-1)[:n1]
+        f2 = s2.cpu().numpy().view(O.SIFT_DTYPE).reshape(-1)[:n2]
+        om = O.match_sift(m.copy(), f2)
+        ok = bool(np.array_equal(m["match"], om["match"]) and np.array_equal(m["score"].view(np.uint32), om["score"].view(np.uint32)))
+        _, _, X0, X1 = O.fill_xu(om, DINO_KINV)
+        okey, ocounts, _ = O.ransac_range_fast(X0, X1, 0, 1024, p.threshold, p.jacobi_sweeps, seed=p.seed)
+        got = (pair.get_inlier_counts(1024).copy(), pair.get_key(), pair.get_E().copy(), pair.get_inlier_mask().copy())
+        c1["parity_vs_oracle"] = bool(ok and full_parity(O, X0, X1, p, n1, okey, ocounts, got))
+    out["c1_dino_pair"] = c1
+    pair.close()
+
+    # configs[4]: host images in, everything per pair inside the C library (sfm_extract_views + sfm_process_pairs)
+    for name, pairs in (("c5_dino_ring_36_pairs", S.ring_pairs(36)), ("c5_dino_all_630_pairs", [(i, j) for i in range(36) for j in range(i + 1, 36)])):
+        S.process_views(ctx, views[:9], DINO_K, DINO_KINV, max_pts=8192, sift=DINO_SIFT, device=dev)
+        runs = []
+        for _ in range(3):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            res, counts = S.process_views(ctx, views, DINO_K, DINO_KINV, pairs=pairs, max_pts=8192, sift=DINO_SIFT, device=dev)
+            torch.cuda.synchronize(); runs.append(time.perf_counter() - t0)
+        e = {"pairs": len(pairs), "done": len(res), "features_per_view": [min(counts), max(counts)], "ms_total": 1e3 * min(runs),
+             "ms_per_pair": 1e3 * min(runs) / len(pairs), "ms_runs": [round(1e3 * r, 3) for r in runs],
+             "note": "host images -> device inside the timed region (PCIe-inclusive)"}
+        if O is not None:
+            # a few pairs against the oracle chain, from the features the GPU extractor delivers for those views
+            ok = len(res) == len(pairs)
+            for pid in sorted({0, len(pairs) // 3, len(pairs) - 1}):
+                i, j = pairs[pid]
+                (si, ni), (sj, nj) = extract(views[i]), extract(views[j])
+                fi = si.cpu().numpy().view(O.SIFT_DTYPE).reshape(-1)[:ni]
+                fj = sj.cpu().numpy().view(O.SIFT_DTYPE).reshape(-1)[:nj]
+                om = O.match_sift(fi.copy(), fj)
+                _, _, X0, X1 = O.fill_xu(om, DINO_KINV)
+                q = S.default_params(ni)
+                okey, _, Ec = O.ransac_range(X0, X1, 0, q.num_hypotheses, q.threshold, q.jacobi_sweeps, seed=q.seed, want_E=True)
+                ocnt, ohyp = O.unpack_key(okey)
+                r = res.get(pid)
+                ok = ok and r is not None and (int(r[26]), int(r[27])) == (ocnt, ohyp) and \
+                    np.array_equal(np.ascontiguousarray(r[:9], np.float32).view(np.uint32), Ec[ohyp].reshape(-1).view(np.uint32))
+            e["parity_vs_oracle"] = bool(ok)
+            e["parity_pairs_checked"] = 3
+        out[name] = e
+    return out
+
+
+def run_extras(S, synth, O, ctx, dev, torch, np, skip):
+    out = {}
+
+    def guarded(name, fn):
+        try:
+            t0 = time.perf_counter()
+            out[name] = fn()
+            if isinstance(out[name], dict):
+                out[name]["wall_s"] = round(time.perf_counter() - t0, 2)
+        except Exception as e:                            # noqa: BLE001 -- an extra must never take the headline line down
+            out[name] = {"error": f"{type(e).__name__}: {e}"}
+
+    if "c3" not in skip:
+        guarded("c3", lambda: extra_ransac(S, synth, O, ctx, dev, torch, np, "c3", 16384, 65536, 50))
+    if "c4" not in skip:
+        guarded("c4_one_gpu", lambda: extra_ransac(S, synth, O, ctx, dev, torch, np, "c4", 16384, 1 << 20, 10))
+    guarded("headline_share_of_one_of_8_ranks", lambda: extra_ransac(S, synth, O, ctx, dev, torch, np, "rank8", N_MATCHES, TOTAL_HYPS, 100, hyp_count=TOTAL_HYPS // 8))
+    guarded("c4_share_of_one_of_8_ranks", lambda: extra_ransac(S, synth, O, ctx, dev, torch, np, "c4rank8", 16384, 1 << 20, 30, hyp_count=(1 << 20) // 8))
+    guarded("match_2048", lambda: extra_match(S, synth, O, ctx, dev, torch, np, 2048, 50))
+    guarded("match_16384", lambda: extra_match(S, synth, O, ctx, dev, torch, np, 16384, 20))
+    try:
+        out.update(extra_dino(S, O, ctx, dev, torch, np))
+    except Exception as e:                                # noqa: BLE001
+        out["dino"] = {"error": f"{type(e).__name__}: {e}"}
+    return out
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -282,6 +617,11 @@ def rank_main(args):
     solve_ms, score_ms, calls = ctx.kernel_timing_read()
     ctx.kernel_timing(False)
     timed_region_kernel_ms = (solve_ms / max(calls, 1), score_ms / max(calls, 1))
+    # what the timed steps left behind (every rank): winner, E, mask
+    hyp, cnt = pair.get_best()
+    main_mask = pair.get_inlier_mask().copy()
+    main_E = pair.get_E().copy()
+    mask_sum = int(main_mask.sum())
     if pipelined:
         # In the timed region consecutive steps overlap on the device, which stretches every kernel's own duration (two
         # launches share the CUs).  The roofline figures describe the kernel, so they come from serial steps: 20 calls of
@@ -301,6 +641,8 @@ def rank_main(args):
         ctx.kernel_timing(False)
     clock_mhz = pair.last_clock_mhz()
     per_rank = [[solve_ms / max(calls, 1), score_ms / max(calls, 1), clock_mhz]]
+    rc = 0
+    agree = None
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -308,11 +650,29 @@ def rank_main(args):
         gathered = [None] * world
         dist.all_gather_object(gathered, per_rank[0])
         per_rank = gathered
+        # every rank must hold the SAME result after the exchange, and the communicator must span all N ranks
+        mine = {"rank": rank, "best": [hyp, cnt], "E_sha": hashlib.sha256(main_E.tobytes()).hexdigest()[:16],
+                "mask_sha": hashlib.sha256(main_mask.tobytes()).hexdigest()[:16],
+                "nccl_ranks": comm.nccl_ranks() if comm is not None else (world if mode == "torch" else 1)}
+        allr = [None] * world
+        dist.all_gather_object(allr, mine)
+        same = all((a["best"], a["E_sha"], a["mask_sha"]) == (allr[0]["best"], allr[0]["E_sha"], allr[0]["mask_sha"]) for a in allr)
+        spans = all(a["nccl_ranks"] == world for a in allr)
+        agree = {"ranks_agree_on_winner_E_mask": bool(same), "communicator_spans_all_ranks": bool(spans), "per_rank": allr}
+        if not (same and spans):
+            print(f"bench.py: rank results differ or the communicator is short: {json.dumps(allr)}", file=sys.stderr)
+            rc = 1
 
-    hyp, cnt = pair.get_best()
-    main_mask = pair.get_inlier_mask().copy()
-    main_E = pair.get_E().copy()
-    mask_sum = int(main_mask.sum())
+    # one serial call of this rank's own path for the parity check (N = 1: counts of all H hypotheses, key, E, mask)
+    serial_result = None
+    if world == 1:
+        pair.estimateE(params)
+        serial_result = (pair.get_inlier_counts(H).copy(), pair.get_key(), pair.get_E().copy(), pair.get_inlier_mask().copy())
+        s_hyp, s_cnt = pair.get_best()
+        if (s_hyp, s_cnt) != (hyp, cnt) or not np.array_equal(serial_result[2], main_E) or not np.array_equal(serial_result[3], main_mask):
+            print("bench.py: the timed (pipelined) steps and a serial estimateE disagree", file=sys.stderr)
+            rc = 1
+    launch = pair.last_launch()
 
     # the other null-vector solver, same workload, a short run after the timed region (all ranks take part in its
     # collectives); reported next to the headline, never instead of it
@@ -337,13 +697,10 @@ def rank_main(args):
                    "value": H * 5 / vel, "ms_per_step": 1e3 * vel / 5, "best_hypothesis": vh, "inliers": vc}
         params.jacobi_sweeps = main_sweeps
 
-    rc = 0
     if rank == 0:
         local_hyps = S.shard_range(H, rank, world)[1]
         score_s = score_ms / 1e3 / max(calls, 1)
         solve_s = solve_ms / 1e3 / max(calls, 1)
-        flops = float(local_hyps) * FLOP_PER_POINT * n
-        achieved = flops / score_s / 1e12 if score_s > 0 else 0.0
         step_mode = ("two-slot pipelined calls: step k + 1 is solved and scored on a second stream and buffer set while step k is still "
                      "running (sfm_estimate_E_pipelined / sfm_estimate_E_sharded_pipelined); --serial times one call at a time"
                      if pipelined else "serial: one estimateE at a time")
@@ -353,21 +710,10 @@ def rank_main(args):
                     "torch": "torch.distributed all_reduce(MAX), 8 bytes"}[mode]
         if comm_note:
             exchange += " -- " + comm_note
-        launch = pair.last_launch()
-        kname = {1: "ransac_score_waves", 2: "ransac_fused_waves", 3: "ransac_score_mfma", 4: "ransac_score_prefilter"}.get(launch["kernel"], "?")
-        traffic_profiled = None                       # HBM bytes per launch from the committed rocprofv3 PMC passes: quoted, NOT measured by this run
-        profiled = None                               # issue-slot occupancy of the kernel from the committed PMC pass: quoted as well
-        try:
-            with open(os.path.join(ROOT, "profiles", "r02_traffic.json")) as f:
-                t = json.load(f).get(kname)
-            if t and t["matches"] == n and t["hypotheses"] == local_hyps:
-                src = f"profiles/r02_traffic.json (rocprofv3 --pmc passes of this command on the final code; quoted, not collected by this run)"
-                traffic_profiled = {"bytes_per_launch": 1024.0 * (t["fetch_kb"] + t["write_kb"]), "source": src}
-                profiled = {k: t[k] for k in ("valu_busy_frac", "mfma_busy_frac", "valu_insts_per_launch", "lds_bank_conflict_frac") if k in t}
-                profiled["source"] = src
-        except (OSError, KeyError, ValueError):
-            pass
-        prefilter = launch["kernel"] == 4
+        kname = KERNEL_NAMES.get(launch["kernel"], "?")
+        measured_in = (("20 serial launches of this rank's shard right after the timed region (in the timed region consecutive "
+                        "steps overlap and stretch each kernel's own duration: solve %.4f ms, scoring %.4f ms per launch there)"
+                        % timed_region_kernel_ms) if pipelined else "the timed region")
         out = {
             "metric": "RANSAC E-matrix hypotheses/sec (8-point, fused scoring), inlier-mask parity vs CPU oracle",
             "value": H * args.steps / elapsed,
@@ -392,38 +738,31 @@ def rank_main(args):
                        "kernel": dict(launch, name=kname), "step_mode": step_mode, "exchange": exchange,
                        "nccl_ranks": comm.nccl_ranks() if comm is not None else (world if mode == "torch" else 1),
                        "per_rank_kernel_ms": [{"rank": r, "solve": v[0], "score": v[1], "shader_clock_mhz": v[2]} for r, v in enumerate(per_rank)]},
-            "roofline": {"bound": "valu_fp32",
-                         "bound_detail": ("vector-ALU issue: the kernel rejects ~99 % of the (hypothesis, point) pairs with 3 fp16 MFMAs per 32 x 32 pairs + "
-                                          "3 vector instructions per pair and runs the exact 38-FLOP test on the rest, so `achieved` -- the ALGORITHMIC FLOP of "
-                                          "SURVEY 8d over the launch time -- may exceed the FP32 peak it is priced against; `issue_profiled` has the occupancy "
-                                          "of the vector and matrix pipes from the committed counter pass"
-                                          if prefilter else
-                                          "FP32 vector ALU issue (v_pk_fma_f32 and friends); 157.3 TFLOP/s = 256 CU x 256 FLOP/clk x 2.4 GHz, "
-                                          "numerically the dense f32 MFMA peak the bench contract prices compute against"),
-                         "kernel": kname, "achieved": achieved, "issue_profiled": profiled,
-                         "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_PEAK_TFLOPS,
-                         "traffic": None, "traffic_profiled": traffic_profiled,
-                         "flop_per_launch": flops, "avg_launch_ms": 1e3 * score_s,
-                         "measured_in": ("20 serial launches of this rank's shard right after the timed region (in the timed region consecutive "
-                                         "steps overlap and stretch each kernel's own duration: solve %.4f ms, scoring %.4f ms per launch there)"
-                                         % timed_region_kernel_ms) if pipelined else "the timed region",
-                         "solve_kernel_avg_ms": 1e3 * solve_s,
-                         "shader_clock_mhz": clock_mhz,
-                         "frac_at_sustained_clock": (achieved / (FP32_PEAK_TFLOPS * clock_mhz / PEAK_CLOCK_MHZ)) if clock_mhz > 0 else None,
-                         "pipeline_frac": (float(local_hyps) * (FLOP_PER_HYP + FLOP_PER_POINT * n)) /
-                                          max(score_s + solve_s, 1e-12) / 1e12 / FP32_PEAK_TFLOPS},
+            "roofline": roofline_block(launch["kernel"], n, local_hyps, score_s, solve_s, clock_mhz, measured_in),
             "result": {"best_hypothesis": hyp, "inliers": cnt, "mask_sum": mask_sum},
         }
+        if agree is not None:
+            out["result"]["multi_gpu"] = agree
         if variant is not None:
             out["variants"] = [variant]
+        O = None
         if world == 1 and not args.no_cpu:
-            base, (O, X0, X1) = cpu_baseline(scene, params, n)
+            O = load_oracle()
+            _, _, X0, X1 = O.fill_xu(scene["sift"], scene["Kinv"])
+            base, okey, ocounts = cpu_baseline(O, X0, X1, params, n, H, args.cpu_seconds)
             out["cpu_baseline"] = base
-            E = O.hypothesis_E(X0, X1, O.sample8(params.seed, hyp, n), params.jacobi_sweeps)
-            ocnt, omask = O.count_inliers(E, X0, X1, params.threshold)
-            out["result"]["parity_vs_oracle"] = bool(ocnt == cnt and np.array_equal(omask, main_mask)
-                                                     and np.array_equal(E.view(np.uint32), main_E.view(np.uint32)))
-            if not out["result"]["parity_vs_oracle"]:
+            ok = full_parity(O, X0, X1, params, n, okey, ocounts, serial_result)
+            out["result"]["parity_vs_oracle"] = ok
+            out["result"]["parity_checked"] = (f"all {H} inlier counts, the arg-max key (first maximum), the winner's E bit for bit and the inlier mask "
+                                               "of one serial estimateE against the CPU oracle; the timed pipelined steps' E / mask / winner equal that call's")
+            if not ok:
+                rc = 1
+        if world == 1 and not args.no_extra:
+            skip = {args.config} if (args.matches is None and args.hyps is None) else set()
+            out["extra"] = run_extras(S, synth, O, ctx, dev, torch, np, skip)
+            bad = [k for k, v in out["extra"].items() if isinstance(v, dict) and (v.get("parity_vs_oracle") is False or "error" in v)]
+            if bad:
+                print(f"bench.py: extra runs failed or lost parity: {bad}", file=sys.stderr)
                 rc = 1
         try:                                        # RCCL writes a start-up banner through C stdio: push it out BEFORE the JSON line
             import ctypes

@@ -123,6 +123,7 @@ int sfm_ctx_set_quirks(sfm_ctx *ctx, unsigned int flags)
     SFM_REQUIRE(ctx, SFM_E_INVALID, "null context");
     SFM_REQUIRE((flags & ~SFM_QUIRK_MATCH_TAIL) == 0, SFM_E_INVALID, "unknown quirk flags 0x%x", flags);
     ctx->quirks = flags;
+    for (sfm_ctx *l : ctx->lane) if (l) l->quirks = flags;          // the lane contexts of sfm_process_pairs / sfm_extract_views
     return SFM_OK;
 }
 
@@ -908,6 +909,7 @@ int sfm_extract_views(sfm_ctx *ctx, const float *const *h_images, int num_views,
             if (rc == SFM_OK) rc = sfm_ctx_own_stream(ctx->lane[l - 1]);
             if (rc != SFM_OK) return rc;
             ctx->lane[l - 1]->match_kernel = ctx->match_kernel;
+            ctx->lane[l - 1]->quirks = ctx->quirks;
         }
         cs[l] = ctx->lane[l - 1];
     }
@@ -1022,6 +1024,7 @@ int sfm_process_pairs(sfm_ctx *ctx, const float h_K[9], const float h_Kinv[9], c
         }
         lanes[l] = ctx->lane[l - 1];
         lanes[l]->match_kernel = ctx->match_kernel;
+        lanes[l]->quirks = ctx->quirks;                     // every pair of one call honours the same SFM_QUIRK_* flags
     }
     for (int l = 0; l < nlanes; ++l)
         if (!ctx->lane_ev[l]) SFM_HIP_TRY(hipEventCreateWithFlags(&ctx->lane_ev[l], hipEventDisableTiming));
@@ -1066,20 +1069,26 @@ int sfm_process_pairs(sfm_ctx *ctx, const float h_K[9], const float h_Kinv[9], c
         if (v == first_views.size()) first_views.push_back(d.d_sift1);
         sfm_ctx *c = lanes[v % (size_t)nlanes];
         sfm_pair *ip = c->pool_pair;
-        if (d.d_sift2) { rc = sfm_match(c, d.d_sift1, d.n1, d.d_sift2, d.n2); if (rc != SFM_OK) return rc; }
-        rc = sfm_pair_reset(ip, d.n1);                                  if (rc != SFM_OK) return rc;
-        rc = sfm_fill_xu(ip, d.d_sift1);                                if (rc != SFM_OK) return rc;
+        if (d.d_sift2) { rc = sfm_match(c, d.d_sift1, d.n1, d.d_sift2, d.n2); if (rc != SFM_OK) break; }
+        rc = sfm_pair_reset(ip, d.n1);                                  if (rc != SFM_OK) break;
+        rc = sfm_fill_xu(ip, d.d_sift1);                                if (rc != SFM_OK) break;
         sfm_ransac_params p;
         sfm_ransac_default_params(&p, d.n1);
         if (num_hypotheses) p.num_hypotheses = num_hypotheses;
-        rc = sfm_estimate_E(ip, &p);                                    if (rc != SFM_OK) return rc;
+        rc = sfm_estimate_E(ip, &p);                                    if (rc != SFM_OK) break;
         // poses, triangulation and the record: one launch in SFM_POSE_REFERENCE (sfm_pose_chain), four otherwise
         rc = pose_chain(ip, pose_mode, ctx->pool_records + (size_t)slot * SFM_RECORD_FLOATS);
-        if (rc != SFM_OK) return rc;
+        if (rc != SFM_OK) break;
     }
+    // join the lanes -- also when an enqueue failed: what the lanes already hold must not outlive this call's view of the buffers
     for (int l = 1; l < nlanes; ++l) {
-        SFM_HIP_TRY(hipEventRecord(ctx->lane_ev[l], lanes[l]->stream));
-        SFM_HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->lane_ev[l], 0));
+        const hipError_t e1 = hipEventRecord(ctx->lane_ev[l], lanes[l]->stream);
+        const hipError_t e2 = e1 == hipSuccess ? hipStreamWaitEvent(ctx->stream, ctx->lane_ev[l], 0) : e1;
+        if (e2 != hipSuccess && rc == SFM_OK) { set_error("lane join failed: %s", hipGetErrorString(e2)); rc = SFM_E_HIP; }
+    }
+    if (rc != SFM_OK) {
+        (void)hipStreamSynchronize(ctx->stream);
+        return rc;
     }
     // ONE read-back for all pairs of this rank
     std::vector<float> rec((size_t)owned * SFM_RECORD_FLOATS);

@@ -43,6 +43,7 @@ struct sfm_ctx {
     // matcher scratch: per-split partial (best, second, index) records
     void *match_ws = nullptr;
     size_t match_ws_bytes = 0;
+    size_t match_ticket_bytes = 0;     // zeroed ticket area in front of the partials (grows with the query-block count)
     // pre-filter matcher (match_prefilter.hip): fp16 copies, norms, per-split partials, candidate lists
     void *match_pf_ws = nullptr;
     size_t match_pf_ws_bytes = 0;
@@ -119,6 +120,7 @@ struct sfm_pair {
     uint32_t cand_h0 = 0, cand_seed = 0;   // what d_Ecand currently holds: shard start, sampler settings
     const int32_t *cand_indices = nullptr;
     int cand_sweeps = 0;
+    bool cand_given = false;               // d_Ecand holds caller-supplied matrices (sfm_ransac_score_candidates), not tuple-derived ones
     // second set of the per-shard buffers (sfm_ransac_score_into_slot, slot 1): two shards in flight on two streams
     int   *alt_counts = nullptr;
     uint32_t *alt_tick = nullptr;

@@ -283,16 +283,21 @@ int launch_match(sfm_ctx *ctx, const float *d1, int n1, int ld1, const float *d2
     nsplit = (n2 + rows_per_split - 1) / rows_per_split;
 
     // scratch: one ticket per query block (zero between calls: the merging block resets its own) + the per-split partials
-    constexpr size_t kTicketBytes = 4096;
+    // The ticket area only ever grows (sized from the largest query-block count seen, so any n1 works); it sits in front of
+    // the partials and is zeroed when the workspace is (re)allocated -- the partials of one call must never land where a
+    // later call expects zeroed tickets.
+    size_t ticket_bytes = ctx->match_ticket_bytes < 4096 ? 4096 : ctx->match_ticket_bytes;
+    if ((size_t)qblocks * 4 > ticket_bytes) ticket_bytes = (size_t)round_up(qblocks * 4, 4096);
+    const size_t kTicketBytes = ticket_bytes;
     const size_t need = kTicketBytes + (size_t)nsplit * n1 * 12;
-    if (qblocks > (int)(kTicketBytes / 4)) { set_error("too many query blocks (%d)", qblocks); return SFM_E_INVALID; }
-    if (need > ctx->match_ws_bytes) {
+    if (need > ctx->match_ws_bytes || kTicketBytes != ctx->match_ticket_bytes) {
         SFM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+        const size_t bytes = need > ctx->match_ws_bytes ? need : ctx->match_ws_bytes;
         if (ctx->match_ws) (void)hipFree(ctx->match_ws);
-        ctx->match_ws = nullptr; ctx->match_ws_bytes = 0;
-        SFM_HIP_TRY(hipMalloc(&ctx->match_ws, need));
+        ctx->match_ws = nullptr; ctx->match_ws_bytes = 0; ctx->match_ticket_bytes = 0;
+        SFM_HIP_TRY(hipMalloc(&ctx->match_ws, bytes));
         SFM_HIP_TRY(hipMemsetAsync(ctx->match_ws, 0, kTicketBytes, ctx->stream));
-        ctx->match_ws_bytes = need;
+        ctx->match_ws_bytes = bytes; ctx->match_ticket_bytes = kTicketBytes;
     }
     unsigned int *tickets = static_cast<unsigned int *>(ctx->match_ws);
     float *wb = reinterpret_cast<float *>(static_cast<char *>(ctx->match_ws) + kTicketBytes);

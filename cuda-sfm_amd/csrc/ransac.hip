@@ -317,6 +317,7 @@ int launch_ransac_score(sfm_pair *pair, const sfm_ransac_params &p, uint32_t h0,
     pair->key_clean = false;
     pair->last_count = count;
     pair->cand_h0 = h0; pair->cand_seed = p.seed; pair->cand_indices = p.d_indices; pair->cand_sweeps = p.jacobi_sweeps;
+    pair->cand_given = d_E_given != nullptr;
     if (count == 0) return SFM_OK;
     int rc = ensure_hyp_capacity(pair, count);
     if (rc != SFM_OK) return rc;
@@ -443,6 +444,13 @@ int launch_ransac_finalize(sfm_pair *pair, const sfm_ransac_params &p, const uns
     sfm_ctx *ctx = pair->ctx;
     if (!stream) stream = ctx->stream;
     (void)ctx;
+    // Caller-supplied candidates (sfm_ransac_score_candidates) have no 8-tuple behind them: the rank that scored the winner
+    // would copy the supplied matrix while every other rank re-derived one from the id's tuple -- different E on
+    // different ranks.  Refused instead.
+    if (pair->cand_given && !rederive) {
+        set_error("finalize after sfm_ransac_score_candidates: the candidates were supplied by the caller, not derived from 8-tuples");
+        return SFM_E_STATE;
+    }
     // winner's E (taken from the candidates or re-derived from the hypothesis id: bit-identical on every rank), inlier
     // mask and count: replaces thrust::max_element + the 9-float D2D copy (sfm.cu:135-140).  One launch (ransac_fused.hip).
     return launch_finalize_block(pair, p, d_key, hyp_host, from_key, stream, rederive);

@@ -210,8 +210,8 @@ int sfm_estimate_E(sfm_pair *pair, const sfm_ransac_params *p);
  * per-shard buffers of its own -- so consecutive calls overlap on the device (the lane-solve kernel and the launch gaps
  * of one call fill what the scoring kernel of the other leaves idle: 851 -> 815 us per call at 2^20 hypotheses,
  * 155 -> 119 us at 131072; profiles/overlap_probe.py).  E, mask and best are those of the last call once
- * sfm_pair_flush has made the context stream wait for it; the sfm_get_* readers flush by themselves, the pose stages
- * and sfm_fill_xu need an explicit sfm_pair_flush first. */
+ * sfm_pair_flush has made the context stream wait for it; every other entry point that works on the pair (the sfm_get_*
+ * readers, sfm_fill_xu, sfm_set_points, the pose stages, sfm_ransac_score / _finalize, sfm_estimate_E) flushes by itself. */
 int sfm_estimate_E_pipelined(sfm_pair *pair, const sfm_ransac_params *p);
 int sfm_pair_flush(sfm_pair *pair);
 /* The same in two steps for multi-GPU use: score the local shard (device key = (count << 32) |
@@ -222,8 +222,9 @@ int sfm_ransac_finalize(sfm_pair *pair, const sfm_ransac_params *p, uint32_t hyp
 /* calculateInliers on its own (sfm.cu:155-236 takes the E candidates as its input): scores hyp_count caller-supplied
  * candidates (d_E: 9 floats each, row-major, DEVICE memory; candidate k has hypothesis id hyp_begin + k) instead of
  * solving them from 8-tuples.  Leaves the counts (sfm_get_inlier_counts), the candidates (sfm_get_E_candidates) and
- * the packed key (sfm_get_key).  sfm_ransac_finalize re-derives E from the hypothesis' tuple, so it does not apply
- * to candidates that did not come from one. */
+ * the packed key (sfm_get_key).  The finalize calls (sfm_ransac_finalize, sfm_ransac_finalize_key) return SFM_E_STATE
+ * after this call: they take the winner's E from the scored candidates where this rank holds it and re-derive it from the
+ * hypothesis' 8-tuple elsewhere, which is only the same matrix when the candidates came from tuples. */
 int sfm_ransac_score_candidates(sfm_pair *pair, const sfm_ransac_params *p, const float *d_E);
 /* Device-resident variants: copy the local key into caller memory (e.g. the tensor handed to the
  * RCCL all-reduce) and finalize from a reduced key without any host round trip. */
