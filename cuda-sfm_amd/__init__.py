@@ -58,7 +58,7 @@ EXPORTS = [
     "sfm_pair_device_ptr", "sfm_pair_ld", "sfm_pair_num_points", "sfm_get_XU", "sfm_get_E", "sfm_get_best",
     "sfm_get_key", "sfm_get_inlier_counts", "sfm_get_inlier_mask", "sfm_get_E_candidates",
     "sfm_get_pose_candidates", "sfm_get_pose_inverses", "sfm_get_pose_index", "sfm_get_points", "sfm_copy_points_to_vbo",
-    "sfm_ransac_last_launch", "sfm_ransac_last_clock", "sfm_ransac_last_phases", "sfm_prefilter_probe", "sfm_process_pairs", "sfm_extract_views",
+    "sfm_ransac_last_launch", "sfm_ransac_last_clock", "sfm_ransac_last_phases", "sfm_ransac_last_trace", "sfm_prefilter_probe", "sfm_process_pairs", "sfm_extract_views",
 ]
 
 
@@ -137,6 +137,7 @@ _lib.sfm_get_pose_index.argtypes = [_vp, C.POINTER(C.c_int)]
 _lib.sfm_get_points.argtypes = [_vp, _vp]
 _lib.sfm_pair_reset.argtypes = [_vp, C.c_int]
 _lib.sfm_get_result.argtypes = [_vp, _vp]
+_lib.sfm_ransac_last_trace.argtypes = [_vp, C.POINTER(C.c_uint64), C.c_size_t, C.POINTER(C.c_size_t)]
 _lib.sfm_ransac_last_launch.argtypes = [_vp] + [C.POINTER(C.c_int)] * 4
 _lib.sfm_ransac_last_clock.argtypes = [_vp, C.POINTER(C.c_double)]
 
@@ -375,6 +376,13 @@ class ImagePair:
         t = (C.c_uint64 * 8)()
         _check(_lib.sfm_ransac_last_phases(self._h, t), "sfm_ransac_last_phases")
         return list(t)
+
+    def last_trace(self):
+        """sfm_ransac_last_trace: [blocks, 20] uint64 -- start, end of wave 0, ids, (tile, column), 16 wave ends (100 MHz ticks)."""
+        buf = (C.c_uint64 * (1024 * 20))()
+        n = C.c_size_t()
+        _check(_lib.sfm_ransac_last_trace(self._h, buf, 1024 * 20, C.byref(n)), "sfm_ransac_last_trace")
+        return np.frombuffer(buf, dtype=np.uint64, count=n.value).reshape(-1, 20).copy()
 
     def ransac_score_candidates(self, params, d_E):
         """calculateInliers on its own: score caller-supplied candidates (float32 device tensor, 9 x hyp_count)."""

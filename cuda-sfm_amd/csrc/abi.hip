@@ -404,14 +404,15 @@ int sfm_pair_create(sfm_ctx *ctx, const float h_K[9], const float h_Kinv[9], int
     A(&p->d_E, 9); A(&p->d_P, 64); A(&p->d_Pinv, 64); A(&p->d_Pind, 8);
     A(&p->d_points, (size_t)4 * num_points);
     A(&p->d_mask, (size_t)num_points);
-    A(&p->d_key, 2); A(&p->d_best, 2); A(&p->d_clk, 8);
+    A(&p->d_key, 2); A(&p->d_best, 2); A(&p->d_clk, kClkWords); A(&p->d_bound, 2);
     if (rc != SFM_OK) { sfm_pair_destroy(p); return rc; }
     hipError_t e = hipMemcpyAsync(p->d_K, h_K, 9 * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(p->d_Kinv, h_Kinv, 9 * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipMemsetAsync(p->d_key, 0, 2 * sizeof(unsigned long long), ctx->stream);
     p->key_clean = true;
     if (e == hipSuccess) e = hipMemsetAsync(p->d_best, 0, 2 * sizeof(uint32_t), ctx->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(p->d_clk, 0, 8 * sizeof(unsigned long long), ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(p->d_bound, 0, 2 * sizeof(unsigned long long), ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(p->d_clk, 0, kClkWords * sizeof(unsigned long long), ctx->stream);
     if (e == hipSuccess) e = hipMemsetAsync(p->d_Pind, 0, 8 * sizeof(int), ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);       // host K arrays may go out of scope
     if (e != hipSuccess) { sfm_pair_destroy(p); set_error("pair init failed: %s", hipGetErrorString(e)); return SFM_E_HIP; }
@@ -438,7 +439,7 @@ int sfm_pair_destroy(sfm_pair *p)
     if (p->ctx) { (void)hipSetDevice(p->ctx->device); (void)hipStreamSynchronize(p->ctx->stream); }
     void *bufs[] = { p->d_K, p->d_Kinv, p->d_U[0], p->d_U[1], p->d_X[0], p->d_X[1], p->d_pts4, p->d_E, p->d_P, p->d_Pinv, p->d_Pind,
                      p->d_points, p->d_mask, p->d_key, p->d_best, p->d_counts, p->d_Ecand, p->d_clk, p->d_tick,
-                     p->alt_counts, p->alt_Ecand, p->alt_tick, p->alt_key };
+                     p->alt_counts, p->alt_Ecand, p->alt_tick, p->alt_key, p->d_pf, p->alt_pf, p->d_bound };
     for (void *b : bufs) if (b) (void)hipFree(b);
     if (p->pipe_stream) { (void)hipStreamSynchronize(p->pipe_stream); (void)hipStreamDestroy(p->pipe_stream); }
     for (hipEvent_t e : p->pipe_final) if (e) (void)hipEventDestroy(e);
@@ -461,6 +462,7 @@ int sfm_fill_xu(sfm_pair *pair, const sfm_sift_point *d_data)
         // the last row of K^-1 is (0 0 1): the scoring kernel may then drop z (ransac_device.hpp)
         pair->unit_z = pair->h_Kinv[6] == 0.0f && pair->h_Kinv[7] == 0.0f && pair->h_Kinv[8] == 1.0f;
         pair->have_pts4 = pair->unit_z;     // fill_xu_kernel wrote the (x1x, x1y, x2x, x2y) records; they stand for the points when every z is 1
+        pair->have_bound = true;            // ... and the bound over all points (the pre-filter kernel's B)
     }
     return rc;
 }
@@ -471,7 +473,7 @@ int sfm_set_points(sfm_pair *pair, const float *d_X0, const float *d_X1)
     if (pair->pipe_pending) { const int rcf = sfm_pair_flush(pair); if (rcf != SFM_OK) return rcf; }
     SFM_HIP_TRY(hipSetDevice(pair->ctx->device));
     int rc = launch_set_points(pair, d_X0, d_X1);
-    if (rc == SFM_OK) { pair->have_points = true; pair->have_E = pair->have_P = pair->have_pose = pair->have_points3d = false; pair->last_count = 0; pair->unit_z = false; pair->have_pts4 = false; }
+    if (rc == SFM_OK) { pair->have_points = true; pair->have_E = pair->have_P = pair->have_pose = pair->have_points3d = false; pair->last_count = 0; pair->unit_z = false; pair->have_pts4 = false; pair->have_bound = false; }
     return rc;
 }
 
@@ -543,6 +545,7 @@ int sfm_ransac_score_into_slot(sfm_pair *pair, const sfm_ransac_params *p, uint6
     auto swap_slot = [&]() {
         std::swap(pair->d_counts, pair->alt_counts); std::swap(pair->d_tick, pair->alt_tick);
         std::swap(pair->d_Ecand, pair->alt_Ecand); std::swap(pair->cap_hyps, pair->alt_cap_hyps);
+        std::swap(pair->d_pf, pair->alt_pf);
         pair->key_clean = false;            // (the flag describes the pair's own key buffer, not the slot's)
         std::swap(pair->d_key, pair->alt_key);
     };
@@ -1131,12 +1134,25 @@ int sfm_ransac_last_phases(sfm_pair *pair, uint64_t ticks[8])
     return SFM_OK;
 }
 
+int sfm_ransac_last_trace(sfm_pair *pair, uint64_t *words, size_t capacity, size_t *count)
+{
+    SFM_REQUIRE(pair && words && count, SFM_E_INVALID, "null argument");
+    const size_t nblocks = (size_t)(pair->last_grid < kTraceBlocks ? pair->last_grid : kTraceBlocks);
+    const size_t need = nblocks * kTraceWords;
+    *count = 0;
+    if (pair->last_kernel != SFM_KERNEL_PREFILTER || need == 0) return SFM_OK;
+    SFM_REQUIRE(capacity >= need, SFM_E_INVALID, "capacity %zu < %zu words", capacity, need);
+    int rc = copy_out(pair, words, pair->d_clk + 8, need * sizeof(uint64_t));
+    if (rc == SFM_OK) *count = need;
+    return rc;
+}
+
 int sfm_prefilter_probe(sfm_ctx *ctx, const float h_E[9], float threshold, float bound, const float h_point[4], int survive_all, float h_out[100])
 {
     SFM_REQUIRE(ctx && h_E && h_point && h_out, SFM_E_INVALID, "null argument");
     SFM_HIP_TRY(hipSetDevice(ctx->device));
     float *d = nullptr;
-    SFM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d), 128 * sizeof(float)));
+    SFM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d), 256 * sizeof(float)));      // result (100) + E (9 at 100) + one PfRecord at 128
     hipError_t e = hipMemcpyAsync(d + 100, h_E, 9 * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
     int rc = e == hipSuccess ? launch_prefilter_probe(ctx, d + 100, threshold, bound, h_point, survive_all, d) : SFM_E_HIP;
     if (rc == SFM_OK) {

@@ -24,6 +24,9 @@ void set_error(const char *fmt, ...);
         if (!(cond)) { ::sfm::set_error(__VA_ARGS__); return (code); }                         \
     } while (0)
 
+constexpr int kTraceBlocks = 1024;     // blocks of a scoring launch whose start / end stamps are kept (sfm_ransac_last_trace)
+constexpr int kTraceWords = 20;        // per block: start, end of wavefront 0, (XCC id << 32 | hardware id), tile << 32 | column, 16 wavefront ends (100 MHz ticks)
+constexpr int kClkWords = 8 + kTraceBlocks * kTraceWords;
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 } // namespace sfm
@@ -110,11 +113,16 @@ struct sfm_pair {
     unsigned long long *d_key = nullptr;   // [0] packed best of last score, [1] scratch
     bool key_clean = false;                // d_key is known to be zero (pair creation, fillXU): the next score launch needs no memset
     uint32_t *d_best = nullptr;        // [0] hyp, [1] count of the finalized hypothesis
+    // [8 ...]: trace of the last pre-filter scoring launch, kTraceWords per block (sfm_ransac_last_trace)
     unsigned long long *d_clk = nullptr;   // [0] shader-clock ticks, [1] 100 MHz ticks over block 0 of the last ransac_score_waves launch
     // per-shard buffers, grown on demand
     int   *d_counts = nullptr;
-    uint32_t *d_tick = nullptr;        // pre-filter kernel: per 64-hypothesis group, how many tiles have been added
+    uint32_t *d_tick = nullptr;        // pre-filter kernel: per 32-hypothesis group, how many tiles have been added
     float *d_Ecand = nullptr;
+    void *d_pf = nullptr;              // pre-filter kernel: one PfRecord (112 bytes, prefilter_record.hpp) per hypothesis of the shard
+    unsigned long long *d_bound = nullptr; // (fillXU epoch << 32) | bits of the largest |coordinate| <= 48 over all points: atomicMax, never reset
+    uint32_t bound_epoch = 0;
+    bool have_bound = false;           // d_bound describes the current points (fillXU)
     size_t cap_hyps = 0;
     uint32_t last_count = 0;           // hyp_count of the last score call
     uint32_t cand_h0 = 0, cand_seed = 0;   // what d_Ecand currently holds: shard start, sampler settings
@@ -125,6 +133,7 @@ struct sfm_pair {
     int   *alt_counts = nullptr;
     uint32_t *alt_tick = nullptr;
     float *alt_Ecand = nullptr;
+    void *alt_pf = nullptr;
     unsigned long long *alt_key = nullptr;   // slot 1's internal key (the fused / MFMA families reduce into the pair's key, then copy)
     size_t alt_cap_hyps = 0;
     // sfm_estimate_E_pipelined: odd steps run on this stream, even steps on the context's; one event per slot
@@ -152,6 +161,10 @@ int launch_permutation_indices(sfm_ctx *ctx, int n, uint32_t seed, int32_t *d_in
 // ransac_prefilter.hip
 bool prefilter_usable(const sfm_pair *pair, const sfm_ransac_params &p, uint32_t count);
 int launch_score_prefilter(sfm_pair *pair, const sfm_ransac_params &p, uint32_t h0, uint32_t count, unsigned long long *key2);
+int launch_pf_prep(sfm_pair *pair, const sfm_ransac_params &p, uint32_t count);        // PfRecords from d_Ecand (paths whose solve kernel does not write them)
+int prefilter_tiles(const sfm_pair *pair);
+// ransac_prefilter_r2.hip (the round-2 kernel, A/B only: sfm_ransac_params.reserved[3] == 2)
+int launch_score_prefilter_r2(sfm_pair *pair, const sfm_ransac_params &p, uint32_t h0, uint32_t count, unsigned long long *key2);
 // ransac_mfma.hip
 int launch_score_mfma(sfm_pair *pair, const sfm_ransac_params &p, uint32_t h0, uint32_t count);
 // ransac_fused.hip

@@ -17,11 +17,14 @@ namespace sfm {
 __global__ __launch_bounds__(256)
 void fill_xu_kernel(const sfm_sift_point *__restrict__ data, int n, int ld, const float *__restrict__ kinv,
                     float *__restrict__ U0, float *__restrict__ U1, float *__restrict__ X0, float *__restrict__ X1,
-                    unsigned long long *__restrict__ key, float4 *__restrict__ pts4)
+                    unsigned long long *__restrict__ key, float4 *__restrict__ pts4, unsigned long long *__restrict__ bound, uint32_t epoch)
 {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j == 0) { key[0] = 0ull; key[1] = 0ull; }           // the estimateE that follows finds its arg-max key cleared: no memset launch
-    if (j >= ld) return;
+    // Bound over all points for the pre-filter scoring kernel (prefilter_math.hpp: B >= |coordinate| of every point that
+    // carries features, i.e. up to 48): (epoch << 32) | bits(max), reduced with atomicMax.  The epoch grows with every
+    // fillXU of the pair, so a new call's words beat every older one without a reset launch.
+    if (j >= ld) return;                                    // (ld is a multiple of 128: whole wavefronts leave)
     const float qnan = __builtin_nanf("");
     float u0[3] = { 0.0f, 0.0f, 0.0f }, u1[3] = { 0.0f, 0.0f, 0.0f };
     float x0[3] = { qnan, qnan, qnan }, x1[3] = { qnan, qnan, qnan };
@@ -43,6 +46,14 @@ void fill_xu_kernel(const sfm_sift_point *__restrict__ data, int n, int ld, cons
         X1[(size_t)r * ld + j] = x1[r];
     }
     pts4[j] = make_float4(x0[0], x0[1], x1[0], x1[1]);        // the sampler's view of a correspondence: one 16-byte gather (ransac.hip)
+    float big = 0.0f;
+    if (j < n) {
+        big = fmaxf(fmaxf(fabsf(x0[0]), fabsf(x0[1])), fmaxf(fabsf(x1[0]), fabsf(x1[1])));
+        if (!(big <= 48.0f)) big = 0.0f;                      // beyond the fp16 feature range (or NaN): the point carries no features
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) big = fmaxf(big, __shfl_xor(big, off));
+    if ((threadIdx.x & 63) == 0) atomicMax(bound, ((unsigned long long)epoch << 32) | __float_as_uint(big));
 }
 
 __global__ __launch_bounds__(256)
@@ -266,7 +277,8 @@ int launch_pose_chain(sfm_pair *pair, float *d_record)
 int launch_fill_xu(sfm_pair *pair, const sfm_sift_point *d_data)
 {
     hipLaunchKernelGGL(fill_xu_kernel, dim3((pair->ld + 255) / 256), dim3(256), 0, pair->ctx->stream,
-                       d_data, pair->n, pair->ld, pair->d_Kinv, pair->d_U[0], pair->d_U[1], pair->d_X[0], pair->d_X[1], pair->d_key, pair->d_pts4);
+                       d_data, pair->n, pair->ld, pair->d_Kinv, pair->d_U[0], pair->d_U[1], pair->d_X[0], pair->d_X[1], pair->d_key, pair->d_pts4,
+                       pair->d_bound, ++pair->bound_epoch);
     SFM_HIP_TRY(hipGetLastError());
     return SFM_OK;
 }

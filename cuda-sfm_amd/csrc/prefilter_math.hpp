@@ -201,12 +201,13 @@ SFM_HD int pf_cell(float c, const PfGrid &gr)
     return (int)fminf(fmaxf(f, -5.0e8f), 5.0e8f);
 }
 
-// Non-zero hash of a cell (equal cells -> equal keys; different cells may collide, which only costs a tile scan).
+// Non-zero hash of a cell (equal cells -> equal keys; different cells may collide, which only costs a tile scan).  Bit 31 is
+// always clear, so 0xFFFFFFFF is free to mean "check every point" in a PfRecord (prefilter_record.hpp).
 SFM_HD uint32_t pf_cell_key(int ix, int iy)
 {
     uint32_t k = (uint32_t)ix * 0x9E3779B1u ^ (uint32_t)iy * 0x85EBCA6Bu;
     k ^= k >> 15;
-    return (k * 0x2C1B3C6Du) | 1u;
+    return ((k * 0x2C1B3C6Du) & 0x7FFFFFFFu) | 1u;
 }
 
 // The divisor of the first residual term exactly as residual() / inlier_filter() compute it (z = 1).

@@ -19,6 +19,7 @@
 //
 // Work per (hypothesis, point): 38 FLOP; per hypothesis: 720 FLOP (A^T A) + solver.
 #include "ransac_device.hpp"
+#include "prefilter_record.hpp"
 
 namespace sfm {
 
@@ -39,11 +40,11 @@ __global__ __launch_bounds__(64)
 void ransac_solve_lanes(const float *__restrict__ X0, const float *__restrict__ X1, int ld, int n,
                         const int32_t *__restrict__ indices, uint32_t seed, uint32_t h0, uint32_t count,
                         int sweeps, float *__restrict__ Ecand, unsigned long long *zero_key, unsigned long long *zero_key2,
-                        int *__restrict__ zero_counts, uint32_t *__restrict__ zero_ticks)
+                        int *__restrict__ zero_counts, uint32_t *__restrict__ zero_ticks, uint32_t nzero)
 {
     reset_keys(zero_key, zero_key2);
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (zero_ticks && i < (count + 63u) / 64u) zero_ticks[i] = 0u;
+    if (zero_ticks && i < nzero) zero_ticks[i] = 0u;
     if (i >= count) return;
     if (zero_counts) zero_counts[i] = 0;                    // tile-parallel scoring accumulates into counts[] with atomics
     float E[9];
@@ -60,11 +61,12 @@ __global__ __launch_bounds__(64)
 void ransac_solve_lanes1_qr(const float *__restrict__ X0, const float *__restrict__ X1, int ld, int n,
                             const int32_t *__restrict__ indices, uint32_t seed, uint32_t h0, uint32_t count,
                             int sweeps, float *__restrict__ Ecand, unsigned long long *zero_key, unsigned long long *zero_key2,
-                            int *__restrict__ zero_counts, uint32_t *__restrict__ zero_ticks, const float4 *__restrict__ pts4)
+                            int *__restrict__ zero_counts, uint32_t *__restrict__ zero_ticks, uint32_t nzero, const float4 *__restrict__ pts4,
+                            PfRecord *__restrict__ recs, float thr, PfScales sc, const unsigned long long *__restrict__ bound_word)
 {
     reset_keys(zero_key, zero_key2);
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (zero_ticks && i < (count + 63u) / 64u) zero_ticks[i] = 0u;
+    if (zero_ticks && i < nzero) zero_ticks[i] = 0u;
     if (i >= count) return;
     if (zero_counts) zero_counts[i] = 0;
     int idx[8];
@@ -91,6 +93,8 @@ void ransac_solve_lanes1_qr(const float *__restrict__ X0, const float *__restric
     normalize_E(E);
 #pragma unroll
     for (int k = 0; k < 9; ++k) Ecand[9 * (size_t)i + k] = E[k];
+    // the operands of the matrix-core pre-filter for this hypothesis (prefilter_record.hpp), once for all tiles
+    if (recs) pf_prep_store(E, thr, __uint_as_float((uint32_t)(*bound_word & 0xFFFFFFFFull)), sc, recs + i);
 }
 
 // Two hypotheses per lane (2i, 2i+1): every mul / add / fma of the solver is a v_pk_*_f32.
@@ -99,11 +103,11 @@ __global__ __launch_bounds__(64)
 void ransac_solve_lanes2(const float *__restrict__ X0, const float *__restrict__ X1, int ld, int n,
                          const int32_t *__restrict__ indices, uint32_t seed, uint32_t h0, uint32_t count,
                          int sweeps, float *__restrict__ Ecand, unsigned long long *zero_key, unsigned long long *zero_key2,
-                         int *__restrict__ zero_counts, uint32_t *__restrict__ zero_ticks, const float4 *__restrict__ pts4)
+                         int *__restrict__ zero_counts, uint32_t *__restrict__ zero_ticks, uint32_t nzero, const float4 *__restrict__ pts4)
 {
     reset_keys(zero_key, zero_key2);
     const uint32_t i = 2u * (blockIdx.x * blockDim.x + threadIdx.x);
-    if (zero_ticks && (i >> 1) < (count + 63u) / 64u) zero_ticks[i >> 1] = 0u;          // the pre-filter kernel's per-group tickets
+    if (zero_ticks && (i >> 1) < nzero) zero_ticks[i >> 1] = 0u;          // the pre-filter kernel's per-group tickets
     if (i >= count) return;
     const uint32_t j = (i + 1 < count) ? i + 1 : i;         // odd count: the last lane solves its hypothesis twice
     if (zero_counts) { zero_counts[i] = 0; zero_counts[j] = 0; }   // tile-parallel scoring accumulates into counts[] with atomics
@@ -261,6 +265,9 @@ void ransac_argmax_counts(const int *__restrict__ counts, uint32_t h0, uint32_t 
 // ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
+// tickets of the pre-filter kernel: one per 32-hypothesis group
+static size_t tick_words(size_t count) { return count / kPfGroup + 2; }
+
 static int ensure_hyp_capacity(sfm_pair *pair, size_t count)
 {
     if (count <= pair->cap_hyps) return SFM_OK;
@@ -268,8 +275,10 @@ static int ensure_hyp_capacity(sfm_pair *pair, size_t count)
     if (pair->d_counts) (void)hipFree(pair->d_counts);
     if (pair->d_Ecand) (void)hipFree(pair->d_Ecand);
     if (pair->d_tick) (void)hipFree(pair->d_tick);
-    pair->d_counts = nullptr; pair->d_Ecand = nullptr; pair->d_tick = nullptr; pair->cap_hyps = 0;
-    SFM_HIP_TRY(hipMalloc(&pair->d_tick, (count / 64 + 2) * sizeof(uint32_t)));
+    if (pair->d_pf) (void)hipFree(pair->d_pf);
+    pair->d_counts = nullptr; pair->d_Ecand = nullptr; pair->d_tick = nullptr; pair->d_pf = nullptr; pair->cap_hyps = 0;
+    SFM_HIP_TRY(hipMalloc(&pair->d_tick, tick_words(count) * sizeof(uint32_t)));
+    SFM_HIP_TRY(hipMalloc(&pair->d_pf, count * sizeof(PfRecord)));
     SFM_HIP_TRY(hipMalloc(&pair->d_counts, count * sizeof(int)));
     SFM_HIP_TRY(hipMalloc(&pair->d_Ecand, count * 9 * sizeof(float)));
     pair->cap_hyps = count;
@@ -363,28 +372,48 @@ int launch_ransac_score(sfm_pair *pair, const sfm_ransac_params &p, uint32_t h0,
     if (timed) SFM_HIP_TRY(hipEventRecord(tev[0], ctx->stream));
     int *zero_counts = (grid2d || prefilter) ? pair->d_counts : nullptr;
     const float4 *pts4 = (pair->have_pts4 && p.reserved[0] != 4) ? pair->d_pts4 : nullptr;      // (reserved[0] == 4: scattered gathers, A/B)
+    // pre-filter kernel: tickets (one per 32-hypothesis group), cleared by the solve kernel's first threads (or by a memset
+    // when there are fewer threads than words); its per-hypothesis records come from the lane-solve kernel itself on the
+    // default path, from pf_prep_kernel otherwise
+    const bool pf_r2 = prefilter && p.reserved[3] == 2;                   // the round-2 kernel (A/B): builds its operands itself
+    const uint32_t nzero = prefilter ? (count + (uint32_t)kPfGroup - 1u) / (uint32_t)kPfGroup : 0u;
+    uint32_t *zero_ticks = prefilter ? pair->d_tick : nullptr;
+    if (prefilter && (d_E_given || nzero > count / 2u)) {
+        SFM_HIP_TRY(hipMemsetAsync(pair->d_tick, 0, (size_t)nzero * sizeof(uint32_t), ctx->stream));
+        zero_ticks = nullptr;
+    }
+    PfScales pf_sc = {};
+    if (prefilter) (void)prefilter_scales(p.threshold, pf_sc);            // (checked by prefilter_usable)
+    bool need_prep = prefilter && !pf_r2;
     if (d_E_given) {                 // caller-supplied candidates (sfm_ransac_score_candidates): no solve, clear what it would have cleared
         SFM_HIP_TRY(hipMemcpyAsync(pair->d_Ecand, d_E_given, (size_t)count * 9 * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
         if (zero_counts) SFM_HIP_TRY(hipMemsetAsync(pair->d_counts, 0, (size_t)count * sizeof(int), ctx->stream));
-        if (prefilter) SFM_HIP_TRY(hipMemsetAsync(pair->d_tick, 0, ((size_t)count / 64 + 2) * sizeof(uint32_t), ctx->stream));
     }
     else if (p.reserved[0] == 1)     // A/B switch: one hypothesis per lane (scalar math)
         hipLaunchKernelGGL(ransac_solve_lanes, dim3((count + 63) / 64), dim3(64), 0, ctx->stream,
                            pair->d_X[0], pair->d_X[1], pair->ld, pair->n, p.d_indices, p.seed, h0, count,
-                           p.jacobi_sweeps, pair->d_Ecand, pair->d_key, key2, zero_counts, prefilter ? pair->d_tick : nullptr);
-    else if (p.jacobi_sweeps <= 0 && (p.reserved[0] == 3 || (p.reserved[0] == 0 && (pts4 != nullptr || count <= kScalarSolveMax))))     // one hypothesis per lane
+                           p.jacobi_sweeps, pair->d_Ecand, pair->d_key, key2, zero_counts, zero_ticks, nzero);
+    else if (p.jacobi_sweeps <= 0 && (p.reserved[0] == 3 || (p.reserved[0] == 0 && (pts4 != nullptr || count <= kScalarSolveMax)))) {     // one hypothesis per lane
+        const bool fuse = need_prep && p.reserved[3] != 3;                // (reserved[3] == 3: records from the stand-alone kernel, A/B)
         hipLaunchKernelGGL(ransac_solve_lanes1_qr, dim3((count + 63) / 64), dim3(64), 0, ctx->stream,
                            pair->d_X[0], pair->d_X[1], pair->ld, pair->n, p.d_indices, p.seed, h0, count,
-                           p.jacobi_sweeps, pair->d_Ecand, pair->d_key, key2, zero_counts, prefilter ? pair->d_tick : nullptr, pts4);
+                           p.jacobi_sweeps, pair->d_Ecand, pair->d_key, key2, zero_counts, zero_ticks, nzero, pts4,
+                           fuse ? reinterpret_cast<PfRecord *>(pair->d_pf) : nullptr, p.threshold, pf_sc, pair->d_bound);
+        if (fuse) need_prep = false;
+    }
     else if (p.jacobi_sweeps <= 0)   // default: two hypotheses per lane (packed math), Householder instantiation
         hipLaunchKernelGGL(ransac_solve_lanes2<true>, dim3((count + 127) / 128), dim3(64), 0, ctx->stream,
                            pair->d_X[0], pair->d_X[1], pair->ld, pair->n, p.d_indices, p.seed, h0, count,
-                           p.jacobi_sweeps, pair->d_Ecand, pair->d_key, key2, zero_counts, prefilter ? pair->d_tick : nullptr, pts4);
+                           p.jacobi_sweeps, pair->d_Ecand, pair->d_key, key2, zero_counts, zero_ticks, nzero, pts4);
     else
         hipLaunchKernelGGL(ransac_solve_lanes2<false>, dim3((count + 127) / 128), dim3(64), 0, ctx->stream,
                            pair->d_X[0], pair->d_X[1], pair->ld, pair->n, p.d_indices, p.seed, h0, count,
-                           p.jacobi_sweeps, pair->d_Ecand, pair->d_key, key2, zero_counts, prefilter ? pair->d_tick : nullptr, pts4);
+                           p.jacobi_sweeps, pair->d_Ecand, pair->d_key, key2, zero_counts, zero_ticks, nzero, pts4);
     SFM_HIP_TRY(hipGetLastError());
+    if (need_prep) {
+        const int rcp = launch_pf_prep(pair, p, count);
+        if (rcp != SFM_OK) return rcp;
+    }
     if (timed) SFM_HIP_TRY(hipEventRecord(tev[1], ctx->stream));
 
     // unit-z layout: fixed 64 KiB (two arrays of kTileMax/2 pair records); generic: 24 B per point
@@ -407,7 +436,8 @@ int launch_ransac_score(sfm_pair *pair, const sfm_ransac_params &p, uint32_t h0,
         if ((uint32_t)grid > nbatch) grid = (int)nbatch;
     }
     if (prefilter) {
-        rc = launch_score_prefilter(pair, p, h0, count, key2);      // arg-max included (per-group tickets)
+        rc = pf_r2 ? launch_score_prefilter_r2(pair, p, h0, count, key2)
+                   : launch_score_prefilter(pair, p, h0, count, key2);      // arg-max included (per-group tickets)
     }
     else if (kernel == SFM_KERNEL_MFMA) {
         rc = launch_score_mfma(pair, p, h0, count);

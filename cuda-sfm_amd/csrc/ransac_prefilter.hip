@@ -5,19 +5,25 @@
 // (device_math.hpp residual / inlier_filter) -- but only for the ~1 % of the pairs that a conservative test on the
 // matrix cores cannot rule out.  prefilter_math.hpp has the rule and its proof obligations.
 //
-// One block = 16 wavefronts sharing one tile of 1024 points, staged ONCE in LDS: fp16 feature fragments (the B operands
-// of v_mfma_f32_32x32x16_f16, 96 bytes per point) and the plain coordinates for the exact test (16 bytes per point).
-// A wavefront prepares the coefficient fragments (A operands) of 64 hypotheses at a time, one hypothesis per lane, and
-// hands them to the two 32-row blocks through a half-wave exchange (v_permlane32_swap); for each 32-row block it walks the tile in 32-point
-// steps:
-//     3 x ds_read_b128 -> 3 MFMAs (G: 1, nt: 2) -> per accumulator v_fma (G - nt^2), v_alignbit (its sign bit) (no branch)
-// which leaves every lane with a 16-bit "rejected" mask of its 16 pairs.  Lanes with a surviving pair append one word to
-// the wavefront's ring in LDS (two 32-point steps share one append); 64 entries at a time go through the exact filter, one entry per lane, and inliers bump the
-// hypothesis' counter in LDS.  Tiles are spread over blockIdx.y; partial counts reach counts[] through integer atomics
-// (order-independent, so the result is deterministic); the wavefront that adds the last tile of a hypothesis group folds its
-// keys into the shard's arg-max key.
+// Round-3 arrangement (the round-2 kernel is kept as ransac_prefilter_r2.hip for A/B runs):
+//   * the per-hypothesis operands (48 fp16 coefficient slots in MFMA A-fragment order + the keys of the grid cells in which
+//     the first divisor can vanish) are built ONCE per hypothesis by pf_prep_store (prefilter_record.hpp; fused into the
+//     lane-solve kernel, or a small kernel of its own) with a bound B over ALL points, not once per (hypothesis, tile)
+//     inside the scoring kernel;
+//   * a block = 16 wavefronts sharing one tile of 1024 points staged once in LDS (fp16 feature fragments, 96 bytes per
+//     point, the three fragments of a 32-point block contiguous; plain coordinates, 16 bytes per point);
+//   * a wavefront takes 32 hypotheses per pass -- first pass by position, further passes from a per-tile counter (the
+//     blocks of a tile finish together whatever their survivor counts were) -- and walks the tile in 32-point steps:
+//         3 x ds_read_b128 -> 3 MFMAs (G: 1, nt: 2) -> per accumulator v_fma (G - nt^2), v_alignbit (its sign bit)
+//     software-pipelined by hand: while the vector unit scans the accumulators of step k, the matrix cores work on step
+//     k + 1 and the fragments of step k + 2 are on their way from LDS (two accumulator sets, sched_group_barrier);
+//   * lanes with a surviving pair append one word per two steps to the wavefront's ring in LDS; 64 entries at a time go
+//     through the exact filter, one entry per lane, and inliers bump the hypothesis' counter in LDS;
+//   * partial counts reach counts[] through integer atomics (order-independent, so the result is deterministic); the
+//     wavefront that adds the last tile of a 32-hypothesis group folds its keys into the shard's arg-max key.
 #include "ransac_device.hpp"
 #include "prefilter_math.hpp"
+#include "prefilter_record.hpp"
 
 namespace sfm {
 
@@ -25,20 +31,18 @@ constexpr int kPfTile = 1024;            // points per tile
 constexpr int kPfWaves = 16;
 constexpr int kPfRing = 128;             // survivor ring entries (8 bytes) per wavefront: < 64 waiting + 64 appended per step;
                                          // a flush re-queues at most 64 more, onto slots its own 64 entries have just left
-typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef float f16v __attribute__((ext_vector_type(16)));
-typedef int i4v __attribute__((ext_vector_type(4)));
 
 // LDS map
-constexpr int kPfLdsBn = 0;                                   // [32-point block][k-step 0..1][lane][8 fp16]
-constexpr int kPfLdsBt = kPfLdsBn + kPfTile * 64;             // [32-point block][lane][8 fp16]
-constexpr int kPfLdsPts = kPfLdsBt + kPfTile * 32;            // float4 (x1x, x1y, x2x, x2y) per point
+constexpr int kPfBlockBytes = 3 * 64 * 16;                    // one 32-point block: [n k-step 0 | n k-step 1 | G][lane][8 fp16]
+constexpr int kPfLdsFrag = 0;
+constexpr int kPfLdsPts = kPfLdsFrag + (kPfTile / 32) * kPfBlockBytes;     // float4 (x1x, x1y, x2x, x2y) per point
 constexpr int kPfLdsWave = kPfLdsPts + kPfTile * 16;          // per wavefront: E table 32 x 9 floats, 32 counters, ring
 constexpr int kPfWaveBytes = 32 * 9 * 4 + 32 * 4 + kPfRing * 8;
-constexpr int kPfLdsBound = kPfLdsWave + kPfWaves * kPfWaveBytes;
 constexpr int kPfHashSlots = 2048;                             // occupied grid cells of the tile (<= 1024 keys): open addressing, 0 = empty
-constexpr int kPfLdsHash = kPfLdsBound + 16;
-constexpr int kPfLdsBytes = kPfLdsHash + kPfHashSlots * 4;
+constexpr int kPfLdsHash = kPfLdsWave + kPfWaves * kPfWaveBytes;
+constexpr int kPfLdsNext = kPfLdsHash + kPfHashSlots * 4;       // the block's pass counter
+constexpr int kPfLdsBytes = kPfLdsNext + 16;
 static_assert(kPfLdsBytes <= 160 * 1024, "one block must fit the CU's LDS");
 
 // rejected = (rejected << 1) | sign(G - nt^2): v_fma_f32 with a negated operand and v_alignbit_b32.  Plain C++ (no inline
@@ -48,73 +52,58 @@ __device__ __forceinline__ uint32_t shift_in_reject(uint32_t rejected, float nt,
     return __builtin_amdgcn_alignbit(rejected, __float_as_uint(fmaf(-nt, nt, G)), 31);
 }
 
-// Coefficient fragments of both 32-row blocks from what every lane prepared for ITS hypothesis: xs = k-slots 0..7 (what
-// MFMA lanes 0..31 hold), ys = k-slots 8..15 (lanes 32..63).  v_permlane32_swap exchanges lanes 32..63 of its first
-// operand with lanes 0..31 of its second: afterwards the first holds { x of hypotheses 0..31 | y of hypotheses 0..31 } --
-// the A fragment of block 0 -- and the second { x of 32..63 | y of 32..63 } -- block 1.  One instruction per dword.
-__device__ __forceinline__ void fetch_fragments(const h8 &xs, const h8 &ys, h8 &f0, h8 &f1)
+__device__ __forceinline__ uint32_t scan16(const f16v &nt, const f16v &G)
 {
-    const i4v xi = __builtin_bit_cast(i4v, xs), yi = __builtin_bit_cast(i4v, ys);
-    i4v o0, o1;
+    uint32_t rejected = 0u;
 #pragma unroll
-    for (int d = 0; d < 4; ++d) {
-        const auto r = __builtin_amdgcn_permlane32_swap((unsigned int)xi[d], (unsigned int)yi[d], false, false);
-        o0[d] = (int)r[0]; o1[d] = (int)r[1];
-    }
-    f0 = __builtin_bit_cast(h8, o0);
-    f1 = __builtin_bit_cast(h8, o1);
+    for (int r = 0; r < 16; ++r) rejected = shift_in_reject(rejected, nt[r], G[r]);
+    return rejected;                        // < 2^16: sixteen bits shifted into 0
 }
 
-// LDS through address-space-3 pointers: pf_flush is a real call (three sites), and plain pointers passed into it would be
-// generic ones -- flat loads / stores / atomics instead of ds_* instructions.
+// LDS through address-space-3 pointers (ds_* instructions, immediate offsets)
 typedef uint32_t u2v __attribute__((ext_vector_type(2)));
 typedef float f4v __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) u2v lds_u2;
 typedef __attribute__((address_space(3))) const f4v lds_cf4;
 typedef __attribute__((address_space(3))) const float lds_cf;
 typedef __attribute__((address_space(3))) int lds_i;
+typedef __attribute__((address_space(3))) const h8 lds_ch8;
 
-// Exact decision for up to 64 ring entries starting at `head`, one entry per lane: the lane evaluates the FIRST surviving
-// pair of its entry; an entry that holds more goes back to the tail of the ring with the rest of its mask, so that every
-// pass of the exact filter runs on (nearly) 64 busy lanes.  Returns the number of re-queued entries.
-// entry = { 32-bit mask of surviving accumulators (bit 31 - r: accumulator r of the pair's first point block, bit 15 - r:
-// of its second), (point-block pair << 6) | lane }.
-__device__ __noinline__ int pf_flush(lds_u2 *ring, int head, int nent, int tail, int lane, lds_cf *etab, lds_i *cnt,
-                                     lds_cf4 *pts, int nvalid_hyp, ThrBand band)
+struct PfFrags { h8 n0, n1, t; };
+
+__device__ __forceinline__ PfFrags load_point_frags(lds_ch8 *frag_lane, int pb)
 {
-    uint32_t rest = 0, tag = 0;
-    if (lane < nent) {
-        const u2v ent = ring[(head + lane) & (kPfRing - 1)];
-        tag = ent.y;
-        const uint32_t surv = ent.x;
-        rest = surv & (surv - 1);
-        const int b = __builtin_ctz(surv);
-        const int r = 15 - (b & 15);
-        const int l = tag & 63, pb = 2 * (int)(tag >> 6) + ((b >> 4) ^ 1);
-        const int hl = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);               // accumulator row = local hypothesis
-        if (hl < nvalid_hyp) {
-            const f4v q = pts[pb * 32 + (l & 31)];
-            lds_cf *e = etab + 9 * hl;
-            const Ess E{ e[0], e[1], e[2], e[3], e[4], e[5], e[6], e[7], e[8] };
-            bool und;
-            bool in = inlier_filter(E, band, q.x, q.y, 1.0f, q.z, q.w, 1.0f, und);
-            if (und) in = residual(E, q.x, q.y, 1.0f, q.z, q.w, 1.0f) < band.thr;
-            if (in) __hip_atomic_fetch_add(cnt + hl, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-    }
-    const unsigned long long more = __ballot(rest != 0u);
-    if (more) {
-        const int slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(more >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)more, 0u));
-        if (rest) ring[(tail + slot) & (kPfRing - 1)] = u2v{ rest, tag };
-    }
-    return __builtin_popcountll(more);
+    lds_ch8 *p = frag_lane + pb * (kPfBlockBytes / 16);
+    return PfFrags{ p[0], p[64], p[128] };
 }
+
+__device__ __forceinline__ void mfma_step(const PfFrags &a, const PfFrags &b, f16v &G, f16v &nt)
+{
+    const f16v z = {};
+    nt = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.n0, b.n0, z, 0, 0, 0);
+    G = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.t, b.t, z, 0, 0, 0);
+    nt = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.n1, b.n1, nt, 0, 0, 0);
+}
+
+// One step's worth of issue order: one MFMA followed by a third of the scan, three times (0x008 = MFMA, 0x002 = VALU); the
+// LDS reads of the step after next are pinned in front of it by a scheduling barrier (their results must not share
+// registers with the accumulators being scanned, or the reads could only be issued after the scan).
+#define PF_SCHED_STEP()                                                 \
+    do {                                                                \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);              \
+        __builtin_amdgcn_sched_group_barrier(0x002, 11, 0);             \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);              \
+        __builtin_amdgcn_sched_group_barrier(0x002, 11, 0);             \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);              \
+        __builtin_amdgcn_sched_group_barrier(0x002, 11, 0);             \
+    } while (0)
 
 __global__ __launch_bounds__(kPfWaves * 64)
 void ransac_score_prefilter(const float *__restrict__ X0, const float *__restrict__ X1, int ld, int n,
-                            const float *__restrict__ Ecand, uint32_t h0, uint32_t count, float thr, PfScales sc,
-                            int *__restrict__ counts, uint32_t *__restrict__ tick, unsigned long long *best_key,
-                            unsigned long long *best_key2, unsigned long long *__restrict__ clk)
+                            const float *__restrict__ Ecand, const PfRecord *__restrict__ recs, uint32_t h0, uint32_t count, float thr,
+                            const unsigned long long *__restrict__ bound_word, int dynamic,
+                            int *__restrict__ counts, uint32_t *__restrict__ tick,
+                            unsigned long long *best_key, unsigned long long *best_key2, unsigned long long *__restrict__ clk)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
@@ -122,228 +111,269 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
     const bool probe = clk && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0;
     unsigned long long c0 = 0, w0 = 0;
     if (probe) { c0 = clock64(); w0 = wall_clock64(); }
-    // the candidates of this wavefront's first pass: requested before the tile is staged, so that their way through the
-    // memory system overlaps the staging instead of the first coefficient preparation
-    const uint32_t npass = (count + 63u) / 64u;
-    const uint32_t ps_first = blockIdx.x * kPfWaves + wave;
-    float e_first[9];
-    {
-        const uint32_t hf = min(ps_first, npass - 1u) * 64u;
-        const float *src = Ecand + 9 * (size_t)(hf + (uint32_t)min(lane, (int)min(64u, count - hf) - 1));
-#pragma unroll
-        for (int k = 0; k < 9; ++k) e_first[k] = src[k];
+    // trace (sfm_ransac_last_trace): start / end stamps of every block and wavefront, a handful of stores per block
+    const uint32_t trace_blk = blockIdx.y * gridDim.x + blockIdx.x;
+    unsigned long long *trace = (clk && trace_blk < (uint32_t)kTraceBlocks) ? clk + 8 + (size_t)trace_blk * kTraceWords : nullptr;
+    if (trace && threadIdx.x == 0) {
+        trace[0] = wall_clock64();
+        trace[2] = ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32) |   // HW_REG_XCC_ID
+                   (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));             // HW_REG_HW_ID
+        trace[3] = ((unsigned long long)blockIdx.y << 32) | blockIdx.x;
     }
-    // ... and parked in the wavefront's own LDS area (64 x 9 floats = exactly the E table + counters + ring, all unused
-    // until the first pass starts) so that they do not occupy registers while the tile is staged
-    float *park = reinterpret_cast<float *>(smem + kPfLdsWave + wave * kPfWaveBytes);
-    static_assert(kPfWaveBytes >= 64 * 9 * 4, "the first pass' candidates are parked in the wavefront's LDS area");
+    const int half = lane >> 5, row = lane & 31;
+    const uint32_t npass = (count + (uint32_t)kPfGroup - 1u) / (uint32_t)kPfGroup;
+    const uint32_t nstatic = gridDim.x * (uint32_t)kPfWaves;             // passes handed out by position
+    float *etab = reinterpret_cast<float *>(smem + kPfLdsWave + wave * kPfWaveBytes);
+    int *cnt = reinterpret_cast<int *>(etab + 32 * 9);
+
+    // Operands of hypothesis (32 ps + row): this lane's half of the three A fragments, its two cell keys, and (lanes 0..31)
+    // its E row.  Rows beyond the range repeat the last hypothesis (never counted).
+    PfFrags afrag = {};
+    uint32_t key0 = 0u, key1 = 0u;
+    float e_row[9] = {};
+    auto fetch_pass = [&](uint32_t pass, PfFrags &af, uint32_t &k0, uint32_t &k1, float (&e)[9]) {
+        const uint32_t hf = pass * (uint32_t)kPfGroup;
+        const uint32_t h = hf + (uint32_t)min(row, (int)min((uint32_t)kPfGroup, count - hf) - 1);
+        const PfRecord *r = recs + h;
+        af.n0 = r->frag[0 + half]; af.n1 = r->frag[2 + half]; af.t = r->frag[4 + half];
+        k0 = r->keys[2 * half]; k1 = r->keys[2 * half + 1];
+        if (half == 0) {
+            const float *src = Ecand + 9 * (size_t)h;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) e[k] = src[k];
+        }
+    };
+    auto install_rows = [&](const float (&e)[9]) {          // E table and counters of a pass (the previous pass' ring is drained, its counters are out)
+        if (half == 0) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) etab[9 * row + k] = e[k];
+            cnt[row] = 0;
+        }
+    };
+    // the first pass' operands are requested before the tile is staged: their way through the memory system overlaps it
+    uint32_t ps = blockIdx.x * (uint32_t)kPfWaves + (uint32_t)wave;
+    bool have = ps < npass;
+    if (have) { fetch_pass(ps, afrag, key0, key1, e_row); install_rows(e_row); }
+
     // ---- stage the tile: one point per thread -> 48 fp16 feature slots in MFMA B-fragment order + its coordinates
-    unsigned int &tile_bound = *reinterpret_cast<unsigned int *>(smem + kPfLdsBound);
+    const float B = __uint_as_float((uint32_t)(*bound_word & 0xFFFFFFFFull));      // bound over all points (fill_xu_kernel)
+    const PfGrid grid = prefilter_grid(B);
     uint32_t *cells = reinterpret_cast<uint32_t *>(smem + kPfLdsHash);
-    if (threadIdx.x == 0) tile_bound = 0u;
     for (int k = threadIdx.x; k < kPfHashSlots; k += kPfWaves * 64) cells[k] = 0u;
+    // The passes of a block -- (16 j + w) for wavefront slot w of its j-th iteration -- are handed out through a counter in
+    // LDS: the wavefronts of a block do not advance at the same rate (the oldest wavefront of a SIMD wins its arbitration:
+    // with one fixed share each, the first finished 230 us before the last of a 630 us launch, profiles/r03_trace_*.txt),
+    // and with first-come-first-served shares they finish within one pass of each other.  (One counter per tile in global
+    // memory would balance the blocks too, but 131072 device-scope atomics on one address take 1.5 ms.)
+    uint32_t *next_idx = reinterpret_cast<uint32_t *>(smem + kPfLdsNext);
+    if (threadIdx.x == 0) *next_idx = (uint32_t)kPfWaves;
     __syncthreads();
     const int tile_first = blockIdx.y * kPfTile;
-    float px = 0.f, py = 0.f;
-    bool hashed = false;
     {
         const int t = threadIdx.x;
         const int p = tile_first + t;
         float u = 0.f, v = 0.f, x = 0.f, y = 0.f;
         const bool real = p < n;
         if (real) { u = X0[p]; v = X0[(size_t)ld + p]; x = X1[p]; y = X1[(size_t)ld + p]; }
-#pragma unroll
-        for (int k = 0; k < 9; ++k) park[k * 64 + lane] = e_first[k];           // (issued before the coordinates: arrives first)
         _Float16 bn[kPfSlots], bt[kPfSlotsT];
         prefilter_point_slots(u, v, x, y, real, bn, bt);
         const float big = fmaxf(fmaxf(fabsf(u), fabsf(v)), fmaxf(fabsf(x), fabsf(y)));
-        if (big <= 48.0f) atomicMax(&tile_bound, __float_as_uint(big));       // points beyond that carry no features (prefilter_point_slots)
-        hashed = real && big <= 48.0f && u == u && v == v && x == x && y == y;     // the points the pre-filter can reject at all
-        px = x; py = y;
+        // the points the pre-filter can reject at all (the others carry no features: prefilter_point_slots)
+        const bool hashed = real && big <= 48.0f && u == u && v == v && x == x && y == y;
         // padding reads as NaN in the exact test (it is always rejected before; NaN never counts)
         reinterpret_cast<float4 *>(smem + kPfLdsPts)[t] = real ? make_float4(u, v, x, y) : make_float4(NAN, NAN, NAN, NAN);
         const int pb = t >> 5, col = t & 31;
+        unsigned char *blk = smem + kPfLdsFrag + pb * kPfBlockBytes;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-            for (int half = 0; half < 2; ++half) {
+            for (int hh = 0; hh < 2; ++hh) {
                 h8 c;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) c[j] = bn[ks * 16 + half * 8 + j];
-                *reinterpret_cast<h8 *>(smem + kPfLdsBn + (((pb * 2 + ks) * 2 + half) * 32 + col) * 16) = c;
+                for (int j = 0; j < 8; ++j) c[j] = bn[ks * 16 + hh * 8 + j];
+                *reinterpret_cast<h8 *>(blk + ks * 1024 + (hh * 32 + col) * 16) = c;
             }
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
+        for (int hh = 0; hh < 2; ++hh) {
             h8 c;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) c[j] = bt[half * 8 + j];
-            *reinterpret_cast<h8 *>(smem + kPfLdsBt + ((pb * 2 + half) * 32 + col) * 16) = c;
+            for (int j = 0; j < 8; ++j) c[j] = bt[hh * 8 + j];
+            *reinterpret_cast<h8 *>(blk + 2048 + (hh * 32 + col) * 16) = c;
+        }
+        // the occupied cells of the zero-divisor grid (prefilter_math.hpp (3)); its pitch follows the bound
+        if (hashed) {
+            const uint32_t key = pf_cell_key(pf_cell(x, grid), pf_cell(y, grid));
+            uint32_t sl = (key >> 8) & (kPfHashSlots - 1);
+            for (;;) {
+                const uint32_t old = atomicCAS(&cells[sl], 0u, key);
+                if (old == 0u || old == key) break;
+                sl = (sl + 1) & (kPfHashSlots - 1);
+            }
         }
     }
     __syncthreads();
-    const float B = __uint_as_float(tile_bound);
     if (probe) clk[2] = wall_clock64() - w0;
-    // the occupied cells of the zero-divisor grid (prefilter_math.hpp (3)); its pitch follows the tile's bound
-    const PfGrid grid = prefilter_grid(B);
-    if (hashed) {
-        const uint32_t key = pf_cell_key(pf_cell(px, grid), pf_cell(py, grid));
-        uint32_t sl = (key >> 8) & (kPfHashSlots - 1);
-        for (;;) {
-            const uint32_t old = atomicCAS(&cells[sl], 0u, key);
-            if (old == 0u || old == key) break;
-            sl = (sl + 1) & (kPfHashSlots - 1);
-        }
-    }
-    __syncthreads();
     const int npb = (min(kPfTile, ld - tile_first) + 31) >> 5;           // 32-point blocks that hold points or padding
-    float *etab = reinterpret_cast<float *>(smem + kPfLdsWave + wave * kPfWaveBytes);
-    int *cnt = reinterpret_cast<int *>(etab + 32 * 9);
+    const int npp = (npb + 1) >> 1;                                      // two 32-point blocks per iteration (a block beyond npb holds padding only: all rejected)
+    const int last_pb = kPfTile / 32 - 1;
     const float4 *pts = reinterpret_cast<const float4 *>(smem + kPfLdsPts);
     lds_cf *etab_l = (lds_cf *)etab;
     lds_i *cnt_l = (lds_i *)cnt;
     lds_u2 *ring = (lds_u2 *)(cnt + 32);
     lds_cf4 *pts_l = (lds_cf4 *)pts;
+    lds_ch8 *frag_lane = (lds_ch8 *)(smem + kPfLdsFrag) + lane;
     const ThrBand band = make_band(thr);
-    const h8 *bn_l = reinterpret_cast<const h8 *>(smem + kPfLdsBn) + lane;
-    const h8 *bt_l = reinterpret_cast<const h8 *>(smem + kPfLdsBt) + lane;
-    const int half = lane >> 5, row = lane & 31;
+    uint32_t passes_done = 0;
 
-    // ---- 64 hypotheses per pass of this wavefront (no block-level synchronisation from here on)
-    for (uint32_t ps = ps_first; ps < npass; ps += gridDim.x * kPfWaves) {
-        const uint32_t h_first = ps * 64u;
-        const int nvalid64 = (int)min(64u, count - h_first);
-        // coefficient slots: lane l prepares hypothesis h_first + l (lanes beyond the range repeat the last one)
-        float e[9];
-        if (ps == ps_first) {
-#pragma unroll
-            for (int k = 0; k < 9; ++k) e[k] = park[k * 64 + lane];
-        } else {
-            const float *src = Ecand + 9 * (size_t)(h_first + (uint32_t)min(lane, nvalid64 - 1));
-#pragma unroll
-            for (int k = 0; k < 9; ++k) e[k] = src[k];
+    // ---- 32 hypotheses per pass of this wavefront (no block-level synchronisation from here on)
+    while (have) {
+        const uint32_t h_first = ps * (uint32_t)kPfGroup;
+        const int nvalid = (int)min((uint32_t)kPfGroup, count - h_first);
+        const bool probe1 = probe && passes_done == 0u;
+        // the next pass of this wavefront: asked for now, needed when this one is done
+        uint32_t ps_next = ps + nstatic;
+        if (dynamic) {
+            uint32_t got = 0u;
+            if (lane == 0) got = atomicAdd(next_idx, 1u);
+            got = (uint32_t)__builtin_amdgcn_readfirstlane((int)got);
+            ps_next = (got / (uint32_t)kPfWaves) * nstatic + blockIdx.x * (uint32_t)kPfWaves + (got % (uint32_t)kPfWaves);
         }
-        // zero divisors (prefilter_math.hpp (3)): nearly every hypothesis is cleared by its 2 x 2 cells; the rest
-        // (~0.5 %) is checked against every point of the tile, one hypothesis at a time by the whole wavefront
-        bool survive_all = false;
+        // zero divisors (prefilter_math.hpp (3)): the record names the (at most 2 x 2) grid cells in which the first divisor of
+        // this hypothesis can vanish; nearly every hypothesis is cleared by finding them unoccupied, the rest (~0.5 %)
+        // is checked against every point of the tile, one hypothesis at a time by the whole wavefront
         {
-            int cx0, cx1, cy0, cy1;
-            int zs = prefilter_zero_divisor_cells(e, B, grid, cx0, cx1, cy0, cy1);
-            if (zs == 1) {
-                zs = 0;
-                for (int cy = cy0; cy <= cy1; ++cy)
-                    for (int cx = cx0; cx <= cx1; ++cx) {
-                        const uint32_t key = pf_cell_key(cx, cy);
-                        uint32_t sl = (key >> 8) & (kPfHashSlots - 1);
-                        for (;;) {
-                            const uint32_t got = cells[sl];
-                            if (got == key) zs = 2;
-                            if (got == key || got == 0u) break;
-                            sl = (sl + 1) & (kPfHashSlots - 1);
-                        }
-                    }
-            }
-            unsigned long long todo = __ballot(zs == 2);
-            while (todo) {
-                const int l = __builtin_ctzll(todo);
-                todo &= todo - 1;
-                float se[9];
+            bool scan = false;
+            if ((key0 | key1) != 0u) {
+                scan = key0 == kPfKeyScan;
+                const uint32_t kk[2] = { key0, key1 };
 #pragma unroll
-                for (int k = 0; k < 6; ++k) se[k] = __shfl(e[k], l);
+                for (int q = 0; q < 2; ++q) {
+                    const uint32_t key = kk[q];
+                    if (key == 0u || key == kPfKeyScan) continue;
+                    uint32_t sl = (key >> 8) & (kPfHashSlots - 1);
+                    for (;;) {
+                        const uint32_t got = cells[sl];
+                        if (got == key) scan = true;
+                        if (got == key || got == 0u) break;
+                        sl = (sl + 1) & (kPfHashSlots - 1);
+                    }
+                }
+            }
+            const unsigned long long sm = __ballot(scan);
+            uint32_t todo = (uint32_t)sm | (uint32_t)(sm >> 32);
+            uint32_t survive = 0u;                                      // rows whose pairs must all survive in this tile
+            while (todo) {
+                const int r = __builtin_ctz(todo);
+                todo &= todo - 1u;
+                float se[6];
+#pragma unroll
+                for (int k = 0; k < 6; ++k) se[k] = etab[9 * r + k];
                 bool z = false;
                 for (int j = 0; j < kPfTile / 64; ++j) {
                     const float4 q = pts[j * 64 + lane];
                     z = z || prefilter_zero_divisor(se, q.z, q.w);              // NaN padding never compares equal to 0
                 }
-                if (__ballot(z) != 0ull && lane == l) survive_all = true;
+                if (__ballot(z) != 0ull) survive |= 1u << r;
+            }
+            if (survive != 0u && ((survive >> row) & 1u)) {             // nt = 0, G = 2^-10 for real points (prefilter_hyp_slots)
+                const h8 zero = {};
+                afrag.n0 = zero; afrag.n1 = zero; afrag.t = zero;
+                if (half) { afrag.n1[3] = (_Float16)1.0f; afrag.t[7] = (_Float16)0.0009765625f; }      // k-slots 27 and 15
             }
         }
-        _Float16 ns[kPfSlots], ts[kPfSlotsT];
-        (void)prefilter_hyp_slots(e, thr, B, sc, ns, ts, survive_all);
-        const bool probe1 = probe && ps == 0u;
-        // X* = k-slots 0..7 of each 16-slot step (the fragment of MFMA lanes 0..31), Y* = k-slots 8..15 (lanes 32..63).
-        // Rows of block b were prepared by lanes 32 b .. 32 b + 31; MFMA lane l needs row l % 32, k-half l / 32.
-        h8 fn0[2], fn1[2], ft[2];
-        {
-            h8 xn0, yn0, xn1, yn1, xt, yt;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                xn0[j] = ns[j];      yn0[j] = ns[8 + j];
-                xn1[j] = ns[16 + j]; yn1[j] = ns[24 + j];
-                xt[j] = ts[j];       yt[j] = ts[8 + j];
-            }
-            fetch_fragments(xn0, yn0, fn0[0], fn0[1]);
-            fetch_fragments(xn1, yn1, fn1[0], fn1[1]);
-            fetch_fragments(xt, yt, ft[0], ft[1]);
-        }
-#pragma unroll
-        for (int blk = 0; blk < 2; ++blk) {
-            const int nvalid = min(32, nvalid64 - 32 * blk);
-            if (nvalid <= 0) break;
-            if (probe1 && blk == 0) clk[3] = wall_clock64() - w0;
-            const h8 an0 = fn0[blk], an1 = fn1[blk], at = ft[blk];
-            // E table and counters of this block (the previous block's ring is drained, its counters are flushed)
-            if (half == blk) {
-#pragma unroll
-                for (int k = 0; k < 9; ++k) etab[9 * row + k] = e[k];
-                cnt[row] = 0;
-            }
+        if (probe1) clk[3] = wall_clock64() - w0;
 
-            int head = 0, nq = 0;                       // ring state (wave-uniform)
-            const int npp = (npb + 1) >> 1;             // two 32-point blocks per iteration (a block beyond npb holds padding only: all rejected)
-            for (int pp = 0; pp < npp; ++pp) {
-                uint32_t rej[2];
-#pragma unroll
-                for (int sub = 0; sub < 2; ++sub) {
-                    const int pb = 2 * pp + sub;
-                    const h8 bt0 = bt_l[pb * 64];
-                    const h8 bn0 = bn_l[(pb * 2 + 0) * 64], bn1 = bn_l[(pb * 2 + 1) * 64];
-                    f16v accg = {}, accn = {};
-                    accg = __builtin_amdgcn_mfma_f32_32x32x16_f16(at, bt0, accg, 0, 0, 0);
-                    accn = __builtin_amdgcn_mfma_f32_32x32x16_f16(an0, bn0, accn, 0, 0, 0);
-                    accn = __builtin_amdgcn_mfma_f32_32x32x16_f16(an1, bn1, accn, 0, 0, 0);
-                    uint32_t rejected = 0u;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) rejected = shift_in_reject(rejected, accn[r], accg[r]);
-                    rej[sub] = rejected;                    // < 2^16: sixteen bits shifted into 0
-                }
-                const uint32_t rej32 = (rej[0] << 16) | rej[1];
-                const bool mine = rej32 != 0xFFFFFFFFu;
-                const unsigned long long any = __ballot(mine);
-                if (any) {
-                    while (nq >= 64) {                  // make room first
-                        const int back = pf_flush(ring, head, 64, head + nq, lane, etab_l, cnt_l, pts_l, nvalid, band);
-                        head = (head + 64) & (kPfRing - 1); nq += back - 64;
-                    }
-                    const int slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(any >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)any, 0u));
-                    if (mine) ring[(head + nq + slot) & (kPfRing - 1)] = u2v{ ~rej32, ((uint32_t)pp << 6) | (uint32_t)lane };
-                    nq += __builtin_popcountll(any);
+        // ---- the scan: two accumulator sets; while set A is scanned the MFMAs of the next step fill set B
+        int head = 0, nq = 0;                       // ring state (wave-uniform)
+        auto flush = [&](int m) {
+            // Exact decision for up to 64 ring entries starting at `head`, one entry per lane: the lane evaluates the FIRST
+            // surviving pair of its entry; an entry that holds more goes back to the tail of the ring with the rest of its
+            // mask, so that every pass of the exact filter runs on (nearly) 64 busy lanes.
+            // entry = { 32-bit mask of surviving accumulators (bit 31 - r: accumulator r of the pair's first point block,
+            // bit 15 - r: of its second), (point-block pair << 6) | lane }.
+            uint32_t rest = 0, tag = 0;
+            if (lane < m) {
+                const u2v ent = ring[(head + lane) & (kPfRing - 1)];
+                tag = ent.y;
+                const uint32_t surv = ent.x;
+                rest = surv & (surv - 1);
+                const int b = __builtin_ctz(surv);
+                const int r = 15 - (b & 15);
+                const int l = tag & 63, pb = 2 * (int)(tag >> 6) + ((b >> 4) ^ 1);
+                const int hl = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);               // accumulator row = local hypothesis
+                if (hl < nvalid) {
+                    const f4v q = pts_l[pb * 32 + (l & 31)];
+                    lds_cf *e = etab_l + 9 * hl;
+                    const Ess E{ e[0], e[1], e[2], e[3], e[4], e[5], e[6], e[7], e[8] };
+                    bool und;
+                    bool in = inlier_filter(E, band, q.x, q.y, 1.0f, q.z, q.w, 1.0f, und);
+                    if (und) in = residual(E, q.x, q.y, 1.0f, q.z, q.w, 1.0f) < band.thr;
+                    if (in) __hip_atomic_fetch_add(cnt_l + hl, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
             }
-            while (nq > 0) {
-                const int m = min(nq, 64);
-                const int back = pf_flush(ring, head, m, head + nq, lane, etab_l, cnt_l, pts_l, nvalid, band);
-                head = (head + m) & (kPfRing - 1); nq += back - m;
+            const unsigned long long more = __ballot(rest != 0u);
+            if (more) {
+                const int slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(more >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)more, 0u));
+                if (rest) ring[(head + nq + slot) & (kPfRing - 1)] = u2v{ rest, tag };
             }
-            if (probe1 && blk == 0) clk[4] = wall_clock64() - w0;
-            // LDS counters -> counts[] (zeroed by the solve kernel); a wavefront's LDS operations complete in order
-            if (lane < nvalid) {
-                const int c = cnt[lane];
-                if (c) atomicAdd(&counts[h_first + 32u * blk + lane], c);
+            head = (head + m) & (kPfRing - 1);
+            nq += __builtin_popcountll(more) - m;
+        };
+
+        PfFrags fa = load_point_frags(frag_lane, 0), fb = load_point_frags(frag_lane, 1);
+        f16v g0, n0, g1, n1;
+        mfma_step(afrag, fa, g0, n0);
+        for (int pp = 0; pp < npp; ++pp) {
+            // phase 1: matrix cores on step 2 pp + 1 (fragments fb), LDS on step 2 pp + 2, vector unit on step 2 pp
+            fa = load_point_frags(frag_lane, min(2 * pp + 2, last_pb));
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_step(afrag, fb, g1, n1);
+            const uint32_t rej_hi = scan16(n0, g0);
+            PF_SCHED_STEP();
+            __builtin_amdgcn_sched_barrier(0);
+            // phase 2: matrix cores on step 2 pp + 2 (fragments fa), LDS on step 2 pp + 3, vector unit on step 2 pp + 1
+            fb = load_point_frags(frag_lane, min(2 * pp + 3, last_pb));
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_step(afrag, fa, g0, n0);
+            const uint32_t rej_lo = scan16(n1, g1);
+            PF_SCHED_STEP();
+            __builtin_amdgcn_sched_barrier(0);
+            const uint32_t rej32 = (rej_hi << 16) | rej_lo;
+            const bool mine = rej32 != 0xFFFFFFFFu;
+            const unsigned long long any = __ballot(mine);
+            if (any) {
+                while (nq >= 64) flush(64);             // make room first (a flush of 64 entries re-queues up to 64: it may take more than one)
+                const int slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(any >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)any, 0u));
+                if (mine) ring[(head + nq + slot) & (kPfRing - 1)] = u2v{ ~rej32, ((uint32_t)pp << 6) | (uint32_t)lane };
+                nq += __builtin_popcountll(any);
             }
         }
-        // arg-max without a kernel of its own: the wavefront that contributes the LAST tile of these 64 hypotheses (ticket)
-        // reads their final counts and folds the best key into the shard's key (first maximum: highest count, lowest id)
-        // Ordering without __threadfence() (an agent-scope release fence writes this XCD's L2 back: 119 -> 190 us per
-        // launch): every datum involved is touched by device-scope atomics only, so it is enough that the count atomics
-        // have been acknowledged (vmcnt, which also tracks atomics without return on gfx9) before the ticket is issued;
-        // the reader's agent-scope atomic loads are issued after its ticket came back.
+        if (probe1) clk[4] = wall_clock64() - w0;
+        // the next pass' operands: requested now, they arrive while the ring is drained and the counts go out
+        const bool have_next = ps_next < npass;
+        PfFrags afrag_next = afrag;
+        uint32_t key0n = 0u, key1n = 0u;
+        if (have_next) fetch_pass(ps_next, afrag_next, key0n, key1n, e_row);
+        while (nq > 0) flush(min(nq, 64));
+        // LDS counters -> counts[] (zeroed by the solve kernel); a wavefront's LDS operations complete in order
+        if (lane < nvalid) {
+            const int c = cnt[lane];
+            if (c) atomicAdd(&counts[h_first + lane], c);
+        }
+        // arg-max without a kernel of its own: the wavefront that contributes the LAST tile of these 32 hypotheses (ticket)
+        // reads their final counts and folds the best key into the shard's key (first maximum: highest count, lowest id).
+        // Ordering: the counts are touched by device-scope atomics only (no cached copies to write back or invalidate), so
+        // it is enough that this wavefront's count atomics have been acknowledged (vmcnt also tracks atomics without return
+        // on gfx9) before its ticket is issued, and that the reader's atomic loads are issued after its ticket came back.
+        // A full release fence here writes this XCD's L2 back (119 -> 190 us per 131072-hypothesis launch, round 2);
+        // tests/test_gpu_prefilter.py::test_prefilter_tickets_under_contention exercises the assumption every round.
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         uint32_t t = 0;
         if (lane == 0) t = atomicAdd(&tick[ps], 1u);
         t = __builtin_amdgcn_readfirstlane(t);
         if (t == gridDim.y - 1) {
             unsigned long long k = 0;
-            if (lane < nvalid64) {
+            if (lane < nvalid) {
                 const int c = __hip_atomic_load(&counts[h_first + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 k = pack_key((uint32_t)c, h0 + h_first + (uint32_t)lane);
             }
@@ -358,26 +388,85 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
             }
         }
         if (probe1) clk[5] = wall_clock64() - w0;
-        if (probe) clk[6] = (unsigned long long)((ps - blockIdx.x * kPfWaves) / (gridDim.x * kPfWaves) + 1u);
+        ++passes_done;
+        // install the next pass
+        have = have_next;
+        if (have_next) {
+            ps = ps_next;
+            afrag = afrag_next; key0 = key0n; key1 = key1n;
+            install_rows(e_row);
+        }
     }
-    if (probe) { clk[0] = clock64() - c0; clk[1] = wall_clock64() - w0; }
+    if (probe) { clk[6] = passes_done; clk[0] = clock64() - c0; clk[1] = wall_clock64() - w0; }
+    if (trace && lane == 0) {
+        const unsigned long long tend = wall_clock64();
+        trace[4 + wave] = tend;
+        if (wave == 0) trace[1] = tend;
+    }
 }
 
-// Test probe (sfm_prefilter_probe): the operands of ONE (hypothesis, point) pair exactly as the kernel above builds them on
+// ---- per-hypothesis operands ------------------------------------------------------------------------------------------
+// Stand-alone kernel for the paths whose solve kernel does not build the records itself (caller-supplied candidates, the
+// packed / Jacobi solve kernels): one hypothesis per lane.
+__global__ __launch_bounds__(256)
+void pf_prep_kernel(const float *__restrict__ Ecand, uint32_t count, float thr, PfScales sc, const unsigned long long *__restrict__ bound_word,
+                    PfRecord *__restrict__ recs)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    float e[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) e[k] = Ecand[9 * (size_t)i + k];
+    const float B = __uint_as_float((uint32_t)(*bound_word & 0xFFFFFFFFull));
+    pf_prep_store(e, thr, B, sc, recs + i);
+}
+
+int launch_pf_prep(sfm_pair *pair, const sfm_ransac_params &p, uint32_t count)
+{
+    PfScales sc;
+    if (!prefilter_scales(p.threshold, sc)) { set_error("threshold %g outside the pre-filter's range", (double)p.threshold); return SFM_E_INVALID; }
+    hipLaunchKernelGGL(pf_prep_kernel, dim3((count + 255) / 256), dim3(256), 0, pair->ctx->stream,
+                       pair->d_Ecand, count, p.threshold, sc, pair->d_bound, reinterpret_cast<PfRecord *>(pair->d_pf));
+    SFM_HIP_TRY(hipGetLastError());
+    return SFM_OK;
+}
+
+// Test probe (sfm_prefilter_probe): the operands of ONE (hypothesis, point) pair exactly as the kernels above build them on
 // the device, and what the matrix cores return for them.  out: ns[32] | ts[16] | bn[32] | bt[16] | nt | G | rejected |
 // zero-divisor state (0 cleared, 1 cells to look up, 2 scan).  tests/test_gpu_prefilter.py compares it with the host build
-// of prefilter_math.hpp bit for bit.
+// of prefilter_math.hpp bit for bit.  The coefficient slots are read back from a PfRecord written by pf_prep_store, i.e.
+// through the very path the scoring kernel takes.
 __global__ __launch_bounds__(64)
 void pf_probe_kernel(const float *__restrict__ E, float thr, float B, PfScales sc, float u, float v, float x, float y, int survive_all,
-                     float *__restrict__ out)
+                     PfRecord *rec, float *__restrict__ out)
 {
     const int lane = threadIdx.x;
     const int half = lane >> 5;
     float e[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) e[k] = E[k];
+    if (lane == 0) pf_prep_store(e, thr, B, sc, rec);
+    __threadfence();
+    __syncthreads();
     _Float16 ns[kPfSlots], ts[kPfSlotsT], bn[kPfSlots], bt[kPfSlotsT];
-    (void)prefilter_hyp_slots(e, thr, B, sc, ns, ts, survive_all != 0);
+    const volatile PfRecord *vr = rec;
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ns[g * 16 + hh * 8 + j] = __builtin_bit_cast(_Float16, vr->raw[(2 * g + hh) * 8 + j]);
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ts[hh * 8 + j] = __builtin_bit_cast(_Float16, vr->raw[(4 + hh) * 8 + j]);
+    if (survive_all) {
+#pragma unroll
+        for (int k = 0; k < kPfSlots; ++k) ns[k] = (_Float16)0.0f;
+#pragma unroll
+        for (int k = 0; k < kPfSlotsT; ++k) ts[k] = (_Float16)0.0f;
+        ns[27] = (_Float16)1.0f; ts[15] = (_Float16)0.0009765625f;
+    }
     prefilter_point_slots(u, v, x, y, true, bn, bt);
     h8 an0, an1, at, b0, b1, b2;
 #pragma unroll
@@ -403,20 +492,25 @@ int launch_prefilter_probe(sfm_ctx *ctx, const float *d_E, float thr, float B, c
 {
     PfScales sc;
     if (!prefilter_scales(thr, sc)) { set_error("threshold %g outside the pre-filter's range", (double)thr); return SFM_E_INVALID; }
-    hipLaunchKernelGGL(pf_probe_kernel, dim3(1), dim3(64), 0, ctx->stream, d_E, thr, B, sc, pt[0], pt[1], pt[2], pt[3], survive_all, d_out);
+    // d_out: 128 floats of result followed by room for one PfRecord (the caller allocates 256 floats)
+    hipLaunchKernelGGL(pf_probe_kernel, dim3(1), dim3(64), 0, ctx->stream, d_E, thr, B, sc, pt[0], pt[1], pt[2], pt[3], survive_all,
+                       reinterpret_cast<PfRecord *>(d_out + 128), d_out);
     SFM_HIP_TRY(hipGetLastError());
     return SFM_OK;
 }
 
-// Conditions under which launch_ransac_score may pick this kernel: the unit-z layout (every z exactly 1), a threshold the
-// fp16 scaling covers, and enough work to fill the chip with 1024-hypothesis x 1024-point block iterations (measured
-// crossover against the plain wavefront kernel at 4096 points: between 16k and 32k hypotheses, profiles/r02_prefilter_ab.txt).
+// Conditions under which launch_ransac_score may pick this kernel: the unit-z layout (every z exactly 1) written by fillXU
+// (which also leaves the bound over all points), a threshold the fp16 scaling covers, and enough work to fill the chip with
+// 512-hypothesis x 1024-point block iterations (measured crossover against the plain wavefront kernel at 4096 points:
+// between 16k and 32k hypotheses, profiles/r02_prefilter_ab.txt).
 bool prefilter_usable(const sfm_pair *pair, const sfm_ransac_params &p, uint32_t count)
 {
     PfScales sc;
     const uint64_t ntiles = (uint64_t)((pair->ld + kPfTile - 1) / kPfTile);
-    return pair->unit_z && count >= 16384u && (uint64_t)count * ntiles >= 131072u && prefilter_scales(p.threshold, sc);
+    return pair->unit_z && pair->have_bound && count >= 16384u && (uint64_t)count * ntiles >= 131072u && prefilter_scales(p.threshold, sc);
 }
+
+int prefilter_tiles(const sfm_pair *pair) { return (pair->ld + kPfTile - 1) / kPfTile; }
 
 int launch_score_prefilter(sfm_pair *pair, const sfm_ransac_params &p, uint32_t h0, uint32_t count, unsigned long long *key2)
 {
@@ -425,19 +519,20 @@ int launch_score_prefilter(sfm_pair *pair, const sfm_ransac_params &p, uint32_t 
     if (!prefilter_scales(p.threshold, sc)) { set_error("threshold %g outside the pre-filter's range", (double)p.threshold); return SFM_E_INVALID; }
     const int rc_lds = allow_big_lds(ctx, reinterpret_cast<const void *>(&ransac_score_prefilter));
     if (rc_lds != SFM_OK) return rc_lds;
-    const int ntiles = (pair->ld + kPfTile - 1) / kPfTile;
-    const uint32_t iters = (count + 64u * kPfWaves - 1) / (64u * kPfWaves);       // 1024-hypothesis block iterations per tile
-    // one block per CU is resident (148 KiB of LDS) and staging a tile is not overlapped with anything, so few, long blocks:
-    // ONE per CU up to four tiles (2^20 x 4096: 0.586 ms against 0.595 with two per CU, 131072 x 4096: 0.097 against 0.105),
-    // two per CU above (16 tiles, 16384 points: 2.27 against 2.31 ms at 2^20 hypotheses) -- profiles/r02_grid_ab.txt
+    const int ntiles = prefilter_tiles(pair);
+    const uint32_t npass = (count + (uint32_t)kPfGroup - 1u) / (uint32_t)kPfGroup;
+    const uint32_t iters = (npass + kPfWaves - 1) / kPfWaves;                     // 512-hypothesis block iterations per tile
+    // one block per CU is resident (156 KiB of LDS), so the grid is one block per CU, spread over the tiles; with more tiles
+    // than that gives columns for, two blocks per CU queue up (16 tiles: 2.27 against 2.31 ms at 2^20 hypotheses, round 2)
     const uint32_t per_cu = ntiles <= 4 ? 1u : 2u;
     uint32_t cols = (per_cu * (uint32_t)ctx->num_cus + (uint32_t)ntiles - 1) / (uint32_t)ntiles;
     if (p.reserved[2] > 0) cols = (uint32_t)p.reserved[2];
     if (cols > iters) cols = iters;
     if (cols < 1) cols = 1;
+    const int dynamic = p.reserved[1] == 2 ? 0 : 1;                               // (reserved[1] == 2: static striding, A/B)
     hipLaunchKernelGGL(ransac_score_prefilter, dim3(cols, ntiles), dim3(kPfWaves * 64), kPfLdsBytes, ctx->stream,
-                       pair->d_X[0], pair->d_X[1], pair->ld, pair->n, pair->d_Ecand, h0, count, p.threshold, sc,
-                       pair->d_counts, pair->d_tick, pair->d_key, key2, pair->d_clk);
+                       pair->d_X[0], pair->d_X[1], pair->ld, pair->n, pair->d_Ecand, reinterpret_cast<const PfRecord *>(pair->d_pf), h0, count, p.threshold,
+                       pair->d_bound, dynamic, pair->d_counts, pair->d_tick, pair->d_key, key2, pair->d_clk);
     SFM_HIP_TRY(hipGetLastError());
     pair->last_grid = (int)cols * ntiles; pair->last_block = kPfWaves * 64; pair->last_lds = kPfLdsBytes;
     return SFM_OK;

@@ -334,6 +334,11 @@ int sfm_ransac_last_clock(sfm_pair *pair, double *shader_mhz);
  * coefficients prepared, [4] first 32-hypothesis block scanned and drained, [5] first pass done (counts and ticket out),
  * [6] number of passes wavefront 0 ran.  Zero where the kernel that ran has no such probe.  Synchronises. */
 int sfm_ransac_last_phases(sfm_pair *pair, uint64_t ticks[8]);
+/* Profiling aid: when did every block / wavefront of the last pre-filter scoring launch start and finish?  20 words per
+ * block (up to 1024 blocks, in blockIdx.y * gridDim.x + blockIdx.x order): [0] start and [1] end of its first wavefront,
+ * [2] (XCC id << 32) | HW_ID, [3] (tile << 32) | column, [4..19] the end of each of its 16 wavefronts -- all in 100 MHz
+ * ticks of one device-wide counter.  *count = words written (0 if another kernel ran).  Synchronises. */
+int sfm_ransac_last_trace(sfm_pair *pair, uint64_t *words, size_t capacity, size_t *count);
 /* Test probe of the matrix-core pre-filter (ransac_prefilter.hip): the fp16 operands of ONE (hypothesis, point) pair as the
  * device builds them and what the matrix cores return for them.  h_point = (x1x, x1y, x2x, x2y), bound = the tile's largest
  * |coordinate|.  h_out: coefficient slots ns[32], ts[16] | feature slots bn[32], bt[16] | nt | G | rejected (0/1) |
