@@ -36,9 +36,10 @@ typedef float f16v __attribute__((ext_vector_type(16)));
 // LDS map
 constexpr int kPfBlockBytes = 3 * 64 * 16;                    // one 32-point block: [n k-step 0 | n k-step 1 | G][lane][8 fp16]
 constexpr int kPfLdsFrag = 0;
-constexpr int kPfLdsPts = kPfLdsFrag + (kPfTile / 32) * kPfBlockBytes;     // float4 (x1x, x1y, x2x, x2y) per point
-constexpr int kPfLdsWave = kPfLdsPts + kPfTile * 16;          // per wavefront: E table 32 x 9 floats, 32 counters, ring
-constexpr int kPfWaveBytes = 32 * 9 * 4 + 32 * 4 + kPfRing * 8;
+constexpr int kPfLdsPts = kPfLdsFrag + (kPfTile / 32) * kPfBlockBytes;     // float4 (x2x, x1x, x2y, x1y) per point
+constexpr int kPfLdsWave = kPfLdsPts + kPfTile * 16;          // per wavefront: E table 32 x 10 floats, 32 counters, ring
+constexpr int kPfERow = 10;                                   // floats per E row: (e2 e6 | e1 e3 | e5 e7 | e0 e4 | e8 -), 8-byte aligned pairs
+constexpr int kPfWaveBytes = 32 * kPfERow * 4 + 32 * 4 + kPfRing * 8;
 constexpr int kPfHashSlots = 2048;                             // occupied grid cells of the tile (<= 1024 keys): open addressing, 0 = empty
 constexpr int kPfLdsHash = kPfLdsWave + kPfWaves * kPfWaveBytes;
 constexpr int kPfLdsNext = kPfLdsHash + kPfHashSlots * 4;       // the block's pass counter
@@ -57,7 +58,7 @@ __device__ __forceinline__ uint32_t scan16(const f16v &nt, const f16v &G)
     uint32_t rejected = 0u;
 #pragma unroll
     for (int r = 0; r < 16; ++r) rejected = shift_in_reject(rejected, nt[r], G[r]);
-    return rejected;                        // < 2^16: sixteen bits shifted into 0
+    return rejected;                        // < 2^16: accumulator r in bit 15 - r
 }
 
 // LDS through address-space-3 pointers (ds_* instructions, immediate offsets)
@@ -68,8 +69,39 @@ typedef __attribute__((address_space(3))) const f4v lds_cf4;
 typedef __attribute__((address_space(3))) const float lds_cf;
 typedef __attribute__((address_space(3))) int lds_i;
 typedef __attribute__((address_space(3))) const h8 lds_ch8;
+typedef __attribute__((address_space(3))) const v2f lds_cv2;
 
 struct PfFrags { h8 n0, n1, t; };
+
+// The exact decision of inlier_filter / residual (device_math.hpp) for one unit-z pair, arranged for the packed FP32
+// instructions: the same IEEE operations in the same order per element -- (a0, b0) and (a1, b1) travel as pairs -- so every
+// intermediate is bit-identical to the scalar form (tests compare every count with the oracle).
+//   E row as stored in the wavefront's table: p0 = (e2, e6), p1 = (e1, e3), p2 = (e5, e7), p3 = (e0, e4), e8
+//   point as stored in LDS: xu = (x2x, x1x), yv = (x2y, x1y)
+__device__ __forceinline__ bool pf_exact_inlier(v2f p0, v2f p1, v2f p2, v2f p3, float e8, v2f xu, v2f yv, const ThrBand &band)
+{
+    const v2f e00 = { p3.x, p3.x }, e44 = { p3.y, p3.y }, e31 = { p1.y, p1.x };
+    // (a0, b0) = (e1 y + (e0 x + e2), e3 v + (e0 u + e6));  (a1, b1) = (e4 y + (e3 x + e5), e4 v + (e1 u + e7))
+    const v2f ab0 = __builtin_elementwise_fma(p1, yv, __builtin_elementwise_fma(e00, xu, p0));
+    const v2f ab1 = __builtin_elementwise_fma(e44, yv, __builtin_elementwise_fma(e31, xu, p2));
+    const float a2 = fmaf(p2.y, yv.x, fmaf(p0.y, xu.x, e8));                       // e7 y + (e6 x + e8)
+    const float nn = fmaf(yv.y, ab1.x, fmaf(xu.y, ab0.x, a2));                     // v a1 + (u a0 + a2)
+    const float n2 = nn * nn;
+    const v2f dd = __builtin_elementwise_fma(ab1, ab1, ab0 * ab0);                 // (da, db)
+    const float da = dd.x, db = dd.y;
+    const float m = n2 * (da + db);
+    const float tp = (da * db) * band.thr;
+    const uint32_t mb = __float_as_uint(m), tb = __float_as_uint(tp);
+    const uint32_t gap = __usad(mb, tb, 0u);                                       // |mb - tb| (v_sad_u32)
+    const bool undecided = (gap < kBandUlps) || (tb < band.lo_bits) || (tb > band.hi_bits);
+    bool in = m < tp;
+    if (undecided) {                                                               // residual(): element_wise_div semantics (kernels.h:305-315)
+        const float t1 = (da == 0.0f) ? 0.0f : n2 / da;
+        const float t2 = (db == 0.0f) ? 0.0f : n2 / db;
+        in = (t1 + t2) < band.thr;
+    }
+    return in;
+}
 
 __device__ __forceinline__ PfFrags load_point_frags(lds_ch8 *frag_lane, int pb)
 {
@@ -124,7 +156,7 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
     const uint32_t npass = (count + (uint32_t)kPfGroup - 1u) / (uint32_t)kPfGroup;
     const uint32_t nstatic = gridDim.x * (uint32_t)kPfWaves;             // passes handed out by position
     float *etab = reinterpret_cast<float *>(smem + kPfLdsWave + wave * kPfWaveBytes);
-    int *cnt = reinterpret_cast<int *>(etab + 32 * 9);
+    int *cnt = reinterpret_cast<int *>(etab + 32 * kPfERow);
 
     // Operands of hypothesis (32 ps + row): this lane's half of the three A fragments, its two cell keys, and (lanes 0..31)
     // its E row.  Rows beyond the range repeat the last hypothesis (never counted).
@@ -145,8 +177,12 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
     };
     auto install_rows = [&](const float (&e)[9]) {          // E table and counters of a pass (the previous pass' ring is drained, its counters are out)
         if (half == 0) {
-#pragma unroll
-            for (int k = 0; k < 9; ++k) etab[9 * row + k] = e[k];
+            float4 *dst = reinterpret_cast<float4 *>(etab + kPfERow * row);      // 40-byte rows: 8-byte aligned
+            reinterpret_cast<float2 *>(dst)[0] = make_float2(e[2], e[6]);
+            reinterpret_cast<float2 *>(dst)[1] = make_float2(e[1], e[3]);
+            reinterpret_cast<float2 *>(dst)[2] = make_float2(e[5], e[7]);
+            reinterpret_cast<float2 *>(dst)[3] = make_float2(e[0], e[4]);
+            etab[kPfERow * row + 8] = e[8];
             cnt[row] = 0;
         }
     };
@@ -181,7 +217,7 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
         // the points the pre-filter can reject at all (the others carry no features: prefilter_point_slots)
         const bool hashed = real && big <= 48.0f && u == u && v == v && x == x && y == y;
         // padding reads as NaN in the exact test (it is always rejected before; NaN never counts)
-        reinterpret_cast<float4 *>(smem + kPfLdsPts)[t] = real ? make_float4(u, v, x, y) : make_float4(NAN, NAN, NAN, NAN);
+        reinterpret_cast<float4 *>(smem + kPfLdsPts)[t] = real ? make_float4(x, u, y, v) : make_float4(NAN, NAN, NAN, NAN);
         const int pb = t >> 5, col = t & 31;
         unsigned char *blk = smem + kPfLdsFrag + pb * kPfBlockBytes;
 #pragma unroll
@@ -265,13 +301,12 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
             while (todo) {
                 const int r = __builtin_ctz(todo);
                 todo &= todo - 1u;
-                float se[6];
-#pragma unroll
-                for (int k = 0; k < 6; ++k) se[k] = etab[9 * r + k];
+                const float *er = etab + kPfERow * r;
+                const float se[6] = { er[6], er[2], er[0], er[3], er[7], er[4] };          // e0 .. e5 out of the permuted row
                 bool z = false;
                 for (int j = 0; j < kPfTile / 64; ++j) {
                     const float4 q = pts[j * 64 + lane];
-                    z = z || prefilter_zero_divisor(se, q.z, q.w);              // NaN padding never compares equal to 0
+                    z = z || prefilter_zero_divisor(se, q.x, q.z);              // NaN padding never compares equal to 0
                 }
                 if (__ballot(z) != 0ull) survive |= 1u << r;
             }
@@ -285,30 +320,30 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
 
         // ---- the scan: two accumulator sets; while set A is scanned the MFMAs of the next step fill set B
         int head = 0, nq = 0;                       // ring state (wave-uniform)
+        // a lane's point in 32-point block 0 (LDS byte address, a multiple of 16) | its accumulator-row offset 4 (lane >> 5)
+        const uint32_t lane_tag = (uint32_t)(size_t)(lds_cf4 *)pts + (uint32_t)(row * 16) + (uint32_t)(half * 4);
         auto flush = [&](int m) {
             // Exact decision for up to 64 ring entries starting at `head`, one entry per lane: the lane evaluates the FIRST
             // surviving pair of its entry; an entry that holds more goes back to the tail of the ring with the rest of its
             // mask, so that every pass of the exact filter runs on (nearly) 64 busy lanes.
-            // entry = { 32-bit mask of surviving accumulators (bit 31 - r: accumulator r of the pair's first point block,
-            // bit 15 - r: of its second), (point-block pair << 6) | lane }.
+            // entry = { 32-bit mask of surviving accumulators (bit 31 - r: accumulator r of the pair's first point block, bit 15 - r:
+            // of its second), LDS byte address of the lane's point in the pair's first block | 4 (lane >> 5) }.
             uint32_t rest = 0, tag = 0;
             if (lane < m) {
                 const u2v ent = ring[(head + lane) & (kPfRing - 1)];
                 tag = ent.y;
                 const uint32_t surv = ent.x;
-                rest = surv & (surv - 1);
-                const int b = __builtin_ctz(surv);
-                const int r = 15 - (b & 15);
-                const int l = tag & 63, pb = 2 * (int)(tag >> 6) + ((b >> 4) ^ 1);
-                const int hl = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);               // accumulator row = local hypothesis
+                const int b = __builtin_clz(surv);                                  // the first surviving accumulator of the first step that has one
+                rest = surv & ~(0x80000000u >> b);
+                const int r = b & 15, sub = b >> 4;
+                const int hl = r + (r & 12) + (int)(tag & 4u);                      // accumulator row = local hypothesis: (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
                 if (hl < nvalid) {
-                    const f4v q = pts_l[pb * 32 + (l & 31)];
-                    lds_cf *e = etab_l + 9 * hl;
-                    const Ess E{ e[0], e[1], e[2], e[3], e[4], e[5], e[6], e[7], e[8] };
-                    bool und;
-                    bool in = inlier_filter(E, band, q.x, q.y, 1.0f, q.z, q.w, 1.0f, und);
-                    if (und) in = residual(E, q.x, q.y, 1.0f, q.z, q.w, 1.0f) < band.thr;
-                    if (in) __hip_atomic_fetch_add(cnt_l + hl, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    const f4v q = *(lds_cf4 *)((__attribute__((address_space(3))) const unsigned char *)0 + ((tag & ~15u) + ((uint32_t)sub << 9)));
+                    lds_cv2 *e = (lds_cv2 *)(etab_l + kPfERow * hl);
+                    const v2f p0 = e[0], p1 = e[1], p2 = e[2], p3 = e[3];
+                    const float e8 = etab_l[kPfERow * hl + 8];
+                    if (pf_exact_inlier(p0, p1, p2, p3, e8, v2f{ q.x, q.y }, v2f{ q.z, q.w }, band))
+                        __hip_atomic_fetch_add(cnt_l + hl, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
             }
             const unsigned long long more = __ballot(rest != 0u);
@@ -328,23 +363,23 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
             fa = load_point_frags(frag_lane, min(2 * pp + 2, last_pb));
             __builtin_amdgcn_sched_barrier(0);
             mfma_step(afrag, fb, g1, n1);
-            const uint32_t rej_hi = scan16(n0, g0);
+            const uint32_t rej_first = scan16(n0, g0);
             PF_SCHED_STEP();
             __builtin_amdgcn_sched_barrier(0);
             // phase 2: matrix cores on step 2 pp + 2 (fragments fa), LDS on step 2 pp + 3, vector unit on step 2 pp + 1
             fb = load_point_frags(frag_lane, min(2 * pp + 3, last_pb));
             __builtin_amdgcn_sched_barrier(0);
             mfma_step(afrag, fa, g0, n0);
-            const uint32_t rej_lo = scan16(n1, g1);
+            const uint32_t rej_second = scan16(n1, g1);
             PF_SCHED_STEP();
             __builtin_amdgcn_sched_barrier(0);
-            const uint32_t rej32 = (rej_hi << 16) | rej_lo;
+            const uint32_t rej32 = (rej_first << 16) | rej_second;
             const bool mine = rej32 != 0xFFFFFFFFu;
             const unsigned long long any = __ballot(mine);
             if (any) {
                 while (nq >= 64) flush(64);             // make room first (a flush of 64 entries re-queues up to 64: it may take more than one)
                 const int slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(any >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)any, 0u));
-                if (mine) ring[(head + nq + slot) & (kPfRing - 1)] = u2v{ ~rej32, ((uint32_t)pp << 6) | (uint32_t)lane };
+                if (mine) ring[(head + nq + slot) & (kPfRing - 1)] = u2v{ ~rej32, lane_tag + ((uint32_t)pp << 10) };
                 nq += __builtin_popcountll(any);
             }
         }

@@ -253,3 +253,55 @@ def test_prefilter_operands_on_the_device_equal_the_host_build(gpu):
         nt = float(Bn[0] @ ns); G = float(Bt[0] @ ts)
         assert abs(float(dv["nt"]) - nt) <= T.ACC * float(np.abs(Bn[0]) @ np.abs(ns)) + 1e-12
         assert abs(float(dv["G"]) - G) <= T.ACC * float(np.abs(Bt[0]) @ np.abs(ts)) + 1e-12
+
+
+@pytest.mark.parametrize("cols,launches,H", [(0, 1000, 1 << 20), (64, 600, 1 << 18), (1, 150, 1 << 18), (0, 400, 1 << 17)])
+def test_prefilter_tickets_under_contention(gpu, cols, launches, H):
+    """The arg-max of the scoring kernel rests on an ordering assumption (ransac_prefilter.hip: the count atomics of a
+    wavefront are acknowledged -- s_waitcnt vmcnt(0) -- before its ticket is issued, and the wavefront that draws the last
+    ticket of a group then reads final counts), not on a release / acquire fence (which costs an L2 write-back per group).
+    This test exercises it: 16 tiles (so 16 wavefronts on 16 CUs race for every group's tickets), grid columns forced to
+    1 / 64 / the default through reserved[2], hundreds of launches, the key of EVERY launch and the counts of every 50th
+    against the oracle.  A reader that ran ahead of another tile's counts would produce a key with too small a count."""
+    torch, dev, ctx = gpu
+    n = 16384
+    scene = synth.two_view_scene(n, seed=77)
+    pair, _ = make_pair(S, gpu, scene)
+    p = S.default_params(n, num_hypotheses=H, seed=11, kernel=S.KERNEL_PREFILTER)
+    p.reserved[2] = cols
+    _, _, X0, X1 = O.fill_xu(scene["sift"], scene["Kinv"])
+    key, ocounts, _ = O.ransac_range_fast(X0, X1, 0, H, p.threshold, p.jacobi_sweeps, seed=p.seed)
+    bad_keys = 0
+    for it in range(launches):
+        pair.ransac_score(p)
+        k = pair.get_key()
+        if k != key:
+            bad_keys += 1
+        if it % 50 == 0:
+            assert pair.last_launch()["kernel"] == S.KERNEL_PREFILTER
+            assert np.array_equal(pair.get_inlier_counts(H), ocounts), f"launch {it}: counts differ"
+    assert bad_keys == 0, f"{bad_keys} of {launches} launches produced a key other than the oracle's"
+
+
+@pytest.mark.parametrize("mode", [2])
+def test_prefilter_static_pass_order_equals_oracle(gpu, mode):
+    """reserved[1] = 2 hands the passes out by position instead of through the block's LDS counter (A/B switch): same counts."""
+    n, H = 3000, 40000
+    scene = synth.two_view_scene(n, seed=5)
+    pair, _ = make_pair(S, gpu, scene)
+    p = S.default_params(n, num_hypotheses=H, seed=3, kernel=S.KERNEL_PREFILTER)
+    p.reserved[1] = mode
+    pair.estimateE(p)
+    check_all(pair, scene, p, H, n)
+
+
+def test_round2_kernel_still_equals_oracle(gpu):
+    """The round-2 scoring kernel kept for A/B runs (reserved[3] = 2)."""
+    n, H = 4096, 65536
+    scene = synth.two_view_scene(n, seed=8)
+    pair, _ = make_pair(S, gpu, scene)
+    p = S.default_params(n, num_hypotheses=H, seed=2, kernel=S.KERNEL_PREFILTER)
+    p.reserved[3] = 2
+    pair.estimateE(p)
+    assert pair.last_launch()["kernel"] == S.KERNEL_PREFILTER
+    check_all(pair, scene, p, H, n)
