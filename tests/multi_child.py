@@ -14,10 +14,29 @@ import torch.distributed as dist
 import cuda_sfm_amd as S
 from cuda_sfm_amd import synth
 
+import hashlib
+import time
+
 rank, world, local = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ["LOCAL_RANK"])
+T0 = time.time()
+diag = {"rank": rank}
+
+
+def stage(name, **kv):
+    """One line per rank and stage on stderr (flushed at once): a hang or a wrong result on a node nobody can log into is
+    then diagnosable from the log alone -- which rank stopped where, and what it held at that point."""
+    diag[name] = kv if kv else True
+    print(f"[multi_child rank {rank}/{world} +{time.time() - T0:6.2f}s] {name} {json.dumps(kv)}", file=sys.stderr, flush=True)
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()[:12]
+
+
 torch.cuda.set_device(local)
 dev = torch.device("cuda", local)
 dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+stage("process_group_up", device=torch.cuda.get_device_name(local), visible=torch.cuda.device_count())
 n, H = 3000, 40001
 scene = synth.two_view_scene(n, seed=77)
 d_sift = torch.from_numpy(scene["sift"].view(np.uint8).reshape(n, 576)).to(dev)
@@ -27,17 +46,35 @@ pair.fillXU(d_sift)
 p = S.default_params(n, num_hypotheses=H, seed=9)
 pair.estimateE(p)                                               # every rank: the whole range on its own GPU
 ref = (pair.get_key(), pair.get_E().copy(), pair.get_inlier_mask().copy(), pair.get_best())
+stage("single_gpu_reference", key=hex(ref[0]), best=list(ref[3]), E=sha(ref[1]), mask=sha(ref[2]))
 uid = [S.Comm.unique_id() if rank == 0 else None]
 dist.broadcast_object_list(uid, src=0)
+stage("unique_id_received", id=hashlib.sha256(bytes(uid[0])).hexdigest()[:12])
 comm = S.Comm(ctx, uid[0], rank, world)
+stage("communicator_up", ncclCommCount=comm.nccl_ranks())
 ok = comm.nccl_ranks() == world
+# the shard's own key BEFORE the exchange (what this rank contributes to the all-reduce) ...
+q = S.default_params(n, num_hypotheses=H, seed=9)
+q.hyp_begin, q.hyp_count = S.shard_range(H, rank, world)
+key_t = torch.zeros(1, dtype=torch.int64, device=dev)
+pair.ransac_score(q, key_out=key_t)
+torch.cuda.synchronize()
+local_key = int(key_t.item())
+stage("shard_scored", shard=[q.hyp_begin, q.hyp_count], local_key=hex(local_key), local_best=list(S.unpack_key(local_key)))
+keys = [None] * world
+dist.all_gather_object(keys, local_key)
+ok = ok and max(keys) == ref[0]                                 # the max over the shard keys must be the single-GPU key
+# ... and the exchange step itself (ncclAllReduce(max, u64) inside libsfm_amd_rccl.so + local finalize)
 q = S.default_params(n, num_hypotheses=H, seed=9)
 comm.estimate_E(pair, q)
+stage("sharded_step_done", key_after_allreduce=hex(pair.get_key()), best=list(pair.get_best()), E=sha(pair.get_E()), mask=sha(pair.get_inlier_mask()))
+ok = ok and pair.get_key() == ref[0]
 ok = ok and (q.hyp_begin, q.hyp_count) == S.shard_range(H, rank, world)
 ok = ok and pair.get_best() == ref[3] and np.array_equal(pair.get_E().view(np.uint32), ref[1].view(np.uint32)) and np.array_equal(pair.get_inlier_mask(), ref[2])
 for _ in range(5):                                              # pipelined: the next step's scoring overlaps this step's exchange
     comm.estimate_E_pipelined(pair, q)
 comm.flush()
+stage("pipelined_steps_done", best=list(pair.get_best()), E=sha(pair.get_E()), mask=sha(pair.get_inlier_mask()))
 ok = ok and pair.get_best() == ref[3] and np.array_equal(pair.get_E().view(np.uint32), ref[1].view(np.uint32)) and np.array_equal(pair.get_inlier_mask(), ref[2])
 # configs[4] inside the C libraries: 5 views (spare slot on the last rank), 5 pairs, against the single-GPU path
 w, h = 384, 288
@@ -50,12 +87,16 @@ vref, vcounts = S.process_views(ctx, views, K, Kinv, pairs=pairs, max_pts=4096, 
 vres, counts = comm.process_views(views, K, Kinv, pairs=pairs, max_pts=4096, sift=sift)
 ok = ok and counts == vcounts and sorted(vres) == sorted(vref) and len(vref) == len(pairs)
 ok = ok and all(np.array_equal(vres[k].view(np.uint32), vref[k].view(np.uint32)) for k in vref)
+stage("views_sharded_done", pairs=len(vres), counts=counts, records=sha(np.stack([vres[k] for k in sorted(vres)])) if vres else None, ok=bool(ok))
 t = torch.tensor([1 if ok else 0], dtype=torch.int64, device=dev)
 dist.all_reduce(t, op=dist.ReduceOp.MIN)
+diag["ok"] = bool(ok)
+everyone = [None] * world
+dist.all_gather_object(everyone, diag)
 if rank == 0:
     import ctypes
     ctypes.CDLL(None).fflush(None)
-    print(json.dumps({"ok": bool(t.item()), "world": world, "nccl_ranks": comm.nccl_ranks(), "best": list(ref[3])}), flush=True)
+    print(json.dumps({"ok": bool(t.item()), "world": world, "nccl_ranks": comm.nccl_ranks(), "best": list(ref[3]), "per_rank": everyone}), flush=True)
 comm.close()
 dist.barrier()
 dist.destroy_process_group()

@@ -100,3 +100,39 @@ int main(void)
     assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
     ver, hyps, sweeps, floats = r.stdout.split()
     assert (int(ver), int(hyps), int(sweeps)) == (1, 512, 0) and int(floats) > 8 * 1920 * 1080
+
+
+def test_comm_library_argument_and_lifecycle_paths_without_a_gpu():
+    """libsfm_amd_rccl.so as far as it can be driven without a GPU: the out-of-band id (ncclGetUniqueId needs no device),
+    argument validation of every entry point (a bad call must come back with SFM_E_INVALID, never dereference), and the
+    lifecycle corners of the Python wrapper -- so that the first real multi-rank run does not die on plumbing."""
+    import cuda_sfm_amd as S
+    L = S.comm_lib()
+    a, b = C.create_string_buffer(S.COMM_ID_BYTES), C.create_string_buffer(S.COMM_ID_BYTES)
+    assert L.sfm_comm_unique_id(a) == S.OK and L.sfm_comm_unique_id(b) == S.OK
+    assert any(a.raw) and a.raw != b.raw                                  # a fresh id per call: rank 0 makes ONE and hands it out
+    assert S.Comm.unique_id() != S.Comm.unique_id() and len(S.Comm.unique_id()) == S.COMM_ID_BYTES
+    assert L.sfm_comm_unique_id(None) == S.E_INVALID
+    out = C.c_void_p()
+    fake_ctx = C.c_void_p(0x1000)                                         # never dereferenced: the checks come first
+    L.sfm_comm_init.restype = C.c_int
+    for ctx, ident, rank, nranks, dst in [(None, a, 0, 1, C.byref(out)), (fake_ctx, None, 0, 1, C.byref(out)), (fake_ctx, a, 0, 1, None),
+                                          (fake_ctx, a, 0, 0, C.byref(out)), (fake_ctx, a, -1, 2, C.byref(out)), (fake_ctx, a, 2, 2, C.byref(out)),
+                                          (fake_ctx, a, 8, 8, C.byref(out))]:
+        assert L.sfm_comm_init(ctx, ident, rank, nranks, dst) == S.E_INVALID
+        assert not out.value
+    n, r = C.c_int(-7), C.c_int(-7)
+    assert L.sfm_comm_nccl_ranks(None, C.byref(n)) == S.E_INVALID and n.value == -7
+    assert L.sfm_comm_rank(None, C.byref(r), C.byref(n)) == S.E_INVALID
+    assert L.sfm_comm_flush(None) == S.E_INVALID                           # flush-before-read on a communicator that never came up
+    p = S.default_params(100)
+    assert L.sfm_estimate_E_sharded(None, C.byref(p), None) == S.E_INVALID
+    assert L.sfm_estimate_E_sharded_pipelined(None, C.byref(p), None) == S.E_INVALID
+    assert L.sfm_comm_destroy(None) == S.OK                                # destroy of nothing is not an error (cleanup paths)
+    # wrapper: close() is idempotent and safe on an object whose constructor failed half-way
+    c = object.__new__(S.Comm)
+    c.close(); c.close()
+    c._h = None
+    c.close()
+    with pytest.raises(AssertionError):
+        S.Comm(None, b"short", 0, 1)                                      # an id of the wrong size never reaches the library

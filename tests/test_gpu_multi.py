@@ -112,6 +112,23 @@ def test_two_ranks_rccl():
     assert rec["ok"] and rec["world"] == 2 and rec["nccl_ranks"] == 2
 
 
+def test_multi_rank_child_script_with_one_rank():
+    """tests/multi_child.py is what runs on the multi-GPU node nobody can log into: started here with ONE rank (RCCL
+    communicator of size 1) so that the script itself -- every stage, the per-rank diagnostics, the final record -- is
+    exercised on every round's 1-GPU box."""
+    code = ("import sys, bench; sys.exit(bench.launch_ranks(1, [], command=[sys.executable, %r], timeout=600))"
+            % os.path.join(ROOT, "tests", "multi_child.py"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    rec = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert rec["ok"] and rec["world"] == 1 and rec["nccl_ranks"] == 1
+    stages = rec["per_rank"][0]
+    for name in ("process_group_up", "single_gpu_reference", "communicator_up", "shard_scored", "sharded_step_done", "pipelined_steps_done", "views_sharded_done"):
+        assert name in stages, name
+    assert stages["shard_scored"]["local_key"] == stages["sharded_step_done"]["key_after_allreduce"] == stages["single_gpu_reference"]["key"]
+    assert "[multi_child rank 0/1" in r.stderr
+
+
 def test_estimate_E_pipelined_equals_estimateE(gpu):
     """sfm_estimate_E_pipelined: consecutive calls alternate between two slots (stream + per-shard buffers) and overlap on
     the device.  Interleaved seeds and sizes, readers flush by themselves: the result is always the LAST call's, equal to
