@@ -123,6 +123,10 @@ struct sfm_pair {
     unsigned long long *d_bound = nullptr; // (fillXU epoch << 32) | bits of the largest |coordinate| <= 48 over all points: atomicMax, never reset
     uint32_t bound_epoch = 0;
     bool have_bound = false;           // d_bound describes the current points (fillXU)
+    uint32_t *d_cells = nullptr;       // pre-filter: open-addressing table of the occupied zero-divisor grid cells of ALL points (launch_pf_cells)
+    hipEvent_t cells_ev = nullptr;     // recorded behind the build: launches on ANOTHER stream (two-slot pipelining) wait for it
+    hipStream_t cells_stream = nullptr;
+    uint32_t cells_cap = 0, cells_mask = 0, cells_epoch = 0;   // slots allocated / in use - 1 / the fillXU epoch the table was built for
     size_t cap_hyps = 0;
     uint32_t last_count = 0;           // hyp_count of the last score call
     uint32_t cand_h0 = 0, cand_seed = 0;   // what d_Ecand currently holds: shard start, sampler settings
@@ -161,7 +165,8 @@ int launch_permutation_indices(sfm_ctx *ctx, int n, uint32_t seed, int32_t *d_in
 // ransac_prefilter.hip
 bool prefilter_usable(const sfm_pair *pair, const sfm_ransac_params &p, uint32_t count);
 int launch_score_prefilter(sfm_pair *pair, const sfm_ransac_params &p, uint32_t h0, uint32_t count, unsigned long long *key2);
-int launch_pf_prep(sfm_pair *pair, const sfm_ransac_params &p, uint32_t count);        // PfRecords from d_Ecand (paths whose solve kernel does not write them)
+int launch_pf_prep(sfm_pair *pair, const sfm_ransac_params &p, uint32_t count);
+int launch_pf_cells(sfm_pair *pair);                                            // the pair's cell table, (re)built when the points changed        // PfRecords from d_Ecand (paths whose solve kernel does not write them)
 int prefilter_tiles(const sfm_pair *pair);
 // ransac_prefilter_r2.hip (the round-2 kernel, A/B only: sfm_ransac_params.reserved[3] == 2)
 int launch_score_prefilter_r2(sfm_pair *pair, const sfm_ransac_params &p, uint32_t h0, uint32_t count, unsigned long long *key2);

@@ -40,9 +40,7 @@ constexpr int kPfLdsPts = kPfLdsFrag + (kPfTile / 32) * kPfBlockBytes;     // fl
 constexpr int kPfLdsWave = kPfLdsPts + kPfTile * 16;          // per wavefront: E table 32 x 10 floats, 32 counters, ring
 constexpr int kPfERow = 10;                                   // floats per E row: (e2 e6 | e1 e3 | e5 e7 | e0 e4 | e8 -), 8-byte aligned pairs
 constexpr int kPfWaveBytes = 32 * kPfERow * 4 + 32 * 4 + kPfRing * 8;
-constexpr int kPfHashSlots = 2048;                             // occupied grid cells of the tile (<= 1024 keys): open addressing, 0 = empty
-constexpr int kPfLdsHash = kPfLdsWave + kPfWaves * kPfWaveBytes;
-constexpr int kPfLdsNext = kPfLdsHash + kPfHashSlots * 4;       // the block's pass counter
+constexpr int kPfLdsNext = kPfLdsWave + kPfWaves * kPfWaveBytes;   // the block's pass counter
 constexpr int kPfLdsBytes = kPfLdsNext + 16;
 static_assert(kPfLdsBytes <= 160 * 1024, "one block must fit the CU's LDS");
 
@@ -133,7 +131,7 @@ __device__ __forceinline__ void mfma_step(const PfFrags &a, const PfFrags &b, f1
 __global__ __launch_bounds__(kPfWaves * 64)
 void ransac_score_prefilter(const float *__restrict__ X0, const float *__restrict__ X1, int ld, int n,
                             const float *__restrict__ Ecand, const PfRecord *__restrict__ recs, uint32_t h0, uint32_t count, float thr,
-                            const unsigned long long *__restrict__ bound_word, int dynamic,
+                            int dynamic,
                             int *__restrict__ counts, uint32_t *__restrict__ tick,
                             unsigned long long *best_key, unsigned long long *best_key2, unsigned long long *__restrict__ clk)
 {
@@ -158,18 +156,19 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
     float *etab = reinterpret_cast<float *>(smem + kPfLdsWave + wave * kPfWaveBytes);
     int *cnt = reinterpret_cast<int *>(etab + 32 * kPfERow);
 
-    // Operands of hypothesis (32 ps + row): this lane's half of the three A fragments, its two cell keys, and (lanes 0..31)
-    // its E row.  Rows beyond the range repeat the last hypothesis (never counted).
+    // Operands of hypothesis (32 ps + row): this lane's half of the three A fragments and (lanes 0..31) its zero-divisor
+    // flag and its E row.  Rows beyond the range repeat the last hypothesis (never counted).
     PfFrags afrag = {};
-    uint32_t key0 = 0u, key1 = 0u;
+    uint32_t key0 = 0u;
     float e_row[9] = {};
-    auto fetch_pass = [&](uint32_t pass, PfFrags &af, uint32_t &k0, uint32_t &k1, float (&e)[9]) {
+    auto fetch_pass = [&](uint32_t pass, PfFrags &af, uint32_t &k0, float (&e)[9]) {
         const uint32_t hf = pass * (uint32_t)kPfGroup;
         const uint32_t h = hf + (uint32_t)min(row, (int)min((uint32_t)kPfGroup, count - hf) - 1);
         const PfRecord *r = recs + h;
         af.n0 = r->frag[0 + half]; af.n1 = r->frag[2 + half]; af.t = r->frag[4 + half];
-        k0 = r->keys[2 * half]; k1 = r->keys[2 * half + 1];
+        k0 = 0u;
         if (half == 0) {
+            k0 = r->keys[0];
             const float *src = Ecand + 9 * (size_t)h;
 #pragma unroll
             for (int k = 0; k < 9; ++k) e[k] = src[k];
@@ -189,13 +188,9 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
     // the first pass' operands are requested before the tile is staged: their way through the memory system overlaps it
     uint32_t ps = blockIdx.x * (uint32_t)kPfWaves + (uint32_t)wave;
     bool have = ps < npass;
-    if (have) { fetch_pass(ps, afrag, key0, key1, e_row); install_rows(e_row); }
+    if (have) { fetch_pass(ps, afrag, key0, e_row); install_rows(e_row); }
 
     // ---- stage the tile: one point per thread -> 48 fp16 feature slots in MFMA B-fragment order + its coordinates
-    const float B = __uint_as_float((uint32_t)(*bound_word & 0xFFFFFFFFull));      // bound over all points (fill_xu_kernel)
-    const PfGrid grid = prefilter_grid(B);
-    uint32_t *cells = reinterpret_cast<uint32_t *>(smem + kPfLdsHash);
-    for (int k = threadIdx.x; k < kPfHashSlots; k += kPfWaves * 64) cells[k] = 0u;
     // The passes of a block -- (16 j + w) for wavefront slot w of its j-th iteration -- are handed out through a counter in
     // LDS: the wavefronts of a block do not advance at the same rate (the oldest wavefront of a SIMD wins its arbitration:
     // with one fixed share each, the first finished 230 us before the last of a 630 us launch, profiles/r03_trace_*.txt),
@@ -213,9 +208,6 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
         if (real) { u = X0[p]; v = X0[(size_t)ld + p]; x = X1[p]; y = X1[(size_t)ld + p]; }
         _Float16 bn[kPfSlots], bt[kPfSlotsT];
         prefilter_point_slots(u, v, x, y, real, bn, bt);
-        const float big = fmaxf(fmaxf(fabsf(u), fabsf(v)), fmaxf(fabsf(x), fabsf(y)));
-        // the points the pre-filter can reject at all (the others carry no features: prefilter_point_slots)
-        const bool hashed = real && big <= 48.0f && u == u && v == v && x == x && y == y;
         // padding reads as NaN in the exact test (it is always rejected before; NaN never counts)
         reinterpret_cast<float4 *>(smem + kPfLdsPts)[t] = real ? make_float4(x, u, y, v) : make_float4(NAN, NAN, NAN, NAN);
         const int pb = t >> 5, col = t & 31;
@@ -235,16 +227,6 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
 #pragma unroll
             for (int j = 0; j < 8; ++j) c[j] = bt[hh * 8 + j];
             *reinterpret_cast<h8 *>(blk + 2048 + (hh * 32 + col) * 16) = c;
-        }
-        // the occupied cells of the zero-divisor grid (prefilter_math.hpp (3)); its pitch follows the bound
-        if (hashed) {
-            const uint32_t key = pf_cell_key(pf_cell(x, grid), pf_cell(y, grid));
-            uint32_t sl = (key >> 8) & (kPfHashSlots - 1);
-            for (;;) {
-                const uint32_t old = atomicCAS(&cells[sl], 0u, key);
-                if (old == 0u || old == key) break;
-                sl = (sl + 1) & (kPfHashSlots - 1);
-            }
         }
     }
     __syncthreads();
@@ -274,27 +256,11 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
             got = (uint32_t)__builtin_amdgcn_readfirstlane((int)got);
             ps_next = (got / (uint32_t)kPfWaves) * nstatic + blockIdx.x * (uint32_t)kPfWaves + (got % (uint32_t)kPfWaves);
         }
-        // zero divisors (prefilter_math.hpp (3)): the record names the (at most 2 x 2) grid cells in which the first divisor of
-        // this hypothesis can vanish; nearly every hypothesis is cleared by finding them unoccupied, the rest (~0.5 %)
-        // is checked against every point of the tile, one hypothesis at a time by the whole wavefront
+        // zero divisors (prefilter_math.hpp (3)): a hypothesis whose record says "cannot tell" (~0.5 %: its first divisor can
+        // vanish in a grid cell that some point of the pair occupies, or no small set of cells could be named) is checked
+        // against every point of the tile, one hypothesis at a time by the whole wavefront
         {
-            bool scan = false;
-            if ((key0 | key1) != 0u) {
-                scan = key0 == kPfKeyScan;
-                const uint32_t kk[2] = { key0, key1 };
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    const uint32_t key = kk[q];
-                    if (key == 0u || key == kPfKeyScan) continue;
-                    uint32_t sl = (key >> 8) & (kPfHashSlots - 1);
-                    for (;;) {
-                        const uint32_t got = cells[sl];
-                        if (got == key) scan = true;
-                        if (got == key || got == 0u) break;
-                        sl = (sl + 1) & (kPfHashSlots - 1);
-                    }
-                }
-            }
+            const bool scan = key0 == kPfKeyScan;
             const unsigned long long sm = __ballot(scan);
             uint32_t todo = (uint32_t)sm | (uint32_t)(sm >> 32);
             uint32_t survive = 0u;                                      // rows whose pairs must all survive in this tile
@@ -387,8 +353,8 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
         // the next pass' operands: requested now, they arrive while the ring is drained and the counts go out
         const bool have_next = ps_next < npass;
         PfFrags afrag_next = afrag;
-        uint32_t key0n = 0u, key1n = 0u;
-        if (have_next) fetch_pass(ps_next, afrag_next, key0n, key1n, e_row);
+        uint32_t key0n = 0u;
+        if (have_next) fetch_pass(ps_next, afrag_next, key0n, e_row);
         while (nq > 0) flush(min(nq, 64));
         // LDS counters -> counts[] (zeroed by the solve kernel); a wavefront's LDS operations complete in order
         if (lane < nvalid) {
@@ -428,7 +394,7 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
         have = have_next;
         if (have_next) {
             ps = ps_next;
-            afrag = afrag_next; key0 = key0n; key1 = key1n;
+            afrag = afrag_next; key0 = key0n;
             install_rows(e_row);
         }
     }
@@ -440,12 +406,64 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
     }
 }
 
+// ---- the pair's table of occupied grid cells (prefilter_math.hpp (3)) ----------------------------------------------------
+// One key per point that carries features (finite, |coordinates| <= 48): the cell of its second-view position on the grid
+// whose pitch follows the bound over all points.  Built once per fillXU (the first scoring launch that needs it), looked up
+// once per hypothesis by pf_prep_store -- not once per (hypothesis, tile) out of a table in LDS as in round 2.
+__global__ __launch_bounds__(256)
+void pf_cells_build_kernel(const float4 *__restrict__ pts4, int n, const unsigned long long *__restrict__ bound_word,
+                           uint32_t *__restrict__ cells, uint32_t mask)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const float4 q = pts4[j];                               // (x1x, x1y, x2x, x2y)
+    const float big = fmaxf(fmaxf(fabsf(q.x), fabsf(q.y)), fmaxf(fabsf(q.z), fabsf(q.w)));
+    if (!(big <= 48.0f) || q.x != q.x || q.y != q.y || q.z != q.z || q.w != q.w) return;
+    const PfGrid grid = prefilter_grid(__uint_as_float((uint32_t)(*bound_word & 0xFFFFFFFFull)));
+    const uint32_t key = pf_cell_key(pf_cell(q.z, grid), pf_cell(q.w, grid));
+    uint32_t sl = pf_cells_slot(key, mask);
+    for (;;) {
+        const uint32_t old = atomicCAS(&cells[sl], 0u, key);
+        if (old == 0u || old == key) break;
+        sl = (sl + 1) & mask;
+    }
+}
+
+int launch_pf_cells(sfm_pair *pair)
+{
+    hipStream_t st = pair->ctx->stream;
+    if (pair->cells_epoch == pair->bound_epoch && pair->d_cells) {                      // built for the current points
+        // ... possibly by a launch on another stream (the other slot of a pipelined burst): order this stream behind it
+        if (st != pair->cells_stream) SFM_HIP_TRY(hipStreamWaitEvent(st, pair->cells_ev, 0));
+        return SFM_OK;
+    }
+    uint32_t slots = 4096;
+    while (slots < 4u * (uint32_t)pair->n) slots <<= 1;                                  // load factor <= 1/4
+    if (slots > pair->cells_cap) {
+        SFM_HIP_TRY(hipStreamSynchronize(st));
+        if (pair->d_cells) (void)hipFree(pair->d_cells);
+        pair->d_cells = nullptr; pair->cells_cap = 0;
+        SFM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&pair->d_cells), (size_t)slots * sizeof(uint32_t)));
+        pair->cells_cap = slots;
+    }
+    pair->cells_mask = slots - 1u;
+    SFM_HIP_TRY(hipMemsetAsync(pair->d_cells, 0, (size_t)slots * sizeof(uint32_t), st));
+    hipLaunchKernelGGL(pf_cells_build_kernel, dim3((pair->n + 255) / 256), dim3(256), 0, st, pair->d_pts4, pair->n, pair->d_bound,
+                       pair->d_cells, pair->cells_mask);
+    SFM_HIP_TRY(hipGetLastError());
+    if (!pair->cells_ev) SFM_HIP_TRY(hipEventCreateWithFlags(&pair->cells_ev, hipEventDisableTiming));
+    SFM_HIP_TRY(hipEventRecord(pair->cells_ev, st));
+    pair->cells_stream = st;
+    pair->cells_epoch = pair->bound_epoch;
+    return SFM_OK;
+}
+
 // ---- per-hypothesis operands ------------------------------------------------------------------------------------------
 // Stand-alone kernel for the paths whose solve kernel does not build the records itself (caller-supplied candidates, the
 // packed / Jacobi solve kernels): one hypothesis per lane.
 __global__ __launch_bounds__(256)
 void pf_prep_kernel(const float *__restrict__ Ecand, uint32_t count, float thr, PfScales sc, const unsigned long long *__restrict__ bound_word,
-                    PfRecord *__restrict__ recs)
+                    const uint32_t *__restrict__ cells, uint32_t cells_mask, PfRecord *__restrict__ recs)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
@@ -453,7 +471,7 @@ void pf_prep_kernel(const float *__restrict__ Ecand, uint32_t count, float thr, 
 #pragma unroll
     for (int k = 0; k < 9; ++k) e[k] = Ecand[9 * (size_t)i + k];
     const float B = __uint_as_float((uint32_t)(*bound_word & 0xFFFFFFFFull));
-    pf_prep_store(e, thr, B, sc, recs + i);
+    pf_prep_store(e, thr, B, sc, cells, cells_mask, recs + i);
 }
 
 int launch_pf_prep(sfm_pair *pair, const sfm_ransac_params &p, uint32_t count)
@@ -461,7 +479,7 @@ int launch_pf_prep(sfm_pair *pair, const sfm_ransac_params &p, uint32_t count)
     PfScales sc;
     if (!prefilter_scales(p.threshold, sc)) { set_error("threshold %g outside the pre-filter's range", (double)p.threshold); return SFM_E_INVALID; }
     hipLaunchKernelGGL(pf_prep_kernel, dim3((count + 255) / 256), dim3(256), 0, pair->ctx->stream,
-                       pair->d_Ecand, count, p.threshold, sc, pair->d_bound, reinterpret_cast<PfRecord *>(pair->d_pf));
+                       pair->d_Ecand, count, p.threshold, sc, pair->d_bound, pair->d_cells, pair->cells_mask, reinterpret_cast<PfRecord *>(pair->d_pf));
     SFM_HIP_TRY(hipGetLastError());
     return SFM_OK;
 }
@@ -480,7 +498,7 @@ void pf_probe_kernel(const float *__restrict__ E, float thr, float B, PfScales s
     float e[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) e[k] = E[k];
-    if (lane == 0) pf_prep_store(e, thr, B, sc, rec);
+    if (lane == 0) pf_prep_store(e, thr, B, sc, nullptr, 0u, rec);
     __threadfence();
     __syncthreads();
     _Float16 ns[kPfSlots], ts[kPfSlotsT], bn[kPfSlots], bt[kPfSlotsT];
@@ -567,7 +585,7 @@ int launch_score_prefilter(sfm_pair *pair, const sfm_ransac_params &p, uint32_t 
     const int dynamic = p.reserved[1] == 2 ? 0 : 1;                               // (reserved[1] == 2: static striding, A/B)
     hipLaunchKernelGGL(ransac_score_prefilter, dim3(cols, ntiles), dim3(kPfWaves * 64), kPfLdsBytes, ctx->stream,
                        pair->d_X[0], pair->d_X[1], pair->ld, pair->n, pair->d_Ecand, reinterpret_cast<const PfRecord *>(pair->d_pf), h0, count, p.threshold,
-                       pair->d_bound, dynamic, pair->d_counts, pair->d_tick, pair->d_key, key2, pair->d_clk);
+                       dynamic, pair->d_counts, pair->d_tick, pair->d_key, key2, pair->d_clk);
     SFM_HIP_TRY(hipGetLastError());
     pair->last_grid = (int)cols * ntiles; pair->last_block = kPfWaves * 64; pair->last_lds = kPfLdsBytes;
     return SFM_OK;
