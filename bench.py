@@ -54,7 +54,7 @@ FLOP_PER_HYP = 720            # A^T A normal equations
 PF_SCAN_VALU_PER_PAIR = 2     # v_fma_f32 (G - nt^2) + v_alignbit_b32 (its sign bit into the lane's mask)
 PF_MFMA_PER_1024_PAIRS = 3    # v_mfma_f32_32x32x16_f16: G (16 k-slots) + nt (32 k-slots)
 PF_MFMA_CYCLES = 32           # issue interval of one 32x32x16 f16 MFMA on a SIMD (8 passes x 4 cycles; profiles/r02_mfma_rate_probe.txt)
-PF_SOURCES = ("ransac_prefilter.hip", "prefilter_math.hpp", "ransac.hip", "ransac_device.hpp", "device_math.hpp")
+PF_SOURCES = ("ransac_prefilter.hip", "prefilter_math.hpp", "prefilter_record.hpp", "ransac.hip", "ransac_device.hpp", "device_math.hpp")
 TRAFFIC_JSON = os.path.join("profiles", "r03_traffic.json")
 PUBLISHED_ESTIMATE_E_MS = 24.12     # img/data.xlsx B5 / README.md:54 of the reference: estimateE on the dino pair, GTX 1080 Ti
 

@@ -28,7 +28,7 @@
 namespace sfm {
 
 constexpr int kPfTile = 1024;            // points per tile
-constexpr int kPfWaves = 16;
+constexpr int kPfWaves = 16;             // wavefronts per block (LDS is laid out for 16; the kernel also runs with 12, see launch_score_prefilter)
 constexpr int kPfRing = 128;             // survivor ring entries (8 bytes) per wavefront: < 64 waiting + 64 appended per step;
                                          // a flush re-queues at most 64 more, onto slots its own 64 entries have just left
 typedef float f16v __attribute__((ext_vector_type(16)));
@@ -128,7 +128,8 @@ __device__ __forceinline__ void mfma_step(const PfFrags &a, const PfFrags &b, f1
         __builtin_amdgcn_sched_group_barrier(0x002, 11, 0);             \
     } while (0)
 
-__global__ __launch_bounds__(kPfWaves * 64)
+template <int W>
+__global__ __launch_bounds__(W * 64)
 void ransac_score_prefilter(const float *__restrict__ X0, const float *__restrict__ X1, int ld, int n,
                             const float *__restrict__ Ecand, const PfRecord *__restrict__ recs, uint32_t h0, uint32_t count, float thr,
                             int dynamic,
@@ -152,7 +153,7 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
     }
     const int half = lane >> 5, row = lane & 31;
     const uint32_t npass = (count + (uint32_t)kPfGroup - 1u) / (uint32_t)kPfGroup;
-    const uint32_t nstatic = gridDim.x * (uint32_t)kPfWaves;             // passes handed out by position
+    const uint32_t nstatic = gridDim.x * (uint32_t)W;             // passes handed out by position
     float *etab = reinterpret_cast<float *>(smem + kPfLdsWave + wave * kPfWaveBytes);
     int *cnt = reinterpret_cast<int *>(etab + 32 * kPfERow);
 
@@ -186,7 +187,7 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
         }
     };
     // the first pass' operands are requested before the tile is staged: their way through the memory system overlaps it
-    uint32_t ps = blockIdx.x * (uint32_t)kPfWaves + (uint32_t)wave;
+    uint32_t ps = blockIdx.x * (uint32_t)W + (uint32_t)wave;
     bool have = ps < npass;
     if (have) { fetch_pass(ps, afrag, key0, e_row); install_rows(e_row); }
 
@@ -197,11 +198,10 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
     // and with first-come-first-served shares they finish within one pass of each other.  (One counter per tile in global
     // memory would balance the blocks too, but 131072 device-scope atomics on one address take 1.5 ms.)
     uint32_t *next_idx = reinterpret_cast<uint32_t *>(smem + kPfLdsNext);
-    if (threadIdx.x == 0) *next_idx = (uint32_t)kPfWaves;
+    if (threadIdx.x == 0) *next_idx = (uint32_t)W;
     __syncthreads();
     const int tile_first = blockIdx.y * kPfTile;
-    {
-        const int t = threadIdx.x;
+    for (int t = threadIdx.x; t < kPfTile; t += W * 64) {
         const int p = tile_first + t;
         float u = 0.f, v = 0.f, x = 0.f, y = 0.f;
         const bool real = p < n;
@@ -254,7 +254,7 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
             uint32_t got = 0u;
             if (lane == 0) got = atomicAdd(next_idx, 1u);
             got = (uint32_t)__builtin_amdgcn_readfirstlane((int)got);
-            ps_next = (got / (uint32_t)kPfWaves) * nstatic + blockIdx.x * (uint32_t)kPfWaves + (got % (uint32_t)kPfWaves);
+            ps_next = (got / (uint32_t)W) * nstatic + blockIdx.x * (uint32_t)W + (got % (uint32_t)W);
         }
         // zero divisors (prefilter_math.hpp (3)): a hypothesis whose record says "cannot tell" (~0.5 %: its first divisor can
         // vanish in a grid cell that some point of the pair occupies, or no small set of cells could be named) is checked
@@ -570,12 +570,17 @@ int launch_score_prefilter(sfm_pair *pair, const sfm_ransac_params &p, uint32_t 
     sfm_ctx *ctx = pair->ctx;
     PfScales sc;
     if (!prefilter_scales(p.threshold, sc)) { set_error("threshold %g outside the pre-filter's range", (double)p.threshold); return SFM_E_INVALID; }
-    const int rc_lds = allow_big_lds(ctx, reinterpret_cast<const void *>(&ransac_score_prefilter));
+    // wavefronts per block: 16 (four per SIMD, all 512 vector registers of a SIMD) by default; reserved[1] == 5 runs 12 -- three
+    // per SIMD, which leaves a quarter of the registers to the lane-solve kernel of the NEXT step when steps are pipelined
+    // on two streams (profiles/r03_waves_ab.txt)
+    const int waves = p.reserved[1] == 5 ? 12 : kPfWaves;
+    const void *fn = waves == 12 ? reinterpret_cast<const void *>(&ransac_score_prefilter<12>) : reinterpret_cast<const void *>(&ransac_score_prefilter<16>);
+    const int rc_lds = allow_big_lds(ctx, fn);
     if (rc_lds != SFM_OK) return rc_lds;
     const int ntiles = prefilter_tiles(pair);
     const uint32_t npass = (count + (uint32_t)kPfGroup - 1u) / (uint32_t)kPfGroup;
-    const uint32_t iters = (npass + kPfWaves - 1) / kPfWaves;                     // 512-hypothesis block iterations per tile
-    // one block per CU is resident (156 KiB of LDS), so the grid is one block per CU, spread over the tiles; with more tiles
+    const uint32_t iters = (npass + (uint32_t)waves - 1) / (uint32_t)waves;       // block iterations per tile
+    // one block per CU is resident (152 KiB of LDS), so the grid is one block per CU, spread over the tiles; with more tiles
     // than that gives columns for, two blocks per CU queue up (16 tiles: 2.27 against 2.31 ms at 2^20 hypotheses, round 2)
     const uint32_t per_cu = ntiles <= 4 ? 1u : 2u;
     uint32_t cols = (per_cu * (uint32_t)ctx->num_cus + (uint32_t)ntiles - 1) / (uint32_t)ntiles;
@@ -583,11 +588,16 @@ int launch_score_prefilter(sfm_pair *pair, const sfm_ransac_params &p, uint32_t 
     if (cols > iters) cols = iters;
     if (cols < 1) cols = 1;
     const int dynamic = p.reserved[1] == 2 ? 0 : 1;                               // (reserved[1] == 2: static striding, A/B)
-    hipLaunchKernelGGL(ransac_score_prefilter, dim3(cols, ntiles), dim3(kPfWaves * 64), kPfLdsBytes, ctx->stream,
-                       pair->d_X[0], pair->d_X[1], pair->ld, pair->n, pair->d_Ecand, reinterpret_cast<const PfRecord *>(pair->d_pf), h0, count, p.threshold,
-                       dynamic, pair->d_counts, pair->d_tick, pair->d_key, key2, pair->d_clk);
+    if (waves == 12)
+        hipLaunchKernelGGL(ransac_score_prefilter<12>, dim3(cols, ntiles), dim3(12 * 64), kPfLdsBytes, ctx->stream,
+                           pair->d_X[0], pair->d_X[1], pair->ld, pair->n, pair->d_Ecand, reinterpret_cast<const PfRecord *>(pair->d_pf), h0, count, p.threshold,
+                           dynamic, pair->d_counts, pair->d_tick, pair->d_key, key2, pair->d_clk);
+    else
+        hipLaunchKernelGGL(ransac_score_prefilter<16>, dim3(cols, ntiles), dim3(16 * 64), kPfLdsBytes, ctx->stream,
+                           pair->d_X[0], pair->d_X[1], pair->ld, pair->n, pair->d_Ecand, reinterpret_cast<const PfRecord *>(pair->d_pf), h0, count, p.threshold,
+                           dynamic, pair->d_counts, pair->d_tick, pair->d_key, key2, pair->d_clk);
     SFM_HIP_TRY(hipGetLastError());
-    pair->last_grid = (int)cols * ntiles; pair->last_block = kPfWaves * 64; pair->last_lds = kPfLdsBytes;
+    pair->last_grid = (int)cols * ntiles; pair->last_block = waves * 64; pair->last_lds = kPfLdsBytes;
     return SFM_OK;
 }
 

@@ -1,12 +1,22 @@
-"""profiles/pmc_<tag>_headline_summary.txt -> r02_traffic.json (what bench.py quotes as roofline.traffic_profiled /
-issue_profiled): HBM KB per launch and issue-slot occupancy of the two RANSAC kernels of the default bench command."""
+"""gpurun_out/pmc_<tag>_summary.txt (profiles/pmc_pf.sh) -> profiles/r03_traffic.json (what bench.py quotes as roofline.traffic /
+issue_profiled): HBM KB per launch and issue-slot occupancy of the RANSAC kernels of the default bench command, together with
+the hash of the kernel sources they were collected on (bench.py refuses to quote them for other sources).
+usage: python profiles/make_traffic_json.py <summary.txt> [matches hypotheses] > profiles/r03_traffic.json"""
 import json
+import os
 import re
 import sys
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench
+
 text = open(sys.argv[1]).read()
-out = {"_comment": "per launch, default bench command (4096 matches, 2^20 hypotheses), rocprofv3 --pmc passes of profiles/collect_r02.sh; "
-                   "FETCH_SIZE / WRITE_SIZE in KB (separate passes); busy fractions = quad-cycle counters x 4 over (GRBM_GUI_ACTIVE / 8 XCDs) x 1024 SIMDs"}
+matches = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
+hyps = int(sys.argv[3]) if len(sys.argv) > 3 else 1 << 20
+out = {"_comment": "per launch, `bench.py --serial` at %d matches x %d hypotheses, rocprofv3 --pmc passes of profiles/pmc_pf.sh; "
+                   "FETCH_SIZE / WRITE_SIZE in KB (separate passes); busy fractions = quad-cycle counters x 4 over (GRBM_GUI_ACTIVE / 8 XCDs) x 1024 SIMDs" % (matches, hyps),
+       "code_sha256_16": bench.source_hash(), "code_files": list(bench.PF_SOURCES)}
 for block in re.split(r"\n(?=sfm::)", text):
     name = block.split("\n", 1)[0].strip().replace("sfm::", "")
     if not name:
@@ -15,8 +25,8 @@ for block in re.split(r"\n(?=sfm::)", text):
     key = name.split("<")[0]
     if key not in ("ransac_score_prefilter", "ransac_solve_lanes2", "ransac_solve_lanes1_qr", "ransac_score_waves"):
         continue
-    e = {"matches": 4096, "hypotheses": 1 << 20, "fetch_kb": vals.get("FETCH_SIZE"), "write_kb": vals.get("WRITE_SIZE"),
-         "valu_insts_per_launch": vals.get("SQ_INSTS_VALU")}
+    e = {"matches": matches, "hypotheses": hyps, "fetch_kb": vals.get("FETCH_SIZE"), "write_kb": vals.get("WRITE_SIZE"),
+         "valu_insts_per_launch": vals.get("SQ_INSTS_VALU"), "salu_insts_per_launch": vals.get("SQ_INSTS_SALU"), "lds_insts_per_launch": vals.get("SQ_INSTS_LDS")}
     cyc = vals.get("GRBM_GUI_ACTIVE", 0.0) / 8.0
     if cyc > 0:
         e["kernel_cycles"] = cyc
@@ -26,5 +36,7 @@ for block in re.split(r"\n(?=sfm::)", text):
             e["mfma_busy_frac"] = round(vals["SQ_VALU_MFMA_BUSY_CYCLES"] / (cyc * 1024.0), 4)
         if vals.get("SQ_LDS_IDX_ACTIVE"):
             e["lds_bank_conflict_frac"] = round(vals.get("SQ_LDS_BANK_CONFLICT", 0.0) / vals["SQ_LDS_IDX_ACTIVE"], 4)
+        if vals.get("SQ_WAVE_CYCLES"):
+            e["mean_resident_waves_per_simd"] = round(4.0 * vals["SQ_WAVE_CYCLES"] / (cyc * 1024.0), 3)
     out[key] = e
 print(json.dumps(out, indent=1))
