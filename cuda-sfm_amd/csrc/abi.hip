@@ -1,5 +1,6 @@
 // abi.hip -- implementation of the C ABI declared in include/sfm_amd.h.
 #include "common.hpp"
+#include "pairs_batch.hpp"
 #include "device_math.hpp"
 #include <stdarg.h>
 #include <stdio.h>
@@ -90,6 +91,7 @@ int sfm_ctx_destroy(sfm_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->match_ws) (void)hipFree(ctx->match_ws);
+    if (ctx->match_jobs_ws) (void)hipFree(ctx->match_jobs_ws);
     if (ctx->match_pf_ws) (void)hipFree(ctx->match_pf_ws);
     if (ctx->homo_ws) (void)hipFree(ctx->homo_ws);
     if (ctx->sift_temp) (void)hipFree(ctx->sift_temp);
@@ -98,6 +100,7 @@ int sfm_ctx_destroy(sfm_ctx *ctx)
     for (sfm_ctx *l : ctx->lane) if (l) (void)sfm_ctx_destroy(l);
     for (hipEvent_t e : ctx->lane_ev) if (e) (void)hipEventDestroy(e);
     if (ctx->pool_records) (void)hipFree(ctx->pool_records);
+    if (ctx->batch_ws) (void)hipFree(ctx->batch_ws);
     if (ctx->views_pinned) (void)hipHostFree(ctx->views_pinned);
     if (ctx->views_image) (void)hipFree(ctx->views_image);
     if (ctx->views_ev) (void)hipEventDestroy(ctx->views_ev);
@@ -1059,10 +1062,150 @@ int sfm_process_pairs(sfm_ctx *ctx, const float h_K[9], const float h_Kinv[9], c
         SFM_HIP_TRY(hipEventRecord(ctx->lane_ev[0], ctx->stream));
         for (int l = 1; l < nlanes; ++l) SFM_HIP_TRY(hipStreamWaitEvent(lanes[l]->stream, ctx->lane_ev[0], 0));
     }
+    // ---- batched path (pairs_batch.hpp): the matcher stays one launch per pair (it fills the chip), everything after it is
+    // THREE launches for all pairs of the call -- 630 pairs x 5 small launches are bound by the host's launch rate, not by
+    // the GPU.  Taken for the reference's own pipeline (SFM_POSE_REFERENCE, K^-1 with last row (0 0 1), up to 4096
+    // hypotheses per pair); anything else runs the per-pair loop below.  Results are bit-identical (same device functions on
+    // the same inputs: tests/test_gpu_dino.py::test_dino_ring_batched_equals_per_pair).
+    bool batched_done = false;
+    int slot = 0;
+    static const bool unbatched_env = getenv("SFM_PAIRS_UNBATCHED") != nullptr;      // A/B and tests
+    const bool unit_z = h_Kinv[6] == 0.0f && h_Kinv[7] == 0.0f && h_Kinv[8] == 1.0f;
+    bool batch = pose_mode == SFM_POSE_REFERENCE && unit_z && owned >= 4 && !unbatched_env;
+    uint32_t max_H = 0;
+    for (int i = first; i < num_pairs && batch; i += stride) {
+        if (pairs[i].n1 < 8 || (pairs[i].d_sift2 && pairs[i].n2 < 1)) continue;
+        const uint32_t H = num_hypotheses ? num_hypotheses : (uint32_t)(pairs[i].n1 / 8);
+        if (H > 4096u || H < 1u) batch = false;
+        if (H > max_H) max_H = H;
+    }
+    // (host staging of the job arrays: declared here so that they outlive every asynchronous copy made from them)
+    std::vector<PairJob> jobs;
+    std::vector<std::vector<MatchJob>> keep_alive;
+    if (batch && max_H > 0) {
+        auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+        std::vector<int> job_slot;
+        jobs.reserve((size_t)owned); job_slot.reserve((size_t)owned);
+        size_t bytes = 0;
+        int slot_b = 0, max_ld = 0, max_nn = 0;
+        for (int i = first; i < num_pairs; i += stride, ++slot_b) {
+            const sfm_pair_desc &d = pairs[i];
+            const bool usable = d.n1 >= 8 && (!d.d_sift2 || d.n2 >= 1);
+            if (h_status) h_status[slot_b] = usable ? SFM_OK : SFM_E_INVALID;
+            if (!usable) continue;
+            PairJob j{};
+            j.s1 = d.d_sift1; j.s2 = d.d_sift2; j.n = d.n1; j.ld = round_up(d.n1, 128);
+            j.H = num_hypotheses ? num_hypotheses : (uint32_t)(d.n1 / 8);
+            sfm_ransac_params dp; sfm_ransac_default_params(&dp, d.n1);
+            j.seed = dp.seed; j.thr = dp.threshold;
+            // offsets first (pointers once the workspace is known)
+            size_t o = bytes;
+            j.m_idx = reinterpret_cast<const int *>(o);            o += up((size_t)j.n * 4);
+            j.X0 = reinterpret_cast<float *>(o);                   o += up((size_t)3 * j.ld * 4);
+            j.X1 = reinterpret_cast<float *>(o);                   o += up((size_t)3 * j.ld * 4);
+            j.counts = reinterpret_cast<int *>(o);                 o += up((size_t)j.H * 4);
+            j.Ecand = reinterpret_cast<float *>(o);                o += up((size_t)j.H * 36);
+            j.key = reinterpret_cast<unsigned long long *>(o);     o += 256;
+            j.mask = reinterpret_cast<uint8_t *>(o);               o += up((size_t)j.n);
+            j.points = reinterpret_cast<float *>(o);               o += up((size_t)4 * j.n * 4);
+            j.chosen = reinterpret_cast<float *>(o);               o += 256;
+            bytes = o;
+            j.record = ctx->pool_records + (size_t)slot_b * SFM_RECORD_FLOATS;
+            if (j.ld > max_ld) max_ld = j.ld;
+            if (j.n > max_nn) max_nn = j.n;
+            jobs.push_back(j); job_slot.push_back(slot_b);
+        }
+        const size_t jobs_bytes = up(jobs.size() * sizeof(PairJob));
+        if (ctx->batch_ws_bytes < bytes + jobs_bytes) {
+            SFM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+            if (ctx->batch_ws) (void)hipFree(ctx->batch_ws);
+            ctx->batch_ws = nullptr; ctx->batch_ws_bytes = 0;
+            SFM_HIP_TRY(hipMalloc(&ctx->batch_ws, bytes + jobs_bytes));
+            ctx->batch_ws_bytes = bytes + jobs_bytes;
+        }
+        char *base = static_cast<char *>(ctx->batch_ws) + jobs_bytes;
+        for (PairJob &j : jobs) {
+            auto fix = [&](auto *&ptr) { ptr = reinterpret_cast<std::remove_reference_t<decltype(ptr)>>(base + reinterpret_cast<size_t>(ptr)); };
+            fix(j.m_idx); fix(j.X0); fix(j.X1); fix(j.counts); fix(j.Ecand); fix(j.key); fix(j.mask); fix(j.points); fix(j.chosen);
+        }
+        PairJob *d_jobs = static_cast<PairJob *>(ctx->batch_ws);
+        SFM_HIP_TRY(hipMemcpyAsync(d_jobs, jobs.data(), jobs.size() * sizeof(PairJob), hipMemcpyHostToDevice, ctx->stream));
+        if (nlanes > 1) {
+            SFM_HIP_TRY(hipEventRecord(ctx->lane_ev[0], ctx->stream));
+            for (int l = 1; l < nlanes; ++l) SFM_HIP_TRY(hipStreamWaitEvent(lanes[l]->stream, ctx->lane_ev[0], 0));
+        }
+        // MatchSiftData per pair: the SiftPoint fields of the first view as always (pairs that share their first view stay
+        // on one lane in list order: the fields end up as after the sequential loop) + the index array the batch reads
+        // Consecutive pairs that share their first view (the all-pairs list of configs[4] has 35, 34, ... of them in a row) go
+        // through ONE matcher launch when the exact MFMA kernel is the one they would run (launch_match_jobs, grid.z = pair).
+        std::vector<const void *> first_views;
+        const int ldf = (int)(sizeof(sfm_sift_point) / sizeof(float));
+        for (size_t k = 0; k < jobs.size() && rc == SFM_OK; ) {
+            PairJob &j = jobs[k];
+            if (!j.s2) { ++k; continue; }
+            size_t v = 0;
+            while (v < first_views.size() && first_views[v] != j.s1) ++v;
+            if (v == first_views.size()) first_views.push_back(j.s1);
+            sfm_ctx *c = lanes[v % (size_t)nlanes];
+            const bool tail = (c->quirks & SFM_QUIRK_MATCH_TAIL) != 0;            // matching.cu:325 (as sfm_match)
+            size_t k1 = k;                                                        // the run [k, k1) of pairs with this first view
+            std::vector<MatchJob> mj;
+            while (k1 < jobs.size() && jobs[k1].s1 == j.s1 && jobs[k1].s2 && jobs[k1].n == j.n) {
+                const sfm_pair_desc &d = pairs[first + job_slot[k1] * stride];
+                const int n2 = tail ? d.n2 - d.n2 % 32 : d.n2;
+                if (n2 < 1 || !match_is_exact(c, j.n, n2)) break;
+                MatchJob m{};
+                m.db = jobs[k1].s2->data; m.ndb = n2; m.lddb = ldf; m.sift2 = jobs[k1].s2;
+                m.sift1 = nullptr;                                                // the record fields: the LAST pair of the run writes them (below)
+                m.out_idx = const_cast<int *>(jobs[k1].m_idx);
+                mj.push_back(m);
+                ++k1;
+            }
+            if (mj.size() >= 2) {
+                mj.back().sift1 = const_cast<sfm_sift_point *>(j.s1);             // as after the sequential loop: the last match's fields
+                keep_alive.push_back(std::move(mj));
+                rc = launch_match_jobs(c, j.s1->data, j.n, ldf, keep_alive.back().data(), (int)keep_alive.back().size());
+                k = k1;
+                continue;
+            }
+            const sfm_pair_desc &d = pairs[first + job_slot[k] * stride];
+            int n2 = d.n2;
+            sfm_sift_point *s1w = const_cast<sfm_sift_point *>(j.s1);
+            if (tail) n2 -= n2 % 32;
+            if (n2 == 0) {
+                rc = launch_match_none(c, j.n, s1w);
+                if (rc == SFM_OK) SFM_HIP_TRY(hipMemsetAsync(const_cast<int *>(j.m_idx), 0xFF, (size_t)j.n * 4, c->stream));      // index -1 everywhere
+            } else {
+                rc = launch_match(c, j.s1->data, j.n, ldf, j.s2->data, n2, ldf, nullptr, nullptr, const_cast<int *>(j.m_idx), s1w, j.s2);
+            }
+            ++k;
+        }
+        for (int l = 1; l < nlanes; ++l) {
+            const hipError_t e1 = hipEventRecord(ctx->lane_ev[l], lanes[l]->stream);
+            const hipError_t e2 = e1 == hipSuccess ? hipStreamWaitEvent(ctx->stream, ctx->lane_ev[l], 0) : e1;
+            if (e2 != hipSuccess && rc == SFM_OK) { set_error("lane join failed: %s", hipGetErrorString(e2)); rc = SFM_E_HIP; }
+        }
+        if (rc != SFM_OK) { (void)hipStreamSynchronize(ctx->stream); return rc; }
+        // already matched pairs (no second view given) read match_xpos / match_ypos of the records: not supported by the
+        // batch kernels -- such lists take the per-pair loop (checked here so that nothing has been launched for them yet)
+        bool all_matched_here = true;
+        for (const PairJob &j : jobs) if (!j.s2) all_matched_here = false;
+        if (all_matched_here) {
+            rc = launch_fill_xu_pairs(ctx, d_jobs, (int)jobs.size(), max_ld, h_Kinv);
+            // eight blocks of eight wavefronts per pair: each stages the pair's points once and runs its share of the batches
+            const int bpp = (int)std::min<uint32_t>(8u, (max_H + 7u) / 8u);
+            if (rc == SFM_OK) rc = launch_fused_pairs(ctx, d_jobs, (int)jobs.size(), bpp);
+            if (rc == SFM_OK) rc = launch_finalize_pose_pairs(ctx, d_jobs, (int)jobs.size(), max_nn);
+            if (rc != SFM_OK) { (void)hipStreamSynchronize(ctx->stream); return rc; }
+            batched_done = true;
+        }
+        // (fall through to the per-pair loop: the matches it repeats are idempotent)
+    }
+    if (!batched_done) {
     // per pair: MatchSiftData (optional) -> fillXU -> estimateE -> pose candidates -> choosePose -> linear triangulation
     // (src/main.cpp:282-307), everything enqueued back to back, no host synchronisation, the record stays on the device
     std::vector<const void *> first_views;
-    int slot = 0;
+    slot = 0;
     for (int i = first; i < num_pairs; i += stride, ++slot) {
         const sfm_pair_desc &d = pairs[i];
         const bool usable = d.n1 >= 8 && (!d.d_sift2 || d.n2 >= 1);
@@ -1093,6 +1236,7 @@ int sfm_process_pairs(sfm_ctx *ctx, const float h_K[9], const float h_Kinv[9], c
     if (rc != SFM_OK) {
         (void)hipStreamSynchronize(ctx->stream);
         return rc;
+    }
     }
     // ONE read-back for all pairs of this rank
     std::vector<float> rec((size_t)owned * SFM_RECORD_FLOATS);

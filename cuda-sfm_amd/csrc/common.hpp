@@ -46,7 +46,9 @@ struct sfm_ctx {
     // matcher scratch: per-split partial (best, second, index) records
     void *match_ws = nullptr;
     size_t match_ws_bytes = 0;
-    size_t match_ticket_bytes = 0;     // zeroed ticket area in front of the partials (grows with the query-block count)
+    size_t match_ticket_bytes = 0;
+    void *match_jobs_ws = nullptr;     // launch_match_jobs: the job array, tickets and per-split partials of every match of the launch
+    size_t match_jobs_ws_bytes = 0;     // zeroed ticket area in front of the partials (grows with the query-block count)
     // pre-filter matcher (match_prefilter.hip): fp16 copies, norms, per-split partials, candidate lists
     void *match_pf_ws = nullptr;
     size_t match_pf_ws_bytes = 0;
@@ -71,6 +73,8 @@ struct sfm_ctx {
     float pool_K[9] = {}, pool_Kinv[9] = {};
     float *pool_records = nullptr;
     size_t pool_records_cap = 0;
+    void *batch_ws = nullptr;          // sfm_process_pairs, batched path: the PairJob array + every pair's buffers (pairs_batch.hpp)
+    size_t batch_ws_bytes = 0;
     void *sift_job = nullptr;          // the extraction in flight (sift.hip: SiftJob), sfm_extract_sift_begin .. _end
     // kernels that already opted in to > 64 KiB of dynamic LDS on THIS context's device (function attributes are
     // per device; a context is used by one host thread at a time, so no process-wide flag)
@@ -202,6 +206,15 @@ int launch_homography(sfm_ctx *ctx, const sfm_sift_point *d_sift, int n, const i
                       float min_score, float max_ambiguity, uint32_t seed, int *num_valid,
                       float h_H[9], int *num_matches, int *h_counts, float *h_homo);
 // match.hip
+struct MatchJob {                       // one database of a many-matches launch (launch_match_jobs)
+    const float *db; int ndb, lddb;     // descriptors of the second view: rows, row stride in floats
+    const sfm_sift_point *sift2;        // its records (positions for match_xpos / match_ypos), or null
+    sfm_sift_point *sift1;              // first view's records to update in place (MatchSiftData), or null
+    int *out_idx;                       // index of the best match per query, or null
+    float *ws_best, *ws_second; int *ws_idx; unsigned int *tickets; int rows_per_split, nsplit;      // filled by the launcher
+};
+int launch_match_jobs(sfm_ctx *ctx, const float *d1, int n1, int ld1, MatchJob *h_jobs, int njobs);
+bool match_is_exact(const sfm_ctx *ctx, int n1, int n2);
 int launch_match_none(sfm_ctx *ctx, int n1, sfm_sift_point *sift1);
 int launch_match_prefilter(sfm_ctx *ctx, const float *d1, int n1, int ld1, const float *d2, int n2, int ld2,
                            float *d_best, float *d_second, int32_t *d_index,

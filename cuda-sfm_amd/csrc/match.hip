@@ -67,22 +67,23 @@ __device__ __forceinline__ void stage_store(float *buf, const float4 (&regs)[16 
 // W = 8 puts two wavefronts on every SIMD of the CU (one block per CU, 67.6 KB of LDS): while one
 // folds its accumulators into the running top-2 or waits at the stage barrier, the other keeps the
 // matrix pipe busy.
+// The work of block (qblock, split) of one match (nsplit database splits); shared by the one-match kernel and the
+// many-matches kernel (grid.z = match, launch_match_jobs).
 template <int CT, int W>
-__global__ __launch_bounds__(W * 64)
-void match_mfma_kernel(const float *__restrict__ q, int nq, int ldq,
+__device__ __forceinline__ void match_body(const float *__restrict__ q, int nq, int ldq,
                        const float *__restrict__ db, int ndb, int lddb,
                        int rows_per_split,
                        float *__restrict__ ws_best, float *__restrict__ ws_second, int *__restrict__ ws_idx,
                        unsigned int *__restrict__ tickets, float *__restrict__ out_best, float *__restrict__ out_second,
-                       int *__restrict__ out_idx, sfm_sift_point *__restrict__ sift1, const sfm_sift_point *__restrict__ sift2)
+                       int *__restrict__ out_idx, sfm_sift_point *__restrict__ sift1, const sfm_sift_point *__restrict__ sift2,
+                       const int qblock, const int split, const int nsplit)
 {
     __shared__ __attribute__((aligned(16))) float lds[2][kRowsPerStage * kLdsStride];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int col = lane & 31;
     const int half = lane >> 5;
-    const int q0 = blockIdx.x * (CT * 32 * W);
-    const int split = blockIdx.y;
+    const int q0 = qblock * (CT * 32 * W);
     const int row_begin = split * rows_per_split;
     const int row_end = min(ndb, row_begin + rows_per_split);
 
@@ -197,13 +198,12 @@ void match_mfma_kernel(const float *__restrict__ q, int nq, int ldq,
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
-        const unsigned int t = atomicAdd(&tickets[blockIdx.x], 1u);
-        s_last = (t == gridDim.y - 1) ? 1 : 0;
-        if (s_last) __hip_atomic_store(&tickets[blockIdx.x], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // ready for the next call
+        const unsigned int t = atomicAdd(&tickets[qblock], 1u);
+        s_last = (t == (unsigned int)nsplit - 1u) ? 1 : 0;
+        if (s_last) __hip_atomic_store(&tickets[qblock], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // ready for the next call
     }
     __syncthreads();
     if (!s_last) return;
-    const int nsplit = gridDim.y;
     for (int k = threadIdx.x; k < CT * 32 * W; k += blockDim.x) {
         const int p1 = q0 + k;
         if (p1 >= nq) break;
@@ -227,6 +227,33 @@ void match_mfma_kernel(const float *__restrict__ q, int nq, int ldq,
         }
         match_emit(p1, t, out_best, out_second, out_idx, sift1, sift2);
     }
+}
+
+template <int CT, int W>
+__global__ __launch_bounds__(W * 64)
+void match_mfma_kernel(const float *__restrict__ q, int nq, int ldq,
+                       const float *__restrict__ db, int ndb, int lddb,
+                       int rows_per_split,
+                       float *__restrict__ ws_best, float *__restrict__ ws_second, int *__restrict__ ws_idx,
+                       unsigned int *__restrict__ tickets, float *__restrict__ out_best, float *__restrict__ out_second,
+                       int *__restrict__ out_idx, sfm_sift_point *__restrict__ sift1, const sfm_sift_point *__restrict__ sift2)
+{
+    match_body<CT, W>(q, nq, ldq, db, ndb, lddb, rows_per_split, ws_best, ws_second, ws_idx, tickets, out_best, out_second, out_idx, sift1, sift2,
+                      (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.y);
+}
+
+// Many matches of ONE query set in one launch (sfm_process_pairs: all pairs (i, j) that share their first view i --
+// BASELINE configs[4] matches every view against up to 35 others): blockIdx.z names the match.  One launch instead of up to
+// 35, the chip stays full across the matches (one 2048 x 2048 match alone is 256 blocks of one wavefront per SIMD and
+// half prologue / epilogue), and with that many blocks the database needs few splits per match.
+template <int CT, int W>
+__global__ __launch_bounds__(W * 64)
+void match_mfma_jobs_kernel(const float *__restrict__ q, int nq, int ldq, const MatchJob *__restrict__ jobs)
+{
+    const MatchJob &j = jobs[blockIdx.z];
+    if ((int)blockIdx.y >= j.nsplit) return;
+    match_body<CT, W>(q, nq, ldq, j.db, j.ndb, j.lddb, j.rows_per_split, j.ws_best, j.ws_second, j.ws_idx, j.tickets, nullptr, nullptr, j.out_idx,
+                      j.sift1, j.sift2, (int)blockIdx.x, (int)blockIdx.y, j.nsplit);
 }
 
 // SFM_QUIRK_MATCH_TAIL with fewer than 32 points in the second set: nothing is searched, every query keeps the initial
@@ -316,6 +343,71 @@ int launch_match(sfm_ctx *ctx, const float *d1, int n1, int ld1, const float *d2
                            d1, n1, ld1, d2, n2, ld2, rows_per_split, wb, wsnd, wi, tickets, d_best, d_second, d_index, sift1, sift2);
     SFM_HIP_TRY(hipGetLastError());
     return SFM_OK;
+}
+
+// njobs matches of the query set (d1, n1) against njobs databases; jobs[k] = { database descriptors, rows, record pointers,
+// index output } filled by the caller except for the workspace / split fields.  Exact matcher only (the caller checks the size).
+int launch_match_jobs(sfm_ctx *ctx, const float *d1, int n1, int ld1, MatchJob *h_jobs, int njobs)
+{
+    if (n1 <= 0 || njobs <= 0) return SFM_OK;
+    const int ct = n1 > 11000 ? 2 : 1;
+    const int wv = n1 > 4500 ? 8 : 4;
+    const int qper = ct * 32 * wv;
+    const int qblocks = (n1 + qper - 1) / qper;
+    // splits: about two rounds of blocks over the CUs in total, at most what the rows allow
+    int want = (2 * ctx->num_cus + qblocks * njobs - 1) / (qblocks * njobs);
+    if (want < 1) want = 1;
+    const size_t ticket_bytes = (size_t)round_up(qblocks * 4, 256);
+    const size_t jobs_bytes = (size_t)round_up(njobs * (int)sizeof(MatchJob), 256);
+    size_t need = jobs_bytes + ticket_bytes * (size_t)njobs;            // [jobs][tickets of every job][partials of every job]
+    int max_split = 1;
+    for (int k = 0; k < njobs; ++k) {
+        MatchJob &j = h_jobs[k];
+        int nsplit = want;
+        const int most = (j.ndb + kRowsPerStage - 1) / kRowsPerStage;
+        if (nsplit > most) nsplit = most;
+        if (nsplit < 1) nsplit = 1;
+        int rps = round_up((j.ndb + nsplit - 1) / nsplit, kRowsPerStage);
+        nsplit = (j.ndb + rps - 1) / rps;
+        j.rows_per_split = rps; j.nsplit = nsplit;
+        if (nsplit > max_split) max_split = nsplit;
+        j.tickets = reinterpret_cast<unsigned int *>(jobs_bytes + ticket_bytes * (size_t)k);
+        j.ws_best = reinterpret_cast<float *>(need);                 need += (size_t)round_up(nsplit * n1 * 4, 256);
+        j.ws_second = reinterpret_cast<float *>(need);               need += (size_t)round_up(nsplit * n1 * 4, 256);
+        j.ws_idx = reinterpret_cast<int *>(need);                    need += (size_t)round_up(nsplit * n1 * 4, 256);
+    }
+    if (need > ctx->match_jobs_ws_bytes) {
+        SFM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if (ctx->match_jobs_ws) (void)hipFree(ctx->match_jobs_ws);
+        ctx->match_jobs_ws = nullptr; ctx->match_jobs_ws_bytes = 0;
+        SFM_HIP_TRY(hipMalloc(&ctx->match_jobs_ws, need));
+        ctx->match_jobs_ws_bytes = need;
+    }
+    char *base = static_cast<char *>(ctx->match_jobs_ws);
+    for (int k = 0; k < njobs; ++k) {
+        MatchJob &j = h_jobs[k];
+        j.tickets = reinterpret_cast<unsigned int *>(base + reinterpret_cast<size_t>(j.tickets));
+        j.ws_best = reinterpret_cast<float *>(base + reinterpret_cast<size_t>(j.ws_best));
+        j.ws_second = reinterpret_cast<float *>(base + reinterpret_cast<size_t>(j.ws_second));
+        j.ws_idx = reinterpret_cast<int *>(base + reinterpret_cast<size_t>(j.ws_idx));
+    }
+    SFM_HIP_TRY(hipMemsetAsync(base + jobs_bytes, 0, ticket_bytes * (size_t)njobs, ctx->stream));     // (the workspace is shared between calls of different shapes)
+    SFM_HIP_TRY(hipMemcpyAsync(base, h_jobs, (size_t)njobs * sizeof(MatchJob), hipMemcpyHostToDevice, ctx->stream));
+    const MatchJob *d_jobs = reinterpret_cast<const MatchJob *>(base);
+    const dim3 grid(qblocks, max_split, njobs);
+    if (ct == 2) hipLaunchKernelGGL((match_mfma_jobs_kernel<2, 8>), grid, dim3(512), 0, ctx->stream, d1, n1, ld1, d_jobs);
+    else if (wv == 8) hipLaunchKernelGGL((match_mfma_jobs_kernel<1, 8>), grid, dim3(512), 0, ctx->stream, d1, n1, ld1, d_jobs);
+    else hipLaunchKernelGGL((match_mfma_jobs_kernel<1, 4>), grid, dim3(256), 0, ctx->stream, d1, n1, ld1, d_jobs);
+    SFM_HIP_TRY(hipGetLastError());
+    ctx->last_match_kernel = SFM_MATCH_EXACT;
+    return SFM_OK;
+}
+
+// whether launch_match would run the exact MFMA kernel for these sizes (the only one launch_match_jobs has)
+bool match_is_exact(const sfm_ctx *ctx, int n1, int n2)
+{
+    const bool big = n1 >= 1024 && n2 >= 1024 && (size_t)n1 * (size_t)n2 >= (size_t)4096 * 4096;
+    return !(ctx->match_kernel == SFM_MATCH_PREFILTER || (ctx->match_kernel == SFM_MATCH_AUTO && big));
 }
 
 } // namespace sfm

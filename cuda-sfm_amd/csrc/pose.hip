@@ -8,6 +8,7 @@
 // kernels is to remove ~40 mallocs/frees, 3 device syncs and the host round trips per pair.
 #include "common.hpp"
 #include "device_math.hpp"
+#include "pairs_batch.hpp"
 
 namespace sfm {
 
@@ -197,18 +198,16 @@ void triangulate_kernel(const float *__restrict__ X0, const float *__restrict__ 
 // d_Pinv, d_Pind) and, when asked, the pair's result record (pair_record_kernel's layout).
 constexpr int kChainPoints = 48;        // points per block: wavefronts 1..3, four lanes per point
 
-__global__ __launch_bounds__(256)
-void pose_chain_reference_kernel(const float *__restrict__ X0, const float *__restrict__ X1, int ld, int n,
-                                 const float *__restrict__ E, int sweeps, float *__restrict__ P, float *__restrict__ Pinv,
-                                 int *__restrict__ pind, float *__restrict__ out, const uint32_t *__restrict__ best,
-                                 float *__restrict__ record)
+// The chain for the 48 points of block `block` of one pair (shared by the one-pair kernel and finalize_pose_pairs).
+// P / Pinv / pind may be null (the many-pairs path keeps only the record).
+__device__ __forceinline__ void pose_chain_body(const float *__restrict__ X0, const float *__restrict__ X1, int ld, int n,
+                                                const float (&e)[9], int sweeps, float *__restrict__ P, float *__restrict__ Pinv,
+                                                int *__restrict__ pind, float *__restrict__ out, uint32_t best_hyp, uint32_t best_count,
+                                                float *__restrict__ record, int block, int &s_choice)
 {
-    __shared__ int s_choice;
     const int wave = threadIdx.x >> 6;
     const int i = threadIdx.x & 3;                 // candidate of this lane
-    float e[9], p[64];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) e[k] = E[k];
+    float p[64];
     pose_candidates(e, SFM_POSE_REFERENCE, p);     // every lane, redundantly: no exchange needed afterwards
     float Pm[16], Q[16];
 #pragma unroll
@@ -231,13 +230,13 @@ void pose_chain_reference_kernel(const float *__restrict__ X0, const float *__re
         const unsigned long long sing = __ballot(!ok) & 0xFull;
         const int choice = m ? (63 - __builtin_clzll(m)) : 0;
         if (threadIdx.x == 0) s_choice = choice;
-        if (blockIdx.x == 0) {
-            if (threadIdx.x < 4) {
+        if (block == 0) {
+            if (threadIdx.x < 4 && P) {
 #pragma unroll
                 for (int k = 0; k < 16; ++k) { P[16 * i + k] = Pm[k]; Pinv[16 * i + k] = Q[k]; }
                 pind[1 + i] = pass ? 1 : 0;
             }
-            if (threadIdx.x == 0) { pind[0] = choice; pind[5] = (int)sing; pind[6] = 0; pind[7] = 0; }
+            if (threadIdx.x == 0 && pind) { pind[0] = choice; pind[5] = (int)sing; pind[6] = 0; pind[7] = 0; }
             if (record) {
                 const int t = threadIdx.x;
                 if (t < 9) record[t] = e[t];
@@ -246,13 +245,13 @@ void pose_chain_reference_kernel(const float *__restrict__ X0, const float *__re
                     for (int k = 0; k < 16; ++k) record[9 + k] = Q[k];
                 }
                 else if (t == 25) record[25] = (float)choice;
-                else if (t == 26) record[26] = (float)best[1];
-                else if (t == 27) record[27] = (float)best[0];
+                else if (t == 26) record[26] = (float)best_count;
+                else if (t == 27) record[27] = (float)best_hyp;
                 else if (t == 28) record[28] = ((sing >> choice) & 1ull) ? 1.0f : 0.0f;
             }
         }
     } else {
-        j = blockIdx.x * kChainPoints + ((int)threadIdx.x - 64) / 4;
+        j = block * kChainPoints + ((int)threadIdx.x - 64) / 4;
         if (j < n) triangulate_point(X0[j], X0[(size_t)ld + j], X1[j], X1[(size_t)ld + j], Q, sweeps, pt);
     }
     __syncthreads();
@@ -262,8 +261,118 @@ void pose_chain_reference_kernel(const float *__restrict__ X0, const float *__re
     }
 }
 
+__global__ __launch_bounds__(256)
+void pose_chain_reference_kernel(const float *__restrict__ X0, const float *__restrict__ X1, int ld, int n,
+                                 const float *__restrict__ E, int sweeps, float *__restrict__ P, float *__restrict__ Pinv,
+                                 int *__restrict__ pind, float *__restrict__ out, const uint32_t *__restrict__ best,
+                                 float *__restrict__ record)
+{
+    __shared__ int s_choice;
+    float e[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) e[k] = E[k];
+    pose_chain_body(X0, X1, ld, n, e, sweeps, P, Pinv, pind, out, best[0], best[1], record, (int)blockIdx.x, s_choice);
+}
+
+// ---- many pairs in one launch (pairs_batch.hpp; grid.y = pair) ----------------------------------------------------------
+// fillXU of every pair from the matcher's index array: U = (xpos, ypos, 1) of the first view, (xpos, ypos, 1) of its match in
+// the second (0, 0, 1 without a match: what MatchSiftData leaves in match_xpos / match_ypos), X = K^-1 U with the very
+// expression of fill_xu_kernel; the pair's arg-max key is cleared for the estimateE that follows.
+struct Kinv9 { float k[9]; };
+
+__global__ __launch_bounds__(256)
+void fill_xu_pairs_kernel(const PairJob *__restrict__ jobs, Kinv9 kinv)
+{
+    const PairJob &job = jobs[blockIdx.y];
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j == 0) job.key[0] = 0ull;
+    if (j >= job.ld) return;
+    const float qnan = __builtin_nanf("");
+    float x0[3] = { qnan, qnan, qnan }, x1[3] = { qnan, qnan, qnan };
+    if (j < job.n) {
+        const sfm_sift_point *p = job.s1 + j;
+        const int m = job.m_idx[j];
+        const float u0[3] = { p->xpos, p->ypos, 1.0f };
+        const float u1[3] = { m >= 0 ? job.s2[m].xpos : 0.0f, m >= 0 ? job.s2[m].ypos : 0.0f, 1.0f };
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            x0[r] = fmaf(kinv.k[3 * r + 2], u0[2], fmaf(kinv.k[3 * r + 1], u0[1], kinv.k[3 * r] * u0[0]));
+            x1[r] = fmaf(kinv.k[3 * r + 2], u1[2], fmaf(kinv.k[3 * r + 1], u1[1], kinv.k[3 * r] * u1[0]));
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        job.X0[(size_t)r * job.ld + j] = x0[r];
+        job.X1[(size_t)r * job.ld + j] = x1[r];
+    }
+}
+
+// ransac_finalize_block + computePosecandidates + choosePose of every pair, ONE wavefront per pair: the winner is the
+// hypothesis the pair's key names, its E the candidate the fused kernel stored (same bits), its count the key's (the
+// recount of ransac_finalize_block applies the same test to the same points).  The chain is the first wavefront of
+// pose_chain_body (block 0 writes the record); E and the chosen inverted candidate go to job.chosen for the points.
+__global__ __launch_bounds__(64)
+void choose_pose_pairs_kernel(const PairJob *__restrict__ jobs, int sweeps)
+{
+    __shared__ int s_choice;
+    const PairJob &job = jobs[blockIdx.x];
+    const unsigned long long key = job.key[0];
+    const uint32_t hyp = 0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFull), cnt = (uint32_t)(key >> 32);
+    float e[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) e[k] = hyp < job.H ? job.Ecand[9 * (size_t)hyp + k] : 0.0f;
+    pose_chain_body(job.X0, job.X1, job.ld, job.n, e, sweeps, nullptr, nullptr, nullptr, job.points, hyp, cnt, job.record, 0, s_choice);
+    // record[9 .. 24] is the chosen inverse (written by the lane that holds it): hand it and E to the point kernel
+    __syncthreads();
+    if (threadIdx.x < 9) job.chosen[threadIdx.x] = e[threadIdx.x];
+    if (threadIdx.x >= 9 && threadIdx.x < 25)          // (written by another lane of this block a barrier ago: read past the L1)
+        job.chosen[threadIdx.x] = __hip_atomic_load(&job.record[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 25) job.chosen[25] = hyp < job.H ? 1.0f : 0.0f;
+}
+
+// linear_triangulation + the inlier mask of every pair: one thread per point, against the inverse choose_pose_pairs chose.
+__global__ __launch_bounds__(256)
+void triangulate_pairs_kernel(const PairJob *__restrict__ jobs, int sweeps)
+{
+    const PairJob &job = jobs[blockIdx.y];
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= job.n) return;
+    float e[9], Q[16];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) e[k] = job.chosen[k];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) Q[k] = job.chosen[9 + k];
+    const size_t ld = (size_t)job.ld;
+    const float x1 = job.X0[j], y1 = job.X0[ld + j], x2 = job.X1[j], y2 = job.X1[ld + j];
+    const Ess E{ e[0], e[1], e[2], e[3], e[4], e[5], e[6], e[7], e[8] };
+    const float r = residual(E, x1, y1, job.X0[2 * ld + j], x2, y2, job.X1[2 * ld + j]);
+    job.mask[j] = (job.chosen[25] != 0.0f && r < job.thr) ? 1 : 0;
+    float pt[4];
+    triangulate_point(x1, y1, x2, y2, Q, sweeps, pt);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) job.points[(size_t)c * job.n + j] = pt[c];     // 4 x n row-major (kernels.h:440-449)
+}
+
 // ---- launchers --------------------------------------------------------------------------------
 constexpr int kSweeps4 = 8;     // one-sided Jacobi sweeps for 4x4 systems
+
+int launch_fill_xu_pairs(sfm_ctx *ctx, const PairJob *d_jobs, int njobs, int max_ld, const float h_Kinv[9])
+{
+    Kinv9 k;
+    for (int i = 0; i < 9; ++i) k.k[i] = h_Kinv[i];
+    hipLaunchKernelGGL(fill_xu_pairs_kernel, dim3((max_ld + 255) / 256, njobs), dim3(256), 0, ctx->stream, d_jobs, k);
+    SFM_HIP_TRY(hipGetLastError());
+    return SFM_OK;
+}
+
+int launch_finalize_pose_pairs(sfm_ctx *ctx, const PairJob *d_jobs, int njobs, int max_n)
+{
+    hipLaunchKernelGGL(choose_pose_pairs_kernel, dim3(njobs), dim3(64), 0, ctx->stream, d_jobs, kSweeps4);
+    SFM_HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(triangulate_pairs_kernel, dim3((max_n + 255) / 256, njobs), dim3(256), 0, ctx->stream, d_jobs, kSweeps4);
+    SFM_HIP_TRY(hipGetLastError());
+    return SFM_OK;
+}
 
 int launch_pose_chain(sfm_pair *pair, float *d_record)
 {

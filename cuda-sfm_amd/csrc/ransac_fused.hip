@@ -17,6 +17,7 @@
 // hypothesis is latency-bound, and 63 short rounds on one wavefront beat one lane grinding through
 // the fully unrolled 44k-instruction solver.
 #include "ransac_device.hpp"
+#include "pairs_batch.hpp"
 
 namespace sfm {
 
@@ -182,14 +183,15 @@ __device__ __forceinline__ void solve_wave(const float *__restrict__ X0, const f
     wave_sync();                                                      // scratch may be reused by the caller
 }
 
+// The body of the fused kernel for the blocks (first_block, first_block + num_blocks, ...) of ONE estimateE: shared by the
+// one-pair kernel and the many-pairs kernel (grid.y = pair, pairs_batch.hip).
 template <int WPB, bool UNITZ>
-__global__ __launch_bounds__(WPB * 64)
-void ransac_fused_waves(const float *__restrict__ X0, const float *__restrict__ X1, int ld, int n,
-                        const int32_t *__restrict__ indices, uint32_t seed, int sweeps,
-                        uint32_t h0, uint32_t count, float thr, int tile, int ntiles,
-                        int *__restrict__ counts, float *__restrict__ Ecand, unsigned long long *best_key)
+__device__ __forceinline__ void fused_body(float *lds, const float *__restrict__ X0, const float *__restrict__ X1, int ld, int n,
+                                           const int32_t *__restrict__ indices, uint32_t seed, int sweeps,
+                                           uint32_t h0, uint32_t count, float thr, int tile, int ntiles,
+                                           int *__restrict__ counts, float *__restrict__ Ecand, unsigned long long *best_key,
+                                           uint32_t first_block, uint32_t num_blocks)
 {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
     const size_t tile_floats = UNITZ ? (size_t)(2 * kUnitZSecond / sizeof(float)) : 6 * (size_t)tile;                  // point tile, then the wave scratches
     uint2 (*sched)[64] = reinterpret_cast<uint2 (*)[64]>(lds + tile_floats + (size_t)WPB * kWaveScratch);
     const int lane = threadIdx.x & 63;
@@ -202,7 +204,7 @@ void ransac_fused_waves(const float *__restrict__ X0, const float *__restrict__ 
     bool staged = false;
     const ThrBand band = make_band(thr);
 
-    for (uint32_t batch = blockIdx.x; batch < nbatch; batch += gridDim.x) {
+    for (uint32_t batch = first_block; batch < nbatch; batch += num_blocks) {
         const uint32_t i = __builtin_amdgcn_readfirstlane(batch * WPB + wave);
         const bool valid = i < count;
         float e[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
@@ -245,6 +247,40 @@ void ransac_fused_waves(const float *__restrict__ X0, const float *__restrict__ 
         for (int w = 1; w < WPB; ++w) b = sbest[w] > b ? sbest[w] : b;
         if (b) atomicMax(best_key, b);
     }
+}
+
+template <int WPB, bool UNITZ>
+__global__ __launch_bounds__(WPB * 64)
+void ransac_fused_waves(const float *__restrict__ X0, const float *__restrict__ X1, int ld, int n,
+                        const int32_t *__restrict__ indices, uint32_t seed, int sweeps,
+                        uint32_t h0, uint32_t count, float thr, int tile, int ntiles,
+                        int *__restrict__ counts, float *__restrict__ Ecand, unsigned long long *best_key)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    fused_body<WPB, UNITZ>(lds, X0, X1, ld, n, indices, seed, sweeps, h0, count, thr, tile, ntiles, counts, Ecand, best_key, blockIdx.x, gridDim.x);
+}
+
+// Many pairs in ONE launch (sfm_process_pairs, BASELINE configs[4]): blockIdx.y names the pair, its blocks are blockIdx.x.
+// Unit-z layout (fillXU), the library's default sampler and solver -- what the per-pair path runs for these pairs.
+__global__ __launch_bounds__(8 * 64)
+void ransac_fused_pairs(const PairJob *__restrict__ jobs)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const PairJob &j = jobs[blockIdx.y];
+    const int tile = j.ld < kTileMax ? j.ld : kTileMax;
+    const int ntiles = (j.ld + tile - 1) / tile;
+    if ((uint32_t)blockIdx.x * 8u >= j.H) return;           // (uniform per block: before any barrier)
+    fused_body<8, true>(lds, j.X0, j.X1, j.ld, j.n, nullptr, j.seed, 0, 0u, j.H, j.thr, tile, ntiles, j.counts, j.Ecand, j.key, blockIdx.x, gridDim.x);
+}
+
+int launch_fused_pairs(sfm_ctx *ctx, const PairJob *d_jobs, int njobs, int blocks_per_pair)
+{
+    const size_t lds = (size_t)2 * kUnitZSecond + (size_t)8 * kWaveScratch * sizeof(float) + 9 * 64 * sizeof(uint2);
+    const int rc_lds = allow_big_lds(ctx, reinterpret_cast<const void *>(&ransac_fused_pairs));
+    if (rc_lds != SFM_OK) return rc_lds;
+    hipLaunchKernelGGL(ransac_fused_pairs, dim3(blocks_per_pair, njobs), dim3(8 * 64), lds, ctx->stream, d_jobs);
+    SFM_HIP_TRY(hipGetLastError());
+    return SFM_OK;
 }
 
 // Winner's E, inlier mask and count in ONE launch of one 1024-thread block (the two launches it replaces cost ~14 us of a
