@@ -26,7 +26,11 @@ all: $(LIB) $(COMMLIB) oracle hostcheck $(DEMO) $(HDEMO) $(SDEMO) $(MAINAPP) $(I
 
 $(BUILD)/%.o: $(CSRC)/%.hip $(HDRS)
 	@mkdir -p $(BUILD)
-	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+	$(HIPCC) $(HIPFLAGS) $(FLAGS_$*) -c $< -o $@
+
+# the lane-solve kernels are long chains of scalar FP32 operations: the SLP vectoriser pairs some of them into v_pk_* and pays
+# for it with register moves (366 v_mov in 2473 instructions); without it the same arithmetic needs fewer issue slots
+FLAGS_ransac := -fno-slp-vectorize
 
 $(LIB): $(OBJS)
 	@mkdir -p $(PKG)/lib

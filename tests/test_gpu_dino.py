@@ -185,3 +185,29 @@ def test_dino_main_program(tmp_path):
     assert n == int(g["num_pts"][0]) and (hyp, cnt) == tuple(int(v) for v in g["best"]) and same_bits(E, g["E"])
     lines = open(ply).read().splitlines()
     assert lines[0] == "ply" and int([l for l in lines if l.startswith("element vertex")][0].split()[-1]) > 100
+
+
+def test_dino_pair_with_1024_hypotheses(gpu):
+    """BASELINE configs[1] as written: the dino pair, ~2k matches, 1024 RANSAC hypotheses (the reference's own run uses
+    H = N/8 = 269: test_dino_pair_every_stage).  Match + estimateE end to end on the real frames, every count, the key, E and
+    the mask against the oracle chain fed with the GPU's features and matches."""
+    torch, dev, ctx = gpu
+    imgs = [read_pnm_grey(frame(k)) for k in (0, 1)]
+    (d1, n1, _), (d2, n2, _) = extract(gpu, imgs[0]), extract(gpu, imgs[1])
+    ctx.match(d1, n1, d2, n2)
+    m = d1.cpu().numpy().view(O.SIFT_DTYPE).reshape(-1)[:n1]
+    f2 = d2.cpu().numpy().view(O.SIFT_DTYPE).reshape(-1)[:n2]
+    om = O.match_sift(m.copy(), f2)
+    assert np.array_equal(m["match"], om["match"]) and same_bits(m["score"], om["score"])
+    pair = S.ImagePair(ctx, DINO_K, DINO_KINV, 2, n1)
+    pair.fillXU(d1)
+    H = 1024
+    p = S.default_params(n1, num_hypotheses=H)
+    pair.estimateE(p)
+    _, _, X0, X1 = O.fill_xu(om, DINO_KINV)
+    key, ocounts, oE = O.ransac_range(X0, X1, 0, H, p.threshold, p.jacobi_sweeps, seed=p.seed, want_E=True)
+    ocnt, ohyp = O.unpack_key(key)
+    assert np.array_equal(pair.get_inlier_counts(H), ocounts) and pair.get_key() == key
+    assert pair.get_best() == (ohyp, ocnt) and same_bits(pair.get_E(), oE[ohyp].reshape(3, 3))
+    assert np.array_equal(pair.get_inlier_mask(), O.count_inliers(oE[ohyp], X0, X1, p.threshold)[1])
+    assert ocnt >= 594                                       # at least the consensus set the 269-hypothesis run finds
