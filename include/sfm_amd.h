@@ -309,7 +309,11 @@ int sfm_extract_views(sfm_ctx *ctx, const float *const *h_images, int num_views,
  * one pooled Image_pair, the result records assembled on the device and read back ONCE at the end.
  * h_records: 28 floats per owned pair in list order (layout of sfm_get_result; all -1 for a pair with fewer than 8
  * features); h_status (optional): SFM_OK / SFM_E_INVALID (too few features) / SFM_E_SINGULAR per owned pair -- when it
- * is NULL a singular pose makes the call return SFM_E_SINGULAR.  Synchronous at the end. */
+ * is NULL a singular pose makes the call return SFM_E_SINGULAR.  Synchronous at the end.
+ * With SFM_POSE_REFERENCE, a K^-1 whose last row is (0 0 1) and at most 4096 hypotheses per pair the call is batched:
+ * consecutive pairs that share their first view go through ONE matcher launch, fillXU / estimateE / choosePose /
+ * triangulation are four launches for ALL owned pairs (same arithmetic, bit-identical records); the environment variable
+ * SFM_PAIRS_UNBATCHED selects the per-pair loop (A/B runs, tests). */
 typedef struct sfm_pair_desc {
     sfm_sift_point *d_sift1;        /* features of the first view (match fields are written when d_sift2 != NULL) */
     int n1;
