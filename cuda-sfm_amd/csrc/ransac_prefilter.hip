@@ -238,7 +238,6 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
     lds_cf *etab_l = (lds_cf *)etab;
     lds_i *cnt_l = (lds_i *)cnt;
     lds_u2 *ring = (lds_u2 *)(cnt + 32);
-    lds_cf4 *pts_l = (lds_cf4 *)pts;
     lds_ch8 *frag_lane = (lds_ch8 *)(smem + kPfLdsFrag) + lane;
     const ThrBand band = make_band(thr);
     uint32_t passes_done = 0;
