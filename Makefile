@@ -31,6 +31,8 @@ $(BUILD)/%.o: $(CSRC)/%.hip $(HDRS)
 # the lane-solve kernels are long chains of scalar FP32 operations: the SLP vectoriser pairs some of them into v_pk_* and pays
 # for it with register moves (366 v_mov in 2473 instructions); without it the same arithmetic needs fewer issue slots
 FLAGS_ransac := -fno-slp-vectorize
+# match_fused's two interleaved exact chains: paired into v_pk_fma_f32 they need a register move per operand
+FLAGS_match_fused := -fno-slp-vectorize
 
 $(LIB): $(OBJS)
 	@mkdir -p $(PKG)/lib

@@ -34,7 +34,7 @@ _lib = C.CDLL(LIB_PATH)
 OK, E_INVALID, E_HIP, E_NOMEM, E_STATE, E_SINGULAR = 0, -1, -2, -3, -4, -5
 KERNEL_AUTO, KERNEL_SPLIT, KERNEL_FUSED, KERNEL_MFMA, KERNEL_PREFILTER = 0, 1, 2, 3, 4
 QUIRK_MATCH_TAIL = 1
-MATCH_AUTO, MATCH_EXACT, MATCH_PREFILTER = 0, 1, 2
+MATCH_AUTO, MATCH_EXACT, MATCH_PREFILTER, MATCH_FUSED = 0, 1, 2, 3
 POSE_REFERENCE, POSE_CORRECT = 0, 1
 (BUF_X0, BUF_X1, BUF_U0, BUF_U1, BUF_E, BUF_P, BUF_PINV, BUF_POINTS, BUF_COUNTS, BUF_MASK, BUF_KEY,
  BUF_ECAND, BUF_PIND) = range(13)
@@ -222,7 +222,7 @@ class Context:
         _check(_lib.sfm_ctx_set_quirks(self._h, C.c_uint(int(flags))), "sfm_ctx_set_quirks")
 
     def set_match_kernel(self, kernel):
-        """MATCH_AUTO / MATCH_EXACT / MATCH_PREFILTER (bit-identical results; A/B runs and tests)."""
+        """MATCH_AUTO / MATCH_EXACT / MATCH_PREFILTER / MATCH_FUSED (bit-identical results; A/B runs and tests)."""
         _check(_lib.sfm_ctx_set_match_kernel(self._h, int(kernel)), "sfm_ctx_set_match_kernel")
 
     def last_match_kernel(self):
@@ -639,16 +639,26 @@ _lib.sfm_process_pairs.argtypes = [_vp, C.POINTER(C.c_float), C.POINTER(C.c_floa
                                    C.c_uint32, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int)]
 
 
+PAIR_DESC_DTYPE = np.dtype({"names": ["d_sift1", "n1", "d_sift2", "n2"], "formats": [np.uint64, np.int32, np.uint64, np.int32],
+                            "offsets": [PairDesc.d_sift1.offset, PairDesc.n1.offset, PairDesc.d_sift2.offset, PairDesc.n2.offset],
+                            "itemsize": C.sizeof(PairDesc)})
+
+
 def process_pairs_local(ctx, descs, K, Kinv, rank=0, world=1, num_hypotheses=None, pose_mode=POSE_REFERENCE):
     """sfm_process_pairs: the pairs rank, rank + world, ... of `descs` through the C library -- per pair MatchSiftData
     (when a second view is given), fillXU, estimateE, pose candidates, choosePose, linear triangulation, enqueued back to
-    back, ONE read-back.  descs: sequence of (d_sift1, n1) [already matched] or (d_sift1, n1, d_sift2, n2).
+    back, ONE read-back.  descs: sequence of (d_sift1, n1) [already matched] or (d_sift1, n1, d_sift2, n2), or a numpy array
+    of PAIR_DESC_DTYPE (device addresses as integers: what process_views builds for hundreds of pairs without a Python loop).
     Returns (records [owned, 28] float32, status [owned] int32) in list order of the owned pairs."""
-    arr = (PairDesc * max(1, len(descs)))()
-    for i, d in enumerate(descs):
-        arr[i].d_sift1 = _ptr(d[0]); arr[i].n1 = int(d[1])
-        arr[i].d_sift2 = _ptr(d[2]) if len(d) > 2 and d[2] is not None else None
-        arr[i].n2 = int(d[3]) if len(d) > 3 else 0
+    if isinstance(descs, np.ndarray):
+        assert descs.dtype == PAIR_DESC_DTYPE and descs.flags.c_contiguous
+        arr = descs.ctypes.data_as(C.POINTER(PairDesc))
+    else:
+        arr = (PairDesc * max(1, len(descs)))()
+        for i, d in enumerate(descs):
+            arr[i].d_sift1 = _ptr(d[0]); arr[i].n1 = int(d[1])
+            arr[i].d_sift2 = _ptr(d[2]) if len(d) > 2 and d[2] is not None else None
+            arr[i].n2 = int(d[3]) if len(d) > 3 else 0
     owned = len(range(int(rank), len(descs), int(world)))
     rec = np.full((max(owned, 1), 28), -1.0, np.float32)
     status = np.zeros(max(owned, 1), np.int32)
@@ -749,25 +759,28 @@ def process_views(ctx, images, K, Kinv, pairs=None, rank=0, world=1, max_pts=819
     # ONE exchange of the fixed-size feature blocks; feature counts of all views with ONE read-back
     feats, counts = exchange_view_features(block, V, world, max_pts, gather_features)
 
-    def view(v):
-        return feats[view_slot(v, world, slots)][:rec_bytes].reshape(max_pts, 576), counts[v]
-
     mine = pair_schedule(len(pairs), rank, world)
     max_local = (len(pairs) + world - 1) // world
     rec = np.full((max(max_local, 1), RESULT_FLOATS + 1), -1.0, np.float32)
     # per pair MatchSiftData + the two-view pipeline, all inside sfm_process_pairs (C): MatchSiftData writes its result
-    # fields (score .. match_ypos) straight into the first view's records -- nothing else of a record changes, so no copy
-    descs = []
-    for (i, j) in pairs:
-        (s1, n1), (s2, n2) = view(i), view(j)
-        descs.append((s1, n1, s2, n2))
+    # fields (score .. match_ypos) straight into the first view's records -- nothing else of a record changes, so no copy.
+    # The descriptor array is built with numpy from the views' device addresses (630 pairs: a Python loop over torch slices
+    # used to keep the GPU idle for milliseconds between the extraction and the first matcher launch).
+    vptr = np.array([feats.data_ptr() + view_slot(v, world, slots) * (rec_bytes + 64) for v in range(V)], np.uint64)
+    vcnt = np.array(counts, np.int32)
+    pij = np.asarray(pairs, np.int64).reshape(-1, 2)
+    descs = np.zeros(len(pairs), PAIR_DESC_DTYPE)
+    if len(pairs):
+        descs["d_sift1"] = vptr[pij[:, 0]]; descs["n1"] = vcnt[pij[:, 0]]
+        descs["d_sift2"] = vptr[pij[:, 1]]; descs["n2"] = vcnt[pij[:, 1]]
     if mine:
         r, status = process_pairs_local(ctx, descs, K, Kinv, rank, world, num_hypotheses, pose_mode)
-        for slot, pid in enumerate(mine):
-            if status[slot] == 0 or status[slot] == E_SINGULAR:
-                rec[slot, :RESULT_FLOATS] = r[slot]
-                rec[slot, RESULT_FLOATS] = pid
-    local = torch.from_numpy(rec).to(dev)
-    gathered = gather_results(local) if (gather_results is not None and world > 1) else local
-    g = gathered.cpu().numpy().reshape(-1, RESULT_FLOATS + 1)
-    return {int(r[RESULT_FLOATS]): r[:RESULT_FLOATS].copy() for r in g if r[RESULT_FLOATS] >= 0}, counts
+        ok = (status == 0) | (status == E_SINGULAR)
+        rec[:len(mine), :RESULT_FLOATS] = np.where(ok[:, None], r, -1.0)
+        rec[:len(mine), RESULT_FLOATS] = np.where(ok, np.asarray(mine, np.float32), -1.0)
+    if gather_results is not None and world > 1:
+        g = gather_results(torch.from_numpy(rec).to(dev)).cpu().numpy().reshape(-1, RESULT_FLOATS + 1)
+    else:
+        g = rec
+    ids = g[:, RESULT_FLOATS]
+    return {int(i): g[k, :RESULT_FLOATS] for k, i in enumerate(ids) if i >= 0}, counts

@@ -133,7 +133,7 @@ int sfm_ctx_set_quirks(sfm_ctx *ctx, unsigned int flags)
 int sfm_ctx_set_match_kernel(sfm_ctx *ctx, int kernel)
 {
     SFM_REQUIRE(ctx, SFM_E_INVALID, "null context");
-    SFM_REQUIRE(kernel == SFM_MATCH_AUTO || kernel == SFM_MATCH_EXACT || kernel == SFM_MATCH_PREFILTER, SFM_E_INVALID, "unknown matcher %d", kernel);
+    SFM_REQUIRE(kernel == SFM_MATCH_AUTO || kernel == SFM_MATCH_EXACT || kernel == SFM_MATCH_PREFILTER || kernel == SFM_MATCH_FUSED, SFM_E_INVALID, "unknown matcher %d", kernel);
     ctx->match_kernel = kernel;
     for (sfm_ctx *l : ctx->lane) if (l) l->match_kernel = kernel;
     return SFM_OK;
@@ -1137,7 +1137,7 @@ int sfm_process_pairs(sfm_ctx *ctx, const float h_K[9], const float h_Kinv[9], c
         // MatchSiftData per pair: the SiftPoint fields of the first view as always (pairs that share their first view stay
         // on one lane in list order: the fields end up as after the sequential loop) + the index array the batch reads
         // Consecutive pairs that share their first view (the all-pairs list of configs[4] has 35, 34, ... of them in a row) go
-        // through ONE matcher launch when the exact MFMA kernel is the one they would run (launch_match_jobs, grid.z = pair).
+        // through ONE matcher launch (launch_match_jobs, grid.z = pair) unless the four-kernel pre-filter is what they would run.
         std::vector<const void *> first_views;
         const int ldf = (int)(sizeof(sfm_sift_point) / sizeof(float));
         for (size_t k = 0; k < jobs.size() && rc == SFM_OK; ) {
@@ -1150,10 +1150,13 @@ int sfm_process_pairs(sfm_ctx *ctx, const float h_K[9], const float h_Kinv[9], c
             const bool tail = (c->quirks & SFM_QUIRK_MATCH_TAIL) != 0;            // matching.cu:325 (as sfm_match)
             size_t k1 = k;                                                        // the run [k, k1) of pairs with this first view
             std::vector<MatchJob> mj;
+            int run_kernel = -1;                                                  // one kernel per launch: what match_pick says for the first pair
             while (k1 < jobs.size() && jobs[k1].s1 == j.s1 && jobs[k1].s2 && jobs[k1].n == j.n) {
                 const sfm_pair_desc &d = pairs[first + job_slot[k1] * stride];
                 const int n2 = tail ? d.n2 - d.n2 % 32 : d.n2;
-                if (n2 < 1 || !match_is_exact(c, j.n, n2)) break;
+                const int pick = n2 < 1 ? SFM_MATCH_PREFILTER : match_pick_jobs(c, j.n, n2);
+                if (pick == SFM_MATCH_PREFILTER || (run_kernel >= 0 && pick != run_kernel)) break;
+                run_kernel = pick;
                 MatchJob m{};
                 m.db = jobs[k1].s2->data; m.ndb = n2; m.lddb = ldf; m.sift2 = jobs[k1].s2;
                 m.sift1 = nullptr;                                                // the record fields: the LAST pair of the run writes them (below)
@@ -1164,7 +1167,7 @@ int sfm_process_pairs(sfm_ctx *ctx, const float h_K[9], const float h_Kinv[9], c
             if (mj.size() >= 2) {
                 mj.back().sift1 = const_cast<sfm_sift_point *>(j.s1);             // as after the sequential loop: the last match's fields
                 keep_alive.push_back(std::move(mj));
-                rc = launch_match_jobs(c, j.s1->data, j.n, ldf, keep_alive.back().data(), (int)keep_alive.back().size());
+                rc = launch_match_jobs(c, j.s1->data, j.n, ldf, keep_alive.back().data(), (int)keep_alive.back().size(), run_kernel);
                 k = k1;
                 continue;
             }

@@ -52,7 +52,7 @@ struct sfm_ctx {
     // pre-filter matcher (match_prefilter.hip): fp16 copies, norms, per-split partials, candidate lists
     void *match_pf_ws = nullptr;
     size_t match_pf_ws_bytes = 0;
-    int match_kernel = 0;              // SFM_MATCH_AUTO / _EXACT / _PREFILTER (sfm_ctx_set_match_kernel)
+    int match_kernel = 0;              // SFM_MATCH_AUTO / _EXACT / _PREFILTER / _FUSED (sfm_ctx_set_match_kernel)
     int last_match_kernel = 0;         // what the last sfm_match / sfm_match_soa call ran
     void *homo_ws = nullptr;           // homography RANSAC scratch
     size_t homo_ws_bytes = 0;
@@ -213,8 +213,14 @@ struct MatchJob {                       // one database of a many-matches launch
     int *out_idx;                       // index of the best match per query, or null
     float *ws_best, *ws_second; int *ws_idx; unsigned int *tickets; int rows_per_split, nsplit;      // filled by the launcher
 };
-int launch_match_jobs(sfm_ctx *ctx, const float *d1, int n1, int ld1, MatchJob *h_jobs, int njobs);
-bool match_is_exact(const sfm_ctx *ctx, int n1, int n2);
+int launch_match_jobs(sfm_ctx *ctx, const float *d1, int n1, int ld1, MatchJob *h_jobs, int njobs, int kernel);
+int match_pick(const sfm_ctx *ctx, int n1, int n2);
+int match_pick_jobs(const sfm_ctx *ctx, int n1, int n2);
+int match_partials_workspace(sfm_ctx *ctx, int qblocks, int nsplit, int n1, unsigned int **tickets, float **ws_best, float **ws_second, int **ws_idx);
+int match_jobs_workspace(sfm_ctx *ctx, int n1, int qblocks, int rows_unit, int rounds, MatchJob *h_jobs, int njobs, const MatchJob **d_jobs, int *max_split_out);
+int launch_match_fused(sfm_ctx *ctx, const float *d1, int n1, int ld1, const float *d2, int n2, int ld2,
+                       float *d_best, float *d_second, int32_t *d_index, sfm_sift_point *sift1, const sfm_sift_point *sift2);
+int launch_match_fused_jobs(sfm_ctx *ctx, const float *d1, int n1, int ld1, MatchJob *h_jobs, int njobs);
 int launch_match_none(sfm_ctx *ctx, int n1, sfm_sift_point *sift1);
 int launch_match_prefilter(sfm_ctx *ctx, const float *d1, int n1, int ld1, const float *d2, int n2, int ld2,
                            float *d_best, float *d_second, int32_t *d_index,

@@ -274,45 +274,12 @@ int launch_match_none(sfm_ctx *ctx, int n1, sfm_sift_point *sift1)
     return SFM_OK;
 }
 
-int launch_match(sfm_ctx *ctx, const float *d1, int n1, int ld1, const float *d2, int n2, int ld2,
-                 float *d_best, float *d_second, int32_t *d_index,
-                 sfm_sift_point *sift1, const sfm_sift_point *sift2)
+// scratch of a one-match launch: one ticket per query block (zero between calls: the merging block resets its own) + the
+// per-split partials.  The ticket area only ever grows (sized from the largest query-block count seen, so any n1 works); it
+// sits in front of the partials and is zeroed when the workspace is (re)allocated -- the partials of one call must never land
+// where a later call expects zeroed tickets.
+int match_partials_workspace(sfm_ctx *ctx, int qblocks, int nsplit, int n1, unsigned int **tickets, float **ws_best, float **ws_second, int **ws_idx)
 {
-    if (n1 <= 0 || n2 <= 0) return SFM_OK;                 // matching.cu:1095-1096
-    // large sets: fp16 matrix-core pre-filter + exact scores of the few candidates (match_prefilter.hip; same results)
-    // (measured crossover, profiles/r02_match_bench.txt: 3000^2 0.043 vs 0.034 ms, 4096^2 0.043 vs 0.050, 5500^2 0.057 vs 0.083, 16384^2 0.15 vs 0.55)
-    const bool big = n1 >= 1024 && n2 >= 1024 && (size_t)n1 * (size_t)n2 >= (size_t)4096 * 4096;
-    if (ctx->match_kernel == SFM_MATCH_PREFILTER || (ctx->match_kernel == SFM_MATCH_AUTO && big)) {
-        ctx->last_match_kernel = SFM_MATCH_PREFILTER;
-        return launch_match_prefilter(ctx, d1, n1, ld1, d2, n2, ld2, d_best, d_second, d_index, sift1, sift2);
-    }
-    ctx->last_match_kernel = SFM_MATCH_EXACT;
-    // three configurations (column tiles per wavefront, wavefronts per block), crossovers measured with profiles/match_cfg_probe.py
-    // (TFLOP/s at n x n):  n      3000   4500   5500   7000   9000   10000  12000  14000  16384
-    //                      (1,4)  64     79     72     79     81
-    //                      (1,8)  58     78     91     98     105    104    110    106    123
-    //                      (2,8)  42     70     84     91     103    102    112    118    127
-    static const char *cfg_env = getenv("SFM_MATCH_CFG");    // profiling only: "ct,wv"
-    int ct = n1 > 11000 ? 2 : 1;
-    int wv = n1 > 4500 ? 8 : 4;                      // wavefronts per block
-    if (cfg_env && cfg_env[0] && cfg_env[1] && cfg_env[2]) { ct = cfg_env[0] == '2' ? 2 : 1; wv = cfg_env[2] == '8' ? 8 : 4; }
-    const int qper = ct * 32 * wv;                          // queries per block
-    const int qblocks = (n1 + qper - 1) / qper;
-    // (query block, database split) pairs: as many as fit in ONE round over the CUs, not more -- rounding the split
-    // count up (11 x 24 = 264 blocks on 256 CUs) costs a whole second round (12000 x 12000: 0.44 -> 0.30 ms), and two
-    // blocks per CU of the small configuration only add prologues and partials (2048 x 2048: 0.026 -> 0.022 ms)
-    int nsplit = ctx->num_cus / qblocks;
-    const int max_split = (n2 + kRowsPerStage - 1) / kRowsPerStage;
-    if (nsplit > max_split) nsplit = max_split;
-    if (nsplit < 1) nsplit = 1;
-    int rows_per_split = (n2 + nsplit - 1) / nsplit;
-    rows_per_split = round_up(rows_per_split, kRowsPerStage);
-    nsplit = (n2 + rows_per_split - 1) / rows_per_split;
-
-    // scratch: one ticket per query block (zero between calls: the merging block resets its own) + the per-split partials
-    // The ticket area only ever grows (sized from the largest query-block count seen, so any n1 works); it sits in front of
-    // the partials and is zeroed when the workspace is (re)allocated -- the partials of one call must never land where a
-    // later call expects zeroed tickets.
     size_t ticket_bytes = ctx->match_ticket_bytes < 4096 ? 4096 : ctx->match_ticket_bytes;
     if ((size_t)qblocks * 4 > ticket_bytes) ticket_bytes = (size_t)round_up(qblocks * 4, 4096);
     const size_t kTicketBytes = ticket_bytes;
@@ -326,48 +293,31 @@ int launch_match(sfm_ctx *ctx, const float *d1, int n1, int ld1, const float *d2
         SFM_HIP_TRY(hipMemsetAsync(ctx->match_ws, 0, kTicketBytes, ctx->stream));
         ctx->match_ws_bytes = bytes; ctx->match_ticket_bytes = kTicketBytes;
     }
-    unsigned int *tickets = static_cast<unsigned int *>(ctx->match_ws);
-    float *wb = reinterpret_cast<float *>(static_cast<char *>(ctx->match_ws) + kTicketBytes);
-    float *wsnd = wb + (size_t)nsplit * n1;
-    int *wi = reinterpret_cast<int *>(wsnd + (size_t)nsplit * n1);
-
-    const dim3 grid(qblocks, nsplit);
-    if (ct == 2)
-        hipLaunchKernelGGL((match_mfma_kernel<2, 8>), grid, dim3(512), 0, ctx->stream,
-                           d1, n1, ld1, d2, n2, ld2, rows_per_split, wb, wsnd, wi, tickets, d_best, d_second, d_index, sift1, sift2);
-    else if (wv == 8)
-        hipLaunchKernelGGL((match_mfma_kernel<1, 8>), grid, dim3(512), 0, ctx->stream,
-                           d1, n1, ld1, d2, n2, ld2, rows_per_split, wb, wsnd, wi, tickets, d_best, d_second, d_index, sift1, sift2);
-    else
-        hipLaunchKernelGGL((match_mfma_kernel<1, 4>), grid, dim3(256), 0, ctx->stream,
-                           d1, n1, ld1, d2, n2, ld2, rows_per_split, wb, wsnd, wi, tickets, d_best, d_second, d_index, sift1, sift2);
-    SFM_HIP_TRY(hipGetLastError());
+    *tickets = static_cast<unsigned int *>(ctx->match_ws);
+    *ws_best = reinterpret_cast<float *>(static_cast<char *>(ctx->match_ws) + kTicketBytes);
+    *ws_second = *ws_best + (size_t)nsplit * n1;
+    *ws_idx = reinterpret_cast<int *>(*ws_second + (size_t)nsplit * n1);
     return SFM_OK;
 }
 
-// njobs matches of the query set (d1, n1) against njobs databases; jobs[k] = { database descriptors, rows, record pointers,
-// index output } filled by the caller except for the workspace / split fields.  Exact matcher only (the caller checks the size).
-int launch_match_jobs(sfm_ctx *ctx, const float *d1, int n1, int ld1, MatchJob *h_jobs, int njobs)
+// scratch of a many-matches launch ([jobs][tickets of every job][partials of every job]) and the split of every job:
+// about `rounds` rounds of blocks over the CUs in total, at most what the rows allow (`rows_unit` rows per stage); the job
+// array is copied to the device, *d_jobs points at it.
+int match_jobs_workspace(sfm_ctx *ctx, int n1, int qblocks, int rows_unit, int rounds, MatchJob *h_jobs, int njobs, const MatchJob **d_jobs, int *max_split_out)
 {
-    if (n1 <= 0 || njobs <= 0) return SFM_OK;
-    const int ct = n1 > 11000 ? 2 : 1;
-    const int wv = n1 > 4500 ? 8 : 4;
-    const int qper = ct * 32 * wv;
-    const int qblocks = (n1 + qper - 1) / qper;
-    // splits: about two rounds of blocks over the CUs in total, at most what the rows allow
-    int want = (2 * ctx->num_cus + qblocks * njobs - 1) / (qblocks * njobs);
+    int want = (rounds * ctx->num_cus + qblocks * njobs - 1) / (qblocks * njobs);
     if (want < 1) want = 1;
     const size_t ticket_bytes = (size_t)round_up(qblocks * 4, 256);
     const size_t jobs_bytes = (size_t)round_up(njobs * (int)sizeof(MatchJob), 256);
-    size_t need = jobs_bytes + ticket_bytes * (size_t)njobs;            // [jobs][tickets of every job][partials of every job]
+    size_t need = jobs_bytes + ticket_bytes * (size_t)njobs;
     int max_split = 1;
     for (int k = 0; k < njobs; ++k) {
         MatchJob &j = h_jobs[k];
         int nsplit = want;
-        const int most = (j.ndb + kRowsPerStage - 1) / kRowsPerStage;
+        const int most = (j.ndb + rows_unit - 1) / rows_unit;
         if (nsplit > most) nsplit = most;
         if (nsplit < 1) nsplit = 1;
-        int rps = round_up((j.ndb + nsplit - 1) / nsplit, kRowsPerStage);
+        int rps = round_up((j.ndb + nsplit - 1) / nsplit, rows_unit);
         nsplit = (j.ndb + rps - 1) / rps;
         j.rows_per_split = rps; j.nsplit = nsplit;
         if (nsplit > max_split) max_split = nsplit;
@@ -393,7 +343,78 @@ int launch_match_jobs(sfm_ctx *ctx, const float *d1, int n1, int ld1, MatchJob *
     }
     SFM_HIP_TRY(hipMemsetAsync(base + jobs_bytes, 0, ticket_bytes * (size_t)njobs, ctx->stream));     // (the workspace is shared between calls of different shapes)
     SFM_HIP_TRY(hipMemcpyAsync(base, h_jobs, (size_t)njobs * sizeof(MatchJob), hipMemcpyHostToDevice, ctx->stream));
-    const MatchJob *d_jobs = reinterpret_cast<const MatchJob *>(base);
+    *d_jobs = reinterpret_cast<const MatchJob *>(base);
+    *max_split_out = max_split;
+    return SFM_OK;
+}
+
+int launch_match(sfm_ctx *ctx, const float *d1, int n1, int ld1, const float *d2, int n2, int ld2,
+                 float *d_best, float *d_second, int32_t *d_index,
+                 sfm_sift_point *sift1, const sfm_sift_point *sift2)
+{
+    if (n1 <= 0 || n2 <= 0) return SFM_OK;                 // matching.cu:1095-1096
+    const int pick = match_pick(ctx, n1, n2);
+    if (pick == SFM_MATCH_PREFILTER) {
+        ctx->last_match_kernel = SFM_MATCH_PREFILTER;
+        return launch_match_prefilter(ctx, d1, n1, ld1, d2, n2, ld2, d_best, d_second, d_index, sift1, sift2);
+    }
+    if (pick == SFM_MATCH_FUSED) return launch_match_fused(ctx, d1, n1, ld1, d2, n2, ld2, d_best, d_second, d_index, sift1, sift2);
+    ctx->last_match_kernel = SFM_MATCH_EXACT;
+    // three configurations (column tiles per wavefront, wavefronts per block), crossovers measured with profiles/match_cfg_probe.py
+    // (TFLOP/s at n x n):  n      3000   4500   5500   7000   9000   10000  12000  14000  16384
+    //                      (1,4)  64     79     72     79     81
+    //                      (1,8)  58     78     91     98     105    104    110    106    123
+    //                      (2,8)  42     70     84     91     103    102    112    118    127
+    static const char *cfg_env = getenv("SFM_MATCH_CFG");    // profiling only: "ct,wv"
+    int ct = n1 > 11000 ? 2 : 1;
+    int wv = n1 > 4500 ? 8 : 4;                      // wavefronts per block
+    if (cfg_env && cfg_env[0] && cfg_env[1] && cfg_env[2]) { ct = cfg_env[0] == '2' ? 2 : 1; wv = cfg_env[2] == '8' ? 8 : 4; }
+    const int qper = ct * 32 * wv;                          // queries per block
+    const int qblocks = (n1 + qper - 1) / qper;
+    // (query block, database split) pairs: as many as fit in ONE round over the CUs, not more -- rounding the split
+    // count up (11 x 24 = 264 blocks on 256 CUs) costs a whole second round (12000 x 12000: 0.44 -> 0.30 ms), and two
+    // blocks per CU of the small configuration only add prologues and partials (2048 x 2048: 0.026 -> 0.022 ms)
+    int nsplit = ctx->num_cus / qblocks;
+    const int max_split = (n2 + kRowsPerStage - 1) / kRowsPerStage;
+    if (nsplit > max_split) nsplit = max_split;
+    if (nsplit < 1) nsplit = 1;
+    int rows_per_split = (n2 + nsplit - 1) / nsplit;
+    rows_per_split = round_up(rows_per_split, kRowsPerStage);
+    nsplit = (n2 + rows_per_split - 1) / rows_per_split;
+
+    unsigned int *tickets; float *wb, *wsnd; int *wi;
+    const int wrc = match_partials_workspace(ctx, qblocks, nsplit, n1, &tickets, &wb, &wsnd, &wi);
+    if (wrc != SFM_OK) return wrc;
+
+    const dim3 grid(qblocks, nsplit);
+    if (ct == 2)
+        hipLaunchKernelGGL((match_mfma_kernel<2, 8>), grid, dim3(512), 0, ctx->stream,
+                           d1, n1, ld1, d2, n2, ld2, rows_per_split, wb, wsnd, wi, tickets, d_best, d_second, d_index, sift1, sift2);
+    else if (wv == 8)
+        hipLaunchKernelGGL((match_mfma_kernel<1, 8>), grid, dim3(512), 0, ctx->stream,
+                           d1, n1, ld1, d2, n2, ld2, rows_per_split, wb, wsnd, wi, tickets, d_best, d_second, d_index, sift1, sift2);
+    else
+        hipLaunchKernelGGL((match_mfma_kernel<1, 4>), grid, dim3(256), 0, ctx->stream,
+                           d1, n1, ld1, d2, n2, ld2, rows_per_split, wb, wsnd, wi, tickets, d_best, d_second, d_index, sift1, sift2);
+    SFM_HIP_TRY(hipGetLastError());
+    return SFM_OK;
+}
+
+// njobs matches of the query set (d1, n1) against njobs databases; jobs[k] = { database descriptors, rows, record pointers,
+// index output } filled by the caller except for the workspace / split fields.  kernel: SFM_MATCH_EXACT or SFM_MATCH_FUSED
+// (what match_pick says for every one of the jobs: the caller checks).
+int launch_match_jobs(sfm_ctx *ctx, const float *d1, int n1, int ld1, MatchJob *h_jobs, int njobs, int kernel)
+{
+    if (n1 <= 0 || njobs <= 0) return SFM_OK;
+    if (kernel == SFM_MATCH_FUSED) return launch_match_fused_jobs(ctx, d1, n1, ld1, h_jobs, njobs);
+    const int ct = n1 > 11000 ? 2 : 1;
+    const int wv = n1 > 4500 ? 8 : 4;
+    const int qper = ct * 32 * wv;
+    const int qblocks = (n1 + qper - 1) / qper;
+    const MatchJob *d_jobs = nullptr;
+    int max_split = 1;
+    const int wrc = match_jobs_workspace(ctx, n1, qblocks, kRowsPerStage, 2, h_jobs, njobs, &d_jobs, &max_split);
+    if (wrc != SFM_OK) return wrc;
     const dim3 grid(qblocks, max_split, njobs);
     if (ct == 2) hipLaunchKernelGGL((match_mfma_jobs_kernel<2, 8>), grid, dim3(512), 0, ctx->stream, d1, n1, ld1, d_jobs);
     else if (wv == 8) hipLaunchKernelGGL((match_mfma_jobs_kernel<1, 8>), grid, dim3(512), 0, ctx->stream, d1, n1, ld1, d_jobs);
@@ -403,11 +424,25 @@ int launch_match_jobs(sfm_ctx *ctx, const float *d1, int n1, int ld1, MatchJob *
     return SFM_OK;
 }
 
-// whether launch_match would run the exact MFMA kernel for these sizes (the only one launch_match_jobs has)
-bool match_is_exact(const sfm_ctx *ctx, int n1, int n2)
+// which kernel launch_match runs for these sizes (all three give the same bits), crossovers from profiles/r03_match_kernels.txt:
+//   exact      (this file) for small sets: one stage per block either way, and its fixed costs are the lowest;
+//   fused      (match_fused.hip: one launch, running fp16 threshold, exact chains for the few listed pairs) in the middle, and
+//              for every many-matches launch (launch_match_jobs);
+//   pre-filter (match_prefilter.hip: four launches, threshold known before listing: fewer exact chains per query) for large sets.
+int match_pick(const sfm_ctx *ctx, int n1, int n2)
 {
-    const bool big = n1 >= 1024 && n2 >= 1024 && (size_t)n1 * (size_t)n2 >= (size_t)4096 * 4096;
-    return !(ctx->match_kernel == SFM_MATCH_PREFILTER || (ctx->match_kernel == SFM_MATCH_AUTO && big));
+    if (ctx->match_kernel != SFM_MATCH_AUTO) return ctx->match_kernel;
+    const size_t pairs = (size_t)n1 * (size_t)n2;
+    if (pairs < (size_t)2048 * 2048) return SFM_MATCH_EXACT;
+    if (pairs < (size_t)6144 * 6144) return SFM_MATCH_FUSED;
+    return n1 >= 1024 && n2 >= 1024 ? SFM_MATCH_PREFILTER : SFM_MATCH_FUSED;
+}
+
+// what a many-matches launch runs for a pair of these sizes: fused unless the four-kernel pre-filter is due (or asked for)
+int match_pick_jobs(const sfm_ctx *ctx, int n1, int n2)
+{
+    const int pick = match_pick(ctx, n1, n2);
+    return pick == SFM_MATCH_EXACT && ctx->match_kernel == SFM_MATCH_AUTO ? SFM_MATCH_FUSED : pick;
 }
 
 } // namespace sfm

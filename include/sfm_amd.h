@@ -65,10 +65,15 @@ int  sfm_ctx_set_quirks(sfm_ctx *ctx, unsigned int flags);
  * SFM_MATCH_EXACT     -- every score as the exact fp32 chain on v_mfma_f32_32x32x2_f32 (match.hip);
  * SFM_MATCH_PREFILTER -- fp16 matrix-core scores select the few rows per query that can be its best or second best, the
  *                        exact chain runs on those only (match_prefilter.hip);
- * SFM_MATCH_AUTO      -- the pre-filter from 4096 x 4096 points on (default).  sfm_ctx_last_match_kernel: what the last call ran. */
+ * SFM_MATCH_FUSED     -- the same idea in ONE launch: the threshold is a running one (the second-largest approximate score seen
+ *                        so far), scores, candidate lists and exact chains never leave the block (match_fused.hip);
+ * SFM_MATCH_AUTO      -- exact below 2048 x 2048 points, fused up to 6144 x 6144, the pre-filter from there on; the batched path
+ *                        of sfm_process_pairs (many matches in one launch) uses fused below that size (default).
+ * sfm_ctx_last_match_kernel: what the last call ran. */
 #define SFM_MATCH_AUTO      0
 #define SFM_MATCH_EXACT     1
 #define SFM_MATCH_PREFILTER 2
+#define SFM_MATCH_FUSED     3
 int  sfm_ctx_set_match_kernel(sfm_ctx *ctx, int kernel);
 int  sfm_ctx_last_match_kernel(sfm_ctx *ctx, int *kernel);
 /* A stream of the context's own (hipStreamNonBlocking, destroyed with the context): callers without HIP headers get a

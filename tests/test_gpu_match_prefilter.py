@@ -1,5 +1,6 @@
-"""GPU parity: the fp16 matrix-core pre-filter matcher (match_prefilter.hip) against the exact MFMA matcher and the oracle.
-Bit-exact scores and indices are the bar: the pre-filter only selects which rows get the exact fp32 chain."""
+"""GPU parity: the fp16 matrix-core pre-filter matchers (match_prefilter.hip: four launches, global threshold; match_fused.hip:
+one launch, running threshold) against the exact MFMA matcher and the oracle.  Bit-exact scores and indices are the bar:
+the pre-filters only select which rows get the exact fp32 chain."""
 import numpy as np
 import pytest
 
@@ -35,6 +36,11 @@ def check_both(gpu, d1, d2, oracle_rows=None):
     assert ran2 == S.MATCH_EXACT
     assert np.array_equal(i, ei)
     assert same_bits(b, eb) and same_bits(s, es)
+    fb, fs, fi, ran3 = run_soa(gpu, d1, d2, S.MATCH_FUSED)
+    assert ran3 == S.MATCH_FUSED
+    bad = np.flatnonzero(fi != ei)
+    assert bad.size == 0, f"fused: {bad.size} indices differ, first queries {bad[:5]}: {fi[bad[:5]]} vs {ei[bad[:5]]}"
+    assert same_bits(fb, eb) and same_bits(fs, es)
     rows = np.arange(d1.shape[0]) if oracle_rows is None else oracle_rows
     ob, os_, oi = O.match_desc(d1[rows], d2)
     assert np.array_equal(i[rows], oi) and same_bits(b[rows], ob) and same_bits(s[rows], os_)
@@ -108,9 +114,9 @@ def test_prefilter_entries_the_fp16_copy_cannot_hold(gpu):
 
 
 def test_prefilter_sift_records_and_auto(gpu):
-    """MatchSiftData semantics through the pre-filter path; AUTO picks it from 4096 x 4096 on."""
+    """MatchSiftData semantics through the pre-filter paths; AUTO: exact, then fused, the four-kernel pre-filter from 6144 x 6144 on."""
     torch, dev, ctx = gpu
-    n1, n2 = 4200, 4100
+    n1, n2 = 6200, 6150
     d1, _, _ = synth.descriptors(n1, seed=31)
     d2, _, _ = synth.descriptors(n2, seed=32)
     s1 = synth.sift_records(d1, seed=33); s2 = synth.sift_records(d2, seed=34)
@@ -128,6 +134,28 @@ def test_prefilter_sift_records_and_auto(gpu):
         assert np.array_equal(out[f], s1[f])
     ctx.match(t1, 700, t2, 900)
     assert ctx.last_match_kernel() == S.MATCH_EXACT
+    ctx.match(t1, 3000, t2, 3100)
+    assert ctx.last_match_kernel() == S.MATCH_FUSED
+    torch.cuda.synchronize()
+    out = t1.cpu().numpy().reshape(-1).view(synth.SIFT_DTYPE)[:3000]
+    ref = O.match_sift(s1[:3000].copy(), s2[:3100])
+    for f in ("score", "ambiguity", "match_xpos", "match_ypos"):
+        assert same_bits(out[f], ref[f]), f
+    assert np.array_equal(out["match"], ref["match"])
+
+
+def test_fused_many_stages_duplicates_across_stages(gpu):
+    """Enough query blocks that a block walks several 128-row stages of the database: duplicated rows in DIFFERENT stages
+    (the lowest index wins, second == best), a query whose best comes late, equal rows filling a whole stage."""
+    rng = np.random.default_rng(41)
+    n1, n2 = 8192, 2500
+    base, _, _ = synth.descriptors(n2, seed=51)
+    q = base[rng.integers(0, n2, n1)].copy()
+    q += rng.normal(scale=0.002, size=q.shape).astype(np.float32)
+    db = base.copy()
+    db[2000] = db[10]; db[1300] = db[10]; db[140] = db[139]
+    db[1500:1700] = db[77]                                     # more than a stage of equal rows
+    check_both(gpu, q, db, oracle_rows=np.arange(0, n1, 61))
 
 
 def test_prefilter_full_size(gpu):
