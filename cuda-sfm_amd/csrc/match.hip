@@ -433,7 +433,7 @@ int match_pick(const sfm_ctx *ctx, int n1, int n2)
 {
     if (ctx->match_kernel != SFM_MATCH_AUTO) return ctx->match_kernel;
     const size_t pairs = (size_t)n1 * (size_t)n2;
-    if (pairs < (size_t)2048 * 2048) return SFM_MATCH_EXACT;
+    if (pairs < (size_t)2560 * 2560) return SFM_MATCH_EXACT;
     if (pairs < (size_t)6144 * 6144) return SFM_MATCH_FUSED;
     return n1 >= 1024 && n2 >= 1024 ? SFM_MATCH_PREFILTER : SFM_MATCH_FUSED;
 }

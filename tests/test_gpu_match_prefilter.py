@@ -164,3 +164,71 @@ def test_prefilter_full_size(gpu):
     d1, d2, perm = synth.descriptors(n)
     b, s, i = check_both(gpu, d2, d1, oracle_rows=np.random.default_rng(1).integers(0, n, 64))
     assert (i == perm).mean() > 0.99
+
+
+def test_fused_random_shapes_and_data(gpu):
+    """Forty random shapes and data families through the fused matcher against the exact one (every query, bit for bit):
+    ragged sizes around the 128-row stage and the 128-query block, clustered descriptors (many near-equal scores: long
+    candidate lists), duplicated rows across stages, sparse non-negative rows, mixed signs."""
+    rng = np.random.default_rng(2026)
+    for trial in range(40):
+        n1 = int(rng.choice([1, 31, 127, 128, 129, 300, 700, 1500, 2600]))
+        n2 = int(rng.choice([1, 2, 33, 127, 128, 129, 255, 257, 900, 2049, 3500]))
+        family = trial % 5
+        if family == 0:
+            d1 = np.abs(rng.standard_normal((n1, 128))).astype(np.float32); d2 = np.abs(rng.standard_normal((n2, 128))).astype(np.float32)
+        elif family == 1:                                   # clusters: rows are small perturbations of a few centres
+            centres = np.abs(rng.standard_normal((6, 128))).astype(np.float32)
+            d1 = centres[rng.integers(0, 6, n1)] + 1e-3 * rng.standard_normal((n1, 128)).astype(np.float32)
+            d2 = centres[rng.integers(0, 6, n2)] + 1e-3 * rng.standard_normal((n2, 128)).astype(np.float32)
+        elif family == 2:                                   # exact duplicates spread over the database
+            base = np.abs(rng.standard_normal((max(2, n2 // 7), 128))).astype(np.float32)
+            d2 = base[rng.integers(0, base.shape[0], n2)].copy()
+            d1 = base[rng.integers(0, base.shape[0], n1)].copy()
+        elif family == 3:                                   # sparse
+            d1 = (np.abs(rng.standard_normal((n1, 128))) * (rng.random((n1, 128)) < 0.15)).astype(np.float32)
+            d2 = (np.abs(rng.standard_normal((n2, 128))) * (rng.random((n2, 128)) < 0.15)).astype(np.float32)
+        else:
+            d1 = rng.standard_normal((n1, 128)).astype(np.float32); d2 = rng.standard_normal((n2, 128)).astype(np.float32)
+        if family != 4:
+            d1 /= np.maximum(np.linalg.norm(d1, axis=1, keepdims=True), 1e-20); d2 /= np.maximum(np.linalg.norm(d2, axis=1, keepdims=True), 1e-20)
+        fb, fs, fi, ran = run_soa(gpu, d1, d2, S.MATCH_FUSED)
+        assert ran == S.MATCH_FUSED
+        eb, es, ei, _ = run_soa(gpu, d1, d2, S.MATCH_EXACT)
+        bad = np.flatnonzero((fi != ei) | (fb.view(np.uint32) != eb.view(np.uint32)) | (fs.view(np.uint32) != es.view(np.uint32)))
+        assert bad.size == 0, f"trial {trial} ({n1} x {n2}, family {family}): {bad.size} queries differ, first {bad[:5]}"
+        if trial % 8 == 0:
+            rows = np.arange(0, n1, max(1, n1 // 50))
+            ob, os_, oi = O.match_desc(d1[rows], d2)
+            assert np.array_equal(fi[rows], oi) and same_bits(fb[rows], ob) and same_bits(fs[rows], os_)
+
+
+def test_fused_many_matches_launch_equals_single_matches(gpu):
+    """The many-matches launch of sfm_process_pairs (grid.z = match, one split per match when there are enough blocks) against
+    one sfm_match call per pair: index arrays and the record fields of every first view."""
+    torch, dev, ctx = gpu
+    V, n = 7, 1337
+    K, Kinv = synth.camera()
+    rng = np.random.default_rng(77)
+    centres = np.abs(rng.standard_normal((40, 128))).astype(np.float32)
+    views = []
+    for v in range(V):
+        d = centres[rng.integers(0, 40, n)] + 0.05 * np.abs(rng.standard_normal((n, 128))).astype(np.float32)
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        views.append(synth.sift_records(d.astype(np.float32), seed=500 + v))
+    pairs_host = [(i, j) for i in range(V) for j in range(i + 1, V)]
+    want = {}
+    for (i, j) in pairs_host:                              # sequential: the fields of view i after its LAST pair are what remain
+        t1, t2 = to_dev(torch, dev, views[i]), to_dev(torch, dev, views[j])
+        ctx.match(t1, n, t2, n)
+        torch.cuda.synchronize()
+        want[i] = t1.cpu().numpy().reshape(-1).view(synth.SIFT_DTYPE).copy()
+    dviews = [to_dev(torch, dev, v) for v in views]
+    descs = [(dviews[i], n, dviews[j], n) for (i, j) in pairs_host]
+    rec, status = S.process_pairs_local(ctx, descs, K, Kinv)
+    torch.cuda.synchronize()
+    for i in range(V - 1):
+        got = dviews[i].cpu().numpy().reshape(-1).view(synth.SIFT_DTYPE)
+        assert np.array_equal(got["match"], want[i]["match"]), f"first view {i}"
+        for f in ("score", "ambiguity", "match_xpos", "match_ypos"):
+            assert same_bits(got[f], want[i][f]), (i, f)
