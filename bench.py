@@ -390,7 +390,8 @@ def extra_match(S, synth, O, ctx, dev, torch, np, n, reps):
     ran = ctx.last_match_kernel()
     res = (best.cpu().numpy().copy(), sec.cpu().numpy().copy(), idx.cpu().numpy().copy())
     flops = 2.0 * n * n * 128
-    out = {"n": n, "ms": ms, "kernel": {S.MATCH_EXACT: "exact fp32 MFMA", S.MATCH_PREFILTER: "fp16 MFMA pre-filter + exact candidates"}.get(ran, str(ran)),
+    out = {"n": n, "ms": ms, "kernel": {S.MATCH_EXACT: "exact fp32 MFMA", S.MATCH_PREFILTER: "fp16 MFMA pre-filter + exact candidates (four launches)",
+                                    S.MATCH_FUSED: "fp16 MFMA pre-filter + exact candidates (one launch, running threshold)"}.get(ran, str(ran)),
            "algorithmic_tflops": flops / ms / 1e9, "perm_recovered": float((res[2] == perm).mean())}
     if ran == S.MATCH_EXACT:
         out["frac_of_fp32_mfma_peak"] = flops / ms / 1e9 / FP32_PEAK_TFLOPS
@@ -518,6 +519,7 @@ def run_extras(S, synth, O, ctx, dev, torch, np, skip):
     guarded("headline_share_of_one_of_8_ranks", lambda: extra_ransac(S, synth, O, ctx, dev, torch, np, "rank8", N_MATCHES, TOTAL_HYPS, 100, hyp_count=TOTAL_HYPS // 8))
     guarded("c4_share_of_one_of_8_ranks", lambda: extra_ransac(S, synth, O, ctx, dev, torch, np, "c4rank8", 16384, 1 << 20, 30, hyp_count=(1 << 20) // 8))
     guarded("match_2048", lambda: extra_match(S, synth, O, ctx, dev, torch, np, 2048, 50))
+    guarded("match_4096", lambda: extra_match(S, synth, O, ctx, dev, torch, np, 4096, 50))
     guarded("match_16384", lambda: extra_match(S, synth, O, ctx, dev, torch, np, 16384, 20))
     try:
         out.update(extra_dino(S, O, ctx, dev, torch, np))

@@ -435,7 +435,8 @@ int match_pick(const sfm_ctx *ctx, int n1, int n2)
     const size_t pairs = (size_t)n1 * (size_t)n2;
     if (pairs < (size_t)2560 * 2560) return SFM_MATCH_EXACT;
     if (pairs < (size_t)6144 * 6144) return SFM_MATCH_FUSED;
-    return n1 >= 1024 && n2 >= 1024 ? SFM_MATCH_PREFILTER : SFM_MATCH_FUSED;
+    if (n1 >= 1024 && n2 >= 1024) return SFM_MATCH_PREFILTER;
+    return n2 < (1 << 27) ? SFM_MATCH_FUSED : SFM_MATCH_EXACT;        // (the fused kernel's list entries hold 27 bits of row index)
 }
 
 // what a many-matches launch runs for a pair of these sizes: fused unless the four-kernel pre-filter is due (or asked for)

@@ -399,6 +399,7 @@ int launch_match_fused(sfm_ctx *ctx, const float *d1, int n1, int ld1, const flo
                        float *d_best, float *d_second, int32_t *d_index, sfm_sift_point *sift1, const sfm_sift_point *sift2)
 {
     if (n1 <= 0 || n2 <= 0) return SFM_OK;
+    SFM_REQUIRE(n2 <= (int)kMfRowMask, SFM_E_INVALID, "SFM_MATCH_FUSED holds 27 bits of row index: %d rows are too many (use SFM_MATCH_AUTO)", n2);
     const int qblocks = (n1 + kMfQ - 1) / kMfQ;
     int nsplit = 2 * ctx->num_cus / qblocks;               // two blocks per CU (45 KB of LDS, at most 256 registers a lane)
     const int most = (n2 + kMfRows - 1) / kMfRows;
