@@ -1197,7 +1197,7 @@ int sfm_process_pairs(sfm_ctx *ctx, const float h_K[9], const float h_Kinv[9], c
             rc = launch_fill_xu_pairs(ctx, d_jobs, (int)jobs.size(), max_ld, h_Kinv);
             // eight blocks of eight wavefronts per pair: each stages the pair's points once and runs its share of the batches
             const int bpp = (int)std::min<uint32_t>(8u, (max_H + 7u) / 8u);
-            if (rc == SFM_OK) rc = launch_fused_pairs(ctx, d_jobs, (int)jobs.size(), bpp);
+            if (rc == SFM_OK) rc = launch_fused_pairs(ctx, d_jobs, (int)jobs.size(), bpp, max_H);
             if (rc == SFM_OK) rc = launch_finalize_pose_pairs(ctx, d_jobs, (int)jobs.size(), max_nn);
             if (rc != SFM_OK) { (void)hipStreamSynchronize(ctx->stream); return rc; }
             batched_done = true;

@@ -26,7 +26,7 @@ struct PairJob {
 };
 
 int launch_fill_xu_pairs(sfm_ctx *ctx, const PairJob *d_jobs, int njobs, int max_ld, const float h_Kinv[9]);
-int launch_fused_pairs(sfm_ctx *ctx, const PairJob *d_jobs, int njobs, int blocks_per_pair);
+int launch_fused_pairs(sfm_ctx *ctx, const PairJob *d_jobs, int njobs, int blocks_per_pair, uint32_t max_H);
 int launch_finalize_pose_pairs(sfm_ctx *ctx, const PairJob *d_jobs, int njobs, int max_n);      // two launches: one wavefront per pair, then the points
 
 } // namespace sfm

@@ -185,7 +185,9 @@ __device__ __forceinline__ void solve_wave(const float *__restrict__ X0, const f
 
 // The body of the fused kernel for the blocks (first_block, first_block + num_blocks, ...) of ONE estimateE: shared by the
 // one-pair kernel and the many-pairs kernel (grid.y = pair, pairs_batch.hip).
-template <int WPB, bool UNITZ>
+// PRESOLVED: the candidates are in Ecand already (many-pairs launch: ransac_pairs_solve, one hypothesis per LANE -- the
+// wave-cooperative Householder solve repeats the same scalar chain in all 64 lanes); the block only scores.
+template <int WPB, bool UNITZ, bool PRESOLVED = false>
 __device__ __forceinline__ void fused_body(float *lds, const float *__restrict__ X0, const float *__restrict__ X1, int ld, int n,
                                            const int32_t *__restrict__ indices, uint32_t seed, int sweeps,
                                            uint32_t h0, uint32_t count, float thr, int tile, int ntiles,
@@ -196,8 +198,10 @@ __device__ __forceinline__ void fused_body(float *lds, const float *__restrict__
     uint2 (*sched)[64] = reinterpret_cast<uint2 (*)[64]>(lds + tile_floats + (size_t)WPB * kWaveScratch);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (wave == 0) build_jacobi_schedule(sched, lane);
-    __syncthreads();
+    if (!PRESOLVED) {
+        if (wave == 0) build_jacobi_schedule(sched, lane);
+        __syncthreads();
+    }
     float *ws = lds + tile_floats + (size_t)wave * kWaveScratch;
     const uint32_t nbatch = (count + WPB - 1) / WPB;
     unsigned long long wbest = 0;
@@ -208,7 +212,11 @@ __device__ __forceinline__ void fused_body(float *lds, const float *__restrict__
         const uint32_t i = __builtin_amdgcn_readfirstlane(batch * WPB + wave);
         const bool valid = i < count;
         float e[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
-        if (valid) {
+        if (valid && PRESOLVED) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) e[k] = Ecand[9 * (size_t)i + k];        // (wave-uniform address)
+        }
+        if (valid && !PRESOLVED) {
             solve_wave(X0, X1, ld, n, indices, seed, h0 + i, sweeps, ws, sched, lane, e);
             if (lane < 9) {
                 float v = e[0];
@@ -262,6 +270,31 @@ void ransac_fused_waves(const float *__restrict__ X0, const float *__restrict__ 
 
 // Many pairs in ONE launch (sfm_process_pairs, BASELINE configs[4]): blockIdx.y names the pair, its blocks are blockIdx.x.
 // Unit-z layout (fillXU), the library's default sampler and solver -- what the per-pair path runs for these pairs.
+// Two kernels: every hypothesis of every pair solved by ONE lane (the scalar chain of the wave-cooperative Householder solve,
+// same functions, same bits: 64 times fewer issue slots), then eight blocks of eight wavefronts per pair score them.
+__global__ __launch_bounds__(64)
+void ransac_pairs_solve(const PairJob *__restrict__ jobs)
+{
+    const PairJob &j = jobs[blockIdx.y];
+    const uint32_t i = blockIdx.x * 64u + threadIdx.x;
+    if (i >= j.H) return;
+    int idx[8];
+    load_tuple(nullptr, j.seed, i, j.n, idx);
+    float x1[8][3], x2[8][3];
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            x1[k][a] = j.X0[(size_t)a * j.ld + idx[k]];
+            x2[k][a] = j.X1[(size_t)a * j.ld + idx[k]];
+        }
+    float E[9];
+    nullvec9_householder(x1, x2, E);
+    normalize_E(E);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) j.Ecand[9 * (size_t)i + k] = E[k];
+}
+
 __global__ __launch_bounds__(8 * 64)
 void ransac_fused_pairs(const PairJob *__restrict__ jobs)
 {
@@ -270,14 +303,15 @@ void ransac_fused_pairs(const PairJob *__restrict__ jobs)
     const int tile = j.ld < kTileMax ? j.ld : kTileMax;
     const int ntiles = (j.ld + tile - 1) / tile;
     if ((uint32_t)blockIdx.x * 8u >= j.H) return;           // (uniform per block: before any barrier)
-    fused_body<8, true>(lds, j.X0, j.X1, j.ld, j.n, nullptr, j.seed, 0, 0u, j.H, j.thr, tile, ntiles, j.counts, j.Ecand, j.key, blockIdx.x, gridDim.x);
+    fused_body<8, true, true>(lds, j.X0, j.X1, j.ld, j.n, nullptr, j.seed, 0, 0u, j.H, j.thr, tile, ntiles, j.counts, j.Ecand, j.key, blockIdx.x, gridDim.x);
 }
 
-int launch_fused_pairs(sfm_ctx *ctx, const PairJob *d_jobs, int njobs, int blocks_per_pair)
+int launch_fused_pairs(sfm_ctx *ctx, const PairJob *d_jobs, int njobs, int blocks_per_pair, uint32_t max_H)
 {
     const size_t lds = (size_t)2 * kUnitZSecond + (size_t)8 * kWaveScratch * sizeof(float) + 9 * 64 * sizeof(uint2);
     const int rc_lds = allow_big_lds(ctx, reinterpret_cast<const void *>(&ransac_fused_pairs));
     if (rc_lds != SFM_OK) return rc_lds;
+    hipLaunchKernelGGL(ransac_pairs_solve, dim3((max_H + 63u) / 64u, njobs), dim3(64), 0, ctx->stream, d_jobs);
     hipLaunchKernelGGL(ransac_fused_pairs, dim3(blocks_per_pair, njobs), dim3(8 * 64), lds, ctx->stream, d_jobs);
     SFM_HIP_TRY(hipGetLastError());
     return SFM_OK;
