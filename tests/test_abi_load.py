@@ -48,6 +48,24 @@ def test_struct_layouts_match_header():
     assert p.num_hypotheses == 512 and abs(p.threshold - 1e-6) < 1e-12 and p.jacobi_sweeps == 0
 
 
+def test_header_constants_match_the_python_mirror():
+    """#define values of include/sfm_amd.h against the names the Python harness uses (matcher / kernel selectors, quirks,
+    pose modes, error codes)."""
+    import cuda_sfm_amd as S
+    txt = open(os.path.join(ROOT, "include", "sfm_amd.h")).read()
+    defs = {m.group(1): int(m.group(2).strip("()").rstrip("u"), 0)
+            for m in re.finditer(r"^#define\s+(SFM_[A-Z0-9_]+)\s+(\(?-?(?:0x)?[0-9a-fA-F]+u?\)?)\s*(?:/\*.*)?$", txt, flags=re.M)}
+    assert len(defs) >= 30
+    checked = 0
+    for name, value in defs.items():
+        py = name[len("SFM_"):]
+        if hasattr(S, py):
+            assert getattr(S, py) == value, (name, value, getattr(S, py))
+            checked += 1
+    assert checked >= 12, checked
+    assert (S.MATCH_AUTO, S.MATCH_EXACT, S.MATCH_PREFILTER, S.MATCH_FUSED) == (0, 1, 2, 3)
+
+
 def test_no_cpu_fallback():
     import torch
     import cuda_sfm_amd as S
