@@ -85,6 +85,8 @@ def parse_args(argv=None):
     ap.add_argument("--serial", action="store_true",
                     help="one estimateE at a time (sfm_estimate_E / sfm_estimate_E_sharded) instead of the two-slot pipelined calls "
                          "(sfm_estimate_E_pipelined / sfm_estimate_E_sharded_pipelined) in which consecutive steps overlap on the device")
+    ap.add_argument("--timed-events", choices=["auto", "on", "off"], default="auto",
+                    help="HIP events around every kernel INSIDE the timed region (auto: only with --serial; pipelined steps are sampled by serial launches right after it)")
     ap.add_argument("--reserved", type=int, nargs="*", default=[], help="sfm_ransac_params.reserved[] A/B switches (profiles/)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg (and with it the full-oracle parity check)")
     ap.add_argument("--no-variants", action="store_true", help="skip the short run with the other null-vector solver")
@@ -624,19 +626,28 @@ def rank_main(args):
             dist.barrier()
         torch.cuda.synchronize()
 
-    # untimed: wake the device up (first launches, buffer growth, clock ramp ~50 ms), then the W warm-up steps of the contract
-    for _ in range(max(0, 20 - args.warmup)):
+    # untimed: wake the device up (first launches, buffer growth, clock ramp: ~50 ms of work -- counted in time, not in steps: a
+    # rank's share of a sharded run is a 0.1 ms step, and twenty of them end before the clock has moved), then the W warm-up
+    # steps of the contract
+    est_step_s = (H / world) * n / 7e12 + 20e-6           # the same number on every rank: the steps contain a collective
+    wake_steps = min(2000, max(20 - args.warmup, int(0.06 / est_step_s)))
+    for _ in range(max(0, wake_steps)):
         step()
     for _ in range(args.warmup):
         step()
     fence()
-    ctx.kernel_timing(True)
+    # Three hipEventRecord per call cost 3-4 us of a 0.1 ms step (a rank's share of a sharded run) and 0.5-1 % of the headline
+    # step (profiles/r03_timed_events_ab.txt); with pipelined steps the kernels overlap inside the timed region anyway and are sampled by serial launches right
+    # after it (below), so the events stay out of the timed region unless the steps are serial (or --timed-events on).
+    events_in_region = args.timed_events == "on" or (args.timed_events == "auto" and not pipelined)
+    if events_in_region:
+        ctx.kernel_timing(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     fence()
     elapsed = time.perf_counter() - t0
-    solve_ms, score_ms, calls = ctx.kernel_timing_read()
+    solve_ms, score_ms, calls = ctx.kernel_timing_read() if events_in_region else (0.0, 0.0, 0)
     ctx.kernel_timing(False)
     timed_region_kernel_ms = (solve_ms / max(calls, 1), score_ms / max(calls, 1))
     # what the timed steps left behind (every rank): winner, E, mask
@@ -734,8 +745,10 @@ def rank_main(args):
             exchange += " -- " + comm_note
         kname = KERNEL_NAMES.get(launch["kernel"], "?")
         measured_in = (("20 serial launches of this rank's shard right after the timed region (in the timed region consecutive "
-                        "steps overlap and stretch each kernel's own duration: solve %.4f ms, scoring %.4f ms per launch there)"
-                        % timed_region_kernel_ms) if pipelined else "the timed region")
+                        "steps overlap and stretch each kernel's own duration"
+                        + (": solve %.4f ms, scoring %.4f ms per launch there)" % timed_region_kernel_ms if events_in_region else
+                           "; no events are recorded there: three hipEventRecord per call cost 3-4 us per step, --timed-events on samples them)"))
+                       if pipelined else "the timed region")
         out = {
             "metric": "RANSAC E-matrix hypotheses/sec (8-point, fused scoring), inlier-mask parity vs CPU oracle",
             "value": H * args.steps / elapsed,
