@@ -416,6 +416,7 @@ def extra_dino(S, O, ctx, dev, torch, np):
     if not os.path.exists(dino_frame(35)):
         return {"skipped": "tests/golden/dino fixtures not present"}
     views = [read_pnm_grey(dino_frame(k)) for k in range(36)]
+    views8 = [v.astype(np.uint8) for v in views]            # the frames as the 8-bit images they are (sfm_extract_views_u8)
     h, w = views[0].shape
     pitch = (w + 127) // 128 * 128
     out = {}
@@ -465,15 +466,15 @@ def extra_dino(S, O, ctx, dev, torch, np):
 
     # configs[4]: host images in, everything per pair inside the C library (sfm_extract_views + sfm_process_pairs)
     for name, pairs in (("c5_dino_ring_36_pairs", S.ring_pairs(36)), ("c5_dino_all_630_pairs", [(i, j) for i in range(36) for j in range(i + 1, 36)])):
-        S.process_views(ctx, views[:9], DINO_K, DINO_KINV, max_pts=8192, sift=DINO_SIFT, device=dev)
+        S.process_views(ctx, views8[:9], DINO_K, DINO_KINV, max_pts=8192, sift=DINO_SIFT, device=dev)
         runs = []
         for _ in range(3):
             torch.cuda.synchronize(); t0 = time.perf_counter()
-            res, counts = S.process_views(ctx, views, DINO_K, DINO_KINV, pairs=pairs, max_pts=8192, sift=DINO_SIFT, device=dev)
+            res, counts = S.process_views(ctx, views8, DINO_K, DINO_KINV, pairs=pairs, max_pts=8192, sift=DINO_SIFT, device=dev)
             torch.cuda.synchronize(); runs.append(time.perf_counter() - t0)
         e = {"pairs": len(pairs), "done": len(res), "features_per_view": [min(counts), max(counts)], "ms_total": 1e3 * min(runs),
              "ms_per_pair": 1e3 * min(runs) / len(pairs), "ms_runs": [round(1e3 * r, 3) for r in runs],
-             "note": "host images -> device inside the timed region (PCIe-inclusive)"}
+             "note": "8-bit host images -> device inside the timed region (PCIe-inclusive; float images: +0.5 ms, profiles/r03_ring_bench.txt)"}
         if O is not None:
             def check_c5(e=e, res=res, pairs=pairs):
                 # a few pairs against the oracle chain, from the features the GPU extractor delivers for those views

@@ -893,10 +893,23 @@ static int views_buffers(sfm_ctx *c, size_t floats)
     return SFM_OK;
 }
 
-int sfm_extract_views(sfm_ctx *ctx, const float *const *h_images, int num_views, int width, int height, int first, int stride,
-                      void *d_block, size_t slot_bytes, int max_pts, int num_octaves, double init_blur, float thresh,
-                      float lowest_scale, int scale_up, int *h_counts)
+// 8-bit grey values -> float (exact), four pixels per thread; count is a multiple of four (the pitch is a multiple of 128)
+__global__ __launch_bounds__(256)
+void views_u8_to_float_kernel(const uchar4 *__restrict__ src, float4 *__restrict__ dst, size_t count4)
 {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= count4) return;
+    const uchar4 v = src[i];
+    dst[i] = make_float4((float)v.x, (float)v.y, (float)v.z, (float)v.w);
+}
+
+// h_images: float images (bytes_per_pixel 4) or 8-bit grey images (bytes_per_pixel 1: a quarter of the PCIe traffic, the
+// conversion -- exact -- runs on the device in front of the extraction)
+static int extract_views_impl(sfm_ctx *ctx, const void *const *h_images, int bytes_per_pixel, int num_views, int width, int height, int first, int stride,
+                              void *d_block, size_t slot_bytes, int max_pts, int num_octaves, double init_blur, float thresh,
+                              float lowest_scale, int scale_up, int *h_counts)
+{
+    const bool u8 = bytes_per_pixel == 1;
     SFM_REQUIRE(ctx && h_images && d_block, SFM_E_INVALID, "null argument");
     SFM_REQUIRE(num_views >= 0 && first >= 0 && stride >= 1, SFM_E_INVALID, "bad view range");
     SFM_REQUIRE(width > 0 && height > 0 && width <= 16384 && height <= 16384, SFM_E_INVALID, "image size %d x %d", width, height);
@@ -939,11 +952,12 @@ int sfm_extract_views(sfm_ctx *ctx, const float *const *h_images, int num_views,
     auto stage = [&](int t) {
         for (int i = t; i < nown && !stop.load(std::memory_order_relaxed); i += NT) {
             while (i - consumed.load(std::memory_order_acquire) >= NR && !stop.load(std::memory_order_relaxed)) std::this_thread::yield();
-            float *pin = ring[i % NR];
-            const float *src = h_images[first + i * stride];
+            char *pin = reinterpret_cast<char *>(ring[i % NR]);
+            const char *src = static_cast<const char *>(h_images[first + i * stride]);
+            const size_t px = (size_t)bytes_per_pixel;
             for (int y = 0; y < height; ++y) {
-                memcpy(pin + (size_t)y * pitch, src + (size_t)y * width, (size_t)width * sizeof(float));
-                if (pitch > width) memset(pin + (size_t)y * pitch + width, 0, (size_t)(pitch - width) * sizeof(float));
+                memcpy(pin + (size_t)y * pitch * px, src + (size_t)y * width * px, (size_t)width * px);
+                if (pitch > width) memset(pin + ((size_t)y * pitch + width) * px, 0, (size_t)(pitch - width) * px);
             }
             staged[(size_t)i].store(1, std::memory_order_release);
         }
@@ -972,7 +986,19 @@ int sfm_extract_views(sfm_ctx *ctx, const float *const *h_images, int num_views,
         rc = finish(k);                                                        // this context's previous view
         if (rc != SFM_OK) break;
         while (staged[(size_t)i].load(std::memory_order_acquire) == 0) std::this_thread::yield();
-        hipError_t e = hipMemcpyAsync(image[k], ring[i % NR], floats * sizeof(float), hipMemcpyHostToDevice, cs[k]->stream);
+        hipError_t e;
+        if (u8) {
+            // (the second half of the context's device image buffer holds the bytes until the kernel has widened them)
+            unsigned char *d_bytes = reinterpret_cast<unsigned char *>(image[k] + floats);
+            e = hipMemcpyAsync(d_bytes, ring[i % NR], floats, hipMemcpyHostToDevice, cs[k]->stream);
+            if (e == hipSuccess) {
+                hipLaunchKernelGGL(views_u8_to_float_kernel, dim3((unsigned)((floats / 4 + 255) / 256)), dim3(256), 0, cs[k]->stream,
+                                   reinterpret_cast<const uchar4 *>(d_bytes), reinterpret_cast<float4 *>(image[k]), floats / 4);
+                e = hipGetLastError();
+            }
+        } else {
+            e = hipMemcpyAsync(image[k], ring[i % NR], floats * sizeof(float), hipMemcpyHostToDevice, cs[k]->stream);
+        }
         if (e != hipSuccess) { set_error("view upload failed: %s", hipGetErrorString(e)); rc = SFM_E_HIP; break; }
         rc = launch_extract_sift_begin(cs[k], reinterpret_cast<sfm_sift_point *>(block + (size_t)i * slot_bytes), max_pts, image[k],
                                        width, height, pitch, num_octaves, init_blur, thresh, lowest_scale, scale_up ? 1 : 0, nullptr);
@@ -998,6 +1024,22 @@ int sfm_extract_views(sfm_ctx *ctx, const float *const *h_images, int num_views,
     SFM_HIP_TRY(hipStreamSynchronize(ctx->stream));
     if (h_counts) memcpy(h_counts, counts.data(), (size_t)nown * sizeof(int));
     return SFM_OK;
+}
+
+int sfm_extract_views(sfm_ctx *ctx, const float *const *h_images, int num_views, int width, int height, int first, int stride,
+                      void *d_block, size_t slot_bytes, int max_pts, int num_octaves, double init_blur, float thresh,
+                      float lowest_scale, int scale_up, int *h_counts)
+{
+    return extract_views_impl(ctx, reinterpret_cast<const void *const *>(h_images), 4, num_views, width, height, first, stride, d_block, slot_bytes,
+                              max_pts, num_octaves, init_blur, thresh, lowest_scale, scale_up, h_counts);
+}
+
+int sfm_extract_views_u8(sfm_ctx *ctx, const unsigned char *const *h_images, int num_views, int width, int height, int first, int stride,
+                         void *d_block, size_t slot_bytes, int max_pts, int num_octaves, double init_blur, float thresh,
+                         float lowest_scale, int scale_up, int *h_counts)
+{
+    return extract_views_impl(ctx, reinterpret_cast<const void *const *>(h_images), 1, num_views, width, height, first, stride, d_block, slot_bytes,
+                              max_pts, num_octaves, init_blur, thresh, lowest_scale, scale_up, h_counts);
 }
 
 // ---- many view pairs --------------------------------------------------------------------------------

@@ -306,6 +306,11 @@ int sfm_get_result(sfm_pair *pair, float h_record[28]);
 int sfm_extract_views(sfm_ctx *ctx, const float *const *h_images, int num_views, int width, int height, int first, int stride,
                       void *d_block, size_t slot_bytes, int max_pts, int num_octaves, double init_blur, float thresh,
                       float lowest_scale, int scale_up, int *h_counts);
+/* The same for 8-bit grey images (what cv::imread(path, 0) hands src/main.cpp:249 before convertTo(CV_32FC1)): a quarter of
+ * the bytes cross PCIe, the exact widening to float runs on the device.  Same features, bit for bit. */
+int sfm_extract_views_u8(sfm_ctx *ctx, const unsigned char *const *h_images, int num_views, int width, int height, int first, int stride,
+                         void *d_block, size_t slot_bytes, int max_pts, int num_octaves, double init_blur, float thresh,
+                         float lowest_scale, int scale_up, int *h_counts);
 
 /* Many view pairs (BASELINE configs[4]): the per-pair sequence of src/main.cpp:282-307 -- MatchSiftData (when d_sift2 is
  * given; it fills the match fields of d_sift1's records), fillXU, estimateE (num_hypotheses = 0: the reference's n1 / 8),

@@ -29,6 +29,8 @@ from helpers import read_pnm_grey, dino_frame
 if os.path.exists(dino_frame(35)):
     dino = [read_pnm_grey(dino_frame(k)) for k in range(36)]
     runs_todo += [("dino_ring_36_pairs", dino, S.ring_pairs(36)), ("dino_all_630_pairs", dino, [(i, j) for i in range(36) for j in range(i + 1, 36)])]
+    dino8 = [d.astype(np.uint8) for d in dino]           # the frames as the 8-bit images they are (sfm_extract_views_u8)
+    runs_todo += [("dino_ring_36_pairs_8bit_images", dino8, S.ring_pairs(36)), ("dino_all_630_pairs_8bit_images", dino8, [(i, j) for i in range(36) for j in range(i + 1, 36)])]
 for name, views, pairs in runs_todo:
     S.process_views(ctx, views[:9], K, Kinv, max_pts=8192, sift=sift, device=dev)      # warm-up (buffers, lanes, clocks)
     runs = []

@@ -131,6 +131,21 @@ def test_dino_ring_of_36_views(gpu):
         assert res[pid][26] >= 8 and np.isfinite(res[pid][:25]).all()
 
 
+def test_dino_views_as_8_bit_images_give_the_same_records(gpu):
+    """sfm_extract_views_u8 (8-bit grey images: a quarter of the PCIe bytes, widened on the device) against the float entry
+    point: feature counts and every result record of the ring of six frames, bit for bit."""
+    torch, dev, ctx = gpu
+    from helpers import dino_frame
+    views = [read_pnm_grey(dino_frame(k)) for k in range(6)]
+    bytes_ = [v.astype(np.uint8) for v in views]
+    assert all(np.array_equal(b.astype(np.float32), v) for b, v in zip(bytes_, views))       # the fixtures ARE 8-bit
+    res_f, counts_f = S.process_views(ctx, views, DINO_K, DINO_KINV, max_pts=8192, sift=DINO_SIFT, device=dev)
+    res_b, counts_b = S.process_views(ctx, bytes_, DINO_K, DINO_KINV, max_pts=8192, sift=DINO_SIFT, device=dev)
+    assert counts_b == counts_f and sorted(res_b) == sorted(res_f) == list(range(6))
+    for pid in res_f:
+        assert same_bits(res_b[pid], res_f[pid]), f"pair {pid}"
+
+
 def test_dino_ring_batched_equals_per_pair(gpu):
     """sfm_process_pairs (every pair enqueued back to back inside the C library, records assembled on the device, one
     read-back) against the same pairs taken one at a time through the Image_pair calls: records bit for bit, for both
