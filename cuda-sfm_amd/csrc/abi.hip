@@ -9,6 +9,7 @@
 #include <atomic>
 #include <utility>
 #include <thread>
+#include <mutex>
 #include <vector>
 
 namespace sfm {
@@ -917,9 +918,9 @@ static int extract_views_impl(sfm_ctx *ctx, const void *const *h_images, int byt
     SFM_REQUIRE(slot_bytes >= (size_t)max_pts * sizeof(sfm_sift_point) + 4 && slot_bytes % 16 == 0, SFM_E_INVALID,
                 "slot_bytes %zu: need max_pts records + the count, a multiple of 16", slot_bytes);
     SFM_HIP_TRY(hipSetDevice(ctx->device));
-    // FOUR contexts (the caller's + the auxiliary lanes): one image's per-level kernels leave most CUs idle, and every view
-    // ends with a host synchronisation (its feature count), so four views are in flight on four streams.
-    constexpr int NC = sfm_ctx::kPairLanes;           // contexts
+    // EIGHT contexts (the caller's + the auxiliary lanes): one image's per-level kernels leave most CUs idle, and every view
+    // ends with a host synchronisation (its feature count), so eight views are in flight on eight streams.
+    constexpr int NC = sfm_ctx::kViewLanes;           // contexts
     constexpr int NR = 2 * NC;                        // pinned staging buffers (two per context)
     constexpr int NT = 3;                             // helper threads that fill them
     sfm_ctx *cs[NC] = { ctx };
@@ -946,12 +947,19 @@ static int extract_views_impl(sfm_ctx *ctx, const void *const *h_images, int byt
     int nown = 0;
     for (int v = first; v < num_views; v += stride) { SFM_REQUIRE(h_images[v], SFM_E_INVALID, "view %d: null image", v); ++nown; }
     if (nown == 0) return SFM_OK;
-    std::vector<std::atomic<int>> staged((size_t)nown);
+    // Threads: NT stagers fill the pinned buffers (view i -> buffer i % NR, once view i - NR is through); one worker per
+    // context uploads, enqueues and reads back the count of the views i = k, k + NC, ... -- about fifteen runtime calls per
+    // view, 60-100 us of host time.  With float images the uploads (1.66 MB per 720 x 576 view, one copy engine) bound the
+    // front end and a single enqueueing thread is enough; with 8-bit images (a quarter of the bytes) the enqueueing thread did.
+    std::vector<std::atomic<int>> staged((size_t)nown), finished((size_t)nown);
     for (auto &f : staged) f.store(0, std::memory_order_relaxed);
-    std::atomic<int> consumed(0), stop(0);
+    for (auto &f : finished) f.store(0, std::memory_order_relaxed);
+    std::atomic<int> stop(0), first_rc(SFM_OK);
+    std::mutex err_mutex;
+    char err_text[512] = "";
     auto stage = [&](int t) {
         for (int i = t; i < nown && !stop.load(std::memory_order_relaxed); i += NT) {
-            while (i - consumed.load(std::memory_order_acquire) >= NR && !stop.load(std::memory_order_relaxed)) std::this_thread::yield();
+            while (i >= NR && finished[(size_t)(i - NR)].load(std::memory_order_acquire) == 0 && !stop.load(std::memory_order_relaxed)) std::this_thread::yield();
             char *pin = reinterpret_cast<char *>(ring[i % NR]);
             const char *src = static_cast<const char *>(h_images[first + i * stride]);
             const size_t px = (size_t)bytes_per_pixel;
@@ -962,61 +970,53 @@ static int extract_views_impl(sfm_ctx *ctx, const void *const *h_images, int byt
             staged[(size_t)i].store(1, std::memory_order_release);
         }
     };
-    std::vector<std::thread> stagers;
-    for (int t = 0; t < NT && t < nown; ++t) stagers.emplace_back(stage, t);
     char *block = static_cast<char *>(d_block);
     std::vector<int> counts((size_t)nown, 0);
-    int pending_slot[NC];
-    for (int k = 0; k < NC; ++k) pending_slot[k] = -1;
-    int done_upto = 0;                                // views 0 .. done_upto - 1 have been read back (in order: contexts take turns)
-    auto finish = [&](int k) -> int {
-        if (pending_slot[k] < 0) return SFM_OK;
-        int n = 0, stored = 0;
-        int rc = launch_extract_sift_end(cs[k], &n, &stored);                  // waits for this context's stream: its upload is done too
-        if (rc != SFM_OK) return rc;
-        counts[(size_t)pending_slot[k]] = n;
-        done_upto = pending_slot[k] + 1;
-        consumed.store(done_upto, std::memory_order_release);                  // staging buffer pending_slot % NR may be refilled
-        pending_slot[k] = -1;
-        return SFM_OK;
-    };
-    int rc = SFM_OK;
-    for (int i = 0; i < nown && rc == SFM_OK; ++i) {
-        const int k = i % NC;
-        rc = finish(k);                                                        // this context's previous view
-        if (rc != SFM_OK) break;
-        while (staged[(size_t)i].load(std::memory_order_acquire) == 0) std::this_thread::yield();
-        hipError_t e;
-        if (u8) {
-            // (the second half of the context's device image buffer holds the bytes until the kernel has widened them)
-            unsigned char *d_bytes = reinterpret_cast<unsigned char *>(image[k] + floats);
-            e = hipMemcpyAsync(d_bytes, ring[i % NR], floats, hipMemcpyHostToDevice, cs[k]->stream);
-            if (e == hipSuccess) {
-                hipLaunchKernelGGL(views_u8_to_float_kernel, dim3((unsigned)((floats / 4 + 255) / 256)), dim3(256), 0, cs[k]->stream,
-                                   reinterpret_cast<const uchar4 *>(d_bytes), reinterpret_cast<float4 *>(image[k]), floats / 4);
-                e = hipGetLastError();
-            }
-        } else {
-            e = hipMemcpyAsync(image[k], ring[i % NR], floats * sizeof(float), hipMemcpyHostToDevice, cs[k]->stream);
+    auto fail = [&](int rc) {
+        int expected = SFM_OK;
+        if (first_rc.compare_exchange_strong(expected, rc)) {
+            std::lock_guard<std::mutex> g(err_mutex);
+            snprintf(err_text, sizeof(err_text), "%s", sfm_last_error());      // (the message lives in this thread's buffer)
         }
-        if (e != hipSuccess) { set_error("view upload failed: %s", hipGetErrorString(e)); rc = SFM_E_HIP; break; }
-        rc = launch_extract_sift_begin(cs[k], reinterpret_cast<sfm_sift_point *>(block + (size_t)i * slot_bytes), max_pts, image[k],
-                                       width, height, pitch, num_octaves, init_blur, thresh, lowest_scale, scale_up ? 1 : 0, nullptr);
-        if (rc == SFM_OK) pending_slot[k] = i;
-    }
-    // the remaining views, oldest first (the staging ring is released in view order)
-    for (int left = 0; left < NC && rc == SFM_OK; ++left) {
-        int oldest = -1;
-        for (int k = 0; k < NC; ++k) if (pending_slot[k] >= 0 && (oldest < 0 || pending_slot[k] < pending_slot[oldest])) oldest = k;
-        if (oldest < 0) break;
-        rc = finish(oldest);
-    }
-    stop.store(1, std::memory_order_relaxed);
-    consumed.store(nown, std::memory_order_release);
-    for (std::thread &t : stagers) t.join();
-    if (rc != SFM_OK) {
-        for (int k = 0; k < NC; ++k) if (pending_slot[k] >= 0) { int n = 0; (void)launch_extract_sift_end(cs[k], &n, nullptr); }
-        return rc;
+        stop.store(1, std::memory_order_relaxed);
+    };
+    auto work = [&](int k) {
+        if (hipSetDevice(ctx->device) != hipSuccess) { set_error("hipSetDevice failed in a view worker"); fail(SFM_E_HIP); return; }
+        for (int i = k; i < nown && !stop.load(std::memory_order_relaxed); i += NC) {
+            while (staged[(size_t)i].load(std::memory_order_acquire) == 0 && !stop.load(std::memory_order_relaxed)) std::this_thread::yield();
+            if (stop.load(std::memory_order_relaxed)) break;
+            hipError_t e;
+            if (u8) {
+                // (the second half of the context's device image buffer holds the bytes until the kernel has widened them)
+                unsigned char *d_bytes = reinterpret_cast<unsigned char *>(image[k] + floats);
+                e = hipMemcpyAsync(d_bytes, ring[i % NR], floats, hipMemcpyHostToDevice, cs[k]->stream);
+                if (e == hipSuccess) {
+                    hipLaunchKernelGGL(views_u8_to_float_kernel, dim3((unsigned)((floats / 4 + 255) / 256)), dim3(256), 0, cs[k]->stream,
+                                       reinterpret_cast<const uchar4 *>(d_bytes), reinterpret_cast<float4 *>(image[k]), floats / 4);
+                    e = hipGetLastError();
+                }
+            } else {
+                e = hipMemcpyAsync(image[k], ring[i % NR], floats * sizeof(float), hipMemcpyHostToDevice, cs[k]->stream);
+            }
+            if (e != hipSuccess) { set_error("view upload failed: %s", hipGetErrorString(e)); fail(SFM_E_HIP); break; }
+            int rc = launch_extract_sift_begin(cs[k], reinterpret_cast<sfm_sift_point *>(block + (size_t)i * slot_bytes), max_pts, image[k],
+                                               width, height, pitch, num_octaves, init_blur, thresh, lowest_scale, scale_up ? 1 : 0, nullptr);
+            int n = 0, stored = 0;
+            if (rc == SFM_OK) rc = launch_extract_sift_end(cs[k], &n, &stored);    // waits for this context's stream: its upload is done too
+            if (rc != SFM_OK) { fail(rc); break; }
+            counts[(size_t)i] = n;
+            finished[(size_t)i].store(1, std::memory_order_release);           // staging buffer i % NR may be refilled
+        }
+    };
+    std::vector<std::thread> threads;
+    for (int t = 0; t < NT && t < nown; ++t) threads.emplace_back(stage, t);
+    for (int k = 1; k < NC && k < nown; ++k) threads.emplace_back(work, k);
+    work(0);                                                                   // (the caller's thread drives the caller's context)
+    for (std::thread &t : threads) t.join();
+    if (first_rc.load() != SFM_OK) {
+        for (sfm_ctx *c : cs) (void)hipStreamSynchronize(c->stream);
+        set_error("%s", err_text);
+        return first_rc.load();
     }
     // the feature counts of all slots with ONE strided copy
     SFM_HIP_TRY(hipMemcpy2DAsync(block + (size_t)max_pts * sizeof(sfm_sift_point), slot_bytes, counts.data(), sizeof(int), sizeof(int), (size_t)nown,
@@ -1065,6 +1065,7 @@ int sfm_process_pairs(sfm_ctx *ctx, const float h_K[9], const float h_Kinv[9], c
     // of a record is only read, so different lanes may work on pairs that share views.
     const int nlanes = owned >= 8 ? sfm_ctx::kPairLanes : 1;
     sfm_ctx *lanes[sfm_ctx::kPairLanes] = { ctx, nullptr, nullptr, nullptr };
+    static_assert(sfm_ctx::kPairLanes == 4 && sfm_ctx::kViewLanes >= sfm_ctx::kPairLanes, "the lane contexts are shared with sfm_extract_views");
     for (int l = 1; l < nlanes; ++l) {
         if (!ctx->lane[l - 1]) {
             rc = sfm_ctx_create(ctx->device, &ctx->lane[l - 1]);

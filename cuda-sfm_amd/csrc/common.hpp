@@ -62,9 +62,11 @@ struct sfm_ctx {
     size_t sift_ws_bytes = 0;
     // many-pairs driver (sfm_process_pairs): pooled Image_pair and device-side result records; up to three auxiliary
     // contexts with streams of their own, so that the small single-wave stages of one pair overlap another pair's matcher
-    static constexpr int kPairLanes = 4;
-    sfm_ctx *lane[kPairLanes - 1] = {};
-    hipEvent_t lane_ev[kPairLanes] = {};
+    static constexpr int kPairLanes = 4;               // streams of sfm_process_pairs
+    static constexpr int kViewLanes = 8;               // streams (and worker threads) of sfm_extract_views: a view is a chain of thirteen
+                                                       // small launches + a count read-back, ~0.15 ms of latency whatever the GPU is doing
+    sfm_ctx *lane[kViewLanes - 1] = {};
+    hipEvent_t lane_ev[kViewLanes] = {};
     sfm_pair *pool_pair = nullptr;
     // many-views front end (sfm_extract_views): pinned staging + device image, one per context
     float *views_pinned = nullptr, *views_image = nullptr;

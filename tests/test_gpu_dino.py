@@ -131,6 +131,39 @@ def test_dino_ring_of_36_views(gpu):
         assert res[pid][26] >= 8 and np.isfinite(res[pid][:25]).all()
 
 
+def test_dino_extract_views_equals_single_extractions(gpu):
+    """sfm_extract_views against sfm_extract_sift view by view: feature counts and every byte of the records, twelve frames,
+    float and 8-bit images (eight per-view chains on eight streams, one worker thread each)."""
+    torch, dev, ctx = gpu
+    import ctypes as C
+    from helpers import dino_frame
+    views = [read_pnm_grey(dino_frame(k)) for k in range(12)]
+    h, w = views[0].shape
+    p = (w + 127) // 128 * 128
+    max_pts = 8192
+    single = []
+    for v in views:
+        pad = np.zeros((h, p), np.float32); pad[:, :w] = v
+        d_sift = torch.zeros((max_pts, 576), dtype=torch.uint8, device=dev)
+        n, _ = ctx.extract_sift(d_sift, max_pts, torch.from_numpy(pad).to(dev), w, h, p, **DINO_SIFT)
+        single.append((n, d_sift.cpu().numpy()[:n].copy()))
+    for u8 in (False, True):
+        imgs = [np.ascontiguousarray(v, np.uint8 if u8 else np.float32) for v in views]
+        ct = C.c_ubyte if u8 else C.c_float
+        ptrs = (C.POINTER(ct) * len(imgs))(*[im.ctypes.data_as(C.POINTER(ct)) for im in imgs])
+        block = torch.zeros((len(imgs), max_pts * 576 + 64), dtype=torch.uint8, device=dev)
+        cnts = (C.c_int * len(imgs))()
+        fn = S._lib.sfm_extract_views_u8 if u8 else S._lib.sfm_extract_views
+        rc = fn(ctx._h, ptrs, len(imgs), w, h, 0, 1, block.data_ptr(), max_pts * 576 + 64, max_pts, int(DINO_SIFT["num_octaves"]),
+                float(DINO_SIFT["init_blur"]), float(DINO_SIFT["thresh"]), float(DINO_SIFT.get("lowest_scale", 0.0)), 0, cnts)
+        assert rc == 0, S.last_error() if hasattr(S, "last_error") else rc
+        got = block.cpu().numpy()
+        for k, (n, rec) in enumerate(single):
+            assert cnts[k] == n, f"view {k} ({'8-bit' if u8 else 'float'}): {cnts[k]} features, single extraction {n}"
+            assert int(got[k, max_pts * 576:max_pts * 576 + 4].view(np.int32)[0]) == n
+            assert np.array_equal(got[k, :n * 576].reshape(n, 576), rec), f"view {k}: records differ"
+
+
 def test_dino_views_as_8_bit_images_give_the_same_records(gpu):
     """sfm_extract_views_u8 (8-bit grey images: a quarter of the PCIe bytes, widened on the device) against the float entry
     point: feature counts and every result record of the ring of six frames, bit for bit."""
