@@ -89,3 +89,74 @@ def test_eps_monotone_and_infinite(H):
     assert H.hc_match_pf_eps(1.0, 1.0) < H.hc_match_pf_eps(1.0, 2.0) < H.hc_match_pf_eps(3.0, 2.0)
     assert np.isinf(H.hc_match_pf_eps(np.inf, 1.0)) and np.isinf(H.hc_match_pf_eps(1.0, np.inf))
     assert not (H.hc_match_pf_eps(np.inf, 0.0) < np.inf)         # inf * 0: NaN, which the kernel treats as "no bound"
+
+
+def chain_all(A, B):
+    """the exact chain of every (row of A, row of B) pair at once (float64 product, one rounding to float32 per step)"""
+    s = np.zeros((A.shape[0], B.shape[0]), np.float32)
+    A64, B64 = A.astype(np.float64), B.astype(np.float64)
+    for d in range(128):
+        s = (A64[:, d:d + 1] * B64[None, :, d] + s.astype(np.float64)).astype(np.float32)
+    return s
+
+
+def reference_fold(scores):
+    """FindMaxCorr10's rule over one query's scores in row order (matching.cu:352-361): (best, second, index)"""
+    best, second, idx = np.float32(0.0), np.float32(0.0), -1
+    for p, s in enumerate(scores):
+        if s > best:
+            second, best, idx = best, s, p
+        elif s > second:
+            second = s
+    return best, second, idx
+
+
+@pytest.mark.parametrize("kind_q,kind_db,seed", [("sift", "sift", 1), ("sift", "sift", 2), ("signed", "signed", 3), ("spiky", "sift", 4),
+                                                 ("half", "half", 5), ("tiny", "sift", 6)])
+def test_fused_running_threshold_lists_every_row_that_matters(H, kind_q, kind_db, seed):
+    """The listing rule of match_fused.hip on the CPU: stages of 128 rows, the maxima of the eight sixteen-row sets a lane pair
+    owns per stage, A2 = the second largest of all set maxima so far, tau = A2 - 2 eps (eps with the largest row norm so far),
+    listed = rows of the stage with approximate score >= tau.  The approximate scores are the fp16 copies' dot products pushed
+    ADVERSARIALLY by the whole accumulation budget (down for the rows that matter, up for the others).  Folding the listed
+    rows' exact scores with the reference's rule must give the reference's (best, second, index) over ALL rows."""
+    rng = np.random.default_rng(seed)
+    nq, ndb = 24, 700                                     # 5.5 stages: a short last one included
+    Q, D = rows(rng, kind_q, nq), rows(rng, kind_db, ndb)
+    if kind_q == "sift":                                  # near-duplicates of some rows, as matched views have
+        for i in range(0, nq, 2):
+            Q[i] = D[rng.integers(0, ndb)] + 1e-3 * rng.standard_normal(128).astype(np.float32)
+    D[333] = D[40]; D[650] = D[40]                        # exact duplicates in different stages
+    exact = chain_all(Q, D)
+    hQ, hD = half_copy(H, Q).astype(np.float64), half_copy(H, D).astype(np.float64)
+    approx = hQ @ hD.T
+    budget = ACC * (np.abs(hQ) @ np.abs(hD).T)
+    qn = np.array([H.hc_match_pf_norm_up(Q[i].ctypes.data_as(f32p)) for i in range(nq)], np.float32)
+    dn = np.array([H.hc_match_pf_norm_up(D[j].ctypes.data_as(f32p)) for j in range(ndb)], np.float32)
+    listed_total = 0
+    for i in range(nq):
+        want = reference_fold(exact[i])
+        # adversary: rows that take part in the reference's result look as small as the budget allows, all others as large
+        matters = exact[i] >= want[1]
+        a = np.where(matters, approx[i] - budget[i], approx[i] + budget[i])
+        A1 = A2 = 0.0
+        bmax = np.float32(0.0)
+        listed = []
+        for s0 in range(0, ndb, 128):
+            rows_s = np.arange(s0, min(ndb, s0 + 128))
+            bmax = max(bmax, dn[rows_s].max())
+            padded = np.zeros(128); padded[:rows_s.size] = a[rows_s]            # rows beyond the end are staged as zeros
+            for rt in range(4):
+                for half in range(2):
+                    members = [32 * rt + (r & 3) + 8 * (r >> 2) + 4 * half for r in range(16)]
+                    m = max(0.0, padded[members].max())
+                    A2 = max(min(A1, m), A2)
+                    A1 = max(A1, m)
+            eps = float(H.hc_match_pf_eps(qn[i], bmax))
+            tau = A2 - 2.0 * eps
+            tau = tau - abs(tau) * 1.2e-7
+            listed += [int(r) for r in rows_s if not (a[r] < tau)]
+        listed_total += len(listed)
+        got = reference_fold(exact[i][listed])
+        got = (got[0], got[1], listed[got[2]] if got[2] >= 0 else -1)
+        assert (got[0], got[1], got[2]) == (want[0], want[1], want[2]), (kind_q, kind_db, i, got, want, len(listed))
+    assert listed_total < nq * ndb // 2 or kind_q in ("tiny", "half")          # the rule does filter on ordinary data
