@@ -772,6 +772,9 @@ def rank_main(args):
                        "jacobi_sweeps": params.jacobi_sweeps,
                        "solver": "householder QR of the 8x9 system" if params.jacobi_sweeps == 0 else f"normal equations + {params.jacobi_sweeps} Jacobi sweeps",
                        "kernel": dict(launch, name=kname), "step_mode": step_mode, "exchange": exchange,
+                       "untimed_steps_before_the_timed_region": {"device_wake_up": max(0, wake_steps), "warmup": args.warmup,
+                                                                 "note": "the wake-up covers ~60 ms of work whatever the step length (clock ramp); neither is timed"},
+                       "hip_events_inside_the_timed_region": bool(events_in_region),
                        "nccl_ranks": comm.nccl_ranks() if comm is not None else (world if mode == "torch" else 1),
                        "per_rank_kernel_ms": [{"rank": r, "solve": v[0], "score": v[1], "shader_clock_mhz": v[2]} for r, v in enumerate(per_rank)]},
             "roofline": roofline_block(launch["kernel"], n, local_hyps, score_s, solve_s, clock_mhz, measured_in),
