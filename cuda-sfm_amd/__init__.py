@@ -747,7 +747,9 @@ def process_views(ctx, images, K, Kinv, pairs=None, rank=0, world=1, max_pts=819
     p = (w + 127) // 128 * 128
     slots = (V + world - 1) // world
     rec_bytes = max_pts * 576
-    block = torch.zeros((slots, rec_bytes + 64), dtype=torch.uint8, device=dev)       # records | int32 count in the tail
+    # records | int32 count in the tail; every slot of a single-rank run is written by sfm_extract_views (records up to the count,
+    # the count itself), so only a multi-rank run -- whose last slots may stay unused -- pays for clearing 4.7 MB per view
+    block = (torch.zeros if world > 1 else torch.empty)((slots, rec_bytes + 64), dtype=torch.uint8, device=dev)
     # ExtractSift for this rank's views inside the C library (sfm_extract_views: pinned staging, two streams)
     mine_views = list(range(rank, V, world))
     if mine_views:
