@@ -1010,8 +1010,11 @@ static int extract_views_impl(sfm_ctx *ctx, const void *const *h_images, int byt
     };
     std::vector<std::thread> threads;
     for (int t = 0; t < NT && t < nown; ++t) threads.emplace_back(stage, t);
-    for (int k = 1; k < NC && k < nown; ++k) threads.emplace_back(work, k);
-    work(0);                                                                   // (the caller's thread drives the caller's context)
+    // the caller's thread takes the LAST context: it starts after the others have been spawned, and the last contexts get one
+    // view fewer when the views do not divide evenly (36 views on eight contexts: 5 5 5 5 4 4 4 4)
+    const int lanes_used = nown < NC ? nown : NC;
+    for (int k = 0; k + 1 < lanes_used; ++k) threads.emplace_back(work, k);
+    work(lanes_used - 1);
     for (std::thread &t : threads) t.join();
     if (first_rc.load() != SFM_OK) {
         for (sfm_ctx *c : cs) (void)hipStreamSynchronize(c->stream);
