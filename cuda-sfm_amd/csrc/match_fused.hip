@@ -151,7 +151,6 @@ __device__ __forceinline__ void match_fused_body(const float *__restrict__ q, in
     {
         float4 qregs[8][2];
         rows_load(q, ldq, q0, nq, qregs);
-        if (nstage > 0) rows_load(db, lddb, row_begin, row_end, regs);
         if (tid == 0) sh.bmax = 0u;
         if (tid < kMfWaves) sh.cnt[tid] = 0;
         for (int k = tid; k < kMfQ; k += kMfWaves * 64) { sh.best[k] = 0ull; sh.second[k] = 0ull; }
@@ -227,13 +226,15 @@ __device__ __forceinline__ void match_fused_body(const float *__restrict__ q, in
         if (s < 3) MF_STAMP(3 + 6 * s);
         const int stage_rows = min(kMfRows, row_end - stage_row0);
         {
+            // (no software prefetch of the next stage: its 64 registers cost the third block per CU, which hides the loads
+            //  better -- 16384^2 227 -> 173 us, the 630 dino pairs unchanged or slightly better, profiles/r03_match_fused_notes.txt)
+            rows_load(db, lddb, stage_row0, row_end, regs);
             const float smax = rows_store(regs, stage_rows, nullptr);
             if (c8 == 0) atomicMax(&sh.bmax, __float_as_uint(match_pf_norm_up(smax)));
         }
         if (s < 3) MF_STAMP(4 + 6 * s);
         __syncthreads();
         if (s < 3) MF_STAMP(5 + 6 * s);
-        if (s + 1 < nstage) rows_load(db, lddb, stage_row0 + kMfRows, row_end, regs);
         const float bmax = __uint_as_float(sh.bmax);
 
         // ---- approximate scores: 4 row tiles x 8 k-steps
@@ -375,7 +376,7 @@ __device__ __forceinline__ void match_fused_body(const float *__restrict__ q, in
     }
 }
 
-__global__ __launch_bounds__(kMfWaves * 64, 2)
+__global__ __launch_bounds__(kMfWaves * 64, 3)
 void match_fused_kernel(const float *__restrict__ q, int nq, int ldq, const float *__restrict__ db, int ndb, int lddb, int rows_per_split,
                         float *__restrict__ ws_best, float *__restrict__ ws_second, int *__restrict__ ws_idx,
                         unsigned int *__restrict__ tickets, float *__restrict__ out_best, float *__restrict__ out_second,
@@ -386,7 +387,7 @@ void match_fused_kernel(const float *__restrict__ q, int nq, int ldq, const floa
 }
 
 // Many matches of ONE query set in one launch (sfm_process_pairs, see match_mfma_jobs_kernel): blockIdx.z names the match.
-__global__ __launch_bounds__(kMfWaves * 64, 2)
+__global__ __launch_bounds__(kMfWaves * 64, 3)
 void match_fused_jobs_kernel(const float *__restrict__ q, int nq, int ldq, const MatchJob *__restrict__ jobs)
 {
     const MatchJob &j = jobs[blockIdx.z];
@@ -401,7 +402,8 @@ int launch_match_fused(sfm_ctx *ctx, const float *d1, int n1, int ld1, const flo
     if (n1 <= 0 || n2 <= 0) return SFM_OK;
     SFM_REQUIRE(n2 <= (int)kMfRowMask, SFM_E_INVALID, "SFM_MATCH_FUSED holds 27 bits of row index: %d rows are too many (use SFM_MATCH_AUTO)", n2);
     const int qblocks = (n1 + kMfQ - 1) / kMfQ;
-    int nsplit = 2 * ctx->num_cus / qblocks;               // two blocks per CU (45 KB of LDS, at most 256 registers a lane)
+    int nsplit = 2 * ctx->num_cus / qblocks;               // two blocks per CU to start with (three fit: 45 KB of LDS, 155 registers a
+                                                           // lane; aiming at three only adds splits, i.e. exact chains: 5500^2 45 -> 55 us)
     const int most = (n2 + kMfRows - 1) / kMfRows;
     if (nsplit > most) nsplit = most;
     if (nsplit < 1) nsplit = 1;
