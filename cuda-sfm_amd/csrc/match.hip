@@ -353,7 +353,12 @@ int launch_match(sfm_ctx *ctx, const float *d1, int n1, int ld1, const float *d2
                  sfm_sift_point *sift1, const sfm_sift_point *sift2)
 {
     if (n1 <= 0 || n2 <= 0) return SFM_OK;                 // matching.cu:1095-1096
-    const int pick = match_pick(ctx, n1, n2);
+    int pick = match_pick(ctx, n1, n2);
+    // rows exactly a multiple of 512 bytes apart (plain descriptor arrays, ld = 128): the scattered 16-byte loads of the fused
+    // matcher's exact chains land on a fraction of the L2 channels (4096^2: 38.5 against 31.5 us with 576-byte records), so AUTO
+    // stays with the exact matcher up to 3400^2 and takes the four-kernel pre-filter from there (profiles/r03_match_fused_notes.txt)
+    if (ctx->match_kernel == SFM_MATCH_AUTO && pick == SFM_MATCH_FUSED && ld2 % 128 == 0)
+        pick = (size_t)n1 * (size_t)n2 < (size_t)3400 * 3400 || n1 < 1024 || n2 < 1024 ? SFM_MATCH_EXACT : SFM_MATCH_PREFILTER;
     if (pick == SFM_MATCH_PREFILTER) {
         ctx->last_match_kernel = SFM_MATCH_PREFILTER;
         return launch_match_prefilter(ctx, d1, n1, ld1, d2, n2, ld2, d_best, d_second, d_index, sift1, sift2);

@@ -68,7 +68,9 @@ int  sfm_ctx_set_quirks(sfm_ctx *ctx, unsigned int flags);
  * SFM_MATCH_FUSED     -- the same idea in ONE launch: the threshold is a running one (the second-largest approximate score seen
  *                        so far), scores, candidate lists and exact chains never leave the block (match_fused.hip);
  * SFM_MATCH_AUTO      -- exact below 2560 x 2560 points, fused up to 6144 x 6144, the pre-filter from there on; the batched path
- *                        of sfm_process_pairs (many matches in one launch) uses fused below that size (default).
+ *                        of sfm_process_pairs (many matches in one launch) uses fused below that size (default); plain descriptor
+ *                        arrays with rows a multiple of 512 bytes apart (sfm_match_soa, ld = 128): exact up to 3400 x 3400, then the
+ *                        pre-filter.
  * sfm_ctx_last_match_kernel: what the last call ran. */
 #define SFM_MATCH_AUTO      0
 #define SFM_MATCH_EXACT     1

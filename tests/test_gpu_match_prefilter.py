@@ -144,6 +144,18 @@ def test_prefilter_sift_records_and_auto(gpu):
     assert np.array_equal(out["match"], ref["match"])
 
 
+def test_auto_on_plain_descriptor_arrays(gpu):
+    """sfm_match_soa with rows 512 bytes apart: AUTO keeps the exact matcher up to 3400^2 and takes the four-kernel pre-filter
+    above (the fused matcher's scattered loads dislike that stride); results as always."""
+    d1, d2, perm = synth.descriptors(4096)
+    b, s, i, ran = run_soa(gpu, d2, d1, S.MATCH_AUTO)
+    assert ran == S.MATCH_PREFILTER and (i == perm).mean() > 0.99
+    b, s, i, ran = run_soa(gpu, d2[:3000], d1[:3000], S.MATCH_AUTO)
+    assert ran == S.MATCH_EXACT
+    ob, os_, oi = O.match_desc(d2[:50], d1[:3000])
+    assert np.array_equal(i[:50], oi) and same_bits(b[:50], ob) and same_bits(s[:50], os_)
+
+
 def test_fused_many_stages_duplicates_across_stages(gpu):
     """Enough query blocks that a block walks several 128-row stages of the database: duplicated rows in DIFFERENT stages
     (the lowest index wins, second == best), a query whose best comes late, equal rows filling a whole stage."""
