@@ -1009,13 +1009,24 @@ static int extract_views_impl(sfm_ctx *ctx, const void *const *h_images, int byt
         }
     };
     std::vector<std::thread> threads;
-    for (int t = 0; t < NT && t < nown; ++t) threads.emplace_back(stage, t);
     // the caller's thread takes the LAST context: it starts after the others have been spawned, and the last contexts get one
     // view fewer when the views do not divide evenly (36 views on eight contexts: 5 5 5 5 4 4 4 4)
     const int lanes_used = nown < NC ? nown : NC;
-    for (int k = 0; k + 1 < lanes_used; ++k) threads.emplace_back(work, k);
-    work(lanes_used - 1);
+    bool spawned = true;
+    try {
+        for (int t = 0; t < NT && t < nown; ++t) threads.emplace_back(stage, t);
+        for (int k = 0; k + 1 < lanes_used; ++k) threads.emplace_back(work, k);
+    } catch (...) {                                       // (std::system_error: the process is out of threads)
+        spawned = false;
+        stop.store(1, std::memory_order_relaxed);
+    }
+    if (spawned) work(lanes_used - 1);
     for (std::thread &t : threads) t.join();
+    if (!spawned) {
+        for (sfm_ctx *c : cs) (void)hipStreamSynchronize(c->stream);
+        set_error("sfm_extract_views could not start its worker threads");
+        return SFM_E_NOMEM;
+    }
     if (first_rc.load() != SFM_OK) {
         for (sfm_ctx *c : cs) (void)hipStreamSynchronize(c->stream);
         set_error("%s", err_text);
