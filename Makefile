@@ -4,15 +4,24 @@ HIPCC    ?= /opt/rocm/bin/hipcc
 ARCH     ?= gfx950
 # -ffp-contract=off + correctly rounded div/sqrt: the arithmetic contract shared with oracle/
 HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -DOCML_BASIC_ROUNDED_OPERATIONS \
-            -fPIC -Wall -Wno-unused-function -Wno-pass-failed
+            -fPIC -fvisibility=hidden -Wall -Wno-unused-function -Wno-pass-failed
 PKG      := cuda-sfm_amd
 CSRC     := $(PKG)/csrc
 BUILD    := build
+BUILD_AB := build/ab
 LIB      := $(PKG)/lib/libsfm_amd.so
 COMMLIB  := $(PKG)/lib/libsfm_amd_rccl.so
+# Two flavours of the same sources:
+#   libsfm_amd.so     the product: what include/sfm_amd.h declares, nothing else (sfm_ransac_params.reserved[] must be 0)
+#   libsfm_amd_ab.so  the lab bench (-DSFM_AB=1): + the A/B switches behind reserved[], the recorded slower kernel variants
+#                     ($(CSRC)/ab/*.hip) and the probe / trace hooks of include/sfm_amd_ab.h.  Loaded only by tests/ and
+#                     profiles/ (`import cuda_sfm_amd_ab`), never by the product path.
+LIB_AB   := $(PKG)/lib/libsfm_amd_ab.so
 SRCS     := $(wildcard $(CSRC)/*.hip)
+SRCS_AB  := $(wildcard $(CSRC)/ab/*.hip)
 OBJS     := $(patsubst $(CSRC)/%.hip,$(BUILD)/%.o,$(SRCS))
-HDRS     := $(wildcard $(CSRC)/*.hpp) include/sfm_amd.h
+OBJS_AB  := $(patsubst $(CSRC)/%.hip,$(BUILD_AB)/%.o,$(SRCS)) $(patsubst $(CSRC)/ab/%.hip,$(BUILD_AB)/ab_%.o,$(SRCS_AB))
+HDRS     := $(wildcard $(CSRC)/*.hpp) include/sfm_amd.h include/sfm_amd_ab.h
 
 DEMO     := $(PKG)/host/two_view_demo
 HDEMO    := $(PKG)/host/homography_demo
@@ -22,11 +31,19 @@ MAINAPP  := $(PKG)/host/sfm_main
 IOTEST   := tests/cpp/io_test
 GEOMTEST := tests/cpp/geom_test
 
-all: $(LIB) $(COMMLIB) oracle hostcheck $(DEMO) $(HDEMO) $(SDEMO) $(MAINAPP) $(IOTEST) $(GEOMTEST)
+all: $(LIB) $(LIB_AB) $(COMMLIB) oracle hostcheck $(DEMO) $(HDEMO) $(SDEMO) $(MAINAPP) $(IOTEST) $(GEOMTEST)
 
 $(BUILD)/%.o: $(CSRC)/%.hip $(HDRS)
 	@mkdir -p $(BUILD)
 	$(HIPCC) $(HIPFLAGS) $(FLAGS_$*) -c $< -o $@
+
+$(BUILD_AB)/%.o: $(CSRC)/%.hip $(HDRS)
+	@mkdir -p $(BUILD_AB)
+	$(HIPCC) $(HIPFLAGS) -DSFM_AB=1 $(FLAGS_$*) -c $< -o $@
+
+$(BUILD_AB)/ab_%.o: $(CSRC)/ab/%.hip $(HDRS)
+	@mkdir -p $(BUILD_AB)
+	$(HIPCC) $(HIPFLAGS) -DSFM_AB=1 -I$(CSRC) -c $< -o $@
 
 # the lane-solve kernels are long chains of scalar FP32 operations: the SLP vectoriser pairs some of them into v_pk_* and pays
 # for it with register moves (366 v_mov in 2473 instructions); without it the same arithmetic needs fewer issue slots
@@ -34,13 +51,19 @@ FLAGS_ransac := -fno-slp-vectorize
 # match_fused's two interleaved exact chains: paired into v_pk_fma_f32 they need a register move per operand
 FLAGS_match_fused := -fno-slp-vectorize
 
-$(LIB): $(OBJS)
+$(LIB): $(OBJS) $(CSRC)/exports.map
 	@mkdir -p $(PKG)/lib
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS) -lpthread
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -Wl,--version-script=$(CSRC)/exports.map -o $@ $(OBJS) -lpthread
+
+$(LIB_AB): $(OBJS_AB) $(CSRC)/exports.map
+	@mkdir -p $(PKG)/lib
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -Wl,--version-script=$(CSRC)/exports.map -o $@ $(OBJS_AB) -lpthread
+
+ab: $(LIB_AB)
 
 # the RCCL exchange step lives in its own library: libsfm_amd.so itself has no RCCL dependency
 $(COMMLIB): $(CSRC)/comm.cpp include/sfm_amd_comm.h include/sfm_amd.h $(LIB)
-	$(HIPCC) -x hip --cuda-host-only -O2 -fPIC -shared -Iinclude -o $@ $< -L$(PKG)/lib -lsfm_amd -L/opt/rocm/lib -lrccl -Wl,-rpath,'$$ORIGIN' -Wl,-rpath,/opt/rocm/lib
+	$(HIPCC) -x hip --cuda-host-only -O2 -fPIC -fvisibility=hidden -shared -Iinclude -Wl,--version-script=$(CSRC)/exports.map -o $@ $< -L$(PKG)/lib -lsfm_amd -L/opt/rocm/lib -lrccl -Wl,-rpath,'$$ORIGIN' -Wl,-rpath,/opt/rocm/lib
 
 oracle:
 	$(MAKE) -C oracle
@@ -70,7 +93,7 @@ tests/hostcheck/libhostcheck.so: tests/hostcheck/hostcheck.hip $(CSRC)/device_ma
 	$(HIPCC) -x hip --cuda-host-only -O2 -ffp-contract=off -mfma -fPIC -shared -Wno-pass-failed -o $@ $<
 
 clean:
-	rm -rf $(BUILD) $(LIB) $(DEMO) $(HDEMO) $(SDEMO) $(MAINAPP) $(IOTEST) $(GEOMTEST) tests/hostcheck/libhostcheck.so
+	rm -rf $(BUILD) $(LIB) $(LIB_AB) $(DEMO) $(HDEMO) $(SDEMO) $(MAINAPP) $(IOTEST) $(GEOMTEST) tests/hostcheck/libhostcheck.so
 	$(MAKE) -C oracle clean
 
-.PHONY: all oracle hostcheck clean
+.PHONY: all ab oracle hostcheck clean

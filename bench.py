@@ -87,7 +87,7 @@ def parse_args(argv=None):
                          "(sfm_estimate_E_pipelined / sfm_estimate_E_sharded_pipelined) in which consecutive steps overlap on the device")
     ap.add_argument("--timed-events", choices=["auto", "on", "off"], default="auto",
                     help="HIP events around every kernel INSIDE the timed region (auto: only with --serial; pipelined steps are sampled by serial launches right after it)")
-    ap.add_argument("--reserved", type=int, nargs="*", default=[], help="sfm_ransac_params.reserved[] A/B switches (profiles/)")
+    ap.add_argument("--reserved", type=int, nargs="*", default=[], help="sfm_ransac_params.reserved[] A/B switches (profiles/): runs on libsfm_amd_ab.so, never part of a judged line")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg (and with it the full-oracle parity check)")
     ap.add_argument("--no-variants", action="store_true", help="skip the short run with the other null-vector solver")
     ap.add_argument("--no-extra", action="store_true", help="skip the short runs of the other BASELINE configurations")
@@ -545,8 +545,12 @@ def rank_main(args):
     import numpy as np
     import torch
     import torch.distributed as dist
-    import cuda_sfm_amd as S
-    from cuda_sfm_amd import synth
+    if any(args.reserved):              # A/B switches exist only in the lab-bench flavour of the library (make ab; profiles/)
+        import cuda_sfm_amd_ab as S
+        from cuda_sfm_amd_ab import synth
+    else:
+        import cuda_sfm_amd as S
+        from cuda_sfm_amd import synth
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -15,7 +15,11 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libsfm_amd.so")
+# Two flavours of one source tree (Makefile): the product library, and the lab bench (-DSFM_AB=1: the A/B switches behind
+# sfm_ransac_params.reserved[], the recorded slower kernel variants, the probe / trace hooks of include/sfm_amd_ab.h).  The lab
+# bench is what `import cuda_sfm_amd_ab` binds -- tests/ and profiles/ only.
+AB = __name__.endswith("_ab")
+LIB_PATH = os.path.join(_HERE, "lib", "libsfm_amd_ab.so" if AB else "libsfm_amd.so")
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -32,7 +36,9 @@ _lib = C.CDLL(LIB_PATH)
 
 # ---- constants (include/sfm_amd.h) --------------------------------------------------------------
 OK, E_INVALID, E_HIP, E_NOMEM, E_STATE, E_SINGULAR = 0, -1, -2, -3, -4, -5
-KERNEL_AUTO, KERNEL_SPLIT, KERNEL_FUSED, KERNEL_MFMA, KERNEL_PREFILTER = 0, 1, 2, 3, 4
+KERNEL_AUTO, KERNEL_SPLIT, KERNEL_FUSED, KERNEL_PREFILTER = 0, 1, 2, 4
+if AB:
+    KERNEL_MFMA = 3             # include/sfm_amd_ab.h
 QUIRK_MATCH_TAIL = 1
 MATCH_AUTO, MATCH_EXACT, MATCH_PREFILTER, MATCH_FUSED = 0, 1, 2, 3
 POSE_REFERENCE, POSE_CORRECT = 0, 1
@@ -58,8 +64,11 @@ EXPORTS = [
     "sfm_pair_device_ptr", "sfm_pair_ld", "sfm_pair_num_points", "sfm_get_XU", "sfm_get_E", "sfm_get_best",
     "sfm_get_key", "sfm_get_inlier_counts", "sfm_get_inlier_mask", "sfm_get_E_candidates",
     "sfm_get_pose_candidates", "sfm_get_pose_inverses", "sfm_get_pose_index", "sfm_get_points", "sfm_copy_points_to_vbo",
-    "sfm_ransac_last_launch", "sfm_ransac_last_clock", "sfm_ransac_last_phases", "sfm_ransac_last_trace", "sfm_prefilter_probe", "sfm_process_pairs", "sfm_extract_views", "sfm_extract_views_u8",
+    "sfm_ransac_last_launch", "sfm_ransac_last_clock", "sfm_process_pairs", "sfm_ctx_last_pairs_batched", "sfm_extract_views", "sfm_extract_views_u8",
 ]
+AB_EXPORTS = ["sfm_ransac_last_phases", "sfm_ransac_last_trace", "sfm_prefilter_probe"]      # include/sfm_amd_ab.h
+if AB:
+    EXPORTS = EXPORTS + AB_EXPORTS
 
 
 class RansacParams(C.Structure):
@@ -110,7 +119,6 @@ _lib.sfm_estimate_E.argtypes = [_vp, C.POINTER(RansacParams)]
 _lib.sfm_ransac_score.argtypes = [_vp, C.POINTER(RansacParams)]
 _lib.sfm_ransac_score_into.argtypes = [_vp, C.POINTER(RansacParams), _vp]
 _lib.sfm_ransac_score_candidates.argtypes = [_vp, C.POINTER(RansacParams), _vp]
-_lib.sfm_ransac_last_phases.argtypes = [_vp, C.POINTER(C.c_uint64)]
 _lib.sfm_ransac_finalize.argtypes = [_vp, C.POINTER(RansacParams), C.c_uint32]
 _lib.sfm_ransac_finalize_key.argtypes = [_vp, C.POINTER(RansacParams), _vp]
 _lib.sfm_ransac_finalize_key_on.argtypes = [_vp, C.POINTER(RansacParams), _vp, _vp]
@@ -137,7 +145,10 @@ _lib.sfm_get_pose_index.argtypes = [_vp, C.POINTER(C.c_int)]
 _lib.sfm_get_points.argtypes = [_vp, _vp]
 _lib.sfm_pair_reset.argtypes = [_vp, C.c_int]
 _lib.sfm_get_result.argtypes = [_vp, _vp]
-_lib.sfm_ransac_last_trace.argtypes = [_vp, C.POINTER(C.c_uint64), C.c_size_t, C.POINTER(C.c_size_t)]
+if AB:
+    _lib.sfm_ransac_last_phases.argtypes = [_vp, C.POINTER(C.c_uint64)]
+    _lib.sfm_ransac_last_trace.argtypes = [_vp, C.POINTER(C.c_uint64), C.c_size_t, C.POINTER(C.c_size_t)]
+_lib.sfm_ctx_last_pairs_batched.argtypes = [_vp, C.POINTER(C.c_int)]
 _lib.sfm_ransac_last_launch.argtypes = [_vp] + [C.POINTER(C.c_int)] * 4
 _lib.sfm_ransac_last_clock.argtypes = [_vp, C.POINTER(C.c_double)]
 
@@ -230,8 +241,14 @@ class Context:
         _check(_lib.sfm_ctx_last_match_kernel(self._h, C.byref(k)), "sfm_ctx_last_match_kernel")
         return k.value
 
+    def last_pairs_batched(self):
+        """Whether the last process_pairs call on this context took the batched path."""
+        b = C.c_int(0)
+        _check(_lib.sfm_ctx_last_pairs_batched(self._h, C.byref(b)), "sfm_ctx_last_pairs_batched")
+        return bool(b.value)
+
     def prefilter_probe(self, E, threshold, bound, point, survive_all=False):
-        """Operands and matrix-core results of one (hypothesis, point) pair of the pre-filter kernel (test probe)."""
+        """Operands and matrix-core results of one (hypothesis, point) pair of the pre-filter kernel (test probe; lab-bench flavour only)."""
         e = np.ascontiguousarray(E, np.float32).reshape(9); pt = np.ascontiguousarray(point, np.float32).reshape(4)
         out = np.zeros(100, np.float32)
         _check(_lib.sfm_prefilter_probe(self._h, e.ctypes.data_as(_vp), C.c_float(float(threshold)), C.c_float(float(bound)), pt.ctypes.data_as(_vp),
@@ -532,6 +549,8 @@ _comm_lib = None
 def comm_lib():
     """libsfm_amd_rccl.so, loaded on first use (it pulls in librccl; the core library does not)."""
     global _comm_lib
+    if AB:
+        raise ImportError("libsfm_amd_rccl.so is linked against the PRODUCT library: the lab-bench flavour has no communicator")
     if _comm_lib is None:
         if not os.path.exists(COMM_LIB_PATH):
             raise ImportError(f"{COMM_LIB_PATH} is missing: run `make` (or __graft_entry__.build())")

@@ -40,6 +40,11 @@ static int resolve_shard(const sfm_pair *pair, const sfm_ransac_params *p, uint3
     SFM_REQUIRE(p->hyp_begin <= p->num_hypotheses, SFM_E_INVALID, "hyp_begin %u beyond num_hypotheses %u", p->hyp_begin, p->num_hypotheses);
     SFM_REQUIRE(p->jacobi_sweeps >= 0 && p->jacobi_sweeps <= 64, SFM_E_INVALID, "jacobi_sweeps out of range (0 = Householder solver)");
     SFM_REQUIRE(p->kernel >= SFM_KERNEL_AUTO && p->kernel <= SFM_KERNEL_PREFILTER, SFM_E_INVALID, "unknown kernel id %d", p->kernel);
+#if !SFM_AB
+    SFM_REQUIRE(p->kernel != 3, SFM_E_INVALID, "kernel id 3 (f32 matrix-core scoring, a recorded A/B variant) exists only in libsfm_amd_ab.so");
+    SFM_REQUIRE(p->reserved[0] == 0 && p->reserved[1] == 0 && p->reserved[2] == 0 && p->reserved[3] == 0, SFM_E_INVALID,
+                "sfm_ransac_params.reserved[] must be zero (the A/B switches exist only in libsfm_amd_ab.so, include/sfm_amd_ab.h)");
+#endif
     uint32_t c = p->hyp_count ? p->hyp_count : p->num_hypotheses - p->hyp_begin;
     SFM_REQUIRE((uint64_t)p->hyp_begin + c <= p->num_hypotheses, SFM_E_INVALID, "shard [%u, %u) exceeds num_hypotheses %u",
                 p->hyp_begin, p->hyp_begin + c, p->num_hypotheses);
@@ -1120,18 +1125,22 @@ int sfm_process_pairs(sfm_ctx *ctx, const float h_K[9], const float h_Kinv[9], c
         for (int l = 1; l < nlanes; ++l) SFM_HIP_TRY(hipStreamWaitEvent(lanes[l]->stream, ctx->lane_ev[0], 0));
     }
     // ---- batched path (pairs_batch.hpp): the matcher stays one launch per pair (it fills the chip), everything after it is
-    // THREE launches for all pairs of the call -- 630 pairs x 5 small launches are bound by the host's launch rate, not by
+    // FIVE launches for all pairs of the call -- 630 pairs x 5 small launches are bound by the host's launch rate, not by
     // the GPU.  Taken for the reference's own pipeline (SFM_POSE_REFERENCE, K^-1 with last row (0 0 1), up to 4096
     // hypotheses per pair); anything else runs the per-pair loop below.  Results are bit-identical (same device functions on
     // the same inputs: tests/test_gpu_dino.py::test_dino_ring_batched_equals_per_pair).
     bool batched_done = false;
     int slot = 0;
-    static const bool unbatched_env = getenv("SFM_PAIRS_UNBATCHED") != nullptr;      // A/B and tests
+    const bool unbatched_env = getenv("SFM_PAIRS_UNBATCHED") != nullptr;      // A/B and tests: read on EVERY call (sfm_ctx_last_pairs_batched says what ran)
     const bool unit_z = h_Kinv[6] == 0.0f && h_Kinv[7] == 0.0f && h_Kinv[8] == 1.0f;
     bool batch = pose_mode == SFM_POSE_REFERENCE && unit_z && owned >= 4 && !unbatched_env;
+    ctx->last_pairs_batched = 0;
     uint32_t max_H = 0;
     for (int i = first; i < num_pairs && batch; i += stride) {
         if (pairs[i].n1 < 8 || (pairs[i].d_sift2 && pairs[i].n2 < 1)) continue;
+        // already matched pairs (no second view given) read match_xpos / match_ypos of the records: not supported by the batch
+        // kernels -- such lists take the per-pair loop, decided HERE, before anything has been launched for them
+        if (!pairs[i].d_sift2) { batch = false; break; }
         const uint32_t H = num_hypotheses ? num_hypotheses : (uint32_t)(pairs[i].n1 / 8);
         if (H > 4096u || H < 1u) batch = false;
         if (H > max_H) max_H = H;
@@ -1234,7 +1243,10 @@ int sfm_process_pairs(sfm_ctx *ctx, const float h_K[9], const float h_Kinv[9], c
             if (tail) n2 -= n2 % 32;
             if (n2 == 0) {
                 rc = launch_match_none(c, j.n, s1w);
-                if (rc == SFM_OK) SFM_HIP_TRY(hipMemsetAsync(const_cast<int *>(j.m_idx), 0xFF, (size_t)j.n * 4, c->stream));      // index -1 everywhere
+                if (rc == SFM_OK) {                                               // index -1 everywhere (no early return: the lanes are joined below)
+                    const hipError_t em = hipMemsetAsync(const_cast<int *>(j.m_idx), 0xFF, (size_t)j.n * 4, c->stream);
+                    if (em != hipSuccess) { set_error("hipMemsetAsync failed: %s", hipGetErrorString(em)); rc = SFM_E_HIP; }
+                }
             } else {
                 rc = launch_match(c, j.s1->data, j.n, ldf, j.s2->data, n2, ldf, nullptr, nullptr, const_cast<int *>(j.m_idx), s1w, j.s2);
             }
@@ -1246,11 +1258,9 @@ int sfm_process_pairs(sfm_ctx *ctx, const float h_K[9], const float h_Kinv[9], c
             if (e2 != hipSuccess && rc == SFM_OK) { set_error("lane join failed: %s", hipGetErrorString(e2)); rc = SFM_E_HIP; }
         }
         if (rc != SFM_OK) { (void)hipStreamSynchronize(ctx->stream); return rc; }
-        // already matched pairs (no second view given) read match_xpos / match_ypos of the records: not supported by the
-        // batch kernels -- such lists take the per-pair loop (checked here so that nothing has been launched for them yet)
-        bool all_matched_here = true;
-        for (const PairJob &j : jobs) if (!j.s2) all_matched_here = false;
-        if (all_matched_here) {
+        {
+            // the rest of the chain for ALL pairs of the call: fill_xu_pairs | ransac_pairs_solve + ransac_fused_pairs |
+            // choose_pose_pairs + triangulate_pairs -- five launches
             rc = launch_fill_xu_pairs(ctx, d_jobs, (int)jobs.size(), max_ld, h_Kinv);
             // eight blocks of eight wavefronts per pair: each stages the pair's points once and runs its share of the batches
             const int bpp = (int)std::min<uint32_t>(8u, (max_H + 7u) / 8u);
@@ -1258,8 +1268,8 @@ int sfm_process_pairs(sfm_ctx *ctx, const float h_K[9], const float h_Kinv[9], c
             if (rc == SFM_OK) rc = launch_finalize_pose_pairs(ctx, d_jobs, (int)jobs.size(), max_nn);
             if (rc != SFM_OK) { (void)hipStreamSynchronize(ctx->stream); return rc; }
             batched_done = true;
+            ctx->last_pairs_batched = 1;
         }
-        // (fall through to the per-pair loop: the matches it repeats are idempotent)
     }
     if (!batched_done) {
     // per pair: MatchSiftData (optional) -> fillXU -> estimateE -> pose candidates -> choosePose -> linear triangulation
@@ -1318,6 +1328,13 @@ int sfm_process_pairs(sfm_ctx *ctx, const float h_K[9], const float h_Kinv[9], c
     return h_status ? SFM_OK : worst;
 }
 
+int sfm_ctx_last_pairs_batched(sfm_ctx *ctx, int *batched)
+{
+    SFM_REQUIRE(ctx && batched, SFM_E_INVALID, "null argument");
+    *batched = ctx->last_pairs_batched;
+    return SFM_OK;
+}
+
 int sfm_ransac_last_clock(sfm_pair *pair, double *shader_mhz)
 {
     SFM_REQUIRE(pair && shader_mhz, SFM_E_INVALID, "null argument");
@@ -1328,6 +1345,7 @@ int sfm_ransac_last_clock(sfm_pair *pair, double *shader_mhz)
     return SFM_OK;
 }
 
+#if SFM_AB
 int sfm_ransac_last_phases(sfm_pair *pair, uint64_t ticks[8])
 {
     SFM_REQUIRE(pair && ticks, SFM_E_INVALID, "null argument");
@@ -1369,6 +1387,7 @@ int sfm_prefilter_probe(sfm_ctx *ctx, const float h_E[9], float threshold, float
     (void)hipFree(d);
     return rc;
 }
+#endif
 
 int sfm_ransac_last_launch(sfm_pair *pair, int *kernel, int *grid, int *block, int *lds_bytes)
 {

@@ -5,6 +5,18 @@
 #include <stddef.h>
 #include <string>
 #include "../../include/sfm_amd.h"
+#if SFM_AB
+#include "../../include/sfm_amd_ab.h"
+#endif
+
+// A/B switches (sfm_ransac_params.reserved[]): read only by the lab-bench flavour of the library (make ab, -DSFM_AB=1).  In the
+// product build they fold to 0 -- the variants they select are not compiled in -- and resolve_shard() (abi.hip) refuses
+// non-zero values with SFM_E_INVALID.
+#if SFM_AB
+#define SFM_SW(p, i) ((p).reserved[i])
+#else
+#define SFM_SW(p, i) 0
+#endif
 
 namespace sfm {
 
@@ -54,6 +66,7 @@ struct sfm_ctx {
     size_t match_pf_ws_bytes = 0;
     int match_kernel = 0;              // SFM_MATCH_AUTO / _EXACT / _PREFILTER / _FUSED (sfm_ctx_set_match_kernel)
     int last_match_kernel = 0;         // what the last sfm_match / sfm_match_soa call ran
+    int last_pairs_batched = 0;        // the last sfm_process_pairs call took the batched path (sfm_ctx_last_pairs_batched)
     void *homo_ws = nullptr;           // homography RANSAC scratch
     size_t homo_ws_bytes = 0;
     void *sift_temp = nullptr;         // pyramid + DoG planes when the caller passes no temp memory
@@ -174,10 +187,13 @@ int launch_score_prefilter(sfm_pair *pair, const sfm_ransac_params &p, uint32_t 
 int launch_pf_prep(sfm_pair *pair, const sfm_ransac_params &p, uint32_t count);
 int launch_pf_cells(sfm_pair *pair);                                            // the pair's cell table, (re)built when the points changed        // PfRecords from d_Ecand (paths whose solve kernel does not write them)
 int prefilter_tiles(const sfm_pair *pair);
-// ransac_prefilter_r2.hip (the round-2 kernel, A/B only: sfm_ransac_params.reserved[3] == 2)
+#if SFM_AB
+// ab/ransac_prefilter_r2.hip (the round-2 kernel: sfm_ransac_params.reserved[3] == 2)
 int launch_score_prefilter_r2(sfm_pair *pair, const sfm_ransac_params &p, uint32_t h0, uint32_t count, unsigned long long *key2);
-// ransac_mfma.hip
+// ab/ransac_mfma.hip (SFM_KERNEL_MFMA: E.X on the f32 matrix cores, measured slower)
 int launch_score_mfma(sfm_pair *pair, const sfm_ransac_params &p, uint32_t h0, uint32_t count);
+int launch_prefilter_probe(sfm_ctx *ctx, const float *d_E, float thr, float B, const float pt[4], int survive_all, float *d_out);
+#endif
 // ransac_fused.hip
 int launch_ransac_fused(sfm_pair *pair, const sfm_ransac_params &p, uint32_t h0, uint32_t count);
 int launch_finalize_block(sfm_pair *pair, const sfm_ransac_params &p, const unsigned long long *d_key, uint32_t hyp_host, bool from_key,
@@ -191,7 +207,6 @@ int launch_choose_pose(sfm_pair *pair, int mode);
 int launch_triangulate(sfm_pair *pair, int mode);
 int launch_points_to_vbo(sfm_pair *pair, float *d_positions, float *d_velocities, float scale);
 int launch_pair_record(sfm_pair *pair, int mode, float *d_record);
-int launch_prefilter_probe(sfm_ctx *ctx, const float *d_E, float thr, float B, const float pt[4], int survive_all, float *d_out);
 int launch_pose_chain(sfm_pair *pair, float *d_record);          // REFERENCE mode: candidates + choosePose + triangulation (+ record) in one launch
 
 // sift.hip

@@ -422,6 +422,8 @@ int launch_match_fused(sfm_ctx *ctx, const float *d1, int n1, int ld1, const flo
 int launch_match_fused_jobs(sfm_ctx *ctx, const float *d1, int n1, int ld1, MatchJob *h_jobs, int njobs)
 {
     if (n1 <= 0 || njobs <= 0) return SFM_OK;
+    for (int j = 0; j < njobs; ++j)                        // list entries pack the row into 27 bits, as in launch_match_fused
+        SFM_REQUIRE(h_jobs[j].ndb <= (int)kMfRowMask, SFM_E_INVALID, "SFM_MATCH_FUSED holds 27 bits of row index: job %d has %d rows (use SFM_MATCH_AUTO)", j, h_jobs[j].ndb);
     const int qblocks = (n1 + kMfQ - 1) / kMfQ;
     const MatchJob *d_jobs = nullptr;
     int max_split = 1;
@@ -435,6 +437,6 @@ int launch_match_fused_jobs(sfm_ctx *ctx, const float *d1, int n1, int ld1, Matc
 
 } // namespace sfm
 #ifdef SFM_MF_TRACE
-extern "C" int sfm_debug_mf(unsigned long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(sfm::mf_dbg), sizeof(sfm::mf_dbg)); }
+extern "C" __attribute__((visibility("default"))) int sfm_debug_mf(unsigned long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(sfm::mf_dbg), sizeof(sfm::mf_dbg)); }
 #endif
 

@@ -36,6 +36,7 @@ __device__ __forceinline__ void reset_keys(unsigned long long *key, unsigned lon
     }
 }
 
+#if SFM_AB          // the generic one-hypothesis-per-lane kernel (either solver): reserved[0] == 1; the product runs lanes1_qr / lanes2
 __global__ __launch_bounds__(64)
 void ransac_solve_lanes(const float *__restrict__ X0, const float *__restrict__ X1, int ld, int n,
                         const int32_t *__restrict__ indices, uint32_t seed, uint32_t h0, uint32_t count,
@@ -52,6 +53,7 @@ void ransac_solve_lanes(const float *__restrict__ X0, const float *__restrict__ 
 #pragma unroll
     for (int k = 0; k < 9; ++k) Ecand[9 * (size_t)i + k] = E[k];
 }
+#endif
 
 // One hypothesis per lane, Householder solver only (the scalar instantiation of the same templates: bit-identical).  Half the
 // registers of the packed kernel below, so twice the hypotheses are in flight per SIMD and every wavefront walks a chain of plain
@@ -308,8 +310,8 @@ static int launch_score_t(sfm_pair *pair, uint32_t h0, uint32_t count, float thr
 // Householder solve: one hypothesis per lane (64 VGPRs, eight wavefronts per SIMD) whenever the points are available as 16-byte
 // records, and up to this many hypotheses otherwise; two per lane (packed) for large generic-z shards.  Measured
 // (profiles/r02_solve_lanes_ab.txt, 4096 points, us per launch at 4096 / 131072 / 2^20 hypotheses): packed + scattered gathers
-// 18.7 / 33.8 / 139, packed + records 17.5 / 27.2 / 96.8, scalar + records 12.5 / 23.2 / 93.7.  reserved[0]: 2 = packed,
-// 3 = scalar, 4 = scattered gathers (A/B).
+// 18.7 / 33.8 / 139, packed + records 17.5 / 27.2 / 96.8, scalar + records 12.5 / 23.2 / 93.7.  AB build, reserved[0]: 2 = packed,
+// 3 = scalar, 4 = scattered gathers.
 constexpr uint32_t kScalarSolveMax = 262144u;
 
 int launch_ransac_score(sfm_pair *pair, const sfm_ransac_params &p, uint32_t h0, uint32_t count, unsigned long long *key2, const float *d_E_given)
@@ -339,12 +341,14 @@ int launch_ransac_score(sfm_pair *pair, const sfm_ransac_params &p, uint32_t h0,
     const uint32_t fused_max = p.jacobi_sweeps > 0 ? 4096u : 1024u;
     int kernel = p.kernel == SFM_KERNEL_AUTO ? (count <= fused_max ? SFM_KERNEL_FUSED : SFM_KERNEL_SPLIT) : p.kernel;
     if (d_E_given && kernel == SFM_KERNEL_FUSED) kernel = SFM_KERNEL_SPLIT;
+    #if SFM_AB
     if (kernel == SFM_KERNEL_MFMA && pair->n >= 65536) kernel = SFM_KERNEL_SPLIT;   // its packed counters are 16-bit
+#endif
     // matrix-core pre-filter in front of the exact test (ransac_prefilter.hip): AUTO takes it whenever it applies
     // (unit-z points, threshold inside the fp16 scaling range, enough hypotheses); asked for explicitly where it does
     // not apply, the call runs the plain wavefront kernel instead (sfm_ransac_last_launch reports which one ran)
     if (kernel == SFM_KERNEL_PREFILTER && !prefilter_usable(pair, p, 0x40000000u)) kernel = SFM_KERNEL_SPLIT;     // asked for explicitly: any size
-    if (p.kernel == SFM_KERNEL_AUTO && kernel == SFM_KERNEL_SPLIT && prefilter_usable(pair, p, count) && p.reserved[3] != 1) kernel = SFM_KERNEL_PREFILTER;
+    if (p.kernel == SFM_KERNEL_AUTO && kernel == SFM_KERNEL_SPLIT && prefilter_usable(pair, p, count) && SFM_SW(p, 3) != 1) kernel = SFM_KERNEL_PREFILTER;
     pair->last_kernel = kernel;
     if (kernel == SFM_KERNEL_FUSED) {
         rc = launch_ransac_fused(pair, p, h0, count);
@@ -364,19 +368,19 @@ int launch_ransac_score(sfm_pair *pair, const sfm_ransac_params &p, uint32_t h0,
     const int nh = (wpb == 16 && count >= 8192u) ? 2 : 1;         // at 4096 hypotheses two per wavefront leave CUs without a block
     const uint32_t nbatch = (count + wpb * nh - 1) / (wpb * nh);
     // more than one tile: one tile per block (blockIdx.y), partial counts through atomics, keys from ransac_argmax_counts
-    // (p.reserved[1] == 1 keeps the tile loop inside the block: the A/B switch of profiles/pipeline_bench.py)
-    const bool grid2d = ntiles > 1 && kernel == SFM_KERNEL_SPLIT && wpb == 16 && p.reserved[1] != 1;
+    // (AB build, reserved[1] == 1: the tile loop stays inside the block -- the A/B switch of profiles/pipeline_bench.py)
+    const bool grid2d = ntiles > 1 && kernel == SFM_KERNEL_SPLIT && wpb == 16 && SFM_SW(p, 1) != 1;
     const bool prefilter = kernel == SFM_KERNEL_PREFILTER;
 
     const bool timed = ctx->timing && ctx->tcount < sfm_ctx::kTimingSlots;
     hipEvent_t *tev = timed ? ctx->tev[ctx->tcount] : nullptr;
     if (timed) SFM_HIP_TRY(hipEventRecord(tev[0], ctx->stream));
     int *zero_counts = (grid2d || prefilter) ? pair->d_counts : nullptr;
-    const float4 *pts4 = (pair->have_pts4 && p.reserved[0] != 4) ? pair->d_pts4 : nullptr;      // (reserved[0] == 4: scattered gathers, A/B)
+    const float4 *pts4 = (pair->have_pts4 && SFM_SW(p, 0) != 4) ? pair->d_pts4 : nullptr;      // (AB build, reserved[0] == 4: scattered gathers)
     // pre-filter kernel: tickets (one per 32-hypothesis group), cleared by the solve kernel's first threads (or by a memset
     // when there are fewer threads than words); its per-hypothesis records come from the lane-solve kernel itself on the
     // default path, from pf_prep_kernel otherwise
-    const bool pf_r2 = prefilter && p.reserved[3] == 2;                   // the round-2 kernel (A/B): builds its operands itself
+    const bool pf_r2 = prefilter && SFM_SW(p, 3) == 2;                   // (AB build) the round-2 kernel: builds its operands itself
     const uint32_t nzero = prefilter ? (count + (uint32_t)kPfGroup - 1u) / (uint32_t)kPfGroup : 0u;
     uint32_t *zero_ticks = prefilter ? pair->d_tick : nullptr;
     if (prefilter && (d_E_given || nzero > count / 2u)) {
@@ -394,12 +398,14 @@ int launch_ransac_score(sfm_pair *pair, const sfm_ransac_params &p, uint32_t h0,
         SFM_HIP_TRY(hipMemcpyAsync(pair->d_Ecand, d_E_given, (size_t)count * 9 * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
         if (zero_counts) SFM_HIP_TRY(hipMemsetAsync(pair->d_counts, 0, (size_t)count * sizeof(int), ctx->stream));
     }
+#if SFM_AB
     else if (p.reserved[0] == 1)     // A/B switch: one hypothesis per lane (scalar math)
         hipLaunchKernelGGL(ransac_solve_lanes, dim3((count + 63) / 64), dim3(64), 0, ctx->stream,
                            pair->d_X[0], pair->d_X[1], pair->ld, pair->n, p.d_indices, p.seed, h0, count,
                            p.jacobi_sweeps, pair->d_Ecand, pair->d_key, key2, zero_counts, zero_ticks, nzero);
-    else if (p.jacobi_sweeps <= 0 && (p.reserved[0] == 3 || (p.reserved[0] == 0 && (pts4 != nullptr || count <= kScalarSolveMax)))) {     // one hypothesis per lane
-        const bool fuse = need_prep && p.reserved[3] != 3;                // (reserved[3] == 3: records from the stand-alone kernel, A/B)
+#endif
+    else if (p.jacobi_sweeps <= 0 && (SFM_SW(p, 0) == 3 || (SFM_SW(p, 0) == 0 && (pts4 != nullptr || count <= kScalarSolveMax)))) {     // one hypothesis per lane
+        const bool fuse = need_prep && SFM_SW(p, 3) != 3;                // (AB build, reserved[3] == 3: records from the stand-alone kernel)
         hipLaunchKernelGGL(ransac_solve_lanes1_qr, dim3((count + 63) / 64), dim3(64), 0, ctx->stream,
                            pair->d_X[0], pair->d_X[1], pair->ld, pair->n, p.d_indices, p.seed, h0, count,
                            p.jacobi_sweeps, pair->d_Ecand, pair->d_key, key2, zero_counts, zero_ticks, nzero, pts4,
@@ -431,7 +437,7 @@ int launch_ransac_score(sfm_pair *pair, const sfm_ransac_params &p, uint32_t h0,
     if (per_cu > 2048 / (wpb * 64)) per_cu = 2048 / (wpb * 64);
     if (per_cu < 1) per_cu = 1;
     const uint32_t resident = (uint32_t)ctx->num_cus * (uint32_t)per_cu;
-    const uint32_t min_batches = p.reserved[2] > 0 ? (uint32_t)p.reserved[2] : 8u;
+    const uint32_t min_batches = SFM_SW(p, 2) > 0 ? (uint32_t)SFM_SW(p, 2) : 8u;
     uint32_t blocks = nbatch / min_batches;
     if (blocks > 16u * (uint32_t)ctx->num_cus) blocks = 16u * (uint32_t)ctx->num_cus;
     if (blocks < resident) blocks = resident;
@@ -441,13 +447,18 @@ int launch_ransac_score(sfm_pair *pair, const sfm_ransac_params &p, uint32_t h0,
         if ((uint32_t)grid > nbatch) grid = (int)nbatch;
     }
     if (prefilter) {
-        rc = pf_r2 ? launch_score_prefilter_r2(pair, p, h0, count, key2)
-                   : launch_score_prefilter(pair, p, h0, count, key2);      // arg-max included (per-group tickets)
+#if SFM_AB
+        if (pf_r2) rc = launch_score_prefilter_r2(pair, p, h0, count, key2);
+        else
+#endif
+        rc = launch_score_prefilter(pair, p, h0, count, key2);      // arg-max included (per-group tickets)
     }
+#if SFM_AB
     else if (kernel == SFM_KERNEL_MFMA) {
         rc = launch_score_mfma(pair, p, h0, count);
         if (rc == SFM_OK && key2) SFM_HIP_TRY(hipMemcpyAsync(key2, pair->d_key, sizeof(unsigned long long), hipMemcpyDeviceToDevice, ctx->stream));
     }
+#endif
     else if (grid2d) {
         rc = uz ? (nh == 2 ? launch_score_t<16, true, 2, true>(pair, h0, count, p.threshold, tile, ntiles, grid, lds, key2)
                            : launch_score_t<16, true, 1, true>(pair, h0, count, p.threshold, tile, ntiles, grid, lds, key2))

@@ -312,6 +312,7 @@ int launch_fused_pairs(sfm_ctx *ctx, const PairJob *d_jobs, int njobs, int block
     const int rc_lds = allow_big_lds(ctx, reinterpret_cast<const void *>(&ransac_fused_pairs));
     if (rc_lds != SFM_OK) return rc_lds;
     hipLaunchKernelGGL(ransac_pairs_solve, dim3((max_H + 63u) / 64u, njobs), dim3(64), 0, ctx->stream, d_jobs);
+    SFM_HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(ransac_fused_pairs, dim3(blocks_per_pair, njobs), dim3(8 * 64), lds, ctx->stream, d_jobs);
     SFM_HIP_TRY(hipGetLastError());
     return SFM_OK;

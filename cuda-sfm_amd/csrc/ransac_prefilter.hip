@@ -142,7 +142,8 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
     const bool probe = clk && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0;
     unsigned long long c0 = 0, w0 = 0;
     if (probe) { c0 = clock64(); w0 = wall_clock64(); }
-    // trace (sfm_ransac_last_trace): start / end stamps of every block and wavefront, a handful of stores per block
+#if SFM_AB
+    // trace (sfm_ransac_last_trace, AB build): start / end stamps of every block and wavefront, a handful of stores per block
     const uint32_t trace_blk = blockIdx.y * gridDim.x + blockIdx.x;
     unsigned long long *trace = (clk && trace_blk < (uint32_t)kTraceBlocks) ? clk + 8 + (size_t)trace_blk * kTraceWords : nullptr;
     if (trace && threadIdx.x == 0) {
@@ -151,6 +152,10 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
                    (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));             // HW_REG_HW_ID
         trace[3] = ((unsigned long long)blockIdx.y << 32) | blockIdx.x;
     }
+#define PF_PHASE(k) do { if (probe1) clk[k] = wall_clock64() - w0; } while (0)
+#else
+#define PF_PHASE(k) do { } while (0)
+#endif
     const int half = lane >> 5, row = lane & 31;
     const uint32_t npass = (count + (uint32_t)kPfGroup - 1u) / (uint32_t)kPfGroup;
     const uint32_t nstatic = gridDim.x * (uint32_t)W;             // passes handed out by position
@@ -230,7 +235,9 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
         }
     }
     __syncthreads();
+#if SFM_AB
     if (probe) clk[2] = wall_clock64() - w0;
+#endif
     const int npb = (min(kPfTile, ld - tile_first) + 31) >> 5;           // 32-point blocks that hold points or padding
     const int npp = (npb + 1) >> 1;                                      // two 32-point blocks per iteration (a block beyond npb holds padding only: all rejected)
     const int last_pb = kPfTile / 32 - 1;
@@ -246,7 +253,9 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
     while (have) {
         const uint32_t h_first = ps * (uint32_t)kPfGroup;
         const int nvalid = (int)min((uint32_t)kPfGroup, count - h_first);
+#if SFM_AB
         const bool probe1 = probe && passes_done == 0u;
+#endif
         // the next pass of this wavefront: asked for now, needed when this one is done
         uint32_t ps_next = ps + nstatic;
         if (dynamic) {
@@ -281,7 +290,7 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
                 if (half) { afrag.n1[3] = (_Float16)1.0f; afrag.t[7] = (_Float16)0.0009765625f; }      // k-slots 27 and 15
             }
         }
-        if (probe1) clk[3] = wall_clock64() - w0;
+        PF_PHASE(3);
 
         // ---- the scan: two accumulator sets; while set A is scanned the MFMAs of the next step fill set B
         int head = 0, nq = 0;                       // ring state (wave-uniform)
@@ -348,7 +357,7 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
                 nq += __builtin_popcountll(any);
             }
         }
-        if (probe1) clk[4] = wall_clock64() - w0;
+        PF_PHASE(4);
         // the next pass' operands: requested now, they arrive while the ring is drained and the counts go out
         const bool have_next = ps_next < npass;
         PfFrags afrag_next = afrag;
@@ -387,7 +396,7 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
                 if (best_key2) atomicMax(best_key2, k);
             }
         }
-        if (probe1) clk[5] = wall_clock64() - w0;
+        PF_PHASE(5);
         ++passes_done;
         // install the next pass
         have = have_next;
@@ -398,11 +407,13 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
         }
     }
     if (probe) { clk[6] = passes_done; clk[0] = clock64() - c0; clk[1] = wall_clock64() - w0; }
+#if SFM_AB
     if (trace && lane == 0) {
         const unsigned long long tend = wall_clock64();
         trace[4 + wave] = tend;
         if (wave == 0) trace[1] = tend;
     }
+#endif
 }
 
 // ---- the pair's table of occupied grid cells (prefilter_math.hpp (3)) ----------------------------------------------------
@@ -483,6 +494,7 @@ int launch_pf_prep(sfm_pair *pair, const sfm_ransac_params &p, uint32_t count)
     return SFM_OK;
 }
 
+#if SFM_AB
 // Test probe (sfm_prefilter_probe): the operands of ONE (hypothesis, point) pair exactly as the kernels above build them on
 // the device, and what the matrix cores return for them.  out: ns[32] | ts[16] | bn[32] | bt[16] | nt | G | rejected |
 // zero-divisor state (0 cleared, 1 cells to look up, 2 scan).  tests/test_gpu_prefilter.py compares it with the host build
@@ -550,6 +562,7 @@ int launch_prefilter_probe(sfm_ctx *ctx, const float *d_E, float thr, float B, c
     SFM_HIP_TRY(hipGetLastError());
     return SFM_OK;
 }
+#endif
 
 // Conditions under which launch_ransac_score may pick this kernel: the unit-z layout (every z exactly 1) written by fillXU
 // (which also leaves the bound over all points), a threshold the fp16 scaling covers, and enough work to fill the chip with
@@ -569,11 +582,15 @@ int launch_score_prefilter(sfm_pair *pair, const sfm_ransac_params &p, uint32_t 
     sfm_ctx *ctx = pair->ctx;
     PfScales sc;
     if (!prefilter_scales(p.threshold, sc)) { set_error("threshold %g outside the pre-filter's range", (double)p.threshold); return SFM_E_INVALID; }
-    // wavefronts per block: 16 (four per SIMD, all 512 vector registers of a SIMD) by default; reserved[1] == 5 runs 12 -- three
+    // wavefronts per block: 16 (four per SIMD, all 512 vector registers of a SIMD) by default; AB build, reserved[1] == 5 runs 12 -- three
     // per SIMD, which leaves a quarter of the registers to the lane-solve kernel of the NEXT step when steps are pipelined
     // on two streams (profiles/r03_waves_ab.txt)
-    const int waves = p.reserved[1] == 5 ? 12 : kPfWaves;
+    const int waves = SFM_SW(p, 1) == 5 ? 12 : kPfWaves;
+#if SFM_AB
     const void *fn = waves == 12 ? reinterpret_cast<const void *>(&ransac_score_prefilter<12>) : reinterpret_cast<const void *>(&ransac_score_prefilter<16>);
+#else
+    const void *fn = reinterpret_cast<const void *>(&ransac_score_prefilter<16>);
+#endif
     const int rc_lds = allow_big_lds(ctx, fn);
     if (rc_lds != SFM_OK) return rc_lds;
     const int ntiles = prefilter_tiles(pair);
@@ -583,15 +600,17 @@ int launch_score_prefilter(sfm_pair *pair, const sfm_ransac_params &p, uint32_t 
     // than that gives columns for, two blocks per CU queue up (16 tiles: 2.27 against 2.31 ms at 2^20 hypotheses, round 2)
     const uint32_t per_cu = ntiles <= 4 ? 1u : 2u;
     uint32_t cols = (per_cu * (uint32_t)ctx->num_cus + (uint32_t)ntiles - 1) / (uint32_t)ntiles;
-    if (p.reserved[2] > 0) cols = (uint32_t)p.reserved[2];
+    if (SFM_SW(p, 2) > 0) cols = (uint32_t)SFM_SW(p, 2);
     if (cols > iters) cols = iters;
     if (cols < 1) cols = 1;
-    const int dynamic = p.reserved[1] == 2 ? 0 : 1;                               // (reserved[1] == 2: static striding, A/B)
+    const int dynamic = SFM_SW(p, 1) == 2 ? 0 : 1;                               // (AB build, reserved[1] == 2: static striding)
+#if SFM_AB
     if (waves == 12)
         hipLaunchKernelGGL(ransac_score_prefilter<12>, dim3(cols, ntiles), dim3(12 * 64), kPfLdsBytes, ctx->stream,
                            pair->d_X[0], pair->d_X[1], pair->ld, pair->n, pair->d_Ecand, reinterpret_cast<const PfRecord *>(pair->d_pf), h0, count, p.threshold,
                            dynamic, pair->d_counts, pair->d_tick, pair->d_key, key2, pair->d_clk);
     else
+#endif
         hipLaunchKernelGGL(ransac_score_prefilter<16>, dim3(cols, ntiles), dim3(16 * 64), kPfLdsBytes, ctx->stream,
                            pair->d_X[0], pair->d_X[1], pair->ld, pair->n, pair->d_Ecand, reinterpret_cast<const PfRecord *>(pair->d_pf), h0, count, p.threshold,
                            dynamic, pair->d_counts, pair->d_tick, pair->d_key, key2, pair->d_clk);

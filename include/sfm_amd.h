@@ -27,8 +27,12 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* the library is built with -fvisibility=hidden: only what this header declares is exported */
+#pragma GCC visibility push(default)
 
-#define SFM_ABI_VERSION 1
+/* 1: rounds 1-3.  2: sfm_ransac_params.reserved[] must be zero, kernel id 3 and the probe / trace hooks moved to the lab-bench
+ * flavour (include/sfm_amd_ab.h, libsfm_amd_ab.so); sfm_ctx_last_pairs_batched, sfm_exchange_* added. */
+#define SFM_ABI_VERSION 2
 
 #define SFM_OK           0
 #define SFM_E_INVALID   (-1)   /* bad argument                                     */
@@ -182,7 +186,7 @@ int sfm_set_points(sfm_pair *pair, const float *d_X0, const float *d_X1);
 #define SFM_KERNEL_AUTO   0
 #define SFM_KERNEL_SPLIT  1   /* solve: one hypothesis per lane; score: one hypothesis per wavefront */
 #define SFM_KERNEL_FUSED  2   /* everything one hypothesis per wavefront in LDS                      */
-#define SFM_KERNEL_MFMA   3   /* lane solve; scoring: 32 hypotheses per wavefront, E.X on the matrix cores */
+                              /* 3: not in this library (a recorded A/B variant, include/sfm_amd_ab.h) -> SFM_E_INVALID */
 #define SFM_KERNEL_PREFILTER 4 /* lane solve; scoring: fp16-split matrix-core pre-filter (32 hypotheses x 32 points per  */
                               /* MFMA tile) rejects the pairs that cannot be inliers, the exact test runs on the rest; */
                               /* needs z == 1 points (fillXU) and 1e-9 <= threshold <= 1e-2, else SFM_KERNEL_SPLIT runs */
@@ -197,11 +201,7 @@ typedef struct sfm_ransac_params {
     int32_t  jacobi_sweeps;   /* null vector of the 8x9 system: 0 (default) = Householder QR of A^T;       */
                               /* k > 0 = normal equations A^T A + k sweeps of 9x9 Jacobi (7 converges)    */
     int32_t  kernel;          /* SFM_KERNEL_*                                                           */
-    int32_t  reserved[4];     /* 0 = defaults.  A/B switches of profiles/: [0] = 1 one hypothesis per lane in the solve kernel,   */
-                              /* = 2 packed FP32 in the pre-filter scan;                                                          */
-                              /* [1] = 1 tile loop inside the scoring block instead of the tile-parallel grid (n > 4096);         */
-                              /* [2] = k > 0 minimum hypothesis batches per scoring block (default 8; pre-filter: grid columns);   */
-                              /* [3] = 1 AUTO never picks SFM_KERNEL_PREFILTER                                                    */
+    int32_t  reserved[4];     /* must be zero (anything else: SFM_E_INVALID)                            */
 } sfm_ransac_params;
 
 void sfm_ransac_default_params(sfm_ransac_params *p, int num_points);
@@ -324,8 +324,10 @@ int sfm_extract_views_u8(sfm_ctx *ctx, const unsigned char *const *h_images, int
  * is NULL a singular pose makes the call return SFM_E_SINGULAR.  Synchronous at the end.
  * With SFM_POSE_REFERENCE, a K^-1 whose last row is (0 0 1) and at most 4096 hypotheses per pair the call is batched:
  * consecutive pairs that share their first view go through ONE matcher launch, fillXU / estimateE / choosePose /
- * triangulation are four launches for ALL owned pairs (same arithmetic, bit-identical records); the environment variable
- * SFM_PAIRS_UNBATCHED selects the per-pair loop (A/B runs, tests). */
+ * triangulation are five launches for ALL owned pairs (fill_xu_pairs, ransac_pairs_solve, ransac_fused_pairs, choose_pose_pairs,
+ * triangulate_pairs: same arithmetic, bit-identical records).  A list that holds an already matched pair (d_sift2 == NULL)
+ * takes the per-pair loop; so does every call while the environment variable SFM_PAIRS_UNBATCHED is set (read on each call;
+ * A/B runs, tests).  sfm_ctx_last_pairs_batched reports which path the last call took. */
 typedef struct sfm_pair_desc {
     sfm_sift_point *d_sift1;        /* features of the first view (match fields are written when d_sift2 != NULL) */
     int n1;
@@ -336,32 +338,18 @@ typedef struct sfm_pair_desc {
 int sfm_process_pairs(sfm_ctx *ctx, const float h_K[9], const float h_Kinv[9], const sfm_pair_desc *pairs, int num_pairs,
                       int first, int stride, uint32_t num_hypotheses, int pose_mode, float *h_records, int *h_status);
 
+int sfm_ctx_last_pairs_batched(sfm_ctx *ctx, int *batched);
+
 /* Image_pair::copyBoidsToVBO (sfm.cu:374-383; kernCopyPositionsToVBO / kernCopyVelocitiesToVBO kernels.h:471-494):
  * interleaved (x, y, z, 1) * scale vertices and the constant (1, 1, 1, 1) colour buffer, written to DEVICE
  * buffers of 4 * num_points floats each (in the reference: the mapped GL buffer objects).  Either may be NULL. */
 int sfm_copy_points_to_vbo(sfm_pair *pair, float *d_positions, float *d_velocities, float scale);
 /* Name and launch geometry of the RANSAC scoring kernel used by the last call (for profiling). */
 int sfm_ransac_last_launch(sfm_pair *pair, int *kernel, int *grid, int *block, int *lds_bytes);
-/* Sustained shader clock (MHz) during the last wavefront-scoring launch (SFM_KERNEL_SPLIT): shader-clock ticks over
+/* Sustained shader clock (MHz) during the last scoring launch (SFM_KERNEL_SPLIT / _PREFILTER): shader-clock ticks over
  * 100 MHz ticks across the lifetime of its first block; 0 if that kernel has not run.  Synchronises. */
 int sfm_ransac_last_clock(sfm_pair *pair, double *shader_mhz);
-/* Where block 0 of the last pre-filter scoring launch (SFM_KERNEL_PREFILTER) spent its time: ticks[0] shader-clock ticks and
- * ticks[1] 100 MHz ticks over its lifetime (as above); 100 MHz ticks since its start at: [2] tile staged, [3] first pass'
- * coefficients prepared, [4] first 32-hypothesis block scanned and drained, [5] first pass done (counts and ticket out),
- * [6] number of passes wavefront 0 ran.  Zero where the kernel that ran has no such probe.  Synchronises. */
-int sfm_ransac_last_phases(sfm_pair *pair, uint64_t ticks[8]);
-/* Profiling aid: when did every block / wavefront of the last pre-filter scoring launch start and finish?  20 words per
- * block (up to 1024 blocks, in blockIdx.y * gridDim.x + blockIdx.x order): [0] start and [1] end of its first wavefront,
- * [2] (XCC id << 32) | HW_ID, [3] (tile << 32) | column, [4..19] the end of each of its 16 wavefronts -- all in 100 MHz
- * ticks of one device-wide counter.  *count = words written (0 if another kernel ran).  Synchronises. */
-int sfm_ransac_last_trace(sfm_pair *pair, uint64_t *words, size_t capacity, size_t *count);
-/* Test probe of the matrix-core pre-filter (ransac_prefilter.hip): the fp16 operands of ONE (hypothesis, point) pair as the
- * device builds them and what the matrix cores return for them.  h_point = (x1x, x1y, x2x, x2y), bound = the tile's largest
- * |coordinate|.  h_out: coefficient slots ns[32], ts[16] | feature slots bn[32], bt[16] | nt | G | rejected (0/1) |
- * zero-divisor state.  tests/test_gpu_prefilter.py compares them with the host build of the same header.  Synchronises. */
-int sfm_prefilter_probe(sfm_ctx *ctx, const float h_E[9], float threshold, float bound, const float h_point[4], int survive_all,
-                        float h_out[100]);
-
+#pragma GCC visibility pop
 #ifdef __cplusplus
 }
 #endif

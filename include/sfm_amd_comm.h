@@ -19,6 +19,7 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+#pragma GCC visibility push(default)
 
 #define SFM_COMM_ID_BYTES 128                 /* = NCCL_UNIQUE_ID_BYTES */
 typedef struct sfm_comm sfm_comm;
@@ -54,6 +55,7 @@ int sfm_process_views_sharded(sfm_comm *comm, const float h_K[9], const float h_
                               double init_blur, float thresh, float lowest_scale, int scale_up, uint32_t num_hypotheses,
                               int pose_mode, float *h_records, int *h_counts);
 
+#pragma GCC visibility pop
 #ifdef __cplusplus
 }
 #endif

@@ -21,3 +21,13 @@ def gpu():
     import cuda_sfm_amd as S
     ctx = S.Context(0, torch.cuda.current_stream().cuda_stream)
     return torch, torch.device("cuda:0"), ctx
+
+
+@pytest.fixture(scope="session")
+def gpu_ab():
+    """The same for the lab-bench flavour of the library (libsfm_amd_ab.so, tests/test_gpu_ab.py)."""
+    import torch
+    assert torch.cuda.is_available(), "GPU test running without a GPU"
+    import cuda_sfm_amd_ab as A
+    ctx = A.Context(0, torch.cuda.current_stream().cuda_stream)
+    return torch, torch.device("cuda:0"), ctx

@@ -24,8 +24,8 @@ def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     import torch
-    import cuda_sfm_amd as S
-    from cuda_sfm_amd import synth
+    import cuda_sfm_amd_ab as S            # the lab-bench flavour: the fuzz also covers the recorded A/B kernel variants
+    from cuda_sfm_amd_ab import synth
     import oracle as O
     from helpers import same_bits, to_dev
 

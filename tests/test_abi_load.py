@@ -22,7 +22,49 @@ def test_header_symbols_exported():
     missing = [n for n in names if not hasattr(S.lib(), n)]
     assert not missing, missing
     assert sorted(S.EXPORTS) == names
-    assert S.lib().sfm_abi_version() == 1
+    assert S.lib().sfm_abi_version() == 2
+    assert not S.AB and S.LIB_PATH.endswith("libsfm_amd.so")
+
+
+def _nm_exports(path):
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+    return sorted(line.split()[-1] for line in out.splitlines() if line.strip())
+
+
+def test_dynamic_symbol_tables_are_exactly_the_headers():
+    """`nm -D` of the product library lists what include/sfm_amd.h declares and NOTHING else (no kernel stubs, no launchers,
+    no probe hooks: csrc/exports.map + -fvisibility=hidden); the lab-bench flavour adds exactly include/sfm_amd_ab.h; the
+    RCCL library exports exactly include/sfm_amd_comm.h."""
+    import cuda_sfm_amd as S
+    assert _nm_exports(S.LIB_PATH) == declared_symbols()
+    ab_txt = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "sfm_amd_ab.h")).read(), flags=re.S)
+    ab_names = sorted(set(re.findall(r"\b(sfm_[a-z0-9_A-Z]+)\s*\(", ab_txt)))
+    assert ab_names == sorted(S.AB_EXPORTS) and len(ab_names) == 3
+    ab_lib = os.path.join(os.path.dirname(S.LIB_PATH), "libsfm_amd_ab.so")
+    assert _nm_exports(ab_lib) == sorted(declared_symbols() + ab_names)
+    assert _nm_exports(S.COMM_LIB_PATH) == sorted(S.COMM_EXPORTS)
+    for n in ab_names:
+        assert not hasattr(S.lib(), n), n
+
+
+def test_integration_md_documents_every_export():
+    """Every entry point of the product library is named in INTEGRATION.md (section 2: the binding a maintainer writes)."""
+    txt = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    missing = [n for n in declared_symbols() if n not in txt]
+    assert not missing, missing
+    for n in ("sfm_prefilter_probe", "sfm_ransac_last_trace", "sfm_ransac_last_phases"):
+        assert n not in txt or "sfm_amd_ab.h" in txt, n
+
+
+def test_lab_bench_flavour_imports_next_to_the_product():
+    import cuda_sfm_amd as S
+    import cuda_sfm_amd_ab as A
+    assert A.AB and A.LIB_PATH.endswith("libsfm_amd_ab.so") and A.KERNEL_MFMA == 3 and not hasattr(S, "KERNEL_MFMA")
+    assert not [n for n in A.EXPORTS if not hasattr(A.lib(), n)]
+    assert A.lib().sfm_abi_version() == 2
+    with pytest.raises(ImportError):
+        A.comm_lib()                                  # the communicator library is linked against the product
 
 
 def test_comm_header_symbols_exported():
@@ -46,6 +88,47 @@ def test_struct_layouts_match_header():
     assert S.SIFT_DTYPE.fields["score"][1] == 24 and S.SIFT_DTYPE.fields["match"][1] == 32   # cudaSift.h:6-22 offsets
     p = S.default_params(4096)
     assert p.num_hypotheses == 512 and abs(p.threshold - 1e-6) < 1e-12 and p.jacobi_sweeps == 0
+
+
+def test_ctypes_mirrors_equal_sizeof_and_offsetof_of_the_header(tmp_path):
+    """A C program prints sizeof / offsetof of every struct that crosses the boundary (sfm_ransac_params, sfm_sift_point,
+    sfm_pair_desc, sfm_sift_layout); the ctypes / numpy mirrors of the harness must agree field by field."""
+    import subprocess
+    import cuda_sfm_amd as S
+    fields = {
+        "sfm_ransac_params": ["num_hypotheses", "hyp_begin", "hyp_count", "seed", "d_indices", "threshold", "jacobi_sweeps", "kernel", "reserved"],
+        "sfm_sift_point": ["xpos", "ypos", "scale", "sharpness", "edgeness", "orientation", "score", "ambiguity", "match", "match_xpos",
+                           "match_ypos", "match_error", "subsampling", "empty", "data"],
+        "sfm_pair_desc": ["d_sift1", "n1", "d_sift2", "n2"],
+        "sfm_sift_layout": ["num_octaves", "width", "height", "pitch", "image_offset", "dog_offset", "up_offset", "total_floats"],
+    }
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "sfm_amd.h"', 'int main(void) {']
+    for st, fs in fields.items():
+        lines.append(f'  printf("{st} %zu\\n", sizeof({st}));')
+        for f in fs:
+            lines.append(f'  printf("{st}.{f} %zu %zu\\n", offsetof({st}, {f}), sizeof((({st} *)0)->{f}));')
+    lines += ['  return 0;', '}']
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    got = {}
+    for line in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.splitlines():
+        k, *v = line.split()
+        got[k] = tuple(int(x) for x in v)
+    mirrors = {"sfm_ransac_params": S.RansacParams, "sfm_pair_desc": S.PairDesc, "sfm_sift_layout": S.SiftLayout}
+    for st, cls in mirrors.items():
+        assert got[st] == (C.sizeof(cls),), (st, got[st], C.sizeof(cls))
+        assert [f for f, _ in cls._fields_] == fields[st]
+        for f in fields[st]:
+            d = getattr(cls, f)
+            assert got[f"{st}.{f}"] == (d.offset, d.size), (st, f, got[f"{st}.{f}"], d.offset, d.size)
+    assert got["sfm_sift_point"] == (S.SIFT_DTYPE.itemsize,) == (576,)
+    assert list(S.SIFT_DTYPE.names) == fields["sfm_sift_point"]
+    for f in fields["sfm_sift_point"]:
+        dt, off = S.SIFT_DTYPE.fields[f][:2]
+        assert got[f"sfm_sift_point.{f}"] == (off, dt.itemsize), (f, got[f"sfm_sift_point.{f}"], off, dt.itemsize)
 
 
 def test_header_constants_match_the_python_mirror():
@@ -117,7 +200,7 @@ int main(void)
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
     ver, hyps, sweeps, floats = r.stdout.split()
-    assert (int(ver), int(hyps), int(sweeps)) == (1, 512, 0) and int(floats) > 8 * 1920 * 1080
+    assert (int(ver), int(hyps), int(sweeps)) == (2, 512, 0) and int(floats) > 8 * 1920 * 1080
 
 
 def test_comm_library_argument_and_lifecycle_paths_without_a_gpu():

@@ -1,0 +1,215 @@
+"""GPU tests of the LAB-BENCH flavour of the library (libsfm_amd_ab.so = the product's sources built with -DSFM_AB=1,
+include/sfm_amd_ab.h): the A/B switches behind sfm_ransac_params.reserved[], the recorded slower kernel variants (f32
+matrix-core scoring, the round-2 pre-filter kernel, the generic lane-solve kernel) and the probe hook -- each against the
+oracle, like the product's kernels.  And the other side of the split: the PRODUCT library refuses all of it."""
+import numpy as np
+import pytest
+
+import cuda_sfm_amd as PROD
+import cuda_sfm_amd_ab as S
+from cuda_sfm_amd_ab import synth
+import oracle as O
+from helpers import same_bits, to_dev, make_pair
+import test_gpu_prefilter as P
+import test_gpu_ransac as R
+
+pytestmark = pytest.mark.gpu
+
+
+def test_flavours():
+    assert S.AB and not PROD.AB and S.LIB_PATH != PROD.LIB_PATH
+    assert S.lib().sfm_abi_version() == PROD.lib().sfm_abi_version() == 2
+    for name in S.AB_EXPORTS:
+        assert hasattr(S.lib(), name) and not hasattr(PROD.lib(), name), name
+
+
+def test_product_library_refuses_the_switches(gpu):
+    """libsfm_amd.so: non-zero reserved[] and kernel id 3 are SFM_E_INVALID -- before anything is launched."""
+    n = 256
+    scene = synth.two_view_scene(n, seed=1)
+    pair, _ = make_pair(PROD, gpu, scene)
+    for i in range(4):
+        p = PROD.default_params(n, num_hypotheses=64)
+        p.reserved[i] = 1
+        with pytest.raises(PROD.SfmError) as e:
+            pair.estimateE(p)
+        assert e.value.code == PROD.E_INVALID and "reserved" in str(e.value)
+        with pytest.raises(PROD.SfmError):
+            pair.ransac_score(p)
+    p = PROD.default_params(n, num_hypotheses=64, kernel=3)
+    with pytest.raises(PROD.SfmError) as e:
+        pair.estimateE(p)
+    assert e.value.code == PROD.E_INVALID
+    pair.estimateE(PROD.default_params(n, num_hypotheses=64))           # and the pair is still usable
+    assert pair.get_best()[1] > 0
+
+
+@pytest.mark.parametrize("sweeps", [0, 7])
+@pytest.mark.parametrize("n,H", [(64, 50), (1000, 300), (4096, 2048), (4500, 600), (9000, 100), (129, 65), (511, 8193)])
+def test_mfma_scoring_counts_winner_mask_E(gpu_ab, n, H, sweeps):
+    """SFM_KERNEL_MFMA (csrc/ab/ransac_mfma.hip): E.X on the f32 matrix cores, every count / key / E / mask against the oracle."""
+    scene = synth.two_view_scene(n, seed=5 + n)
+    pair, _ = make_pair(S, gpu_ab, scene)
+    p = S.default_params(n, num_hypotheses=H, seed=77, kernel=S.KERNEL_MFMA, jacobi_sweeps=sweeps)
+    pair.estimateE(p)
+    assert pair.last_launch()["kernel"] == S.KERNEL_MFMA
+    _, _, X0, X1 = O.fill_xu(scene["sift"], scene["Kinv"])
+    key, ocounts, oE = O.ransac_range(X0, X1, 0, H, p.threshold, sweeps, seed=77, want_E=True)
+    assert np.array_equal(pair.get_inlier_counts(H), ocounts) and pair.get_key() == key
+    ocnt, ohyp = O.unpack_key(key)
+    assert same_bits(pair.get_E(), oE[ohyp].reshape(3, 3))
+    assert np.array_equal(pair.get_inlier_mask(), O.count_inliers(oE[ohyp], X0, X1, p.threshold)[1])
+
+
+def test_mfma_score_into_leaves_the_key_in_caller_memory(gpu_ab):
+    torch, dev, ctx = gpu_ab
+    n, H = 1200, 2000
+    scene = synth.two_view_scene(n, seed=71)
+    pair, _ = make_pair(S, gpu_ab, scene)
+    p = S.default_params(n, num_hypotheses=H, seed=4, kernel=S.KERNEL_MFMA)
+    pair.ransac_score(p)
+    want = pair.get_key()
+    out = torch.full((1,), 5, dtype=torch.int64, device=dev)
+    pair.ransac_score_into(S.default_params(n, num_hypotheses=H, seed=4, kernel=S.KERNEL_MFMA), out)
+    torch.cuda.synchronize()
+    assert int(out.cpu().numpy().view(np.uint64)[0]) == want
+
+
+@pytest.mark.parametrize("n,H", [(4097, 9000), (8192, 20000), (12345, 8192), (16384, 65536)])
+def test_tile_parallel_grid_equals_tile_loop(gpu_ab, n, H):
+    """n > 4096: tile-parallel scoring (default) against the in-block tile loop (reserved[1] = 1) and the oracle."""
+    scene = synth.two_view_scene(n, seed=n)
+    pair, _ = make_pair(S, gpu_ab, scene)
+    p = S.default_params(n, num_hypotheses=H, seed=3, kernel=S.KERNEL_SPLIT)
+    pair.estimateE(p)
+    a = (pair.get_inlier_counts(H).copy(), pair.get_key(), pair.get_inlier_mask().copy())
+    q = S.default_params(n, num_hypotheses=H, seed=3, kernel=S.KERNEL_SPLIT)
+    q.reserved[1] = 1
+    pair.estimateE(q)
+    assert np.array_equal(pair.get_inlier_counts(H), a[0]) and pair.get_key() == a[1] and np.array_equal(pair.get_inlier_mask(), a[2])
+    _, _, X0, X1 = R.oracle_xu(scene)
+    rng = np.random.default_rng(n)
+    R._oracle_sample_check(X0, X1, p, a[0], rng.integers(0, H, 30).tolist(), n)
+
+
+@pytest.mark.parametrize("n,H", [(1000, 3000), (4096, 20000), (700, 300001)])
+def test_lane_solve_variants_give_the_oracle_candidates(gpu_ab, n, H):
+    """The lane-solve kernel's arrangements -- one hypothesis per lane with the sampled points gathered as 16-byte records (the
+    default after fillXU), two per lane (packed), scattered dword gathers, the solver-agnostic scalar kernel; with fillXU's
+    unit-z points and with sfm_set_points (no records) -- must all produce the oracle's E for every hypothesis, bit for bit."""
+    torch, dev, ctx = gpu_ab
+    scene = synth.two_view_scene(n, seed=300 + n)
+    pair, _ = make_pair(S, gpu_ab, scene)
+    _, _, X0, X1 = O.fill_xu(scene["sift"], scene["Kinv"])
+    Hs = min(H, 2048)                                           # oracle candidates for the head and the tail of the range
+    _, _, e_head = O.ransac_range(X0, X1, 0, Hs, 1e-6, 0, seed=9, want_E=True)
+    _, _, e_tail = O.ransac_range(X0, X1, H - Hs, Hs, 1e-6, 0, seed=9, want_E=True)
+    cands = {}
+    for variant in (0, 2, 3, 4, 1):
+        p = S.default_params(n, num_hypotheses=H, seed=9, kernel=S.KERNEL_SPLIT)
+        p.reserved[0] = variant
+        pair.ransac_score(p)
+        cands[variant] = pair.get_E_candidates(H).reshape(H, 9).copy()
+        assert same_bits(cands[variant][:Hs], e_head.reshape(Hs, 9)) and same_bits(cands[variant][H - Hs:], e_tail.reshape(Hs, 9)), variant
+    for variant in (2, 3, 4, 1):
+        assert same_bits(cands[variant], cands[0]), variant
+    # no records: pre-normalised points through sfm_set_points (generic z), same coordinates
+    d0, d1 = to_dev(torch, dev, np.ascontiguousarray(X0[:, :n])), to_dev(torch, dev, np.ascontiguousarray(X1[:, :n]))
+    pair.set_points(d0, d1)
+    for variant in (0, 2, 3):
+        p = S.default_params(n, num_hypotheses=H, seed=9, kernel=S.KERNEL_SPLIT)
+        p.reserved[0] = variant
+        pair.ransac_score(p)
+        assert same_bits(pair.get_E_candidates(H).reshape(H, 9), cands[0]), ("set_points", variant)
+
+def test_prefilter_operands_on_the_device_equal_the_host_build(gpu_ab):
+    """sfm_prefilter_probe: the fp16 coefficient and feature slots the device builds for one (hypothesis, point) pair, against
+    tests/hostcheck (the same header compiled for the host) bit for bit -- random pairs, the committed tie cases, crafted
+    exact-tie coordinates -- and hi + lo of every feature must reproduce the fp32 feature to 2^-21."""
+    import ctypes as C
+    import test_hostcheck_prefilter as T
+    torch, dev, ctx = gpu_ab
+    h = C.CDLL(T.LIB)
+    f32p = O.f32p
+    h.hc_pf_hyp_slots.restype = C.c_float
+    h.hc_pf_hyp_slots.argtypes = [f32p, C.c_float, C.c_float, C.c_int, f32p, f32p]
+    h.hc_pf_point_slots.argtypes = [C.c_float] * 4 + [C.c_int, f32p, f32p]
+    rng = np.random.default_rng(77)
+    pairs = [(np.float32(c["E"]), np.float32(c["thr"]), np.float32(c["x1"] + c["x2"])) for c in P._tie_cases()]
+    ties = P._fp16_tie_coordinates(rng, 24)
+    for k in range(24):
+        E = rng.standard_normal(9).astype(np.float32); E /= np.linalg.norm(E)
+        pt = rng.uniform(-1.8, 1.8, 4).astype(np.float32)
+        pt[2] = ties[k]
+        if k % 2:
+            pt[3] = ties[(k + 5) % 24]
+        pairs.append((E, np.float32(10.0 ** rng.uniform(-8, -3)), pt))
+    for E, thr, pt in pairs:
+        B = float(np.abs(pt).max()) * 1.01
+        dv = ctx.prefilter_probe(E, thr, B, pt)
+        ns, ts, _ = T.hyp_slots(h, E, float(thr), float(np.float32(B)))
+        Bn, Bt = T.point_slots(h, np.float32([[pt[0]], [pt[1]], [1.0]]), np.float32([[pt[2]], [pt[3]], [1.0]]))
+        for name, a, b in (("ns", dv["ns"], ns), ("ts", dv["ts"], ts), ("bn", dv["bn"], Bn[0]), ("bt", dv["bt"], Bt[0])):
+            assert np.array_equal(a.astype(np.float64), b), (name, a, b)
+        x, y = np.float64(pt[2]), np.float64(pt[3])
+        for j, f in enumerate((np.float32(pt[2] * pt[2]), np.float32(pt[2] * pt[3]), np.float32(pt[3] * pt[3]), pt[2], pt[3])):
+            hi, lo = np.float64(dv["bt"][3 * j]), np.float64(dv["bt"][3 * j + 1])
+            assert dv["bt"][3 * j + 2] == dv["bt"][3 * j]
+            assert abs(hi + lo - np.float64(f)) <= abs(np.float64(f)) * 2.0 ** -21 + 2.0 ** -25, (j, hi, lo, f)
+        # the matrix cores on these operands: the contraction in float64 within the accumulation budget
+        nt = float(Bn[0] @ ns); G = float(Bt[0] @ ts)
+        assert abs(float(dv["nt"]) - nt) <= T.ACC * float(np.abs(Bn[0]) @ np.abs(ns)) + 1e-12
+        assert abs(float(dv["G"]) - G) <= T.ACC * float(np.abs(Bt[0]) @ np.abs(ts)) + 1e-12
+
+
+@pytest.mark.parametrize("cols,launches,H", [(64, 600, 1 << 18), (1, 150, 1 << 18)])
+def test_prefilter_tickets_under_contention_forced_columns(gpu_ab, cols, launches, H):
+    """The arg-max of the scoring kernel rests on an ordering assumption (ransac_prefilter.hip: the count atomics of a
+    wavefront are acknowledged -- s_waitcnt vmcnt(0) -- before its ticket is issued, and the wavefront that draws the last
+    ticket of a group then reads final counts), not on a release / acquire fence (which costs an L2 write-back per group).
+    This test exercises it: 16 tiles (so 16 wavefronts on 16 CUs race for every group's tickets), grid columns forced to
+    1 / 64 / the default through reserved[2], hundreds of launches, the key of EVERY launch and the counts of every 50th
+    against the oracle.  A reader that ran ahead of another tile's counts would produce a key with too small a count."""
+    torch, dev, ctx = gpu_ab
+    n = 16384
+    scene = synth.two_view_scene(n, seed=77)
+    pair, _ = make_pair(S, gpu_ab, scene)
+    p = S.default_params(n, num_hypotheses=H, seed=11, kernel=S.KERNEL_PREFILTER)
+    p.reserved[2] = cols
+    _, _, X0, X1 = O.fill_xu(scene["sift"], scene["Kinv"])
+    key, ocounts, _ = O.ransac_range_fast(X0, X1, 0, H, p.threshold, p.jacobi_sweeps, seed=p.seed)
+    bad_keys = 0
+    for it in range(launches):
+        pair.ransac_score(p)
+        k = pair.get_key()
+        if k != key:
+            bad_keys += 1
+        if it % 50 == 0:
+            assert pair.last_launch()["kernel"] == S.KERNEL_PREFILTER
+            assert np.array_equal(pair.get_inlier_counts(H), ocounts), f"launch {it}: counts differ"
+    assert bad_keys == 0, f"{bad_keys} of {launches} launches produced a key other than the oracle's"
+
+
+@pytest.mark.parametrize("mode", [2])
+def test_prefilter_static_pass_order_equals_oracle(gpu_ab, mode):
+    """reserved[1] = 2 hands the passes out by position instead of through the block's LDS counter (A/B switch): same counts."""
+    n, H = 3000, 40000
+    scene = synth.two_view_scene(n, seed=5)
+    pair, _ = make_pair(S, gpu_ab, scene)
+    p = S.default_params(n, num_hypotheses=H, seed=3, kernel=S.KERNEL_PREFILTER)
+    p.reserved[1] = mode
+    pair.estimateE(p)
+    P.check_all(pair, scene, p, H, n)
+
+
+def test_round2_kernel_still_equals_oracle(gpu_ab):
+    """The round-2 scoring kernel kept for A/B runs (reserved[3] = 2)."""
+    n, H = 4096, 65536
+    scene = synth.two_view_scene(n, seed=8)
+    pair, _ = make_pair(S, gpu_ab, scene)
+    p = S.default_params(n, num_hypotheses=H, seed=2, kernel=S.KERNEL_PREFILTER)
+    p.reserved[3] = 2
+    pair.estimateE(p)
+    assert pair.last_launch()["kernel"] == S.KERNEL_PREFILTER
+    P.check_all(pair, scene, p, H, n)
+
