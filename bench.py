@@ -50,12 +50,13 @@ PEAK_CLOCK_MHZ = 2400.0
 NUM_SIMDS = 1024              # 256 CU x 4
 FLOP_PER_POINT = 38           # residual of one (hypothesis, point)
 FLOP_PER_HYP = 720            # A^T A normal equations
+ALG_BYTES_PER_HYP = 72.0       # 32 B indices + 36 B E + 4 B count
 # ransac_score_prefilter, per (hypothesis, point) pair, what cannot be removed from this formulation:
 PF_SCAN_VALU_PER_PAIR = 2     # v_fma_f32 (G - nt^2) + v_alignbit_b32 (its sign bit into the lane's mask)
 PF_MFMA_PER_1024_PAIRS = 3    # v_mfma_f32_32x32x16_f16: G (16 k-slots) + nt (32 k-slots)
 PF_MFMA_CYCLES = 32           # issue interval of one 32x32x16 f16 MFMA on a SIMD (8 passes x 4 cycles; profiles/r02_mfma_rate_probe.txt)
 PF_SOURCES = ("ransac_prefilter.hip", "prefilter_math.hpp", "prefilter_record.hpp", "ransac.hip", "ransac_device.hpp", "device_math.hpp")
-TRAFFIC_JSON = os.path.join("profiles", "r03_traffic.json")
+TRAFFIC_JSON = os.path.join("profiles", "r04_traffic.json")
 PUBLISHED_ESTIMATE_E_MS = 24.12     # img/data.xlsx B5 / README.md:54 of the reference: estimateE on the dino pair, GTX 1080 Ti
 
 # BASELINE.json configs that are RANSAC workloads (configs[1] and [4] are pipelines: see `extra`)
@@ -63,6 +64,7 @@ CONFIGS = {
     "headline": (N_MATCHES, TOTAL_HYPS, "the metric's '4k matches' configuration"),
     "c3": (16384, 65536, "BASELINE configs[2]: synthetic 16k-match pair, 65k hypotheses"),
     "c4": (16384, 1 << 20, "BASELINE configs[3]: synthetic 16k matches, 1M hypotheses (sharded over --gpus)"),
+    "c5": (0, 0, "BASELINE configs[4]: 36-view dino ring, all pairwise estimateE + triangulation, view pairs streamed over --gpus"),
 }
 KERNEL_NAMES = {1: "ransac_score_waves", 2: "ransac_fused_waves", 3: "ransac_score_mfma", 4: "ransac_score_prefilter"}
 
@@ -88,6 +90,8 @@ def parse_args(argv=None):
     ap.add_argument("--timed-events", choices=["auto", "on", "off"], default="auto",
                     help="HIP events around every kernel INSIDE the timed region (auto: only with --serial; pipelined steps are sampled by serial launches right after it)")
     ap.add_argument("--reserved", type=int, nargs="*", default=[], help="sfm_ransac_params.reserved[] A/B switches (profiles/): runs on libsfm_amd_ab.so, never part of a judged line")
+    ap.add_argument("--pairs", choices=["all", "ring"], default="all", help="--config c5: all 630 unordered pairs of the 36 views, or the 36 ring pairs")
+    ap.add_argument("--regions", type=int, default=5, help="timed regions of K steps each: the contractual one + (regions - 1) more, reported as ms_per_step_regions")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg (and with it the full-oracle parity check)")
     ap.add_argument("--no-variants", action="store_true", help="skip the short run with the other null-vector solver")
     ap.add_argument("--no-extra", action="store_true", help="skip the short runs of the other BASELINE configurations")
@@ -185,7 +189,7 @@ def load_oracle():
     return O
 
 
-def cpu_baseline(O, X0, X1, params, n_matches, H, seconds):
+def cpu_baseline(O, X0, X1, params, n_matches, H, seconds, scene=None):
     """CPU port of the same algorithm on a bounded sample (oracle/: OpenMP over hypotheses; the scoring loop is the
     vectorised division-free filter + exact fallback).  The sample STARTS with hypotheses 0..H-1, counts kept: that sweep
     is also what the GPU's counts and arg-max key are compared with.  Returns (baseline dict, oracle key, oracle counts)."""
@@ -221,13 +225,52 @@ def cpu_baseline(O, X0, X1, params, n_matches, H, seconds):
            "sample": f"hypotheses 0..{sample - 1} of the same {n_matches}-match scene ({H} of them with counts kept for the parity check), "
                      f"{dt:.1f} s, OpenMP x{cores}",
            # north_star also names OpenCV's cv::findEssentialMat (a 5-point solver: wall-time sanity, not a parity target)
-           "opencv_findEssentialMat": "unavailable: OpenCV (cv2) is not installed in this image"}
-    try:
-        import cv2                                   # noqa: F401
-        out["opencv_findEssentialMat"] = "cv2 importable but not timed by this script"
-    except ImportError:
-        pass
+           "opencv_findEssentialMat": opencv_leg(scene)}
     return out, key, counts
+
+
+def opencv_leg(scene):
+    """cv::findEssentialMat(pts1, pts2, K, RANSAC, 0.999, 1.0) on the step's matches and cv::BFMatcher on a 2048 x 2048 descriptor
+    set, timed on the host cores whenever cv2 imports (SURVEY 8(d) iii: a 5-point solver with adaptive termination -- a wall-time
+    and pose sanity figure, not a parity target and not the cpu_baseline value).  This image has no OpenCV: the leg then says so."""
+    try:
+        import cv2
+    except ImportError:
+        return "unavailable: OpenCV (cv2) is not installed in this image"
+    import numpy as np
+    try:
+        sift = scene["sift"]
+        p1 = np.ascontiguousarray(np.stack([sift["xpos"], sift["ypos"]], 1), np.float64)
+        p2 = np.ascontiguousarray(np.stack([sift["match_xpos"], sift["match_ypos"]], 1), np.float64)
+        K = np.ascontiguousarray(scene["K"], np.float64).reshape(3, 3)
+        cv2.setNumThreads(len(os.sched_getaffinity(0)))
+        best = None
+        for _ in range(3):
+            t0 = time.perf_counter()
+            E, mask = cv2.findEssentialMat(p1, p2, K, method=cv2.RANSAC, prob=0.999, threshold=1.0)
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        out = {"findEssentialMat_ms": 1e3 * best, "matches": int(len(p1)), "inliers": int(mask.sum()) if mask is not None else None,
+               "args": "cv2.RANSAC, prob 0.999, threshold 1.0 px (5-point solver, adaptive iteration count)",
+               "threads": cv2.getNumThreads(), "version": cv2.__version__}
+        sys.path.insert(0, ROOT)
+        from cuda_sfm_amd_synth import synth
+        d1, d2, _ = synth.descriptors(2048)
+        bf = cv2.BFMatcher(cv2.NORM_L2)
+        t0 = time.perf_counter()
+        bf.knnMatch(d2, d1, k=2)
+        out["BFMatcher_knn2_2048x2048_ms"] = 1e3 * (time.perf_counter() - t0)
+        return out
+    except Exception as e:                            # noqa: BLE001 -- a reported side figure must not take the line down
+        return f"cv2 {getattr(cv2, '__version__', '?')} imported but the leg failed: {type(e).__name__}: {e}"
+
+
+def regions_summary(region_s, steps):
+    ms = sorted(1e3 * r / steps for r in region_s)
+    med = ms[len(ms) // 2] if len(ms) % 2 else 0.5 * (ms[len(ms) // 2 - 1] + ms[len(ms) // 2])
+    return {"regions": len(ms), "steps_per_region": steps, "median": med, "min": ms[0], "max": ms[-1],
+            "all": [round(1e3 * r / steps, 5) for r in region_s],
+            "note": "all[0] is the contractual region (= ms_per_step / value); the others follow it back to back, timed the same way"}
 
 
 def full_parity(O, X0, X1, params, n, okey, ocounts, gpu):
@@ -268,8 +311,11 @@ def quoted_counters(kname, n, local_hyps):
         have = source_hash()
         if doc.get("code_sha256_16") != have:
             return None, (f"{TRAFFIC_JSON} was collected on kernel sources {doc.get('code_sha256_16')}, this tree has {have}: "
-                          "not quoted (re-run profiles/collect_r03.sh)")
+                          "not quoted (re-run profiles/collect_r04.sh)")
         t = dict(t)
+        solve = doc.get("ransac_solve_lanes1_qr") or doc.get("ransac_solve_lanes2") or {}
+        if solve.get("fetch_kb") is not None and solve.get("write_kb") is not None:
+            t["solve_fetch_kb"], t["solve_write_kb"] = solve["fetch_kb"], solve["write_kb"]
         t["source"] = f"{TRAFFIC_JSON} (rocprofv3 --pmc passes of this command on sources {have}; quoted, not collected by this run)"
         return t, None
     except (OSError, KeyError, ValueError) as e:
@@ -317,7 +363,13 @@ def roofline_block(kernel_id, n, local_hyps, score_s, solve_s, clock_mhz, measur
     if quoted:
         out["traffic"] = 1024.0 * (quoted["fetch_kb"] + quoted["write_kb"])
         out["traffic_source"] = quoted["source"]
-        out["traffic_algorithmic_bytes"] = float(local_hyps) * 36.0 * ((n + 1023) // 1024 if kernel_id == 4 else 1) + 4.0 * local_hyps
+        # 32 B of sample indices in (here: derived from the id, never read) + 36 B E + 4 B count out per hypothesis,
+        # + the 16 N-byte point set once.  Per-tile re-reads of E / the records are implementation, not algorithm.
+        out["traffic_algorithmic_bytes"] = ALG_BYTES_PER_HYP * float(local_hyps) + 16.0 * n
+        out["traffic_step_bytes"] = 1024.0 * (quoted["fetch_kb"] + quoted["write_kb"] + quoted.get("solve_fetch_kb", 0.0) + quoted.get("solve_write_kb", 0.0))
+        out["traffic_step_over_algorithmic"] = out["traffic_step_bytes"] / out["traffic_algorithmic_bytes"]
+        out["traffic_note"] = ("traffic = FETCH_SIZE + WRITE_SIZE of the scoring kernel per launch; traffic_step_bytes adds the lane-solve kernel of the same "
+                               "step; algorithmic = 72 B per hypothesis + 16 B per match (SURVEY 8(d))")
         out["issue_profiled"] = {k: quoted[k] for k in ("valu_busy_frac", "mfma_busy_frac", "valu_insts_per_launch", "lds_bank_conflict_frac", "kernel_cycles") if k in quoted}
     else:
         out["traffic"] = None
@@ -399,13 +451,42 @@ def extra_match(S, synth, O, ctx, dev, torch, np, n, reps):
         out["frac_of_fp32_mfma_peak"] = flops / ms / 1e9 / FP32_PEAK_TFLOPS
     if O is not None:
         def check():
-            # the CPU matcher restates MatchC1 (CudaSift/match.cu:57-71): all queries at 2048, the first 1024 queries at 16384
-            q = n if n <= 4096 else 1024
-            cb, cs, ci = O.match_desc(d2[:q], d1, nthreads=len(os.sched_getaffinity(0)))
-            out["parity_vs_oracle"] = bool(np.array_equal(ci, res[2][:q]) and np.array_equal(cb.view(np.uint32), res[0][:q].view(np.uint32)))
-            out["parity_queries_checked"] = q
+            # the CPU matcher restates MatchC1 (CudaSift/match.cu:57-71): EVERY query at every size (16384^2: ~6 s of host time),
+            # index, best and second score bit for bit
+            t0 = time.perf_counter()
+            cb, cs, ci = O.match_desc(d2, d1, nthreads=len(os.sched_getaffinity(0)))
+            out["oracle_sweep_s"] = time.perf_counter() - t0
+            out["parity_vs_oracle"] = bool(np.array_equal(ci, res[2]) and np.array_equal(cb.view(np.uint32), res[0].view(np.uint32))
+                                           and np.array_equal(cs.view(np.uint32), res[1].view(np.uint32)))
+            out["parity_queries_checked"] = n
         out["_check"] = check
     return out
+
+
+def dino_pairs_vs_oracle(S, O, np, feats, pairs, res, Kinv):
+    """Every pair of `pairs` (view indices into feats = per-view SiftPoint records) through the oracle chain of src/main.cpp:282-307
+    against the GPU records res[pid] = [E(9) | chosen pose(16) | pose index, inliers, best hypothesis].  Returns the ids that differ."""
+    bad = []
+    for pid, (i, j) in enumerate(pairs):
+        fi, fj = feats[i], feats[j]
+        r = res.get(pid) if hasattr(res, "get") else res[pid]
+        if len(fi) < 8:
+            if r is not None and r[26] >= 0:
+                bad.append(pid)
+            continue
+        om = O.match_sift(fi.copy(), fj)
+        _, _, X0, X1 = O.fill_xu(om, Kinv)
+        q = S.default_params(len(fi))
+        okey, _, Ec = O.ransac_range(X0, X1, 0, q.num_hypotheses, q.threshold, q.jacobi_sweeps, seed=q.seed, want_E=True)
+        ocnt, ohyp = O.unpack_key(okey)
+        oP = O.pose_candidates(Ec[ohyp], S.POSE_REFERENCE)
+        oind, oPinv, _, _ = O.choose_pose(X0, X1, oP, S.POSE_REFERENCE, 8)
+        ok = r is not None and (int(r[26]), int(r[27]), int(r[25])) == (ocnt, ohyp, oind) and \
+            np.array_equal(np.ascontiguousarray(r[:9], np.float32).view(np.uint32), Ec[ohyp].reshape(-1).view(np.uint32)) and \
+            np.array_equal(np.ascontiguousarray(r[9:25], np.float32).view(np.uint32), np.ascontiguousarray(oPinv[oind], np.float32).reshape(-1).view(np.uint32))
+        if not ok:
+            bad.append(pid)
+    return bad
 
 
 def extra_dino(S, O, ctx, dev, torch, np):
@@ -464,6 +545,15 @@ def extra_dino(S, O, ctx, dev, torch, np):
     out["c1_dino_pair"] = c1
     pair.close()
 
+    feats_cache = []
+
+    def view_feats():                                     # the 36 views' features as the GPU extractor delivers them, once
+        if not feats_cache:
+            for v in views:
+                sv, nv = extract(v)
+                feats_cache.append(sv.cpu().numpy().view(O.SIFT_DTYPE).reshape(-1)[:nv].copy())
+        return feats_cache
+
     # configs[4]: host images in, everything per pair inside the C library (sfm_extract_views + sfm_process_pairs)
     for name, pairs in (("c5_dino_ring_36_pairs", S.ring_pairs(36)), ("c5_dino_all_630_pairs", [(i, j) for i in range(36) for j in range(i + 1, 36)])):
         S.process_views(ctx, views8[:9], DINO_K, DINO_KINV, max_pts=8192, sift=DINO_SIFT, device=dev)
@@ -477,23 +567,15 @@ def extra_dino(S, O, ctx, dev, torch, np):
              "note": "8-bit host images -> device inside the timed region (PCIe-inclusive; float images: +0.5 ms, profiles/r03_ring_bench.txt)"}
         if O is not None:
             def check_c5(e=e, res=res, pairs=pairs):
-                # a few pairs against the oracle chain, from the features the GPU extractor delivers for those views
-                ok = len(res) == len(pairs)
-                for pid in sorted({0, len(pairs) // 3, len(pairs) - 1}):
-                    i, j = pairs[pid]
-                    (si, ni), (sj, nj) = extract(views[i]), extract(views[j])
-                    fi = si.cpu().numpy().view(O.SIFT_DTYPE).reshape(-1)[:ni]
-                    fj = sj.cpu().numpy().view(O.SIFT_DTYPE).reshape(-1)[:nj]
-                    om = O.match_sift(fi.copy(), fj)
-                    _, _, X0, X1 = O.fill_xu(om, DINO_KINV)
-                    q = S.default_params(ni)
-                    okey, _, Ec = O.ransac_range(X0, X1, 0, q.num_hypotheses, q.threshold, q.jacobi_sweeps, seed=q.seed, want_E=True)
-                    ocnt, ohyp = O.unpack_key(okey)
-                    r = res.get(pid)
-                    ok = ok and r is not None and (int(r[26]), int(r[27])) == (ocnt, ohyp) and \
-                        np.array_equal(np.ascontiguousarray(r[:9], np.float32).view(np.uint32), Ec[ohyp].reshape(-1).view(np.uint32))
-                e["parity_vs_oracle"] = bool(ok)
-                e["parity_pairs_checked"] = 3
+                # EVERY pair against the oracle chain (MatchC1 restatement -> fillXU -> estimateE -> pose candidates -> choosePose),
+                # from the features the GPU extractor delivers for the views: winner, count, E bits, pose index, chosen pose
+                t0 = time.perf_counter()
+                bad = dino_pairs_vs_oracle(S, O, np, view_feats(), pairs, res, DINO_KINV)
+                e["parity_vs_oracle"] = bool(len(res) == len(pairs) and not bad)
+                e["parity_pairs_checked"] = len(pairs)
+                e["oracle_sweep_s"] = round(time.perf_counter() - t0, 2)
+                if bad:
+                    e["pairs_that_differ"] = bad[:8]
             e["_check"] = check_c5
         out[name] = e
     return out
@@ -654,6 +736,15 @@ def rank_main(args):
     elapsed = time.perf_counter() - t0
     solve_ms, score_ms, calls = ctx.kernel_timing_read() if events_in_region else (0.0, 0.0, 0)
     ctx.kernel_timing(False)
+    # The contractual region above is ONE sample (12 ms at --steps 20).  Four more regions of the same K steps, timed the same way
+    # (fence on both sides, no events), say how much one sample is worth: the line carries median / min / max next to it.
+    region_s = [elapsed]
+    for _ in range(0 if args.regions <= 1 else args.regions - 1):
+        r0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        region_s.append(time.perf_counter() - r0)
     timed_region_kernel_ms = (solve_ms / max(calls, 1), score_ms / max(calls, 1))
     # what the timed steps left behind (every rank): winner, E, mask
     hyp, cnt = pair.get_best()
@@ -682,9 +773,10 @@ def rank_main(args):
     rc = 0
     agree = None
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor(region_s, dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        region_s = [float(v) for v in t.cpu().numpy()]
+        elapsed = region_s[0]
         gathered = [None] * world
         dist.all_gather_object(gathered, per_rank[0])
         per_rank = gathered
@@ -762,6 +854,7 @@ def rank_main(args):
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
+            "ms_per_step_regions": regions_summary(region_s, args.steps),
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
@@ -792,7 +885,7 @@ def rank_main(args):
         if world == 1 and not args.no_cpu:
             O = load_oracle()
             _, _, X0, X1 = O.fill_xu(scene["sift"], scene["Kinv"])
-            base, okey, ocounts = cpu_baseline(O, X0, X1, params, n, H, args.cpu_seconds)
+            base, okey, ocounts = cpu_baseline(O, X0, X1, params, n, H, args.cpu_seconds, scene)
             out["cpu_baseline"] = base
             ok = full_parity(O, X0, X1, params, n, okey, ocounts, serial_result)
             out["result"]["parity_vs_oracle"] = ok
@@ -803,6 +896,13 @@ def rank_main(args):
         if world == 1 and not args.no_extra:
             skip = {args.config} if (args.matches is None and args.hyps is None) else set()
             out["extra"] = run_extras(S, synth, O, ctx, dev, torch, np, skip)
+            share = out["extra"].get("headline_share_of_one_of_8_ranks", {})
+            if args.config == "headline" and args.matches is None and args.hyps is None and share.get("ms_per_step"):
+                out["scaling_projection"] = {
+                    "gpus": 8, "one_gpu_ms_per_step": out["ms_per_step"], "one_of_8_ranks_ms_per_step": share["ms_per_step"],
+                    "projected_speedup": out["ms_per_step"] / share["ms_per_step"],
+                    "status": "UNMEASURED ON HARDWARE: a projection from one GPU running one rank's 1/8 shard in the same invocation; it excludes the "
+                              "8-byte all-reduce and any cross-rank skew.  No multi-GPU node has run this code; the driver's SCALE run is the measurement."}
             bad = [k for k, v in out["extra"].items() if isinstance(v, dict) and (v.get("parity_vs_oracle") is False or "error" in v)]
             if bad:
                 print(f"bench.py: extra runs failed or lost parity: {bad}", file=sys.stderr)
@@ -821,11 +921,159 @@ def rank_main(args):
     return rc
 
 
+# ------------------------------------------------------------------------------------------------------------------
+# --config c5: BASELINE configs[4] as a job of its own (N >= 1 ranks)
+# ------------------------------------------------------------------------------------------------------------------
+def c5_rank_main(args):
+    """One "step" = the whole many-views job: 36 host images (the reference's dino frames, 8-bit grey fixtures) -> ExtractSift per
+    view on the rank that owns it -> the count-sized feature exchange -> MatchSiftData + the Image_pair sequence for every pair on
+    the rank that owns it -> one gather of the result records.  PCIe-inclusive by construction (the job starts from host images).
+    N > 1: --comm rccl = sfm_process_views_sharded (C, RCCL), --comm torch = the Python harness over torch.distributed."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import cuda_sfm_amd as S
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import read_pnm_grey, dino_frame, DINO_K, DINO_KINV, DINO_SIFT
+
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+        return 2
+    if not torch.cuda.is_available():
+        print("bench.py needs a GPU (there is no CPU fallback)", file=sys.stderr)
+        return 2
+    if not os.path.exists(dino_frame(35)):
+        print("bench.py --config c5: tests/golden/dino fixtures not present", file=sys.stderr)
+        return 2
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    views_f = [read_pnm_grey(dino_frame(k)) for k in range(36)]
+    views8 = [v.astype(np.uint8) for v in views_f]
+    pairs = S.ring_pairs(36) if args.pairs == "ring" else [(i, j) for i in range(36) for j in range(i + 1, 36)]
+    ctx = S.Context(local, torch.cuda.current_stream().cuda_stream)
+    mode = "none" if world == 1 else ("torch" if args.comm == "torch" else "rccl")
+    comm = None
+    if mode == "rccl":
+        uid = [S.Comm.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        comm = S.Comm(ctx, uid[0], rank, world)
+    xstats = {}
+
+    def gather_results(t):
+        out = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        dist.all_gather_into_tensor(out, t)
+        return out
+
+    def step():
+        if comm is not None:
+            res, counts = comm.process_views(views_f, DINO_K, DINO_KINV, pairs=pairs, max_pts=8192, sift=DINO_SIFT)
+            xstats["feature_bytes"], xstats["slot_bytes"] = comm.last_exchange()
+            return res, counts
+        return S.process_views(ctx, views8, DINO_K, DINO_KINV, pairs=pairs, rank=rank, world=world, max_pts=8192, sift=DINO_SIFT,
+                               dist=dist if world > 1 else None, gather_results=gather_results if world > 1 else None, device=dev, stats=xstats)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(max(args.warmup, 2)):
+        res, counts = step()
+    fence()
+    steps = args.steps
+    region_s = []
+    for _ in range(max(1, args.regions)):
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            res, counts = step()
+        fence()
+        region_s.append(time.perf_counter() - t0)
+    rc = 0
+    rec = np.stack([res[k] if k in res else np.full(28, -1.0, np.float32) for k in range(len(pairs))])
+    agree = None
+    if world > 1:
+        t = torch.tensor(region_s, dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        region_s = [float(v) for v in t.cpu().numpy()]
+        mine = {"rank": rank, "records_sha": hashlib.sha256(rec.tobytes()).hexdigest()[:16], "pairs_done": len(res), "counts_sha": hashlib.sha256(np.asarray(counts, np.int32).tobytes()).hexdigest()[:16],
+                "nccl_ranks": comm.nccl_ranks() if comm is not None else world, "exchange": dict(xstats)}
+        allr = [None] * world
+        dist.all_gather_object(allr, mine)
+        same = all((a["records_sha"], a["counts_sha"], a["pairs_done"]) == (allr[0]["records_sha"], allr[0]["counts_sha"], allr[0]["pairs_done"]) for a in allr)
+        spans = all(a["nccl_ranks"] == world for a in allr)
+        agree = {"ranks_hold_identical_records": bool(same), "communicator_spans_all_ranks": bool(spans), "per_rank": allr}
+        if not (same and spans):
+            print(f"bench.py: rank results differ or the communicator is short: {json.dumps(allr)}", file=sys.stderr)
+            rc = 1
+    if rank == 0:
+        elapsed = region_s[0]
+        real = int(sum(counts)) * 576
+        out = {"metric": "view pairs/sec: MatchSiftData + estimateE + pose + triangulation per pair, ExtractSift per view, host images in (BASELINE configs[4])",
+               "value": len(pairs) * steps / elapsed, "unit": "pairs/s", "n_gpus": world, "steps": steps, "warmup": max(args.warmup, 2),
+               "ms_per_step": 1e3 * elapsed / steps, "ms_per_step_regions": regions_summary(region_s, steps), "higher_is_better": True, "scaling": "strong",
+               "vs_baseline": None, "dtype": "f32", "data": "the reference's 36 dino frames (data/dino/viff.000-035.ppm as 8-bit grey fixtures, tests/golden/dino)",
+               "config": {"workload": f"36 views 720 x 576, {len(pairs)} view pairs ({args.pairs}), H = n/8 hypotheses per pair (the reference's own count), views and pairs dealt round-robin over {world} GPU(s)",
+                          "preset": "c5", "preset_note": CONFIGS["c5"][2], "features_per_view": [int(min(counts)), int(max(counts))],
+                          "path": {"none": "one rank: sfm_extract_views_u8 + sfm_process_pairs (no exchange)",
+                                   "rccl": "sfm_process_views_sharded (libsfm_amd_rccl.so): counts all-gather, count-sized grouped ncclBroadcast of the features, records all-gather; float host images",
+                                   "torch": "Python harness over torch.distributed (RCCL): counts all_gather, per-view broadcast, records all_gather; 8-bit host images"}[mode],
+                          "nccl_ranks": comm.nccl_ranks() if comm is not None else (world if mode == "torch" else 1)},
+               "exchange": {"feature_bytes_into_each_rank": xstats.get("feature_bytes", 0), "sum_count_x_576": real,
+                            "over_real_bytes": (xstats.get("feature_bytes", 0) / real) if (real and world > 1) else None,
+                            "max_pts_slot_bytes_equivalent": xstats.get("slot_bytes", 0),
+                            "note": "bytes every rank receives in the feature exchange; before ABI version 2 the exchange moved max_pts-sized slots (4.6 x the real bytes on these frames)"},
+               "roofline": None,
+               "roofline_note": "a pipeline of ~50 launch-bound kernels per view / pair batch, not one kernel: no roofline is claimed (the headline line carries the scoring kernel's)",
+               "scaling_status": ("one GPU" if world == 1 else f"{world} ranks ran") + "; no multi-GPU curve of this configuration had been measured by the builder (1-GPU boxes only): the driver's SCALE run is the measurement",
+               "result": {"pairs_done": len(res)}}
+        if agree is not None:
+            out["result"]["multi_gpu"] = agree
+        if world == 1 and not args.no_cpu:
+            O = load_oracle()
+            d_feats = []
+            pitch = (720 + 127) // 128 * 128
+            for v in views_f:
+                pad = np.zeros((576, pitch), np.float32); pad[:, :720] = v
+                d_sift = torch.zeros((8192, 576), dtype=torch.uint8, device=dev)
+                nv, _ = ctx.extract_sift(d_sift, 8192, torch.from_numpy(pad).to(dev), 720, 576, pitch, **DINO_SIFT)
+                d_feats.append(d_sift.cpu().numpy().view(O.SIFT_DTYPE).reshape(-1)[:nv].copy())
+            t0 = time.perf_counter()
+            bad = dino_pairs_vs_oracle(S, O, np, d_feats, pairs, res, DINO_KINV)
+            dt = time.perf_counter() - t0
+            out["result"]["parity_vs_oracle"] = bool(len(res) == len(pairs) and not bad)
+            out["result"]["parity_pairs_checked"] = len(pairs)
+            out["cpu_baseline"] = {"value": len(pairs) / dt, "unit": "pairs/s", "cores": len(os.sched_getaffinity(0)), "kind": "port",
+                                   "sample": f"the oracle chain (match + fillXU + estimateE + poses, no extraction) for all {len(pairs)} pairs, {dt:.1f} s; it is also the parity sweep"}
+            if bad:
+                out["result"]["pairs_that_differ"] = bad[:8]
+                rc = 1
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        print(json.dumps(out), flush=True)
+    if comm is not None:
+        comm.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return rc
+
+
 def main():
     argv = sys.argv[1:]
     args = parse_args(argv)
     if args.gpus > 1 and "RANK" not in os.environ:
         return launcher_main(args, argv)
+    if args.config == "c5":
+        if "--steps" not in " ".join(argv):
+            args.steps = 10
+        return c5_rank_main(args)
     return rank_main(args)
 
 

@@ -540,7 +540,7 @@ def estimate_E_distributed(pair, params, rank, world, key_tensor, all_reduce_max
 
 # ---- RCCL exchange step in C (include/sfm_amd_comm.h, libsfm_amd_rccl.so) ----------------------------
 COMM_EXPORTS = ["sfm_comm_unique_id", "sfm_comm_init", "sfm_comm_destroy", "sfm_comm_rank", "sfm_comm_nccl_ranks", "sfm_estimate_E_sharded",
-                "sfm_estimate_E_sharded_pipelined", "sfm_comm_flush", "sfm_process_views_sharded"]
+                "sfm_estimate_E_sharded_pipelined", "sfm_comm_flush", "sfm_process_views_sharded", "sfm_comm_last_exchange"]
 COMM_LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), "libsfm_amd_rccl.so")
 COMM_ID_BYTES = 128
 _comm_lib = None
@@ -563,6 +563,7 @@ def comm_lib():
         L.sfm_estimate_E_sharded_pipelined.argtypes = [_vp, C.POINTER(RansacParams), _vp]
         L.sfm_comm_flush.argtypes = [_vp]
         L.sfm_comm_nccl_ranks.argtypes = [_vp, C.POINTER(C.c_int)]
+        L.sfm_comm_last_exchange.argtypes = [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.sfm_process_views_sharded.argtypes = [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.POINTER(C.c_float)), C.c_int, C.c_int, C.c_int,
                                                 C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.c_double, C.c_float, C.c_float, C.c_int, C.c_uint32,
                                                 C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int)]
@@ -602,7 +603,8 @@ class Comm:
         _check(comm_lib().sfm_comm_flush(self._h), "sfm_comm_flush")
 
     def process_views(self, images, K, Kinv, pairs=None, max_pts=8192, sift=None, num_hypotheses=None, pose_mode=POSE_REFERENCE):
-        """sfm_process_views_sharded: BASELINE configs[4] over all ranks inside the C libraries (two ncclAllGathers).
+        """sfm_process_views_sharded: BASELINE configs[4] over all ranks inside the C libraries (counts all-gather, count-sized
+        grouped broadcasts of the features, records all-gather).
         Returns ({pair_id: record}, counts) like process_views; every rank gets every record."""
         sift = dict(sift or {})
         V = len(images)
@@ -620,6 +622,12 @@ class Comm:
                                                     int(bool(sift.get("scale_up", False))), int(num_hypotheses or 0), int(pose_mode),
                                                     rec.ctypes.data_as(C.POINTER(C.c_float)), counts), "sfm_process_views_sharded")
         return {pid: rec[pid].copy() for pid in range(len(pairs)) if rec[pid][26] >= 0}, list(counts)
+
+    def last_exchange(self):
+        """(bytes the feature exchange of the last process_views moved into this rank, bytes max_pts-sized slots would have been)."""
+        a, b = C.c_uint64(), C.c_uint64()
+        _check(comm_lib().sfm_comm_last_exchange(self._h, C.byref(a), C.byref(b)), "sfm_comm_last_exchange")
+        return a.value, b.value
 
     def nccl_ranks(self):
         n = C.c_int()
@@ -730,31 +738,59 @@ def view_slot(v, world, slots):
     return (int(v) % int(world)) * int(slots) + int(v) // int(world)
 
 
-def exchange_view_features(block, num_views, world, max_pts, gather_features=None):
-    """The one collective of the many-views front end.  block: this rank's uint8 tensor [slots, max_pts * 576 + 64]
-    (slot s = view rank + s * world: its SiftPoint records, then its int32 feature count in the tail).
-    gather_features(block) -> all ranks' blocks concatenated in rank order (torch.distributed.all_gather_into_tensor over
-    RCCL; gloo in the CPU tests; None / world == 1: identity).  Returns (gathered [world * slots, ...] tensor, counts per
-    view); view v sits in row view_slot(v, world, slots)."""
+def exchange_view_features(block, num_views, rank, world, max_pts, dist=None):
+    """The feature exchange of the many-views front end, sized by what exists.  block: this rank's uint8 tensor
+    [slots, max_pts * 576 + 64] (slot s = view rank + s * world: its SiftPoint records, then its int32 feature count in the tail).
+    dist: torch.distributed (RCCL on the GPUs, gloo in the CPU tests) or None for a single rank.
+      1. all_gather_into_tensor of the `slots` counts of every rank (4 bytes per view);
+      2. every view's count x 576 bytes broadcast from its owner (rank v % world) into ONE compact buffer, views back to back in
+         view order (offsets are multiples of 576: descriptors stay 16-byte aligned); a view without features ships nothing.
+    Returns (feats, counts, offsets, stats): feats = flat uint8 tensor, view v's records start at byte offsets[v];
+    stats = {"feature_bytes": bytes moved into this rank, "slot_bytes": what an all-gather of the max_pts-sized slots moved}.
+    A single rank exchanges nothing: feats is the block itself, offsets are its slot starts."""
+    import torch
     rec_bytes = int(max_pts) * 576
     slots = block.shape[0]
-    feats = gather_features(block) if (gather_features is not None and world > 1) else block
-    feats = feats.reshape(-1, rec_bytes + 64)
-    assert feats.shape[0] == world * slots, f"gathered {feats.shape[0]} slots, expected {world * slots}"
-    tail = feats[:, rec_bytes:rec_bytes + 4].cpu().numpy().view(np.int32).reshape(-1)
-    counts = [int(tail[view_slot(v, world, slots)]) for v in range(int(num_views))]
-    return feats, counts
+    num_views, rank, world = int(num_views), int(rank), int(world)
+    mine = block[:, rec_bytes:rec_bytes + 4].contiguous().view(torch.int32).reshape(-1)
+    if world == 1 or dist is None:
+        c = mine.cpu().numpy()
+        counts = [int(c[v]) for v in range(num_views)]
+        return block.reshape(-1), counts, [v * (rec_bytes + 64) for v in range(num_views)], {"feature_bytes": 0, "slot_bytes": 0}
+    allc = torch.empty(world * slots, dtype=torch.int32, device=block.device)
+    dist.all_gather_into_tensor(allc, mine)
+    c = allc.cpu().numpy()
+    counts = [int(c[(v % world) * slots + v // world]) for v in range(num_views)]
+    assert all(0 <= n <= int(max_pts) for n in counts), counts
+    offsets, total = [], 0
+    for n in counts:
+        offsets.append(total)
+        total += n * 576
+    feats = torch.empty(max(total, 1), dtype=torch.uint8, device=block.device)
+    work = []
+    for v in range(num_views):
+        nb = counts[v] * 576
+        if nb == 0:
+            continue
+        dst = feats[offsets[v]:offsets[v] + nb]
+        if v % world == rank:
+            dst.copy_(block[v // world, :nb])
+        work.append(dist.broadcast(dst, src=v % world, async_op=True))
+    for w in work:
+        w.wait()
+    return feats, counts, offsets, {"feature_bytes": total + 4 * world * slots, "slot_bytes": world * slots * (rec_bytes + 64)}
 
 
 def process_views(ctx, images, K, Kinv, pairs=None, rank=0, world=1, max_pts=8192, sift=None, num_hypotheses=None,
-                  pose_mode=POSE_REFERENCE, gather_features=None, gather_results=None, device=None):
+                  pose_mode=POSE_REFERENCE, dist=None, gather_results=None, device=None, stats=None):
     """Many-view front end of process_pairs: images -> ExtractSift per view (views round-robin over the ranks) ->
-    ONE exchange of fixed-size feature blocks -> per pair MatchSiftData + the two-view pipeline on the rank that
+    the count-sized feature exchange (exchange_view_features) -> per pair MatchSiftData + the two-view pipeline on the rank that
     owns the pair -> ONE gather of fixed-size result records.
 
     images: list of equally sized 2-D float32 arrays (grey values 0..255).  sift: dict of ExtractSift arguments
-    (num_octaves, init_blur, thresh, lowest_scale, scale_up).  gather_features(uint8 tensor [slots, max_pts*576 + 64])
-    and gather_results(float tensor) are all_gather_into_tensor wrappers (identity when world == 1).
+    (num_octaves, init_blur, thresh, lowest_scale, scale_up).  dist: torch.distributed for world > 1 (None: single rank);
+    gather_results(float tensor) is an all_gather_into_tensor wrapper (identity when world == 1).  stats (optional dict)
+    receives the exchange's byte counts.
     Returns ({pair_id: record}, counts) with record = [E(9) | P(16) | pose index, inliers, best hypothesis] as in
     process_pairs and counts = number of features of every view."""
     import torch
@@ -768,7 +804,15 @@ def process_views(ctx, images, K, Kinv, pairs=None, rank=0, world=1, max_pts=819
     rec_bytes = max_pts * 576
     # records | int32 count in the tail; every slot of a single-rank run is written by sfm_extract_views (records up to the count,
     # the count itself), so only a multi-rank run -- whose last slots may stay unused -- pays for clearing 4.7 MB per view
-    block = (torch.zeros if world > 1 else torch.empty)((slots, rec_bytes + 64), dtype=torch.uint8, device=dev)
+    # (kept on the context between calls: 36 slots of 8192 records are 170 MB, and a fresh allocation per call shows up as
+    # occasional 10-40 ms steps of a 5 ms job)
+    cache = getattr(ctx, "_views_block", None)
+    if cache is None or cache.shape != (slots, rec_bytes + 64) or cache.device != dev:
+        cache = torch.zeros((slots, rec_bytes + 64), dtype=torch.uint8, device=dev)
+        ctx._views_block = cache
+    block = cache
+    if world > 1:
+        block[:, rec_bytes:].zero_()                      # the counts of slots this rank does not fill must read 0
     # ExtractSift for this rank's views inside the C library (sfm_extract_views: pinned staging, two streams)
     mine_views = list(range(rank, V, world))
     if mine_views:
@@ -783,8 +827,10 @@ def process_views(ctx, images, K, Kinv, pairs=None, rank=0, world=1, max_pts=819
         _check(fn(ctx._h, ptrs, V, w, h, int(rank), int(world), _ptr(block), rec_bytes + 64, int(max_pts),
                   int(sift.get("num_octaves", 5)), float(sift.get("init_blur", 1.0)), float(sift.get("thresh", 3.0)),
                   float(sift.get("lowest_scale", 0.0)), int(bool(sift.get("scale_up", False))), cnts), "sfm_extract_views")
-    # ONE exchange of the fixed-size feature blocks; feature counts of all views with ONE read-back
-    feats, counts = exchange_view_features(block, V, world, max_pts, gather_features)
+    # the counts of all views (one small all-gather + read-back), then every view's own bytes from its owner
+    feats, counts, offsets, xstats = exchange_view_features(block, V, rank, world, max_pts, dist)
+    if stats is not None:
+        stats.update(xstats)
 
     mine = pair_schedule(len(pairs), rank, world)
     max_local = (len(pairs) + world - 1) // world
@@ -793,7 +839,7 @@ def process_views(ctx, images, K, Kinv, pairs=None, rank=0, world=1, max_pts=819
     # fields (score .. match_ypos) straight into the first view's records -- nothing else of a record changes, so no copy.
     # The descriptor array is built with numpy from the views' device addresses (630 pairs: a Python loop over torch slices
     # used to keep the GPU idle for milliseconds between the extraction and the first matcher launch).
-    vptr = np.array([feats.data_ptr() + view_slot(v, world, slots) * (rec_bytes + 64) for v in range(V)], np.uint64)
+    vptr = np.array([feats.data_ptr() + offsets[v] for v in range(V)], np.uint64)
     vcnt = np.array(counts, np.int32)
     pij = np.asarray(pairs, np.int64).reshape(-1, 2)
     descs = np.zeros(len(pairs), PAIR_DESC_DTYPE)

@@ -24,8 +24,11 @@ struct sfm_comm {
     hipEvent_t ev_scored[2] = { nullptr, nullptr }, ev_final[2] = { nullptr, nullptr }, ev_call = nullptr;
     unsigned long long step = 0;
     bool final_pending = false;
-    void *d_views = nullptr;            // sfm_process_views_sharded: feature slots + result records, mine and everybody's
+    void *d_views = nullptr;            // sfm_process_views_sharded: my feature slots, counts and result records (mine and everybody's)
     size_t views_bytes = 0;
+    void *d_feats = nullptr;            // ... and every view's records back to back (count x 576 bytes each), grown on demand
+    size_t feats_bytes = 0;
+    uint64_t last_feature_bytes = 0, last_slot_bytes = 0;      // sfm_comm_last_exchange
 };
 
 namespace {
@@ -94,10 +97,19 @@ extern "C" int sfm_comm_destroy(sfm_comm *c)
     }
     if (c->d_keys) (void)hipFree(c->d_keys);
     if (c->d_views) (void)sfm_device_free(c->ctx, c->d_views);
+    if (c->d_feats) (void)sfm_device_free(c->ctx, c->d_feats);
     if (c->xstream) (void)hipStreamDestroy(c->xstream);
     if (c->sstream) (void)hipStreamDestroy(c->sstream);
     if (c->ev_call) (void)hipEventDestroy(c->ev_call);
     delete c;
+    return SFM_OK;
+}
+
+extern "C" int sfm_comm_last_exchange(const sfm_comm *c, uint64_t *feature_bytes, uint64_t *slot_bytes)
+{
+    if (!c || !feature_bytes) return SFM_E_INVALID;
+    *feature_bytes = c->last_feature_bytes;
+    if (slot_bytes) *slot_bytes = c->last_slot_bytes;
     return SFM_OK;
 }
 
@@ -200,7 +212,11 @@ extern "C" int sfm_comm_flush(sfm_comm *c)
     return SFM_OK;
 }
 
-// BASELINE configs[4] over all ranks without leaving C: views and pairs are dealt round-robin, two collectives in total.
+// BASELINE configs[4] over all ranks without leaving C: views and pairs are dealt round-robin.  Three collectives in total:
+// the views' feature COUNTS (4 bytes per view), the features themselves -- count x 576 bytes per view, broadcast from the
+// view's owner into one compact buffer (a grouped ncclBroadcast per view: RCCL has no all-gather-v) -- and the fixed-size
+// result records.  The feature exchange ships what exists: 36 dino views are ~37 MB, where max_pts-sized slots were 170 MB
+// (680 MB with the reference's own InitSiftData(..., 32768, ...), src/main.cpp:271).
 extern "C" int sfm_process_views_sharded(sfm_comm *c, const float h_K[9], const float h_Kinv[9], const float *const *h_images, int num_views,
                                          int width, int height, const int *h_pairs, int num_pairs, int max_pts, int num_octaves,
                                          double init_blur, float thresh, float lowest_scale, int scale_up, uint32_t num_hypotheses,
@@ -218,39 +234,73 @@ extern "C" int sfm_process_views_sharded(sfm_comm *c, const float h_K[9], const 
     const size_t rec_bytes = (size_t)max_pts * sizeof(sfm_sift_point), slot_bytes = rec_bytes + 64;
     const int max_local = (num_pairs + G - 1) / G > 0 ? (num_pairs + G - 1) / G : 1;
     const size_t local_bytes = (size_t)slots * slot_bytes, recs_local = (size_t)max_local * SFM_RECORD_FLOATS * sizeof(float);
-    // one allocation: [my feature slots][everybody's feature slots][my records][everybody's records]
-    const size_t need = local_bytes * (size_t)(1 + G) + recs_local * (size_t)(1 + G);
+    const size_t cnt_local = ((size_t)slots * sizeof(int) + 63) & ~(size_t)63;
+    // one allocation: [my feature slots][my counts][everybody's counts][my records][everybody's records]
+    const size_t need = local_bytes + cnt_local * (size_t)(1 + G) + recs_local * (size_t)(1 + G);
     if (need > c->views_bytes) {
         (void)sfm_ctx_synchronize(c->ctx);
         if (c->d_views) (void)sfm_device_free(c->ctx, c->d_views);
+    if (c->d_feats) (void)sfm_device_free(c->ctx, c->d_feats);
         c->d_views = nullptr; c->views_bytes = 0;
         rc = sfm_device_alloc(c->ctx, need, &c->d_views);
         if (rc != SFM_OK) return rc;
         c->views_bytes = need;
     }
-    char *d_local = static_cast<char *>(c->d_views), *d_all = d_local + local_bytes;
-    char *d_rec_local = d_all + local_bytes * (size_t)G, *d_rec_all = d_rec_local + recs_local;
-    COMM_HIP_TRY(hipMemsetAsync(d_local, 0, local_bytes, stream));                       // spare slots: zero features
-    COMM_HIP_TRY(hipStreamSynchronize(stream));                                          // extraction runs on its own streams
-    // 1. ExtractSift for my views, 2. ONE all-gather of the fixed-size feature slots (rank-major: view v sits in slot
-    //    (v % G) * slots + v / G), 3. the pairs I own, 4. ONE all-gather of the fixed-size result records
+    char *d_local = static_cast<char *>(c->d_views);
+    char *d_cnt_local = d_local + local_bytes, *d_cnt_all = d_cnt_local + cnt_local;
+    char *d_rec_local = d_cnt_all + cnt_local * (size_t)G, *d_rec_all = d_rec_local + recs_local;
+    // 1. ExtractSift for my views (local slots of max_pts records: scratch of this rank, never exchanged as such)
+    std::vector<int> my_counts((size_t)(cnt_local / sizeof(int)), 0);
     rc = sfm_extract_views(c->ctx, h_images, num_views, width, height, r, G, d_local, slot_bytes, max_pts, num_octaves, init_blur, thresh,
-                           lowest_scale, scale_up, nullptr);
+                           lowest_scale, scale_up, my_counts.data());
     if (rc != SFM_OK) return rc;
-    COMM_NCCL_TRY(ncclAllGather(d_local, d_all, local_bytes, ncclChar, c->nccl, stream));
-    std::vector<int> tails((size_t)slots * G);
-    COMM_HIP_TRY(hipMemcpy2DAsync(tails.data(), sizeof(int), d_all + rec_bytes, slot_bytes, sizeof(int), (size_t)slots * G, hipMemcpyDeviceToHost, stream));
+    // 2. the counts of all views: one all-gather of `slots` ints per rank (view v: rank v % G, slot v / G)
+    COMM_HIP_TRY(hipMemcpyAsync(d_cnt_local, my_counts.data(), cnt_local, hipMemcpyHostToDevice, stream));
+    COMM_NCCL_TRY(ncclAllGather(d_cnt_local, d_cnt_all, cnt_local, ncclChar, c->nccl, stream));
+    std::vector<int> all_counts((size_t)(cnt_local / sizeof(int)) * (size_t)G);
+    COMM_HIP_TRY(hipMemcpyAsync(all_counts.data(), d_cnt_all, cnt_local * (size_t)G, hipMemcpyDeviceToHost, stream));
     COMM_HIP_TRY(hipStreamSynchronize(stream));
-    auto slot_of = [&](int v) { return (size_t)(v % G) * slots + (size_t)(v / G); };
     std::vector<int> counts((size_t)num_views);
-    for (int v = 0; v < num_views; ++v) counts[(size_t)v] = tails[slot_of(v)];
+    std::vector<size_t> offset((size_t)num_views);
+    size_t total = 0;
+    for (int v = 0; v < num_views; ++v) {
+        int n = all_counts[(size_t)(v % G) * (cnt_local / sizeof(int)) + (size_t)(v / G)];
+        if (n < 0 || n > max_pts) return fail("sfm_process_views_sharded", "a rank reported a feature count outside [0, max_pts]");
+        counts[(size_t)v] = n;
+        offset[(size_t)v] = total;                                                   // multiples of 576: 16-byte aligned descriptors
+        total += (size_t)n * sizeof(sfm_sift_point);
+    }
     if (h_counts) std::memcpy(h_counts, counts.data(), counts.size() * sizeof(int));
+    if (total + 64 > c->feats_bytes) {
+        (void)sfm_ctx_synchronize(c->ctx);
+        if (c->d_feats) (void)sfm_device_free(c->ctx, c->d_feats);
+        c->d_feats = nullptr; c->feats_bytes = 0;
+        rc = sfm_device_alloc(c->ctx, total + 64, &c->d_feats);
+        if (rc != SFM_OK) return rc;
+        c->feats_bytes = total + 64;
+    }
+    char *d_all = static_cast<char *>(c->d_feats);
+    // 3. the features: every view's count x 576 bytes from its owner to everybody, one grouped operation
+    COMM_NCCL_TRY(ncclGroupStart());
+    for (int v = 0; v < num_views; ++v) {
+        const size_t nb = (size_t)counts[(size_t)v] * sizeof(sfm_sift_point);
+        if (nb == 0) continue;                                                       // a view without features ships nothing
+        const int owner = v % G;
+        char *dst = d_all + offset[(size_t)v];
+        const char *src = owner == r ? d_local + (size_t)(v / G) * slot_bytes : dst;
+        const ncclResult_t br = ncclBroadcast(src, dst, nb, ncclChar, owner, c->nccl, stream);
+        if (br != ncclSuccess) { (void)ncclGroupEnd(); return fail("ncclBroadcast", ncclGetErrorString(br)); }
+    }
+    COMM_NCCL_TRY(ncclGroupEnd());
+    c->last_feature_bytes = (uint64_t)total + (uint64_t)cnt_local * (uint64_t)G;
+    c->last_slot_bytes = (uint64_t)local_bytes * (uint64_t)G;
+    // 4. the pairs I own, 5. ONE all-gather of the fixed-size result records
     std::vector<sfm_pair_desc> descs((size_t)(num_pairs > 0 ? num_pairs : 1));
     for (int k = 0; k < num_pairs; ++k) {
         const int i = h_pairs[2 * k], j = h_pairs[2 * k + 1];
         if (i < 0 || i >= num_views || j < 0 || j >= num_views) return fail("sfm_process_views_sharded", "pair names a view out of range");
-        descs[(size_t)k].d_sift1 = reinterpret_cast<sfm_sift_point *>(d_all + slot_of(i) * slot_bytes); descs[(size_t)k].n1 = counts[(size_t)i];
-        descs[(size_t)k].d_sift2 = reinterpret_cast<const sfm_sift_point *>(d_all + slot_of(j) * slot_bytes); descs[(size_t)k].n2 = counts[(size_t)j];
+        descs[(size_t)k].d_sift1 = reinterpret_cast<sfm_sift_point *>(d_all + offset[(size_t)i]); descs[(size_t)k].n1 = counts[(size_t)i];
+        descs[(size_t)k].d_sift2 = reinterpret_cast<const sfm_sift_point *>(d_all + offset[(size_t)j]); descs[(size_t)k].n2 = counts[(size_t)j];
     }
     const int owned = num_pairs > r ? (num_pairs - r + G - 1) / G : 0;
     std::vector<float> mine((size_t)max_local * SFM_RECORD_FLOATS, -1.0f), all((size_t)max_local * SFM_RECORD_FLOATS * (size_t)G);

@@ -31,7 +31,7 @@ extern "C" {
 #pragma GCC visibility push(default)
 
 /* 1: rounds 1-3.  2: sfm_ransac_params.reserved[] must be zero, kernel id 3 and the probe / trace hooks moved to the lab-bench
- * flavour (include/sfm_amd_ab.h, libsfm_amd_ab.so); sfm_ctx_last_pairs_batched, sfm_exchange_* added. */
+ * flavour (include/sfm_amd_ab.h, libsfm_amd_ab.so); sfm_ctx_last_pairs_batched added; sfm_amd_comm.h: count-sized feature exchange, sfm_comm_last_exchange. */
 #define SFM_ABI_VERSION 2
 
 #define SFM_OK           0

@@ -45,7 +45,9 @@ int sfm_estimate_E_sharded_pipelined(sfm_pair *pair, sfm_ransac_params *p, sfm_c
 int sfm_comm_flush(sfm_comm *comm);
 
 /* BASELINE configs[4] over all ranks: many views -> ExtractSift (views dealt round-robin: rank r extracts r, r + G, ...) ->
- * ONE ncclAllGather of fixed-size feature slots -> per pair MatchSiftData + the Image_pair sequence on the rank that owns
+ * the feature exchange, sized by what exists: an ncclAllGather of the views' feature COUNTS (4 bytes per view), then every
+ * view's count x 576 bytes from its owner to all ranks into one compact buffer (a grouped ncclBroadcast per view; a view
+ * without features ships nothing) -> per pair MatchSiftData + the Image_pair sequence on the rank that owns
  * it (pairs r, r + G, ... of the list; sfm_process_pairs) -> ONE ncclAllGather of fixed-size result records.
  * h_images: num_views host images (width x height floats, grey 0..255); h_pairs: num_pairs x 2 view indices;
  * h_records: num_pairs x 28 floats on EVERY rank (layout of sfm_get_result; all -1 for a pair with too few features);
@@ -54,6 +56,11 @@ int sfm_process_views_sharded(sfm_comm *comm, const float h_K[9], const float h_
                               int width, int height, const int *h_pairs, int num_pairs, int max_pts, int num_octaves,
                               double init_blur, float thresh, float lowest_scale, int scale_up, uint32_t num_hypotheses,
                               int pose_mode, float *h_records, int *h_counts);
+
+/* What the feature exchange of the last sfm_process_views_sharded call moved INTO every rank: *feature_bytes = sum of count x 576
+ * over all views + the gathered counts; *slot_bytes (optional) = what an all-gather of max_pts-sized slots would have moved
+ * (the arrangement before ABI version 2). */
+int sfm_comm_last_exchange(const sfm_comm *comm, uint64_t *feature_bytes, uint64_t *slot_bytes);
 
 #pragma GCC visibility pop
 #ifdef __cplusplus

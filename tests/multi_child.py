@@ -87,7 +87,20 @@ vref, vcounts = S.process_views(ctx, views, K, Kinv, pairs=pairs, max_pts=4096, 
 vres, counts = comm.process_views(views, K, Kinv, pairs=pairs, max_pts=4096, sift=sift)
 ok = ok and counts == vcounts and sorted(vres) == sorted(vref) and len(vref) == len(pairs)
 ok = ok and all(np.array_equal(vres[k].view(np.uint32), vref[k].view(np.uint32)) for k in vref)
-stage("views_sharded_done", pairs=len(vres), counts=counts, records=sha(np.stack([vres[k] for k in sorted(vres)])) if vres else None, ok=bool(ok))
+moved, slots_eq = comm.last_exchange()
+ok = ok and sum(counts) * 576 <= moved <= 1.1 * sum(counts) * 576
+stage("views_sharded_done", pairs=len(vres), counts=counts, records=sha(np.stack([vres[k] for k in sorted(vres)])) if vres else None,
+      exchange_bytes=moved, slot_bytes_equivalent=slots_eq, ok=bool(ok))
+# the same job through the Python harness over torch.distributed (counts all_gather, per-view broadcast, records all_gather)
+def _gather(t):
+    out = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    dist.all_gather_into_tensor(out, t)
+    return out
+xs = {}
+tres, tcounts = S.process_views(ctx, views, K, Kinv, pairs=pairs, rank=rank, world=world, max_pts=4096, sift=sift,
+                                dist=dist if world > 1 else None, gather_results=_gather if world > 1 else None, device=dev, stats=xs)
+ok = ok and tcounts == vcounts and sorted(tres) == sorted(vref) and all(np.array_equal(tres[k].view(np.uint32), vref[k].view(np.uint32)) for k in vref)
+stage("views_torch_done", pairs=len(tres), exchange=xs, ok=bool(ok))
 t = torch.tensor([1 if ok else 0], dtype=torch.int64, device=dev)
 dist.all_reduce(t, op=dist.ReduceOp.MIN)
 diag["ok"] = bool(ok)

@@ -70,7 +70,7 @@ def test_mfma_score_into_leaves_the_key_in_caller_memory(gpu_ab):
     pair.ransac_score(p)
     want = pair.get_key()
     out = torch.full((1,), 5, dtype=torch.int64, device=dev)
-    pair.ransac_score_into(S.default_params(n, num_hypotheses=H, seed=4, kernel=S.KERNEL_MFMA), out)
+    pair.ransac_score(S.default_params(n, num_hypotheses=H, seed=4, kernel=S.KERNEL_MFMA), key_out=out)
     torch.cuda.synchronize()
     assert int(out.cpu().numpy().view(np.uint64)[0]) == want
 

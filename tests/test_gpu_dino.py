@@ -131,6 +131,45 @@ def test_dino_ring_of_36_views(gpu):
         assert res[pid][26] >= 8 and np.isfinite(res[pid][:25]).all()
 
 
+def test_dino_all_630_pairs_every_record_equals_the_oracle_chain(gpu):
+    """BASELINE configs[4], all 630 unordered pairs of the 36 dino frames, SWEPT: every pair's record out of the batched
+    sfm_process_pairs (many-matches launches, five launches for the rest of the chain) against the oracle chain on the same
+    features -- MatchC1 restatement (CudaSift/match.cu:57-71) -> fillXU -> estimateE (H = n/8) -> computePosecandidates ->
+    choosePose (src/main.cpp:282-307 per pair): best hypothesis, inlier count, E bit for bit, pose index, the chosen pose.
+    The match itself is compared pair by pair as well: sfm_match's index / score / ambiguity / match position fields against
+    the oracle's for all 630 pairs (the index arrays the batched launch feeds fillXU with are these)."""
+    torch, dev, ctx = gpu
+    from helpers import dino_frame
+    views = [read_pnm_grey(dino_frame(k)) for k in range(36)]
+    pairs = [(i, j) for i in range(36) for j in range(i + 1, 36)]
+    res, counts = S.process_views(ctx, views, DINO_K, DINO_KINV, pairs=pairs, max_pts=8192, sift=DINO_SIFT, device=dev)
+    assert ctx.last_pairs_batched() and sorted(res) == list(range(630))
+    feats = []
+    for v in views:                                            # the features the extractor delivers (its own parity: the tests above)
+        d, n, st = extract(gpu, v, 8192)
+        feats.append((d, n, d.cpu().numpy().view(O.SIFT_DTYPE).reshape(-1)[:n].copy()))
+    assert counts == [f[1] for f in feats]
+    bad = []
+    for pid, (i, j) in enumerate(pairs):
+        (di, ni, fi), (dj, nj, fj) = feats[i], feats[j]
+        om = O.match_sift(fi.copy(), fj)
+        ctx.match(di, ni, dj, nj)                              # writes view i's match fields (di is re-used: fillXU reads only positions)
+        gm = di.cpu().numpy().view(O.SIFT_DTYPE).reshape(-1)[:ni]
+        ok = np.array_equal(gm["match"], om["match"]) and all(same_bits(gm[f], om[f]) for f in ("score", "ambiguity", "match_xpos", "match_ypos"))
+        _, _, X0, X1 = O.fill_xu(om, DINO_KINV)
+        p = S.default_params(ni)
+        key, _, Ec = O.ransac_range(X0, X1, 0, p.num_hypotheses, p.threshold, p.jacobi_sweeps, seed=p.seed, want_E=True)
+        ocnt, ohyp = O.unpack_key(key)
+        oP = O.pose_candidates(Ec[ohyp], S.POSE_REFERENCE)
+        oind, oPinv, _, _ = O.choose_pose(X0, X1, oP, S.POSE_REFERENCE, 8)
+        r = res[pid]
+        ok = ok and same_bits(r[:9], Ec[ohyp]) and (int(r[26]), int(r[27])) == (ocnt, ohyp) and int(r[25]) == oind \
+            and same_bits(r[9:25], oPinv[oind].reshape(16))
+        if not ok:
+            bad.append((pid, i, j))
+    assert not bad, f"{len(bad)} of 630 pairs differ from the oracle chain, first: {bad[:5]}"
+
+
 def test_dino_extract_views_equals_single_extractions(gpu):
     """sfm_extract_views against sfm_extract_sift view by view: feature counts and every byte of the records, twelve frames,
     float and 8-bit images (eight per-view chains on eight streams, one worker thread each)."""

@@ -74,12 +74,15 @@ def test_match_sift_records(gpu):
 
 
 def test_match_full_size_properties(gpu):
-    """16384 x 16384 (match.cu benchmark size): permutation recovery + sampled oracle rows."""
+    """16384 x 16384 (match.cu benchmark size; the north_star size of the matcher): permutation recovery, and EVERY query's
+    (best, second, index) against the CPU restatement of MatchC1 (CudaSift/match.cu:57-71) bit for bit -- a sweep, not a sample:
+    the oracle matcher needs ~6 s for the 2.7e8 pairs."""
     n = 16384
     d1, d2, perm = synth.descriptors(n)
     b, s, i = run_soa(gpu, d2, d1)
     assert (i == perm).mean() > 0.99
     assert (b >= s).all() and (i >= 0).all()
-    rows = np.random.default_rng(1).integers(0, n, 64)
-    ob, os_, oi = O.match_desc(d2[rows], d1)
-    assert np.array_equal(i[rows], oi) and same_bits(b[rows], ob) and same_bits(s[rows], os_)
+    ob, os_, oi = O.match_desc(d2, d1)
+    bad = np.flatnonzero(i != oi)
+    assert bad.size == 0, f"{bad.size} of {n} indices differ, first queries {bad[:5]}"
+    assert same_bits(b, ob) and same_bits(s, os_)

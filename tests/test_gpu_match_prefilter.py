@@ -171,10 +171,12 @@ def test_fused_many_stages_duplicates_across_stages(gpu):
 
 
 def test_prefilter_full_size(gpu):
-    """16384 x 16384 (match.cu benchmark size): both matchers agree on every query; sampled oracle rows."""
+    """16384 x 16384 (match.cu benchmark size, the size north_star names for the matcher): EXACT, PREFILTER and FUSED agree on
+    every query, and all 16384 queries (best, second, index) equal the CPU oracle's MatchC1 restatement bit for bit -- the fp16
+    pre-filters are checked against the oracle on the whole set, not against the HIP path itself."""
     n = 16384
     d1, d2, perm = synth.descriptors(n)
-    b, s, i = check_both(gpu, d2, d1, oracle_rows=np.random.default_rng(1).integers(0, n, 64))
+    b, s, i = check_both(gpu, d2, d1)                          # oracle_rows=None: every row
     assert (i == perm).mean() > 0.99
 
 

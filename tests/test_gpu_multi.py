@@ -46,9 +46,10 @@ def test_pipelined_step_single_rank_equals_estimateE(gpu):
 
 
 def test_process_views_sharded_single_rank(gpu):
-    """sfm_process_views_sharded (configs[4] inside the C libraries: extract -> ncclAllGather of feature slots -> owned
-    pairs -> ncclAllGather of records) with a 1-rank communicator against process_views on the same synthetic views;
-    a pair list that is not the ring, and a second call with fewer views through the cached buffers."""
+    """sfm_process_views_sharded (configs[4] inside the C libraries: extract -> counts all-gather -> count-sized grouped
+    ncclBroadcast of every view's features -> owned pairs -> ncclAllGather of records) with a 1-rank communicator against
+    process_views on the same synthetic views, bit for bit; a pair list that is not the ring, a second call with fewer views
+    through the cached buffers; and the exchange moves what exists (sum of count x 576), not max_pts-sized slots."""
     torch, dev, ctx = gpu
     w, h = 384, 288
     base_d = np.array([5.0, 8.0, 12.0, 16.0, 7.0, 10.0], np.float32)
@@ -62,6 +63,9 @@ def test_process_views_sharded_single_rank(gpu):
     assert counts == rcounts and sorted(res) == sorted(ref) and len(ref) == len(pairs)
     for pid in ref:
         assert same_bits(res[pid], ref[pid]), f"pair {pid}"
+    moved, slots_eq = comm.last_exchange()
+    real = sum(counts) * 576
+    assert real <= moved <= 1.1 * real and slots_eq == len(views) * (4096 * 576 + 64) > real
     res2, counts2 = comm.process_views(views[:3], K, Kinv, max_pts=4096, sift=sift)
     ref2, _ = S.process_views(ctx, views[:3], K, Kinv, max_pts=4096, sift=sift, device=dev)
     assert counts2 == rcounts[:3] and all(same_bits(res2[k], ref2[k]) for k in ref2) and sorted(res2) == sorted(ref2)

@@ -135,6 +135,14 @@ def test_process_views_ring_from_images(gpu):
             assert np.abs(P[:3, :3] - np.eye(3)).max() < 0.03 and abs(abs(P[0, 3]) - 1.0) < 0.03
 
 
+def _view_count(v):
+    return 0 if v == 3 else (1 + (7 * v) % 5)                              # unequal counts, view 3 has no features at all
+
+
+def _view_body(v, nbytes):
+    return (np.arange(nbytes, dtype=np.int64) * (v + 1) % 251).astype(np.uint8)
+
+
 def _views_worker(rank, world, port, V, max_pts, q):
     import sys
     sys.path.insert(0, ROOT)
@@ -144,23 +152,20 @@ def _views_worker(rank, world, port, V, max_pts, q):
     slots = (V + world - 1) // world
     rec_bytes = max_pts * 576
     block = torch.zeros((slots, rec_bytes + 64), dtype=torch.uint8)
-    for slot, v in enumerate(range(rank, V, world)):                       # what process_views leaves in the local block
-        n = 10 + 3 * v                                                     # feature count of view v
-        body = (np.arange(rec_bytes, dtype=np.int64) * (v + 1) % 251).astype(np.uint8)
-        block[slot, :rec_bytes] = torch.from_numpy(body)
+    for slot, v in enumerate(range(rank, V, world)):                       # what sfm_extract_views leaves in the local block
+        n = _view_count(v)
+        block[slot, :rec_bytes] = torch.from_numpy(_view_body(v, rec_bytes))   # (bytes beyond count x 576 are stale scratch: never shipped)
         block[slot, rec_bytes:rec_bytes + 4] = torch.from_numpy(np.array([n], np.int32).view(np.uint8))
 
-    def gather(b):
-        out = torch.empty((world * b.shape[0],) + tuple(b.shape[1:]), dtype=b.dtype)
-        dist.all_gather_into_tensor(out, b)
-        return out
-
-    feats, counts = S.exchange_view_features(block, V, world, max_pts, gather)
-    ok = counts == [10 + 3 * v for v in range(V)]
+    feats, counts, offsets, stats = S.exchange_view_features(block, V, rank, world, max_pts, dist)
+    ok = counts == [_view_count(v) for v in range(V)]
+    real = sum(counts) * 576
+    ok = ok and feats.numel() == max(real, 1) and offsets == [sum(counts[:v]) * 576 for v in range(V)]
     for v in range(V):
-        row = feats[S.view_slot(v, world, slots)]
-        want = (np.arange(rec_bytes, dtype=np.int64) * (v + 1) % 251).astype(np.uint8)
-        ok = ok and np.array_equal(row[:rec_bytes].numpy(), want)
+        nb = counts[v] * 576
+        ok = ok and np.array_equal(feats[offsets[v]:offsets[v] + nb].numpy(), _view_body(v, rec_bytes)[:nb])
+    # bytes on the wire: what exists (+ the counts), not max_pts-sized slots
+    ok = ok and real <= stats["feature_bytes"] <= 1.1 * real and stats["slot_bytes"] == world * slots * (rec_bytes + 64) > 4 * real
     # the pair schedule on top of it: every pair owned by exactly one rank, both of its views present on that rank
     pairs = S.ring_pairs(V)
     mine = S.pair_schedule(len(pairs), rank, world)
@@ -170,13 +175,15 @@ def _views_worker(rank, world, port, V, max_pts, q):
 
 @pytest.mark.parametrize("V", [5, 8])
 def test_two_rank_feature_exchange_of_process_views(V):
-    """The ONE collective between extraction and pairing (exchange_view_features) with real slot contents, world 2, gloo:
-    after the all-gather every rank finds every view's records and feature count at view_slot(), also when the views do
-    not divide evenly over the ranks (the spare slot stays empty); the ring pairs are dealt without overlap."""
+    """The feature exchange between extraction and pairing (exchange_view_features) with real slot contents, world 2, gloo:
+    unequal feature counts, one view with NO features, views that do not divide evenly over the ranks.  After the exchange
+    every rank holds every view's count x 576 bytes back to back in view order, the counts of all views, and what crossed the
+    wire is at most 1.1 x the bytes that exist (the max_pts-sized slots of the earlier all-gather were 4.6 x on the dino ring);
+    the ring pairs are dealt without overlap."""
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_views_worker, args=(r, 2, port, V, 4, q)) for r in range(2)]
+    procs = [ctx.Process(target=_views_worker, args=(r, 2, port, V, 16, q)) for r in range(2)]
     for p in procs: p.start()
     res = sorted(q.get(timeout=120) for _ in procs)
     for p in procs:
@@ -184,3 +191,14 @@ def test_two_rank_feature_exchange_of_process_views(V):
     assert all(r[1] for r in res)
     assert sorted(res[0][2] + res[1][2]) == list(range(V)) and not set(res[0][2]) & set(res[1][2])
     assert res[0][3] == res[1][3]
+
+
+def test_single_rank_exchange_is_the_block_itself():
+    import cuda_sfm_amd as S
+    V, max_pts = 3, 4
+    block = torch.zeros((V, max_pts * 576 + 64), dtype=torch.uint8)
+    for v in range(V):
+        block[v, max_pts * 576:max_pts * 576 + 4] = torch.from_numpy(np.array([v + 1], np.int32).view(np.uint8))
+    feats, counts, offsets, stats = S.exchange_view_features(block, V, 0, 1, max_pts)
+    assert counts == [1, 2, 3] and offsets == [v * (max_pts * 576 + 64) for v in range(V)]
+    assert feats.data_ptr() == block.data_ptr() and stats["feature_bytes"] == 0
