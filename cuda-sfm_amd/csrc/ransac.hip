@@ -45,7 +45,7 @@ void ransac_solve_lanes(const float *__restrict__ X0, const float *__restrict__ 
 {
     reset_keys(zero_key, zero_key2);
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (zero_ticks && i < nzero) zero_ticks[i] = 0u;
+    if (zero_ticks) for (uint32_t w = i; w < nzero; w += gridDim.x * blockDim.x) zero_ticks[w] = 0u;
     if (i >= count) return;
     if (zero_counts) zero_counts[i] = 0;                    // tile-parallel scoring accumulates into counts[] with atomics
     float E[9];
@@ -69,7 +69,8 @@ void ransac_solve_lanes1_qr(const float *__restrict__ X0, const float *__restric
 {
     reset_keys(zero_key, zero_key2);
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (zero_ticks && i < nzero) zero_ticks[i] = 0u;
+    // the pre-filter kernel's per-hypothesis accumulators (two words each: count | tiles arrived), cleared here
+    if (zero_ticks) for (uint32_t w = i; w < nzero; w += gridDim.x * blockDim.x) zero_ticks[w] = 0u;
     if (i >= count) return;
     if (zero_counts) zero_counts[i] = 0;
     int idx[8];
@@ -110,7 +111,7 @@ void ransac_solve_lanes2(const float *__restrict__ X0, const float *__restrict__
 {
     reset_keys(zero_key, zero_key2);
     const uint32_t i = 2u * (blockIdx.x * blockDim.x + threadIdx.x);
-    if (zero_ticks && (i >> 1) < nzero) zero_ticks[i >> 1] = 0u;          // the pre-filter kernel's per-group tickets
+    if (zero_ticks) for (uint32_t w = i >> 1; w < nzero; w += gridDim.x * blockDim.x) zero_ticks[w] = 0u;   // the pre-filter kernel's accumulators
     if (i >= count) return;
     const uint32_t j = (i + 1 < count) ? i + 1 : i;         // odd count: the last lane solves its hypothesis twice
     if (zero_counts) { zero_counts[i] = 0; zero_counts[j] = 0; }   // tile-parallel scoring accumulates into counts[] with atomics
@@ -268,8 +269,8 @@ void ransac_argmax_counts(const int *__restrict__ counts, uint32_t h0, uint32_t 
 // ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
-// tickets of the pre-filter kernel: one per 32-hypothesis group
-static size_t tick_words(size_t count) { return count / kPfGroup + 2; }
+// accumulators of the pre-filter kernel: one 64-bit word per hypothesis (count | tiles arrived)
+static size_t tick_words(size_t count) { return 2 * count + 64; }
 
 static int ensure_hyp_capacity(sfm_pair *pair, size_t count)
 {
@@ -375,15 +376,16 @@ int launch_ransac_score(sfm_pair *pair, const sfm_ransac_params &p, uint32_t h0,
     const bool timed = ctx->timing && ctx->tcount < sfm_ctx::kTimingSlots;
     hipEvent_t *tev = timed ? ctx->tev[ctx->tcount] : nullptr;
     if (timed) SFM_HIP_TRY(hipEventRecord(tev[0], ctx->stream));
-    int *zero_counts = (grid2d || prefilter) ? pair->d_counts : nullptr;
+    const bool pf_tickets = prefilter && (SFM_SW(p, 3) == 2 || SFM_SW(p, 3) == 17);      // (AB build: kernels that sum into counts[] and draw tickets)
+    int *zero_counts = (grid2d || pf_tickets) ? pair->d_counts : nullptr;
     const float4 *pts4 = (pair->have_pts4 && SFM_SW(p, 0) != 4) ? pair->d_pts4 : nullptr;      // (AB build, reserved[0] == 4: scattered gathers)
-    // pre-filter kernel: tickets (one per 32-hypothesis group), cleared by the solve kernel's first threads (or by a memset
-    // when there are fewer threads than words); its per-hypothesis records come from the lane-solve kernel itself on the
-    // default path, from pf_prep_kernel otherwise
+    // pre-filter kernel: one 64-bit accumulator per hypothesis (count | tiles arrived; round 3: a ticket per 32 hypotheses next to
+    // zeroed counts), cleared by the solve kernel (or by a memset when there is none); its per-hypothesis records come from the
+    // lane-solve kernel itself on the default path, from pf_prep_kernel otherwise
     const bool pf_r2 = prefilter && SFM_SW(p, 3) == 2;                   // (AB build) the round-2 kernel: builds its operands itself
-    const uint32_t nzero = prefilter ? (count + (uint32_t)kPfGroup - 1u) / (uint32_t)kPfGroup : 0u;
+    const uint32_t nzero = !prefilter ? 0u : (pf_tickets ? (count + (uint32_t)kPfGroup - 1u) / (uint32_t)kPfGroup : 2u * count);
     uint32_t *zero_ticks = prefilter ? pair->d_tick : nullptr;
-    if (prefilter && (d_E_given || nzero > count / 2u)) {
+    if (prefilter && d_E_given) {
         SFM_HIP_TRY(hipMemsetAsync(pair->d_tick, 0, (size_t)nzero * sizeof(uint32_t), ctx->stream));
         zero_ticks = nullptr;
     }

@@ -128,7 +128,11 @@ __device__ __forceinline__ void mfma_step(const PfFrags &a, const PfFrags &b, f1
         __builtin_amdgcn_sched_group_barrier(0x002, 11, 0);             \
     } while (0)
 
-template <int W>
+// VAR (AB build only; the product instantiates VAR = 0): bit 0 = round 3's epilogue -- partial counts summed into counts[] with
+// atomics, a ticket per 32-hypothesis group, the last wavefront re-reads the counts (two dependent round trips per pass).
+constexpr int kPfVarTickets = 1;
+
+template <int W, int VAR = 0>
 __global__ __launch_bounds__(W * 64)
 void ransac_score_prefilter(const float *__restrict__ X0, const float *__restrict__ X1, int ld, int n,
                             const float *__restrict__ Ecand, const PfRecord *__restrict__ recs, uint32_t h0, uint32_t count, float thr,
@@ -364,6 +368,7 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
         uint32_t key0n = 0u;
         if (have_next) fetch_pass(ps_next, afrag_next, key0n, e_row);
         while (nq > 0) flush(min(nq, 64));
+        if (VAR & kPfVarTickets) {
         // LDS counters -> counts[] (zeroed by the solve kernel); a wavefront's LDS operations complete in order
         if (lane < nvalid) {
             const int c = cnt[lane];
@@ -374,8 +379,6 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
         // Ordering: the counts are touched by device-scope atomics only (no cached copies to write back or invalidate), so
         // it is enough that this wavefront's count atomics have been acknowledged (vmcnt also tracks atomics without return
         // on gfx9) before its ticket is issued, and that the reader's atomic loads are issued after its ticket came back.
-        // A full release fence here writes this XCD's L2 back (119 -> 190 us per 131072-hypothesis launch, round 2);
-        // tests/test_gpu_prefilter.py::test_prefilter_tickets_under_contention exercises the assumption every round.
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         uint32_t t = 0;
         if (lane == 0) t = atomicAdd(&tick[ps], 1u);
@@ -396,14 +399,53 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
                 if (best_key2) atomicMax(best_key2, k);
             }
         }
+        } else {
+        // LDS counters -> the hypothesis' accumulator in global memory: ONE 64-bit atomic per hypothesis adds this tile's count
+        // to the low word and 1 to the high word and returns what was there -- the lane that finds ntiles - 1 tiles already
+        // arrived holds the hypothesis' FINAL count (old sum + its own), stores it to counts[] and owns its arg-max key.  One
+        // round trip per pass (round 3: count atomics, wait, a ticket, wait, then re-read the counts) and no ordering argument:
+        // the sum and the arrival count travel in the same word.  The accumulators are zeroed by the solve kernel; counts[]
+        // needs no clearing (every hypothesis is completed exactly once per launch).
+        // The round trip is covered by installing the next pass (its operands were requested before the drain): E rows and
+        // counters into LDS, fragments into place; the answer is looked at after that.
+        uint32_t c_mine = 0u;
+        unsigned long long old = 0ull;
+        if (lane < nvalid) {
+            c_mine = (uint32_t)cnt[lane];
+            unsigned long long *acc = reinterpret_cast<unsigned long long *>(tick) + (h_first + (uint32_t)lane);
+            old = atomicAdd(acc, (1ull << 32) | (unsigned long long)c_mine);
+        }
+        const int nvalid_done = nvalid;
+        const uint32_t h_done = h_first;
+        if (have_next) { afrag = afrag_next; key0 = key0n; install_rows(e_row); }
+        unsigned long long k = 0;
+        if (lane < nvalid_done && (uint32_t)(old >> 32) == gridDim.y - 1u) {
+            const uint32_t total = (uint32_t)old + c_mine;
+            counts[h_done + lane] = (int)total;
+            k = pack_key(total, h0 + h_done + (uint32_t)lane);
+        }
+        // arg-max: keys of the hypotheses completed here (first maximum: highest count, lowest id), folded over the wavefront;
+        // the shard's key is only touched when this one beats what it was seen to hold (a stale, i.e. smaller, value read
+        // there costs an atomic, never a result: the key only grows)
+        if (__ballot(k != 0ull) != 0ull) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const unsigned long long o = __shfl_xor(k, off);
+                k = o > k ? o : k;
+            }
+            if (lane == 0 && k > __hip_atomic_load(best_key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                atomicMax(best_key, k);
+                if (best_key2) atomicMax(best_key2, k);
+            }
+        }
+        }
         PF_PHASE(5);
         ++passes_done;
         // install the next pass
         have = have_next;
         if (have_next) {
             ps = ps_next;
-            afrag = afrag_next; key0 = key0n;
-            install_rows(e_row);
+            if (VAR & kPfVarTickets) { afrag = afrag_next; key0 = key0n; install_rows(e_row); }     // (otherwise installed above, under the accumulator's round trip)
         }
     }
     if (probe) { clk[6] = passes_done; clk[0] = clock64() - c0; clk[1] = wall_clock64() - w0; }
@@ -586,13 +628,6 @@ int launch_score_prefilter(sfm_pair *pair, const sfm_ransac_params &p, uint32_t 
     // per SIMD, which leaves a quarter of the registers to the lane-solve kernel of the NEXT step when steps are pipelined
     // on two streams (profiles/r03_waves_ab.txt)
     const int waves = SFM_SW(p, 1) == 5 ? 12 : kPfWaves;
-#if SFM_AB
-    const void *fn = waves == 12 ? reinterpret_cast<const void *>(&ransac_score_prefilter<12>) : reinterpret_cast<const void *>(&ransac_score_prefilter<16>);
-#else
-    const void *fn = reinterpret_cast<const void *>(&ransac_score_prefilter<16>);
-#endif
-    const int rc_lds = allow_big_lds(ctx, fn);
-    if (rc_lds != SFM_OK) return rc_lds;
     const int ntiles = prefilter_tiles(pair);
     const uint32_t npass = (count + (uint32_t)kPfGroup - 1u) / (uint32_t)kPfGroup;
     const uint32_t iters = (npass + (uint32_t)waves - 1) / (uint32_t)waves;       // block iterations per tile
@@ -604,16 +639,24 @@ int launch_score_prefilter(sfm_pair *pair, const sfm_ransac_params &p, uint32_t 
     if (cols > iters) cols = iters;
     if (cols < 1) cols = 1;
     const int dynamic = SFM_SW(p, 1) == 2 ? 0 : 1;                               // (AB build, reserved[1] == 2: static striding)
-#if SFM_AB
-    if (waves == 12)
-        hipLaunchKernelGGL(ransac_score_prefilter<12>, dim3(cols, ntiles), dim3(12 * 64), kPfLdsBytes, ctx->stream,
+    const int var = SFM_SW(p, 3) >= 16 ? SFM_SW(p, 3) - 16 : 0;                 // (AB build, reserved[3] = 16 + VAR bits)
+    auto launch = [&](auto kernel) -> int {
+        const int rc_lds = allow_big_lds(ctx, reinterpret_cast<const void *>(kernel));
+        if (rc_lds != SFM_OK) return rc_lds;
+        hipLaunchKernelGGL(kernel, dim3(cols, ntiles), dim3(waves * 64), kPfLdsBytes, ctx->stream,
                            pair->d_X[0], pair->d_X[1], pair->ld, pair->n, pair->d_Ecand, reinterpret_cast<const PfRecord *>(pair->d_pf), h0, count, p.threshold,
                            dynamic, pair->d_counts, pair->d_tick, pair->d_key, key2, pair->d_clk);
+        return SFM_OK;
+    };
+    int rcl;
+#if SFM_AB
+    if (waves == 12) rcl = launch(&ransac_score_prefilter<12, 0>);
+    else if (var == 1) rcl = launch(&ransac_score_prefilter<16, 1>);
     else
 #endif
-        hipLaunchKernelGGL(ransac_score_prefilter<16>, dim3(cols, ntiles), dim3(16 * 64), kPfLdsBytes, ctx->stream,
-                           pair->d_X[0], pair->d_X[1], pair->ld, pair->n, pair->d_Ecand, reinterpret_cast<const PfRecord *>(pair->d_pf), h0, count, p.threshold,
-                           dynamic, pair->d_counts, pair->d_tick, pair->d_key, key2, pair->d_clk);
+    rcl = launch(&ransac_score_prefilter<16, 0>);
+    (void)var;
+    if (rcl != SFM_OK) return rcl;
     SFM_HIP_TRY(hipGetLastError());
     pair->last_grid = (int)cols * ntiles; pair->last_block = waves * 64; pair->last_lds = kPfLdsBytes;
     return SFM_OK;

@@ -6,8 +6,8 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
-import cuda_sfm_amd as S
-from cuda_sfm_amd import synth
+import cuda_sfm_amd_ab as S            # the lab-bench flavour (make ab): switches, probes, traces
+from cuda_sfm_amd_ab import synth
 
 dev = torch.device("cuda", 0)
 ctx = S.Context(0, torch.cuda.current_stream().cuda_stream)

@@ -11,8 +11,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
-import cuda_sfm_amd as S
-from cuda_sfm_amd import synth
+import cuda_sfm_amd_ab as S            # the lab-bench flavour (make ab): switches, probes, traces
+from cuda_sfm_amd_ab import synth
 
 cases = json.loads(sys.argv[1])
 dev = torch.device("cuda:0")

@@ -1,8 +1,8 @@
 import sys, os
 ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo"); sys.path.insert(0, ROOT)
 import numpy as np, torch
-import cuda_sfm_amd as S
-from cuda_sfm_amd import synth
+import cuda_sfm_amd_ab as S            # the lab-bench flavour (make ab): switches, probes, traces
+from cuda_sfm_amd_ab import synth
 dev = torch.device("cuda:0"); ctx = S.Context(0, torch.cuda.current_stream().cuda_stream)
 n, H = 4096, 1 << 20
 sc = synth.two_view_scene(n)

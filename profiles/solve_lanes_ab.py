@@ -3,8 +3,8 @@ import os, sys, json
 import numpy as np
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import torch
-import cuda_sfm_amd as S
-from cuda_sfm_amd import synth
+import cuda_sfm_amd_ab as S            # the lab-bench flavour (make ab): switches, probes, traces
+from cuda_sfm_amd_ab import synth
 dev = torch.device("cuda", 0)
 ctx = S.Context(0, torch.cuda.current_stream().cuda_stream)
 n = 4096
