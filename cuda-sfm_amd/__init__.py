@@ -19,7 +19,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # sfm_ransac_params.reserved[], the recorded slower kernel variants, the probe / trace hooks of include/sfm_amd_ab.h).  The lab
 # bench is what `import cuda_sfm_amd_ab` binds -- tests/ and profiles/ only.
 AB = __name__.endswith("_ab")
-LIB_PATH = os.path.join(_HERE, "lib", "libsfm_amd_ab.so" if AB else "libsfm_amd.so")
+# SFM_AMD_LIB_DIR: another build of the same ABI (profiles/: same-box A/B of two commits); never set by tests or bench.py itself
+LIB_PATH = os.path.join(os.environ.get("SFM_AMD_LIB_DIR") or os.path.join(_HERE, "lib"), "libsfm_amd_ab.so" if AB else "libsfm_amd.so")
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(

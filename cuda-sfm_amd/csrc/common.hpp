@@ -138,7 +138,7 @@ struct sfm_pair {
     int   *d_counts = nullptr;
     uint32_t *d_tick = nullptr;        // pre-filter kernel: per 32-hypothesis group, how many tiles have been added
     float *d_Ecand = nullptr;
-    void *d_pf = nullptr;              // pre-filter kernel: one PfRecord (112 bytes, prefilter_record.hpp) per hypothesis of the shard
+    void *d_pf = nullptr;              // pre-filter kernel: one PfRecord (64 bytes, prefilter_record.hpp) per hypothesis of the shard
     unsigned long long *d_bound = nullptr; // (fillXU epoch << 32) | bits of the largest |coordinate| <= 48 over all points: atomicMax, never reset
     uint32_t bound_epoch = 0;
     bool have_bound = false;           // d_bound describes the current points (fillXU)

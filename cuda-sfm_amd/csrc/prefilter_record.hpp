@@ -1,11 +1,20 @@
 // prefilter_record.hpp -- what the matrix-core pre-filter needs to know about ONE hypothesis, built once per hypothesis
-// (by the lane-solve kernel, or by pf_prep_kernel) and read by ransac_score_prefilter once per (hypothesis, tile):
-//   frag[0..5]  the 48 fp16 coefficient slots of prefilter_hyp_slots in MFMA A-fragment order: {n k-step 0, n k-step 1, G}
-//               x {k-slots 0..7 (what MFMA lanes 0..31 hold), k-slots 8..15 (lanes 32..63)}
-//   keys[0]     the zero-divisor state (prefilter_math.hpp (3)): 0 = no point of the pair can zero the first divisor of
-//               this hypothesis -- prefilter_zero_divisor_cells says so outright, or names at most 2 x 2 grid cells and none
-//               of them is occupied in the pair's cell table (pf_cells_build_kernel: the cells of ALL points, built once
-//               per fillXU); kPfKeyScan = cannot tell, every tile checks all its points for this hypothesis (~0.5 %).
+// (by the lane-solve kernel, or by pf_prep_kernel) and read by ransac_score_prefilter once per (hypothesis, tile).
+//
+// 64 bytes: the 30 DISTINCT fp16 values behind the 48 coefficient slots of prefilter_hyp_slots (a product term's slots are
+// (E_hi, E_hi, E_lo) against (f_hi, f_lo, f_hi) of the point: the duplicate is rebuilt with a byte permute when the record is
+// read) + the zero-divisor flag, split by which half of the wavefront needs them -- an MFMA A fragment holds k-slots 0..7 in
+// lanes 0..31 and k-slots 8..15 in lanes 32..63, so a lane reads the 32 bytes of its half and nothing else:
+//   lo[16] (lanes 0..31):  h0 m0 | h1 m1 | h2 h5 | m5 h6 | m6 h7 | m7 H0 | M0 H1 | M1 H2
+//   hi[16] (lanes 32..63): m2 h3 | m3 h4 | m4 h5 | e8h e8m | e8l FLAG | M2 H3 | M3 H4 | M4 cst
+// with (h_i, m_i) the two fp16 parts of n's coefficient i (order e0 e1 e3 e4 e2 e5 e6 e7), (e8h, e8m, e8l) the three parts of e8,
+// (H_j, M_j) the parts of G's coefficient j and cst its constant slot (prefilter_math.hpp).  Until round 4 the record held the 48
+// slots as they sit in the fragments plus four key words: 112 bytes per hypothesis written by the solve kernel and read by
+// every tile's block -- 117 of the 264 MB a 2^20-hypothesis step moved.
+//   FLAG    the zero-divisor state (prefilter_math.hpp (3)): 0 = no point of the pair can zero the first divisor of
+//           this hypothesis -- prefilter_zero_divisor_cells says so outright, or names at most 2 x 2 grid cells and none
+//           of them is occupied in the pair's cell table (pf_cells_build_kernel: the cells of ALL points, built once
+//           per fillXU); kPfFlagScan = cannot tell, every tile checks all its points for this hypothesis (~0.5 %).
 // The bound B is over ALL points of the pair (fill_xu_kernel), so the record serves every tile; with B >= the bound of a
 // tile every error bound of prefilter_math.hpp only grows, i.e. the rule stays conservative.
 #pragma once
@@ -16,16 +25,13 @@ namespace sfm {
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 
 constexpr int kPfGroup = 32;                       // hypotheses per pass of a scoring wavefront (one MFMA row block)
-constexpr uint32_t kPfKeyScan = 0xFFFFFFFFu;       // pf_cell_key never returns it (bit 31 is cleared there)
+constexpr unsigned short kPfFlagScan = 0x3C00u;    // "check every point" (any non-zero pattern would do; this one is fp16 1.0)
 
 struct alignas(16) PfRecord {
-    union {
-        h8 frag[6];
-        unsigned short raw[48];
-    };
-    uint32_t keys[4];
+    unsigned short lo[16];          // what lanes 0..31 of the scoring wavefront read
+    unsigned short hi[16];          // what lanes 32..63 read
 };
-static_assert(sizeof(PfRecord) == 112, "7 x 16 bytes per hypothesis");
+static_assert(sizeof(PfRecord) == 64, "4 x 16 bytes per hypothesis");
 
 #if defined(__HIPCC__)
 // Slot of a key in an open-addressing table of `mask + 1` (a power of two) words, 0 = empty.
@@ -56,17 +62,48 @@ __device__ __forceinline__ void pf_prep_store(const float e[9], float thr, float
                     }
                 }
     }
-    const uint32_t k[4] = { scan ? kPfKeyScan : 0u, 0u, 0u, 0u };
+    auto bits = [](_Float16 v) { return __builtin_bit_cast(unsigned short, v); };
+    // n: term i at slots (3i, 3i + 1, 3i + 2) = (h_i, h_i, m_i); e8 at 24..26; G: term j at (3j, 3j + 1, 3j + 2) = (H_j, H_j, M_j), cst at 15
+    const unsigned short lo[16] = { bits(ns[0]), bits(ns[2]), bits(ns[3]), bits(ns[5]), bits(ns[6]), bits(ns[15]), bits(ns[17]), bits(ns[18]),
+                                    bits(ns[20]), bits(ns[21]), bits(ns[23]), bits(ts[0]), bits(ts[2]), bits(ts[3]), bits(ts[5]), bits(ts[6]) };
+    const unsigned short hi[16] = { bits(ns[8]), bits(ns[9]), bits(ns[11]), bits(ns[12]), bits(ns[14]), bits(ns[15]), bits(ns[24]), bits(ns[25]),
+                                    bits(ns[26]), (unsigned short)(scan ? kPfFlagScan : 0u), bits(ts[8]), bits(ts[9]), bits(ts[11]), bits(ts[12]), bits(ts[14]), bits(ts[15]) };
+    uint4 q[4];
 #pragma unroll
-    for (int g = 0; g < 3; ++g)
-#pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-            h8 c;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) c[j] = g < 2 ? ns[g * 16 + hh * 8 + j] : ts[hh * 8 + j];
-            out->frag[2 * g + hh] = c;
-        }
-    *reinterpret_cast<uint4 *>(out->keys) = make_uint4(k[0], k[1], k[2], k[3]);
+    for (int w = 0; w < 8; ++w) {
+        reinterpret_cast<uint32_t *>(q)[w] = (uint32_t)lo[2 * w] | ((uint32_t)lo[2 * w + 1] << 16);
+        reinterpret_cast<uint32_t *>(q)[8 + w] = (uint32_t)hi[2 * w] | ((uint32_t)hi[2 * w + 1] << 16);
+    }
+    uint4 *dst = reinterpret_cast<uint4 *>(out);
+    dst[0] = q[0]; dst[1] = q[1]; dst[2] = q[2]; dst[3] = q[3];
+}
+
+// The three A fragments of a lane (its half's 8 k-slots of n k-step 0, n k-step 1 and G) out of the 32 bytes of its half of the
+// record (two 16-byte loads: r0 = words 0..3, r1 = words 4..7), and the zero-divisor flag (upper half only; 0 in the lower).
+__device__ __forceinline__ uint32_t pf_pick(uint32_t a, int ia, uint32_t b, int ib)          // (a's half ia, b's half ib) -> one word
+{
+    return __builtin_amdgcn_perm(b, a, (uint32_t)(2 * ia) | ((uint32_t)(2 * ia + 1) << 8) | ((uint32_t)(4 + 2 * ib) << 16) | ((uint32_t)(5 + 2 * ib) << 24));
+}
+
+__device__ __forceinline__ void pf_record_expand(const uint4 r0, const uint4 r1, int half, h8 &n0, h8 &n1, h8 &t, uint32_t &flag)
+{
+    uint32_t o[12];
+    if (half == 0) {
+        const uint32_t A0 = r0.x, A1 = r0.y, A2 = r0.z, A3 = r0.w, A4 = r1.x, A5 = r1.y, A6 = r1.z, A7 = r1.w;
+        o[0] = pf_pick(A0, 0, A0, 0); o[1] = pf_pick(A0, 1, A1, 0); o[2] = A1;                  o[3] = pf_pick(A2, 0, A2, 0);     // h0 h0 | m0 h1 | h1 m1 | h2 h2
+        o[4] = pf_pick(A2, 1, A3, 0); o[5] = pf_pick(A3, 1, A3, 1); o[6] = A4;                  o[7] = pf_pick(A4, 1, A5, 0);     // h5 m5 | h6 h6 | m6 h7 | h7 m7
+        o[8] = pf_pick(A5, 1, A5, 1); o[9] = A6;                  o[10] = pf_pick(A6, 1, A7, 0); o[11] = pf_pick(A7, 1, A7, 1);    // H0 H0 | M0 H1 | H1 M1 | H2 H2
+        flag = 0u;
+    } else {
+        const uint32_t B0 = r0.x, B1 = r0.y, B2 = r0.z, B3 = r0.w, B4 = r1.x, B5 = r1.y, B6 = r1.z, B7 = r1.w;
+        o[0] = B0;                  o[1] = pf_pick(B0, 1, B1, 0); o[2] = pf_pick(B1, 1, B1, 1); o[3] = B2;                          // m2 h3 | h3 m3 | h4 h4 | m4 h5
+        o[4] = B3;                  o[5] = (B4 & 0xFFFFu) | 0x3C000000u; o[6] = 0u;              o[7] = 0u;                          // e8h e8m | e8l 1 | 0 0 | 0 0
+        o[8] = B5;                  o[9] = pf_pick(B5, 1, B6, 0); o[10] = pf_pick(B6, 1, B6, 1); o[11] = B7;                         // M2 H3 | H3 M3 | H4 H4 | M4 cst
+        flag = B4 >> 16;
+    }
+    n0 = __builtin_bit_cast(h8, uint4{ o[0], o[1], o[2], o[3] });
+    n1 = __builtin_bit_cast(h8, uint4{ o[4], o[5], o[6], o[7] });
+    t = __builtin_bit_cast(h8, uint4{ o[8], o[9], o[10], o[11] });
 }
 #endif
 

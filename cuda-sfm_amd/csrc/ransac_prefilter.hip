@@ -174,11 +174,10 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
     auto fetch_pass = [&](uint32_t pass, PfFrags &af, uint32_t &k0, float (&e)[9]) {
         const uint32_t hf = pass * (uint32_t)kPfGroup;
         const uint32_t h = hf + (uint32_t)min(row, (int)min((uint32_t)kPfGroup, count - hf) - 1);
-        const PfRecord *r = recs + h;
-        af.n0 = r->frag[0 + half]; af.n1 = r->frag[2 + half]; af.t = r->frag[4 + half];
-        k0 = 0u;
+        const uint4 *r = reinterpret_cast<const uint4 *>(recs + h) + 2 * half;        // this lane's half of the record: 32 bytes
+        const uint4 r0 = r[0], r1 = r[1];
+        pf_record_expand(r0, r1, half, af.n0, af.n1, af.t, k0);
         if (half == 0) {
-            k0 = r->keys[0];
             const float *src = Ecand + 9 * (size_t)h;
 #pragma unroll
             for (int k = 0; k < 9; ++k) e[k] = src[k];
@@ -272,7 +271,7 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
         // vanish in a grid cell that some point of the pair occupies, or no small set of cells could be named) is checked
         // against every point of the tile, one hypothesis at a time by the whole wavefront
         {
-            const bool scan = key0 == kPfKeyScan;
+            const bool scan = key0 != 0u;                               // (the flag sits in the upper half's part of the record)
             const unsigned long long sm = __ballot(scan);
             uint32_t todo = (uint32_t)sm | (uint32_t)(sm >> 32);
             uint32_t survive = 0u;                                      // rows whose pairs must all survive in this tile
@@ -368,6 +367,7 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
         uint32_t key0n = 0u;
         if (have_next) fetch_pass(ps_next, afrag_next, key0n, e_row);
         while (nq > 0) flush(min(nq, 64));
+        PF_PHASE(7);
         if (VAR & kPfVarTickets) {
         // LDS counters -> counts[] (zeroed by the solve kernel); a wavefront's LDS operations complete in order
         if (lane < nvalid) {
@@ -555,17 +555,19 @@ void pf_probe_kernel(const float *__restrict__ E, float thr, float B, PfScales s
     __threadfence();
     __syncthreads();
     _Float16 ns[kPfSlots], ts[kPfSlotsT], bn[kPfSlots], bt[kPfSlotsT];
-    const volatile PfRecord *vr = rec;
+    {   // both halves of the record through the very expansion the scoring kernel uses
+        const volatile uint4 *vr = reinterpret_cast<const volatile uint4 *>(rec);
+        uint4 w[4];
 #pragma unroll
-    for (int g = 0; g < 2; ++g)
+        for (int q = 0; q < 4; ++q) { w[q].x = vr[q].x; w[q].y = vr[q].y; w[q].z = vr[q].z; w[q].w = vr[q].w; }
 #pragma unroll
-        for (int hh = 0; hh < 2; ++hh)
+        for (int hh = 0; hh < 2; ++hh) {
+            h8 f0, f1, ft; uint32_t fl;
+            pf_record_expand(w[2 * hh], w[2 * hh + 1], hh, f0, f1, ft, fl);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) ns[g * 16 + hh * 8 + j] = __builtin_bit_cast(_Float16, vr->raw[(2 * g + hh) * 8 + j]);
-#pragma unroll
-    for (int hh = 0; hh < 2; ++hh)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) ts[hh * 8 + j] = __builtin_bit_cast(_Float16, vr->raw[(4 + hh) * 8 + j]);
+            for (int j = 0; j < 8; ++j) { ns[hh * 8 + j] = f0[j]; ns[16 + hh * 8 + j] = f1[j]; ts[hh * 8 + j] = ft[j]; }
+        }
+    }
     if (survive_all) {
 #pragma unroll
         for (int k = 0; k < kPfSlots; ++k) ns[k] = (_Float16)0.0f;
@@ -631,10 +633,11 @@ int launch_score_prefilter(sfm_pair *pair, const sfm_ransac_params &p, uint32_t 
     const int ntiles = prefilter_tiles(pair);
     const uint32_t npass = (count + (uint32_t)kPfGroup - 1u) / (uint32_t)kPfGroup;
     const uint32_t iters = (npass + (uint32_t)waves - 1) / (uint32_t)waves;       // block iterations per tile
-    // one block per CU is resident (152 KiB of LDS), so the grid is one block per CU, spread over the tiles; with more tiles
-    // than that gives columns for, two blocks per CU queue up (16 tiles: 2.27 against 2.31 ms at 2^20 hypotheses, round 2)
-    const uint32_t per_cu = ntiles <= 4 ? 1u : 2u;
-    uint32_t cols = (per_cu * (uint32_t)ctx->num_cus + (uint32_t)ntiles - 1) / (uint32_t)ntiles;
+    // one block per CU is resident (152 KiB of LDS), so the grid is at most one block per CU, spread over the tiles: columns =
+    // floor(CUs / tiles).  Until round 4 sixteen tiles got two blocks per CU queued up (32 columns): the second block of a CU
+    // pays the tile staging and the end-of-block tail once more -- 16384 x 65536: 0.1557 -> 0.1475 ms with 16 columns, 16384 x 2^20
+    // unchanged (profiles/r04_ab_c3cols.txt); and rounding the column count UP left a few blocks for a second round.
+    uint32_t cols = (uint32_t)ctx->num_cus / (uint32_t)ntiles;
     if (SFM_SW(p, 2) > 0) cols = (uint32_t)SFM_SW(p, 2);
     if (cols > iters) cols = iters;
     if (cols < 1) cols = 1;

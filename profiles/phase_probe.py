@@ -26,5 +26,5 @@ for H, cols in ((131072, 0), (131072, 64), (262144, 0), (1048576, 0), (1048576, 
     t = pair.last_phases()
     us = lambda k: round(t[k] / 100.0, 2)
     print(json.dumps({"hypotheses": H, "grid": pair.last_launch()["grid"], "block0_lifetime_us": us(1), "tile_staged_us": us(2), "first_pass_prepared_us": us(3),
-                      "first_block_scanned_us": us(4), "first_pass_done_us": us(5), "passes_of_wave0": t[6],
+                      "first_block_scanned_us": us(4), "ring_drained_us": us(7), "first_pass_done_us": us(5), "passes_of_wave0": t[6],
                       "shader_mhz": round(100.0 * t[0] / max(t[1], 1))}), flush=True)
