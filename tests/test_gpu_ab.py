@@ -162,8 +162,9 @@ def test_prefilter_operands_on_the_device_equal_the_host_build(gpu_ab):
         assert abs(float(dv["G"]) - G) <= T.ACC * float(np.abs(Bt[0]) @ np.abs(ts)) + 1e-12
 
 
+@pytest.mark.parametrize("var", [16, 17])                 # 16 = the product's accumulator epilogue, 17 = round 3's tickets
 @pytest.mark.parametrize("cols,launches,H", [(64, 600, 1 << 18), (1, 150, 1 << 18)])
-def test_prefilter_tickets_under_contention_forced_columns(gpu_ab, cols, launches, H):
+def test_prefilter_tickets_under_contention_forced_columns(gpu_ab, cols, launches, H, var):
     """The arg-max of the scoring kernel rests on an ordering assumption (ransac_prefilter.hip: the count atomics of a
     wavefront are acknowledged -- s_waitcnt vmcnt(0) -- before its ticket is issued, and the wavefront that draws the last
     ticket of a group then reads final counts), not on a release / acquire fence (which costs an L2 write-back per group).
@@ -176,6 +177,7 @@ def test_prefilter_tickets_under_contention_forced_columns(gpu_ab, cols, launche
     pair, _ = make_pair(S, gpu_ab, scene)
     p = S.default_params(n, num_hypotheses=H, seed=11, kernel=S.KERNEL_PREFILTER)
     p.reserved[2] = cols
+    p.reserved[3] = var
     _, _, X0, X1 = O.fill_xu(scene["sift"], scene["Kinv"])
     key, ocounts, _ = O.ransac_range_fast(X0, X1, 0, H, p.threshold, p.jacobi_sweeps, seed=p.seed)
     bad_keys = 0

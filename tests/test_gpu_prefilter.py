@@ -216,13 +216,13 @@ def test_prefilter_keeps_inliers_whose_feature_is_an_fp16_tie(gpu, case):
 
 
 @pytest.mark.parametrize("launches,H", [(1000, 1 << 20), (400, 1 << 17)])
-def test_prefilter_tickets_under_contention(gpu, launches, H):
-    """The arg-max of the scoring kernel rests on an ordering assumption (ransac_prefilter.hip: the count atomics of a
-    wavefront are acknowledged -- s_waitcnt vmcnt(0) -- before its ticket is issued, and the wavefront that draws the last
-    ticket of a group then reads final counts), not on a release / acquire fence (which costs an L2 write-back per group).
-    This test exercises it: 16 tiles (so 16 wavefronts on 16 CUs race for every group's tickets), the default grid here (columns forced to
-    1 / 64: tests/test_gpu_ab.py), hundreds of launches, the key of EVERY launch and the counts of every 50th
-    against the oracle.  A reader that ran ahead of another tile's counts would produce a key with too small a count."""
+def test_prefilter_accumulators_under_contention(gpu, launches, H):
+    """Counts and arg-max of the scoring kernel across tiles: every (hypothesis, tile) adds its partial count and one arrival to
+    the hypothesis' 64-bit accumulator with ONE atomic; the lane that sees ntiles - 1 earlier arrivals owns the final count and
+    the key (ransac_prefilter.hip; round 3 used count atomics + a ticket per group + an ordering argument, still exercised as an
+    A/B variant in tests/test_gpu_ab.py).  16 tiles (16 wavefronts on 16 CUs race for every hypothesis), hundreds of launches,
+    the key of EVERY launch and the counts of every 50th against the oracle.  A completion detected too early, twice or never
+    shows up as a wrong count or key."""
     torch, dev, ctx = gpu
     n = 16384
     scene = synth.two_view_scene(n, seed=77)
