@@ -38,7 +38,9 @@ constexpr int kPfBlockBytes = 3 * 64 * 16;                    // one 32-point bl
 constexpr int kPfLdsFrag = 0;
 constexpr int kPfLdsPts = kPfLdsFrag + (kPfTile / 32) * kPfBlockBytes;     // float4 (x2x, x1x, x2y, x1y) per point
 constexpr int kPfLdsWave = kPfLdsPts + kPfTile * 16;          // per wavefront: E table 32 x 10 floats, 32 counters, ring
-constexpr int kPfERow = 10;                                   // floats per E row: (e2 e6 | e1 e3 | e5 e7 | e0 e4 | e8 -), 8-byte aligned pairs
+constexpr int kPfERow = 10;                                   // floats per hypothesis in the E table (9 used).  Component-major since round 4: etab[32 k + row]
+                                                              // -- a lane's nine reads for a random row hit bank (row mod 32) + const, so distinct rows never conflict
+                                                              // (row-major 40-byte rows put rows r and r + 16 on the same banks: 19 % of the LDS cycles were conflicts)
 constexpr int kPfWaveBytes = 32 * kPfERow * 4 + 32 * 4 + kPfRing * 8;
 constexpr int kPfLdsNext = kPfLdsWave + kPfWaves * kPfWaveBytes;   // the block's pass counter
 constexpr int kPfLdsBytes = kPfLdsNext + 16;
@@ -185,12 +187,8 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
     };
     auto install_rows = [&](const float (&e)[9]) {          // E table and counters of a pass (the previous pass' ring is drained, its counters are out)
         if (half == 0) {
-            float4 *dst = reinterpret_cast<float4 *>(etab + kPfERow * row);      // 40-byte rows: 8-byte aligned
-            reinterpret_cast<float2 *>(dst)[0] = make_float2(e[2], e[6]);
-            reinterpret_cast<float2 *>(dst)[1] = make_float2(e[1], e[3]);
-            reinterpret_cast<float2 *>(dst)[2] = make_float2(e[5], e[7]);
-            reinterpret_cast<float2 *>(dst)[3] = make_float2(e[0], e[4]);
-            etab[kPfERow * row + 8] = e[8];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) etab[32 * k + row] = e[k];
             cnt[row] = 0;
         }
     };
@@ -278,8 +276,7 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
             while (todo) {
                 const int r = __builtin_ctz(todo);
                 todo &= todo - 1u;
-                const float *er = etab + kPfERow * r;
-                const float se[6] = { er[6], er[2], er[0], er[3], er[7], er[4] };          // e0 .. e5 out of the permuted row
+                const float se[6] = { etab[r], etab[32 + r], etab[64 + r], etab[96 + r], etab[128 + r], etab[160 + r] };          // e0 .. e5
                 bool z = false;
                 for (int j = 0; j < kPfTile / 64; ++j) {
                     const float4 q = pts[j * 64 + lane];
@@ -316,9 +313,9 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
                 const int hl = r + (r & 12) + (int)(tag & 4u);                      // accumulator row = local hypothesis: (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
                 if (hl < nvalid) {
                     const f4v q = *(lds_cf4 *)((__attribute__((address_space(3))) const unsigned char *)0 + ((tag & ~15u) + ((uint32_t)sub << 9)));
-                    lds_cv2 *e = (lds_cv2 *)(etab_l + kPfERow * hl);
-                    const v2f p0 = e[0], p1 = e[1], p2 = e[2], p3 = e[3];
-                    const float e8 = etab_l[kPfERow * hl + 8];
+                    lds_cf *e = etab_l + hl;
+                    const v2f p0 = { e[64], e[192] }, p1 = { e[32], e[96] }, p2 = { e[160], e[224] }, p3 = { e[0], e[128] };      // (e2 e6) (e1 e3) (e5 e7) (e0 e4)
+                    const float e8 = e[256];
                     if (pf_exact_inlier(p0, p1, p2, p3, e8, v2f{ q.x, q.y }, v2f{ q.z, q.w }, band))
                         __hip_atomic_fetch_add(cnt_l + hl, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
