@@ -240,7 +240,6 @@ extern "C" int sfm_process_views_sharded(sfm_comm *c, const float h_K[9], const 
     if (need > c->views_bytes) {
         (void)sfm_ctx_synchronize(c->ctx);
         if (c->d_views) (void)sfm_device_free(c->ctx, c->d_views);
-    if (c->d_feats) (void)sfm_device_free(c->ctx, c->d_feats);
         c->d_views = nullptr; c->views_bytes = 0;
         rc = sfm_device_alloc(c->ctx, need, &c->d_views);
         if (rc != SFM_OK) return rc;
@@ -253,7 +252,10 @@ extern "C" int sfm_process_views_sharded(sfm_comm *c, const float h_K[9], const 
     std::vector<int> my_counts((size_t)(cnt_local / sizeof(int)), 0);
     rc = sfm_extract_views(c->ctx, h_images, num_views, width, height, r, G, d_local, slot_bytes, max_pts, num_octaves, init_blur, thresh,
                            lowest_scale, scale_up, my_counts.data());
-    if (rc != SFM_OK) return rc;
+    // a rank whose extraction failed must not leave the others waiting in the collective: it publishes -1 counts, and every
+    // rank returns an error after the all-gather
+    const int rc_extract = rc;
+    if (rc_extract != SFM_OK) for (int &v : my_counts) v = -1;
     // 2. the counts of all views: one all-gather of `slots` ints per rank (view v: rank v % G, slot v / G)
     COMM_HIP_TRY(hipMemcpyAsync(d_cnt_local, my_counts.data(), cnt_local, hipMemcpyHostToDevice, stream));
     COMM_NCCL_TRY(ncclAllGather(d_cnt_local, d_cnt_all, cnt_local, ncclChar, c->nccl, stream));
@@ -265,7 +267,8 @@ extern "C" int sfm_process_views_sharded(sfm_comm *c, const float h_K[9], const 
     size_t total = 0;
     for (int v = 0; v < num_views; ++v) {
         int n = all_counts[(size_t)(v % G) * (cnt_local / sizeof(int)) + (size_t)(v / G)];
-        if (n < 0 || n > max_pts) return fail("sfm_process_views_sharded", "a rank reported a feature count outside [0, max_pts]");
+        if (n < 0) return rc_extract != SFM_OK ? rc_extract : fail("sfm_process_views_sharded", "ExtractSift failed on another rank");
+        if (n > max_pts) return fail("sfm_process_views_sharded", "a rank reported a feature count above max_pts");
         counts[(size_t)v] = n;
         offset[(size_t)v] = total;                                                   // multiples of 576: 16-byte aligned descriptors
         total += (size_t)n * sizeof(sfm_sift_point);

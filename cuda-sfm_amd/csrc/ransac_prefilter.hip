@@ -37,11 +37,14 @@ typedef float f16v __attribute__((ext_vector_type(16)));
 constexpr int kPfBlockBytes = 3 * 64 * 16;                    // one 32-point block: [n k-step 0 | n k-step 1 | G][lane][8 fp16]
 constexpr int kPfLdsFrag = 0;
 constexpr int kPfLdsPts = kPfLdsFrag + (kPfTile / 32) * kPfBlockBytes;     // float4 (x2x, x1x, x2y, x1y) per point
-constexpr int kPfLdsWave = kPfLdsPts + kPfTile * 16;          // per wavefront: E table 32 x 10 floats, 32 counters, ring
-constexpr int kPfERow = 10;                                   // floats per hypothesis in the E table (9 used).  Component-major since round 4: etab[32 k + row]
-                                                              // -- a lane's nine reads for a random row hit bank (row mod 32) + const, so distinct rows never conflict
+constexpr int kPfLdsRingBase = kPfLdsPts + kPfTile * 16;      // the wavefronts' survivor rings, 1024 bytes each, 1024-byte aligned (a slot's
+                                                              // address is (offset & 1023) | base: one v_and_or_b32)
+constexpr int kPfLdsWave = kPfLdsRingBase + kPfWaves * kPfRing * 8;   // per wavefront: E table 9 x 32 floats (component-major), 32 counters
+constexpr int kPfERow = 10;                                   // floats per hypothesis reserved in the E table (9 used): etab[32 k + row] -- a lane's nine
+                                                              // reads for a random row hit bank (row mod 32) + const, so distinct rows never conflict
                                                               // (row-major 40-byte rows put rows r and r + 16 on the same banks: 19 % of the LDS cycles were conflicts)
-constexpr int kPfWaveBytes = 32 * kPfERow * 4 + 32 * 4 + kPfRing * 8;
+constexpr int kPfWaveBytes = 32 * kPfERow * 4 + 32 * 4;
+static_assert(kPfLdsRingBase % 1024 == 0 && kPfRing * 8 == 1024, "ring slots are addressed with (offset & 1023) | base");
 constexpr int kPfLdsNext = kPfLdsWave + kPfWaves * kPfWaveBytes;   // the block's pass counter
 constexpr int kPfLdsBytes = kPfLdsNext + 16;
 static_assert(kPfLdsBytes <= 160 * 1024, "one block must fit the CU's LDS");
@@ -241,11 +244,15 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
 #endif
     const int npb = (min(kPfTile, ld - tile_first) + 31) >> 5;           // 32-point blocks that hold points or padding
     const int npp = (npb + 1) >> 1;                                      // two 32-point blocks per iteration (a block beyond npb holds padding only: all rejected)
-    const int last_pb = kPfTile / 32 - 1;
     const float4 *pts = reinterpret_cast<const float4 *>(smem + kPfLdsPts);
     lds_cf *etab_l = (lds_cf *)etab;
     lds_i *cnt_l = (lds_i *)cnt;
-    lds_u2 *ring = (lds_u2 *)(cnt + 32);
+    const uint32_t ring_base = (uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char *)(smem + kPfLdsRingBase) + (uint32_t)wave * (uint32_t)(kPfRing * 8);
+    uint32_t ring_mask = (uint32_t)(kPfRing * 8 - 1);
+    asm("" : "+v"(ring_mask));                            // in a vector register: v_and_or_b32 takes one scalar operand, and that is the base
+    auto ring_at = [&](uint32_t index8) {                 // index8 = 8 x (slot index, not yet wrapped)
+        return (lds_u2 *)((__attribute__((address_space(3))) unsigned char *)0 + ((index8 & ring_mask) | ring_base));
+    };
     lds_ch8 *frag_lane = (lds_ch8 *)(smem + kPfLdsFrag) + lane;
     const ThrBand band = make_band(thr);
     uint32_t passes_done = 0;
@@ -304,7 +311,7 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
             // of its second), LDS byte address of the lane's point in the pair's first block | 4 (lane >> 5) }.
             uint32_t rest = 0, tag = 0;
             if (lane < m) {
-                const u2v ent = ring[(head + lane) & (kPfRing - 1)];
+                const u2v ent = *ring_at(((uint32_t)head + (uint32_t)lane) * 8u);
                 tag = ent.y;
                 const uint32_t surv = ent.x;
                 const int b = __builtin_clz(surv);                                  // the first surviving accumulator of the first step that has one
@@ -323,7 +330,7 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
             const unsigned long long more = __ballot(rest != 0u);
             if (more) {
                 const int slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(more >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)more, 0u));
-                if (rest) ring[(head + nq + slot) & (kPfRing - 1)] = u2v{ rest, tag };
+                if (rest) *ring_at(((uint32_t)(head + nq) + (uint32_t)slot) * 8u) = u2v{ rest, tag };
             }
             head = (head + m) & (kPfRing - 1);
             nq += __builtin_popcountll(more) - m;
@@ -332,16 +339,21 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
         PfFrags fa = load_point_frags(frag_lane, 0), fb = load_point_frags(frag_lane, 1);
         f16v g0, n0, g1, n1;
         mfma_step(afrag, fa, g0, n0);
+        // one running address for the look-ahead reads (32-point blocks 2 pp + 2 and 2 pp + 3: six immediate offsets, one add per
+        // iteration).  The last iterations read one or two blocks past the tile -- coordinates and rings, still inside the block's
+        // LDS -- into fragments no scan ever looks at.
+        lds_ch8 *fp = frag_lane + 2 * (kPfBlockBytes / 16);
         for (int pp = 0; pp < npp; ++pp) {
             // phase 1: matrix cores on step 2 pp + 1 (fragments fb), LDS on step 2 pp + 2, vector unit on step 2 pp
-            fa = load_point_frags(frag_lane, min(2 * pp + 2, last_pb));
+            fa = load_point_frags(fp, 0);
             __builtin_amdgcn_sched_barrier(0);
             mfma_step(afrag, fb, g1, n1);
             const uint32_t rej_first = scan16(n0, g0);
             PF_SCHED_STEP();
             __builtin_amdgcn_sched_barrier(0);
             // phase 2: matrix cores on step 2 pp + 2 (fragments fa), LDS on step 2 pp + 3, vector unit on step 2 pp + 1
-            fb = load_point_frags(frag_lane, min(2 * pp + 3, last_pb));
+            fb = load_point_frags(fp, 1);
+            fp += 2 * (kPfBlockBytes / 16);
             __builtin_amdgcn_sched_barrier(0);
             mfma_step(afrag, fa, g0, n0);
             const uint32_t rej_second = scan16(n1, g1);
@@ -353,7 +365,7 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
             if (any) {
                 while (nq >= 64) flush(64);             // make room first (a flush of 64 entries re-queues up to 64: it may take more than one)
                 const int slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(any >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)any, 0u));
-                if (mine) ring[(head + nq + slot) & (kPfRing - 1)] = u2v{ ~rej32, lane_tag + ((uint32_t)pp << 10) };
+                if (mine) *ring_at(((uint32_t)(head + nq) + (uint32_t)slot) * 8u) = u2v{ ~rej32, lane_tag + ((uint32_t)pp << 10) };
                 nq += __builtin_popcountll(any);
             }
         }

@@ -69,6 +69,10 @@ def test_process_views_sharded_single_rank(gpu):
     res2, counts2 = comm.process_views(views[:3], K, Kinv, max_pts=4096, sift=sift)
     ref2, _ = S.process_views(ctx, views[:3], K, Kinv, max_pts=4096, sift=sift, device=dev)
     assert counts2 == rcounts[:3] and all(same_bits(res2[k], ref2[k]) for k in ref2) and sorted(res2) == sorted(ref2)
+    more = views + [views[1], views[3]]                             # seven views: both device buffers of the communicator grow
+    res3, counts3 = comm.process_views(more, K, Kinv, pairs=pairs + [(5, 6), (6, 0)], max_pts=4096, sift=sift)
+    ref3, rc3 = S.process_views(ctx, more, K, Kinv, pairs=pairs + [(5, 6), (6, 0)], max_pts=4096, sift=sift, device=dev)
+    assert counts3 == rc3 and sorted(res3) == sorted(ref3) and all(same_bits(res3[k], ref3[k]) for k in ref3)
     comm.close()
 
 
