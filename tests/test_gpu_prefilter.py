@@ -25,7 +25,8 @@ def check_all(pair, scene, p, H, n):
     assert np.array_equal(pair.get_inlier_mask(), O.count_inliers(oE[ohyp], X0, X1, p.threshold)[1])
 
 
-@pytest.mark.parametrize("n,H", [(1024, 16384), (1000, 20000), (4096, 32768), (4500, 17000), (700, 16385), (2048, 65536)])
+@pytest.mark.parametrize("n,H", [(1024, 16384), (1000, 20000), (4096, 32768), (4500, 17000), (700, 16385), (2048, 65536),
+                                 (70000, 16384), (270000, 16384)])      # 69 tiles (3 grid columns); 264 tiles: more tiles than CUs, one column
 def test_prefilter_counts_equal_oracle(gpu, n, H):
     scene = synth.two_view_scene(n, seed=200 + n)
     pair, _ = make_pair(S, gpu, scene)
