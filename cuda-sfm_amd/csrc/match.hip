@@ -63,6 +63,51 @@ __device__ __forceinline__ void stage_store(float *buf, const float4 (&regs)[16 
     }
 }
 
+// The scores of one staged block of database rows (RT row tiles of 32) against the wavefront's resident queries, folded into
+// the running top-2 in ascending database index.
+template <int CT, int RT>
+__device__ __forceinline__ void stage_scores(const float *cur, const float (&bq)[CT][64], Top2 (&top)[CT], int stage_row0)
+{
+    const int lane = threadIdx.x & 63;
+    const int col = lane & 31;
+    const int half = lane >> 5;
+    f32x16 acc[RT][CT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[rt][ct][r] = 0.0f;
+
+    const float *a0p = cur + col * kLdsStride + 4 * half;
+    const float *a1p = a0p + 32 * kLdsStride;
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+        const float4 a0 = *reinterpret_cast<const float4 *>(a0p + 8 * m);
+        const float a0v[4] = { a0.x, a0.y, a0.z, a0.w };
+        float a1v[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+        if (RT == 2) {
+            const float4 a1 = *reinterpret_cast<const float4 *>(a1p + 8 * m);
+            a1v[0] = a1.x; a1v[1] = a1.y; a1v[2] = a1.z; a1v[3] = a1.w;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                acc[0][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0v[k], bq[ct][4 * m + k], acc[0][ct], 0, 0, 0);
+                if (RT == 2) acc[RT - 1][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1v[k], bq[ct][4 * m + k], acc[RT - 1][ct], 0, 0, 0);
+            }
+    }
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int p2 = stage_row0 + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) top2_push(top[ct], acc[rt][ct][r], p2);
+        }
+}
+
 // One block: W waves x CT column tiles = 32*CT*W queries against database rows [row_begin, row_end).
 // W = 8 puts two wavefronts on every SIMD of the CU (one block per CU, 67.6 KB of LDS): while one
 // folds its accumulators into the running top-2 or waits at the stage barrier, the other keeps the
@@ -133,41 +178,10 @@ __device__ __forceinline__ void match_body(const float *__restrict__ q, int nq, 
         const float *cur = lds[s & 1];
         if (s + 1 < nstage) stage_load<W>(db, lddb, row_begin + (s + 1) * kRowsPerStage, row_end, regs);
 
-        f32x16 acc[2][CT];
-#pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-            for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[rt][ct][r] = 0.0f;
-
-        const float *a0p = cur + col * kLdsStride + 4 * half;
-        const float *a1p = a0p + 32 * kLdsStride;
-#pragma unroll
-        for (int m = 0; m < 16; ++m) {
-            const float4 a0 = *reinterpret_cast<const float4 *>(a0p + 8 * m);
-            const float4 a1 = *reinterpret_cast<const float4 *>(a1p + 8 * m);
-            const float a0v[4] = { a0.x, a0.y, a0.z, a0.w };
-            const float a1v[4] = { a1.x, a1.y, a1.z, a1.w };
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-#pragma unroll
-                for (int ct = 0; ct < CT; ++ct) {
-                    acc[0][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0v[k], bq[ct][4 * m + k], acc[0][ct], 0, 0, 0);
-                    acc[1][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1v[k], bq[ct][4 * m + k], acc[1][ct], 0, 0, 0);
-                }
-        }
-
-        // fold the 2 x CT accumulator tiles into the running top-2 (ascending database index)
+        // a split is a multiple of 32 rows: its last stage may hold one row tile only (wave-uniform)
         const int stage_row0 = row_begin + s * kRowsPerStage;
-#pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int p2 = stage_row0 + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-#pragma unroll
-                for (int ct = 0; ct < CT; ++ct) top2_push(top[ct], acc[rt][ct][r], p2);
-            }
+        if (row_end - stage_row0 > 32) stage_scores<CT, 2>(cur, bq, top, stage_row0);
+        else stage_scores<CT, 1>(cur, bq, top, stage_row0);
 
         if (s + 1 < nstage) stage_store<W>(lds[(s + 1) & 1], regs, row_begin + (s + 1) * kRowsPerStage, row_end);
         __syncthreads();
@@ -383,8 +397,10 @@ int launch_match(sfm_ctx *ctx, const float *d1, int n1, int ld1, const float *d2
     const int max_split = (n2 + kRowsPerStage - 1) / kRowsPerStage;
     if (nsplit > max_split) nsplit = max_split;
     if (nsplit < 1) nsplit = 1;
+    // a split is a whole number of 32-row tiles (its last stage runs one row tile instead of two when 32 rows or fewer are
+    // left): 2155 x 2170 is 14 splits of 160 rows = 2.5 stages of matrix work per wavefront instead of 12 x 192 = 3
     int rows_per_split = (n2 + nsplit - 1) / nsplit;
-    rows_per_split = round_up(rows_per_split, kRowsPerStage);
+    rows_per_split = round_up(rows_per_split, kRowsPerStage / 2);
     nsplit = (n2 + rows_per_split - 1) / rows_per_split;
 
     unsigned int *tickets; float *wb, *wsnd; int *wi;

@@ -7,7 +7,7 @@ from cuda_sfm_amd import synth
 dev = torch.device("cuda", 0)
 ctx = S.Context(0, torch.cuda.current_stream().cuda_stream)
 out = {}
-for n in (1200, 2048, 2500, 3000, 5500, 16384):
+for n in (1200, 1500, 1800, 2048, 2155, 2300, 2500, 3000, 4000, 5500, 16384):
     d1, d2, perm = synth.descriptors(n)
     t1, t2 = torch.from_numpy(d1).to(dev), torch.from_numpy(d2).to(dev)
     best = torch.empty(n, dtype=torch.float32, device=dev); sec = torch.empty_like(best); idx = torch.empty(n, dtype=torch.int32, device=dev)
