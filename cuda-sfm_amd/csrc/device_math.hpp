@@ -707,17 +707,23 @@ SFM_HD void nullvec4(const float A[16], const int sweeps, float v[4])
                     be = fmaf(G[4 * k + q], G[4 * k + q], be);
                     ga = fmaf(G[4 * k + p], G[4 * k + q], ga);
                 }
-                if (ga == 0.0f) continue;
+                // a pair with ga == 0 is left alone.  Written as selects on the results, not as a branch around the rotation:
+                // a divergent `continue` here made the compiler copy G and V (~50 register moves per rotation next to ~60
+                // instructions of arithmetic; this loop is most of the 18 us pose chain of one pair).  The selects keep the
+                // untouched values bit for bit (signed zeros, NaN), which c = 1, s = 0 through the formulas would not.
+                const bool rot = !(ga == 0.0f);
                 float c, s;
                 jacobi_cs(al, be, ga, c, s);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const float gp = G[4 * k + p], gq = G[4 * k + q];
-                    G[4 * k + p] = fmaf(-s, gq, c * gp);
-                    G[4 * k + q] = fmaf(s, gp, c * gq);
+                    const float ngp = fmaf(-s, gq, c * gp), ngq = fmaf(s, gp, c * gq);
+                    G[4 * k + p] = rot ? ngp : gp;
+                    G[4 * k + q] = rot ? ngq : gq;
                     const float vp = V[4 * k + p], vq = V[4 * k + q];
-                    V[4 * k + p] = fmaf(-s, vq, c * vp);
-                    V[4 * k + q] = fmaf(s, vp, c * vq);
+                    const float nvp = fmaf(-s, vq, c * vp), nvq = fmaf(s, vp, c * vq);
+                    V[4 * k + p] = rot ? nvp : vp;
+                    V[4 * k + q] = rot ? nvq : vq;
                 }
             }
     }
