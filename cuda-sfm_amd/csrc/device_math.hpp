@@ -263,6 +263,7 @@ SFM_HD void svd3(const T *a, T *u, T *s, T *v)
     Svd3<T> J;
     J.s0 = ata[0]; J.s3 = ata[3]; J.s4 = ata[4]; J.s6 = ata[6]; J.s7 = ata[7]; J.s8 = ata[8];
     J.q[0] = splat_t<T>(0.0f); J.q[1] = splat_t<T>(0.0f); J.q[2] = splat_t<T>(0.0f); J.q[3] = one;
+#pragma unroll
     for (int it = 0; it < 4; ++it) {               // svd.h:201-210
         J.conj(0, 1, 2);
         J.conj(1, 2, 0);

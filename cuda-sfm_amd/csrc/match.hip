@@ -224,19 +224,21 @@ __device__ __forceinline__ void match_body(const float *__restrict__ q, int nq, 
         Top2 t{ __hip_atomic_load(&ws_best[p1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
                 __hip_atomic_load(&ws_second[p1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
                 __hip_atomic_load(&ws_idx[p1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) };
-        // eight splits' partials are requested before the first is merged: one memory round trip per eight splits, not
-        // per split (the loads are atomics, which the compiler never hoists over the merge of the previous split)
-        for (int sp0 = 1; sp0 < nsplit; sp0 += 8) {
-            Top2 part[8];
+        // sixteen splits' partials are requested before the first is merged: one memory round trip per sixteen splits, not
+        // per split (the loads are atomics, which the compiler never hoists over the merge of the previous split); one-match
+        // launches have up to 16 or 17 splits for the small sizes, i.e. ONE trip
+        constexpr int kMergeBatch = 16;
+        for (int sp0 = 1; sp0 < nsplit; sp0 += kMergeBatch) {
+            Top2 part[kMergeBatch];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < kMergeBatch; ++u) {
                 const size_t w = (size_t)min(sp0 + u, nsplit - 1) * nq + p1;
                 part[u].best = __hip_atomic_load(&ws_best[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 part[u].second = __hip_atomic_load(&ws_second[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 part[u].idx = __hip_atomic_load(&ws_idx[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
+            for (int u = 0; u < kMergeBatch; ++u)
                 if (sp0 + u < nsplit) t = top2_merge(t, part[u]);
         }
         match_emit(p1, t, out_best, out_second, out_idx, sift1, sift2);
