@@ -247,14 +247,21 @@ __device__ __forceinline__ void score_tile_n(const Ess (&E)[NH], const float *ld
     const int rest = nvalid - (full << 7);      // 0..127 real points in the ragged iteration
     if (rest > 0) {
         const unsigned long long va = __ballot(2 * lane < rest), vb = __ballot(2 * lane + 1 < rest);
-        const PairPts p = load_pair<UNITZ>(rec);
+        PairPts p = load_pair<UNITZ>(rec);
+        // The lane that holds the last real point of an ODD tile next to a padding point scores its real point twice (the
+        // copy's answer is masked out by vb): the NaN padding would otherwise read as "undecided" in the lane's trackers and
+        // send EVERY hypothesis of an odd-sized pair through the exact recount below (the dino pair has 2155 matches: the
+        // scoring phase of its fused estimateE was 5.6 us, 4 of them this recount; profiles/r04_fused_stamps.txt).
+        if (2 * lane + 1 >= rest) {
+            p.x1x.y = p.x1x.x; p.x1y.y = p.x1y.x; p.x1z.y = p.x1z.x;
+            p.x2x.y = p.x2x.x; p.x2y.y = p.x2y.x; p.x2z.y = p.x2z.x;
+        }
 #pragma unroll
         for (int h = 0; h < NH; ++h) {
             unsigned long long in_a, in_b;
             FilterAcc t{ 0xFFFFFFFFu, 0xFFFFFFFFu, 0u };
             filter_pair<UNITZ>(E[h], ad[h], band.thr, p, in_a, in_b, t);
-            // trackers of padding lanes are discarded; a lane holding one real and one padding point
-            // keeps them (NaN padding then reads as "undecided", which is merely conservative)
+            // trackers of padding lanes are discarded
             if (2 * lane < rest) {
                 acc[h].gap_min = min(acc[h].gap_min, t.gap_min);
                 acc[h].tb_min = min(acc[h].tb_min, t.tb_min);

@@ -198,8 +198,8 @@ __device__ __forceinline__ void fused_body(float *lds, const float *__restrict__
     uint2 (*sched)[64] = reinterpret_cast<uint2 (*)[64]>(lds + tile_floats + (size_t)WPB * kWaveScratch);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (!PRESOLVED) {
-        if (wave == 0) build_jacobi_schedule(sched, lane);
+    if (!PRESOLVED && sweeps > 0) {                       // (the Householder solver has no use for the schedule: 1.4 us of integer
+        if (wave == 0) build_jacobi_schedule(sched, lane);  //  divisions and a barrier in front of a 17 us kernel)
         __syncthreads();
     }
     float *ws = lds + tile_floats + (size_t)wave * kWaveScratch;
@@ -350,7 +350,7 @@ void ransac_finalize_block(const float *__restrict__ X0, const float *__restrict
             if (threadIdx.x < 9) sE[threadIdx.x] = Ecand[9 * (size_t)(hyp - h0) + threadIdx.x];
         } else {
             float E[9];
-            build_jacobi_schedule(sched, threadIdx.x);
+            if (sweeps > 0) build_jacobi_schedule(sched, threadIdx.x);
             wave_sync();
             solve_wave(X0, X1, ld, n, indices, seed, hyp, sweeps, ws, sched, threadIdx.x, E);
             if (threadIdx.x == 0) {
