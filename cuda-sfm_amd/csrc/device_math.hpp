@@ -40,23 +40,31 @@ SFM_HD uint32_t mulhi32(uint32_t a, uint32_t b)
     return (uint32_t)(((uint64_t)a * (uint64_t)b) >> 32);
 }
 
-// 8 distinct point ids, a pure function of (seed, hyp, n).
+// 8 distinct point ids, a pure function of (seed, hyp, n): candidates cand(k) = mulhi(hash(base + k * phi), n), k = 0, 1, ..
+// (at most 256 of them), each kept unless it repeats an id already kept; if 256 candidates do not yield 8 ids, the rest are the
+// smallest integers not kept yet (unreachable for n >= 8 in practice).
+// Written slot by slot: slot i is compared with the i ids in front of it only (28 comparisons per sample in the usual case of no
+// repeat, not 8 per candidate against a partly filled array), the redraw loop runs only in lanes that met a repeat.  The
+// sequence of candidates and the ids kept are exactly those of the plain loop (oracle/: orc_sample8).
 SFM_HD void sample8(uint32_t seed, uint32_t hyp, int n, int idx[8])
 {
     const uint32_t base = hash32(hash32(seed) + hyp);
-    int got = 0;
+    uint32_t k = 0;
+    int got = 8;
 #pragma unroll
     for (int i = 0; i < 8; ++i) idx[i] = -1;
-    for (uint32_t k = 0; k < 256u && got < 8; ++k) {
-        const int cand = (int)mulhi32(hash32(base + k * 0x9E3779B9U), (uint32_t)n);
-        bool dup = false;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) dup |= (j < got) & (idx[j] == cand);
-        if (!dup) {
+    for (int i = 0; i < 8; ++i) {
+        bool placed = false;
+        while (k < 256u) {
+            const int cand = (int)mulhi32(hash32(base + k * 0x9E3779B9U), (uint32_t)n);
+            ++k;
+            bool dup = false;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) if (j == got) idx[j] = cand;
-            ++got;
+            for (int j = 0; j < i; ++j) dup |= (idx[j] == cand);
+            if (!dup) { idx[i] = cand; placed = true; break; }
         }
+        if (!placed) { got = i; break; }          // (k == 256: no later slot can be placed either)
     }
     for (int cand = 0; got < 8; ++cand) {          // unreachable for n >= 8 in practice
         bool dup = false;

@@ -41,12 +41,18 @@ def fp(a):
 
 
 def test_sampler(H):
-    for n in (8, 9, 100, 4096, 1 << 20):
-        for h in (0, 1, 77, 65535, 2 ** 31 + 5):
-            a = O.sample8(0x5EED5F3D, h, n)
-            b = np.empty(8, np.int32)
-            H.hc_sample8(C.c_uint32(0x5EED5F3D), C.c_uint32(h), n, b.ctypes.data_as(i32p))
-            assert np.array_equal(a, b)
+    """The product's slot-by-slot sampler against the oracle's plain loop: same candidate sequence, same ids -- including sets
+    so small that nearly every candidate repeats (n = 8 .. 12: dozens of redraws per sample) and sets of fewer than 8 points,
+    where 256 candidates cannot yield 8 ids and the sequential fallback fills the rest."""
+    b = np.empty(8, np.int32)
+    for n in (1, 2, 5, 7, 8, 9, 10, 12, 16, 33, 100, 2155, 4096, 1 << 20):
+        hyps = list(range(300 if n <= 100 else 60)) + [65535, 2 ** 31 + 5, 2 ** 32 - 1]
+        for seed in (0x5EED5F3D, 0, 12345):
+            for h in hyps:
+                a = O.sample8(seed, h, n)
+                H.hc_sample8(C.c_uint32(seed), C.c_uint32(h), n, b.ctypes.data_as(i32p))
+                assert np.array_equal(a, b), (n, seed, h, a, b)
+                if n >= 8: assert len(set(b.tolist())) == 8 and b.min() >= 0 and b.max() < n
 
 
 def test_hypothesis_E_bit_exact(H, scene):
