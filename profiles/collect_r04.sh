@@ -27,6 +27,9 @@ python3 profiles/pipeline_bench.py > $O/${TAG}_pipeline_bench.txt 2>/dev/null
 python3 profiles/ring_bench.py > $O/${TAG}_ring_bench.txt 2>/dev/null
 MATCH_SIZES=1200,2048,3000,4096,5500,8192,16384 python3 profiles/match_bench.py > $O/${TAG}_match_bench.txt 2>/dev/null
 python3 profiles/small_h_bench.py > $O/${TAG}_small_h_bench.txt 2>/dev/null
+# 4b. the dino pair end to end: per-kernel durations and gaps of one iteration (rocprofv3 --kernel-trace inside the script)
+{ sh profiles/c1_timeline.sh 1024; sh profiles/c1_timeline.sh 269; } > $O/${TAG}_c1_timeline.txt 2>&1
+python3 profiles/c1_ab.py > $O/${TAG}_c1_latency.txt 2>/dev/null
 # 5. rocprof: kernel stats of the bench command (serial steps: one kernel at a time), c3, c4 and a rank's share; pipelined steps
 cd /tmp && export TMPDIR=/tmp
 for cfg in "headline:" "c3:--config c3" "c4:--config c4 --steps 30 --warmup 5" "rank8:--hyps 131072"; do
