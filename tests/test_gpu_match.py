@@ -32,6 +32,24 @@ def test_match_soa_bit_exact(gpu, n1, n2):
     assert same_bits(b, ob) and same_bits(s, os_)
 
 
+@pytest.mark.parametrize("n1,n2", [(2155, 2170), (1500, 1500), (130, 1900), (2400, 96), (700, 2530), (3000, 161), (257, 33)])
+def test_exact_matcher_split_tails(gpu, n1, n2):
+    """The exact MFMA matcher with database splits that are an odd number of 32-row tiles (the last stage of a split then runs one
+    row tile, match.hip: stage_scores<CT, 1>), with more than sixteen splits (two merge trips) and with a single short split."""
+    import cuda_sfm_amd as S
+    torch, dev, ctx = gpu
+    d1, _, _ = synth.descriptors(n1, seed=300 + n1)
+    d2, _, _ = synth.descriptors(n2, seed=400 + n2)
+    ctx.set_match_kernel(S.MATCH_EXACT)
+    try:
+        b, s, i = run_soa(gpu, d1, d2)
+    finally:
+        ctx.set_match_kernel(S.MATCH_AUTO)
+    ob, os_, oi = O.match_desc(d1, d2)
+    assert np.array_equal(i, oi)
+    assert same_bits(b, ob) and same_bits(s, os_)
+
+
 def test_match_recovers_permutation_and_ties(gpu):
     n = 2048
     d1, d2, perm = synth.descriptors(n)

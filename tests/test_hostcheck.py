@@ -132,6 +132,30 @@ def test_filter_adversarial_thresholds(H, scene):
         assert H.hc_inlier_filter(fp(E), np.float32(thr), *[float(v) for v in (*X0[:, 0], *X1[:, 0])]) < 0
 
 
+def test_nullvec4_skipped_rotations(H):
+    """Column pairs that are exactly orthogonal are left alone by the 4x4 Jacobi (`if (ga == 0) continue;` in the oracle, selects on
+    the results in the product): matrices with orthogonal, zero, signed-zero, duplicate and NaN / infinite columns -- every bit of
+    the null vector equal, signs of zeros included."""
+    rng = np.random.default_rng(5)
+    cases = [np.eye(4), np.diag([3.0, -2.0, 0.5, 0.0]), np.eye(4)[[1, 0, 3, 2]], np.zeros((4, 4)), -np.zeros((4, 4)),
+             np.array([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 1], [0, 0, 1, 1.0]]),
+             np.array([[1, 1, 0, 0], [1, -1, 0, 0], [0, 0, 2, 0], [0, 0, 0, -0.0]]),
+             np.array([[1, 2, 3, 4], [0, 0, 0, 0], [5, 6, 7, 8], [0, -0.0, 0, 0.0]])]
+    for _ in range(40):                                      # random matrices with some columns zeroed / some blocks decoupled
+        A = rng.standard_normal((4, 4))
+        if rng.random() < 0.5: A[:, rng.integers(0, 4)] = 0.0
+        if rng.random() < 0.5: A[:2, 2:] = 0.0; A[2:, :2] = 0.0
+        if rng.random() < 0.3: A[rng.integers(0, 4), :] = -0.0
+        cases.append(A)
+    nanA = rng.standard_normal((4, 4)); nanA[1, 2] = np.nan; cases.append(nanA)
+    infA = rng.standard_normal((4, 4)); infA[3, 0] = np.inf; cases.append(infA)
+    for A in cases:
+        A = np.ascontiguousarray(A, np.float32).reshape(16)
+        for sweeps in (1, 8):
+            v = np.empty(4, np.float32); H.hc_nullvec4(fp(A), sweeps, fp(v))
+            assert same_bits(v, O.nullvec4(A, sweeps)), (A, sweeps)
+
+
 def test_pose_and_4x4(H, scene):
     X0, X1 = scene
     rng = np.random.default_rng(0)
