@@ -698,43 +698,78 @@ SFM_HD void tri_rows(float x1, float y1, float x2, float y2, const float *m1, co
     }
 }
 
-// replaces cusolverDnSgesvdjBatched on 4x4 (svd_square, kernels.h:175-194)
+// One rotation of the 4x4 one-sided Jacobi on columns (p, q) of G (and V).  A pair with ga == 0 is left alone -- written as
+// selects on the results, not as a branch around the rotation: a divergent `continue` made the compiler copy G and V (~50
+// register moves per rotation next to ~60 instructions of arithmetic; this loop is most of the pose chain of one pair).  The
+// selects keep the untouched values bit for bit (signed zeros, NaN), which c = 1, s = 0 through the formulas would not.
+template <int p, int q>
+SFM_HD void jacobi4_rotate(float (&G)[16], float (&V)[16])
+{
+    float al = G[p] * G[p], be = G[q] * G[q], ga = G[p] * G[q];
+#pragma unroll
+    for (int k = 1; k < 4; ++k) {
+        al = fmaf(G[4 * k + p], G[4 * k + p], al);
+        be = fmaf(G[4 * k + q], G[4 * k + q], be);
+        ga = fmaf(G[4 * k + p], G[4 * k + q], ga);
+    }
+    const bool rot = !(ga == 0.0f);
+    float c, s;
+    jacobi_cs(al, be, ga, c, s);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float gp = G[4 * k + p], gq = G[4 * k + q];
+        const float ngp = fmaf(-s, gq, c * gp), ngq = fmaf(s, gp, c * gq);
+        G[4 * k + p] = rot ? ngp : gp;
+        G[4 * k + q] = rot ? ngq : gq;
+        const float vp = V[4 * k + p], vq = V[4 * k + q];
+        const float nvp = fmaf(-s, vq, c * vp), nvq = fmaf(s, vp, c * vq);
+        V[4 * k + p] = rot ? nvp : vp;
+        V[4 * k + q] = rot ? nvq : vq;
+    }
+}
+
+// The rotations (0,3) and (1,2) follow each other in the cyclic order and touch disjoint columns: done together, element 0 of
+// every packed value = pair (0,3), element 1 = pair (1,2) -- per element exactly the operations of jacobi4_rotate.
+SFM_HD void jacobi4_rotate_03_12(float (&G)[16], float (&V)[16])
+{
+    v2f P[4], Q[4], VP[4], VQ[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        P[k] = v2f{ G[4 * k + 0], G[4 * k + 1] };  Q[k] = v2f{ G[4 * k + 3], G[4 * k + 2] };
+        VP[k] = v2f{ V[4 * k + 0], V[4 * k + 1] }; VQ[k] = v2f{ V[4 * k + 3], V[4 * k + 2] };
+    }
+    v2f al = P[0] * P[0], be = Q[0] * Q[0], ga = P[0] * Q[0];
+#pragma unroll
+    for (int k = 1; k < 4; ++k) {
+        al = fma_t(P[k], P[k], al);
+        be = fma_t(Q[k], Q[k], be);
+        ga = fma_t(P[k], Q[k], ga);
+    }
+    const v2i rot = ne_t(ga, splat_t<v2f>(0.0f));          // !(ga == 0): true for NaN as well
+    v2f c, s;
+    jacobi_cs(al, be, ga, c, s);
+    const v2f ns = neg_t(s);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const v2f nP = sel_t(rot, fma_t(ns, Q[k], c * P[k]), P[k]), nQ = sel_t(rot, fma_t(s, P[k], c * Q[k]), Q[k]);
+        const v2f nVP = sel_t(rot, fma_t(ns, VQ[k], c * VP[k]), VP[k]), nVQ = sel_t(rot, fma_t(s, VP[k], c * VQ[k]), VQ[k]);
+        G[4 * k + 0] = nP.x;  G[4 * k + 1] = nP.y;  G[4 * k + 3] = nQ.x;  G[4 * k + 2] = nQ.y;
+        V[4 * k + 0] = nVP.x; V[4 * k + 1] = nVP.y; V[4 * k + 3] = nVQ.x; V[4 * k + 2] = nVQ.y;
+    }
+}
+
+// replaces cusolverDnSgesvdjBatched on 4x4 (svd_square, kernels.h:175-194): cyclic order (0,1) (0,2) (0,3) (1,2) (1,3) (2,3)
 SFM_HD void nullvec4(const float A[16], const int sweeps, float v[4])
 {
     float G[16], V[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) { G[i] = A[i]; V[i] = (i % 5 == 0) ? 1.0f : 0.0f; }
     for (int sw = 0; sw < sweeps; ++sw) {
-#pragma unroll
-        for (int p = 0; p < 3; ++p)
-#pragma unroll
-            for (int q = p + 1; q < 4; ++q) {
-                float al = G[p] * G[p], be = G[q] * G[q], ga = G[p] * G[q];
-#pragma unroll
-                for (int k = 1; k < 4; ++k) {
-                    al = fmaf(G[4 * k + p], G[4 * k + p], al);
-                    be = fmaf(G[4 * k + q], G[4 * k + q], be);
-                    ga = fmaf(G[4 * k + p], G[4 * k + q], ga);
-                }
-                // a pair with ga == 0 is left alone.  Written as selects on the results, not as a branch around the rotation:
-                // a divergent `continue` here made the compiler copy G and V (~50 register moves per rotation next to ~60
-                // instructions of arithmetic; this loop is most of the 18 us pose chain of one pair).  The selects keep the
-                // untouched values bit for bit (signed zeros, NaN), which c = 1, s = 0 through the formulas would not.
-                const bool rot = !(ga == 0.0f);
-                float c, s;
-                jacobi_cs(al, be, ga, c, s);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const float gp = G[4 * k + p], gq = G[4 * k + q];
-                    const float ngp = fmaf(-s, gq, c * gp), ngq = fmaf(s, gp, c * gq);
-                    G[4 * k + p] = rot ? ngp : gp;
-                    G[4 * k + q] = rot ? ngq : gq;
-                    const float vp = V[4 * k + p], vq = V[4 * k + q];
-                    const float nvp = fmaf(-s, vq, c * vp), nvq = fmaf(s, vp, c * vq);
-                    V[4 * k + p] = rot ? nvp : vp;
-                    V[4 * k + q] = rot ? nvq : vq;
-                }
-            }
+        jacobi4_rotate<0, 1>(G, V);
+        jacobi4_rotate<0, 2>(G, V);
+        jacobi4_rotate_03_12(G, V);
+        jacobi4_rotate<1, 3>(G, V);
+        jacobi4_rotate<2, 3>(G, V);
     }
     int m = 0;
     float best = 0.0f;
