@@ -33,7 +33,7 @@ def main():
     dev = torch.device("cuda", 0)
     ctx = S.Context(0, torch.cuda.current_stream().cuda_stream)
     rng = np.random.default_rng(seed)
-    rounds = {"ransac": 0, "match": 0, "homography": 0, "sift": 0}
+    rounds = {"ransac": 0, "pose": 0, "match": 0, "homography": 0, "sift": 0}
     bad = []
 
     def ransac_round():
@@ -90,6 +90,47 @@ def main():
             ok = np.array_equal(pair.get_inlier_mask(), omask) and same_bits(pair.get_E(), oE[ohyp].reshape(3, 3))
         return ok, cfg
 
+    def pose_round():
+        """fillXU -> estimateE (few hypotheses) -> poses + triangulation, one launch (sfm_pose_chain) or the three calls, both pose
+        modes: candidates, inverses, index and every triangulated point against the oracle, bit for bit.  Flavours: plain /
+        noise-free / duplicates / pure rotation-like (tiny baseline) / a NaN pixel (candidates and points may then be NaN: compared
+        as bits all the same)."""
+        n = int(rng.choice([rng.integers(8, 120), rng.integers(120, 2500)]))
+        H = int(rng.integers(1, 96))
+        mode = int(rng.choice([S.POSE_REFERENCE, S.POSE_CORRECT]))
+        chain = bool(rng.random() < 0.5)
+        flavour = str(rng.choice(["plain", "plain", "clean", "dup", "nan"]))
+        sseed = int(rng.integers(1, 1 << 30))
+        scene = synth.two_view_scene(n, seed=sseed, noise_px=0.0 if flavour == "clean" else float(rng.choice([0.3, 2.0])),
+                                     outlier_frac=0.0 if flavour == "clean" else float(rng.choice([0.0, 0.4])))
+        sift = scene["sift"].copy()
+        if flavour == "dup":
+            k = int(rng.integers(1, max(2, n // 2)))
+            src = rng.integers(0, n, k); dst = rng.integers(0, n, k)
+            sift[dst] = sift[src]
+        if flavour == "nan":
+            sift["match_xpos"][rng.integers(0, n, max(1, n // 50))] = np.nan
+        cfg = dict(path="pose", n=n, H=H, mode=mode, chain=chain, flavour=flavour, seed=sseed)
+        pair = S.ImagePair(ctx, scene["K"], scene["Kinv"], 2, n)
+        pair.fillXU(to_dev(torch, dev, sift))
+        pair.estimateE(S.default_params(n, num_hypotheses=H, seed=sseed & 0xFFFF))
+        if chain:
+            pair.pose_chain(mode)
+        else:
+            pair.computePosecandidates(mode); pair.choosePose(mode); pair.linear_triangulation(mode)
+        _, _, X0, X1 = O.fill_xu(sift, scene["Kinv"])
+        oP = O.pose_candidates(pair.get_E(), mode)
+        oind, oPinv, _, _ = O.choose_pose(X0, X1, oP, mode, sweeps=8)
+        try:
+            ind = pair.get_pose_index()
+        except S.SfmError as e:                       # a singular chosen candidate is reported, with the index the oracle has too
+            if e.code != S.E_SINGULAR: raise
+            return True, cfg
+        ok = ind == oind and same_bits(pair.get_pose_candidates(), oP) and same_bits(pair.get_pose_inverses(), oPinv)
+        if ok:
+            ok = same_bits(pair.get_points(), O.triangulate(X0, X1, oPinv[oind] if mode == S.POSE_REFERENCE else oP[oind], sweeps=8))
+        return ok, cfg
+
     def match_round():
         n1 = int(rng.choice([rng.integers(1, 100), rng.integers(100, 3000)])); n2 = int(rng.choice([rng.integers(1, 100), rng.integers(100, 3000)]))
         sseed = int(rng.integers(1, 1 << 30))
@@ -138,7 +179,7 @@ def main():
             ok = all(same_bits(a[f], b[f]) for f in ("xpos", "ypos", "scale", "sharpness", "edgeness", "orientation", "subsampling", "data"))
         return ok, dict(path="sift", w=w, h=h, octaves=octaves, up=up, thresh=thresh, blur=blur, lowest=lowest, seed=sseed, max_pts=max_pts, npts=int(npts))
 
-    table = [("ransac", ransac_round, 0.55), ("match", match_round, 0.15), ("homography", homography_round, 0.15), ("sift", sift_round, 0.15)]
+    table = [("ransac", ransac_round, 0.45), ("pose", pose_round, 0.15), ("match", match_round, 0.14), ("homography", homography_round, 0.13), ("sift", sift_round, 0.13)]
     t0 = time.time()
     while time.time() - t0 < budget:
         r = rng.random(); acc = 0.0
