@@ -31,7 +31,7 @@ MAINAPP  := $(PKG)/host/sfm_main
 IOTEST   := tests/cpp/io_test
 GEOMTEST := tests/cpp/geom_test
 
-all: $(LIB) $(LIB_AB) $(COMMLIB) oracle hostcheck $(DEMO) $(HDEMO) $(SDEMO) $(MAINAPP) $(IOTEST) $(GEOMTEST)
+all: $(LIB) $(LIB_AB) $(COMMLIB) oracle hostcheck fakeccl $(DEMO) $(HDEMO) $(SDEMO) $(MAINAPP) $(IOTEST) $(GEOMTEST)
 
 $(BUILD)/%.o: $(CSRC)/%.hip $(HDRS)
 	@mkdir -p $(BUILD)
@@ -87,13 +87,20 @@ $(IOTEST): tests/cpp/io_test.cpp $(PKG)/host/sfm_io.h $(PKG)/host/cudaSift.h inc
 $(GEOMTEST): tests/cpp/geom_test.cpp $(PKG)/host/geomFuncs.h $(PKG)/host/sfm_io.h $(PKG)/host/cudaSift.h include/sfm_amd.h
 	g++ -O2 -std=c++14 -ffp-contract=off -Wall -o $@ $<
 
-hostcheck: tests/hostcheck/libhostcheck.so
+hostcheck: tests/hostcheck/libhostcheck.so tests/fake_ccl/libsfm_amd_fakeccl.so
+
+# TEST HARNESS: comm.cpp linked against a shared-memory stand-in for the nine RCCL calls it makes, so that a 1-GPU box can run the
+# exchange code with two real ranks (tests/test_gpu_fakeccl.py); the product's libsfm_amd_rccl.so is linked against librccl
+FAKECCL := tests/fake_ccl/libsfm_amd_fakeccl.so
+fakeccl: $(FAKECCL)
+$(FAKECCL): $(CSRC)/comm.cpp tests/fake_ccl/fake_ccl.cpp include/sfm_amd_comm.h include/sfm_amd.h $(LIB)
+	$(HIPCC) -x hip --cuda-host-only -O2 -fPIC -fvisibility=hidden -shared -Iinclude -Wl,--version-script=$(CSRC)/exports.map -o $@ $(CSRC)/comm.cpp tests/fake_ccl/fake_ccl.cpp -L$(PKG)/lib -lsfm_amd -lrt -lpthread -Wl,-rpath,'$$ORIGIN/../../$(PKG)/lib'
 
 tests/hostcheck/libhostcheck.so: tests/hostcheck/hostcheck.hip $(CSRC)/device_math.hpp $(CSRC)/sift_math.hpp $(CSRC)/prefilter_math.hpp $(CSRC)/match_prefilter_math.hpp
 	$(HIPCC) -x hip --cuda-host-only -O2 -ffp-contract=off -mfma -fPIC -shared -Wno-pass-failed -o $@ $<
 
 clean:
-	rm -rf $(BUILD) $(LIB) $(LIB_AB) $(DEMO) $(HDEMO) $(SDEMO) $(MAINAPP) $(IOTEST) $(GEOMTEST) tests/hostcheck/libhostcheck.so
+	rm -rf $(BUILD) $(LIB) $(LIB_AB) $(DEMO) $(HDEMO) $(SDEMO) $(MAINAPP) $(IOTEST) $(GEOMTEST) tests/hostcheck/libhostcheck.so tests/fake_ccl/libsfm_amd_fakeccl.so
 	$(MAKE) -C oracle clean
 
-.PHONY: all ab oracle hostcheck clean
+.PHONY: all ab oracle hostcheck fakeccl clean

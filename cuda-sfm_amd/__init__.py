@@ -542,7 +542,9 @@ def estimate_E_distributed(pair, params, rank, world, key_tensor, all_reduce_max
 # ---- RCCL exchange step in C (include/sfm_amd_comm.h, libsfm_amd_rccl.so) ----------------------------
 COMM_EXPORTS = ["sfm_comm_unique_id", "sfm_comm_init", "sfm_comm_destroy", "sfm_comm_rank", "sfm_comm_nccl_ranks", "sfm_estimate_E_sharded",
                 "sfm_estimate_E_sharded_pipelined", "sfm_comm_flush", "sfm_process_views_sharded", "sfm_comm_last_exchange"]
-COMM_LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), "libsfm_amd_rccl.so")
+# (SFM_AMD_COMM_LIB: tests only -- tests/fake_ccl/libsfm_amd_fakeccl.so is the same comm.cpp linked against a shared-memory stand-in for
+#  RCCL, so that two ranks can run on the ONE GPU of a test box: tests/test_gpu_fakeccl.py)
+COMM_LIB_PATH = os.environ.get("SFM_AMD_COMM_LIB") or os.path.join(os.path.dirname(LIB_PATH), "libsfm_amd_rccl.so")
 COMM_ID_BYTES = 128
 _comm_lib = None
 
