@@ -626,6 +626,23 @@ def run_extras(S, synth, O, ctx, dev, torch, np, skip):
 # ------------------------------------------------------------------------------------------------------------------
 # one rank
 # ------------------------------------------------------------------------------------------------------------------
+def dist_backend():
+    """"nccl" (= RCCL), or what SFM_BENCH_DIST_BACKEND names: tests run two ranks on ONE GPU with gloo as torch.distributed's
+    backend and tests/fake_ccl behind libsfm_amd_rccl's entry points (tests/test_gpu_fakeccl.py) -- two RCCL ranks cannot share a GPU."""
+    return os.environ.get("SFM_BENCH_DIST_BACKEND", "nccl")
+
+
+def init_dist(dist, rank, world, dev):
+    if dist_backend() == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group(dist_backend(), rank=rank, world_size=world)
+
+
+def ctl_device(dev):
+    return dev if dist_backend() == "nccl" else "cpu"
+
+
 def rank_main(args):
     import numpy as np
     import torch
@@ -650,7 +667,8 @@ def rank_main(args):
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        init_dist(dist, rank, world, dev)
+    cdev = ctl_device(dev)                                # where the few control-plane tensors of this script live
 
     n = args.matches if args.matches is not None else CONFIGS[args.config][0]
     H = args.hyps if args.hyps is not None else CONFIGS[args.config][1]
@@ -686,7 +704,7 @@ def rank_main(args):
             comm = S.Comm(ctx, uid[0], rank, world)
         except Exception as e:                            # noqa: BLE001 -- any failure means "use the other exchange"
             err = f"{type(e).__name__}: {e}"
-        ok = torch.tensor([0 if err else 1], dtype=torch.int32, device=dev)
+        ok = torch.tensor([0 if err else 1], dtype=torch.int32, device=cdev)
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         if int(ok.item()) == 0:
             comm = None
@@ -776,7 +794,7 @@ def rank_main(args):
     rc = 0
     agree = None
     if world > 1:
-        t = torch.tensor(region_s, dtype=torch.float64, device=dev)
+        t = torch.tensor(region_s, dtype=torch.float64, device=ctl_device(dev))
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         region_s = [float(v) for v in t.cpu().numpy()]
         elapsed = region_s[0]
@@ -822,7 +840,7 @@ def rank_main(args):
         fence()
         vel = time.perf_counter() - vt0
         if world > 1:
-            t = torch.tensor([vel], dtype=torch.float64, device=dev)
+            t = torch.tensor([vel], dtype=torch.float64, device=cdev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             vel = float(t.item())
         vh, vc = pair.get_best()
@@ -953,7 +971,7 @@ def c5_rank_main(args):
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        init_dist(dist, rank, world, dev)
     views_f = [read_pnm_grey(dino_frame(k)) for k in range(36)]
     views8 = [v.astype(np.uint8) for v in views_f]
     pairs = S.ring_pairs(36) if args.pairs == "ring" else [(i, j) for i in range(36) for j in range(i + 1, 36)]
@@ -1002,7 +1020,7 @@ def c5_rank_main(args):
     rec = np.stack([res[k] if k in res else np.full(28, -1.0, np.float32) for k in range(len(pairs))])
     agree = None
     if world > 1:
-        t = torch.tensor(region_s, dtype=torch.float64, device=dev)
+        t = torch.tensor(region_s, dtype=torch.float64, device=ctl_device(dev))
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         region_s = [float(v) for v in t.cpu().numpy()]
         mine = {"rank": rank, "records_sha": hashlib.sha256(rec.tobytes()).hexdigest()[:16], "pairs_done": len(res), "counts_sha": hashlib.sha256(np.asarray(counts, np.int32).tobytes()).hexdigest()[:16],
