@@ -663,6 +663,8 @@ def rank_main(args):
     if not torch.cuda.is_available():
         print("bench.py needs a GPU (there is no CPU fallback)", file=sys.stderr)
         return 2
+    if dist_backend() != "nccl":                          # (tests: several ranks on the GPUs there are, tests/test_gpu_fakeccl.py)
+        local %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
@@ -967,6 +969,8 @@ def c5_rank_main(args):
     if not os.path.exists(dino_frame(35)):
         print("bench.py --config c5: tests/golden/dino fixtures not present", file=sys.stderr)
         return 2
+    if dist_backend() != "nccl":                          # (tests: several ranks on the GPUs there are, tests/test_gpu_fakeccl.py)
+        local %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:

@@ -98,3 +98,24 @@ def test_bench_c5_two_ranks_on_one_gpu():
     assert rec["config"]["nccl_ranks"] == 2
     ex = rec["exchange"]
     assert ex["sum_count_x_576"] <= ex["feature_bytes_into_each_rank"] <= 1.1 * ex["sum_count_x_576"]
+
+
+@pytest.mark.parametrize("nproc", [2, 8])
+def test_bench_under_torch_distributed_run_on_one_gpu(nproc):
+    """The driver's own command line: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N --steps K --warmup W` (torchrun sets RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*), with the
+    N ranks folded onto the one GPU of this box (N = 2 and N = 8, the driver's largest)."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, SFM_AMD_COMM_LIB=FAKE, SFM_BENCH_DIST_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", str(nproc), "--steps", "3", "--warmup", "1", "--regions", "1", "--hyps", "65536", "--no-variants"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == nproc and rec["steps"] == 3 and rec["warmup"] == 1 and rec["higher_is_better"] is True
+    assert rec["result"]["multi_gpu"]["ranks_agree_on_winner_E_mask"] and rec["config"]["nccl_ranks"] == nproc
+    assert len(rec["result"]["multi_gpu"]["per_rank"]) == nproc
+    for key in ("metric", "value", "unit", "ms_per_step", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in rec, key
