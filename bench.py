@@ -174,7 +174,7 @@ def launch_ranks(n, argv, env_extra=None, command=None, timeout=3600.0):
 
 def launcher_main(args, argv):
     have = visible_gpus()
-    if have < args.gpus:
+    if have < args.gpus and os.environ.get("SFM_BENCH_DIST_BACKEND", "nccl") == "nccl":      # (tests fold the ranks onto the GPUs there are)
         print(f"bench.py: --gpus {args.gpus} but this node shows {have} GPU(s); nothing was run", file=sys.stderr)
         return 2
     return launch_ranks(args.gpus, argv)

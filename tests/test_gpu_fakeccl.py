@@ -119,3 +119,17 @@ def test_bench_under_torch_distributed_run_on_one_gpu(nproc):
     assert len(rec["result"]["multi_gpu"]["per_rank"]) == nproc
     for key in ("metric", "value", "unit", "ms_per_step", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
         assert key in rec, key
+
+
+def test_bench_own_launcher_on_one_gpu():
+    """`python bench.py --gpus 2 ...` without a launcher around it: bench.py starts its own ranks (launcher_main)."""
+    env = dict(os.environ, SFM_AMD_COMM_LIB=FAKE, SFM_BENCH_DIST_BACKEND="gloo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--regions", "1", "--hyps", "65536",
+                        "--no-variants"], env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["config"]["nccl_ranks"] == 2 and rec["result"]["multi_gpu"]["ranks_agree_on_winner_E_mask"]
