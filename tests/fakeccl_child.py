@@ -97,6 +97,21 @@ for seed in (5, 6, 7):
     ok = ok and p2.get_key() == want[0] and np.array_equal(p2.get_E().view(np.uint32), want[1].view(np.uint32)) and np.array_equal(p2.get_inlier_mask(), want[2])
     stage("other_scene", seed=seed, winner_owner=owner, ok=bool(ok))
 
+# fewer hypotheses than ranks, and counts that do not divide: some ranks own an EMPTY shard (key 0) and still take part
+for Ht in (1, 2, 3, 5, 64, 65):
+    pt = S.default_params(n, num_hypotheses=Ht, seed=3)
+    pair.estimateE(pt)
+    want = (pair.get_key(), pair.get_E().copy(), pair.get_inlier_mask().copy(), pair.get_best())
+    pt = S.default_params(n, num_hypotheses=Ht, seed=3)
+    comm.estimate_E(pair, pt)
+    good = pair.get_key() == want[0] and pair.get_best() == want[3] and np.array_equal(pair.get_E().view(np.uint32), want[1].view(np.uint32)) and np.array_equal(pair.get_inlier_mask(), want[2])
+    for _ in range(3):
+        comm.estimate_E_pipelined(pair, pt)
+    comm.flush()
+    good = good and pair.get_best() == want[3] and np.array_equal(pair.get_E().view(np.uint32), want[1].view(np.uint32)) and np.array_equal(pair.get_inlier_mask(), want[2])
+    ok = ok and good
+    stage("tiny_range", H=Ht, my_shard=list(S.shard_range(Ht, rank, world)), ok=bool(good))
+
 # configs[4] inside the C library: 5 views over 2 ranks (3 + 2), one of them without a single feature, 6 pairs
 w, h = 384, 288
 base_d = np.array([5.0, 8.0, 12.0, 16.0, 7.0, 10.0], np.float32)

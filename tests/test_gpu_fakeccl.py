@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 FAKE = os.path.join(ROOT, "tests", "fake_ccl", "libsfm_amd_fakeccl.so")
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_ranks_on_one_gpu_through_comm_cpp(world):
     assert os.path.exists(FAKE), "run `make` (the fakeccl target builds tests/fake_ccl/libsfm_amd_fakeccl.so)"
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
