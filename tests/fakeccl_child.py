@@ -97,6 +97,20 @@ for seed in (5, 6, 7):
     ok = ok and p2.get_key() == want[0] and np.array_equal(p2.get_E().view(np.uint32), want[1].view(np.uint32)) and np.array_equal(p2.get_inlier_mask(), want[2])
     stage("other_scene", seed=seed, winner_owner=owner, ok=bool(ok))
 
+# two pairs interleaved through the pipelined entry point (each step's slot, key and finalize belong to ITS pair), then a serial
+# call right behind pipelined ones without an explicit flush
+q = S.default_params(n, num_hypotheses=H, seed=9)
+for _ in range(3):
+    comm.estimate_E_pipelined(pair, q)
+    comm.estimate_E_pipelined(p2, r2)
+comm.flush()
+good = same_as_ref(with_key=False) and np.array_equal(p2.get_E().view(np.uint32), want[1].view(np.uint32)) and np.array_equal(p2.get_inlier_mask(), want[2])
+comm.estimate_E_pipelined(p2, r2)
+comm.estimate_E(pair, q)                                        # (flushes the pending finalize itself)
+good = good and same_as_ref() and np.array_equal(p2.get_E().view(np.uint32), want[1].view(np.uint32))
+ok = ok and good
+stage("interleaved_pairs", ok=bool(good))
+
 # fewer hypotheses than ranks, and counts that do not divide: some ranks own an EMPTY shard (key 0) and still take part
 for Ht in (1, 2, 3, 5, 64, 65):
     pt = S.default_params(n, num_hypotheses=Ht, seed=3)
