@@ -67,6 +67,23 @@ def test_lab_bench_flavour_imports_next_to_the_product():
         A.comm_lib()                                  # the communicator library is linked against the product
 
 
+def test_test_only_comm_build_has_the_products_abi_and_no_rccl():
+    """tests/fake_ccl/libsfm_amd_fakeccl.so (comm.cpp linked against the shared-memory stand-in, tests/test_gpu_fakeccl.py) exports
+    exactly what libsfm_amd_rccl.so exports, depends on the core library and NOT on librccl -- and the product's comm library does
+    depend on librccl (the stand-in never ships)."""
+    import subprocess
+    import cuda_sfm_amd as S
+    fake = os.path.join(ROOT, "tests", "fake_ccl", "libsfm_amd_fakeccl.so")
+    assert os.path.exists(fake), "run `make`"
+    assert _nm_exports(fake) == sorted(S.COMM_EXPORTS)
+    need_fake = subprocess.run(["readelf", "-d", fake], capture_output=True, text=True).stdout
+    assert "libsfm_amd.so" in need_fake and "rccl" not in need_fake and "nccl" not in need_fake
+    default_comm = os.path.join(os.path.dirname(S.LIB_PATH), "libsfm_amd_rccl.so")
+    need_real = subprocess.run(["readelf", "-d", default_comm], capture_output=True, text=True).stdout
+    assert "librccl" in need_real
+    assert "fakeccl" not in S.COMM_LIB_PATH or os.environ.get("SFM_AMD_COMM_LIB")
+
+
 def test_comm_header_symbols_exported():
     """include/sfm_amd_comm.h <-> libsfm_amd_rccl.so (the RCCL exchange step lives in its own library)."""
     import cuda_sfm_amd as S
