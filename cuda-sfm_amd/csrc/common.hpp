@@ -139,7 +139,8 @@ struct sfm_pair {
     uint32_t *d_tick = nullptr;        // pre-filter kernel: per 32-hypothesis group, how many tiles have been added
     float *d_Ecand = nullptr;
     void *d_pf = nullptr;              // pre-filter kernel: one PfRecord (64 bytes, prefilter_record.hpp) per hypothesis of the shard
-    unsigned long long *d_bound = nullptr; // (fillXU epoch << 32) | bits of the largest |coordinate| <= 48 over all points: atomicMax, never reset
+    unsigned long long *d_bound = nullptr; // (fillXU epoch << 32) | bits of the largest |coordinate| <= 48 over all points: atomicMax, never reset;
+                                           // words 2..9: the same for the coordinate ranges of the two views (prefilter_math.hpp: pf_box_from_words)
     uint32_t bound_epoch = 0;
     bool have_bound = false;           // d_bound describes the current points (fillXU)
     uint32_t *d_cells = nullptr;       // pre-filter: open-addressing table of the occupied zero-divisor grid cells of ALL points (launch_pf_cells)
@@ -183,6 +184,7 @@ int launch_ransac_finalize(sfm_pair *pair, const sfm_ransac_params &p, const uns
 int launch_permutation_indices(sfm_ctx *ctx, int n, uint32_t seed, int32_t *d_indices);
 // ransac_prefilter.hip
 bool prefilter_usable(const sfm_pair *pair, const sfm_ransac_params &p, uint32_t count);
+int prefilter_rule(const sfm_ransac_params &p);                                 // kPfRuleBand (the product) / kPfRuleG (lab bench, reserved[3] == 4)
 int launch_score_prefilter(sfm_pair *pair, const sfm_ransac_params &p, uint32_t h0, uint32_t count, unsigned long long *key2);
 int launch_pf_prep(sfm_pair *pair, const sfm_ransac_params &p, uint32_t count);
 int launch_pf_cells(sfm_pair *pair);                                            // the pair's cell table, (re)built when the points changed        // PfRecords from d_Ecand (paths whose solve kernel does not write them)

@@ -290,4 +290,143 @@ SFM_HD bool prefilter_reject(float nt, float G)
     return (f32_bits(fmaf(-nt, nt, G)) >> 31) != 0u;
 }
 
+// =====================================================================================================================
+// Round 5: the BAND rule -- one vector instruction per pair instead of two, two matrix-core instructions per 32 x 32 pairs
+// instead of three.
+//
+// The G rule above compares nt^2 with a per-PAIR threshold G (a second contraction), which costs a v_fma and a v_alignbit per
+// pair.  The band rule compares |n| with a per-HYPOTHESIS constant: with Da >= da_c, Db >= db_c for every point of the pair
+// (maxima of convex functions over the bounding boxes of the two views' coordinates: attained at a corner),
+//     inlier, da_c, db_c > 0   =>   nn_c^2 <= thr (1 + 2^-21) da_c db_c / (da_c + db_c) <= thr (1 + 2^-21) Da Db / (Da + Db)
+//     inlier, db_c = 0 < da_c  =>   nn_c^2 <= thr (1 + 2^-21) da_c                      <= thr (1 + 2^-21) Da
+// (x y / (x + y) grows with x and with y; fl(t1 + t2) < thr gives t1 + t2 <= thr (1 + 2^-24), t_i >= (1 - 2^-24) n2 / d_i, n2 >=
+// (1 - 2^-24) nn_c^2; a quotient that underflows only makes the left side smaller).  So with
+//     C  = thr (1 + 2^-19) H,   H = Da Db / (Da + Db)  if no point of the pair can have db_c = 0,  Da otherwise
+//     W  = sqrt(C) + dn + floor                                   (dn, floor: |nt / sigma - nn_c|, see below)
+// every inlier with da_c > 0 has |nn_c| <= sqrt(C) and |nt| <= sigma W, and the coefficients are scaled by
+//     sigma = 1.998 / W      (per hypothesis: a row scaling of the contraction, free)
+// so that the test is |nt| >= 2, i.e. ONE BIT of the accumulator -- bit 30, the top bit of the biased exponent, is set exactly
+// when |x| >= 2 (or x is inf / NaN, which never happens: no inf / NaN enters a matrix-core operand).  The kernel shifts that
+// bit into the lane's mask with one v_alignbit_b32 per accumulator (two bits per accumulator, the sign rides along unused).
+// da_c = 0 is handled exactly as for the G rule ((3) above: per (hypothesis, tile), all pairs survive); db_c = 0 only selects
+// the weaker constant, per hypothesis, through the same analysis on the transposed system and the first view's cell keys.
+//
+// Errors.  nt = sum over 27 k-slots of exact fp16 x fp16 products, accumulated in fp32; coefficient c_k = fl(e_k sigma) / 16,
+// feature g_k = 16 f_k, each split in two fp16 parts (e8: three), the products hi hi, hi lo, lo hi kept:
+//   relative part  <= (3 * 2^-22 [split] + 8 * 2^-24 [accumulation, measured 1.2 * 2^-24 per instruction] + 2^-24 [fl(e sigma)]
+//                     + 2 * 2^-24 [fl(u x), the scaling] + 8 * 2^-24 [the fma chains of nn_c]) sabs  <  3 * 2^-20 sabs = dn
+//   fp16 subnormal floor: a low part below 2^-14 is rounded to a multiple of 2^-24 (error <= 2^-25 absolute):
+//       coefficient low parts   9 * 2^-25 * 16 max(1, B^2) / sigma        (in units of n)  <= 2.2e-6 (1 + B^2) W
+//       feature low parts       8 * 2^-25 * (2 sigma / 16) / sigma         = 2^-25
+//   clamping sigma to 2^18 (fp16 range of the high parts) changes the first floor by < 3.8e-8.
+// Hence W = (sqrt(C) (1 + 2^-22) + dn + 8e-8) (1 + 2.5e-6 (1 + B^2)).  tests/test_hostcheck_prefilter.py runs this header on the
+// CPU against the oracle's residual with both contractions pushed by the full budget.
+struct PfBox { float xlo, xhi, ylo, yhi, ulo, uhi, vlo, vhi; };       // second-view (x, y) and first-view (u, v) coordinate ranges
+
+// Order-preserving map float -> uint32 (for atomicMax over signed floats) and back.
+SFM_HD uint32_t pf_order_bits(float f)
+{
+    const uint32_t b = f32_bits(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+SFM_HD float pf_order_float(uint32_t k)
+{
+    union { float f; uint32_t u; } c;
+    c.u = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k;
+    return c.f;
+}
+
+// The pair's boxes from the eight words fill_xu_kernel leaves behind the bound (low halves: ordered bits of the maxima of
+// x, -x, y, -y of the second view, then u, -u, v, -v of the first); a side without any point falls back to [-B, B].
+SFM_HD PfBox pf_box_from_words(const unsigned long long *w, float B)
+{
+    float m[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) m[k] = pf_order_float((uint32_t)(w[k] & 0xFFFFFFFFull));
+    PfBox box = { -m[1], m[0], -m[3], m[2], -m[5], m[4], -m[7], m[6] };
+    if (!(box.xlo <= box.xhi) || !(box.ylo <= box.yhi) || !(box.xhi <= B) || !(box.xlo >= -B) || !(box.yhi <= B) || !(box.ylo >= -B)) { box.xlo = box.ylo = -B; box.xhi = box.yhi = B; }
+    if (!(box.ulo <= box.uhi) || !(box.vlo <= box.vhi) || !(box.uhi <= B) || !(box.ulo >= -B) || !(box.vhi <= B) || !(box.vlo >= -B)) { box.ulo = box.vlo = -B; box.uhi = box.vhi = B; }
+    return box;
+}
+
+constexpr float kPfBandSigmaMax = 262144.0f;                            // 2^18: |e| <= 2 -> |c| <= 2^15 in fp16
+
+// max over the corners of [lo0, hi0] x [lo1, hi1] of (|c0 X + c1 Y + c2| + 2 eta)^2 + (|c3 X + c4 Y + c5| + 2 eta)^2: an upper bound
+// of the divisor the exact test computes for any point of the box (eta >= the rounding of one affine form, on either side)
+SFM_HD float pf_band_corner_max(float c0, float c1, float c2, float c3, float c4, float c5, float lo0, float hi0, float lo1, float hi1, float eta)
+{
+    float m = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float X = (k & 1) ? hi0 : lo0, Y = (k & 2) ? hi1 : lo1;
+        const float p = fabsf(fmaf(c1, Y, fmaf(c0, X, c2))) + 2.0f * eta;
+        const float q = fabsf(fmaf(c4, Y, fmaf(c3, X, c5))) + 2.0f * eta;
+        m = fmaxf(m, fmaf(q, q, p * p));
+    }
+    return m * 1.000001f;
+}
+
+// sigma of a hypothesis (0: every pair survives).  b_safe: no point of the pair can have db_c == 0.
+SFM_HD float prefilter_band_sigma(const float e[9], float thr, float B, const PfBox &box, bool b_safe)
+{
+    float ae[9];
+    bool tame = B <= 48.0f;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { ae[k] = fabsf(e[k]); tame = tame && (ae[k] <= 2.0f); }      // NaN compares false
+    if (!tame) return 0.0f;
+    const float sabs = ae[8] + B * (ae[2] + ae[5] + ae[6] + ae[7]) + B * B * (ae[0] + ae[1] + ae[3] + ae[4]);
+    const float dn = 2.8610229e-06f * sabs;                                                    // 3 * 2^-20
+    const float lin = B * (ae[0] + ae[1] + ae[3] + ae[4]);
+    const float eta_a = 2.3841858e-07f * (ae[2] + ae[5] + lin), eta_b = 2.3841858e-07f * (ae[6] + ae[7] + lin);      // 4 * 2^-24
+    const float Da = pf_band_corner_max(e[0], e[1], e[2], e[3], e[4], e[5], box.xlo, box.xhi, box.ylo, box.yhi, eta_a);
+    const float Db = pf_band_corner_max(e[0], e[3], e[6], e[1], e[4], e[7], box.ulo, box.uhi, box.vlo, box.vhi, eta_b);
+    float H = Da;
+    if (b_safe) H = (Da * Db) / (Da + Db) * 1.000001f;
+    const float C = (thr * 1.000002f) * H;
+    const float W = (sqrtf(C) * 1.0000003f + dn + 8e-8f) * (1.0f + 2.5e-6f * (1.0f + B * B));
+    float sigma = 1.998f / W;
+    if (!(sigma <= kPfBandSigmaMax)) sigma = kPfBandSigmaMax;                                  // (also W == 0 or NaN: 0 / 0 boxes)
+    if (!(W > 0.0f) || !(W < 64.0f) || !(H == H)) return 0.0f;                                 // nothing sensible to scale by: every pair survives
+    return sigma;
+}
+
+// Coefficient slots of the band rule (same k-slot order as prefilter_hyp_slots' ns); sigma == 0: all zero (nt = 0: survives).
+SFM_HD void prefilter_band_hyp_slots(const float e[9], float sigma, _Float16 ns[kPfSlots])
+{
+#pragma unroll
+    for (int k = 0; k < kPfSlots; ++k) ns[k] = (_Float16)0.0f;
+    ns[27] = (_Float16)1.0f;                            // x the pad marker of a padding point (256 >= 2: rejected)
+    if (!(sigma > 0.0f)) return;
+    const int order[8] = { 0, 1, 3, 4, 2, 5, 6, 7 };
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        _Float16 h, m;
+        pf_split2((e[order[i]] * sigma) * 0.0625f, h, m);
+        ns[3 * i] = h; ns[3 * i + 1] = h; ns[3 * i + 2] = m;
+    }
+    pf_split3((e[8] * sigma) * 0.0625f, ns[24], ns[25], ns[26]);
+}
+
+// The rule: bit 30 of the accumulator (|nt| >= 2).
+SFM_HD bool prefilter_band_reject(float nt)
+{
+    return ((f32_bits(nt) >> 30) & 1u) != 0u;
+}
+
+// The coefficients of the OTHER divisor in the positions prefilter_zero_divisor_cells / prefilter_zero_divisor read:
+// b = A^T x1 + (e6, e7) has rows (e0 e3 e6), (e1 e4 e7), so the same code decides db_c = 0 for first-view positions.
+SFM_HD void prefilter_transposed(const float e[9], float et[9])
+{
+    et[0] = e[0]; et[1] = e[3]; et[2] = e[6];
+    et[3] = e[1]; et[4] = e[4]; et[5] = e[7];
+    et[6] = e[2]; et[7] = e[5]; et[8] = e[8];
+}
+
+// Keys of the two views in ONE table of occupied cells: the first view's are told apart by a flipped bit pattern.
+SFM_HD uint32_t pf_cell_key_side(int ix, int iy, int side)
+{
+    const uint32_t k = pf_cell_key(ix, iy);
+    return side ? ((k ^ 0x2AAAAAAAu) | 1u) : k;
+}
+
 } // namespace sfm

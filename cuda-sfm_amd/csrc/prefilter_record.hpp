@@ -24,6 +24,7 @@ namespace sfm {
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 
+constexpr int kPfRuleG = 0, kPfRuleBand = 1;       // which rule a record / a scoring kernel instance follows (prefilter_math.hpp)
 constexpr int kPfGroup = 32;                       // hypotheses per pass of a scoring wavefront (one MFMA row block)
 constexpr unsigned short kPfFlagScan = 0x3C00u;    // "check every point" (any non-zero pattern would do; this one is fp16 1.0)
 
@@ -104,6 +105,77 @@ __device__ __forceinline__ void pf_record_expand(const uint4 r0, const uint4 r1,
     n0 = __builtin_bit_cast(h8, uint4{ o[0], o[1], o[2], o[3] });
     n1 = __builtin_bit_cast(h8, uint4{ o[4], o[5], o[6], o[7] });
     t = __builtin_bit_cast(h8, uint4{ o[8], o[9], o[10], o[11] });
+}
+// ---- band rule (prefilter_math.hpp, round 5): the same 64-byte record with the threshold contraction's slots unused ------------
+//   lo[16]: h0 m0 | h1 m1 | h2 h5 | m5 h6 | m6 h7 | m7 0 | 0 0 | 0 0         hi[16]: m2 h3 | m3 h4 | m4 h5 | e8h e8m | e8l FLAG | 0 ...
+// box: the coordinate ranges of the pair's points (fill_xu_kernel); cells: the pair's table of occupied cells, BOTH views (the
+// first view's keys flipped, pf_cell_key_side).  FLAG as above (first divisor); a possible zero of the SECOND divisor only selects
+// the weaker constant of the rule.
+__device__ __forceinline__ bool pf_cells_occupied(const uint32_t *__restrict__ cells, uint32_t cells_mask, int cx0, int cx1, int cy0, int cy1, int side)
+{
+    bool hit = false;
+    for (int cy = cy0; cy <= cy1; ++cy)
+        for (int cx = cx0; cx <= cx1; ++cx) {
+            const uint32_t key = pf_cell_key_side(cx, cy, side);
+            uint32_t sl = pf_cells_slot(key, cells_mask);
+            for (;;) {
+                const uint32_t got = cells[sl];
+                if (got == key) hit = true;
+                if (got == key || got == 0u) break;
+                sl = (sl + 1) & cells_mask;
+            }
+        }
+    return hit;
+}
+
+__device__ __forceinline__ void pf_band_prep_store(const float e[9], float thr, float B, const PfBox &box, const uint32_t *__restrict__ cells,
+                                                   uint32_t cells_mask, PfRecord *out)
+{
+    const PfGrid grid = prefilter_grid(B);
+    int cx0, cx1, cy0, cy1;
+    const int zs = prefilter_zero_divisor_cells(e, B, grid, cx0, cx1, cy0, cy1);
+    bool scan = zs == 2;
+    if (zs == 1) scan = !cells || pf_cells_occupied(cells, cells_mask, cx0, cx1, cy0, cy1, 0);
+    float et[9];
+    prefilter_transposed(e, et);
+    const int zb = prefilter_zero_divisor_cells(et, B, grid, cx0, cx1, cy0, cy1);
+    bool b_safe = zb == 0;
+    if (zb == 1) b_safe = cells && !pf_cells_occupied(cells, cells_mask, cx0, cx1, cy0, cy1, 1);
+    const float sigma = prefilter_band_sigma(e, thr, B, box, b_safe);
+    _Float16 ns[kPfSlots];
+    prefilter_band_hyp_slots(e, sigma, ns);
+    auto bits = [](_Float16 v) { return __builtin_bit_cast(unsigned short, v); };
+    const unsigned short lo[16] = { bits(ns[0]), bits(ns[2]), bits(ns[3]), bits(ns[5]), bits(ns[6]), bits(ns[15]), bits(ns[17]), bits(ns[18]),
+                                    bits(ns[20]), bits(ns[21]), bits(ns[23]), 0, 0, 0, 0, 0 };
+    const unsigned short hi[16] = { bits(ns[8]), bits(ns[9]), bits(ns[11]), bits(ns[12]), bits(ns[14]), bits(ns[15]), bits(ns[24]), bits(ns[25]),
+                                    bits(ns[26]), (unsigned short)(scan ? kPfFlagScan : 0u), 0, 0, 0, 0, 0, 0 };
+    uint4 q[4];
+#pragma unroll
+    for (int w = 0; w < 8; ++w) {
+        reinterpret_cast<uint32_t *>(q)[w] = (uint32_t)lo[2 * w] | ((uint32_t)lo[2 * w + 1] << 16);
+        reinterpret_cast<uint32_t *>(q)[8 + w] = (uint32_t)hi[2 * w] | ((uint32_t)hi[2 * w + 1] << 16);
+    }
+    uint4 *dst = reinterpret_cast<uint4 *>(out);
+    dst[0] = q[0]; dst[1] = q[1]; dst[2] = q[2]; dst[3] = q[3];
+}
+
+// The two A fragments of a lane out of its half of a band-rule record (r0 = words 0..3, r1 = words 4..7 of the half).
+__device__ __forceinline__ void pf_band_record_expand(const uint4 r0, const uint4 r1, int half, h8 &n0, h8 &n1, uint32_t &flag)
+{
+    uint32_t o[8];
+    if (half == 0) {
+        const uint32_t A0 = r0.x, A1 = r0.y, A2 = r0.z, A3 = r0.w, A4 = r1.x, A5 = r1.y;
+        o[0] = pf_pick(A0, 0, A0, 0); o[1] = pf_pick(A0, 1, A1, 0); o[2] = A1;                  o[3] = pf_pick(A2, 0, A2, 0);     // h0 h0 | m0 h1 | h1 m1 | h2 h2
+        o[4] = pf_pick(A2, 1, A3, 0); o[5] = pf_pick(A3, 1, A3, 1); o[6] = A4;                  o[7] = pf_pick(A4, 1, A5, 0);     // h5 m5 | h6 h6 | m6 h7 | h7 m7
+        flag = 0u;
+    } else {
+        const uint32_t B0 = r0.x, B1 = r0.y, B2 = r0.z, B3 = r0.w, B4 = r1.x;
+        o[0] = B0;                  o[1] = pf_pick(B0, 1, B1, 0); o[2] = pf_pick(B1, 1, B1, 1); o[3] = B2;                          // m2 h3 | h3 m3 | h4 h4 | m4 h5
+        o[4] = B3;                  o[5] = (B4 & 0xFFFFu) | 0x3C000000u; o[6] = 0u;              o[7] = 0u;                          // e8h e8m | e8l 1 | 0 0 | 0 0
+        flag = B4 >> 16;
+    }
+    n0 = __builtin_bit_cast(h8, uint4{ o[0], o[1], o[2], o[3] });
+    n1 = __builtin_bit_cast(h8, uint4{ o[4], o[5], o[6], o[7] });
 }
 #endif
 

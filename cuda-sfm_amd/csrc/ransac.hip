@@ -65,7 +65,7 @@ void ransac_solve_lanes1_qr(const float *__restrict__ X0, const float *__restric
                             int sweeps, float *__restrict__ Ecand, unsigned long long *zero_key, unsigned long long *zero_key2,
                             int *__restrict__ zero_counts, uint32_t *__restrict__ zero_ticks, uint32_t nzero, const float4 *__restrict__ pts4,
                             PfRecord *__restrict__ recs, float thr, PfScales sc, const unsigned long long *__restrict__ bound_word,
-                            const uint32_t *__restrict__ cells, uint32_t cells_mask)
+                            const uint32_t *__restrict__ cells, uint32_t cells_mask, int rule)
 {
     reset_keys(zero_key, zero_key2);
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -98,7 +98,14 @@ void ransac_solve_lanes1_qr(const float *__restrict__ X0, const float *__restric
 #pragma unroll
     for (int k = 0; k < 9; ++k) Ecand[9 * (size_t)i + k] = E[k];
     // the operands of the matrix-core pre-filter for this hypothesis (prefilter_record.hpp), once for all tiles
-    if (recs) pf_prep_store(E, thr, __uint_as_float((uint32_t)(*bound_word & 0xFFFFFFFFull)), sc, cells, cells_mask, recs + i);
+    if (recs) {
+        const float B = __uint_as_float((uint32_t)(*bound_word & 0xFFFFFFFFull));
+#if SFM_AB
+        if (rule == kPfRuleG) pf_prep_store(E, thr, B, sc, cells, cells_mask, recs + i);
+        else
+#endif
+        pf_band_prep_store(E, thr, B, pf_box_from_words(bound_word + 2, B), cells, cells_mask, recs + i);
+    }
 }
 
 // Two hypotheses per lane (2i, 2i+1): every mul / add / fma of the solver is a v_pk_*_f32.
@@ -411,7 +418,8 @@ int launch_ransac_score(sfm_pair *pair, const sfm_ransac_params &p, uint32_t h0,
         hipLaunchKernelGGL(ransac_solve_lanes1_qr, dim3((count + 63) / 64), dim3(64), 0, ctx->stream,
                            pair->d_X[0], pair->d_X[1], pair->ld, pair->n, p.d_indices, p.seed, h0, count,
                            p.jacobi_sweeps, pair->d_Ecand, pair->d_key, key2, zero_counts, zero_ticks, nzero, pts4,
-                           fuse ? reinterpret_cast<PfRecord *>(pair->d_pf) : nullptr, p.threshold, pf_sc, pair->d_bound, pair->d_cells, pair->cells_mask);
+                           fuse ? reinterpret_cast<PfRecord *>(pair->d_pf) : nullptr, p.threshold, pf_sc, pair->d_bound, pair->d_cells, pair->cells_mask,
+                           prefilter_rule(p));
         if (fuse) need_prep = false;
     }
     else if (p.jacobi_sweeps <= 0)   // default: two hypotheses per lane (packed math), Householder instantiation

@@ -33,21 +33,29 @@ constexpr int kPfRing = 128;             // survivor ring entries (8 bytes) per 
                                          // a flush re-queues at most 64 more, onto slots its own 64 entries have just left
 typedef float f16v __attribute__((ext_vector_type(16)));
 
+// The pre-filter rule a kernel instance runs (prefilter_math.hpp): the G rule of rounds 2-4 (a per-pair threshold from a third
+// matrix-core instruction: v_fma + v_alignbit per pair) or round 5's band rule (a per-hypothesis constant folded into the
+// coefficients: one v_alignbit per pair, two matrix-core instructions per 32 x 32 pairs, ~1.9 x the survivors).
+// (kPfRuleG = 0, kPfRuleBand = 1: prefilter_record.hpp)
+
 // LDS map
-constexpr int kPfBlockBytes = 3 * 64 * 16;                    // one 32-point block: [n k-step 0 | n k-step 1 | G][lane][8 fp16]
-constexpr int kPfLdsFrag = 0;
-constexpr int kPfLdsPts = kPfLdsFrag + (kPfTile / 32) * kPfBlockBytes;     // float4 (x2x, x1x, x2y, x1y) per point
-constexpr int kPfLdsRingBase = kPfLdsPts + kPfTile * 16;      // the wavefronts' survivor rings, 1024 bytes each, 1024-byte aligned (a slot's
-                                                              // address is (offset & 1023) | base: one v_and_or_b32)
-constexpr int kPfLdsWave = kPfLdsRingBase + kPfWaves * kPfRing * 8;   // per wavefront: E table 9 x 32 floats (component-major), 32 counters
 constexpr int kPfERow = 10;                                   // floats per hypothesis reserved in the E table (9 used): etab[32 k + row] -- a lane's nine
                                                               // reads for a random row hit bank (row mod 32) + const, so distinct rows never conflict
                                                               // (row-major 40-byte rows put rows r and r + 16 on the same banks: 19 % of the LDS cycles were conflicts)
 constexpr int kPfWaveBytes = 32 * kPfERow * 4 + 32 * 4;
-static_assert(kPfLdsRingBase % 1024 == 0 && kPfRing * 8 == 1024, "ring slots are addressed with (offset & 1023) | base");
-constexpr int kPfLdsNext = kPfLdsWave + kPfWaves * kPfWaveBytes;   // the block's pass counter
-constexpr int kPfLdsBytes = kPfLdsNext + 16;
-static_assert(kPfLdsBytes <= 160 * 1024, "one block must fit the CU's LDS");
+template <int RULE> struct PfLds {
+    static constexpr int kFragsPerBlock = RULE == kPfRuleBand ? 2 : 3;
+    static constexpr int kBlockBytes = kFragsPerBlock * 64 * 16;   // one 32-point block: [n k-step 0 | n k-step 1 (| G)][lane][8 fp16]
+    static constexpr int kFrag = 0;
+    static constexpr int kPts = kFrag + (kPfTile / 32) * kBlockBytes;       // float4 (x2x, x1x, x2y, x1y) per point
+    static constexpr int kRingBase = kPts + kPfTile * 16;     // the wavefronts' survivor rings, 1024 bytes each, 1024-byte aligned (a slot's
+                                                              // address is (offset & 1023) | base: one v_and_or_b32)
+    static constexpr int kWave = kRingBase + kPfWaves * kPfRing * 8;        // per wavefront: E table 9 x 32 floats (component-major), 32 counters
+    static constexpr int kNext = kWave + kPfWaves * kPfWaveBytes;           // the block's pass counter
+    static constexpr int kBytes = kNext + 16;
+    static_assert(kRingBase % 1024 == 0 && kPfRing * 8 == 1024, "ring slots are addressed with (offset & 1023) | base");
+    static_assert(kBytes <= 160 * 1024, "one block must fit the CU's LDS");
+};
 
 // rejected = (rejected << 1) | sign(G - nt^2): v_fma_f32 with a negated operand and v_alignbit_b32.  Plain C++ (no inline
 // assembly), so the compiler inserts the wait states the MFMA result registers need before a vector instruction reads them.
@@ -62,6 +70,16 @@ __device__ __forceinline__ uint32_t scan16(const f16v &nt, const f16v &G)
 #pragma unroll
     for (int r = 0; r < 16; ++r) rejected = shift_in_reject(rejected, nt[r], G[r]);
     return rejected;                        // < 2^16: accumulator r in bit 15 - r
+}
+
+// Band rule: mask = (mask << 2) | (bits(nt) >> 30) -- one v_alignbit_b32 per accumulator; the low bit of each pair is the
+// accumulator's bit 30 (|nt| >= 2: rejected), the high one its sign (unused).  Accumulator r ends up in bits 31 - 2 r, 30 - 2 r.
+__device__ __forceinline__ uint32_t scan16_band(const f16v &nt)
+{
+    uint32_t w = 0u;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) w = __builtin_amdgcn_alignbit(w, __float_as_uint(nt[r]), 30);
+    return w;
 }
 
 // LDS through address-space-3 pointers (ds_* instructions, immediate offsets)
@@ -106,17 +124,20 @@ __device__ __forceinline__ bool pf_exact_inlier(v2f p0, v2f p1, v2f p2, v2f p3, 
     return in;
 }
 
+template <int RULE>
 __device__ __forceinline__ PfFrags load_point_frags(lds_ch8 *frag_lane, int pb)
 {
-    lds_ch8 *p = frag_lane + pb * (kPfBlockBytes / 16);
+    lds_ch8 *p = frag_lane + pb * (PfLds<RULE>::kBlockBytes / 16);
+    if (RULE == kPfRuleBand) return PfFrags{ p[0], p[64], h8{} };
     return PfFrags{ p[0], p[64], p[128] };
 }
 
+template <int RULE>
 __device__ __forceinline__ void mfma_step(const PfFrags &a, const PfFrags &b, f16v &G, f16v &nt)
 {
     const f16v z = {};
     nt = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.n0, b.n0, z, 0, 0, 0);
-    G = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.t, b.t, z, 0, 0, 0);
+    if (RULE == kPfRuleG) G = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.t, b.t, z, 0, 0, 0);
     nt = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.n1, b.n1, nt, 0, 0, 0);
 }
 
@@ -125,19 +146,26 @@ __device__ __forceinline__ void mfma_step(const PfFrags &a, const PfFrags &b, f1
 // registers with the accumulators being scanned, or the reads could only be issued after the scan).
 #define PF_SCHED_STEP()                                                 \
     do {                                                                \
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);              \
-        __builtin_amdgcn_sched_group_barrier(0x002, 11, 0);             \
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);              \
-        __builtin_amdgcn_sched_group_barrier(0x002, 11, 0);             \
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);              \
-        __builtin_amdgcn_sched_group_barrier(0x002, 11, 0);             \
+        if (RULE == kPfRuleBand) {                                      \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);          \
+            __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);          \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);          \
+            __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);          \
+        } else {                                                        \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);          \
+            __builtin_amdgcn_sched_group_barrier(0x002, 11, 0);         \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);          \
+            __builtin_amdgcn_sched_group_barrier(0x002, 11, 0);         \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);          \
+            __builtin_amdgcn_sched_group_barrier(0x002, 11, 0);         \
+        }                                                               \
     } while (0)
 
 // VAR (AB build only; the product instantiates VAR = 0): bit 0 = round 3's epilogue -- partial counts summed into counts[] with
 // atomics, a ticket per 32-hypothesis group, the last wavefront re-reads the counts (two dependent round trips per pass).
 constexpr int kPfVarTickets = 1;
 
-template <int W, int VAR = 0>
+template <int W, int VAR = 0, int RULE = kPfRuleBand>
 __global__ __launch_bounds__(W * 64)
 void ransac_score_prefilter(const float *__restrict__ X0, const float *__restrict__ X1, int ld, int n,
                             const float *__restrict__ Ecand, const PfRecord *__restrict__ recs, uint32_t h0, uint32_t count, float thr,
@@ -168,7 +196,8 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
     const int half = lane >> 5, row = lane & 31;
     const uint32_t npass = (count + (uint32_t)kPfGroup - 1u) / (uint32_t)kPfGroup;
     const uint32_t nstatic = gridDim.x * (uint32_t)W;             // passes handed out by position
-    float *etab = reinterpret_cast<float *>(smem + kPfLdsWave + wave * kPfWaveBytes);
+    using L = PfLds<RULE>;
+    float *etab = reinterpret_cast<float *>(smem + L::kWave + wave * kPfWaveBytes);
     int *cnt = reinterpret_cast<int *>(etab + 32 * kPfERow);
 
     // Operands of hypothesis (32 ps + row): this lane's half of the three A fragments and (lanes 0..31) its zero-divisor
@@ -181,7 +210,8 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
         const uint32_t h = hf + (uint32_t)min(row, (int)min((uint32_t)kPfGroup, count - hf) - 1);
         const uint4 *r = reinterpret_cast<const uint4 *>(recs + h) + 2 * half;        // this lane's half of the record: 32 bytes
         const uint4 r0 = r[0], r1 = r[1];
-        pf_record_expand(r0, r1, half, af.n0, af.n1, af.t, k0);
+        if (RULE == kPfRuleBand) pf_band_record_expand(r0, r1, half, af.n0, af.n1, k0);
+        else pf_record_expand(r0, r1, half, af.n0, af.n1, af.t, k0);
         if (half == 0) {
             const float *src = Ecand + 9 * (size_t)h;
 #pragma unroll
@@ -206,7 +236,7 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
     // with one fixed share each, the first finished 230 us before the last of a 630 us launch, profiles/r03_trace_*.txt),
     // and with first-come-first-served shares they finish within one pass of each other.  (One counter per tile in global
     // memory would balance the blocks too, but 131072 device-scope atomics on one address take 1.5 ms.)
-    uint32_t *next_idx = reinterpret_cast<uint32_t *>(smem + kPfLdsNext);
+    uint32_t *next_idx = reinterpret_cast<uint32_t *>(smem + L::kNext);
     if (threadIdx.x == 0) *next_idx = (uint32_t)W;
     __syncthreads();
     const int tile_first = blockIdx.y * kPfTile;
@@ -218,9 +248,9 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
         _Float16 bn[kPfSlots], bt[kPfSlotsT];
         prefilter_point_slots(u, v, x, y, real, bn, bt);
         // padding reads as NaN in the exact test (it is always rejected before; NaN never counts)
-        reinterpret_cast<float4 *>(smem + kPfLdsPts)[t] = real ? make_float4(x, u, y, v) : make_float4(NAN, NAN, NAN, NAN);
+        reinterpret_cast<float4 *>(smem + L::kPts)[t] = real ? make_float4(x, u, y, v) : make_float4(NAN, NAN, NAN, NAN);
         const int pb = t >> 5, col = t & 31;
-        unsigned char *blk = smem + kPfLdsFrag + pb * kPfBlockBytes;
+        unsigned char *blk = smem + L::kFrag + pb * L::kBlockBytes;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -230,12 +260,14 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
                 for (int j = 0; j < 8; ++j) c[j] = bn[ks * 16 + hh * 8 + j];
                 *reinterpret_cast<h8 *>(blk + ks * 1024 + (hh * 32 + col) * 16) = c;
             }
+        if (RULE == kPfRuleG) {
 #pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-            h8 c;
+            for (int hh = 0; hh < 2; ++hh) {
+                h8 c;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) c[j] = bt[hh * 8 + j];
-            *reinterpret_cast<h8 *>(blk + 2048 + (hh * 32 + col) * 16) = c;
+                for (int j = 0; j < 8; ++j) c[j] = bt[hh * 8 + j];
+                *reinterpret_cast<h8 *>(blk + 2048 + (hh * 32 + col) * 16) = c;
+            }
         }
     }
     __syncthreads();
@@ -244,16 +276,16 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
 #endif
     const int npb = (min(kPfTile, ld - tile_first) + 31) >> 5;           // 32-point blocks that hold points or padding
     const int npp = (npb + 1) >> 1;                                      // two 32-point blocks per iteration (a block beyond npb holds padding only: all rejected)
-    const float4 *pts = reinterpret_cast<const float4 *>(smem + kPfLdsPts);
+    const float4 *pts = reinterpret_cast<const float4 *>(smem + L::kPts);
     lds_cf *etab_l = (lds_cf *)etab;
     lds_i *cnt_l = (lds_i *)cnt;
-    const uint32_t ring_base = (uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char *)(smem + kPfLdsRingBase) + (uint32_t)wave * (uint32_t)(kPfRing * 8);
+    const uint32_t ring_base = (uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char *)(smem + L::kRingBase) + (uint32_t)wave * (uint32_t)(kPfRing * 8);
     uint32_t ring_mask = (uint32_t)(kPfRing * 8 - 1);
     asm("" : "+v"(ring_mask));                            // in a vector register: v_and_or_b32 takes one scalar operand, and that is the base
     auto ring_at = [&](uint32_t index8) {                 // index8 = 8 x (slot index, not yet wrapped)
         return (lds_u2 *)((__attribute__((address_space(3))) unsigned char *)0 + ((index8 & ring_mask) | ring_base));
     };
-    lds_ch8 *frag_lane = (lds_ch8 *)(smem + kPfLdsFrag) + lane;
+    lds_ch8 *frag_lane = (lds_ch8 *)(smem + L::kFrag) + lane;
     const ThrBand band = make_band(thr);
     uint32_t passes_done = 0;
 
@@ -316,7 +348,8 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
                 const uint32_t surv = ent.x;
                 const int b = __builtin_clz(surv);                                  // the first surviving accumulator of the first step that has one
                 rest = surv & ~(0x80000000u >> b);
-                const int r = b & 15, sub = b >> 4;
+                // G rule: bit 31 - r = accumulator r of the first step, 15 - r of the second; band rule: 31 - 2 r and 30 - 2 r
+                const int r = RULE == kPfRuleBand ? b >> 1 : b & 15, sub = RULE == kPfRuleBand ? b & 1 : b >> 4;
                 const int hl = r + (r & 12) + (int)(tag & 4u);                      // accumulator row = local hypothesis: (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
                 if (hl < nvalid) {
                     const f4v q = *(lds_cf4 *)((__attribute__((address_space(3))) const unsigned char *)0 + ((tag & ~15u) + ((uint32_t)sub << 9)));
@@ -336,30 +369,33 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
             nq += __builtin_popcountll(more) - m;
         };
 
-        PfFrags fa = load_point_frags(frag_lane, 0), fb = load_point_frags(frag_lane, 1);
+        PfFrags fa = load_point_frags<RULE>(frag_lane, 0), fb = load_point_frags<RULE>(frag_lane, 1);
         f16v g0, n0, g1, n1;
-        mfma_step(afrag, fa, g0, n0);
+        mfma_step<RULE>(afrag, fa, g0, n0);
         // one running address for the look-ahead reads (32-point blocks 2 pp + 2 and 2 pp + 3: six immediate offsets, one add per
         // iteration).  The last iterations read one or two blocks past the tile -- coordinates and rings, still inside the block's
         // LDS -- into fragments no scan ever looks at.
-        lds_ch8 *fp = frag_lane + 2 * (kPfBlockBytes / 16);
+        lds_ch8 *fp = frag_lane + 2 * (L::kBlockBytes / 16);
         for (int pp = 0; pp < npp; ++pp) {
             // phase 1: matrix cores on step 2 pp + 1 (fragments fb), LDS on step 2 pp + 2, vector unit on step 2 pp
-            fa = load_point_frags(fp, 0);
+            fa = load_point_frags<RULE>(fp, 0);
             __builtin_amdgcn_sched_barrier(0);
-            mfma_step(afrag, fb, g1, n1);
-            const uint32_t rej_first = scan16(n0, g0);
+            mfma_step<RULE>(afrag, fb, g1, n1);
+            const uint32_t rej_first = RULE == kPfRuleBand ? scan16_band(n0) : scan16(n0, g0);
             PF_SCHED_STEP();
             __builtin_amdgcn_sched_barrier(0);
             // phase 2: matrix cores on step 2 pp + 2 (fragments fa), LDS on step 2 pp + 3, vector unit on step 2 pp + 1
-            fb = load_point_frags(fp, 1);
-            fp += 2 * (kPfBlockBytes / 16);
+            fb = load_point_frags<RULE>(fp, 1);
+            fp += 2 * (L::kBlockBytes / 16);
             __builtin_amdgcn_sched_barrier(0);
-            mfma_step(afrag, fa, g0, n0);
-            const uint32_t rej_second = scan16(n1, g1);
+            mfma_step<RULE>(afrag, fa, g0, n0);
+            const uint32_t rej_second = RULE == kPfRuleBand ? scan16_band(n1) : scan16(n1, g1);
             PF_SCHED_STEP();
             __builtin_amdgcn_sched_barrier(0);
-            const uint32_t rej32 = (rej_first << 16) | rej_second;
+            // band rule: the reject bits of the two steps interleaved (first step's in the odd positions), every bit meaningful:
+            // (w1 << 1) supplies the odd bits, w2 the even ones (v_lshlrev + v_bfi)
+            const uint32_t rej32 = RULE == kPfRuleBand ? (((rej_first << 1) & 0xAAAAAAAAu) | (rej_second & 0x55555555u))
+                                                       : ((rej_first << 16) | rej_second);
             const bool mine = rej32 != 0xFFFFFFFFu;
             const unsigned long long any = __ballot(mine);
             if (any) {
@@ -481,12 +517,16 @@ void pf_cells_build_kernel(const float4 *__restrict__ pts4, int n, const unsigne
     const float big = fmaxf(fmaxf(fabsf(q.x), fabsf(q.y)), fmaxf(fabsf(q.z), fabsf(q.w)));
     if (!(big <= 48.0f) || q.x != q.x || q.y != q.y || q.z != q.z || q.w != q.w) return;
     const PfGrid grid = prefilter_grid(__uint_as_float((uint32_t)(*bound_word & 0xFFFFFFFFull)));
-    const uint32_t key = pf_cell_key(pf_cell(q.z, grid), pf_cell(q.w, grid));
-    uint32_t sl = pf_cells_slot(key, mask);
-    for (;;) {
-        const uint32_t old = atomicCAS(&cells[sl], 0u, key);
-        if (old == 0u || old == key) break;
-        sl = (sl + 1) & mask;
+    // second-view cell (first divisor) and first-view cell (second divisor, keys flipped: pf_cell_key_side) in one table
+#pragma unroll
+    for (int side = 0; side < 2; ++side) {
+        const uint32_t key = side ? pf_cell_key_side(pf_cell(q.x, grid), pf_cell(q.y, grid), 1) : pf_cell_key(pf_cell(q.z, grid), pf_cell(q.w, grid));
+        uint32_t sl = pf_cells_slot(key, mask);
+        for (;;) {
+            const uint32_t old = atomicCAS(&cells[sl], 0u, key);
+            if (old == 0u || old == key) break;
+            sl = (sl + 1) & mask;
+        }
     }
 }
 
@@ -499,7 +539,7 @@ int launch_pf_cells(sfm_pair *pair)
         return SFM_OK;
     }
     uint32_t slots = 4096;
-    while (slots < 4u * (uint32_t)pair->n) slots <<= 1;                                  // load factor <= 1/4
+    while (slots < 8u * (uint32_t)pair->n) slots <<= 1;                                  // two keys per point, load factor <= 1/4
     if (slots > pair->cells_cap) {
         SFM_HIP_TRY(hipStreamSynchronize(st));
         if (pair->d_cells) (void)hipFree(pair->d_cells);
@@ -522,6 +562,7 @@ int launch_pf_cells(sfm_pair *pair)
 // ---- per-hypothesis operands ------------------------------------------------------------------------------------------
 // Stand-alone kernel for the paths whose solve kernel does not build the records itself (caller-supplied candidates, the
 // packed / Jacobi solve kernels): one hypothesis per lane.
+template <int RULE>
 __global__ __launch_bounds__(256)
 void pf_prep_kernel(const float *__restrict__ Ecand, uint32_t count, float thr, PfScales sc, const unsigned long long *__restrict__ bound_word,
                     const uint32_t *__restrict__ cells, uint32_t cells_mask, PfRecord *__restrict__ recs)
@@ -532,15 +573,22 @@ void pf_prep_kernel(const float *__restrict__ Ecand, uint32_t count, float thr, 
 #pragma unroll
     for (int k = 0; k < 9; ++k) e[k] = Ecand[9 * (size_t)i + k];
     const float B = __uint_as_float((uint32_t)(*bound_word & 0xFFFFFFFFull));
-    pf_prep_store(e, thr, B, sc, cells, cells_mask, recs + i);
+    if (RULE == kPfRuleBand) pf_band_prep_store(e, thr, B, pf_box_from_words(bound_word + 2, B), cells, cells_mask, recs + i);
+    else pf_prep_store(e, thr, B, sc, cells, cells_mask, recs + i);
 }
 
 int launch_pf_prep(sfm_pair *pair, const sfm_ransac_params &p, uint32_t count)
 {
     PfScales sc;
     if (!prefilter_scales(p.threshold, sc)) { set_error("threshold %g outside the pre-filter's range", (double)p.threshold); return SFM_E_INVALID; }
-    hipLaunchKernelGGL(pf_prep_kernel, dim3((count + 255) / 256), dim3(256), 0, pair->ctx->stream,
-                       pair->d_Ecand, count, p.threshold, sc, pair->d_bound, pair->d_cells, pair->cells_mask, reinterpret_cast<PfRecord *>(pair->d_pf));
+    if (prefilter_rule(p) == kPfRuleBand)
+        hipLaunchKernelGGL(pf_prep_kernel<kPfRuleBand>, dim3((count + 255) / 256), dim3(256), 0, pair->ctx->stream,
+                           pair->d_Ecand, count, p.threshold, sc, pair->d_bound, pair->d_cells, pair->cells_mask, reinterpret_cast<PfRecord *>(pair->d_pf));
+#if SFM_AB
+    else
+        hipLaunchKernelGGL(pf_prep_kernel<kPfRuleG>, dim3((count + 255) / 256), dim3(256), 0, pair->ctx->stream,
+                           pair->d_Ecand, count, p.threshold, sc, pair->d_bound, pair->d_cells, pair->cells_mask, reinterpret_cast<PfRecord *>(pair->d_pf));
+#endif
     SFM_HIP_TRY(hipGetLastError());
     return SFM_OK;
 }
@@ -621,6 +669,13 @@ int launch_prefilter_probe(sfm_ctx *ctx, const float *d_E, float thr, float B, c
 // (which also leaves the bound over all points), a threshold the fp16 scaling covers, and enough work to fill the chip with
 // 512-hypothesis x 1024-point block iterations (measured crossover against the plain wavefront kernel at 4096 points:
 // between 16k and 32k hypotheses, profiles/r02_prefilter_ab.txt).
+// Which rule a call runs: the band rule; the lab-bench library keeps the G rule of rounds 2-4 behind reserved[3] == 4 (and for the
+// recorded variants that were built on it: the ticket epilogue, reserved[3] >= 16).
+int prefilter_rule(const sfm_ransac_params &p)
+{
+    return (SFM_SW(p, 3) == 4 || SFM_SW(p, 3) >= 16) ? kPfRuleG : kPfRuleBand;
+}
+
 bool prefilter_usable(const sfm_pair *pair, const sfm_ransac_params &p, uint32_t count)
 {
     PfScales sc;
@@ -652,25 +707,29 @@ int launch_score_prefilter(sfm_pair *pair, const sfm_ransac_params &p, uint32_t 
     if (cols < 1) cols = 1;
     const int dynamic = SFM_SW(p, 1) == 2 ? 0 : 1;                               // (AB build, reserved[1] == 2: static striding)
     const int var = SFM_SW(p, 3) >= 16 ? SFM_SW(p, 3) - 16 : 0;                 // (AB build, reserved[3] = 16 + VAR bits)
+    const int rule = prefilter_rule(p);
+    const int lds_bytes = rule == kPfRuleBand ? PfLds<kPfRuleBand>::kBytes : PfLds<kPfRuleG>::kBytes;
     auto launch = [&](auto kernel) -> int {
         const int rc_lds = allow_big_lds(ctx, reinterpret_cast<const void *>(kernel));
         if (rc_lds != SFM_OK) return rc_lds;
-        hipLaunchKernelGGL(kernel, dim3(cols, ntiles), dim3(waves * 64), kPfLdsBytes, ctx->stream,
+        hipLaunchKernelGGL(kernel, dim3(cols, ntiles), dim3(waves * 64), lds_bytes, ctx->stream,
                            pair->d_X[0], pair->d_X[1], pair->ld, pair->n, pair->d_Ecand, reinterpret_cast<const PfRecord *>(pair->d_pf), h0, count, p.threshold,
                            dynamic, pair->d_counts, pair->d_tick, pair->d_key, key2, pair->d_clk);
         return SFM_OK;
     };
     int rcl;
 #if SFM_AB
-    if (waves == 12) rcl = launch(&ransac_score_prefilter<12, 0>);
-    else if (var == 1) rcl = launch(&ransac_score_prefilter<16, 1>);
+    if (rule == kPfRuleG && waves == 12) rcl = launch(&ransac_score_prefilter<12, 0, kPfRuleG>);
+    else if (rule == kPfRuleG && var == 1) rcl = launch(&ransac_score_prefilter<16, 1, kPfRuleG>);
+    else if (rule == kPfRuleG) rcl = launch(&ransac_score_prefilter<16, 0, kPfRuleG>);
+    else if (waves == 12) rcl = launch(&ransac_score_prefilter<12, 0, kPfRuleBand>);
     else
 #endif
-    rcl = launch(&ransac_score_prefilter<16, 0>);
+    rcl = launch(&ransac_score_prefilter<16, 0, kPfRuleBand>);
     (void)var;
     if (rcl != SFM_OK) return rcl;
     SFM_HIP_TRY(hipGetLastError());
-    pair->last_grid = (int)cols * ntiles; pair->last_block = waves * 64; pair->last_lds = kPfLdsBytes;
+    pair->last_grid = (int)cols * ntiles; pair->last_block = waves * 64; pair->last_lds = lds_bytes;
     return SFM_OK;
 }
 
