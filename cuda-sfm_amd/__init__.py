@@ -67,7 +67,7 @@ EXPORTS = [
     "sfm_get_pose_candidates", "sfm_get_pose_inverses", "sfm_get_pose_index", "sfm_get_points", "sfm_copy_points_to_vbo",
     "sfm_ransac_last_launch", "sfm_ransac_last_clock", "sfm_process_pairs", "sfm_ctx_last_pairs_batched", "sfm_extract_views", "sfm_extract_views_u8",
 ]
-AB_EXPORTS = ["sfm_ransac_last_phases", "sfm_ransac_last_trace", "sfm_prefilter_probe"]      # include/sfm_amd_ab.h
+AB_EXPORTS = ["sfm_ransac_last_phases", "sfm_ransac_last_trace", "sfm_prefilter_probe", "sfm_prefilter_band_probe"]      # include/sfm_amd_ab.h
 if AB:
     EXPORTS = EXPORTS + AB_EXPORTS
 
@@ -255,6 +255,16 @@ class Context:
         _check(_lib.sfm_prefilter_probe(self._h, e.ctypes.data_as(_vp), C.c_float(float(threshold)), C.c_float(float(bound)), pt.ctypes.data_as(_vp),
                                         int(bool(survive_all)), out.ctypes.data_as(_vp)), "sfm_prefilter_probe")
         return {"ns": out[0:32], "ts": out[32:48], "bn": out[48:80], "bt": out[80:96], "nt": out[96], "G": out[97], "rejected": bool(out[98]), "zero_divisor_state": int(out[99])}
+
+    def prefilter_band_probe(self, E, threshold, bound, box, b_safe, point, survive_all=False):
+        """The band rule's operands and matrix-core result of one (hypothesis, point) pair (test probe; lab-bench flavour only)."""
+        e = np.ascontiguousarray(E, np.float32).reshape(9); pt = np.ascontiguousarray(point, np.float32).reshape(4)
+        bx = np.ascontiguousarray(box, np.float32).reshape(8)
+        out = np.zeros(104, np.float32)
+        _check(_lib.sfm_prefilter_band_probe(self._h, e.ctypes.data_as(_vp), C.c_float(float(threshold)), C.c_float(float(bound)), bx.ctypes.data_as(_vp),
+                                             int(bool(b_safe)), pt.ctypes.data_as(_vp), int(bool(survive_all)), out.ctypes.data_as(_vp)), "sfm_prefilter_band_probe")
+        return {"ns": out[0:32], "bn": out[48:80], "nt": out[96], "sigma": out[97], "rejected": bool(out[98]),
+                "zero_divisor_state": int(out[99]), "second_divisor_state": int(out[100])}
 
     def own_stream(self):
         """Give the context a non-blocking stream of its own (for a second context next to a torch-owned one)."""

@@ -1387,6 +1387,26 @@ int sfm_prefilter_probe(sfm_ctx *ctx, const float h_E[9], float threshold, float
     (void)hipFree(d);
     return rc;
 }
+
+int sfm_prefilter_band_probe(sfm_ctx *ctx, const float h_E[9], float threshold, float bound, const float h_box[8], int b_safe, const float h_point[4],
+                             int survive_all, float h_out[104])
+{
+    SFM_REQUIRE(ctx && h_E && h_point && h_out && h_box, SFM_E_INVALID, "null argument");
+    SFM_HIP_TRY(hipSetDevice(ctx->device));
+    float *d = nullptr;
+    SFM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d), 256 * sizeof(float)));      // result (104) + E (9 at 112) + one PfRecord at 128
+    hipError_t e = hipMemsetAsync(d, 0, 256 * sizeof(float), ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d + 112, h_E, 9 * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
+    int rc = e == hipSuccess ? launch_prefilter_band_probe(ctx, d + 112, threshold, bound, h_box, b_safe, h_point, survive_all, d) : SFM_E_HIP;
+    if (rc == SFM_OK) {
+        e = hipMemcpyAsync(h_out, d, 104 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) { set_error("probe copy failed: %s", hipGetErrorString(e)); rc = SFM_E_HIP; }
+    }
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d);
+    return rc;
+}
 #endif
 
 int sfm_ransac_last_launch(sfm_pair *pair, int *kernel, int *grid, int *block, int *lds_bytes)

@@ -195,6 +195,7 @@ int launch_score_prefilter_r2(sfm_pair *pair, const sfm_ransac_params &p, uint32
 // ab/ransac_mfma.hip (SFM_KERNEL_MFMA: E.X on the f32 matrix cores, measured slower)
 int launch_score_mfma(sfm_pair *pair, const sfm_ransac_params &p, uint32_t h0, uint32_t count);
 int launch_prefilter_probe(sfm_ctx *ctx, const float *d_E, float thr, float B, const float pt[4], int survive_all, float *d_out);
+int launch_prefilter_band_probe(sfm_ctx *ctx, const float *d_E, float thr, float B, const float box[8], int b_safe, const float pt[4], int survive_all, float *d_out);
 #endif
 // ransac_fused.hip
 int launch_ransac_fused(sfm_pair *pair, const sfm_ransac_params &p, uint32_t h0, uint32_t count);

@@ -128,6 +128,9 @@ __device__ __forceinline__ bool pf_cells_occupied(const uint32_t *__restrict__ c
     return hit;
 }
 
+// the record of a hypothesis whose sigma and first-divisor flag are known
+__device__ __forceinline__ void pf_band_store(const float e[9], float sigma, bool scan, PfRecord *out);
+
 __device__ __forceinline__ void pf_band_prep_store(const float e[9], float thr, float B, const PfBox &box, const uint32_t *__restrict__ cells,
                                                    uint32_t cells_mask, PfRecord *out)
 {
@@ -141,7 +144,11 @@ __device__ __forceinline__ void pf_band_prep_store(const float e[9], float thr, 
     const int zb = prefilter_zero_divisor_cells(et, B, grid, cx0, cx1, cy0, cy1);
     bool b_safe = zb == 0;
     if (zb == 1) b_safe = cells && !pf_cells_occupied(cells, cells_mask, cx0, cx1, cy0, cy1, 1);
-    const float sigma = prefilter_band_sigma(e, thr, B, box, b_safe);
+    pf_band_store(e, prefilter_band_sigma(e, thr, B, box, b_safe), scan, out);
+}
+
+__device__ __forceinline__ void pf_band_store(const float e[9], float sigma, bool scan, PfRecord *out)
+{
     _Float16 ns[kPfSlots];
     prefilter_band_hyp_slots(e, sigma, ns);
     auto bits = [](_Float16 v) { return __builtin_bit_cast(unsigned short, v); };

@@ -653,6 +653,67 @@ void pf_probe_kernel(const float *__restrict__ E, float thr, float B, PfScales s
     }
 }
 
+// The same for the band rule: sigma from the given boxes, the record through pf_band_store / pf_band_record_expand, two MFMAs.
+// out: ns[32] | - | bn[32] at 48 | nt at 96 | sigma at 97 | rejected at 98 | first divisor's state at 99 | second divisor's at 100
+__global__ __launch_bounds__(64)
+void pf_band_probe_kernel(const float *__restrict__ E, float thr, float B, PfBox box, int b_safe, float u, float v, float x, float y, int survive_all,
+                          PfRecord *rec, float *__restrict__ out)
+{
+    const int lane = threadIdx.x;
+    const int half = lane >> 5;
+    float e[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) e[k] = E[k];
+    const float sigma = survive_all ? 0.0f : prefilter_band_sigma(e, thr, B, box, b_safe != 0);
+    if (lane == 0) pf_band_store(e, sigma, false, rec);
+    __threadfence();
+    __syncthreads();
+    _Float16 ns[kPfSlots], bn[kPfSlots], bt[kPfSlotsT];
+    {
+        const volatile uint4 *vr = reinterpret_cast<const volatile uint4 *>(rec);
+        uint4 w[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { w[q].x = vr[q].x; w[q].y = vr[q].y; w[q].z = vr[q].z; w[q].w = vr[q].w; }
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            h8 f0, f1; uint32_t fl;
+            pf_band_record_expand(w[2 * hh], w[2 * hh + 1], hh, f0, f1, fl);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { ns[hh * 8 + j] = f0[j]; ns[16 + hh * 8 + j] = f1[j]; }
+        }
+    }
+    prefilter_point_slots(u, v, x, y, true, bn, bt);
+    h8 an0, an1, b0, b1;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        an0[j] = half ? ns[8 + j] : ns[j];   an1[j] = half ? ns[24 + j] : ns[16 + j];
+        b0[j] = half ? bn[8 + j] : bn[j];    b1[j] = half ? bn[24 + j] : bn[16 + j];
+    }
+    f16v accn = {};
+    accn = __builtin_amdgcn_mfma_f32_32x32x16_f16(an0, b0, accn, 0, 0, 0);
+    accn = __builtin_amdgcn_mfma_f32_32x32x16_f16(an1, b1, accn, 0, 0, 0);
+    if (lane == 0) {
+        for (int k = 0; k < 32; ++k) { out[k] = (float)ns[k]; out[48 + k] = (float)bn[k]; }
+        out[96] = accn[0]; out[97] = sigma;
+        f16v one = {}; one[0] = accn[0];
+        out[98] = (float)((scan16_band(one) >> 30) & 1u);
+        int cx0, cx1, cy0, cy1;
+        out[99] = (float)prefilter_zero_divisor_cells(e, B, prefilter_grid(B), cx0, cx1, cy0, cy1);
+        float et[9];
+        prefilter_transposed(e, et);
+        out[100] = (float)prefilter_zero_divisor_cells(et, B, prefilter_grid(B), cx0, cx1, cy0, cy1);
+    }
+}
+
+int launch_prefilter_band_probe(sfm_ctx *ctx, const float *d_E, float thr, float B, const float box[8], int b_safe, const float pt[4], int survive_all, float *d_out)
+{
+    const PfBox bx = { box[0], box[1], box[2], box[3], box[4], box[5], box[6], box[7] };
+    hipLaunchKernelGGL(pf_band_probe_kernel, dim3(1), dim3(64), 0, ctx->stream, d_E, thr, B, bx, b_safe, pt[0], pt[1], pt[2], pt[3], survive_all,
+                       reinterpret_cast<PfRecord *>(d_out + 128), d_out);
+    SFM_HIP_TRY(hipGetLastError());
+    return SFM_OK;
+}
+
 int launch_prefilter_probe(sfm_ctx *ctx, const float *d_E, float thr, float B, const float pt[4], int survive_all, float *d_out)
 {
     PfScales sc;

@@ -46,6 +46,12 @@ int sfm_ransac_last_trace(sfm_pair *pair, uint64_t *words, size_t capacity, size
 int sfm_prefilter_probe(sfm_ctx *ctx, const float h_E[9], float threshold, float bound, const float h_point[4], int survive_all,
                         float h_out[100]);
 
+/* The same for the band rule (round 5): h_box = the coordinate ranges (x2 lo hi, y2 lo hi, x1 lo hi, y1 lo hi), b_safe = the second
+ * divisor cannot vanish.  h_out: ns[32] | (unused) | bn[32] at 48 | nt at 96 | sigma at 97 | rejected at 98 | zero-divisor state of
+ * the first divisor at 99, of the second at 100.  Synchronises. */
+int sfm_prefilter_band_probe(sfm_ctx *ctx, const float h_E[9], float threshold, float bound, const float h_box[8], int b_safe,
+                             const float h_point[4], int survive_all, float h_out[104]);
+
 #pragma GCC visibility pop
 #ifdef __cplusplus
 }

@@ -1,11 +1,14 @@
-"""Time-budgeted randomised parity run on the GPU (not collected by pytest: run it by hand on the GPU box).
+"""Time-budgeted randomised parity run on the GPU.
 
-    python tests/fuzz_gpu.py [seconds] [seed]
+    python tests/fuzz_gpu.py [seconds] [seed] [--lib product|ab]
 
 Every round draws a random configuration of one of the product paths (RANSAC in all kernel families and both
 null-vector solvers, with ordinary, degenerate, generic-z and huge-coordinate point sets; the matcher; the
 homography search; SIFT extraction), runs it through the C ABI and compares with the CPU oracle bit for bit.
 Prints one JSON line with the number of rounds per path and every mismatch (configuration included).
+--lib product (default) loads libsfm_amd.so, what ships; --lib ab the lab-bench flavour, which adds the recorded A/B kernel
+variants to the draw.  tests/test_gpu_fuzz_slice.py runs a bounded slice of the same rounds (product library, seed from the
+committed tests/fuzz_seed.txt) under pytest -m gpu, i.e. on the driver's box.
 """
 import json
 import os
@@ -20,26 +23,20 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 
 
-def main():
-    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
-    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-    import torch
-    import cuda_sfm_amd_ab as S            # the lab-bench flavour: the fuzz also covers the recorded A/B kernel variants
-    from cuda_sfm_amd_ab import synth
+def make_rounds(S, torch, dev, ctx, rng):
+    """[(name, round function -> (ok, cfg), probability)] for library flavour S (cuda_sfm_amd or cuda_sfm_amd_ab)."""
+    import importlib
+    synth = importlib.import_module(S.__name__ + ".synth")
     import oracle as O
     from helpers import same_bits, to_dev
-
-    assert torch.cuda.is_available()
-    dev = torch.device("cuda", 0)
-    ctx = S.Context(0, torch.cuda.current_stream().cuda_stream)
-    rng = np.random.default_rng(seed)
-    rounds = {"ransac": 0, "pose": 0, "match": 0, "homography": 0, "sift": 0}
-    bad = []
+    kernels = [S.KERNEL_AUTO, S.KERNEL_SPLIT, S.KERNEL_FUSED, S.KERNEL_PREFILTER, S.KERNEL_PREFILTER]
+    if hasattr(S, "KERNEL_MFMA"):
+        kernels.append(S.KERNEL_MFMA)
 
     def ransac_round():
         n = int(rng.choice([rng.integers(8, 200), rng.integers(200, 3000), rng.integers(3000, 9000)]))
         H = int(rng.choice([rng.integers(1, 64), rng.integers(64, 1500), rng.integers(1500, 6000), rng.integers(6000, 24000)]))
-        kernel = int(rng.choice([S.KERNEL_AUTO, S.KERNEL_SPLIT, S.KERNEL_FUSED, S.KERNEL_MFMA, S.KERNEL_PREFILTER, S.KERNEL_PREFILTER]))
+        kernel = int(rng.choice(kernels))
         sweeps = int(rng.choice([0, 0, 7, 3]))
         thr = float(np.float32(10.0 ** rng.uniform(-9, -2)))
         flavour = str(rng.choice(["plain", "plain", "clean", "dup", "epipole", "genericz", "huge", "nan"]))
@@ -179,9 +176,15 @@ def main():
             ok = all(same_bits(a[f], b[f]) for f in ("xpos", "ypos", "scale", "sharpness", "edgeness", "orientation", "subsampling", "data"))
         return ok, dict(path="sift", w=w, h=h, octaves=octaves, up=up, thresh=thresh, blur=blur, lowest=lowest, seed=sseed, max_pts=max_pts, npts=int(npts))
 
-    table = [("ransac", ransac_round, 0.45), ("pose", pose_round, 0.15), ("match", match_round, 0.14), ("homography", homography_round, 0.13), ("sift", sift_round, 0.13)]
+    return [("ransac", ransac_round, 0.45), ("pose", pose_round, 0.15), ("match", match_round, 0.14), ("homography", homography_round, 0.13), ("sift", sift_round, 0.13)]
+
+
+def run_rounds(table, rng, budget_s=None, max_rounds=None, max_bad=20):
+    rounds = {name: 0 for name, _, _ in table}
+    bad = []
     t0 = time.time()
-    while time.time() - t0 < budget:
+    done = 0
+    while (budget_s is None or time.time() - t0 < budget_s) and (max_rounds is None or done < max_rounds):
         r = rng.random(); acc = 0.0
         for name, fn, pr in table:
             acc += pr
@@ -192,11 +195,32 @@ def main():
         except Exception as e:                        # an exception in a legal configuration is a finding too
             ok, cfg = False, dict(path=name, exception=repr(e))
         rounds[name] += 1
+        done += 1
         if not ok:
             bad.append(cfg)
-            if len(bad) >= 20:
+            if len(bad) >= max_bad:
                 break
-    print(json.dumps({"seconds": round(time.time() - t0, 1), "seed": seed, "rounds": rounds, "mismatches": bad}))
+    return rounds, bad, time.time() - t0
+
+
+def main():
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    budget = float(args[0]) if len(args) > 0 else 60.0
+    seed = int(args[1]) if len(args) > 1 else 1
+    lib = "product"
+    if "--lib" in sys.argv:
+        lib = sys.argv[sys.argv.index("--lib") + 1]
+    import torch
+    if lib == "ab":
+        import cuda_sfm_amd_ab as S
+    else:
+        import cuda_sfm_amd as S
+    assert torch.cuda.is_available()
+    dev = torch.device("cuda", 0)
+    ctx = S.Context(0, torch.cuda.current_stream().cuda_stream)
+    rng = np.random.default_rng(seed)
+    rounds, bad, secs = run_rounds(make_rounds(S, torch, dev, ctx, rng), rng, budget_s=budget)
+    print(json.dumps({"seconds": round(secs, 1), "seed": seed, "lib": lib, "rounds": rounds, "mismatches": bad}))
     sys.exit(1 if bad else 0)
 
 

@@ -92,6 +92,29 @@ void hc_pf_point_slots(float u, float v, float x, float y, int real, float *bn /
 
 int hc_pf_reject(float nt, float G) { return sfm::prefilter_reject(nt, G) ? 1 : 0; }
 
+// ---- band rule (round 5): sigma of a hypothesis, its coefficient slots, the rule, the second divisor's transposed system
+float hc_pf_band_sigma(const float *e, float thr, float B, const float *box /*xlo xhi ylo yhi ulo uhi vlo vhi*/, int b_safe)
+{
+    const sfm::PfBox bx = { box[0], box[1], box[2], box[3], box[4], box[5], box[6], box[7] };
+    return sfm::prefilter_band_sigma(e, thr, B, bx, b_safe != 0);
+}
+void hc_pf_band_hyp_slots(const float *e, float sigma, float *ns /*32*/)
+{
+    _Float16 n16[sfm::kPfSlots];
+    sfm::prefilter_band_hyp_slots(e, sigma, n16);
+    for (int k = 0; k < sfm::kPfSlots; ++k) ns[k] = (float)n16[k];
+}
+int hc_pf_band_reject(float nt) { return sfm::prefilter_band_reject(nt) ? 1 : 0; }
+void hc_pf_transposed(const float *e, float *et) { sfm::prefilter_transposed(e, et); }
+uint32_t hc_pf_cell_key_side(int ix, int iy, int side) { return sfm::pf_cell_key_side(ix, iy, side); }
+// the boxes as the device derives them: ordered bits of the maxima of (x, -x, y, -y, u, -u, v, -v) -> PfBox (8 floats)
+uint32_t hc_pf_order_bits(float f) { return sfm::pf_order_bits(f); }
+void hc_pf_box_from_words(const unsigned long long *w /*8*/, float B, float *box /*8*/)
+{
+    const sfm::PfBox b = sfm::pf_box_from_words(w, B);
+    box[0] = b.xlo; box[1] = b.xhi; box[2] = b.ylo; box[3] = b.yhi; box[4] = b.ulo; box[5] = b.uhi; box[6] = b.vlo; box[7] = b.vhi;
+}
+
 void hc_sample8(uint32_t seed, uint32_t hyp, int n, int *idx) { sfm::sample8(seed, hyp, n, idx); }
 
 void hc_svd3(const float *a, float *u, float *s, float *v) { sfm::svd3(a, u, s, v); }

@@ -162,6 +162,62 @@ def test_prefilter_operands_on_the_device_equal_the_host_build(gpu_ab):
         assert abs(float(dv["G"]) - G) <= T.ACC * float(np.abs(Bt[0]) @ np.abs(ts)) + 1e-12
 
 
+def test_band_rule_operands_on_the_device_equal_the_host_build(gpu_ab):
+    """sfm_prefilter_band_probe: sigma, the coefficient slots read back through the record the scoring kernel reads, the feature
+    slots and the matrix cores' nt for one (hypothesis, point) pair, against tests/hostcheck bit for bit (sigma included: sqrtf and
+    the division are correctly rounded on both sides); the rule's bit equals |nt| >= 2."""
+    import ctypes as C
+    import test_hostcheck_prefilter as T
+    torch, dev, ctx = gpu_ab
+    h = C.CDLL(T.LIB)
+    f32p = O.f32p
+    h.hc_pf_band_sigma.restype = C.c_float
+    h.hc_pf_band_sigma.argtypes = [f32p, C.c_float, C.c_float, f32p, C.c_int]
+    h.hc_pf_band_hyp_slots.argtypes = [f32p, C.c_float, f32p]
+    h.hc_pf_point_slots.argtypes = [C.c_float] * 4 + [C.c_int, f32p, f32p]
+    h.hc_pf_zero_divisor_cells.argtypes = [f32p, C.c_float, C.POINTER(C.c_int), f32p]
+    h.hc_pf_transposed.argtypes = [f32p, f32p]
+    rng = np.random.default_rng(78)
+    ties = P._fp16_tie_coordinates(rng, 24)
+    rejected = 0
+    for k in range(64):
+        E = rng.standard_normal(9).astype(np.float32); E /= np.linalg.norm(E)
+        if k % 7 == 0:
+            E[:6] *= np.float32(10.0 ** rng.uniform(-7, -1))                        # small divisors: sigma towards its clamp
+        pt = rng.uniform(-1.8, 1.8, 4).astype(np.float32)
+        if k < 24:
+            pt[2] = ties[k]
+        thr = np.float32(10.0 ** rng.uniform(-8.5, -2.1))
+        B = float(np.float32(np.abs(pt).max() * 1.01))
+        lo = np.sort(rng.uniform(-B, B, (4, 2)).astype(np.float32), axis=1)
+        box = np.float32([lo[0, 0], lo[0, 1], lo[1, 0], lo[1, 1], lo[2, 0], lo[2, 1], lo[3, 0], lo[3, 1]])
+        if k % 5 == 0:                                                             # a point of the hypothesis' own zero band: |n| small
+            a = E.reshape(3, 3) @ np.float32([pt[2], pt[3], 1.0])
+            pt[0] = np.float32(-(a[1] * pt[1] + a[2]) / a[0]) if abs(a[0]) > 1e-3 else pt[0]
+            B = float(np.float32(max(B, abs(pt[0]) * 1.01)))
+        b_safe = k % 3 != 0
+        dv = ctx.prefilter_band_probe(E, thr, B, box, b_safe, pt)
+        sigma = float(h.hc_pf_band_sigma(T.fp(E), thr, B, T.fp(box), int(b_safe)))
+        assert np.float32(sigma).view(np.uint32) == np.float32(dv["sigma"]).view(np.uint32), (k, sigma, dv["sigma"])
+        ns = np.zeros(32, np.float32)
+        h.hc_pf_band_hyp_slots(T.fp(E), sigma, T.fp(ns))
+        Bn, _ = T.point_slots(h, np.float32([[pt[0]], [pt[1]], [1.0]]), np.float32([[pt[2]], [pt[3]], [1.0]]))
+        assert np.array_equal(dv["ns"], ns), (k, dv["ns"], ns)
+        assert np.array_equal(dv["bn"].astype(np.float64), Bn[0])
+        nt = float(Bn[0] @ ns.astype(np.float64))
+        assert abs(float(dv["nt"]) - nt) <= T.ACC * float(np.abs(Bn[0]) @ np.abs(ns.astype(np.float64))) + 1e-12
+        assert dv["rejected"] == (abs(float(dv["nt"])) >= 2.0)
+        rejected += dv["rejected"]
+        cells = (C.c_int * 4)(); g = C.c_float()
+        et = np.zeros(9, np.float32); h.hc_pf_transposed(T.fp(E), T.fp(et))
+        assert dv["zero_divisor_state"] == h.hc_pf_zero_divisor_cells(T.fp(E), B, cells, C.byref(g))
+        assert dv["second_divisor_state"] == h.hc_pf_zero_divisor_cells(T.fp(et), B, cells, C.byref(g))
+    assert 8 < rejected < 64
+    # survive-all: all-zero coefficients but the pad marker's, nt = 0
+    dv = ctx.prefilter_band_probe(E, thr, B, box, True, pt, survive_all=True)
+    assert dv["sigma"] == 0 and not dv["ns"][:27].any() and dv["ns"][27] == 1 and dv["nt"] == 0 and not dv["rejected"]
+
+
 @pytest.mark.parametrize("var", [16, 17])                 # 16 = the product's accumulator epilogue, 17 = round 3's tickets
 @pytest.mark.parametrize("cols,launches,H", [(64, 600, 1 << 18), (1, 150, 1 << 18)])
 def test_prefilter_tickets_under_contention_forced_columns(gpu_ab, cols, launches, H, var):
@@ -215,3 +271,25 @@ def test_round2_kernel_still_equals_oracle(gpu_ab):
     assert pair.last_launch()["kernel"] == S.KERNEL_PREFILTER
     P.check_all(pair, scene, p, H, n)
 
+
+
+@pytest.mark.parametrize("n,H,thr", [(4096, 65536, 1e-6), (1000, 20000, 1e-4), (16384, 16384, 1e-6), (700, 16385, 1e-8)])
+def test_g_rule_kernel_still_equals_oracle(gpu_ab, n, H, thr):
+    """The G rule of rounds 2-4 (a per-pair threshold contraction: v_fma + v_alignbit per pair, three MFMAs per 32 x 32 pairs), kept
+    behind reserved[3] = 4 for A/B runs against the band rule: every count, key, E, mask -- and both rules' LDS footprints."""
+    scene = synth.two_view_scene(n, seed=8)
+    pair, _ = make_pair(S, gpu_ab, scene)
+    p = S.default_params(n, num_hypotheses=H, seed=2, kernel=S.KERNEL_PREFILTER, threshold=thr)
+    p.reserved[3] = 4
+    pair.estimateE(p)
+    g = pair.last_launch()
+    assert g["kernel"] == S.KERNEL_PREFILTER
+    P.check_all(pair, scene, p, H, n)
+    q = S.default_params(n, num_hypotheses=H, seed=2, kernel=S.KERNEL_PREFILTER, threshold=thr)
+    pair.estimateE(q)
+    b = pair.last_launch()
+    P.check_all(pair, scene, q, H, n)
+    assert b["lds_bytes"] + 32 * 1024 == g["lds_bytes"]                  # 64 instead of 96 bytes of fragments per point of the 1024-point tile
+    p.reserved[3] = 3                                                    # stand-alone record kernel, band rule
+    pair.estimateE(p)
+    P.check_all(pair, scene, p, H, n)

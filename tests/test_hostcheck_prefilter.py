@@ -1,7 +1,9 @@
-"""CPU: the matrix-core pre-filter's operands and decision rule (cuda-sfm_amd/csrc/prefilter_math.hpp, compiled as HIP host
-code by tests/hostcheck) against the oracle.  The rule may only REJECT pairs the exact test would not count; here the two
-fp16 contractions are evaluated in float64 and then pushed by the full accumulation-error budget in every direction that
-favours a rejection -- a single rejected oracle inlier fails the test.  (The GPU twin is tests/test_gpu_prefilter.py:
+"""CPU: the matrix-core pre-filter's operands and decision rules (cuda-sfm_amd/csrc/prefilter_math.hpp, compiled as HIP host
+code by tests/hostcheck) against the oracle.  A rule may only REJECT pairs the exact test would not count; here the fp16
+contractions are evaluated in float64 and then pushed by the full accumulation-error budget in every direction that
+favours a rejection -- a single rejected oracle inlier fails the test.  Both rules run: "band" (round 5, the product: a
+per-hypothesis constant folded into the coefficient scaling, the test is bit 30 of the accumulator) and "G" (rounds 2-4, kept
+in the lab-bench library: a per-pair threshold from a second contraction).  (The GPU twin is tests/test_gpu_prefilter.py:
 counts bit for bit.)"""
 import ctypes as C
 import os
@@ -31,7 +33,20 @@ def H():
     h.hc_pf_cell_key.restype = C.c_uint32
     h.hc_pf_cell_key.argtypes = [C.c_int, C.c_int]
     h.hc_pf_zero_divisor_any.argtypes = [f32p, f32p, f32p, C.c_int]
+    h.hc_pf_band_sigma.restype = C.c_float
+    h.hc_pf_band_sigma.argtypes = [f32p, C.c_float, C.c_float, f32p, C.c_int]
+    h.hc_pf_band_hyp_slots.argtypes = [f32p, C.c_float, f32p]
+    h.hc_pf_band_reject.argtypes = [C.c_float]
+    h.hc_pf_transposed.argtypes = [f32p, f32p]
+    h.hc_pf_cell_key_side.restype = C.c_uint32
+    h.hc_pf_cell_key_side.argtypes = [C.c_int, C.c_int, C.c_int]
+    h.hc_pf_order_bits.restype = C.c_uint32
+    h.hc_pf_order_bits.argtypes = [C.c_float]
+    h.hc_pf_box_from_words.argtypes = [C.POINTER(C.c_uint64), C.c_float, f32p]
     return h
+
+
+RULES = ["band", "G"]
 
 
 def fp(a):
@@ -74,13 +89,46 @@ def rejected(H, ns, ts, Bn, Bt):
     return out
 
 
+def rejected_band(H, ns, Bn):
+    """The band rule (bit 30 of the accumulator: |nt| >= 2) under the worst accumulation error."""
+    nt = Bn @ ns
+    en = ACC * (np.abs(Bn) @ np.abs(ns))
+    worst = (np.abs(nt) + en).astype(np.float32)
+    bits = worst.view(np.uint32)
+    rej = ((bits >> 30) & 1).astype(bool)
+    assert np.array_equal(rej, worst >= 2.0)                        # the bit IS the comparison (no NaN / inf among the operands)
+    for k in np.flatnonzero(rej)[:4]:
+        assert H.hc_pf_band_reject(float(worst[k])) == 1
+    return rej
+
+
+def band_box(H, X0, X1, n, B):
+    """The boxes as fill_xu_kernel leaves them: ordered-bit maxima of (x, -x, y, -y | u, -u, v, -v) over the points that carry
+    features, decoded by pf_box_from_words."""
+    with np.errstate(invalid="ignore"):
+        c = np.stack([X0[0, :n], X0[1, :n], X1[0, :n], X1[1, :n]])
+        feat = np.isfinite(c).all(axis=0) & (np.abs(c).max(axis=0) <= 48.0)
+    words = (C.c_uint64 * 8)()
+    vals = [X1[0, :n], -X1[0, :n], X1[1, :n], -X1[1, :n], X0[0, :n], -X0[0, :n], X0[1, :n], -X0[1, :n]]
+    for k, v in enumerate(vals):
+        m = np.float32(v[feat].max()) if feat.any() else np.float32(-np.inf)
+        words[k] = (7 << 32) | H.hc_pf_order_bits(float(m))          # an epoch in the upper half, ignored by the decoder
+    box = np.zeros(8, np.float32)
+    H.hc_pf_box_from_words(words, float(B), fp(box))
+    if feat.any():
+        assert box[0] <= X1[0, :n][feat].min() and box[1] >= X1[0, :n][feat].max() and box[4] <= X0[0, :n][feat].min() and box[7] >= X0[1, :n][feat].max()
+    return box
+
+
 class ZeroDivisorGuard:
     """prefilter_math.hpp (3) as the kernel stages it: occupied cells of the tile's points, per hypothesis the 2 x 2 cell
     test, and the scan of the whole tile for those it cannot clear.  decide() also checks the guard's own claim -- a
-    hypothesis it clears must not have a zero-divisor point (brute force over the tile)."""
+    hypothesis it clears must not have a zero-divisor point (brute force over the tile).  side = 1: the SECOND divisor
+    (transposed system, first-view positions, flipped keys) -- the band rule only asks whether it can be ruled out."""
 
-    def __init__(self, H, X1, n, B):
+    def __init__(self, H, X1, n, B, side=0):
         self.H, self.B = H, float(B)
+        self.side = side
         ok = np.isfinite(X1[:2, :n]).all(axis=0)
         self.x = np.ascontiguousarray(X1[0, :n], np.float32); self.y = np.ascontiguousarray(X1[1, :n], np.float32)
         self.n = n
@@ -88,12 +136,17 @@ class ZeroDivisorGuard:
         cell = (C.c_int * 2)(); key = C.c_uint32()
         for j in np.nonzero(ok)[0]:
             H.hc_pf_point_cell(float(self.x[j]), float(self.y[j]), self.B, cell, C.byref(key))
-            self.keys.add(key.value)
+            self.keys.add(H.hc_pf_cell_key_side(cell[0], cell[1], side))
+            assert side == 1 or self.keys.issuperset({key.value})
         self.states = [0, 0, 0]
         self.scans = 0
 
     def decide(self, E):
         e = np.ascontiguousarray(E, np.float32).reshape(9)
+        if self.side:
+            et = np.zeros(9, np.float32)
+            self.H.hc_pf_transposed(fp(e), fp(et))
+            e = et
         cells = (C.c_int * 4)(); g = C.c_float()
         st = self.H.hc_pf_zero_divisor_cells(fp(e), self.B, cells, C.byref(g))
         self.states[st] += 1
@@ -101,16 +154,16 @@ class ZeroDivisorGuard:
             truth = self.H.hc_pf_zero_divisor_any(fp(e), fp(self.x), fp(self.y), self.n) > 0
         if st == 1:
             assert 0 <= cells[1] - cells[0] <= 1 and 0 <= cells[3] - cells[2] <= 1
-            hit = any(self.H.hc_pf_cell_key(cx, cy) in self.keys for cx in range(cells[0], cells[1] + 1) for cy in range(cells[2], cells[3] + 1))
+            hit = any(self.H.hc_pf_cell_key_side(cx, cy, self.side) in self.keys for cx in range(cells[0], cells[1] + 1) for cy in range(cells[2], cells[3] + 1))
             st = 2 if hit else 0
         if st == 0:
             assert not truth, "the guard cleared a hypothesis that has a zero-divisor point in the tile"
             return False
         self.scans += 1
-        return truth
+        return truth if self.side == 0 else True                     # second divisor: "cannot rule it out" is all the rule asks
 
 
-def check_scene(H, X0, X1, Es, thr, n_real=None, max_survivors=None, scans_below=None):
+def check_scene(H, X0, X1, Es, thr, n_real=None, max_survivors=None, scans_below=None, rule="G"):
     ok, a, (sigE, sigF, sig2a) = scales(H, thr)
     assert ok
     n = X0.shape[1] if n_real is None else n_real
@@ -120,9 +173,23 @@ def check_scene(H, X0, X1, Es, thr, n_real=None, max_survivors=None, scans_below
     Bn, Bt = point_slots(H, X0, X1, n_real)
     surv = 0
     guard = ZeroDivisorGuard(H, X1, n, B)
+    if rule == "band":
+        guard_b = ZeroDivisorGuard(H, X0, n, B, side=1)
+        box = band_box(H, X0, X1, n, B)
     for E in Es:
-        ns, ts, _ = hyp_slots(H, E, thr, B, guard.decide(E))
-        rej = rejected(H, ns, ts, Bn, Bt)
+        if rule == "band":
+            e = np.ascontiguousarray(E, np.float32).reshape(9)
+            with np.errstate(invalid="ignore", over="ignore"):
+                b_safe = not guard_b.decide(E)
+                sigma = 0.0 if guard.decide(E) else float(H.hc_pf_band_sigma(fp(e), thr, B, fp(box), int(b_safe)))
+            assert 0.0 <= sigma <= 262144.0
+            ns32 = np.zeros(32, np.float32)
+            H.hc_pf_band_hyp_slots(fp(e), sigma, fp(ns32))
+            assert ns32[27] == 1.0 and (sigma > 0 or not ns32[:27].any())
+            rej = rejected_band(H, ns32.astype(np.float64), Bn)
+        else:
+            ns, ts, _ = hyp_slots(H, E, thr, B, guard.decide(E))
+            rej = rejected(H, ns, ts, Bn, Bt)
         _, mask = O.count_inliers(np.ascontiguousarray(E, np.float32).reshape(3, 3), X0[:, :n], X1[:, :n], thr)
         inl = np.zeros(rej.shape, bool); inl[:n] = mask.astype(bool)
         assert not (rej & inl).any(), f"rejected {int((rej & inl).sum())} oracle inliers"
@@ -137,28 +204,31 @@ def check_scene(H, X0, X1, Es, thr, n_real=None, max_survivors=None, scans_below
     return rate
 
 
+@pytest.mark.parametrize("rule", RULES)
 @pytest.mark.parametrize("thr", [1e-8, 1e-6, 1e-4, 1e-3])
 @pytest.mark.parametrize("focal", [600.0, 2360.0])
-def test_no_oracle_inlier_is_rejected(H, thr, focal):
+def test_no_oracle_inlier_is_rejected(H, thr, focal, rule):
     n = 1024
     sc = synth.two_view_scene(n, seed=7, focal=focal)
     _, _, X0, X1 = O.fill_xu(sc["sift"], sc["Kinv"])
     Es = [O.hypothesis_E(X0, X1, O.sample8(99, h, n), 0) for h in range(96)]
-    rate = check_scene(H, X0, X1, Es, np.float32(thr), scans_below=0.05)
+    rate = check_scene(H, X0, X1, Es, np.float32(thr), scans_below=0.05, rule=rule)
     if thr == 1e-6 and focal == 2360.0:
-        assert rate < 0.03                                          # and it still filters: ~1 % survive at the reference threshold
+        assert rate < (0.04 if rule == "band" else 0.03)            # and it still filters: 1-2 % survive at the reference threshold
 
 
-def test_padding_and_ragged_tile(H):
+@pytest.mark.parametrize("rule", RULES)
+def test_padding_and_ragged_tile(H, rule):
     n = 300
     sc = synth.two_view_scene(384, seed=3)
     _, _, X0, X1 = O.fill_xu(sc["sift"], sc["Kinv"])
     X0[:, n:] = np.nan; X1[:, n:] = np.nan                          # what the tail of a padded row looks like
     Es = [O.hypothesis_E(X0[:, :n], X1[:, :n], O.sample8(5, h, n), 0) for h in range(40)]
-    check_scene(H, X0, X1, Es, np.float32(1e-6), n_real=n)
+    check_scene(H, X0, X1, Es, np.float32(1e-6), n_real=n, rule=rule)
 
 
-def test_zero_divisor_pairs_survive(H):
+@pytest.mark.parametrize("rule", RULES)
+def test_zero_divisor_pairs_survive(H, rule):
     """da_c == 0 zeroes the first term of the residual (the reference's element_wise_div guard): forward motion with a
     correspondence whose x2 sits exactly on the epipole has r = n^2 / db, possibly an inlier, although n^2 / da is 'infinite'."""
     E = np.array([[0, -1, 0], [1, 0, 0], [0, 0, 0]], np.float32)            # t = (0, 0, 1), R = I; singular values (1, 1, 0)
@@ -172,7 +242,7 @@ def test_zero_divisor_pairs_survive(H):
     X1[:2, 2] = np.float32(1e-30)                                            # da underflows
     cnt, mask = O.count_inliers(E, X0, X1, np.float32(1e-6))
     assert mask[0] == 1 and mask[1] == 1
-    check_scene(H, X0, X1, [E, -E, (E * np.float32(0.5)).astype(np.float32)], np.float32(1e-6))
+    check_scene(H, X0, X1, [E, -E, (E * np.float32(0.5)).astype(np.float32)], np.float32(1e-6), rule=rule)
     # the same with n != 0: rows 0 and 1 parallel (rank 2), x2 orthogonal to them but not to row 2 -> a0 = a1 = 0 exactly,
     # n = a2 = x2y, r = n^2 / db: an inlier for |x2y| < 1e-3 that the one-sided bound n^2 / da = inf would throw away
     E2 = np.array([[1, 0, -0.125], [2, 0, -0.25], [0, 1, 0]], np.float32)
@@ -182,17 +252,25 @@ def test_zero_divisor_pairs_survive(H):
     Y1[1] = np.array([5e-4, -9e-4, 2e-3, 0.0, 1e-5, 0.3, -0.3, 9.9e-4], np.float32)
     cnt, mask = O.count_inliers(E2, Y0, Y1, np.float32(1e-6))
     assert mask[0] == 1 and mask[1] == 1 and mask[2] == 0 and mask[5] == 0
-    check_scene(H, Y0, Y1, [E2], np.float32(1e-6))
+    check_scene(H, Y0, Y1, [E2], np.float32(1e-6), rule=rule)
     # the test is live: without the zero-divisor guard the rule WOULD reject those inliers
-    ns, ts, _ = hyp_slots(H, E2, np.float32(1e-6), 0.3, survive_all=False)
     Bn, Bt = point_slots(H, Y0, Y1)
-    assert rejected(H, ns, ts, Bn, Bt)[:2].all()
+    if rule == "band":
+        sigma = float(H.hc_pf_band_sigma(fp(E2.reshape(9)), np.float32(1e-6), 0.3, fp(band_box(H, Y0, Y1, 8, 0.3)), 1))
+        ns32 = np.zeros(32, np.float32)
+        H.hc_pf_band_hyp_slots(fp(E2.reshape(9)), sigma, fp(ns32))
+        # (the first divisor's maximum over the box is 0 here, so the constant is the error floor alone: |n| = 5e-4 and 9e-4 are far outside)
+        assert sigma > 0 and rejected_band(H, ns32.astype(np.float64), Bn)[:2].all()
+    else:
+        ns, ts, _ = hyp_slots(H, E2, np.float32(1e-6), 0.3, survive_all=False)
+        assert rejected(H, ns, ts, Bn, Bt)[:2].all()
     g = ZeroDivisorGuard(H, Y1, 8, 0.3)
     assert g.decide(E2) and g.scans == 1
 
 
+@pytest.mark.parametrize("rule", RULES)
 @pytest.mark.parametrize("scale,thr", [(0.3, 1e-6), (5.0, 1e-3)])
-def test_crafted_candidates_of_the_gpu_test(H, scale, thr):
+def test_crafted_candidates_of_the_gpu_test(H, scale, thr, rule):
     """The candidate set of tests/test_gpu_prefilter.py::test_prefilter_supplied_candidates_and_zero_divisors through the
     host model of the rule (one tile of it)."""
     from helpers import crafted_candidates, lattice_points
@@ -202,10 +280,11 @@ def test_crafted_candidates_of_the_gpu_test(H, scale, thr):
     kept = sum(O.count_inliers(Es[h], X0, X1, np.float32(thr))[0] for h in range(10, 512, 16))
     assert kept > 0
     with np.errstate(invalid="ignore", over="ignore"):
-        check_scene(H, X0, X1, list(Es), np.float32(thr))
+        check_scene(H, X0, X1, list(Es), np.float32(thr), rule=rule)
 
 
-def test_degenerate_hypotheses_and_points(H):
+@pytest.mark.parametrize("rule", RULES)
+def test_degenerate_hypotheses_and_points(H, rule):
     sc = synth.two_view_scene(256, seed=11)
     _, _, X0, X1 = O.fill_xu(sc["sift"], sc["Kinv"])
     X0 = X0.copy(); X1 = X1.copy()
@@ -215,10 +294,11 @@ def test_degenerate_hypotheses_and_points(H):
           np.full((3, 3), np.nan, np.float32), good * np.float32(3.0),                 # non-finite, and entries above the tame bound
           good, np.diag([1, 1, 0]).astype(np.float32), np.array([[0, 0, 0], [0, 0, -1], [0, 1, 0]], np.float32)]
     with np.errstate(invalid="ignore"):
-        check_scene(H, X0, X1, Es, np.float32(1e-6))
+        check_scene(H, X0, X1, Es, np.float32(1e-6), rule=rule)
 
 
-def test_random_matrices_and_scales(H):
+@pytest.mark.parametrize("rule", RULES)
+def test_random_matrices_and_scales(H, rule):
     rng = np.random.default_rng(5)
     n = 512
     for scale in (0.05, 0.5, 3.0, 20.0):
@@ -232,7 +312,7 @@ def test_random_matrices_and_scales(H):
             Es.append((M * rng.uniform(0.2, 1.9)).astype(np.float32))
         for thr in (1e-7, 1e-5, 1e-3):
             t = np.float32(min(max(thr * scale * scale, 1e-9), 1e-2))            # inside the range the fp16 scaling covers
-            check_scene(H, X0, X1, Es, t)
+            check_scene(H, X0, X1, Es, t, rule=rule)
 
 
 def test_threshold_range(H):
@@ -322,7 +402,89 @@ def test_committed_tie_cases_are_kept_and_their_splits_are_consistent(H):
         cnt, mask = O.count_inliers(E, X0, X1, np.float32(c["thr"]))
         assert mask[0]
         check_scene(H, X0, X1, [E], float(np.float32(c["thr"])))
+        check_scene(H, X0, X1, [E], float(np.float32(c["thr"])), rule="band")
         p = np.float32(X1[0, 0] * X1[0, 0])
         assert abs(float(p) - float(np.float16(p))) * 2 == float(np.spacing(np.float16(p)))         # the tie
         Bn, Bt = point_slots(H, X0[:, :1], X1[:, :1])
         assert Bt[0][0] == Bt[0][2] and abs(Bt[0][0] + Bt[0][1] - float(p)) <= 2.0 ** -21 * float(p)
+
+
+# ---- band rule only ---------------------------------------------------------------------------------------------------------
+def test_band_second_divisor_zero_selects_the_weaker_constant(H):
+    """db_c == 0 zeroes the SECOND term: the pair is an inlier iff n^2 < thr da, which can exceed the harmonic constant
+    thr Da Db / (Da + Db) the rule uses when no point can have db_c == 0.  The guard on the transposed system must notice."""
+    thr = np.float32(1e-6)
+    # b = (e0 u + e3 v + e6, e1 u + e4 v + e7) vanishes exactly at x1 = (0.25, -0.125); a = (x, y) + (0.5, 0.25): |a| ~ 0.56
+    E = np.array([[1, 0, 0.5], [0, 1, 0.25], [-0.25, 0.125, 0.0]], np.float32)
+    n = 16
+    rng = np.random.default_rng(4)
+    X0 = np.ones((3, n), np.float32); X1 = np.ones((3, n), np.float32)
+    X0[:2] = rng.uniform(-0.3, 0.3, (2, n)).astype(np.float32)
+    X1[:2] = rng.uniform(-0.3, 0.3, (2, n)).astype(np.float32)
+    X0[0, 0] = 0.25; X0[1, 0] = -0.125                                   # db_c == 0 for point 0
+    # with b(x1) = 0 the numerator is n = b2 = e2 u + e5 v + e8 = 0.09375 + e8 whatever x2 is; x2 in the corner of the box where da is
+    # largest (0.94, against a harmonic constant of ~0.32): e8 makes n^2 ~ 0.8 thr da
+    X1[0, 0] = 0.3; X1[1, 0] = 0.3
+    E[2, 2] = np.float32(-0.09375 + 8.67e-4)
+    r = O.residual(E, (0.25, -0.125, 1.0), (float(X1[0, 0]), float(X1[1, 0]), 1.0))
+    assert 0.6 * thr < r < 0.95 * thr                                     # r = n^2 / da alone: the second term is zeroed
+    cnt, mask = O.count_inliers(E, X0, X1, thr)
+    assert mask[0] == 1
+    check_scene(H, X0, X1, [E], thr, rule="band")
+    # live: with the harmonic constant (b_safe forced) the same pair is rejected
+    Bn, _ = point_slots(H, X0, X1)
+    box = band_box(H, X0, X1, n, 0.3)
+    for b_safe, expect in ((1, True), (0, False)):
+        sigma = float(H.hc_pf_band_sigma(fp(E.reshape(9)), thr, 0.3, fp(box), b_safe))
+        ns32 = np.zeros(32, np.float32)
+        H.hc_pf_band_hyp_slots(fp(E.reshape(9)), sigma, fp(ns32))
+        assert bool(rejected_band(H, ns32.astype(np.float64), Bn)[0]) == expect
+
+
+def test_band_small_and_large_matrices_sigma_clamp(H):
+    """Tiny first rows make the constant tiny and sigma hits its fp16-range clamp (2^18); the rule must stay conservative."""
+    rng = np.random.default_rng(8)
+    n = 512
+    sc = synth.two_view_scene(n, seed=21)
+    _, _, X0, X1 = O.fill_xu(sc["sift"], sc["Kinv"])
+    base = [O.hypothesis_E(X0, X1, O.sample8(3, h, n), 0) for h in range(12)]
+    Es = []
+    for E in base:
+        for f in (1e-7, 1e-5, 1e-3, 1.0, 1.9):
+            Es.append((E * np.float32(f)).astype(np.float32))
+        M = E.copy(); M[:2] *= np.float32(1e-6); Es.append(M)              # divisors ~1e-12, n of order one
+        M = E.copy(); M[2] *= np.float32(1e-6); Es.append(M)
+    clamped = 0
+    box = band_box(H, X0, X1, n, float(np.abs(np.concatenate([X0[:2].ravel(), X1[:2].ravel()])).max()))
+    for E in Es:
+        clamped += float(H.hc_pf_band_sigma(fp(np.ascontiguousarray(E, np.float32).reshape(9)), np.float32(1e-6), 0.7, fp(box), 1)) == 262144.0
+    assert clamped >= 12
+    for thr in (1e-9, 1e-6, 1e-2):
+        check_scene(H, X0, X1, Es, np.float32(thr), rule="band")
+
+
+def test_band_ordered_bits_and_boxes(H):
+    vals = np.float32([-np.inf, -48.0, -1.0, -1e-30, -0.0, 0.0, 1e-30, 0.5, 48.0, np.inf])
+    keys = [H.hc_pf_order_bits(float(v)) for v in vals]
+    assert keys == sorted(keys) and len(set(keys)) == len(keys) - 0 or keys[4] < keys[5]      # -0 < +0 in the key order, everything else strictly increasing
+    # a side without points (all maxima -inf) falls back to [-B, B]; so does a range that leaves it
+    words = (C.c_uint64 * 8)(*[H.hc_pf_order_bits(float("-inf"))] * 8)
+    box = np.zeros(8, np.float32)
+    H.hc_pf_box_from_words(words, 0.5, fp(box))
+    assert np.array_equal(box, np.float32([-0.5, 0.5, -0.5, 0.5, -0.5, 0.5, -0.5, 0.5]))
+    m = [0.25, 0.125, 0.3, -0.1, 0.6, 0.2, 0.1, 0.1]                     # maxima of (x, -x, y, -y, u, -u, v, -v): u's 0.6 exceeds B
+    words = (C.c_uint64 * 8)(*[(3 << 32) | H.hc_pf_order_bits(v) for v in m])
+    H.hc_pf_box_from_words(words, 0.5, fp(box))
+    assert np.allclose(box, [-0.125, 0.25, 0.1, 0.3, -0.5, 0.5, -0.5, 0.5])
+
+
+def test_band_survivor_rate_on_the_bench_scene(H):
+    """What the rule costs: ~1.2 % of the pairs of the bench scene survive (G rule: ~0.7 %, inliers: 0.35 %)."""
+    n = 1024
+    sc = synth.two_view_scene(4096)
+    _, _, X0, X1 = O.fill_xu(sc["sift"], sc["Kinv"])
+    X0 = np.ascontiguousarray(X0[:, :n]); X1 = np.ascontiguousarray(X1[:, :n])
+    Es = [O.hypothesis_E(X0, X1, O.sample8(0x5EED5F3D, h, n), 0) for h in range(200)]
+    rate_b = check_scene(H, X0, X1, Es, np.float32(1e-6), rule="band")
+    rate_g = check_scene(H, X0, X1, Es, np.float32(1e-6), rule="G")
+    assert rate_g < rate_b < 0.02
