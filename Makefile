@@ -87,7 +87,9 @@ $(IOTEST): tests/cpp/io_test.cpp $(PKG)/host/sfm_io.h $(PKG)/host/cudaSift.h inc
 $(GEOMTEST): tests/cpp/geom_test.cpp $(PKG)/host/geomFuncs.h $(PKG)/host/sfm_io.h $(PKG)/host/cudaSift.h include/sfm_amd.h
 	g++ -O2 -std=c++14 -ffp-contract=off -Wall -o $@ $<
 
-hostcheck: tests/hostcheck/libhostcheck.so tests/fake_ccl/libsfm_amd_fakeccl.so
+# CPU-only: the host-compiled arithmetic check of the non-GPU tests (the fakeccl target, which needs the gfx950 build and the RCCL
+# header, is a target of its own and part of `all`)
+hostcheck: tests/hostcheck/libhostcheck.so
 
 # TEST HARNESS: comm.cpp linked against a shared-memory stand-in for the nine RCCL calls it makes, so that a 1-GPU box can run the
 # exchange code with two real ranks (tests/test_gpu_fakeccl.py); the product's libsfm_amd_rccl.so is linked against librccl

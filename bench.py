@@ -52,8 +52,10 @@ FLOP_PER_POINT = 38           # residual of one (hypothesis, point)
 FLOP_PER_HYP = 720            # A^T A normal equations
 ALG_BYTES_PER_HYP = 72.0       # 32 B indices + 36 B E + 4 B count
 # ransac_score_prefilter, per (hypothesis, point) pair, what cannot be removed from this formulation:
-PF_SCAN_VALU_PER_PAIR = 2     # v_fma_f32 (G - nt^2) + v_alignbit_b32 (its sign bit into the lane's mask)
-PF_MFMA_PER_1024_PAIRS = 3    # v_mfma_f32_32x32x16_f16: G (16 k-slots) + nt (32 k-slots)
+# irreducible work of the pre-filter scan per rule (prefilter_math.hpp): "band" (round 5, the product) = one v_alignbit_b32 per pair (bit 30 of
+# the accumulator into the lane's mask) and two v_mfma_f32_32x32x16_f16 per 32 x 32 pairs; "G" (rounds 2-4, lab bench, reserved[3] == 4) =
+# v_fma_f32 + v_alignbit_b32 per pair and three MFMAs
+PF_RULES = {"band": (1, 2), "G": (2, 3)}
 PF_MFMA_CYCLES = 32           # issue interval of one 32x32x16 f16 MFMA on a SIMD (8 passes x 4 cycles; profiles/r02_mfma_rate_probe.txt)
 PF_SOURCES = ("ransac_prefilter.hip", "prefilter_math.hpp", "prefilter_record.hpp", "ransac.hip", "ransac_device.hpp", "device_math.hpp")
 TRAFFIC_JSON = os.path.join("profiles", "r04_traffic.json")
@@ -96,7 +98,30 @@ def parse_args(argv=None):
     ap.add_argument("--no-variants", action="store_true", help="skip the short run with the other null-vector solver")
     ap.add_argument("--no-extra", action="store_true", help="skip the short runs of the other BASELINE configurations")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU time budget of the cpu_baseline sample")
+    ap.add_argument("--exchange-probe", action="store_true", help="internal: the child process of a one-GPU run that times the exchange step alone")
+    ap.add_argument("--launch-timeout", type=float, default=900.0,
+                    help="--gpus N started without a launcher: seconds after which bench.py's own launcher reports every rank's last stage, stops the ranks and exits 124")
     return ap.parse_args(argv)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# stage lines: every rank says where it is (stderr, and the file the launcher reads when it has to give up on a rank)
+# ------------------------------------------------------------------------------------------------------------------
+_T0 = time.time()
+
+
+def stage(msg):
+    r, w = os.environ.get("RANK", "0"), os.environ.get("WORLD_SIZE", "1")
+    line = f"[bench rank {r}/{w} +{time.time() - _T0:7.2f}s] stage {msg}"
+    if int(w) > 1 or os.environ.get("SFM_BENCH_STAGES"):
+        print(line, file=sys.stderr, flush=True)
+    path = os.environ.get("SFM_BENCH_STAGE_FILE")
+    if path:
+        try:
+            with open(path, "a") as f:
+                f.write(line + "\n")
+        except OSError:
+            pass
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -120,17 +145,22 @@ def free_port():
     return port
 
 
-def launch_ranks(n, argv, env_extra=None, command=None, timeout=3600.0):
+def launch_ranks(n, argv, env_extra=None, command=None, timeout=900.0):
     """Starts n child processes of this script (or of `command`), one per rank, and relays rank 0's stdout.
     Returns the exit code for the parent: 0 only if every rank exited 0.  The children are polled: the first rank that
     exits non-zero ends the job at once (the others, possibly blocked in a collective that can no longer complete, are
-    terminated) instead of leaving the launcher waiting for the time-out."""
+    terminated) instead of leaving the launcher waiting for the time-out.  On the time-out (default 900 s: inside the
+    1800 s the driver gives a SCALE step, so that a hang in ncclCommInitRank or the first collective is REPORTED, not cut off)
+    the launcher prints the last stage line of every rank (their SFM_BENCH_STAGE_FILE), stops exactly the processes it started
+    and returns 124."""
+    import tempfile
     port = free_port()
     procs = []
+    stage_dir = tempfile.mkdtemp(prefix="bench_stages_")
     for r in range(n):
         env = dict(os.environ)
         env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
-                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "SFM_BENCH_STAGE_FILE": os.path.join(stage_dir, f"rank{r}.stage")})
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL across processes needs it on this host driver
         if env_extra:
             env.update(env_extra)
@@ -152,7 +182,18 @@ def launch_ranks(n, argv, env_extra=None, command=None, timeout=3600.0):
         if all(c == 0 for c in codes):
             break
         if time.time() > deadline:
-            print(f"bench.py: time-out after {timeout:.0f} s", file=sys.stderr)
+            print(f"bench.py: time-out after {timeout:.0f} s; last stage of every rank:", file=sys.stderr)
+            for r in range(n):
+                last = "(no stage line: the rank never got as far as importing the libraries)"
+                try:
+                    with open(os.path.join(stage_dir, f"rank{r}.stage")) as f:
+                        lines = f.read().splitlines()
+                    if lines:
+                        last = lines[-1]
+                except OSError:
+                    pass
+                state = "running" if codes[r] is None else f"exited {codes[r]}"
+                print(f"bench.py:   rank {r} ({state}): {last}", file=sys.stderr)
             rc = 124
             break
         time.sleep(0.2)
@@ -169,6 +210,15 @@ def launch_ranks(n, argv, env_extra=None, command=None, timeout=3600.0):
     for line in out0:                             # library banners (gloo / RCCL print to stdout) go to stderr: stdout carries the JSON line only
         (sys.stdout if line.lstrip().startswith("{") else sys.stderr).write(line if line.endswith("\n") else line + "\n")
     sys.stdout.flush()
+    try:
+        for r in range(n):
+            os.remove(os.path.join(stage_dir, f"rank{r}.stage"))
+    except OSError:
+        pass
+    try:
+        os.rmdir(stage_dir)
+    except OSError:
+        pass
     return rc
 
 
@@ -177,7 +227,7 @@ def launcher_main(args, argv):
     if have < args.gpus and os.environ.get("SFM_BENCH_DIST_BACKEND", "nccl") == "nccl":      # (tests fold the ranks onto the GPUs there are)
         print(f"bench.py: --gpus {args.gpus} but this node shows {have} GPU(s); nothing was run", file=sys.stderr)
         return 2
-    return launch_ranks(args.gpus, argv)
+    return launch_ranks(args.gpus, argv, timeout=args.launch_timeout)
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -322,7 +372,8 @@ def quoted_counters(kname, n, local_hyps):
         return None, f"{TRAFFIC_JSON}: {type(e).__name__}"
 
 
-def roofline_block(kernel_id, n, local_hyps, score_s, solve_s, clock_mhz, measured_in):
+def roofline_block(kernel_id, n, local_hyps, score_s, solve_s, clock_mhz, measured_in, rule="band"):
+    PF_SCAN_VALU_PER_PAIR, PF_MFMA_PER_1024_PAIRS = PF_RULES[rule]
     kname = KERNEL_NAMES.get(kernel_id, "?")
     pairs = float(local_hyps) * n
     alg_flops = pairs * FLOP_PER_POINT
@@ -342,17 +393,27 @@ def roofline_block(kernel_id, n, local_hyps, score_s, solve_s, clock_mhz, measur
             # one vector instruction-lane priced as one FMA slot (2 FLOP) of the plain (non-packed) FP32 vector rate
             bound, peak = "valu_issue", FP32_PEAK_TFLOPS / 2.0
             achieved = pairs * PF_SCAN_VALU_PER_PAIR * 2.0 / score_s / 1e12 if score_s > 0 else 0.0
-            detail = (f"vector-ALU issue: the irreducible scan is {PF_SCAN_VALU_PER_PAIR} vector instructions per pair (v_fma_f32 G - nt^2, v_alignbit_b32), "
-                      "each priced as one FMA lane-slot = 2 FLOP against the plain FP32 vector rate 78.65 TFLOP/s (1024 SIMDs x 16 lanes x 2 FLOP x 2.4 GHz); "
-                      "the three fp16 MFMAs per 1024 pairs issue next to it (mfma_floor_ms)")
+            detail = (f"vector-ALU issue: the irreducible scan of the {rule} rule is {PF_SCAN_VALU_PER_PAIR} vector instruction(s) per pair "
+                      + ("(v_alignbit_b32: bit 30 of the accumulator, |nt| >= 2, into the lane's mask), " if rule == "band" else "(v_fma_f32 G - nt^2, v_alignbit_b32), ")
+                      + "each priced as one FMA lane-slot = 2 FLOP against the plain FP32 vector rate 78.65 TFLOP/s (1024 SIMDs x 16 lanes x 2 FLOP x 2.4 GHz); "
+                      f"the {PF_MFMA_PER_1024_PAIRS} fp16 MFMAs per 1024 pairs issue next to it (mfma_floor_ms)")
         else:
             bound, peak = "mfma", FP16_MFMA_PEAK_TFLOPS
             achieved = pairs / 1024.0 * PF_MFMA_PER_1024_PAIRS * 32768.0 / score_s / 1e12 if score_s > 0 else 0.0
-            detail = "fp16 MFMA issue: three v_mfma_f32_32x32x16_f16 (32768 FLOP each) per 1024 pairs"
+            detail = f"fp16 MFMA issue: {PF_MFMA_PER_1024_PAIRS} v_mfma_f32_32x32x16_f16 (32768 FLOP each) per 1024 pairs"
         out = {"bound": bound, "bound_detail": detail, "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                "frac": (floor / score_s) if score_s > 0 else 0.0,
                "valu_floor_ms": 1e3 * valu_floor, "mfma_floor_ms": 1e3 * mfma_floor,
                "frac_at_sustained_clock": (floor / score_s * PEAK_CLOCK_MHZ / clock_mhz) if (score_s > 0 and clock_mhz > 0) else None}
+        # Continuity with rounds 2-4, whose kernel executed the G rule (2 vector instructions per pair: floor 0.2185 ms at 2^32 pairs), and
+        # the issue model measured in round 3 (a vector instruction holds a SIMD's issue port for 4 cycles, a 32x32x16 fp16 MFMA for ~16 of
+        # its 32): frac = max(valu, mfma) floors of THIS rule over the launch time; the formulation's floor moved, the launch got shorter.
+        g_floor = pairs * 2 / 64.0 / NUM_SIMDS * 4.0 / clock
+        model = pairs / 1024.0 * (4.0 * 16 * PF_SCAN_VALU_PER_PAIR + 16.0 * PF_MFMA_PER_1024_PAIRS) / NUM_SIMDS / clock
+        out["rule"] = rule
+        out["frac_against_the_round4_floor"] = (g_floor / score_s) if score_s > 0 else 0.0
+        out["frac_against_the_issue_model"] = (model / score_s) if score_s > 0 else 0.0
+        out["issue_model_floor_ms"] = 1e3 * model
     else:
         out = {"bound": "valu_fp32",
                "bound_detail": ("FP32 vector ALU issue (v_pk_fma_f32 and friends); 157.3 TFLOP/s = 256 CU x 256 FLOP/clk x 2.4 GHz, "
@@ -401,6 +462,15 @@ def extra_ransac(S, synth, O, ctx, dev, torch, np, name, n, H, steps, hyp_count=
         pair.estimateE_pipelined(p)
     pair.flush(); torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
+    ks = max(5, min(steps, 50))
+    for _ in range(3):
+        pair.estimateE(p)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(ks):
+        pair.estimateE(p)                                 # one call at a time
+    torch.cuda.synchronize()
+    dt_serial = (time.perf_counter() - t0) / ks
     for _ in range(3):
         pair.ransac_score(p)
     ctx.synchronize()
@@ -413,11 +483,12 @@ def extra_ransac(S, synth, O, ctx, dev, torch, np, name, n, H, steps, hyp_count=
     launch = pair.last_launch()
     got = (pair.get_inlier_counts(local).copy(), pair.get_key(), pair.get_E().copy(), pair.get_inlier_mask().copy())
     hyp, cnt = pair.get_best()
-    out = {"matches": n, "hypotheses_per_step": local, "ms_per_step": 1e3 * dt, "hypotheses_per_s": local / dt, "steps": steps,
+    out = {"matches": n, "hypotheses_per_step": local, "ms_per_step": 1e3 * dt, "serial_ms_per_step": 1e3 * dt_serial, "hypotheses_per_s": local / dt, "steps": steps,
            "kernel": KERNEL_NAMES.get(launch["kernel"], "?"), "score_kernel_ms": score_ms / max(calls, 1), "solve_kernel_ms": solve_ms / max(calls, 1),
            "best_hypothesis": hyp, "inliers": cnt}
     if launch["kernel"] == 4 and score_ms > 0:
         r = roofline_block(4, n, local, score_ms / 1e3 / calls, solve_ms / 1e3 / calls, pair.last_clock_mhz(), "20 serial launches")
+        out["roofline_frac_against_the_round4_floor"] = r["frac_against_the_round4_floor"]
         out["roofline_frac"] = r["frac"]
     pair.close()
     if O is not None:
@@ -643,6 +714,79 @@ def ctl_device(dev):
     return dev if dist_backend() == "nccl" else "cpu"
 
 
+def exchange_probe(S, torch, comm, ctx, pair, n, H, kernel, sweeps, seed, world, fence):
+    """100 x (8-byte all-reduce of the key + finalize) on the context stream, back to back: the part of a sharded call that does not
+    shrink with the shard."""
+    xp = S.default_params(n, num_hypotheses=H, kernel=kernel)
+    xp.jacobi_sweeps = sweeps
+    xp.seed = seed
+    comm.estimate_E(pair, xp)                             # a scored pair
+    for _ in range(10):
+        comm.exchange_only(pair, xp)
+    fence()
+    x0 = time.perf_counter()
+    for _ in range(100):
+        comm.exchange_only(pair, xp)
+    fence()
+    return {"calls": 100, "seconds": time.perf_counter() - x0, "ranks": world,
+            "what": "ncclAllReduce(max, u64) of the key + ransac_finalize_block, on the context stream, back to back (sfm_comm_exchange_only)"}
+
+
+def exchange_probe_main(args):
+    """`bench.py --exchange-probe`: the child process of a one-GPU run (see rank_main)."""
+    import numpy as np
+    import torch
+    import cuda_sfm_amd as S
+    from cuda_sfm_amd import synth
+    n = args.matches if args.matches is not None else CONFIGS[args.config][0]
+    H = args.hyps if args.hyps is not None else CONFIGS[args.config][1]
+    dev = torch.device("cuda", 0)
+    scene = synth.two_view_scene(n)
+    ctx = S.Context(0, torch.cuda.current_stream().cuda_stream)
+    pair = S.ImagePair(ctx, scene["K"], scene["Kinv"], 2, n)
+    pair.fillXU(torch.from_numpy(scene["sift"].view(np.uint8).reshape(n, 576)).to(dev))
+    comm = S.Comm(ctx, S.Comm.unique_id(), 0, 1)
+    out = exchange_probe(S, torch, comm, ctx, pair, n, H, args.kernel, max(args.sweeps, 0), 1, 1, torch.cuda.synchronize)
+    out["note"] = "one-rank communicator in a child process: a floor (no peer to wait for)"
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except OSError:
+        pass
+    print(json.dumps(out), flush=True)
+    comm.close()
+    return 0
+
+
+ASSUMED_EXCHANGE_US = 20.0      # a small-message RCCL all-reduce over xGMI + the finalize behind it, as SURVEY.md 8(e) budgets it (10-20 us)
+
+
+def projection(out, share, c4, c4_share):
+    """What ONE GPU can say about 8: this invocation's full-size step against one rank's 1/8 shard, in both step modes, with and
+    without the exchange (measured through a one-rank communicator -- a floor -- and at the assumed 20 us)."""
+    def ratios(full_ms, share_ms):
+        if not full_ms or not share_ms:
+            return None
+        x_meas = (out.get("exchange_us") or 0.0) / 1e3
+        return {"one_gpu_ms_per_step": full_ms, "one_of_8_ranks_ms_per_step": share_ms,
+                "excl_exchange": full_ms / share_ms,
+                "incl_exchange_as_measured_with_one_rank": full_ms / (share_ms + x_meas),
+                "incl_exchange_assumed_20us": full_ms / (share_ms + ASSUMED_EXCHANGE_US / 1e3)}
+    p = {"gpus": 8,
+         "pipelined": ratios(out["ms_per_step"] if out["config"]["step_mode"].startswith("two-slot") else None, share.get("ms_per_step")),
+         "serial": ratios(out.get("serial_ms_per_step"), share.get("serial_ms_per_step")),
+         "exchange_us_measured_one_rank": out.get("exchange_us"), "exchange_us_assumed": ASSUMED_EXCHANGE_US,
+         "configs3_16384_matches": {"pipelined": ratios(c4.get("ms_per_step"), c4_share.get("ms_per_step")),
+                                    "serial": ratios(c4.get("serial_ms_per_step"), c4_share.get("serial_ms_per_step"))},
+         "note": "pipelined: back-to-back calls, the exchange of step k overlaps step k + 1 (throughput); serial: ONE call at a time, the "
+                 "exchange on the critical path (latency).  In pipelined mode the exchange is hidden unless it exceeds the share's step.",
+         "status": "UNMEASURED ON HARDWARE: projections from one GPU running one rank's 1/8 shard in the same invocation; no cross-rank skew, "
+                   "no xGMI.  No multi-GPU node has run this code; the driver's SCALE run is the measurement."}
+    if p["pipelined"]:
+        p["projected_speedup"] = p["pipelined"]["excl_exchange"]          # (the field earlier rounds reported)
+    return p
+
+
 def rank_main(args):
     import numpy as np
     import torch
@@ -667,9 +811,11 @@ def rank_main(args):
         local %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    stage(f"libraries imported, device cuda:{local}")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         init_dist(dist, rank, world, dev)
+        stage(f"process group up ({dist_backend()})")
     cdev = ctl_device(dev)                                # where the few control-plane tensors of this script live
 
     n = args.matches if args.matches is not None else CONFIGS[args.config][0]
@@ -703,9 +849,12 @@ def rank_main(args):
         try:
             uid = [S.Comm.unique_id() if rank == 0 else None]
             dist.broadcast_object_list(uid, src=0)        # the out-of-band hand-over of the ncclUniqueId
+            stage("unique id received, ncclCommInitRank next")
             comm = S.Comm(ctx, uid[0], rank, world)
+            stage(f"communicator up (nccl_ranks {comm.nccl_ranks()})")
         except Exception as e:                            # noqa: BLE001 -- any failure means "use the other exchange"
             err = f"{type(e).__name__}: {e}"
+            stage(f"communicator FAILED: {err}")
         ok = torch.tensor([0 if err else 1], dtype=torch.int32, device=cdev)
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         if int(ok.item()) == 0:
@@ -715,14 +864,21 @@ def rank_main(args):
             mode = "torch"
             pipelined = False
 
-    def step():
-        if mode == "rccl":
+    # Every step scores NEW hypotheses: step k samples with seed0 + k (the same sequence on every rank), so a result cached from
+    # an earlier step could not pass for the current one; the parity check below re-runs and sweeps the LAST timed step's seed.
+    seed0 = int(params.seed)
+    nstep = [0]
+
+    def step(serial=False):
+        nstep[0] += 1
+        params.seed = (seed0 + nstep[0]) & 0xFFFFFFFF
+        if mode == "rccl" and not serial:
             comm.estimate_E_pipelined(pair, params)
-        elif mode == "rccl-serial":
+        elif mode in ("rccl", "rccl-serial"):
             comm.estimate_E(pair, params)
         elif mode == "torch":
             S.estimate_E_distributed(pair, params, rank, world, key_t, reduce_max)
-        elif pipelined:
+        elif pipelined and not serial:
             pair.estimateE_pipelined(params)              # two slots: consecutive steps overlap on the device
         else:
             pair.estimateE(params)
@@ -741,11 +897,15 @@ def rank_main(args):
     # steps of the contract
     est_step_s = (H / world) * n / 7e12 + 20e-6           # the same number on every rank: the steps contain a collective
     wake_steps = min(2000, max(20 - args.warmup, int(0.06 / est_step_s)))
-    for _ in range(max(0, wake_steps)):
+    for k in range(max(0, wake_steps)):
         step()
+        if k == 0:
+            fence()
+            stage("first step done")
     for _ in range(args.warmup):
         step()
     fence()
+    stage("warm-up done, timed region next")
     # Three hipEventRecord per call cost 3-4 us of a 0.1 ms step (a rank's share of a sharded run) and 0.5-1 % of the headline
     # step (profiles/r03_timed_events_ab.txt); with pipelined steps the kernels overlap inside the timed region anyway and are sampled by serial launches right
     # after it (below), so the events stay out of the timed region unless the steps are serial (or --timed-events on).
@@ -769,7 +929,9 @@ def rank_main(args):
         fence()
         region_s.append(time.perf_counter() - r0)
     timed_region_kernel_ms = (solve_ms / max(calls, 1), score_ms / max(calls, 1))
-    # what the timed steps left behind (every rank): winner, E, mask
+    stage("timed regions done")
+    # what the timed steps left behind (every rank): winner, E, mask -- of the LAST timed step, whose seed this is
+    last_seed = int(params.seed)
     hyp, cnt = pair.get_best()
     main_mask = pair.get_inlier_mask().copy()
     main_E = pair.get_E().copy()
@@ -792,13 +954,51 @@ def rank_main(args):
         solve_ms, score_ms, calls = ctx.kernel_timing_read()
         ctx.kernel_timing(False)
     clock_mhz = pair.last_clock_mhz()
+    # Two more regions, so that the line shows what ONE call at a time costs and what the exchange costs on its own:
+    #   serial      the same steps through the one-call-at-a-time entry point (the reference's contract: one estimateE per pair,
+    #               SfM/sfm.cu:94-153) -- unless the main region already was serial;
+    #   exchange    world > 1: the 8-byte all-reduce + the finalize behind it, alone, 100 times (what does not shrink with the shard);
+    #               world == 1: the same through a one-rank RCCL communicator (a floor: no peer to wait for).
+    other_mode = None
+    if pipelined and args.regions > 0:
+        ks = max(5, min(args.steps, 50))
+        for _ in range(3):
+            step(serial=True)
+        fence()
+        s0 = time.perf_counter()
+        for _ in range(ks):
+            step(serial=True)
+        fence()
+        other_mode = {"mode": "serial", "steps": ks, "seconds": time.perf_counter() - s0}
+    xprobe = None
+    try:
+        if comm is not None:
+            xprobe = exchange_probe(S, torch, comm, ctx, pair, n, H, args.kernel, params.jacobi_sweeps, last_seed, world, fence)
+        elif world == 1 and not any(args.reserved) and args.regions > 0:
+            # one rank: the same probe through a one-rank RCCL communicator, in a CHILD process -- the one-GPU line must not depend on
+            # RCCL coming up (3-4 s, and a library this process otherwise never loads)
+            stage("exchange probe (child process) next")
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--exchange-probe", "--matches", str(n), "--hyps", str(H), "--kernel", str(args.kernel),
+                                "--sweeps", str(params.jacobi_sweeps)], capture_output=True, text=True, timeout=180)
+            lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            xprobe = json.loads(lines[-1]) if (r.returncode == 0 and lines) else {"error": f"child exited {r.returncode}: {r.stderr[-300:]}"}
+            stage("exchange probe done")
+    except Exception as e:                                # noqa: BLE001 -- a diagnostic: never takes the line down
+        xprobe = {"error": f"{type(e).__name__}: {e}"}
+    params.seed = last_seed
     per_rank = [[solve_ms / max(calls, 1), score_ms / max(calls, 1), clock_mhz]]
     rc = 0
     agree = None
     if world > 1:
-        t = torch.tensor(region_s, dtype=torch.float64, device=ctl_device(dev))
+        extra_s = [other_mode["seconds"] if other_mode else 0.0, xprobe["seconds"] if (xprobe and "seconds" in xprobe) else 0.0]
+        t = torch.tensor(region_s + extra_s, dtype=torch.float64, device=ctl_device(dev))
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        region_s = [float(v) for v in t.cpu().numpy()]
+        allv = [float(v) for v in t.cpu().numpy()]
+        region_s = allv[:len(region_s)]
+        if other_mode:
+            other_mode["seconds"] = allv[-2]
+        if xprobe and "seconds" in xprobe:
+            xprobe["seconds"] = allv[-1]
         elapsed = region_s[0]
         gathered = [None] * world
         dist.all_gather_object(gathered, per_rank[0])
@@ -849,6 +1049,7 @@ def rank_main(args):
         variant = {"solver": "normal equations + 7 Jacobi sweeps" if params.jacobi_sweeps == 7 else "householder QR of the 8x9 system",
                    "value": H * 5 / vel, "ms_per_step": 1e3 * vel / 5, "best_hypothesis": vh, "inliers": vc}
         params.jacobi_sweeps = main_sweeps
+        params.seed = last_seed
 
     if rank == 0:
         local_hyps = S.shard_range(H, rank, world)[1]
@@ -878,6 +1079,9 @@ def rank_main(args):
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
             "ms_per_step_regions": regions_summary(region_s, args.steps),
+            "serial_ms_per_step": (1e3 * other_mode["seconds"] / other_mode["steps"]) if other_mode else (1e3 * elapsed / args.steps if not pipelined else None),
+            "exchange_us": (1e6 * xprobe["seconds"] / xprobe["calls"]) if (xprobe and "seconds" in xprobe) else None,
+            "exchange_probe": xprobe,
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
@@ -889,6 +1093,7 @@ def rank_main(args):
                        "preset": args.config if (args.matches is None and args.hyps is None) else "custom",
                        "preset_note": CONFIGS[args.config][2] if (args.matches is None and args.hyps is None) else None,
                        "matches": n, "hypotheses_per_step": H, "threshold": params.threshold,
+                       "sampler_seed": f"step k samples with seed {seed0} + k (every step scores new hypotheses); the parity check sweeps the last timed step's seed {last_seed}",
                        "jacobi_sweeps": params.jacobi_sweeps,
                        "solver": "householder QR of the 8x9 system" if params.jacobi_sweeps == 0 else f"normal equations + {params.jacobi_sweeps} Jacobi sweeps",
                        "kernel": dict(launch, name=kname), "step_mode": step_mode, "exchange": exchange,
@@ -897,8 +1102,9 @@ def rank_main(args):
                        "hip_events_inside_the_timed_region": bool(events_in_region),
                        "nccl_ranks": comm.nccl_ranks() if comm is not None else (world if mode == "torch" else 1),
                        "per_rank_kernel_ms": [{"rank": r, "solve": v[0], "score": v[1], "shader_clock_mhz": v[2]} for r, v in enumerate(per_rank)]},
-            "roofline": roofline_block(launch["kernel"], n, local_hyps, score_s, solve_s, clock_mhz, measured_in),
-            "result": {"best_hypothesis": hyp, "inliers": cnt, "mask_sum": mask_sum},
+            "roofline": roofline_block(launch["kernel"], n, local_hyps, score_s, solve_s, clock_mhz, measured_in,
+                                       rule="G" if (len(args.reserved) > 3 and (args.reserved[3] == 4 or args.reserved[3] >= 16)) else "band"),
+            "result": {"best_hypothesis": hyp, "inliers": cnt, "mask_sum": mask_sum, "sampler_seed_of_this_result": last_seed},
         }
         if agree is not None:
             out["result"]["multi_gpu"] = agree
@@ -913,7 +1119,8 @@ def rank_main(args):
             ok = full_parity(O, X0, X1, params, n, okey, ocounts, serial_result)
             out["result"]["parity_vs_oracle"] = ok
             out["result"]["parity_checked"] = (f"all {H} inlier counts, the arg-max key (first maximum), the winner's E bit for bit and the inlier mask "
-                                               "of one serial estimateE against the CPU oracle; the timed pipelined steps' E / mask / winner equal that call's")
+                                               f"of the LAST timed step's hypotheses (sampler seed {last_seed}) against the CPU oracle: the step's own "
+                                               "winner / E / mask as the timed region left them, and every count from one serial estimateE with that seed")
             if not ok:
                 rc = 1
         if world == 1 and not args.no_extra:
@@ -921,11 +1128,7 @@ def rank_main(args):
             out["extra"] = run_extras(S, synth, O, ctx, dev, torch, np, skip)
             share = out["extra"].get("headline_share_of_one_of_8_ranks", {})
             if args.config == "headline" and args.matches is None and args.hyps is None and share.get("ms_per_step"):
-                out["scaling_projection"] = {
-                    "gpus": 8, "one_gpu_ms_per_step": out["ms_per_step"], "one_of_8_ranks_ms_per_step": share["ms_per_step"],
-                    "projected_speedup": out["ms_per_step"] / share["ms_per_step"],
-                    "status": "UNMEASURED ON HARDWARE: a projection from one GPU running one rank's 1/8 shard in the same invocation; it excludes the "
-                              "8-byte all-reduce and any cross-rank skew.  No multi-GPU node has run this code; the driver's SCALE run is the measurement."}
+                out["scaling_projection"] = projection(out, share, out["extra"].get("c4_one_gpu", {}), out["extra"].get("c4_share_of_one_of_8_ranks", {}))
             bad = [k for k, v in out["extra"].items() if isinstance(v, dict) and (v.get("parity_vs_oracle") is False or "error" in v)]
             if bad:
                 print(f"bench.py: extra runs failed or lost parity: {bad}", file=sys.stderr)
@@ -973,19 +1176,18 @@ def c5_rank_main(args):
         local %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    stage(f"libraries imported, device cuda:{local}")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         init_dist(dist, rank, world, dev)
+        stage(f"process group up ({dist_backend()})")
     views_f = [read_pnm_grey(dino_frame(k)) for k in range(36)]
     views8 = [v.astype(np.uint8) for v in views_f]
     pairs = S.ring_pairs(36) if args.pairs == "ring" else [(i, j) for i in range(36) for j in range(i + 1, 36)]
     ctx = S.Context(local, torch.cuda.current_stream().cuda_stream)
     mode = "none" if world == 1 else ("torch" if args.comm == "torch" else "rccl")
     comm = None
-    if mode == "rccl":
-        uid = [S.Comm.unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
-        comm = S.Comm(ctx, uid[0], rank, world)
+    comm_note = None
     xstats = {}
 
     def gather_results(t):
@@ -993,13 +1195,52 @@ def c5_rank_main(args):
         dist.all_gather_into_tensor(out, t)
         return out
 
-    def step():
-        if comm is not None:
-            res, counts = comm.process_views(views_f, DINO_K, DINO_KINV, pairs=pairs, max_pts=8192, sift=DINO_SIFT)
-            xstats["feature_bytes"], xstats["slot_bytes"] = comm.last_exchange()
-            return res, counts
+    def torch_step():
         return S.process_views(ctx, views8, DINO_K, DINO_KINV, pairs=pairs, rank=rank, world=world, max_pts=8192, sift=DINO_SIFT,
                                dist=dist if world > 1 else None, gather_results=gather_results if world > 1 else None, device=dev, stats=xstats)
+
+    if mode == "rccl":
+        # The C path (sfm_process_views_sharded_u8: ~36 grouped ncclBroadcasts, two all-gathers, two status all-reduces) has only ever
+        # run with more than one rank over the shared-memory stand-in of tests/fake_ccl.  Should the communicator or the first,
+        # untimed job fail on ANY rank, every rank falls back to the torch.distributed harness (agreed through one collective) and
+        # the line says so; when both paths work, their records are compared once.
+        err = ""
+        first = None
+        try:
+            uid = [S.Comm.unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0)
+            stage("unique id received, ncclCommInitRank next")
+            comm = S.Comm(ctx, uid[0], rank, world)
+            stage(f"communicator up (nccl_ranks {comm.nccl_ranks()})")
+            first = comm.process_views(views8, DINO_K, DINO_KINV, pairs=pairs, max_pts=8192, sift=DINO_SIFT)
+            stage("first sharded job done (C path)")
+        except Exception as e:                            # noqa: BLE001 -- any failure means "use the other exchange"
+            err = f"{type(e).__name__}: {e}"
+            stage(f"C path FAILED: {err}")
+        ok = torch.tensor([0 if err else 1], dtype=torch.int32, device=ctl_device(dev))
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            comm_note = f"sfm_process_views_sharded unavailable on some rank ({err or 'another rank'}): torch.distributed harness instead"
+            print("bench.py: " + comm_note, file=sys.stderr)
+            if comm is not None:
+                try:
+                    comm.close()
+                except Exception:                         # noqa: BLE001
+                    pass
+            comm = None
+            mode = "torch"
+        else:
+            tres, tcounts = torch_step()                  # cross-check of the first real multi-rank run: same records from both paths
+            same = list(tcounts) == list(first[1]) and sorted(tres) == sorted(first[0]) and all(np.array_equal(tres[k].view(np.uint32), first[0][k].view(np.uint32)) for k in tres)
+            xstats["c_path_equals_torch_path"] = bool(same)
+            stage(f"C path against the torch harness: {'identical records' if same else 'RECORDS DIFFER'}")
+
+    def step():
+        if comm is not None:
+            res, counts = comm.process_views(views8, DINO_K, DINO_KINV, pairs=pairs, max_pts=8192, sift=DINO_SIFT)
+            xstats["feature_bytes"], xstats["slot_bytes"] = comm.last_exchange()
+            return res, counts
+        return torch_step()
 
     def fence():
         if world > 1:
@@ -1009,9 +1250,12 @@ def c5_rank_main(args):
     # untimed: the HIP runtime grows an internal pool once, ~15000 launches into a process (a 40 ms step near call 25 of this job,
     # profiles/c5_step_probe.py): enough untimed steps to be past it whatever --warmup says, then the W warm-up steps of the contract
     wake_steps = max(0, 40 - args.warmup)
-    for _ in range(wake_steps + max(args.warmup, 2)):
+    for k in range(wake_steps + max(args.warmup, 2)):
         res, counts = step()
+        if k == 0:
+            stage("first step done")
     fence()
+    stage("warm-up done, timed regions next")
     steps = args.steps
     region_s = []
     for _ in range(max(1, args.regions)):
@@ -1020,7 +1264,11 @@ def c5_rank_main(args):
             res, counts = step()
         fence()
         region_s.append(time.perf_counter() - t0)
+    stage("timed regions done")
     rc = 0
+    if xstats.get("c_path_equals_torch_path") is False:
+        print("bench.py: sfm_process_views_sharded and the torch.distributed harness returned different records", file=sys.stderr)
+        rc = 1
     rec = np.stack([res[k] if k in res else np.full(28, -1.0, np.float32) for k in range(len(pairs))])
     agree = None
     if world > 1:
@@ -1047,8 +1295,11 @@ def c5_rank_main(args):
                "config": {"workload": f"36 views 720 x 576, {len(pairs)} view pairs ({args.pairs}), H = n/8 hypotheses per pair (the reference's own count), views and pairs dealt round-robin over {world} GPU(s)",
                           "preset": "c5", "preset_note": CONFIGS["c5"][2], "features_per_view": [int(min(counts)), int(max(counts))],
                           "path": {"none": "one rank: sfm_extract_views_u8 + sfm_process_pairs (no exchange)",
-                                   "rccl": "sfm_process_views_sharded (libsfm_amd_rccl.so): counts all-gather, count-sized grouped ncclBroadcast of the features, records all-gather; float host images",
-                                   "torch": "Python harness over torch.distributed (RCCL): counts all_gather, per-view broadcast, records all_gather; 8-bit host images"}[mode],
+                                   "rccl": "sfm_process_views_sharded_u8 (libsfm_amd_rccl.so): counts all-gather, count-sized grouped ncclBroadcast of the features, records all-gather",
+                                   "torch": "Python harness over torch.distributed (RCCL): counts all_gather, per-view broadcast, records all_gather"}[mode]
+                                  + (" -- " + comm_note if comm_note else ""),
+                          "host_image_format": "8-bit grey (what cv::imread(path, 0) delivers, src/main.cpp:249), the same on every path and rank count",
+                          "c_path_equals_torch_path": xstats.get("c_path_equals_torch_path"),
                           "nccl_ranks": comm.nccl_ranks() if comm is not None else (world if mode == "torch" else 1)},
                "exchange": {"feature_bytes_into_each_rank": xstats.get("feature_bytes", 0), "sum_count_x_576": real,
                             "over_real_bytes": (xstats.get("feature_bytes", 0) / real) if (real and world > 1) else None,
@@ -1098,6 +1349,8 @@ def main():
     args = parse_args(argv)
     if args.gpus > 1 and "RANK" not in os.environ:
         return launcher_main(args, argv)
+    if args.exchange_probe:
+        return exchange_probe_main(args)
     if args.config == "c5":
         if "--steps" not in " ".join(argv):
             args.steps = 10

@@ -343,6 +343,8 @@ class Context:
                "sfm_ransac_permutation_indices")
 
     def close(self):
+        self._views_block = None                          # process_views' slot block and feature buffer (170 MB at 36 views of 8192 records)
+        self._views_feats = None
         if getattr(self, "_h", None):
             _lib.sfm_ctx_destroy(self._h)
             self._h = None
@@ -551,7 +553,8 @@ def estimate_E_distributed(pair, params, rank, world, key_tensor, all_reduce_max
 
 # ---- RCCL exchange step in C (include/sfm_amd_comm.h, libsfm_amd_rccl.so) ----------------------------
 COMM_EXPORTS = ["sfm_comm_unique_id", "sfm_comm_init", "sfm_comm_destroy", "sfm_comm_rank", "sfm_comm_nccl_ranks", "sfm_estimate_E_sharded",
-                "sfm_estimate_E_sharded_pipelined", "sfm_comm_flush", "sfm_process_views_sharded", "sfm_comm_last_exchange"]
+                "sfm_estimate_E_sharded_pipelined", "sfm_comm_flush", "sfm_process_views_sharded", "sfm_process_views_sharded_u8", "sfm_comm_last_exchange",
+                "sfm_comm_exchange_only"]
 # (SFM_AMD_COMM_LIB: tests only -- tests/fake_ccl/libsfm_amd_fakeccl.so is the same comm.cpp linked against a shared-memory stand-in for
 #  RCCL, so that two ranks can run on the ONE GPU of a test box: tests/test_gpu_fakeccl.py)
 COMM_LIB_PATH = os.environ.get("SFM_AMD_COMM_LIB") or os.path.join(os.path.dirname(LIB_PATH), "libsfm_amd_rccl.so")
@@ -580,6 +583,10 @@ def comm_lib():
         L.sfm_process_views_sharded.argtypes = [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.POINTER(C.c_float)), C.c_int, C.c_int, C.c_int,
                                                 C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.c_double, C.c_float, C.c_float, C.c_int, C.c_uint32,
                                                 C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int)]
+        L.sfm_process_views_sharded_u8.argtypes = [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.POINTER(C.c_ubyte)), C.c_int, C.c_int, C.c_int,
+                                                   C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.c_double, C.c_float, C.c_float, C.c_int, C.c_uint32,
+                                                   C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int)]
+        L.sfm_comm_exchange_only.argtypes = [_vp, C.POINTER(RansacParams), _vp]
         _comm_lib = L
     return _comm_lib
 
@@ -612,6 +619,10 @@ class Comm:
         overlaps this call's all-reduce; flush() before reading results."""
         _check(comm_lib().sfm_estimate_E_sharded_pipelined(pair._h, C.byref(params), self._h), "sfm_estimate_E_sharded_pipelined")
 
+    def exchange_only(self, pair, params):
+        """The exchange step alone (all-reduce of the pair's current key + finalize): diagnostics, bench.py's exchange_us."""
+        _check(comm_lib().sfm_comm_exchange_only(pair._h, C.byref(params), self._h), "sfm_comm_exchange_only")
+
     def flush(self):
         _check(comm_lib().sfm_comm_flush(self._h), "sfm_comm_flush")
 
@@ -622,18 +633,21 @@ class Comm:
         sift = dict(sift or {})
         V = len(images)
         pairs = ring_pairs(V) if pairs is None else list(pairs)
-        imgs = [np.ascontiguousarray(im, np.float32) for im in images]
+        u8 = all(getattr(im, "dtype", None) == np.uint8 for im in images)           # 8-bit grey images go through sfm_process_views_sharded_u8
+        imgs = [np.ascontiguousarray(im, np.uint8 if u8 else np.float32) for im in images]
         h, w = imgs[0].shape
-        ptrs = (C.POINTER(C.c_float) * V)(*[im.ctypes.data_as(C.POINTER(C.c_float)) for im in imgs])
+        ctype = C.c_ubyte if u8 else C.c_float
+        ptrs = (C.POINTER(ctype) * V)(*[im.ctypes.data_as(C.POINTER(ctype)) for im in imgs])
+        entry = comm_lib().sfm_process_views_sharded_u8 if u8 else comm_lib().sfm_process_views_sharded
         pij = np.ascontiguousarray(np.array(pairs, np.int32).reshape(-1))
         rec = np.empty((max(len(pairs), 1), 28), np.float32)
         counts = (C.c_int * V)()
         k = np.ascontiguousarray(K, np.float32).reshape(9); ki = np.ascontiguousarray(Kinv, np.float32).reshape(9)
-        _check(comm_lib().sfm_process_views_sharded(self._h, k.ctypes.data_as(C.POINTER(C.c_float)), ki.ctypes.data_as(C.POINTER(C.c_float)), ptrs, V, w, h,
-                                                    pij.ctypes.data_as(C.POINTER(C.c_int)), len(pairs), int(max_pts), int(sift.get("num_octaves", 5)),
-                                                    float(sift.get("init_blur", 1.0)), float(sift.get("thresh", 3.0)), float(sift.get("lowest_scale", 0.0)),
-                                                    int(bool(sift.get("scale_up", False))), int(num_hypotheses or 0), int(pose_mode),
-                                                    rec.ctypes.data_as(C.POINTER(C.c_float)), counts), "sfm_process_views_sharded")
+        _check(entry(self._h, k.ctypes.data_as(C.POINTER(C.c_float)), ki.ctypes.data_as(C.POINTER(C.c_float)), ptrs, V, w, h,
+                     pij.ctypes.data_as(C.POINTER(C.c_int)), len(pairs), int(max_pts), int(sift.get("num_octaves", 5)),
+                     C.c_double(float(sift.get("init_blur", 1.0))), C.c_float(float(sift.get("thresh", 3.0))), C.c_float(float(sift.get("lowest_scale", 0.0))),
+                     int(bool(sift.get("scale_up", False))), int(num_hypotheses or 0), int(pose_mode),
+                     rec.ctypes.data_as(C.POINTER(C.c_float)), counts), "sfm_process_views_sharded")
         return {pid: rec[pid].copy() for pid in range(len(pairs)) if rec[pid][26] >= 0}, list(counts)
 
     def last_exchange(self):
@@ -751,7 +765,7 @@ def view_slot(v, world, slots):
     return (int(v) % int(world)) * int(slots) + int(v) // int(world)
 
 
-def exchange_view_features(block, num_views, rank, world, max_pts, dist=None):
+def exchange_view_features(block, num_views, rank, world, max_pts, dist=None, cache=None):
     """The feature exchange of the many-views front end, sized by what exists.  block: this rank's uint8 tensor
     [slots, max_pts * 576 + 64] (slot s = view rank + s * world: its SiftPoint records, then its int32 feature count in the tail).
     dist: torch.distributed (RCCL on the GPUs, gloo in the CPU tests) or None for a single rank.
@@ -779,7 +793,14 @@ def exchange_view_features(block, num_views, rank, world, max_pts, dist=None):
     for n in counts:
         offsets.append(total)
         total += n * 576
-    feats = torch.empty(max(total, 1), dtype=torch.uint8, device=block.device)
+    # the compact buffer is kept on `cache` (an object with a _views_feats attribute: the Context) and grown on demand, as comm.cpp
+    # does with its d_feats: a fresh 37 MB allocation per call of a 5 ms job shows up as occasional slow steps
+    buf = getattr(cache, "_views_feats", None) if cache is not None else None
+    if buf is None or buf.numel() < max(total, 1) or buf.device != block.device:
+        buf = torch.empty(max(total, 1) + ((max(total, 1) >> 3) if cache is not None else 0), dtype=torch.uint8, device=block.device)
+        if cache is not None:
+            cache._views_feats = buf
+    feats = buf[:max(total, 1)]
     work = []
     for v in range(num_views):
         nb = counts[v] * 576
@@ -819,11 +840,13 @@ def process_views(ctx, images, K, Kinv, pairs=None, rank=0, world=1, max_pts=819
     # the count itself), so only a multi-rank run -- whose last slots may stay unused -- pays for clearing 4.7 MB per view
     # (kept on the context between calls: 36 slots of 8192 records are 170 MB, and a fresh allocation per call shows up as
     # occasional 10-40 ms steps of a 5 ms job)
+    # Re-used when it is at least as large as this call needs (alternating view counts / max_pts do not re-allocate); Context.close() drops it.
+    need = slots * (rec_bytes + 64)
     cache = getattr(ctx, "_views_block", None)
-    if cache is None or cache.shape != (slots, rec_bytes + 64) or cache.device != dev:
-        cache = torch.zeros((slots, rec_bytes + 64), dtype=torch.uint8, device=dev)
+    if cache is None or cache.numel() < need or cache.device != dev:
+        cache = torch.zeros(need, dtype=torch.uint8, device=dev)
         ctx._views_block = cache
-    block = cache
+    block = cache[:need].view(slots, rec_bytes + 64)
     if world > 1:
         block[:, rec_bytes:].zero_()                      # the counts of slots this rank does not fill must read 0
     # ExtractSift for this rank's views inside the C library (sfm_extract_views: pinned staging, two streams)
@@ -841,7 +864,7 @@ def process_views(ctx, images, K, Kinv, pairs=None, rank=0, world=1, max_pts=819
                   int(sift.get("num_octaves", 5)), float(sift.get("init_blur", 1.0)), float(sift.get("thresh", 3.0)),
                   float(sift.get("lowest_scale", 0.0)), int(bool(sift.get("scale_up", False))), cnts), "sfm_extract_views")
     # the counts of all views (one small all-gather + read-back), then every view's own bytes from its owner
-    feats, counts, offsets, xstats = exchange_view_features(block, V, rank, world, max_pts, dist)
+    feats, counts, offsets, xstats = exchange_view_features(block, V, rank, world, max_pts, dist, cache=ctx)
     if stats is not None:
         stats.update(xstats)
 

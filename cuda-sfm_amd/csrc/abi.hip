@@ -413,7 +413,7 @@ int sfm_pair_create(sfm_ctx *ctx, const float h_K[9], const float h_Kinv[9], int
     A(&p->d_E, 9); A(&p->d_P, 64); A(&p->d_Pinv, 64); A(&p->d_Pind, 8);
     A(&p->d_points, (size_t)4 * num_points);
     A(&p->d_mask, (size_t)num_points);
-    A(&p->d_key, 2); A(&p->d_best, 2); A(&p->d_clk, kClkWords); A(&p->d_bound, 10);      // [0] bound, [2..9] the coordinate boxes (fill_xu_kernel)
+    A(&p->d_key, 2); A(&p->d_best, 2); A(&p->d_clk, kClkWords); A(&p->d_bound, 10);      // [0] bound (fill_xu_kernel), [2..9] the coordinate boxes (pf_cells_build_kernel)
     if (rc != SFM_OK) { sfm_pair_destroy(p); return rc; }
     hipError_t e = hipMemcpyAsync(p->d_K, h_K, 9 * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(p->d_Kinv, h_Kinv, 9 * sizeof(float), hipMemcpyHostToDevice, ctx->stream);

@@ -140,7 +140,7 @@ struct sfm_pair {
     float *d_Ecand = nullptr;
     void *d_pf = nullptr;              // pre-filter kernel: one PfRecord (64 bytes, prefilter_record.hpp) per hypothesis of the shard
     unsigned long long *d_bound = nullptr; // (fillXU epoch << 32) | bits of the largest |coordinate| <= 48 over all points: atomicMax, never reset;
-                                           // words 2..9: the same for the coordinate ranges of the two views (prefilter_math.hpp: pf_box_from_words)
+                                           // words 2..9: the same for the coordinate ranges of the two views (pf_cells_build_kernel; prefilter_math.hpp: pf_box_from_words)
     uint32_t bound_epoch = 0;
     bool have_bound = false;           // d_bound describes the current points (fillXU)
     uint32_t *d_cells = nullptr;       // pre-filter: open-addressing table of the occupied zero-divisor grid cells of ALL points (launch_pf_cells)

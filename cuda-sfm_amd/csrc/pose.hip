@@ -8,7 +8,6 @@
 // kernels is to remove ~40 mallocs/frees, 3 device syncs and the host round trips per pair.
 #include "common.hpp"
 #include "device_math.hpp"
-#include "prefilter_math.hpp"
 #include "pairs_batch.hpp"
 
 namespace sfm {
@@ -49,29 +48,13 @@ void fill_xu_kernel(const sfm_sift_point *__restrict__ data, int n, int ld, cons
     }
     pts4[j] = make_float4(x0[0], x0[1], x1[0], x1[1]);        // the sampler's view of a correspondence: one 16-byte gather (ransac.hip)
     float big = 0.0f;
-    bool feat = false;                                        // the point carries pre-filter features (prefilter_point_slots' own test)
     if (j < n) {
         big = fmaxf(fmaxf(fabsf(x0[0]), fabsf(x0[1])), fmaxf(fabsf(x1[0]), fabsf(x1[1])));
-        feat = big <= 48.0f && x0[0] == x0[0] && x0[1] == x0[1] && x1[0] == x1[0] && x1[1] == x1[1];
         if (!(big <= 48.0f)) big = 0.0f;                      // beyond the fp16 feature range (or NaN): the point carries no features
     }
-    // Coordinate ranges of the points that carry features, per view and axis (the band rule of the pre-filter bounds both
-    // divisors over these boxes, prefilter_math.hpp): bound[2 + k] = (epoch << 32) | ordered bits of (x2x, -x2x, x2y, -x2y, x1x,
-    // -x1x, x1y, -x1y) maxima.  A wavefront without such a point contributes -inf (the smallest key of its epoch).
-    float ext[8];
-    ext[0] = feat ? x1[0] : -INFINITY; ext[1] = feat ? -x1[0] : -INFINITY; ext[2] = feat ? x1[1] : -INFINITY; ext[3] = feat ? -x1[1] : -INFINITY;
-    ext[4] = feat ? x0[0] : -INFINITY; ext[5] = feat ? -x0[0] : -INFINITY; ext[6] = feat ? x0[1] : -INFINITY; ext[7] = feat ? -x0[1] : -INFINITY;
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        big = fmaxf(big, __shfl_xor(big, off));
-#pragma unroll
-        for (int k = 0; k < 8; ++k) ext[k] = fmaxf(ext[k], __shfl_xor(ext[k], off));
-    }
-    if ((threadIdx.x & 63) == 0) {
-        atomicMax(bound, ((unsigned long long)epoch << 32) | __float_as_uint(big));
-#pragma unroll
-        for (int k = 0; k < 8; ++k) atomicMax(bound + 2 + k, ((unsigned long long)epoch << 32) | pf_order_bits(ext[k]));
-    }
+    for (int off = 32; off > 0; off >>= 1) big = fmaxf(big, __shfl_xor(big, off));
+    if ((threadIdx.x & 63) == 0) atomicMax(bound, ((unsigned long long)epoch << 32) | __float_as_uint(big));
 }
 
 __global__ __launch_bounds__(256)

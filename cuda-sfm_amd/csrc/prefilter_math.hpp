@@ -336,7 +336,7 @@ SFM_HD float pf_order_float(uint32_t k)
     return c.f;
 }
 
-// The pair's boxes from the eight words fill_xu_kernel leaves behind the bound (low halves: ordered bits of the maxima of
+// The pair's boxes from the eight words pf_cells_build_kernel leaves behind the bound (low halves: ordered bits of the maxima of
 // x, -x, y, -y of the second view, then u, -u, v, -v of the first); a side without any point falls back to [-B, B].
 SFM_HD PfBox pf_box_from_words(const unsigned long long *w, float B)
 {

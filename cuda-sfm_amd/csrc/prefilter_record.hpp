@@ -108,7 +108,7 @@ __device__ __forceinline__ void pf_record_expand(const uint4 r0, const uint4 r1,
 }
 // ---- band rule (prefilter_math.hpp, round 5): the same 64-byte record with the threshold contraction's slots unused ------------
 //   lo[16]: h0 m0 | h1 m1 | h2 h5 | m5 h6 | m6 h7 | m7 0 | 0 0 | 0 0         hi[16]: m2 h3 | m3 h4 | m4 h5 | e8h e8m | e8l FLAG | 0 ...
-// box: the coordinate ranges of the pair's points (fill_xu_kernel); cells: the pair's table of occupied cells, BOTH views (the
+// box: the coordinate ranges of the pair's points (pf_cells_build_kernel); cells: the pair's table of occupied cells, BOTH views (the
 // first view's keys flipped, pf_cell_key_side).  FLAG as above (first divisor); a possible zero of the SECOND divisor only selects
 // the weaker constant of the rule.
 __device__ __forceinline__ bool pf_cells_occupied(const uint32_t *__restrict__ cells, uint32_t cells_mask, int cx0, int cx1, int cy0, int cy1, int side)

@@ -507,15 +507,33 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
 // One key per point that carries features (finite, |coordinates| <= 48): the cell of its second-view position on the grid
 // whose pitch follows the bound over all points.  Built once per fillXU (the first scoring launch that needs it), looked up
 // once per hypothesis by pf_prep_store -- not once per (hypothesis, tile) out of a table in LDS as in round 2.
+// The same pass leaves the coordinate ranges of the points that carry features, per view and axis, behind the bound (the band rule
+// bounds both divisors over these boxes, prefilter_math.hpp: pf_box_from_words): bound[2 + k] = (epoch << 32) | ordered bits of the
+// maxima of (x2x, -x2x, x2y, -x2y, x1x, -x1x, x1y, -x1y), atomicMax like the bound itself (a newer epoch beats every older word).
 __global__ __launch_bounds__(256)
-void pf_cells_build_kernel(const float4 *__restrict__ pts4, int n, const unsigned long long *__restrict__ bound_word,
-                           uint32_t *__restrict__ cells, uint32_t mask)
+void pf_cells_build_kernel(const float4 *__restrict__ pts4, int n, unsigned long long *__restrict__ bound_word,
+                           uint32_t *__restrict__ cells, uint32_t mask, uint32_t epoch)
 {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n) return;
-    const float4 q = pts4[j];                               // (x1x, x1y, x2x, x2y)
-    const float big = fmaxf(fmaxf(fabsf(q.x), fabsf(q.y)), fmaxf(fabsf(q.z), fabsf(q.w)));
-    if (!(big <= 48.0f) || q.x != q.x || q.y != q.y || q.z != q.z || q.w != q.w) return;
+    float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+    bool feat = false;
+    if (j < n) {
+        q = pts4[j];                                        // (x1x, x1y, x2x, x2y)
+        const float big = fmaxf(fmaxf(fabsf(q.x), fabsf(q.y)), fmaxf(fabsf(q.z), fabsf(q.w)));
+        feat = big <= 48.0f && q.x == q.x && q.y == q.y && q.z == q.z && q.w == q.w;       // prefilter_point_slots' own test
+    }
+    float ext[8] = { q.z, -q.z, q.w, -q.w, q.x, -q.x, q.y, -q.y };
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        if (!feat) ext[k] = -INFINITY;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) ext[k] = fmaxf(ext[k], __shfl_xor(ext[k], off));
+    }
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) atomicMax(bound_word + 2 + k, ((unsigned long long)epoch << 32) | pf_order_bits(ext[k]));
+    }
+    if (!feat) return;
     const PfGrid grid = prefilter_grid(__uint_as_float((uint32_t)(*bound_word & 0xFFFFFFFFull)));
     // second-view cell (first divisor) and first-view cell (second divisor, keys flipped: pf_cell_key_side) in one table
 #pragma unroll
@@ -550,7 +568,7 @@ int launch_pf_cells(sfm_pair *pair)
     pair->cells_mask = slots - 1u;
     SFM_HIP_TRY(hipMemsetAsync(pair->d_cells, 0, (size_t)slots * sizeof(uint32_t), st));
     hipLaunchKernelGGL(pf_cells_build_kernel, dim3((pair->n + 255) / 256), dim3(256), 0, st, pair->d_pts4, pair->n, pair->d_bound,
-                       pair->d_cells, pair->cells_mask);
+                       pair->d_cells, pair->cells_mask, pair->bound_epoch);
     SFM_HIP_TRY(hipGetLastError());
     if (!pair->cells_ev) SFM_HIP_TRY(hipEventCreateWithFlags(&pair->cells_ev, hipEventDisableTiming));
     SFM_HIP_TRY(hipEventRecord(pair->cells_ev, st));

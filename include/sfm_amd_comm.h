@@ -35,6 +35,11 @@ int sfm_comm_nccl_ranks(const sfm_comm *comm, int *nccl_ranks);      /* ncclComm
  * Asynchronous (context stream) like sfm_estimate_E; every rank must call it with the same arguments. */
 int sfm_estimate_E_sharded(sfm_pair *pair, sfm_ransac_params *p, sfm_comm *comm);
 
+/* The exchange step of sfm_estimate_E_sharded alone: ncclAllReduce(max, u64) of the pair's current key + the finalize behind it on
+ * the context stream (diagnostics: the part of a sharded call that does not shrink with the shard; bench.py's `exchange_us`).
+ * Needs a scored pair (sfm_ransac_score / sfm_estimate_E_sharded before it).  Asynchronous. */
+int sfm_comm_exchange_only(sfm_pair *pair, sfm_ransac_params *p, sfm_comm *comm);
+
 /* The same step software-pipelined over consecutive calls (a stream of pairs, or bench.py's repeated steps): the shard is
  * scored on the context stream, the all-reduce and the finalize run on the communicator's own exchange stream behind an
  * event, so the NEXT call's scoring overlaps this call's 8-byte exchange.  Two key slots; the finalize re-derives the
@@ -51,11 +56,20 @@ int sfm_comm_flush(sfm_comm *comm);
  * it (pairs r, r + G, ... of the list; sfm_process_pairs) -> ONE ncclAllGather of fixed-size result records.
  * h_images: num_views host images (width x height floats, grey 0..255); h_pairs: num_pairs x 2 view indices;
  * h_records: num_pairs x 28 floats on EVERY rank (layout of sfm_get_result; all -1 for a pair with too few features);
- * h_counts (optional): features per view.  Synchronous; every rank calls it with the same arguments. */
+ * h_counts (optional): features per view.  Synchronous; every rank calls it with the same arguments.
+ * A failure on one rank (a device allocation, ExtractSift, sfm_process_pairs) is published through the next collective -- two 8-byte
+ * all-reduces of a status word sit in front of the large ones for that -- and comes back as an error on EVERY rank: no rank is
+ * left waiting in a collective. */
 int sfm_process_views_sharded(sfm_comm *comm, const float h_K[9], const float h_Kinv[9], const float *const *h_images, int num_views,
                               int width, int height, const int *h_pairs, int num_pairs, int max_pts, int num_octaves,
                               double init_blur, float thresh, float lowest_scale, int scale_up, uint32_t num_hypotheses,
                               int pose_mode, float *h_records, int *h_counts);
+
+/* The same job from 8-bit grey host images (sfm_extract_views_u8: a quarter of the bytes cross PCIe, same features bit for bit). */
+int sfm_process_views_sharded_u8(sfm_comm *comm, const float h_K[9], const float h_Kinv[9], const unsigned char *const *h_images, int num_views,
+                                 int width, int height, const int *h_pairs, int num_pairs, int max_pts, int num_octaves,
+                                 double init_blur, float thresh, float lowest_scale, int scale_up, uint32_t num_hypotheses,
+                                 int pose_mode, float *h_records, int *h_counts);
 
 /* What the feature exchange of the last sfm_process_views_sharded call moved INTO every rank: *feature_bytes = sum of count x 576
  * over all views + the gathered counts; *slot_bytes (optional) = what an all-gather of max_pts-sized slots would have moved

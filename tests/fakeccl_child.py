@@ -143,6 +143,24 @@ for rep in range(2):                                            # twice: the sec
     ok = ok and sum(counts) * 576 <= moved <= 1.1 * sum(counts) * 576 + 4096 and min(counts) == 0
     stage("views_sharded_done", rep=rep, pairs=len(vres), counts=counts, exchange_bytes=moved, slot_bytes_equivalent=slots_eq, ok=bool(ok))
 
+# A failure on ONE rank (its slot allocation, ExtractSift, the feature buffer, sfm_process_pairs: comm.cpp's fault injection) must
+# come back as an error on EVERY rank -- nobody may be left waiting in the next collective (each stage is reached by all ranks within
+# the harness' time-out or the test fails) -- and the communicator must still work afterwards.
+for fstage in (1, 2, 3, 4):
+    os.environ["SFM_COMM_TEST_FAIL"] = f"{world - 1}:{fstage}"
+    raised = False
+    try:
+        comm.process_views(views, K, Kinv, pairs=pairs, max_pts=4096, sift=sift)
+    except S.SfmError:
+        raised = True
+    ok = ok and raised
+    stage("injected_failure", stage=fstage, failing_rank=world - 1, this_rank_got_an_error=bool(raised))
+os.environ.pop("SFM_COMM_TEST_FAIL", None)
+vres, counts = comm.process_views(views, K, Kinv, pairs=pairs, max_pts=4096, sift=sift)
+good = counts == vcounts and all(np.array_equal(vres[k].view(np.uint32), vref[k].view(np.uint32)) for k in vref)
+ok = ok and good
+stage("views_sharded_after_failures", ok=bool(good))
+
 t = torch.tensor([1 if ok else 0], dtype=torch.int64)
 dist.all_reduce(t, op=dist.ReduceOp.MIN)
 everyone = [None] * world

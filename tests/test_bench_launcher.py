@@ -30,6 +30,20 @@ def test_launcher_fails_when_a_rank_fails():
     assert "rank 1 exited with code 3" in r.stderr
 
 
+def test_launcher_timeout_reports_every_ranks_last_stage():
+    """A rank that hangs with the communicator half up (the first real multi-GPU run could): after the launcher's time-out the
+    last stage line of EVERY rank is on stderr, the children are gone and the exit code is 124 -- in well under 30 s here."""
+    import time
+    t0 = time.time()
+    r = run_launcher("import sys, bench; sys.exit(bench.launch_ranks(2, [], command=[sys.executable, %r, 'hang'], timeout=6))" % CHILD)
+    assert time.time() - t0 < 30
+    assert r.returncode == 124, (r.returncode, r.stderr)
+    assert "time-out after 6 s; last stage of every rank" in r.stderr
+    assert "rank 0 (running): [bench rank 0/2" in r.stderr and "stage first step done" in r.stderr
+    assert "rank 1 (running): [bench rank 1/2" in r.stderr and "stage communicator up (nccl_ranks pending)" in r.stderr
+    assert r.stdout.strip() == ""
+
+
 def test_gpus_2_without_two_gpus_exits_nonzero_with_a_message():
     """This container has no GPU (and a 1-GPU box has one): the bare command must refuse, not assert or hang."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}

@@ -36,7 +36,8 @@ def test_ranks_on_one_gpu_through_comm_cpp(world):
     rec = json.loads([ln for ln in outs[0][0].splitlines() if ln.startswith("{")][-1])
     assert rec["ok"] and rec["world"] == world and rec["ranks"] == world
     for stages in rec["per_rank"]:
-        for name in ("communicator_up", "shard_scored", "sharded_step_done", "pipelined_steps_done", "other_scene", "views_sharded_done"):
+        for name in ("communicator_up", "shard_scored", "sharded_step_done", "pipelined_steps_done", "other_scene", "views_sharded_done",
+                     "injected_failure", "views_sharded_after_failures"):
             assert name in stages, name
 
 
@@ -85,8 +86,10 @@ def test_bench_multi_rank_flow_on_one_gpu(mode):
     scene = synth.two_view_scene(4096)
     pair = S.ImagePair(ctx, scene["K"], scene["Kinv"], 2, 4096)
     pair.fillXU(torch.from_numpy(scene["sift"].view(np.uint8).reshape(4096, 576)).to(dev))
-    pair.estimateE(S.default_params(4096, num_hypotheses=65536))
+    # (every timed step samples with its own seed: the line names the seed of the step whose result it reports)
+    pair.estimateE(S.default_params(4096, num_hypotheses=65536, seed=rec["result"]["sampler_seed_of_this_result"]))
     assert list(pair.get_best()) == [rec["result"]["best_hypothesis"], rec["result"]["inliers"]]
+    assert rec["serial_ms_per_step"] > 0 and (mode != [] or rec["exchange_us"] > 0)
 
 
 def test_bench_c5_two_ranks_on_one_gpu():
