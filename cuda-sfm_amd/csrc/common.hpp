@@ -188,7 +188,6 @@ int prefilter_rule(const sfm_ransac_params &p);                                 
 int launch_score_prefilter(sfm_pair *pair, const sfm_ransac_params &p, uint32_t h0, uint32_t count, unsigned long long *key2);
 int launch_pf_prep(sfm_pair *pair, const sfm_ransac_params &p, uint32_t count);
 int launch_pf_cells(sfm_pair *pair);                                            // the pair's cell table, (re)built when the points changed        // PfRecords from d_Ecand (paths whose solve kernel does not write them)
-int prefilter_tiles(const sfm_pair *pair);
 #if SFM_AB
 // ab/ransac_prefilter_r2.hip (the round-2 kernel: sfm_ransac_params.reserved[3] == 2)
 int launch_score_prefilter_r2(sfm_pair *pair, const sfm_ransac_params &p, uint32_t h0, uint32_t count, unsigned long long *key2);

@@ -22,6 +22,14 @@
 
 #define SFM_HD __host__ __device__ __forceinline__
 
+// Census builds (profiles/isa_census.py: -DSFM_CENSUS, assembly only, never linked): a scheduling barrier and a comment in the
+// instruction stream at every phase boundary, so that the instructions of a kernel can be counted per phase.
+#if defined(SFM_CENSUS) && defined(__HIP_DEVICE_COMPILE__)
+#define SFM_PHASE(name) do { __builtin_amdgcn_sched_barrier(0); asm volatile("; ##PHASE " name ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define SFM_PHASE(name) do { } while (0)
+#endif
+
 namespace sfm {
 
 // ------------------------------------------------------------------------------------------

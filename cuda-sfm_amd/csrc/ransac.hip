@@ -73,8 +73,10 @@ void ransac_solve_lanes1_qr(const float *__restrict__ X0, const float *__restric
     if (zero_ticks) for (uint32_t w = i; w < nzero; w += gridDim.x * blockDim.x) zero_ticks[w] = 0u;
     if (i >= count) return;
     if (zero_counts) zero_counts[i] = 0;
+    SFM_PHASE("sampler");
     int idx[8];
     load_tuple(indices, seed, h0 + i, n, idx);
+    SFM_PHASE("gather");
     float x1[8][3], x2[8][3];
     if (pts4) {                                             // unit-z points as 16-byte records: 8 gathers instead of 48
 #pragma unroll
@@ -93,10 +95,14 @@ void ransac_solve_lanes1_qr(const float *__restrict__ X0, const float *__restric
             }
     }
     float E[9];
+    SFM_PHASE("householder");
     nullvec9_householder(x1, x2, E);
+    SFM_PHASE("normalize_E");
     normalize_E(E);
+    SFM_PHASE("store_E");
 #pragma unroll
     for (int k = 0; k < 9; ++k) Ecand[9 * (size_t)i + k] = E[k];
+    SFM_PHASE("record");
     // the operands of the matrix-core pre-filter for this hypothesis (prefilter_record.hpp), once for all tiles
     if (recs) {
         const float B = __uint_as_float((uint32_t)(*bound_word & 0xFFFFFFFFull));
@@ -106,6 +112,7 @@ void ransac_solve_lanes1_qr(const float *__restrict__ X0, const float *__restric
 #endif
         pf_band_prep_store(E, thr, B, pf_box_from_words(bound_word + 2, B), cells, cells_mask, recs + i);
     }
+    SFM_PHASE("end");
 }
 
 // Two hypotheses per lane (2i, 2i+1): every mul / add / fma of the solver is a v_pk_*_f32.

@@ -27,7 +27,11 @@
 
 namespace sfm {
 
-constexpr int kPfTile = 1024;            // points per tile
+constexpr int kPfTileMax = 1024;         // points per tile at most; a launch picks the smallest multiple of 32 that covers the points with the fewest
+                                         // tiles (pf_tile_points).  The band rule's 80 bytes per point would allow 1536 (3 tiles for 4096 points, 11 for
+                                         // 16384: fewer, longer passes) -- measured SLOWER at every size (profiles/r05_ab_tile_size.txt: 0.369 against
+                                         // 0.360 ms at 2^20 x 4096, 0.068 against 0.058 at a rank's share): coarser passes, longer tails.  AB build,
+                                         // reserved[1] == 7: tiles of up to 1536 points.
 constexpr int kPfWaves = 16;             // wavefronts per block (LDS is laid out for 16; the kernel also runs with 12, see launch_score_prefilter)
 constexpr int kPfRing = 128;             // survivor ring entries (8 bytes) per wavefront: < 64 waiting + 64 appended per step;
                                          // a flush re-queues at most 64 more, onto slots its own 64 entries have just left
@@ -43,19 +47,37 @@ constexpr int kPfERow = 10;                                   // floats per hypo
                                                               // reads for a random row hit bank (row mod 32) + const, so distinct rows never conflict
                                                               // (row-major 40-byte rows put rows r and r + 16 on the same banks: 19 % of the LDS cycles were conflicts)
 constexpr int kPfWaveBytes = 32 * kPfERow * 4 + 32 * 4;
+// component order of the table: slot k holds E entry kPfESlot[k] -- the pairs the packed exact filter wants, (e2 e6) (e1 e3) (e5 e7)
+// (e0 e4), sit in neighbouring slots, so each arrives as ONE ds_read2_b32 in an aligned register pair (the natural order cost six
+// register moves per flush)
+__device__ constexpr int kPfESlot[9] = { 2, 6, 1, 3, 5, 7, 0, 4, 8 };
+// The map for a tile of `tile` points (a multiple of 32); an even number of 32-point blocks is staged (the scan takes two per iteration).
 template <int RULE> struct PfLds {
     static constexpr int kFragsPerBlock = RULE == kPfRuleBand ? 2 : 3;
     static constexpr int kBlockBytes = kFragsPerBlock * 64 * 16;   // one 32-point block: [n k-step 0 | n k-step 1 (| G)][lane][8 fp16]
     static constexpr int kFrag = 0;
-    static constexpr int kPts = kFrag + (kPfTile / 32) * kBlockBytes;       // float4 (x2x, x1x, x2y, x1y) per point
-    static constexpr int kRingBase = kPts + kPfTile * 16;     // the wavefronts' survivor rings, 1024 bytes each, 1024-byte aligned (a slot's
-                                                              // address is (offset & 1023) | base: one v_and_or_b32)
-    static constexpr int kWave = kRingBase + kPfWaves * kPfRing * 8;        // per wavefront: E table 9 x 32 floats (component-major), 32 counters
-    static constexpr int kNext = kWave + kPfWaves * kPfWaveBytes;           // the block's pass counter
-    static constexpr int kBytes = kNext + 16;
-    static_assert(kRingBase % 1024 == 0 && kPfRing * 8 == 1024, "ring slots are addressed with (offset & 1023) | base");
-    static_assert(kBytes <= 160 * 1024, "one block must fit the CU's LDS");
+    static constexpr int kTileMax = kPfTileMax;
+    int staged, pts, ring, wave, next, bytes;
+    __host__ __device__ explicit PfLds(int tile)
+    {
+        staged = (tile + 63) & ~63;                           // points staged: whole iterations of two blocks (beyond `tile`: padding)
+        pts = kFrag + (staged / 32) * kBlockBytes;            // float4 (x2x, x1x, x2y, x1y) per point
+        ring = pts + staged * 16;                             // the wavefronts' survivor rings, 1024 bytes each, 1024-byte aligned (a slot's
+                                                              // address is (offset & 1023) | base: one v_and_or_b32): staged is a multiple of 64
+        wave = ring + kPfWaves * kPfRing * 8;                 // per wavefront: E table 9 x 32 floats (component-major), 32 counters
+        next = wave + kPfWaves * kPfWaveBytes;                // the block's pass counter
+        bytes = next + 16;
+    }
 };
+static_assert(kPfRing * 8 == 1024, "ring slots are addressed with (offset & 1023) | base");
+
+// Tile size of a launch: the fewest tiles of at most `tmax` points, equal sizes rounded up to 32 (4096 points: 4 x 1024; 4608: 5 x 928).
+static int pf_tile_points(int ld, int tmax)
+{
+    const int ntiles = (ld + tmax - 1) / tmax;
+    const int t = ((ld + ntiles - 1) / ntiles + 31) & ~31;
+    return t < 32 ? 32 : t;
+}
 
 // rejected = (rejected << 1) | sign(G - nt^2): v_fma_f32 with a negated operand and v_alignbit_b32.  Plain C++ (no inline
 // assembly), so the compiler inserts the wait states the MFMA result registers need before a vector instruction reads them.
@@ -169,7 +191,7 @@ template <int W, int VAR = 0, int RULE = kPfRuleBand>
 __global__ __launch_bounds__(W * 64)
 void ransac_score_prefilter(const float *__restrict__ X0, const float *__restrict__ X1, int ld, int n,
                             const float *__restrict__ Ecand, const PfRecord *__restrict__ recs, uint32_t h0, uint32_t count, float thr,
-                            int dynamic,
+                            int dynamic, int tile,
                             int *__restrict__ counts, uint32_t *__restrict__ tick,
                             unsigned long long *best_key, unsigned long long *best_key2, unsigned long long *__restrict__ clk)
 {
@@ -196,8 +218,9 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
     const int half = lane >> 5, row = lane & 31;
     const uint32_t npass = (count + (uint32_t)kPfGroup - 1u) / (uint32_t)kPfGroup;
     const uint32_t nstatic = gridDim.x * (uint32_t)W;             // passes handed out by position
-    using L = PfLds<RULE>;
-    float *etab = reinterpret_cast<float *>(smem + L::kWave + wave * kPfWaveBytes);
+    using LT = PfLds<RULE>;
+    const LT L(tile);
+    float *etab = reinterpret_cast<float *>(smem + L.wave + wave * kPfWaveBytes);
     int *cnt = reinterpret_cast<int *>(etab + 32 * kPfERow);
 
     // Operands of hypothesis (32 ps + row): this lane's half of the three A fragments and (lanes 0..31) its zero-divisor
@@ -221,7 +244,7 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
     auto install_rows = [&](const float (&e)[9]) {          // E table and counters of a pass (the previous pass' ring is drained, its counters are out)
         if (half == 0) {
 #pragma unroll
-            for (int k = 0; k < 9; ++k) etab[32 * k + row] = e[k];
+            for (int k = 0; k < 9; ++k) etab[32 * k + row] = e[kPfESlot[k]];
             cnt[row] = 0;
         }
     };
@@ -230,27 +253,28 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
     bool have = ps < npass;
     if (have) { fetch_pass(ps, afrag, key0, e_row); install_rows(e_row); }
 
+    SFM_PHASE("stage_tile");
     // ---- stage the tile: one point per thread -> 48 fp16 feature slots in MFMA B-fragment order + its coordinates
     // The passes of a block -- (16 j + w) for wavefront slot w of its j-th iteration -- are handed out through a counter in
     // LDS: the wavefronts of a block do not advance at the same rate (the oldest wavefront of a SIMD wins its arbitration:
     // with one fixed share each, the first finished 230 us before the last of a 630 us launch, profiles/r03_trace_*.txt),
     // and with first-come-first-served shares they finish within one pass of each other.  (One counter per tile in global
     // memory would balance the blocks too, but 131072 device-scope atomics on one address take 1.5 ms.)
-    uint32_t *next_idx = reinterpret_cast<uint32_t *>(smem + L::kNext);
+    uint32_t *next_idx = reinterpret_cast<uint32_t *>(smem + L.next);
     if (threadIdx.x == 0) *next_idx = (uint32_t)W;
     __syncthreads();
-    const int tile_first = blockIdx.y * kPfTile;
-    for (int t = threadIdx.x; t < kPfTile; t += W * 64) {
+    const int tile_first = blockIdx.y * tile;
+    for (int t = threadIdx.x; t < L.staged; t += W * 64) {
         const int p = tile_first + t;
         float u = 0.f, v = 0.f, x = 0.f, y = 0.f;
-        const bool real = p < n;
+        const bool real = p < n && t < tile;                    // (a staged point beyond the tile belongs to the next one: padding here)
         if (real) { u = X0[p]; v = X0[(size_t)ld + p]; x = X1[p]; y = X1[(size_t)ld + p]; }
         _Float16 bn[kPfSlots], bt[kPfSlotsT];
         prefilter_point_slots(u, v, x, y, real, bn, bt);
         // padding reads as NaN in the exact test (it is always rejected before; NaN never counts)
-        reinterpret_cast<float4 *>(smem + L::kPts)[t] = real ? make_float4(x, u, y, v) : make_float4(NAN, NAN, NAN, NAN);
+        reinterpret_cast<float4 *>(smem + L.pts)[t] = real ? make_float4(x, u, y, v) : make_float4(NAN, NAN, NAN, NAN);
         const int pb = t >> 5, col = t & 31;
-        unsigned char *blk = smem + L::kFrag + pb * L::kBlockBytes;
+        unsigned char *blk = smem + LT::kFrag + pb * LT::kBlockBytes;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -274,23 +298,24 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
 #if SFM_AB
     if (probe) clk[2] = wall_clock64() - w0;
 #endif
-    const int npb = (min(kPfTile, ld - tile_first) + 31) >> 5;           // 32-point blocks that hold points or padding
+    const int npb = (min(tile, ld - tile_first) + 31) >> 5;              // 32-point blocks that hold points or padding
     const int npp = (npb + 1) >> 1;                                      // two 32-point blocks per iteration (a block beyond npb holds padding only: all rejected)
-    const float4 *pts = reinterpret_cast<const float4 *>(smem + L::kPts);
+    const float4 *pts = reinterpret_cast<const float4 *>(smem + L.pts);
     lds_cf *etab_l = (lds_cf *)etab;
     lds_i *cnt_l = (lds_i *)cnt;
-    const uint32_t ring_base = (uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char *)(smem + L::kRingBase) + (uint32_t)wave * (uint32_t)(kPfRing * 8);
+    const uint32_t ring_base = (uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char *)(smem + L.ring) + (uint32_t)wave * (uint32_t)(kPfRing * 8);
     uint32_t ring_mask = (uint32_t)(kPfRing * 8 - 1);
     asm("" : "+v"(ring_mask));                            // in a vector register: v_and_or_b32 takes one scalar operand, and that is the base
     auto ring_at = [&](uint32_t index8) {                 // index8 = 8 x (slot index, not yet wrapped)
         return (lds_u2 *)((__attribute__((address_space(3))) unsigned char *)0 + ((index8 & ring_mask) | ring_base));
     };
-    lds_ch8 *frag_lane = (lds_ch8 *)(smem + L::kFrag) + lane;
+    lds_ch8 *frag_lane = (lds_ch8 *)(smem + LT::kFrag) + lane;
     const ThrBand band = make_band(thr);
     uint32_t passes_done = 0;
 
     // ---- 32 hypotheses per pass of this wavefront (no block-level synchronisation from here on)
     while (have) {
+        SFM_PHASE("pass_begin");
         const uint32_t h_first = ps * (uint32_t)kPfGroup;
         const int nvalid = (int)min((uint32_t)kPfGroup, count - h_first);
 #if SFM_AB
@@ -315,9 +340,9 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
             while (todo) {
                 const int r = __builtin_ctz(todo);
                 todo &= todo - 1u;
-                const float se[6] = { etab[r], etab[32 + r], etab[64 + r], etab[96 + r], etab[128 + r], etab[160 + r] };          // e0 .. e5
+                const float se[6] = { etab[6 * 32 + r], etab[2 * 32 + r], etab[r], etab[3 * 32 + r], etab[7 * 32 + r], etab[4 * 32 + r] };          // e0 .. e5 (slots 6 2 0 3 7 4)
                 bool z = false;
-                for (int j = 0; j < kPfTile / 64; ++j) {
+                for (int j = 0; j < L.staged / 64; ++j) {
                     const float4 q = pts[j * 64 + lane];
                     z = z || prefilter_zero_divisor(se, q.x, q.z);              // NaN padding never compares equal to 0
                 }
@@ -354,7 +379,7 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
                 if (hl < nvalid) {
                     const f4v q = *(lds_cf4 *)((__attribute__((address_space(3))) const unsigned char *)0 + ((tag & ~15u) + ((uint32_t)sub << 9)));
                     lds_cf *e = etab_l + hl;
-                    const v2f p0 = { e[64], e[192] }, p1 = { e[32], e[96] }, p2 = { e[160], e[224] }, p3 = { e[0], e[128] };      // (e2 e6) (e1 e3) (e5 e7) (e0 e4)
+                    const v2f p0 = { e[0], e[32] }, p1 = { e[64], e[96] }, p2 = { e[128], e[160] }, p3 = { e[192], e[224] };      // (e2 e6) (e1 e3) (e5 e7) (e0 e4): one ds_read2_b32 each
                     const float e8 = e[256];
                     if (pf_exact_inlier(p0, p1, p2, p3, e8, v2f{ q.x, q.y }, v2f{ q.z, q.w }, band))
                         __hip_atomic_fetch_add(cnt_l + hl, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -375,8 +400,9 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
         // one running address for the look-ahead reads (32-point blocks 2 pp + 2 and 2 pp + 3: six immediate offsets, one add per
         // iteration).  The last iterations read one or two blocks past the tile -- coordinates and rings, still inside the block's
         // LDS -- into fragments no scan ever looks at.
-        lds_ch8 *fp = frag_lane + 2 * (L::kBlockBytes / 16);
+        lds_ch8 *fp = frag_lane + 2 * (LT::kBlockBytes / 16);
         for (int pp = 0; pp < npp; ++pp) {
+            SFM_PHASE("scan_two_steps");
             // phase 1: matrix cores on step 2 pp + 1 (fragments fb), LDS on step 2 pp + 2, vector unit on step 2 pp
             fa = load_point_frags<RULE>(fp, 0);
             __builtin_amdgcn_sched_barrier(0);
@@ -386,7 +412,7 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
             __builtin_amdgcn_sched_barrier(0);
             // phase 2: matrix cores on step 2 pp + 2 (fragments fa), LDS on step 2 pp + 3, vector unit on step 2 pp + 1
             fb = load_point_frags<RULE>(fp, 1);
-            fp += 2 * (L::kBlockBytes / 16);
+            fp += 2 * (LT::kBlockBytes / 16);
             __builtin_amdgcn_sched_barrier(0);
             mfma_step<RULE>(afrag, fa, g0, n0);
             const uint32_t rej_second = RULE == kPfRuleBand ? scan16_band(n1) : scan16(n1, g1);
@@ -398,6 +424,7 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
                                                        : ((rej_first << 16) | rej_second);
             const bool mine = rej32 != 0xFFFFFFFFu;
             const unsigned long long any = __ballot(mine);
+            SFM_PHASE("append_and_inloop_flush");
             if (any) {
                 while (nq >= 64) flush(64);             // make room first (a flush of 64 entries re-queues up to 64: it may take more than one)
                 const int slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(any >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)any, 0u));
@@ -406,12 +433,15 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
             }
         }
         PF_PHASE(4);
+        SFM_PHASE("pass_end_fetch_next");
         // the next pass' operands: requested now, they arrive while the ring is drained and the counts go out
         const bool have_next = ps_next < npass;
         PfFrags afrag_next = afrag;
         uint32_t key0n = 0u;
         if (have_next) fetch_pass(ps_next, afrag_next, key0n, e_row);
+        SFM_PHASE("drain_flush");
         while (nq > 0) flush(min(nq, 64));
+        SFM_PHASE("epilogue");
         PF_PHASE(7);
         if (VAR & kPfVarTickets) {
         // LDS counters -> counts[] (zeroed by the solve kernel); a wavefront's LDS operations complete in order
@@ -493,6 +523,7 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
             if (VAR & kPfVarTickets) { afrag = afrag_next; key0 = key0n; install_rows(e_row); }     // (otherwise installed above, under the accumulator's round trip)
         }
     }
+    SFM_PHASE("kernel_end");
     if (probe) { clk[6] = passes_done; clk[0] = clock64() - c0; clk[1] = wall_clock64() - w0; }
 #if SFM_AB
     if (trace && lane == 0) {
@@ -758,11 +789,16 @@ int prefilter_rule(const sfm_ransac_params &p)
 bool prefilter_usable(const sfm_pair *pair, const sfm_ransac_params &p, uint32_t count)
 {
     PfScales sc;
-    const uint64_t ntiles = (uint64_t)((pair->ld + kPfTile - 1) / kPfTile);
-    return pair->unit_z && pair->have_bound && count >= 16384u && (uint64_t)count * ntiles >= 131072u && prefilter_scales(p.threshold, sc);
+    // (enough work: 2^27 pairs -- 131072 block passes of 32 hypotheses x 1024 points in the geometry the crossover was measured with)
+    return pair->unit_z && pair->have_bound && count >= 16384u && (uint64_t)count * (uint64_t)pair->ld >= (1ull << 27) && prefilter_scales(p.threshold, sc);
 }
 
-int prefilter_tiles(const sfm_pair *pair) { return (pair->ld + kPfTile - 1) / kPfTile; }
+// points per tile of a launch on this pair (AB build, reserved[1] == 7: up to 1536 points with the band rule)
+static int pf_tile_of(const sfm_pair *pair, const sfm_ransac_params &p)
+{
+    if (SFM_SW(p, 1) == 7 && prefilter_rule(p) == kPfRuleBand) return pf_tile_points(pair->ld, 1536);
+    return pf_tile_points(pair->ld, kPfTileMax);
+}
 
 int launch_score_prefilter(sfm_pair *pair, const sfm_ransac_params &p, uint32_t h0, uint32_t count, unsigned long long *key2)
 {
@@ -773,7 +809,8 @@ int launch_score_prefilter(sfm_pair *pair, const sfm_ransac_params &p, uint32_t 
     // per SIMD, which leaves a quarter of the registers to the lane-solve kernel of the NEXT step when steps are pipelined
     // on two streams (profiles/r03_waves_ab.txt)
     const int waves = SFM_SW(p, 1) == 5 ? 12 : kPfWaves;
-    const int ntiles = prefilter_tiles(pair);
+    const int tile = pf_tile_of(pair, p);
+    const int ntiles = (pair->ld + tile - 1) / tile;
     const uint32_t npass = (count + (uint32_t)kPfGroup - 1u) / (uint32_t)kPfGroup;
     const uint32_t iters = (npass + (uint32_t)waves - 1) / (uint32_t)waves;       // block iterations per tile
     // one block per CU is resident (152 KiB of LDS), so the grid is at most one block per CU, spread over the tiles: columns =
@@ -787,13 +824,14 @@ int launch_score_prefilter(sfm_pair *pair, const sfm_ransac_params &p, uint32_t 
     const int dynamic = SFM_SW(p, 1) == 2 ? 0 : 1;                               // (AB build, reserved[1] == 2: static striding)
     const int var = SFM_SW(p, 3) >= 16 ? SFM_SW(p, 3) - 16 : 0;                 // (AB build, reserved[3] = 16 + VAR bits)
     const int rule = prefilter_rule(p);
-    const int lds_bytes = rule == kPfRuleBand ? PfLds<kPfRuleBand>::kBytes : PfLds<kPfRuleG>::kBytes;
+    const int lds_bytes = rule == kPfRuleBand ? PfLds<kPfRuleBand>(tile).bytes : PfLds<kPfRuleG>(tile).bytes;
+    if (lds_bytes > 160 * 1024) { set_error("pre-filter tile of %d points needs %d bytes of LDS", tile, lds_bytes); return SFM_E_INVALID; }
     auto launch = [&](auto kernel) -> int {
         const int rc_lds = allow_big_lds(ctx, reinterpret_cast<const void *>(kernel));
         if (rc_lds != SFM_OK) return rc_lds;
         hipLaunchKernelGGL(kernel, dim3(cols, ntiles), dim3(waves * 64), lds_bytes, ctx->stream,
                            pair->d_X[0], pair->d_X[1], pair->ld, pair->n, pair->d_Ecand, reinterpret_cast<const PfRecord *>(pair->d_pf), h0, count, p.threshold,
-                           dynamic, pair->d_counts, pair->d_tick, pair->d_key, key2, pair->d_clk);
+                           dynamic, tile, pair->d_counts, pair->d_tick, pair->d_key, key2, pair->d_clk);
         return SFM_OK;
     };
     int rcl;

@@ -287,9 +287,14 @@ def test_g_rule_kernel_still_equals_oracle(gpu_ab, n, H, thr):
     P.check_all(pair, scene, p, H, n)
     q = S.default_params(n, num_hypotheses=H, seed=2, kernel=S.KERNEL_PREFILTER, threshold=thr)
     pair.estimateE(q)
-    b = pair.last_launch()
     P.check_all(pair, scene, q, H, n)
-    assert b["lds_bytes"] + 32 * 1024 == g["lds_bytes"]                  # 64 instead of 96 bytes of fragments per point of the 1024-point tile
+    b = pair.last_launch()
+    if n % 1024 == 0:
+        assert b["lds_bytes"] + 32 * 1024 == g["lds_bytes"]              # 64 instead of 96 bytes of fragments per point of a 1024-point tile
+    q.reserved[1] = 7                                                    # tiles of up to 1536 points (measured slower: profiles/r05_ab_tile_size.txt)
+    pair.estimateE(q)
+    assert pair.last_launch()["lds_bytes"] >= b["lds_bytes"]
+    P.check_all(pair, scene, q, H, n)
     p.reserved[3] = 3                                                    # stand-alone record kernel, band rule
     pair.estimateE(p)
     P.check_all(pair, scene, p, H, n)
