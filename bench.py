@@ -58,7 +58,7 @@ ALG_BYTES_PER_HYP = 72.0       # 32 B indices + 36 B E + 4 B count
 PF_RULES = {"band": (1, 2), "G": (2, 3)}
 PF_MFMA_CYCLES = 32           # issue interval of one 32x32x16 f16 MFMA on a SIMD (8 passes x 4 cycles; profiles/r02_mfma_rate_probe.txt)
 PF_SOURCES = ("ransac_prefilter.hip", "prefilter_math.hpp", "prefilter_record.hpp", "ransac.hip", "ransac_device.hpp", "device_math.hpp")
-TRAFFIC_JSON = os.path.join("profiles", "r04_traffic.json")
+TRAFFIC_JSON = os.path.join("profiles", "r05_traffic.json")
 PUBLISHED_ESTIMATE_E_MS = 24.12     # img/data.xlsx B5 / README.md:54 of the reference: estimateE on the dino pair, GTX 1080 Ti
 
 # BASELINE.json configs that are RANSAC workloads (configs[1] and [4] are pipelines: see `extra`)
@@ -361,7 +361,7 @@ def quoted_counters(kname, n, local_hyps):
         have = source_hash()
         if doc.get("code_sha256_16") != have:
             return None, (f"{TRAFFIC_JSON} was collected on kernel sources {doc.get('code_sha256_16')}, this tree has {have}: "
-                          "not quoted (re-run profiles/collect_r04.sh)")
+                          "not quoted (re-run profiles/collect_r05.sh)")
         t = dict(t)
         solve = doc.get("ransac_solve_lanes1_qr") or doc.get("ransac_solve_lanes2") or {}
         if solve.get("fetch_kb") is not None and solve.get("write_kb") is not None:
