@@ -59,6 +59,7 @@ struct sfm_ctx {
     void *match_ws = nullptr;
     size_t match_ws_bytes = 0;
     size_t match_ticket_bytes = 0;
+    unsigned int match_epoch = 0;      // one-match launches of the exact matcher tag their partials with it (match.hip: POLL)
     void *match_jobs_ws = nullptr;     // launch_match_jobs: the job array, tickets and per-split partials of every match of the launch
     size_t match_jobs_ws_bytes = 0;     // zeroed ticket area in front of the partials (grows with the query-block count)
     // pre-filter matcher (match_prefilter.hip): fp16 copies, norms, per-split partials, candidate lists

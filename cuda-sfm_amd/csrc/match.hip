@@ -114,14 +114,23 @@ __device__ __forceinline__ void stage_scores(const float *cur, const float (&bq)
 // matrix pipe busy.
 // The work of block (qblock, split) of one match (nsplit database splits); shared by the one-match kernel and the
 // many-matches kernel (grid.z = match, launch_match_jobs).
-template <int CT, int W>
+// POLL (one-match launches, whose blocks are all resident at once: at most one per CU): the partials travel as self-validating
+// 64-bit words (launch epoch << 32 | payload) and the block of the LAST split -- dispatched after every other split of its
+// query block, so it never holds a CU that a block it waits for still needs -- polls them instead of drawing a ticket.  What the
+// ticket scheme serialises (partials acknowledged -> ticket round trip, 16 atomics on one address -> loads of the partials -> merge)
+// becomes one wait for the slowest peer's words.  The wait is bounded (kPollLimit polls, ~0.1 s): a launch that gives up sets
+// tickets[qblock] to kPollGaveUp, which the next launch_match reports (nothing in the protocol can time out short of a lost block).
+constexpr unsigned int kPollLimit = 1u << 20;
+constexpr unsigned int kPollGaveUp = 0xDEADu;
+
+template <int CT, int W, bool POLL = false>
 __device__ __forceinline__ void match_body(const float *__restrict__ q, int nq, int ldq,
                        const float *__restrict__ db, int ndb, int lddb,
                        int rows_per_split,
                        float *__restrict__ ws_best, float *__restrict__ ws_second, int *__restrict__ ws_idx,
                        unsigned int *__restrict__ tickets, float *__restrict__ out_best, float *__restrict__ out_second,
                        int *__restrict__ out_idx, sfm_sift_point *__restrict__ sift1, const sfm_sift_point *__restrict__ sift2,
-                       const int qblock, const int split, const int nsplit)
+                       const int qblock, const int split, const int nsplit, const unsigned int epoch = 0u)
 {
     __shared__ __attribute__((aligned(16))) float lds[2][kRowsPerStage * kLdsStride];
     const int lane = threadIdx.x & 63;
@@ -188,6 +197,76 @@ __device__ __forceinline__ void match_body(const float *__restrict__ q, int nq, 
     }
 
     // ---- merge the two k-parity halves of each column and emit the split's partial ------------
+    if (POLL) {
+        // words (epoch << 32 | bits) at ws64[(3 split + k) nq + p1], k = best / second / index; the last split keeps its own in LDS
+        unsigned long long *ws64 = reinterpret_cast<unsigned long long *>(ws_best);
+        float *own = &lds[0][0];                         // (the stages are done with: 3 x CT x 32 x W floats of the first buffer)
+        const unsigned long long tag = (unsigned long long)epoch << 32;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            Top2 o;
+            o.best = __shfl_xor(top[ct].best, 32);
+            o.second = __shfl_xor(top[ct].second, 32);
+            o.idx = __shfl_xor(top[ct].idx, 32);
+            const Top2 mrg = top2_merge(top[ct], o);
+            const int k = (wave * CT + ct) * 32 + col;
+            const int p1 = q0 + k;
+            if (half == 0 && p1 < nq) {
+                if (split == nsplit - 1) {
+                    own[3 * k] = mrg.best; own[3 * k + 1] = mrg.second; own[3 * k + 2] = __int_as_float(mrg.idx);
+                } else {
+                    unsigned long long *w = ws64 + (size_t)(3 * split) * nq + p1;
+                    __hip_atomic_store(w, tag | __float_as_uint(mrg.best), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(w + nq, tag | __float_as_uint(mrg.second), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(w + 2 * (size_t)nq, tag | (unsigned int)mrg.idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
+        if (split != nsplit - 1) return;
+        __syncthreads();
+        for (int k = threadIdx.x; k < CT * 32 * W; k += blockDim.x) {
+            const int p1 = q0 + k;
+            if (p1 >= nq) break;
+            // the merge runs in ascending database order (equal scores: the lower index wins through top2_merge's tie rule whatever
+            // the order, but the seed of the merge is split 0 as in the ticket scheme): this block's own partial comes last
+            Top2 t{ 0.0f, 0.0f, -1 };
+            bool first = true, gave_up = false;
+            constexpr int kMergeBatch = 16;
+            for (int sp0 = 0; sp0 < nsplit - 1; sp0 += kMergeBatch) {
+                unsigned long long wv[kMergeBatch][3];
+                unsigned int polls = 0;
+                for (;;) {
+                    bool fresh = true;
+#pragma unroll
+                    for (int u = 0; u < kMergeBatch; ++u) {
+                        const unsigned long long *w = ws64 + (size_t)(3 * min(sp0 + u, nsplit - 2)) * nq + p1;
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) wv[u][c] = __hip_atomic_load(w + (size_t)c * nq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+#pragma unroll
+                    for (int u = 0; u < kMergeBatch; ++u)
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) fresh = fresh && (unsigned int)(wv[u][c] >> 32) == epoch;
+                    if (fresh) break;
+                    if (++polls > kPollLimit) { gave_up = true; break; }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                if (gave_up) break;
+#pragma unroll
+                for (int u = 0; u < kMergeBatch; ++u)
+                    if (sp0 + u < nsplit - 1) {
+                        const Top2 part{ __uint_as_float((unsigned int)wv[u][0]), __uint_as_float((unsigned int)wv[u][1]), (int)(unsigned int)wv[u][2] };
+                        t = first ? part : top2_merge(t, part);
+                        first = false;
+                    }
+            }
+            const Top2 mine{ own[3 * k], own[3 * k + 1], __float_as_int(own[3 * k + 2]) };
+            t = first ? mine : top2_merge(t, mine);
+            if (gave_up) { tickets[qblock] = kPollGaveUp; t = Top2{ 0.0f, 0.0f, -1 }; }
+            match_emit(p1, t, out_best, out_second, out_idx, sift1, sift2);
+        }
+        return;
+    }
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
         Top2 o;
@@ -245,17 +324,17 @@ __device__ __forceinline__ void match_body(const float *__restrict__ q, int nq, 
     }
 }
 
-template <int CT, int W>
+template <int CT, int W, bool POLL>
 __global__ __launch_bounds__(W * 64)
 void match_mfma_kernel(const float *__restrict__ q, int nq, int ldq,
                        const float *__restrict__ db, int ndb, int lddb,
                        int rows_per_split,
                        float *__restrict__ ws_best, float *__restrict__ ws_second, int *__restrict__ ws_idx,
                        unsigned int *__restrict__ tickets, float *__restrict__ out_best, float *__restrict__ out_second,
-                       int *__restrict__ out_idx, sfm_sift_point *__restrict__ sift1, const sfm_sift_point *__restrict__ sift2)
+                       int *__restrict__ out_idx, sfm_sift_point *__restrict__ sift1, const sfm_sift_point *__restrict__ sift2, unsigned int epoch)
 {
-    match_body<CT, W>(q, nq, ldq, db, ndb, lddb, rows_per_split, ws_best, ws_second, ws_idx, tickets, out_best, out_second, out_idx, sift1, sift2,
-                      (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.y);
+    match_body<CT, W, POLL>(q, nq, ldq, db, ndb, lddb, rows_per_split, ws_best, ws_second, ws_idx, tickets, out_best, out_second, out_idx, sift1, sift2,
+                            (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.y, epoch);
 }
 
 // Many matches of ONE query set in one launch (sfm_process_pairs: all pairs (i, j) that share their first view i --
@@ -299,14 +378,16 @@ int match_partials_workspace(sfm_ctx *ctx, int qblocks, int nsplit, int n1, unsi
     size_t ticket_bytes = ctx->match_ticket_bytes < 4096 ? 4096 : ctx->match_ticket_bytes;
     if ((size_t)qblocks * 4 > ticket_bytes) ticket_bytes = (size_t)round_up(qblocks * 4, 4096);
     const size_t kTicketBytes = ticket_bytes;
-    const size_t need = kTicketBytes + (size_t)nsplit * n1 * 12;
+    // partials: 12 bytes per (split, query) for the ticket scheme, 24 for the polled one (three epoch-tagged 64-bit words); the whole
+    // area is zeroed when it is (re)allocated -- epoch 0 is never used, so a word of a fresh workspace can never pass for a partial
+    const size_t need = kTicketBytes + (size_t)nsplit * n1 * 24;
     if (need > ctx->match_ws_bytes || kTicketBytes != ctx->match_ticket_bytes) {
         SFM_HIP_TRY(hipStreamSynchronize(ctx->stream));
         const size_t bytes = need > ctx->match_ws_bytes ? need : ctx->match_ws_bytes;
         if (ctx->match_ws) (void)hipFree(ctx->match_ws);
         ctx->match_ws = nullptr; ctx->match_ws_bytes = 0; ctx->match_ticket_bytes = 0;
         SFM_HIP_TRY(hipMalloc(&ctx->match_ws, bytes));
-        SFM_HIP_TRY(hipMemsetAsync(ctx->match_ws, 0, kTicketBytes, ctx->stream));
+        SFM_HIP_TRY(hipMemsetAsync(ctx->match_ws, 0, bytes, ctx->stream));
         ctx->match_ws_bytes = bytes; ctx->match_ticket_bytes = kTicketBytes;
     }
     *tickets = static_cast<unsigned int *>(ctx->match_ws);
@@ -410,15 +491,23 @@ int launch_match(sfm_ctx *ctx, const float *d1, int n1, int ld1, const float *d2
     if (wrc != SFM_OK) return wrc;
 
     const dim3 grid(qblocks, nsplit);
-    if (ct == 2)
-        hipLaunchKernelGGL((match_mfma_kernel<2, 8>), grid, dim3(512), 0, ctx->stream,
-                           d1, n1, ld1, d2, n2, ld2, rows_per_split, wb, wsnd, wi, tickets, d_best, d_second, d_index, sift1, sift2);
-    else if (wv == 8)
-        hipLaunchKernelGGL((match_mfma_kernel<1, 8>), grid, dim3(512), 0, ctx->stream,
-                           d1, n1, ld1, d2, n2, ld2, rows_per_split, wb, wsnd, wi, tickets, d_best, d_second, d_index, sift1, sift2);
-    else
-        hipLaunchKernelGGL((match_mfma_kernel<1, 4>), grid, dim3(256), 0, ctx->stream,
-                           d1, n1, ld1, d2, n2, ld2, rows_per_split, wb, wsnd, wi, tickets, d_best, d_second, d_index, sift1, sift2);
+    // Every block of a one-match launch is resident at once (at most one per CU), so the partials can be POLLED by the last split's
+    // block (match_body<POLL>): no ticket, no ordering round trips.  SFM_MATCH_MERGE=ticket (environment, read once; A/B runs and
+    // tests) keeps the ticket scheme of rounds 1-4.
+    static const char *merge_env = getenv("SFM_MATCH_MERGE");
+    const bool poll = !(merge_env && merge_env[0] == 't') && (long long)qblocks * nsplit <= 2ll * ctx->num_cus;
+    if (++ctx->match_epoch == 0u) {                          // (2^32 launches later: a stale word could carry the new epoch)
+        SFM_HIP_TRY(hipMemsetAsync(ctx->match_ws, 0, ctx->match_ws_bytes, ctx->stream));
+        ctx->match_epoch = 1u;
+    }
+    const unsigned int epoch = ctx->match_epoch;
+#define SFM_MATCH_LAUNCH(CT_, W_, POLL_)                                                                                                      \
+    hipLaunchKernelGGL((match_mfma_kernel<CT_, W_, POLL_>), grid, dim3(W_ * 64), 0, ctx->stream,                                             \
+                       d1, n1, ld1, d2, n2, ld2, rows_per_split, wb, wsnd, wi, tickets, d_best, d_second, d_index, sift1, sift2, epoch)
+    if (ct == 2) { if (poll) SFM_MATCH_LAUNCH(2, 8, true); else SFM_MATCH_LAUNCH(2, 8, false); }
+    else if (wv == 8) { if (poll) SFM_MATCH_LAUNCH(1, 8, true); else SFM_MATCH_LAUNCH(1, 8, false); }
+    else { if (poll) SFM_MATCH_LAUNCH(1, 4, true); else SFM_MATCH_LAUNCH(1, 4, false); }
+#undef SFM_MATCH_LAUNCH
     SFM_HIP_TRY(hipGetLastError());
     return SFM_OK;
 }
