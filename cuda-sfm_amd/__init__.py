@@ -55,7 +55,7 @@ SIFT_DTYPE = np.dtype([
 assert SIFT_DTYPE.itemsize == 576
 
 EXPORTS = [
-    "sfm_abi_version", "sfm_last_error", "sfm_ctx_create", "sfm_ctx_destroy", "sfm_ctx_set_stream", "sfm_ctx_set_quirks", "sfm_ctx_set_match_kernel", "sfm_ctx_last_match_kernel",
+    "sfm_abi_version", "sfm_last_error", "sfm_ctx_create", "sfm_ctx_destroy", "sfm_ctx_retain", "sfm_ctx_release", "sfm_ctx_set_stream", "sfm_ctx_set_quirks", "sfm_ctx_set_match_kernel", "sfm_ctx_last_match_kernel",
     "sfm_ctx_synchronize", "sfm_ctx_own_stream", "sfm_ctx_get_stream", "sfm_ctx_get_device", "sfm_ctx_timer_start", "sfm_ctx_timer_stop", "sfm_ctx_kernel_timing",
     "sfm_ctx_kernel_timing_read", "sfm_device_alloc", "sfm_device_free", "sfm_copy_to_device", "sfm_copy_to_host",
     "sfm_copy_to_host_2d", "sfm_copy_to_device_2d", "sfm_find_homography", "sfm_sift_temp_layout", "sfm_extract_sift", "sfm_extract_sift_begin", "sfm_extract_sift_end", "sfm_match", "sfm_match_soa",

@@ -91,12 +91,46 @@ int sfm_ctx_create(int device_id, sfm_ctx **out)
     return SFM_OK;
 }
 
+int sfm_ctx_retain(sfm_ctx *ctx)
+{
+    SFM_REQUIRE(ctx, SFM_E_INVALID, "null context");
+    ctx->refs++;
+    return SFM_OK;
+}
+
+static int ctx_destroy_now(sfm_ctx *ctx);
+
+// one reference less (a pair or a communicator went away); the last one destroys a context whose owner has already let go of it
+static void ctx_release(sfm_ctx *ctx)
+{
+    if (!ctx) return;
+    if (ctx->refs > 0) ctx->refs--;
+    if (ctx->refs == 0 && ctx->destroy_requested) (void)ctx_destroy_now(ctx);
+}
+
+int sfm_ctx_release(sfm_ctx *ctx)
+{
+    SFM_REQUIRE(ctx, SFM_E_INVALID, "null context");
+    ctx_release(ctx);
+    return SFM_OK;
+}
+
 int sfm_ctx_destroy(sfm_ctx *ctx)
 {
     if (!ctx) return SFM_OK;
+    if (ctx->refs > 0) {                         // pairs / communicators still point here: the last of them destroys the context
+        ctx->destroy_requested = true;
+        return SFM_OK;
+    }
+    return ctx_destroy_now(ctx);
+}
+
+static int ctx_destroy_now(sfm_ctx *ctx)
+{
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->match_ws) (void)hipFree(ctx->match_ws);
+    if (ctx->match_poll_ws) (void)hipFree(ctx->match_poll_ws);
     if (ctx->match_jobs_ws) (void)hipFree(ctx->match_jobs_ws);
     if (ctx->match_pf_ws) (void)hipFree(ctx->match_pf_ws);
     if (ctx->homo_ws) (void)hipFree(ctx->homo_ws);
@@ -400,6 +434,7 @@ int sfm_pair_create(sfm_ctx *ctx, const float h_K[9], const float h_Kinv[9], int
     sfm_pair *p = new (std::nothrow) sfm_pair();
     SFM_REQUIRE(p, SFM_E_NOMEM, "host allocation failed");
     p->ctx = ctx;
+    p->holds_ctx_ref = true; ctx->refs++;
     p->image_count = image_count;
     p->n = num_points;
     p->cap_points = num_points;
@@ -455,7 +490,9 @@ int sfm_pair_destroy(sfm_pair *p)
     if (p->pipe_call) (void)hipEventDestroy(p->pipe_call);
     if (p->cells_ev) (void)hipEventDestroy(p->cells_ev);
     if (p->pipe_keys) (void)hipFree(p->pipe_keys);
+    sfm_ctx *owner = p->holds_ctx_ref ? p->ctx : nullptr;
     delete p;
+    ctx_release(owner);
     return SFM_OK;
 }
 
@@ -1107,6 +1144,7 @@ int sfm_process_pairs(sfm_ctx *ctx, const float h_K[9], const float h_Kinv[9], c
             }
             if (!c->pool_pair) {
                 rc = sfm_pair_create(c, h_K, h_Kinv, 2, max_n, &c->pool_pair);
+                if (rc == SFM_OK) { c->pool_pair->holds_ctx_ref = false; c->refs--; }      // the context's own pair: destroyed WITH the context
                 if (rc != SFM_OK) return rc;
                 memcpy(c->pool_K, h_K, 36); memcpy(c->pool_Kinv, h_Kinv, 36);
             }

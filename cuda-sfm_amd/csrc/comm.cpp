@@ -75,6 +75,7 @@ extern "C" int sfm_comm_init(sfm_ctx *ctx, const void *id128, int rank, int nran
         delete c;
         return fail("hipMalloc", "the communicator's status word");
     }
+    (void)sfm_ctx_retain(ctx);          // the communicator points at the context: it stays valid until sfm_comm_destroy (sfm_amd.h)
     *out = c;
     return SFM_OK;
 }
@@ -112,7 +113,9 @@ extern "C" int sfm_comm_destroy(sfm_comm *c)
     if (c->xstream) (void)hipStreamDestroy(c->xstream);
     if (c->sstream) (void)hipStreamDestroy(c->sstream);
     if (c->ev_call) (void)hipEventDestroy(c->ev_call);
+    sfm_ctx *ctx = c->ctx;
     delete c;
+    (void)sfm_ctx_release(ctx);
     return SFM_OK;
 }
 

@@ -44,6 +44,11 @@ inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 } // namespace sfm
 
 struct sfm_ctx {
+    // Objects that point at the context (every sfm_pair, every sfm_comm) hold a reference: sfm_ctx_destroy on a context that still
+    // has some only marks it, the last of them to go destroys it -- whatever order a host language's finalizers run in (Python's
+    // cyclic collector destroys a context and its pairs in arbitrary order), nobody is left with a dangling pointer.
+    int refs = 0;
+    bool destroy_requested = false;
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;           // created by sfm_ctx_own_stream, destroyed with the context
@@ -60,6 +65,8 @@ struct sfm_ctx {
     size_t match_ws_bytes = 0;
     size_t match_ticket_bytes = 0;
     unsigned int match_epoch = 0;      // one-match launches of the exact matcher tag their partials with it (match.hip: POLL)
+    void *match_poll_ws = nullptr;     // ... in a buffer nothing else writes (epoch-tagged 64-bit words)
+    size_t match_poll_ws_bytes = 0;
     void *match_jobs_ws = nullptr;     // launch_match_jobs: the job array, tickets and per-split partials of every match of the launch
     size_t match_jobs_ws_bytes = 0;     // zeroed ticket area in front of the partials (grows with the query-block count)
     // pre-filter matcher (match_prefilter.hip): fp16 copies, norms, per-split partials, candidate lists
@@ -167,6 +174,7 @@ struct sfm_pair {
     uint64_t *pipe_keys = nullptr;
     unsigned long long pipe_step = 0;
     bool pipe_pending = false;
+    bool holds_ctx_ref = false;        // this pair counts in ctx->refs (every pair but the context's own pooled one)
     bool have_points = false, have_E = false, have_P = false, have_pose = false;
     bool have_points3d = false;        // linear_triangulation ran for the current pose (sfm_get_points / VBO export need it)
     bool unit_z = false;               // every X z-coordinate is exactly 1 (fillXU with K^-1 last row (0 0 1))

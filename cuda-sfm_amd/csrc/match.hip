@@ -378,16 +378,14 @@ int match_partials_workspace(sfm_ctx *ctx, int qblocks, int nsplit, int n1, unsi
     size_t ticket_bytes = ctx->match_ticket_bytes < 4096 ? 4096 : ctx->match_ticket_bytes;
     if ((size_t)qblocks * 4 > ticket_bytes) ticket_bytes = (size_t)round_up(qblocks * 4, 4096);
     const size_t kTicketBytes = ticket_bytes;
-    // partials: 12 bytes per (split, query) for the ticket scheme, 24 for the polled one (three epoch-tagged 64-bit words); the whole
-    // area is zeroed when it is (re)allocated -- epoch 0 is never used, so a word of a fresh workspace can never pass for a partial
-    const size_t need = kTicketBytes + (size_t)nsplit * n1 * 24;
+    const size_t need = kTicketBytes + (size_t)nsplit * n1 * 12;
     if (need > ctx->match_ws_bytes || kTicketBytes != ctx->match_ticket_bytes) {
         SFM_HIP_TRY(hipStreamSynchronize(ctx->stream));
         const size_t bytes = need > ctx->match_ws_bytes ? need : ctx->match_ws_bytes;
         if (ctx->match_ws) (void)hipFree(ctx->match_ws);
         ctx->match_ws = nullptr; ctx->match_ws_bytes = 0; ctx->match_ticket_bytes = 0;
         SFM_HIP_TRY(hipMalloc(&ctx->match_ws, bytes));
-        SFM_HIP_TRY(hipMemsetAsync(ctx->match_ws, 0, bytes, ctx->stream));
+        SFM_HIP_TRY(hipMemsetAsync(ctx->match_ws, 0, kTicketBytes, ctx->stream));
         ctx->match_ws_bytes = bytes; ctx->match_ticket_bytes = kTicketBytes;
     }
     *tickets = static_cast<unsigned int *>(ctx->match_ws);
@@ -496,9 +494,25 @@ int launch_match(sfm_ctx *ctx, const float *d1, int n1, int ld1, const float *d2
     // tests) keeps the ticket scheme of rounds 1-4.
     static const char *merge_env = getenv("SFM_MATCH_MERGE");
     const bool poll = !(merge_env && merge_env[0] == 't') && (long long)qblocks * nsplit <= 2ll * ctx->num_cus;
-    if (++ctx->match_epoch == 0u) {                          // (2^32 launches later: a stale word could carry the new epoch)
-        SFM_HIP_TRY(hipMemsetAsync(ctx->match_ws, 0, ctx->match_ws_bytes, ctx->stream));
-        ctx->match_epoch = 1u;
+    // The polled partials live in a buffer of their OWN (24 bytes per (split, query): three epoch-tagged 64-bit words) that nothing
+    // else ever writes: the ticket workspace above is shared with the fused matcher, whose floats and indices could land in the
+    // upper half of a polled word and pass for the current epoch.  Zeroed when (re)allocated and when the epoch wraps; epoch 0 is
+    // never used, the epoch only grows: a word carries the current epoch only if THIS launch wrote it.
+    if (poll) {
+        const size_t pneed = (size_t)nsplit * n1 * 24;
+        if (pneed > ctx->match_poll_ws_bytes) {
+            SFM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+            if (ctx->match_poll_ws) (void)hipFree(ctx->match_poll_ws);
+            ctx->match_poll_ws = nullptr; ctx->match_poll_ws_bytes = 0;
+            SFM_HIP_TRY(hipMalloc(&ctx->match_poll_ws, pneed));
+            SFM_HIP_TRY(hipMemsetAsync(ctx->match_poll_ws, 0, pneed, ctx->stream));
+            ctx->match_poll_ws_bytes = pneed;
+        }
+        if (++ctx->match_epoch == 0u) {                      // (2^32 launches later: a stale word could carry the new epoch)
+            SFM_HIP_TRY(hipMemsetAsync(ctx->match_poll_ws, 0, ctx->match_poll_ws_bytes, ctx->stream));
+            ctx->match_epoch = 1u;
+        }
+        wb = static_cast<float *>(ctx->match_poll_ws);
     }
     const unsigned int epoch = ctx->match_epoch;
 #define SFM_MATCH_LAUNCH(CT_, W_, POLL_)                                                                                                      \

@@ -58,7 +58,13 @@ typedef struct sfm_pair sfm_pair;   /* state of one SfM::Image_pair (sfm.h:20-60
 int  sfm_abi_version(void);
 const char *sfm_last_error(void);
 int  sfm_ctx_create(int device_id, sfm_ctx **out);          /* replaces InitCuda + cuBLAS/cuSOLVER handle setup (sfm.cu:46-75) */
+/* Destroys the context -- once nothing points at it any more: every sfm_pair (and every sfm_comm of libsfm_amd_rccl.so) holds a
+ * reference, and a context destroyed while some are alive is only marked; the last of them to be destroyed takes it down.  A host
+ * language whose finalizers run in no particular order (Python's cyclic collector) can therefore never leave a pair with a
+ * dangling context.  sfm_ctx_retain / sfm_ctx_release are that reference count for objects built ON the ABI (the communicator). */
 int  sfm_ctx_destroy(sfm_ctx *ctx);
+int  sfm_ctx_retain(sfm_ctx *ctx);
+int  sfm_ctx_release(sfm_ctx *ctx);
 int  sfm_ctx_set_stream(sfm_ctx *ctx, void *hip_stream);    /* NULL = default stream                                          */
 /* Behaviours of the reference that the product fixes, selectable for A/B runs against it (SURVEY.md, quirk list):
  * SFM_QUIRK_MATCH_TAIL -- FindMaxCorr10's tile loop (matching.cu:325) never visits the last num_pts2 % 32 points of the

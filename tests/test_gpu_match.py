@@ -104,3 +104,30 @@ def test_match_full_size_properties(gpu):
     bad = np.flatnonzero(i != oi)
     assert bad.size == 0, f"{bad.size} of {n} indices differ, first queries {bad[:5]}"
     assert same_bits(b, ob) and same_bits(s, os_)
+
+
+def test_exact_polled_merge_next_to_the_other_matchers(gpu):
+    """The polled merge of the exact matcher trusts a partial by its epoch tag alone, so nothing else may ever write where it polls:
+    the fused matcher's ticket workspace (floats and row indices: an index equal to the launch counter in the upper half of a polled
+    word would pass for a fresh partial) is a different buffer.  150 alternations of fused and exact launches on one context, sizes
+    whose indices sweep the range of the epochs, every result against the oracle's."""
+    torch, dev, ctx = gpu
+    rng = np.random.default_rng(5)
+    n1, n2 = 1500, 2049
+    d1, _, _ = synth.descriptors(n1, seed=11)
+    d2, _, _ = synth.descriptors(n2, seed=12)
+    ob, os_, oi = O.match_desc(d1, d2)
+    t1, t2 = to_dev(torch, dev, d1), to_dev(torch, dev, d2)
+    best = torch.empty(n1, dtype=torch.float32, device=dev); sec = torch.empty_like(best); idx = torch.empty(n1, dtype=torch.int32, device=dev)
+    try:
+        for it in range(150):
+            ctx.set_match_kernel(S.MATCH_FUSED)
+            ctx.match_soa(t1, n1, 128, t2, n2, 128, best, sec, idx)
+            ctx.set_match_kernel(S.MATCH_EXACT)
+            best.fill_(-1.0); sec.fill_(-1.0); idx.fill_(-9)
+            ctx.match_soa(t1, n1, 128, t2, n2, 128, best, sec, idx)
+            torch.cuda.synchronize()
+            assert ctx.last_match_kernel() == S.MATCH_EXACT
+            assert np.array_equal(idx.cpu().numpy(), oi) and same_bits(best.cpu().numpy(), ob) and same_bits(sec.cpu().numpy(), os_), it
+    finally:
+        ctx.set_match_kernel(S.MATCH_AUTO)

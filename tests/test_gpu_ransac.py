@@ -376,3 +376,27 @@ def test_finalize_from_a_key_that_names_no_hypothesis(gpu):
     pair.estimateE(p)                                          # and the pair is still usable
     assert pair.get_best()[0] < 10
 
+
+
+def test_a_context_outlives_its_destroy_call_while_pairs_point_at_it(gpu):
+    """sfm_ctx_destroy on a context with live pairs only marks it (include/sfm_amd.h): a host language whose finalizers run in no
+    particular order -- Python's cyclic collector at interpreter exit did, and an Image_pair then synchronised a freed context's stream
+    -- cannot leave a pair with a dangling pointer.  The pair keeps working; the last pair to go takes the context down."""
+    torch, dev, _ = gpu
+    n = 600
+    scene = synth.two_view_scene(n, seed=31)
+    ctx2 = S.Context(0, torch.cuda.current_stream().cuda_stream)
+    pair_a, d_sift = make_pair(S, (torch, dev, ctx2), scene)
+    pair_b = S.ImagePair(ctx2, scene["K"], scene["Kinv"], 2, n)
+    ctx2.close()                                            # the owner lets go first
+    assert ctx2._h is None
+    p = S.default_params(n, num_hypotheses=300, seed=4)
+    pair_a.estimateE(p)                                     # ... and the pair still has a valid context under it
+    _, _, X0, X1 = oracle_xu(scene)
+    key, ocounts, _ = O.ransac_range(X0, X1, 0, 300, p.threshold, 0, seed=4)
+    assert pair_a.get_key() == key and np.array_equal(pair_a.get_inlier_counts(300), ocounts)
+    pair_b.fillXU(d_sift)
+    pair_a.close()
+    pair_b.estimateE(p)
+    assert pair_b.get_key() == key
+    pair_b.close()                                          # the last reference: the context goes with it
