@@ -58,13 +58,14 @@ template <int RULE> struct PfLds {
     static constexpr int kFrag = 0;
     static constexpr int kTileMax = kPfTileMax;
     int staged, pts, ring, wave, next, bytes;
-    __host__ __device__ explicit PfLds(int tile)
+    __host__ __device__ explicit PfLds(int tile, int ring_entries = kPfRing)
     {
         staged = (tile + 63) & ~63;                           // points staged: whole iterations of two blocks (beyond `tile`: padding)
         pts = kFrag + (staged / 32) * kBlockBytes;            // float4 (x2x, x1x, x2y, x1y) per point
         ring = pts + staged * 16;                             // the wavefronts' survivor rings, 1024 bytes each, 1024-byte aligned (a slot's
                                                               // address is (offset & 1023) | base: one v_and_or_b32): staged is a multiple of 64
-        wave = ring + kPfWaves * kPfRing * 8;                 // per wavefront: E table 9 x 32 floats (component-major), 32 counters
+        ring = (ring + ring_entries * 8 - 1) & ~(ring_entries * 8 - 1);
+        wave = ring + kPfWaves * ring_entries * 8;            // per wavefront: E table 9 x 32 floats (component-major), 32 counters
         next = wave + kPfWaves * kPfWaveBytes;                // the block's pass counter
         bytes = next + 16;
     }
@@ -187,7 +188,8 @@ __device__ __forceinline__ void mfma_step(const PfFrags &a, const PfFrags &b, f1
 // atomics, a ticket per 32-hypothesis group, the last wavefront re-reads the counts (two dependent round trips per pass).
 constexpr int kPfVarTickets = 1;
 
-template <int W, int VAR = 0, int RULE = kPfRuleBand>
+// FL2 (experiment): a ring of 256 entries, flushed 128 at a time -- two entries per lane, their LDS reads issued together
+template <int W, int VAR = 0, int RULE = kPfRuleBand, int FL2 = 0>
 __global__ __launch_bounds__(W * 64)
 void ransac_score_prefilter(const float *__restrict__ X0, const float *__restrict__ X1, int ld, int n,
                             const float *__restrict__ Ecand, const PfRecord *__restrict__ recs, uint32_t h0, uint32_t count, float thr,
@@ -219,7 +221,8 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
     const uint32_t npass = (count + (uint32_t)kPfGroup - 1u) / (uint32_t)kPfGroup;
     const uint32_t nstatic = gridDim.x * (uint32_t)W;             // passes handed out by position
     using LT = PfLds<RULE>;
-    const LT L(tile);
+    constexpr int kRing = FL2 ? 256 : kPfRing;
+    const LT L(tile, kRing);
     float *etab = reinterpret_cast<float *>(smem + L.wave + wave * kPfWaveBytes);
     int *cnt = reinterpret_cast<int *>(etab + 32 * kPfERow);
 
@@ -303,8 +306,8 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
     const float4 *pts = reinterpret_cast<const float4 *>(smem + L.pts);
     lds_cf *etab_l = (lds_cf *)etab;
     lds_i *cnt_l = (lds_i *)cnt;
-    const uint32_t ring_base = (uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char *)(smem + L.ring) + (uint32_t)wave * (uint32_t)(kPfRing * 8);
-    uint32_t ring_mask = (uint32_t)(kPfRing * 8 - 1);
+    const uint32_t ring_base = (uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char *)(smem + L.ring) + (uint32_t)wave * (uint32_t)(kRing * 8);
+    uint32_t ring_mask = (uint32_t)(kRing * 8 - 1);
     asm("" : "+v"(ring_mask));                            // in a vector register: v_and_or_b32 takes one scalar operand, and that is the base
     auto ring_at = [&](uint32_t index8) {                 // index8 = 8 x (slot index, not yet wrapped)
         return (lds_u2 *)((__attribute__((address_space(3))) unsigned char *)0 + ((index8 & ring_mask) | ring_base));
@@ -390,8 +393,38 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
                 const int slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(more >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)more, 0u));
                 if (rest) *ring_at(((uint32_t)(head + nq) + (uint32_t)slot) * 8u) = u2v{ rest, tag };
             }
-            head = (head + m) & (kPfRing - 1);
+            head = (head + m) & (kRing - 1);
             nq += __builtin_popcountll(more) - m;
+        };
+        // 128 entries, two per lane (FL2): both entries' LDS reads are in flight before either is used
+        auto flush2 = [&]() {
+            const u2v entA = *ring_at(((uint32_t)head + (uint32_t)lane) * 8u), entB = *ring_at(((uint32_t)head + 64u + (uint32_t)lane) * 8u);
+            const int bA = __builtin_clz(entA.x), bB = __builtin_clz(entB.x);
+            const uint32_t restA = entA.x & ~(0x80000000u >> bA), restB = entB.x & ~(0x80000000u >> bB);
+            const int rA = bA >> 1, rB = bB >> 1;
+            const int hlA = rA + (rA & 12) + (int)(entA.y & 4u), hlB = rB + (rB & 12) + (int)(entB.y & 4u);
+            const int hcA = min(hlA, nvalid - 1), hcB = min(hlB, nvalid - 1);          // rows beyond the range: evaluated on a valid row, never counted
+            const f4v qA = *(lds_cf4 *)((__attribute__((address_space(3))) const unsigned char *)0 + ((entA.y & ~15u) + ((uint32_t)(bA & 1) << 9)));
+            const f4v qB = *(lds_cf4 *)((__attribute__((address_space(3))) const unsigned char *)0 + ((entB.y & ~15u) + ((uint32_t)(bB & 1) << 9)));
+            lds_cf *eA = etab_l + hcA, *eB = etab_l + hcB;
+            const v2f a0 = { eA[0], eA[32] }, a1 = { eA[64], eA[96] }, a2 = { eA[128], eA[160] }, a3 = { eA[192], eA[224] };
+            const float a8 = eA[256];
+            const v2f b0 = { eB[0], eB[32] }, b1 = { eB[64], eB[96] }, b2 = { eB[128], eB[160] }, b3 = { eB[192], eB[224] };
+            const float b8 = eB[256];
+            const bool inA = pf_exact_inlier(a0, a1, a2, a3, a8, v2f{ qA.x, qA.y }, v2f{ qA.z, qA.w }, band);
+            const bool inB = pf_exact_inlier(b0, b1, b2, b3, b8, v2f{ qB.x, qB.y }, v2f{ qB.z, qB.w }, band);
+            if (inA && hlA < nvalid) __hip_atomic_fetch_add(cnt_l + hlA, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (inB && hlB < nvalid) __hip_atomic_fetch_add(cnt_l + hlB, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const unsigned long long moreA = __ballot(restA != 0u), moreB = __ballot(restB != 0u);
+            if (moreA | moreB) {
+                const int nA = __builtin_popcountll(moreA);
+                const int slotA = __builtin_amdgcn_mbcnt_hi((uint32_t)(moreA >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)moreA, 0u));
+                const int slotB = nA + __builtin_amdgcn_mbcnt_hi((uint32_t)(moreB >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)moreB, 0u));
+                if (restA) *ring_at(((uint32_t)(head + nq) + (uint32_t)slotA) * 8u) = u2v{ restA, entA.y };
+                if (restB) *ring_at(((uint32_t)(head + nq) + (uint32_t)slotB) * 8u) = u2v{ restB, entB.y };
+            }
+            head = (head + 128) & (kRing - 1);
+            nq += __builtin_popcountll(moreA) + __builtin_popcountll(moreB) - 128;
         };
 
         PfFrags fa = load_point_frags<RULE>(frag_lane, 0), fb = load_point_frags<RULE>(frag_lane, 1);
@@ -426,6 +459,8 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
             const unsigned long long any = __ballot(mine);
             SFM_PHASE("append_and_inloop_flush");
             if (any) {
+                if (FL2) { while (nq >= 128) flush2(); }
+                else
                 while (nq >= 64) flush(64);             // make room first (a flush of 64 entries re-queues up to 64: it may take more than one)
                 const int slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(any >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)any, 0u));
                 if (mine) *ring_at(((uint32_t)(head + nq) + (uint32_t)slot) * 8u) = u2v{ ~rej32, lane_tag + ((uint32_t)pp << 10) };
@@ -440,6 +475,7 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
         uint32_t key0n = 0u;
         if (have_next) fetch_pass(ps_next, afrag_next, key0n, e_row);
         SFM_PHASE("drain_flush");
+        if (FL2) { while (nq >= 128) flush2(); }
         while (nq > 0) flush(min(nq, 64));
         SFM_PHASE("epilogue");
         PF_PHASE(7);
@@ -824,7 +860,8 @@ int launch_score_prefilter(sfm_pair *pair, const sfm_ransac_params &p, uint32_t 
     const int dynamic = SFM_SW(p, 1) == 2 ? 0 : 1;                               // (AB build, reserved[1] == 2: static striding)
     const int var = SFM_SW(p, 3) >= 16 ? SFM_SW(p, 3) - 16 : 0;                 // (AB build, reserved[3] = 16 + VAR bits)
     const int rule = prefilter_rule(p);
-    const int lds_bytes = rule == kPfRuleBand ? PfLds<kPfRuleBand>(tile).bytes : PfLds<kPfRuleG>(tile).bytes;
+    const bool fl2 = rule == kPfRuleBand && waves == kPfWaves && SFM_SW(p, 1) == 9;      // (AB build: 256-entry ring, two entries per lane per flush)
+    const int lds_bytes = fl2 ? PfLds<kPfRuleBand>(tile, 256).bytes : rule == kPfRuleBand ? PfLds<kPfRuleBand>(tile).bytes : PfLds<kPfRuleG>(tile).bytes;
     if (lds_bytes > 160 * 1024) { set_error("pre-filter tile of %d points needs %d bytes of LDS", tile, lds_bytes); return SFM_E_INVALID; }
     auto launch = [&](auto kernel) -> int {
         const int rc_lds = allow_big_lds(ctx, reinterpret_cast<const void *>(kernel));
@@ -840,10 +877,11 @@ int launch_score_prefilter(sfm_pair *pair, const sfm_ransac_params &p, uint32_t 
     else if (rule == kPfRuleG && var == 1) rcl = launch(&ransac_score_prefilter<16, 1, kPfRuleG>);
     else if (rule == kPfRuleG) rcl = launch(&ransac_score_prefilter<16, 0, kPfRuleG>);
     else if (waves == 12) rcl = launch(&ransac_score_prefilter<12, 0, kPfRuleBand>);
+    else if (fl2) rcl = launch(&ransac_score_prefilter<16, 0, kPfRuleBand, 1>);
     else
 #endif
     rcl = launch(&ransac_score_prefilter<16, 0, kPfRuleBand>);
-    (void)var;
+    (void)var; (void)fl2;
     if (rcl != SFM_OK) return rcl;
     SFM_HIP_TRY(hipGetLastError());
     pair->last_grid = (int)cols * ntiles; pair->last_block = waves * 64; pair->last_lds = lds_bytes;
