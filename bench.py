@@ -45,6 +45,7 @@ sys.path.insert(0, ROOT)
 N_MATCHES = 4096              # "4k matches" of the BASELINE metric
 TOTAL_HYPS = 1 << 20          # hypotheses per step over the whole job (BASELINE configs[3] count)
 FP32_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: 256 CU x 256 FLOP/clk x 2.4 GHz
+HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 FP16_MFMA_PEAK_TFLOPS = 2516.6  # dense fp16 MFMA: 256 CU x 4096 FLOP/clk x 2.4 GHz (MI355X_MICROARCH.md, no sparsity)
 PEAK_CLOCK_MHZ = 2400.0
 NUM_SIMDS = 1024              # 256 CU x 4
@@ -502,6 +503,37 @@ def extra_ransac(S, synth, O, ctx, dev, torch, np, name, n, H, steps, hyp_count=
     return out
 
 
+MATCH_TRAFFIC_JSON = os.path.join("profiles", "r05_match_traffic.json")
+MATCH_SOURCES = ("match.hip", "match_fused.hip", "match_prefilter.hip", "match_common.hpp", "match_prefilter_math.hpp")
+
+
+def match_traffic(n, prefixes, ms):
+    """HBM bytes per sfm_match_soa call from the committed PMC passes (profiles/pmc_match.sh: FETCH_SIZE / WRITE_SIZE in passes of their
+    own, KB), summed over the kernels of the family that ran, and the GB/s that is at the time measured HERE; quoted only when the
+    matcher sources are the ones the counters were collected on."""
+    try:
+        with open(os.path.join(ROOT, MATCH_TRAFFIC_JSON)) as f:
+            doc = json.load(f)
+        h = hashlib.sha256()
+        for name in MATCH_SOURCES:
+            with open(os.path.join(ROOT, "cuda-sfm_amd", "csrc", name), "rb") as f:
+                h.update(f.read())
+        have = h.hexdigest()[:16]
+        if doc.get("code_sha256_16") != have:
+            return {"note": f"{MATCH_TRAFFIC_JSON} was collected on matcher sources {doc.get('code_sha256_16')}, this tree has {have}: not quoted"}
+        ks = {k: v for k, v in doc.get("sizes", {}).get(str(n), {}).items() if any(k.startswith(p) for p in prefixes)}
+        if not ks or any(v.get("fetch_kb") is None or v.get("write_kb") is None for v in ks.values()):
+            return {"note": f"{MATCH_TRAFFIC_JSON} has no FETCH_SIZE / WRITE_SIZE for this kernel family at n = {n}"}
+        fetch = sum(v["fetch_kb"] for v in ks.values()) * 1024.0
+        write = sum(v["write_kb"] for v in ks.values()) * 1024.0
+        algorithmic = 2.0 * n * 128 * 4 + n * 12.0       # both descriptor sets once + best, second, index
+        return {"kernels": sorted(ks), "fetch_bytes": fetch, "write_bytes": write, "algorithmic_bytes": algorithmic,
+                "hbm_gb_per_s_at_this_time": (fetch + write) / ms / 1e6, "frac_of_hbm_peak": (fetch + write) / ms / 1e6 / HBM_PEAK_GBS,
+                "source": f"{MATCH_TRAFFIC_JSON} (rocprofv3 --pmc passes of profiles/pmc_match.sh on sources {have}; quoted, not collected by this run)"}
+    except Exception as e:  # noqa: BLE001 - the counters are optional evidence
+        return {"note": f"{MATCH_TRAFFIC_JSON}: {type(e).__name__}"}
+
+
 def extra_match(S, synth, O, ctx, dev, torch, np, n, reps):
     d1, d2, perm = synth.descriptors(n)
     t1, t2 = torch.from_numpy(d1).to(dev), torch.from_numpy(d2).to(dev)
@@ -523,6 +555,7 @@ def extra_match(S, synth, O, ctx, dev, torch, np, n, reps):
            "algorithmic_tflops": flops / ms / 1e9, "perm_recovered": float((res[2] == perm).mean())}
     if ran == S.MATCH_EXACT:
         out["frac_of_fp32_mfma_peak"] = flops / ms / 1e9 / FP32_PEAK_TFLOPS
+    out["traffic"] = match_traffic(n, {S.MATCH_EXACT: ("match_mfma_kernel",), S.MATCH_PREFILTER: ("match_pf_",), S.MATCH_FUSED: ("match_fused",)}.get(ran, ()), ms)
     if O is not None:
         def check():
             # the CPU matcher restates MatchC1 (CudaSift/match.cu:57-71): EVERY query at every size (16384^2: ~6 s of host time),
