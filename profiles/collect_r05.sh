@@ -31,6 +31,7 @@ python3 profiles/small_h_bench.py > $O/${TAG}_small_h_bench.txt 2>/dev/null
 # 4b. matcher counters on the current kernels (2048^2: exact fp32 MFMA; 16384^2: fp16 pre-filter + exact candidates)
 sh profiles/pmc_match.sh 2048 > $O/pmc_${TAG}_match_2048_summary.txt 2>&1
 sh profiles/pmc_match.sh 16384 > $O/pmc_${TAG}_match_16384_summary.txt 2>&1
+python3 profiles/make_match_traffic_json.py 2048:$O/pmc_${TAG}_match_2048_summary.txt 16384:$O/pmc_${TAG}_match_16384_summary.txt > $O/${TAG}_match_traffic.json
 # 5. rocprof: kernel stats of the bench command (serial steps: one kernel at a time), c3, c4 and a rank's share; pipelined steps
 cd /tmp && export TMPDIR=/tmp
 for cfg in "headline:" "c3:--config c3" "c4:--config c4 --steps 30 --warmup 5" "rank8:--hyps 131072"; do
