@@ -67,11 +67,6 @@ void ransac_solve_lanes1_qr(const float *__restrict__ X0, const float *__restric
                             PfRecord *__restrict__ recs, float thr, PfScales sc, const unsigned long long *__restrict__ bound_word,
                             const uint32_t *__restrict__ cells, uint32_t cells_mask, int rule)
 {
-#if SFM_AB          // (lab bench, reserved[1] == 11 / 12: this kernel's wavefronts at issue priority 3 / 1 next to the scoring kernel of the previous step)
-    if (rule & 0x100) __builtin_amdgcn_s_setprio(3);
-    if (rule & 0x200) __builtin_amdgcn_s_setprio(1);
-    rule &= 0xff;
-#endif
     reset_keys(zero_key, zero_key2);
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     // the pre-filter kernel's per-hypothesis accumulators (two words each: count | tiles arrived), cleared here
@@ -431,7 +426,7 @@ int launch_ransac_score(sfm_pair *pair, const sfm_ransac_params &p, uint32_t h0,
                            pair->d_X[0], pair->d_X[1], pair->ld, pair->n, p.d_indices, p.seed, h0, count,
                            p.jacobi_sweeps, pair->d_Ecand, pair->d_key, key2, zero_counts, zero_ticks, nzero, pts4,
                            fuse ? reinterpret_cast<PfRecord *>(pair->d_pf) : nullptr, p.threshold, pf_sc, pair->d_bound, pair->d_cells, pair->cells_mask,
-                           prefilter_rule(p) | (SFM_SW(p, 1) == 11 ? 0x100 : SFM_SW(p, 1) == 12 ? 0x200 : 0));
+                           prefilter_rule(p));
         if (fuse) need_prep = false;
     }
     else if (p.jacobi_sweeps <= 0)   // default: two hypotheses per lane (packed math), Householder instantiation

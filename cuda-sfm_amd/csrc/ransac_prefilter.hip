@@ -204,8 +204,6 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
     unsigned long long c0 = 0, w0 = 0;
     if (probe) { c0 = clock64(); w0 = wall_clock64(); }
 #if SFM_AB
-    if (dynamic & 0x100) __builtin_amdgcn_s_setprio(2);        // (lab bench, reserved[1] == 14: the scoring wavefronts above the co-resident solve)
-    dynamic &= 0xff;
     // trace (sfm_ransac_last_trace, AB build): start / end stamps of every block and wavefront, a handful of stores per block
     const uint32_t trace_blk = blockIdx.y * gridDim.x + blockIdx.x;
     unsigned long long *trace = (clk && trace_blk < (uint32_t)kTraceBlocks) ? clk + 8 + (size_t)trace_blk * kTraceWords : nullptr;
@@ -859,7 +857,7 @@ int launch_score_prefilter(sfm_pair *pair, const sfm_ransac_params &p, uint32_t 
     if (SFM_SW(p, 2) > 0) cols = (uint32_t)SFM_SW(p, 2);
     if (cols > iters) cols = iters;
     if (cols < 1) cols = 1;
-    const int dynamic = (SFM_SW(p, 1) == 2 ? 0 : 1) | (SFM_SW(p, 1) == 14 ? 0x100 : 0);                               // (AB build, reserved[1] == 2: static striding)
+    const int dynamic = SFM_SW(p, 1) == 2 ? 0 : 1;                               // (AB build, reserved[1] == 2: static striding)
     const int var = SFM_SW(p, 3) >= 16 ? SFM_SW(p, 3) - 16 : 0;                 // (AB build, reserved[3] = 16 + VAR bits)
     const int rule = prefilter_rule(p);
     const bool fl2 = rule == kPfRuleBand && waves == kPfWaves && SFM_SW(p, 1) == 9;      // (AB build: 256-entry ring, two entries per lane per flush)

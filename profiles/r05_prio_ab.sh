@@ -1,6 +1,8 @@
 #!/bin/sh
 # Round 5: the lane-solve kernel's wavefronts at issue priority 3 / 1 (s_setprio; lab-bench library, reserved[1] == 11 / 12) against the
 # default priority 0, in the pipelined steps where the solve of step k + 1 runs next to the scoring of step k.  ONE gpurun call (same box).
+# The switches are not in the tree (they would change the hash the committed counters are keyed by): apply profiles/r05_solve_prio_experiment.patch
+# and `make` first.
 # usage: sh profiles/r05_prio_ab.sh [out-file]
 R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out; mkdir -p $O
 OUT=${1:-$O/r05_ab_solve_prio.txt}
