@@ -396,7 +396,8 @@ def roofline_block(kernel_id, n, local_hyps, score_s, solve_s, clock_mhz, measur
             achieved = pairs * PF_SCAN_VALU_PER_PAIR * 2.0 / score_s / 1e12 if score_s > 0 else 0.0
             detail = (f"vector-ALU issue: the irreducible scan of the {rule} rule is {PF_SCAN_VALU_PER_PAIR} vector instruction(s) per pair "
                       + ("(v_alignbit_b32: bit 30 of the accumulator, |nt| >= 2, into the lane's mask), " if rule == "band" else "(v_fma_f32 G - nt^2, v_alignbit_b32), ")
-                      + "each priced as one FMA lane-slot = 2 FLOP against the plain FP32 vector rate 78.65 TFLOP/s (1024 SIMDs x 16 lanes x 2 FLOP x 2.4 GHz); "
+                      + "a VOP3 instruction, which a SIMD of gfx950 issues every 4.24 cycles (VOP2 fp32 / integer: 2.1; measured, profiles/r05_valu_rate_table.txt), "
+                      + "priced at 4 cycles per wave64 instruction = one FMA lane-slot (2 FLOP) of a 78.65 TFLOP/s rate (1024 SIMDs x 64 lanes / 4 cycles x 2 FLOP x 2.4 GHz); "
                       f"the {PF_MFMA_PER_1024_PAIRS} fp16 MFMAs per 1024 pairs issue next to it (mfma_floor_ms)")
         else:
             bound, peak = "mfma", FP16_MFMA_PEAK_TFLOPS
@@ -407,8 +408,9 @@ def roofline_block(kernel_id, n, local_hyps, score_s, solve_s, clock_mhz, measur
                "valu_floor_ms": 1e3 * valu_floor, "mfma_floor_ms": 1e3 * mfma_floor,
                "frac_at_sustained_clock": (floor / score_s * PEAK_CLOCK_MHZ / clock_mhz) if (score_s > 0 and clock_mhz > 0) else None}
         # Continuity with rounds 2-4, whose kernel executed the G rule (2 vector instructions per pair: floor 0.2185 ms at 2^32 pairs), and
-        # the issue model measured in round 3 (a vector instruction holds a SIMD's issue port for 4 cycles, a 32x32x16 fp16 MFMA for ~16 of
-        # its 32): frac = max(valu, mfma) floors of THIS rule over the launch time; the formulation's floor moved, the launch got shorter.
+        # the issue model fitted in round 3 (4 cycles per vector instruction, ~16 per 32x32x16 fp16 MFMA; round 5 measured why it fits: VOP3
+        # instructions -- the scan's v_alignbit_b32 -- take 4.24 cycles of a SIMD, VOP2 ones 2.1, profiles/r05_valu_rate_table.txt):
+        # frac = max(valu, mfma) floors of THIS rule over the launch time; the formulation's floor moved, the launch got shorter.
         g_floor = pairs * 2 / 64.0 / NUM_SIMDS * 4.0 / clock
         model = pairs / 1024.0 * (4.0 * 16 * PF_SCAN_VALU_PER_PAIR + 16.0 * PF_MFMA_PER_1024_PAIRS) / NUM_SIMDS / clock
         out["rule"] = rule

@@ -36,8 +36,15 @@ __device__ __forceinline__ void reset_keys(unsigned long long *key, unsigned lon
     }
 }
 
-#if SFM_AB          // the generic one-hypothesis-per-lane kernel (either solver): reserved[0] == 1; the product runs lanes1_qr / lanes2
-__global__ __launch_bounds__(64)
+// The generic one-hypothesis-per-lane kernel (either solver).  The product runs it for the normal-equations + Jacobi solver
+// (jacobi_sweeps > 0) with the register allocation capped at 256 (WPE = 2): S (45) and V (81) of one hypothesis and the round's
+// temporaries fit with one spill, and TWO wavefronts per SIMD issue an instruction every ~5.4 cycles where one issues every ~10
+// whatever its instruction-level parallelism (profiles/r05_pk_fma_probe.txt).  Measured at 4096 x 2^20, 7 sweeps
+// (profiles/r05_ab_jacobi_lanes.txt): 0.66 ms against 0.79 for two hypotheses per lane packed (502 registers, one wavefront per
+// SIMD, v_pk_* at 1.3-1.5 x the issue time of the plain instructions), 1.00 unconstrained (257 registers: one wavefront per
+// SIMD), 0.69 capped at 168 (99 spills).  Lab bench, reserved[0]: 1 = unconstrained, 7 = capped at 168, 2 = packed.
+template <int WPE>          // wavefronts per SIMD the register allocation must allow (1: unconstrained)
+__global__ __launch_bounds__(64, WPE)
 void ransac_solve_lanes(const float *__restrict__ X0, const float *__restrict__ X1, int ld, int n,
                         const int32_t *__restrict__ indices, uint32_t seed, uint32_t h0, uint32_t count,
                         int sweeps, float *__restrict__ Ecand, unsigned long long *zero_key, unsigned long long *zero_key2,
@@ -53,7 +60,6 @@ void ransac_solve_lanes(const float *__restrict__ X0, const float *__restrict__ 
 #pragma unroll
     for (int k = 0; k < 9; ++k) Ecand[9 * (size_t)i + k] = E[k];
 }
-#endif
 
 // One hypothesis per lane, Householder solver only (the scalar instantiation of the same templates: bit-identical).  Half the
 // registers of the packed kernel below, so twice the hypotheses are in flight per SIMD and every wavefront walks a chain of plain
@@ -415,10 +421,12 @@ int launch_ransac_score(sfm_pair *pair, const sfm_ransac_params &p, uint32_t h0,
         if (zero_counts) SFM_HIP_TRY(hipMemsetAsync(pair->d_counts, 0, (size_t)count * sizeof(int), ctx->stream));
     }
 #if SFM_AB
-    else if (p.reserved[0] == 1)     // A/B switch: one hypothesis per lane (scalar math)
-        hipLaunchKernelGGL(ransac_solve_lanes, dim3((count + 63) / 64), dim3(64), 0, ctx->stream,
+    else if (p.reserved[0] == 1 || p.reserved[0] == 7) {     // A/B switch: one hypothesis per lane, registers unconstrained / capped at 168
+        auto kern = p.reserved[0] == 1 ? ransac_solve_lanes<1> : ransac_solve_lanes<3>;
+        hipLaunchKernelGGL(kern, dim3((count + 63) / 64), dim3(64), 0, ctx->stream,
                            pair->d_X[0], pair->d_X[1], pair->ld, pair->n, p.d_indices, p.seed, h0, count,
                            p.jacobi_sweeps, pair->d_Ecand, pair->d_key, key2, zero_counts, zero_ticks, nzero);
+    }
 #endif
     else if (p.jacobi_sweeps <= 0 && (SFM_SW(p, 0) == 3 || (SFM_SW(p, 0) == 0 && (pts4 != nullptr || count <= kScalarSolveMax)))) {     // one hypothesis per lane
         const bool fuse = need_prep && SFM_SW(p, 3) != 3;                // (AB build, reserved[3] == 3: records from the stand-alone kernel)
@@ -433,10 +441,16 @@ int launch_ransac_score(sfm_pair *pair, const sfm_ransac_params &p, uint32_t h0,
         hipLaunchKernelGGL(ransac_solve_lanes2<true>, dim3((count + 127) / 128), dim3(64), 0, ctx->stream,
                            pair->d_X[0], pair->d_X[1], pair->ld, pair->n, p.d_indices, p.seed, h0, count,
                            p.jacobi_sweeps, pair->d_Ecand, pair->d_key, key2, zero_counts, zero_ticks, nzero, pts4);
-    else
+#if SFM_AB
+    else if (p.reserved[0] == 2)     // A/B switch: the Jacobi solver two hypotheses per lane, packed (the product's choice up to round 4)
         hipLaunchKernelGGL(ransac_solve_lanes2<false>, dim3((count + 127) / 128), dim3(64), 0, ctx->stream,
                            pair->d_X[0], pair->d_X[1], pair->ld, pair->n, p.d_indices, p.seed, h0, count,
                            p.jacobi_sweeps, pair->d_Ecand, pair->d_key, key2, zero_counts, zero_ticks, nzero, pts4);
+#endif
+    else                             // normal equations + Jacobi: one hypothesis per lane, two wavefronts per SIMD
+        hipLaunchKernelGGL(ransac_solve_lanes<2>, dim3((count + 63) / 64), dim3(64), 0, ctx->stream,
+                           pair->d_X[0], pair->d_X[1], pair->ld, pair->n, p.d_indices, p.seed, h0, count,
+                           p.jacobi_sweeps, pair->d_Ecand, pair->d_key, key2, zero_counts, zero_ticks, nzero);
     SFM_HIP_TRY(hipGetLastError());
     if (need_prep) {
         const int rcp = launch_pf_prep(pair, p, count);

@@ -122,6 +122,30 @@ def test_lane_solve_variants_give_the_oracle_candidates(gpu_ab, n, H):
         pair.ransac_score(p)
         assert same_bits(pair.get_E_candidates(H).reshape(H, 9), cands[0]), ("set_points", variant)
 
+@pytest.mark.parametrize("n,H", [(900, 2500), (4096, 70001)])
+def test_jacobi_lane_solve_variants_give_the_oracle_candidates(gpu_ab, n, H):
+    """The normal-equations + Jacobi solver (jacobi_sweeps = 7) above the fused kernel's range: one hypothesis per lane with the
+    registers capped at 256 (the product's arrangement), two per lane packed (the product up to round 4), one per lane unconstrained
+    and capped at 168 (spills) -- every hypothesis' E equal to the oracle's, bit for bit."""
+    torch, dev, ctx = gpu_ab
+    scene = synth.two_view_scene(n, seed=500 + n)
+    pair, _ = make_pair(S, gpu_ab, scene)
+    _, _, X0, X1 = O.fill_xu(scene["sift"], scene["Kinv"])
+    Hs = min(H, 1024)
+    _, _, e_head = O.ransac_range(X0, X1, 0, Hs, 1e-6, 7, seed=11, want_E=True)
+    _, _, e_tail = O.ransac_range(X0, X1, H - Hs, Hs, 1e-6, 7, seed=11, want_E=True)
+    cands = {}
+    for variant in (0, 2, 1, 7):
+        p = S.default_params(n, num_hypotheses=H, seed=11, kernel=S.KERNEL_SPLIT)
+        p.jacobi_sweeps = 7
+        p.reserved[0] = variant
+        pair.ransac_score(p)
+        cands[variant] = pair.get_E_candidates(H).reshape(H, 9).copy()
+        assert same_bits(cands[variant][:Hs], e_head.reshape(Hs, 9)) and same_bits(cands[variant][H - Hs:], e_tail.reshape(Hs, 9)), variant
+    for variant in (2, 1, 7):
+        assert same_bits(cands[variant], cands[0]), variant
+
+
 def test_prefilter_operands_on_the_device_equal_the_host_build(gpu_ab):
     """sfm_prefilter_probe: the fp16 coefficient and feature slots the device builds for one (hypothesis, point) pair, against
     tests/hostcheck (the same header compiled for the host) bit for bit -- random pairs, the committed tie cases, crafted
