@@ -1068,11 +1068,12 @@ def rank_main(args):
     if not args.no_variants:
         main_sweeps = params.jacobi_sweeps
         params.jacobi_sweeps = 7 if main_sweeps == 0 else 0
-        for _ in range(2):
+        VSTEPS = 20
+        for _ in range(3):
             step()
         fence()
         vt0 = time.perf_counter()
-        for _ in range(5):
+        for _ in range(VSTEPS):
             step()
         fence()
         vel = time.perf_counter() - vt0
@@ -1082,7 +1083,7 @@ def rank_main(args):
             vel = float(t.item())
         vh, vc = pair.get_best()
         variant = {"solver": "normal equations + 7 Jacobi sweeps" if params.jacobi_sweeps == 7 else "householder QR of the 8x9 system",
-                   "value": H * 5 / vel, "ms_per_step": 1e3 * vel / 5, "best_hypothesis": vh, "inliers": vc}
+                   "value": H * VSTEPS / vel, "ms_per_step": 1e3 * vel / VSTEPS, "steps": VSTEPS, "best_hypothesis": vh, "inliers": vc}
         params.jacobi_sweeps = main_sweeps
         params.seed = last_seed
 
