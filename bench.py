@@ -417,6 +417,12 @@ def roofline_block(kernel_id, n, local_hyps, score_s, solve_s, clock_mhz, measur
         out["frac_against_the_round4_floor"] = (g_floor / score_s) if score_s > 0 else 0.0
         out["frac_against_the_issue_model"] = (model / score_s) if score_s > 0 else 0.0
         out["issue_model_floor_ms"] = 1e3 * model
+        if rule == "band":
+            # measured in isolation (profiles/r05_mfma_valu_overlap_probe.txt): the scan phase of 1024 pairs -- two fp16 MFMAs and sixteen
+            # v_alignbit_b32 -- takes 85 cycles of a SIMD with four wavefronts on it (69 / 67 for either half alone), before any survivor
+            scan = pairs / 1024.0 * 85.0 / NUM_SIMDS / clock
+            out["measured_scan_floor_ms"] = 1e3 * scan
+            out["frac_against_the_measured_scan_floor"] = (scan / score_s) if score_s > 0 else 0.0
     else:
         out = {"bound": "valu_fp32",
                "bound_detail": ("FP32 vector ALU issue (v_pk_fma_f32 and friends); 157.3 TFLOP/s = 256 CU x 256 FLOP/clk x 2.4 GHz, "
