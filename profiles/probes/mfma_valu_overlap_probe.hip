@@ -1,7 +1,7 @@
 // How much of the matrix pipe's time do vector instructions of the same SIMD overlap?  The scoring kernel's phase in miniature: 2 x
 // v_mfma_f32_32x32x16_f16 (one 32 x 32 x K32 tile, accumulators n) + 16 x v_alignbit_b32 on the OTHER accumulator set (independent of the
 // MFMAs in flight), 128 phases per timed block, 1 / 2 / 4 wavefronts per SIMD; the block's span (s_memtime) / phases per SIMD.
-// Build: hipcc -O3 --offload-arch=gfx950 -o profiles/probes/mfma_valu_overlap_probe profiles/probes/mfma_valu_overlap_probe.hip
+// Build: hipcc -O3 --offload-arch=gfx950 -o profiles/probes/mfma_valu_overlap_probe.bin profiles/probes/mfma_valu_overlap_probe.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
 

@@ -2,7 +2,7 @@
 // with s_memtime (shader cycles) by wavefront 0 of block 0 between two barriers; 1 / 2 / 4 / 8 wavefronts per SIMD (blocks of 256 / 512 / 1024
 // threads, one or two blocks per CU).  Chains: "dep" = every instruction reads the previous one's result, "ind8" = eight independent chains
 // interleaved, "ind2" / "ind4" = two / four.
-// Build: hipcc -O3 --offload-arch=gfx950 -o profiles/probes/valu_issue_probe profiles/probes/valu_issue_probe.hip
+// Build: hipcc -O3 --offload-arch=gfx950 -o profiles/probes/valu_issue_probe.bin profiles/probes/valu_issue_probe.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
 

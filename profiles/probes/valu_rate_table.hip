@@ -1,7 +1,7 @@
 // Which vector instructions of gfx950 run at the full SIMD-32 rate (a wave64 instruction every 2 cycles per SIMD) and which at half of it?
 // Four independent chains per wavefront, 4 wavefronts per SIMD (blocks of 1024 threads, one per CU), straight-line blocks of 256
 // instructions; cycles = the block's span (first start to last end, s_memtime) / instructions per SIMD.
-// Build: hipcc -O3 --offload-arch=gfx950 -o profiles/probes/valu_rate_table profiles/probes/valu_rate_table.hip
+// Build: hipcc -O3 --offload-arch=gfx950 -o profiles/probes/valu_rate_table.bin profiles/probes/valu_rate_table.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
 
