@@ -21,13 +21,16 @@ extern "C" {
 #define SFM_KERNEL_MFMA   3
 
 /* sfm_ransac_params.reserved[] in this flavour (0 = the product's behaviour):
- *   [0] solve kernel: 1 generic one-hypothesis-per-lane kernel, 2 packed two-per-lane, 3 scalar Householder, 4 scattered
- *       dword gathers instead of the 16-byte point records;
+ *   [0] solve kernel: 1 generic one-hypothesis-per-lane kernel with unconstrained registers (the product runs it capped at 256
+ *       for the Jacobi solver), 7 the same capped at 168, 2 packed two-per-lane (Householder or Jacobi), 3 scalar Householder,
+ *       4 scattered dword gathers instead of the 16-byte point records;
  *   [1] 1 tile loop inside the scoring block instead of the tile-parallel grid (n > 4096); 2 pre-filter passes handed out by
- *       position instead of through the block's LDS counter; 5 twelve wavefronts per pre-filter block;
+ *       position instead of through the block's LDS counter; 5 twelve wavefronts per pre-filter block; 7 tiles of up to 1536
+ *       points; 9 a 256-entry ring flushed 128 entries at a time;
  *   [2] k > 0: minimum hypothesis batches per scoring block (default 8); pre-filter kernel: grid columns;
  *   [3] 1 AUTO never picks SFM_KERNEL_PREFILTER; 2 the round-2 pre-filter kernel (csrc/ab/ransac_prefilter_r2.hip);
- *       3 per-hypothesis records from the stand-alone kernel instead of the lane-solve kernel. */
+ *       3 per-hypothesis records from the stand-alone kernel instead of the lane-solve kernel; 4 the G rule of rounds 2-4
+ *       (per-pair threshold, three MFMAs per 32 x 32 pairs) instead of the band rule; 16 + bits: recorded variants built on it. */
 
 /* Where block 0 of the last pre-filter scoring launch (SFM_KERNEL_PREFILTER) spent its time: ticks[0] shader-clock ticks and
  * ticks[1] 100 MHz ticks over its lifetime (as above); 100 MHz ticks since its start at: [2] tile staged, [3] first pass'
