@@ -256,15 +256,17 @@ class Context:
                                         int(bool(survive_all)), out.ctypes.data_as(_vp)), "sfm_prefilter_probe")
         return {"ns": out[0:32], "ts": out[32:48], "bn": out[48:80], "bt": out[80:96], "nt": out[96], "G": out[97], "rejected": bool(out[98]), "zero_divisor_state": int(out[99])}
 
-    def prefilter_band_probe(self, E, threshold, bound, box, b_safe, point, survive_all=False):
-        """The band rule's operands and matrix-core result of one (hypothesis, point) pair (test probe; lab-bench flavour only)."""
+    def prefilter_band_probe(self, E, threshold, bound, box, b_safe, point, survive_all=False, pack=False):
+        """The band rule's operands and matrix-core result of one (hypothesis, point) pair (test probe; lab-bench flavour only).
+        pack: the packed scan of round 6 (sigma = 1.873 / W, `rejected` from the six-bit conversion).  pack_slots_ok / pack_bit: the
+        conversion, the bit picking and the survivor table on the RAW value point[0] in each of the 32 (accumulator, step) slots."""
         e = np.ascontiguousarray(E, np.float32).reshape(9); pt = np.ascontiguousarray(point, np.float32).reshape(4)
         bx = np.ascontiguousarray(box, np.float32).reshape(8)
         out = np.zeros(104, np.float32)
         _check(_lib.sfm_prefilter_band_probe(self._h, e.ctypes.data_as(_vp), C.c_float(float(threshold)), C.c_float(float(bound)), bx.ctypes.data_as(_vp),
-                                             int(bool(b_safe)), pt.ctypes.data_as(_vp), int(bool(survive_all)), out.ctypes.data_as(_vp)), "sfm_prefilter_band_probe")
+                                             int(bool(b_safe)) | (2 if pack else 0), pt.ctypes.data_as(_vp), int(bool(survive_all)), out.ctypes.data_as(_vp)), "sfm_prefilter_band_probe")
         return {"ns": out[0:32], "bn": out[48:80], "nt": out[96], "sigma": out[97], "rejected": bool(out[98]),
-                "zero_divisor_state": int(out[99]), "second_divisor_state": int(out[100])}
+                "zero_divisor_state": int(out[99]), "second_divisor_state": int(out[100]), "pack_slots_ok": int(out[101]), "pack_bit": bool(out[102])}
 
     def own_stream(self):
         """Give the context a non-blocking stream of its own (for a second context next to a torch-owned one)."""

@@ -193,7 +193,7 @@ int launch_ransac_finalize(sfm_pair *pair, const sfm_ransac_params &p, const uns
 int launch_permutation_indices(sfm_ctx *ctx, int n, uint32_t seed, int32_t *d_indices);
 // ransac_prefilter.hip
 bool prefilter_usable(const sfm_pair *pair, const sfm_ransac_params &p, uint32_t count);
-int prefilter_rule(const sfm_ransac_params &p);                                 // kPfRuleBand (the product) / kPfRuleG (lab bench, reserved[3] == 4)
+int prefilter_rule(const sfm_ransac_params &p);                                 // kPfRuleBandPack (the product) / kPfRuleBand, kPfRuleG (lab bench, reserved[3] == 5 / 4)
 int launch_score_prefilter(sfm_pair *pair, const sfm_ransac_params &p, uint32_t h0, uint32_t count, unsigned long long *key2);
 int launch_pf_prep(sfm_pair *pair, const sfm_ransac_params &p, uint32_t count);
 int launch_pf_cells(sfm_pair *pair);                                            // the pair's cell table, (re)built when the points changed        // PfRecords from d_Ecand (paths whose solve kernel does not write them)

@@ -351,6 +351,19 @@ SFM_HD PfBox pf_box_from_words(const unsigned long long *w, float B)
 
 constexpr float kPfBandSigmaMax = 262144.0f;                            // 2^18: |e| <= 2 -> |c| <= 2^15 in fp16
 
+// Where the scaled band ends: sigma = top / W puts every inlier at |nt| <= top, and the scan rejects from the next value up.
+//   kPfBandTop      the v_alignbit scan of round 5: rejected <=> bit 30 of the accumulator <=> |nt| >= 2
+//   kPfBandTopPack  round 6's scan: ONE v_cvt_scalef32_2xpk16_bf6_f32 turns the 32 accumulators of two 32-point steps into 32 six-bit
+//                   floats (1 sign, 3 exponent, 2 mantissa bits, bias 3; round to nearest even, saturating: measured,
+//                   profiles/r06_cvt_pack_probe.txt) whose top exponent bit is set exactly when the rounded magnitude is >= 2, i.e.
+//                   when |nt| >= 1.875 (the half-way point between 1.75 and 2 goes to the even mantissa, 2.0).  Whatever the rounding
+//                   mode were, a magnitude BELOW 1.875 can never round to 2 (1.75 and 1.875's neighbours below are representable
+//                   or round down / to 1.75), so with top < 1.875 the rule never rejects an inlier; the exact switching point only
+//                   moves the survivor rate.  inf / NaN / anything >= 28 saturate to 28 (bit set: rejected); no such value occurs.
+constexpr float kPfBandTop = 1.998f;
+constexpr float kPfBandTopPack = 1.873f;
+constexpr float kPfBandPackSwitch = 1.875f;
+
 // max over the corners of [lo0, hi0] x [lo1, hi1] of (|c0 X + c1 Y + c2| + 2 eta)^2 + (|c3 X + c4 Y + c5| + 2 eta)^2: an upper bound
 // of the divisor the exact test computes for any point of the box (eta >= the rounding of one affine form, on either side)
 SFM_HD float pf_band_corner_max(float c0, float c1, float c2, float c3, float c4, float c5, float lo0, float hi0, float lo1, float hi1, float eta)
@@ -367,7 +380,7 @@ SFM_HD float pf_band_corner_max(float c0, float c1, float c2, float c3, float c4
 }
 
 // sigma of a hypothesis (0: every pair survives).  b_safe: no point of the pair can have db_c == 0.
-SFM_HD float prefilter_band_sigma(const float e[9], float thr, float B, const PfBox &box, bool b_safe)
+SFM_HD float prefilter_band_sigma(const float e[9], float thr, float B, const PfBox &box, bool b_safe, float top = kPfBandTop)
 {
     float ae[9];
     bool tame = B <= 48.0f;
@@ -384,7 +397,7 @@ SFM_HD float prefilter_band_sigma(const float e[9], float thr, float B, const Pf
     if (b_safe) H = (Da * Db) / (Da + Db) * 1.000001f;
     const float C = (thr * 1.000002f) * H;
     const float W = (sqrtf(C) * 1.0000003f + dn + 8e-8f) * (1.0f + 2.5e-6f * (1.0f + B * B));
-    float sigma = 1.998f / W;
+    float sigma = top / W;
     if (!(sigma <= kPfBandSigmaMax)) sigma = kPfBandSigmaMax;                                  // (also W == 0 or NaN: 0 / 0 boxes)
     if (!(W > 0.0f) || !(W < 64.0f) || !(H == H)) return 0.0f;                                 // nothing sensible to scale by: every pair survives
     return sigma;
@@ -411,6 +424,26 @@ SFM_HD void prefilter_band_hyp_slots(const float e[9], float sigma, _Float16 ns[
 SFM_HD bool prefilter_band_reject(float nt)
 {
     return ((f32_bits(nt) >> 30) & 1u) != 0u;
+}
+
+// The packed scan's rule (kPfBandTopPack): the top exponent bit of the accumulator converted to the six-bit float.
+SFM_HD bool prefilter_band_pack_reject(float nt)
+{
+    return fabsf(nt) >= kPfBandPackSwitch;
+}
+
+// The packed scan's word of 32 reject bits (ransac_prefilter.hip, pack_reject_bits): the conversion writes field f = 2 j + s (accumulator
+// j of step s) to bits 6 f .. 6 f + 5 of six registers, its top exponent bit to bit 6 f + 4; registers 0..2 are merged into the even
+// bits of the word (their reject bits sit at positions 4, 2 and 0 (mod 6): disjoint), registers 3..5 into the odd bits (shifted up by
+// one).  pf_pack_code(b) = what the survivor at bit (31 - b) is: ((j & 3) + 8 (j >> 2)) | s << 5 -- the accumulator's row offset among
+// the 32 hypotheses of a pass (device_math's MFMA row order) and the step.
+SFM_HD uint32_t pf_pack_code(int b)
+{
+    const int bitpos = 31 - b, odd = bitpos & 1, p = bitpos - odd;
+    const int reg = (p % 6 == 4) ? 0 : (p % 6 == 2) ? 1 : 2;
+    const int f = (32 * (reg + 3 * odd) + p - 4) / 6;
+    const int j = f >> 1, st = f & 1;
+    return (uint32_t)((j & 3) + 8 * (j >> 2)) | ((uint32_t)st << 5);
 }
 
 // The coefficients of the OTHER divisor in the positions prefilter_zero_divisor_cells / prefilter_zero_divisor read:

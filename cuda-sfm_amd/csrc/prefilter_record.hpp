@@ -24,7 +24,9 @@ namespace sfm {
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 
-constexpr int kPfRuleG = 0, kPfRuleBand = 1;       // which rule a record / a scoring kernel instance follows (prefilter_math.hpp)
+// which rule a record / a scoring kernel instance follows (prefilter_math.hpp): the G rule of rounds 2-4, the band rule scanned with
+// v_alignbit_b32 (round 5) or with the six-bit conversion (round 6, the product; same record layout, sigma = 1.873 / W instead of 1.998 / W)
+constexpr int kPfRuleG = 0, kPfRuleBand = 1, kPfRuleBandPack = 2;
 constexpr int kPfGroup = 32;                       // hypotheses per pass of a scoring wavefront (one MFMA row block)
 constexpr unsigned short kPfFlagScan = 0x3C00u;    // "check every point" (any non-zero pattern would do; this one is fp16 1.0)
 
@@ -132,7 +134,7 @@ __device__ __forceinline__ bool pf_cells_occupied(const uint32_t *__restrict__ c
 __device__ __forceinline__ void pf_band_store(const float e[9], float sigma, bool scan, PfRecord *out);
 
 __device__ __forceinline__ void pf_band_prep_store(const float e[9], float thr, float B, const PfBox &box, const uint32_t *__restrict__ cells,
-                                                   uint32_t cells_mask, PfRecord *out)
+                                                   uint32_t cells_mask, PfRecord *out, float top = kPfBandTop)
 {
     const PfGrid grid = prefilter_grid(B);
     int cx0, cx1, cy0, cy1;
@@ -144,7 +146,7 @@ __device__ __forceinline__ void pf_band_prep_store(const float e[9], float thr, 
     const int zb = prefilter_zero_divisor_cells(et, B, grid, cx0, cx1, cy0, cy1);
     bool b_safe = zb == 0;
     if (zb == 1) b_safe = cells && !pf_cells_occupied(cells, cells_mask, cx0, cx1, cy0, cy1, 1);
-    pf_band_store(e, prefilter_band_sigma(e, thr, B, box, b_safe), scan, out);
+    pf_band_store(e, prefilter_band_sigma(e, thr, B, box, b_safe, top), scan, out);
 }
 
 __device__ __forceinline__ void pf_band_store(const float e[9], float sigma, bool scan, PfRecord *out)

@@ -116,7 +116,7 @@ void ransac_solve_lanes1_qr(const float *__restrict__ X0, const float *__restric
         if (rule == kPfRuleG) pf_prep_store(E, thr, B, sc, cells, cells_mask, recs + i);
         else
 #endif
-        pf_band_prep_store(E, thr, B, pf_box_from_words(bound_word + 2, B), cells, cells_mask, recs + i);
+        pf_band_prep_store(E, thr, B, pf_box_from_words(bound_word + 2, B), cells, cells_mask, recs + i, rule == kPfRuleBandPack ? kPfBandTopPack : kPfBandTop);
     }
     SFM_PHASE("end");
 }

@@ -53,11 +53,11 @@ constexpr int kPfWaveBytes = 32 * kPfERow * 4 + 32 * 4;
 __device__ constexpr int kPfESlot[9] = { 2, 6, 1, 3, 5, 7, 0, 4, 8 };
 // The map for a tile of `tile` points (a multiple of 32); an even number of 32-point blocks is staged (the scan takes two per iteration).
 template <int RULE> struct PfLds {
-    static constexpr int kFragsPerBlock = RULE == kPfRuleBand ? 2 : 3;
+    static constexpr int kFragsPerBlock = RULE == kPfRuleG ? 3 : 2;
     static constexpr int kBlockBytes = kFragsPerBlock * 64 * 16;   // one 32-point block: [n k-step 0 | n k-step 1 (| G)][lane][8 fp16]
     static constexpr int kFrag = 0;
     static constexpr int kTileMax = kPfTileMax;
-    int staged, pts, ring, wave, next, bytes;
+    int staged, pts, ring, wave, next, lut, bytes;
     __host__ __device__ explicit PfLds(int tile, int ring_entries = kPfRing)
     {
         staged = (tile + 63) & ~63;                           // points staged: whole iterations of two blocks (beyond `tile`: padding)
@@ -67,7 +67,8 @@ template <int RULE> struct PfLds {
         ring = (ring + ring_entries * 8 - 1) & ~(ring_entries * 8 - 1);
         wave = ring + kPfWaves * ring_entries * 8;            // per wavefront: E table 9 x 32 floats (component-major), 32 counters
         next = wave + kPfWaves * kPfWaveBytes;                // the block's pass counter
-        bytes = next + 16;
+        lut = next + 16;                                      // packed scan: survivor bit -> (accumulator row, step), 32 bytes (pf_pack_code)
+        bytes = lut + 32;
     }
 };
 static_assert(kPfRing * 8 == 1024, "ring slots are addressed with (offset & 1023) | base");
@@ -105,6 +106,29 @@ __device__ __forceinline__ uint32_t scan16_band(const f16v &nt)
     return w;
 }
 
+// ---- round 6: the packed scan (kPfRuleBandPack) ---------------------------------------------------------------------------------
+// v_cvt_scalef32_2xpk16_bf6_f32 D[0:5], S0[0:15], S1[0:15], scale: the 32 accumulators of TWO 32-point steps -> 32 six-bit floats,
+// interleaved: field 2 j = S0[j], field 2 j + 1 = S1[j], field f in bits 6 f .. 6 f + 5 of the 192-bit result; bit 4 of a field (the top
+// exponent bit) is set exactly when |accumulator| >= 1.875 (prefilter_math.hpp, kPfBandTopPack; measured layout and rounding:
+// profiles/r06_cvt_pack_probe.txt).  One instruction at 64.6 cycles of a SIMD where 32 v_alignbit_b32 take 136.  The 32 reject bits sit
+// at bit 6 f + 4 of the 192-bit string: in registers 0 and 3 at positions 4 (mod 6), in 1 and 4 at 2 (mod 6), in 2 and 5 at 0 (mod 6) --
+// three disjoint sets of even positions, so two bit-field inserts merge registers 0..2 (fields 0..15) into the even bits of one word,
+// two more registers 3..5 (fields 16..31), and a third pair puts the latter into the odd bits: 5 x v_bfi / v_bitop3 + 1 shift per 2048
+// pairs.  A survivor's bit position is turned back into (accumulator, step) through a 32-byte table in LDS when its entry is flushed.
+typedef uint32_t u6v __attribute__((ext_vector_type(6)));
+constexpr uint32_t kPackM0 = 0x10410410u, kPackM1 = 0x04104104u;          // positions 4 (mod 6) and 2 (mod 6)
+
+// (m & a) | (~m & b) as ONE v_bitop3_b32 (3.1 cycles of a SIMD; written as plain C the compiler prefers three v_and with literals + v_or3)
+__device__ __forceinline__ uint32_t pf_bfi(uint32_t m, uint32_t a, uint32_t b) { return __builtin_amdgcn_bitop3_b32(m, a, b, 0xCA); }
+
+// the 32 reject bits of two steps in one word; pf_pack_code (prefilter_math.hpp) names the (accumulator, step) behind each position
+__device__ __forceinline__ uint32_t pack_reject_bits(const u6v &d)
+{
+    const uint32_t wa = pf_bfi(kPackM0 | kPackM1, pf_bfi(kPackM0, d[0], d[1]), d[2]);      // even positions: fields 0..15 (odd ones: rubbish)
+    const uint32_t wb = pf_bfi(kPackM0 | kPackM1, pf_bfi(kPackM0, d[3], d[4]), d[5]);      // even positions: fields 16..31
+    return pf_bfi(0x55555555u, wa, wb << 1);
+}
+
 // LDS through address-space-3 pointers (ds_* instructions, immediate offsets)
 typedef uint32_t u2v __attribute__((ext_vector_type(2)));
 typedef float f4v __attribute__((ext_vector_type(4)));
@@ -114,6 +138,7 @@ typedef __attribute__((address_space(3))) const float lds_cf;
 typedef __attribute__((address_space(3))) int lds_i;
 typedef __attribute__((address_space(3))) const h8 lds_ch8;
 typedef __attribute__((address_space(3))) const v2f lds_cv2;
+typedef __attribute__((address_space(3))) const unsigned char lds_cu8;
 
 struct PfFrags { h8 n0, n1, t; };
 
@@ -151,7 +176,7 @@ template <int RULE>
 __device__ __forceinline__ PfFrags load_point_frags(lds_ch8 *frag_lane, int pb)
 {
     lds_ch8 *p = frag_lane + pb * (PfLds<RULE>::kBlockBytes / 16);
-    if (RULE == kPfRuleBand) return PfFrags{ p[0], p[64], h8{} };
+    if (RULE != kPfRuleG) return PfFrags{ p[0], p[64], h8{} };
     return PfFrags{ p[0], p[64], p[128] };
 }
 
@@ -169,7 +194,7 @@ __device__ __forceinline__ void mfma_step(const PfFrags &a, const PfFrags &b, f1
 // registers with the accumulators being scanned, or the reads could only be issued after the scan).
 #define PF_SCHED_STEP()                                                 \
     do {                                                                \
-        if (RULE == kPfRuleBand) {                                      \
+        if (RULE != kPfRuleG) {                                         \
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);          \
             __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);          \
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);          \
@@ -189,7 +214,7 @@ __device__ __forceinline__ void mfma_step(const PfFrags &a, const PfFrags &b, f1
 constexpr int kPfVarTickets = 1;
 
 // FL2 (experiment): a ring of 256 entries, flushed 128 at a time -- two entries per lane, their LDS reads issued together
-template <int W, int VAR = 0, int RULE = kPfRuleBand, int FL2 = 0>
+template <int W, int VAR = 0, int RULE = kPfRuleBandPack, int FL2 = 0, int PIPE = 0>
 __global__ __launch_bounds__(W * 64)
 void ransac_score_prefilter(const float *__restrict__ X0, const float *__restrict__ X1, int ld, int n,
                             const float *__restrict__ Ecand, const PfRecord *__restrict__ recs, uint32_t h0, uint32_t count, float thr,
@@ -221,6 +246,8 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
     const uint32_t npass = (count + (uint32_t)kPfGroup - 1u) / (uint32_t)kPfGroup;
     const uint32_t nstatic = gridDim.x * (uint32_t)W;             // passes handed out by position
     using LT = PfLds<RULE>;
+    constexpr bool kBand = RULE != kPfRuleG, kPack = RULE == kPfRuleBandPack;
+    static_assert(!(FL2 && kPack) && !(VAR && kPack), "the recorded variants were built on the v_alignbit scan");
     constexpr int kRing = FL2 ? 256 : kPfRing;
     const LT L(tile, kRing);
     float *etab = reinterpret_cast<float *>(smem + L.wave + wave * kPfWaveBytes);
@@ -236,7 +263,7 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
         const uint32_t h = hf + (uint32_t)min(row, (int)min((uint32_t)kPfGroup, count - hf) - 1);
         const uint4 *r = reinterpret_cast<const uint4 *>(recs + h) + 2 * half;        // this lane's half of the record: 32 bytes
         const uint4 r0 = r[0], r1 = r[1];
-        if (RULE == kPfRuleBand) pf_band_record_expand(r0, r1, half, af.n0, af.n1, k0);
+        if (kBand) pf_band_record_expand(r0, r1, half, af.n0, af.n1, k0);
         else pf_record_expand(r0, r1, half, af.n0, af.n1, af.t, k0);
         if (half == 0) {
             const float *src = Ecand + 9 * (size_t)h;
@@ -265,6 +292,7 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
     // memory would balance the blocks too, but 131072 device-scope atomics on one address take 1.5 ms.)
     uint32_t *next_idx = reinterpret_cast<uint32_t *>(smem + L.next);
     if (threadIdx.x == 0) *next_idx = (uint32_t)W;
+    if (kPack && threadIdx.x < 32) smem[L.lut + threadIdx.x] = (unsigned char)pf_pack_code((int)threadIdx.x);
     __syncthreads();
     const int tile_first = blockIdx.y * tile;
     for (int t = threadIdx.x; t < L.staged; t += W * 64) {
@@ -306,6 +334,7 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
     const float4 *pts = reinterpret_cast<const float4 *>(smem + L.pts);
     lds_cf *etab_l = (lds_cf *)etab;
     lds_i *cnt_l = (lds_i *)cnt;
+    lds_cu8 *lut_l = (lds_cu8 *)(smem + L.lut);
     const uint32_t ring_base = (uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char *)(smem + L.ring) + (uint32_t)wave * (uint32_t)(kRing * 8);
     uint32_t ring_mask = (uint32_t)(kRing * 8 - 1);
     asm("" : "+v"(ring_mask));                            // in a vector register: v_and_or_b32 takes one scalar operand, and that is the base
@@ -376,9 +405,17 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
                 const uint32_t surv = ent.x;
                 const int b = __builtin_clz(surv);                                  // the first surviving accumulator of the first step that has one
                 rest = surv & ~(0x80000000u >> b);
-                // G rule: bit 31 - r = accumulator r of the first step, 15 - r of the second; band rule: 31 - 2 r and 30 - 2 r
-                const int r = RULE == kPfRuleBand ? b >> 1 : b & 15, sub = RULE == kPfRuleBand ? b & 1 : b >> 4;
-                const int hl = r + (r & 12) + (int)(tag & 4u);                      // accumulator row = local hypothesis: (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+                // G rule: bit 31 - r = accumulator r of the first step, 15 - r of the second; band rule: 31 - 2 r and 30 - 2 r; packed
+                // scan: the table (pf_pack_code)
+                int hl, sub;
+                if (kPack) {
+                    const uint32_t code = lut_l[b];
+                    hl = (int)(code & 31u) + (int)(tag & 4u); sub = (int)(code >> 5);
+                } else {
+                    const int r = kBand ? b >> 1 : b & 15;
+                    sub = kBand ? b & 1 : b >> 4;
+                    hl = r + (r & 12) + (int)(tag & 4u);                            // accumulator row = local hypothesis: (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+                }
                 if (hl < nvalid) {
                     const f4v q = *(lds_cf4 *)((__attribute__((address_space(3))) const unsigned char *)0 + ((tag & ~15u) + ((uint32_t)sub << 9)));
                     lds_cf *e = etab_l + hl;
@@ -427,6 +464,93 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
             nq += __builtin_popcountll(moreA) + __builtin_popcountll(moreB) - 128;
         };
 
+        if constexpr (kPack && PIPE) {
+        // ---- packed scan, software-pipelined over FOUR accumulator sets: while the conversion and the bit picking work on the two
+        // sets of the previous two steps, the four MFMAs of the next two steps go out between them, one at a time (a wavefront that
+        // issues its MFMAs back to back waits for the matrix pipe with nothing else to do, and waits again for their results)
+        PfFrags fa = load_point_frags<RULE>(frag_lane, 0), fb = load_point_frags<RULE>(frag_lane, 1);
+        lds_ch8 *fp = frag_lane + 2 * (LT::kBlockBytes / 16);
+        const f16v zero16 = {};
+        f16v a0, a1, b0, b1;
+        a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(afrag.n0, fa.n0, zero16, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(afrag.n0, fb.n0, zero16, 0, 0, 0);
+        a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(afrag.n1, fa.n1, a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(afrag.n1, fb.n1, a1, 0, 0, 0);
+        fa = load_point_frags<RULE>(fp, 0);
+        fb = load_point_frags<RULE>(fp, 1);
+        fp += 2 * (LT::kBlockBytes / 16);
+        auto phase = [&](const f16v &c0, const f16v &c1, f16v &m0, f16v &m1, int pp) {
+            SFM_PHASE("scan_two_steps");
+            __builtin_amdgcn_sched_barrier(0);
+            m0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(afrag.n0, fa.n0, zero16, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            const u6v d = __builtin_amdgcn_cvt_scalef32_2xpk16_bf6_f32(c0, c1, 1.0f);
+            __builtin_amdgcn_sched_barrier(0);
+            m1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(afrag.n0, fb.n0, zero16, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            const uint32_t rej32 = pack_reject_bits(d);
+            __builtin_amdgcn_sched_barrier(0);
+            m0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(afrag.n1, fa.n1, m0, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            const bool mine = rej32 != 0xFFFFFFFFu;
+            const unsigned long long any = __ballot(mine);
+            __builtin_amdgcn_sched_barrier(0);
+            m1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(afrag.n1, fb.n1, m1, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            // the fragments of the two steps after those (the last iterations read past the tile, inside the block's LDS, into
+            // fragments whose products nothing looks at)
+            fa = load_point_frags<RULE>(fp, 0);
+            fb = load_point_frags<RULE>(fp, 1);
+            fp += 2 * (LT::kBlockBytes / 16);
+            __builtin_amdgcn_sched_barrier(0);
+            SFM_PHASE("append_and_inloop_flush");
+            if (any) {
+                while (nq >= 64) flush(64);
+                const int slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(any >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)any, 0u));
+                if (mine) *ring_at(((uint32_t)(head + nq) + (uint32_t)slot) * 8u) = u2v{ ~rej32, lane_tag + ((uint32_t)pp << 10) };
+                nq += __builtin_popcountll(any);
+            }
+        };
+        for (int pp = 0; pp < npp; pp += 2) {
+            phase(a0, a1, b0, b1, pp);
+            if (pp + 1 < npp) phase(b0, b1, a0, a1, pp + 1);
+        }
+        } else if constexpr (kPack) {
+        // ---- packed scan: the four MFMAs of two steps, then (under them) the survivors of the previous two, then ONE conversion
+        // that waits for the MFMAs -- the other wavefronts of the SIMD issue meanwhile
+        PfFrags fa = load_point_frags<RULE>(frag_lane, 0), fb = load_point_frags<RULE>(frag_lane, 1);
+        lds_ch8 *fp = frag_lane + 2 * (LT::kBlockBytes / 16);
+        f16v g0, n0, n1;
+        u6v dpk = {};
+        auto append = [&](const u6v &d, int pp) {
+            const uint32_t rej32 = pack_reject_bits(d);
+            const bool mine = rej32 != 0xFFFFFFFFu;
+            const unsigned long long any = __ballot(mine);
+            SFM_PHASE("append_and_inloop_flush");
+            if (any) {
+                while (nq >= 64) flush(64);
+                const int slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(any >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)any, 0u));
+                if (mine) *ring_at(((uint32_t)(head + nq) + (uint32_t)slot) * 8u) = u2v{ ~rej32, lane_tag + ((uint32_t)pp << 10) };
+                nq += __builtin_popcountll(any);
+            }
+        };
+        for (int pp = 0; pp < npp; ++pp) {
+            SFM_PHASE("scan_two_steps");
+            mfma_step<RULE>(afrag, fa, g0, n0);
+            mfma_step<RULE>(afrag, fb, g0, n1);
+            // the fragments of the two steps after these (the last iteration reads past the tile, inside the block's LDS, into
+            // fragments nothing looks at)
+            fa = load_point_frags<RULE>(fp, 0);
+            fb = load_point_frags<RULE>(fp, 1);
+            fp += 2 * (LT::kBlockBytes / 16);
+            __builtin_amdgcn_sched_barrier(0);
+            if (pp > 0) append(dpk, pp - 1);
+            __builtin_amdgcn_sched_barrier(0);
+            dpk = __builtin_amdgcn_cvt_scalef32_2xpk16_bf6_f32(n0, n1, 1.0f);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        append(dpk, npp - 1);
+        } else {
         PfFrags fa = load_point_frags<RULE>(frag_lane, 0), fb = load_point_frags<RULE>(frag_lane, 1);
         f16v g0, n0, g1, n1;
         mfma_step<RULE>(afrag, fa, g0, n0);
@@ -440,7 +564,7 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
             fa = load_point_frags<RULE>(fp, 0);
             __builtin_amdgcn_sched_barrier(0);
             mfma_step<RULE>(afrag, fb, g1, n1);
-            const uint32_t rej_first = RULE == kPfRuleBand ? scan16_band(n0) : scan16(n0, g0);
+            const uint32_t rej_first = kBand ? scan16_band(n0) : scan16(n0, g0);
             PF_SCHED_STEP();
             __builtin_amdgcn_sched_barrier(0);
             // phase 2: matrix cores on step 2 pp + 2 (fragments fa), LDS on step 2 pp + 3, vector unit on step 2 pp + 1
@@ -448,12 +572,12 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
             fp += 2 * (LT::kBlockBytes / 16);
             __builtin_amdgcn_sched_barrier(0);
             mfma_step<RULE>(afrag, fa, g0, n0);
-            const uint32_t rej_second = RULE == kPfRuleBand ? scan16_band(n1) : scan16(n1, g1);
+            const uint32_t rej_second = kBand ? scan16_band(n1) : scan16(n1, g1);
             PF_SCHED_STEP();
             __builtin_amdgcn_sched_barrier(0);
             // band rule: the reject bits of the two steps interleaved (first step's in the odd positions), every bit meaningful:
             // (w1 << 1) supplies the odd bits, w2 the even ones (v_lshlrev + v_bfi)
-            const uint32_t rej32 = RULE == kPfRuleBand ? (((rej_first << 1) & 0xAAAAAAAAu) | (rej_second & 0x55555555u))
+            const uint32_t rej32 = kBand ? (((rej_first << 1) & 0xAAAAAAAAu) | (rej_second & 0x55555555u))
                                                        : ((rej_first << 16) | rej_second);
             const bool mine = rej32 != 0xFFFFFFFFu;
             const unsigned long long any = __ballot(mine);
@@ -466,6 +590,7 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
                 if (mine) *ring_at(((uint32_t)(head + nq) + (uint32_t)slot) * 8u) = u2v{ ~rej32, lane_tag + ((uint32_t)pp << 10) };
                 nq += __builtin_popcountll(any);
             }
+        }
         }
         PF_PHASE(4);
         SFM_PHASE("pass_end_fetch_next");
@@ -658,7 +783,7 @@ void pf_prep_kernel(const float *__restrict__ Ecand, uint32_t count, float thr, 
 #pragma unroll
     for (int k = 0; k < 9; ++k) e[k] = Ecand[9 * (size_t)i + k];
     const float B = __uint_as_float((uint32_t)(*bound_word & 0xFFFFFFFFull));
-    if (RULE == kPfRuleBand) pf_band_prep_store(e, thr, B, pf_box_from_words(bound_word + 2, B), cells, cells_mask, recs + i);
+    if (RULE != kPfRuleG) pf_band_prep_store(e, thr, B, pf_box_from_words(bound_word + 2, B), cells, cells_mask, recs + i, RULE == kPfRuleBandPack ? kPfBandTopPack : kPfBandTop);
     else pf_prep_store(e, thr, B, sc, cells, cells_mask, recs + i);
 }
 
@@ -666,10 +791,13 @@ int launch_pf_prep(sfm_pair *pair, const sfm_ransac_params &p, uint32_t count)
 {
     PfScales sc;
     if (!prefilter_scales(p.threshold, sc)) { set_error("threshold %g outside the pre-filter's range", (double)p.threshold); return SFM_E_INVALID; }
-    if (prefilter_rule(p) == kPfRuleBand)
-        hipLaunchKernelGGL(pf_prep_kernel<kPfRuleBand>, dim3((count + 255) / 256), dim3(256), 0, pair->ctx->stream,
+    if (prefilter_rule(p) == kPfRuleBandPack)
+        hipLaunchKernelGGL(pf_prep_kernel<kPfRuleBandPack>, dim3((count + 255) / 256), dim3(256), 0, pair->ctx->stream,
                            pair->d_Ecand, count, p.threshold, sc, pair->d_bound, pair->d_cells, pair->cells_mask, reinterpret_cast<PfRecord *>(pair->d_pf));
 #if SFM_AB
+    else if (prefilter_rule(p) == kPfRuleBand)
+        hipLaunchKernelGGL(pf_prep_kernel<kPfRuleBand>, dim3((count + 255) / 256), dim3(256), 0, pair->ctx->stream,
+                           pair->d_Ecand, count, p.threshold, sc, pair->d_bound, pair->d_cells, pair->cells_mask, reinterpret_cast<PfRecord *>(pair->d_pf));
     else
         hipLaunchKernelGGL(pf_prep_kernel<kPfRuleG>, dim3((count + 255) / 256), dim3(256), 0, pair->ctx->stream,
                            pair->d_Ecand, count, p.threshold, sc, pair->d_bound, pair->d_cells, pair->cells_mask, reinterpret_cast<PfRecord *>(pair->d_pf));
@@ -740,6 +868,10 @@ void pf_probe_kernel(const float *__restrict__ E, float thr, float B, PfScales s
 
 // The same for the band rule: sigma from the given boxes, the record through pf_band_store / pf_band_record_expand, two MFMAs.
 // out: ns[32] | - | bn[32] at 48 | nt at 96 | sigma at 97 | rejected at 98 | first divisor's state at 99 | second divisor's at 100
+// b_safe: bit 0 = the second divisor cannot vanish, bit 1 = the packed scan (sigma = 1.873 / W, `rejected` from the conversion itself).
+// Always: out[101] = how many of the 32 (accumulator, step) slots the packed scan handles correctly for the RAW value u -- lane L < 32
+// puts u into accumulator L >> 1 of step L & 1 and 256 everywhere else, converts, picks the bits, and expects either no survivor
+// (|u| >= 1.875) or exactly one whose table code names its own slot; out[102] = the conversion's reject bit for u (0 / 1).
 __global__ __launch_bounds__(64)
 void pf_band_probe_kernel(const float *__restrict__ E, float thr, float B, PfBox box, int b_safe, float u, float v, float x, float y, int survive_all,
                           PfRecord *rec, float *__restrict__ out)
@@ -749,7 +881,8 @@ void pf_band_probe_kernel(const float *__restrict__ E, float thr, float B, PfBox
     float e[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) e[k] = E[k];
-    const float sigma = survive_all ? 0.0f : prefilter_band_sigma(e, thr, B, box, b_safe != 0);
+    const bool pack = (b_safe & 2) != 0;
+    const float sigma = survive_all ? 0.0f : prefilter_band_sigma(e, thr, B, box, (b_safe & 1) != 0, pack ? kPfBandTopPack : kPfBandTop);
     if (lane == 0) pf_band_store(e, sigma, false, rec);
     __threadfence();
     __syncthreads();
@@ -782,11 +915,34 @@ void pf_band_probe_kernel(const float *__restrict__ E, float thr, float B, PfBox
         out[96] = accn[0]; out[97] = sigma;
         f16v one = {}; one[0] = accn[0];
         out[98] = (float)((scan16_band(one) >> 30) & 1u);
+        if (pack) {
+            f16v far = {};
+#pragma unroll
+            for (int k = 0; k < 16; ++k) far[k] = 256.0f;
+            f16v s0 = far; s0[0] = accn[0];
+            const uint32_t rej = pack_reject_bits(__builtin_amdgcn_cvt_scalef32_2xpk16_bf6_f32(s0, far, 1.0f));
+            out[98] = (float)((~rej) == 0u);
+        }
         int cx0, cx1, cy0, cy1;
         out[99] = (float)prefilter_zero_divisor_cells(e, B, prefilter_grid(B), cx0, cx1, cy0, cy1);
         float et[9];
         prefilter_transposed(e, et);
         out[100] = (float)prefilter_zero_divisor_cells(et, B, prefilter_grid(B), cx0, cx1, cy0, cy1);
+    }
+    {   // the packed scan on the raw value u, every slot
+        const int j = (lane & 31) >> 1, st = lane & 1;
+        f16v s0, s1;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { s0[k] = (k == j && st == 0) ? u : 256.0f; s1[k] = (k == j && st == 1) ? u : 256.0f; }
+        const uint32_t surv = ~pack_reject_bits(__builtin_amdgcn_cvt_scalef32_2xpk16_bf6_f32(s0, s1, 1.0f));
+        bool ok;
+        if (prefilter_band_pack_reject(u)) ok = surv == 0u;
+        else {
+            const int b = __builtin_clz(surv | 1u);
+            ok = surv != 0u && (surv & (surv - 1u)) == 0u && pf_pack_code(b) == ((uint32_t)((j & 3) + 8 * (j >> 2)) | ((uint32_t)st << 5));
+        }
+        const unsigned long long okm = __ballot(ok && lane < 32);
+        if (lane == 0) { out[101] = (float)__builtin_popcountll(okm); out[102] = (float)(surv == 0u); }
     }
 }
 
@@ -815,11 +971,14 @@ int launch_prefilter_probe(sfm_ctx *ctx, const float *d_E, float thr, float B, c
 // (which also leaves the bound over all points), a threshold the fp16 scaling covers, and enough work to fill the chip with
 // 512-hypothesis x 1024-point block iterations (measured crossover against the plain wavefront kernel at 4096 points:
 // between 16k and 32k hypotheses, profiles/r02_prefilter_ab.txt).
-// Which rule a call runs: the band rule; the lab-bench library keeps the G rule of rounds 2-4 behind reserved[3] == 4 (and for the
-// recorded variants that were built on it: the ticket epilogue, reserved[3] >= 16).
+// Which rule a call runs: the band rule with the packed scan (round 6); the lab-bench library keeps round 5's v_alignbit scan behind
+// reserved[3] == 5 (and for the recorded variants that were built on it: 12 wavefronts, 1536-point tiles, the 256-entry ring) and the
+// G rule of rounds 2-4 behind reserved[3] == 4 (and for the ticket epilogue, reserved[3] >= 16).
 int prefilter_rule(const sfm_ransac_params &p)
 {
-    return (SFM_SW(p, 3) == 4 || SFM_SW(p, 3) >= 16) ? kPfRuleG : kPfRuleBand;
+    if (SFM_SW(p, 3) == 4 || SFM_SW(p, 3) >= 16) return kPfRuleG;
+    if (SFM_SW(p, 3) == 5 || SFM_SW(p, 1) == 5 || SFM_SW(p, 1) == 7 || SFM_SW(p, 1) == 9) return kPfRuleBand;
+    return kPfRuleBandPack;
 }
 
 bool prefilter_usable(const sfm_pair *pair, const sfm_ransac_params &p, uint32_t count)
@@ -844,7 +1003,7 @@ int launch_score_prefilter(sfm_pair *pair, const sfm_ransac_params &p, uint32_t 
     // wavefronts per block: 16 (four per SIMD, all 512 vector registers of a SIMD) by default; AB build, reserved[1] == 5 runs 12 -- three
     // per SIMD, which leaves a quarter of the registers to the lane-solve kernel of the NEXT step when steps are pipelined
     // on two streams (profiles/r03_waves_ab.txt)
-    const int waves = SFM_SW(p, 1) == 5 ? 12 : kPfWaves;
+    const int waves = (SFM_SW(p, 1) == 5 || SFM_SW(p, 1) == 12) ? 12 : kPfWaves;
     const int tile = pf_tile_of(pair, p);
     const int ntiles = (pair->ld + tile - 1) / tile;
     const uint32_t npass = (count + (uint32_t)kPfGroup - 1u) / (uint32_t)kPfGroup;
@@ -861,7 +1020,7 @@ int launch_score_prefilter(sfm_pair *pair, const sfm_ransac_params &p, uint32_t 
     const int var = SFM_SW(p, 3) >= 16 ? SFM_SW(p, 3) - 16 : 0;                 // (AB build, reserved[3] = 16 + VAR bits)
     const int rule = prefilter_rule(p);
     const bool fl2 = rule == kPfRuleBand && waves == kPfWaves && SFM_SW(p, 1) == 9;      // (AB build: 256-entry ring, two entries per lane per flush)
-    const int lds_bytes = fl2 ? PfLds<kPfRuleBand>(tile, 256).bytes : rule == kPfRuleBand ? PfLds<kPfRuleBand>(tile).bytes : PfLds<kPfRuleG>(tile).bytes;
+    const int lds_bytes = fl2 ? PfLds<kPfRuleBand>(tile, 256).bytes : rule != kPfRuleG ? PfLds<kPfRuleBand>(tile).bytes : PfLds<kPfRuleG>(tile).bytes;
     if (lds_bytes > 160 * 1024) { set_error("pre-filter tile of %d points needs %d bytes of LDS", tile, lds_bytes); return SFM_E_INVALID; }
     auto launch = [&](auto kernel) -> int {
         const int rc_lds = allow_big_lds(ctx, reinterpret_cast<const void *>(kernel));
@@ -878,9 +1037,12 @@ int launch_score_prefilter(sfm_pair *pair, const sfm_ransac_params &p, uint32_t 
     else if (rule == kPfRuleG) rcl = launch(&ransac_score_prefilter<16, 0, kPfRuleG>);
     else if (waves == 12) rcl = launch(&ransac_score_prefilter<12, 0, kPfRuleBand>);
     else if (fl2) rcl = launch(&ransac_score_prefilter<16, 0, kPfRuleBand, 1>);
+    else if (rule == kPfRuleBand) rcl = launch(&ransac_score_prefilter<16, 0, kPfRuleBand>);
+    else if (SFM_SW(p, 1) == 11) rcl = launch(&ransac_score_prefilter<16, 0, kPfRuleBandPack, 0, 1>);
+    else if (SFM_SW(p, 1) == 12) rcl = launch(&ransac_score_prefilter<12, 0, kPfRuleBandPack, 0, 1>);
     else
 #endif
-    rcl = launch(&ransac_score_prefilter<16, 0, kPfRuleBand>);
+    rcl = launch(&ransac_score_prefilter<16, 0, kPfRuleBandPack>);
     (void)var; (void)fl2;
     if (rcl != SFM_OK) return rcl;
     SFM_HIP_TRY(hipGetLastError());

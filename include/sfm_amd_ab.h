@@ -30,7 +30,9 @@ extern "C" {
  *   [2] k > 0: minimum hypothesis batches per scoring block (default 8); pre-filter kernel: grid columns;
  *   [3] 1 AUTO never picks SFM_KERNEL_PREFILTER; 2 the round-2 pre-filter kernel (csrc/ab/ransac_prefilter_r2.hip);
  *       3 per-hypothesis records from the stand-alone kernel instead of the lane-solve kernel; 4 the G rule of rounds 2-4
- *       (per-pair threshold, three MFMAs per 32 x 32 pairs) instead of the band rule; 16 + bits: recorded variants built on it. */
+ *       (per-pair threshold, three MFMAs per 32 x 32 pairs) instead of the band rule; 5 the band rule scanned with one
+ *       v_alignbit_b32 per pair (round 5) instead of the six-bit conversion of round 6 ([1] = 5, 7, 9 imply it: those variants were
+ *       built on that scan); 16 + bits: recorded variants built on the G rule. */
 
 /* Where block 0 of the last pre-filter scoring launch (SFM_KERNEL_PREFILTER) spent its time: ticks[0] shader-clock ticks and
  * ticks[1] 100 MHz ticks over its lifetime (as above); 100 MHz ticks since its start at: [2] tile staged, [3] first pass'
@@ -51,7 +53,9 @@ int sfm_prefilter_probe(sfm_ctx *ctx, const float h_E[9], float threshold, float
 
 /* The same for the band rule (round 5): h_box = the coordinate ranges (x2 lo hi, y2 lo hi, x1 lo hi, y1 lo hi), b_safe = the second
  * divisor cannot vanish.  h_out: ns[32] | (unused) | bn[32] at 48 | nt at 96 | sigma at 97 | rejected at 98 | zero-divisor state of
- * the first divisor at 99, of the second at 100.  Synchronises. */
+ * the first divisor at 99, of the second at 100.  b_safe bit 1: the packed scan of round 6 (sigma = 1.873 / W, `rejected` from the
+ * six-bit conversion).  At 101: how many of the 32 (accumulator, step) slots of the packed scan come out right for the RAW value
+ * h_point[0]; at 102: the conversion's reject bit for it.  Synchronises. */
 int sfm_prefilter_band_probe(sfm_ctx *ctx, const float h_E[9], float threshold, float bound, const float h_box[8], int b_safe,
                              const float h_point[4], int survive_all, float h_out[104]);
 

@@ -105,6 +105,15 @@ void hc_pf_band_hyp_slots(const float *e, float sigma, float *ns /*32*/)
     for (int k = 0; k < sfm::kPfSlots; ++k) ns[k] = (float)n16[k];
 }
 int hc_pf_band_reject(float nt) { return sfm::prefilter_band_reject(nt) ? 1 : 0; }
+// round 6, the packed scan: sigma = top / W with top = 1.873, rejected <=> |nt| >= 1.875, and the survivor table
+float hc_pf_band_sigma_top(const float *e, float thr, float B, const float *box, int b_safe, float top)
+{
+    const sfm::PfBox bx = { box[0], box[1], box[2], box[3], box[4], box[5], box[6], box[7] };
+    return sfm::prefilter_band_sigma(e, thr, B, bx, b_safe != 0, top);
+}
+float hc_pf_band_top(int pack) { return pack ? sfm::kPfBandTopPack : sfm::kPfBandTop; }
+int hc_pf_band_pack_reject(float nt) { return sfm::prefilter_band_pack_reject(nt) ? 1 : 0; }
+uint32_t hc_pf_pack_code(int b) { return sfm::pf_pack_code(b); }
 void hc_pf_transposed(const float *e, float *et) { sfm::prefilter_transposed(e, et); }
 uint32_t hc_pf_cell_key_side(int ix, int iy, int side) { return sfm::pf_cell_key_side(ix, iy, side); }
 // the boxes as the device derives them: ordered bits of the maxima of (x, -x, y, -y, u, -u, v, -v) -> PfBox (8 floats)

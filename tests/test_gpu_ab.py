@@ -186,17 +186,21 @@ def test_prefilter_operands_on_the_device_equal_the_host_build(gpu_ab):
         assert abs(float(dv["G"]) - G) <= T.ACC * float(np.abs(Bt[0]) @ np.abs(ts)) + 1e-12
 
 
-def test_band_rule_operands_on_the_device_equal_the_host_build(gpu_ab):
+@pytest.mark.parametrize("pack", [True, False])
+def test_band_rule_operands_on_the_device_equal_the_host_build(gpu_ab, pack):
     """sfm_prefilter_band_probe: sigma, the coefficient slots read back through the record the scoring kernel reads, the feature
     slots and the matrix cores' nt for one (hypothesis, point) pair, against tests/hostcheck bit for bit (sigma included: sqrtf and
-    the division are correctly rounded on both sides); the rule's bit equals |nt| >= 2."""
+    the division are correctly rounded on both sides); the rule's bit equals |nt| >= 2 (round 5's v_alignbit scan) or what the
+    six-bit conversion says, |nt| >= 1.875 (round 6's packed scan, the product)."""
     import ctypes as C
     import test_hostcheck_prefilter as T
     torch, dev, ctx = gpu_ab
     h = C.CDLL(T.LIB)
     f32p = O.f32p
-    h.hc_pf_band_sigma.restype = C.c_float
-    h.hc_pf_band_sigma.argtypes = [f32p, C.c_float, C.c_float, f32p, C.c_int]
+    h.hc_pf_band_sigma_top.restype = C.c_float
+    h.hc_pf_band_sigma_top.argtypes = [f32p, C.c_float, C.c_float, f32p, C.c_int, C.c_float]
+    h.hc_pf_band_top.restype = C.c_float
+    h.hc_pf_band_top.argtypes = [C.c_int]
     h.hc_pf_band_hyp_slots.argtypes = [f32p, C.c_float, f32p]
     h.hc_pf_point_slots.argtypes = [C.c_float] * 4 + [C.c_int, f32p, f32p]
     h.hc_pf_zero_divisor_cells.argtypes = [f32p, C.c_float, C.POINTER(C.c_int), f32p]
@@ -220,8 +224,8 @@ def test_band_rule_operands_on_the_device_equal_the_host_build(gpu_ab):
             pt[0] = np.float32(-(a[1] * pt[1] + a[2]) / a[0]) if abs(a[0]) > 1e-3 else pt[0]
             B = float(np.float32(max(B, abs(pt[0]) * 1.01)))
         b_safe = k % 3 != 0
-        dv = ctx.prefilter_band_probe(E, thr, B, box, b_safe, pt)
-        sigma = float(h.hc_pf_band_sigma(T.fp(E), thr, B, T.fp(box), int(b_safe)))
+        dv = ctx.prefilter_band_probe(E, thr, B, box, b_safe, pt, pack=pack)
+        sigma = float(h.hc_pf_band_sigma_top(T.fp(E), thr, B, T.fp(box), int(b_safe), h.hc_pf_band_top(int(pack))))
         assert np.float32(sigma).view(np.uint32) == np.float32(dv["sigma"]).view(np.uint32), (k, sigma, dv["sigma"])
         ns = np.zeros(32, np.float32)
         h.hc_pf_band_hyp_slots(T.fp(E), sigma, T.fp(ns))
@@ -230,16 +234,50 @@ def test_band_rule_operands_on_the_device_equal_the_host_build(gpu_ab):
         assert np.array_equal(dv["bn"].astype(np.float64), Bn[0])
         nt = float(Bn[0] @ ns.astype(np.float64))
         assert abs(float(dv["nt"]) - nt) <= T.ACC * float(np.abs(Bn[0]) @ np.abs(ns.astype(np.float64))) + 1e-12
-        assert dv["rejected"] == (abs(float(dv["nt"])) >= 2.0)
+        assert dv["rejected"] == (abs(float(dv["nt"])) >= (1.875 if pack else 2.0))
         rejected += dv["rejected"]
+        assert dv["pack_slots_ok"] == 32 and dv["pack_bit"] == (abs(float(pt[0])) >= 1.875)
         cells = (C.c_int * 4)(); g = C.c_float()
         et = np.zeros(9, np.float32); h.hc_pf_transposed(T.fp(E), T.fp(et))
         assert dv["zero_divisor_state"] == h.hc_pf_zero_divisor_cells(T.fp(E), B, cells, C.byref(g))
         assert dv["second_divisor_state"] == h.hc_pf_zero_divisor_cells(T.fp(et), B, cells, C.byref(g))
     assert 8 < rejected < 64
     # survive-all: all-zero coefficients but the pad marker's, nt = 0
-    dv = ctx.prefilter_band_probe(E, thr, B, box, True, pt, survive_all=True)
+    dv = ctx.prefilter_band_probe(E, thr, B, box, True, pt, survive_all=True, pack=pack)
     assert dv["sigma"] == 0 and not dv["ns"][:27].any() and dv["ns"][27] == 1 and dv["nt"] == 0 and not dv["rejected"]
+
+
+def test_packed_scan_switches_at_1_875_in_every_slot(gpu_ab):
+    """The instruction the packed scan rests on, on this GPU: v_cvt_scalef32_2xpk16_bf6_f32 rounds to nearest even and saturates, so
+    the top exponent bit of a field is set exactly from |x| = 1.875 up (prefilter_math.hpp, kPfBandTopPack) -- for positive and
+    negative values, subnormals, huge values and infinities -- in each of the 32 (accumulator, step) slots, and the kernel's bit
+    picking + survivor table name the slot (pack_slots_ok)."""
+    torch, dev, ctx = gpu_ab
+    E = np.float32([0, -1, 0, 1, 0, 0, 0, 0, 0]); box = np.float32([-1, 1, -1, 1, -1, 1, -1, 1])
+    sw = np.float32(1.875)
+    vals = [0.0, 1e-40, 1e-30, 0.25, 1.0, 1.5, 1.75, 1.86, 1.873, 1.8749, float(np.nextafter(sw, np.float32(0))), 1.875,
+            float(np.nextafter(sw, np.float32(4))), 1.876, 1.9, 1.9375, 1.998, 2.0, 2.5, 3.9, 7.0, 28.0, 29.0, 255.0, 256.0, 1e10, 3e38, float("inf")]
+    rng = np.random.default_rng(6)
+    vals += list(rng.uniform(1.8, 1.95, 40).astype(np.float32)) + list((10.0 ** rng.uniform(-8, 8, 30)).astype(np.float32))
+    for v in vals:
+        for sgn in (1.0, -1.0):
+            u = np.float32(sgn * v)
+            dv = ctx.prefilter_band_probe(E, np.float32(1e-6), 300.0, box, True, np.float32([u, 0.1, 0.2, 0.3]), pack=True)
+            assert dv["pack_bit"] == bool(abs(u) >= sw), (u, dv["pack_bit"])
+            assert dv["pack_slots_ok"] == 32, (u, dv["pack_slots_ok"])
+
+
+@pytest.mark.parametrize("n,H,thr", [(4096, 65536, 1e-6), (1000, 20000, 1e-4), (700, 16385, 1e-8)])
+def test_round5_alignbit_scan_still_equals_oracle(gpu_ab, n, H, thr):
+    """Round 5's scan of the band rule (one v_alignbit_b32 per pair, sigma = 1.998 / W), kept behind reserved[3] = 5 for A/B runs
+    against the packed scan: every count, key, E, mask."""
+    scene = synth.two_view_scene(n, seed=9)
+    pair, _ = make_pair(S, gpu_ab, scene)
+    p = S.default_params(n, num_hypotheses=H, seed=4, kernel=S.KERNEL_PREFILTER, threshold=thr)
+    p.reserved[3] = 5
+    pair.estimateE(p)
+    assert pair.last_launch()["kernel"] == S.KERNEL_PREFILTER
+    P.check_all(pair, scene, p, H, n)
 
 
 @pytest.mark.parametrize("var", [16, 17])                 # 16 = the product's accumulator epilogue, 17 = round 3's tickets

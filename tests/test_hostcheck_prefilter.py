@@ -1,9 +1,10 @@
 """CPU: the matrix-core pre-filter's operands and decision rules (cuda-sfm_amd/csrc/prefilter_math.hpp, compiled as HIP host
 code by tests/hostcheck) against the oracle.  A rule may only REJECT pairs the exact test would not count; here the fp16
 contractions are evaluated in float64 and then pushed by the full accumulation-error budget in every direction that
-favours a rejection -- a single rejected oracle inlier fails the test.  Both rules run: "band" (round 5, the product: a
-per-hypothesis constant folded into the coefficient scaling, the test is bit 30 of the accumulator) and "G" (rounds 2-4, kept
-in the lab-bench library: a per-pair threshold from a second contraction).  (The GPU twin is tests/test_gpu_prefilter.py:
+favours a rejection -- a single rejected oracle inlier fails the test.  All rules run: "pack" (round 6, the product: the band
+rule -- a per-hypothesis constant folded into the coefficient scaling -- scanned with the six-bit conversion: rejected <=> |nt| >=
+1.875), "band" (round 5: the same rule scanned with v_alignbit_b32, the test is bit 30 of the accumulator) and "G" (rounds 2-4: a
+per-pair threshold from a second contraction); the last two are kept in the lab-bench library.  (The GPU twin is tests/test_gpu_prefilter.py:
 counts bit for bit.)"""
 import ctypes as C
 import os
@@ -37,6 +38,13 @@ def H():
     h.hc_pf_band_sigma.argtypes = [f32p, C.c_float, C.c_float, f32p, C.c_int]
     h.hc_pf_band_hyp_slots.argtypes = [f32p, C.c_float, f32p]
     h.hc_pf_band_reject.argtypes = [C.c_float]
+    h.hc_pf_band_sigma_top.restype = C.c_float
+    h.hc_pf_band_sigma_top.argtypes = [f32p, C.c_float, C.c_float, f32p, C.c_int, C.c_float]
+    h.hc_pf_band_top.restype = C.c_float
+    h.hc_pf_band_top.argtypes = [C.c_int]
+    h.hc_pf_band_pack_reject.argtypes = [C.c_float]
+    h.hc_pf_pack_code.restype = C.c_uint32
+    h.hc_pf_pack_code.argtypes = [C.c_int]
     h.hc_pf_transposed.argtypes = [f32p, f32p]
     h.hc_pf_cell_key_side.restype = C.c_uint32
     h.hc_pf_cell_key_side.argtypes = [C.c_int, C.c_int, C.c_int]
@@ -46,7 +54,13 @@ def H():
     return h
 
 
-RULES = ["band", "G"]
+RULES = ["pack", "band", "G"]
+BAND_RULES = ("pack", "band")
+
+
+def band_sigma(H, e, thr, B, box, b_safe, rule):
+    """sigma of a hypothesis under either scan of the band rule (top = 1.998 / 1.873)."""
+    return float(H.hc_pf_band_sigma_top(fp(e), thr, B, fp(box), int(b_safe), H.hc_pf_band_top(int(rule == "pack"))))
 
 
 def fp(a):
@@ -99,6 +113,17 @@ def rejected_band(H, ns, Bn):
     assert np.array_equal(rej, worst >= 2.0)                        # the bit IS the comparison (no NaN / inf among the operands)
     for k in np.flatnonzero(rej)[:4]:
         assert H.hc_pf_band_reject(float(worst[k])) == 1
+    return rej
+
+
+def rejected_pack(H, ns, Bn):
+    """The packed scan (the six-bit conversion's top exponent bit: |nt| >= 1.875) under the worst accumulation error."""
+    nt = Bn @ ns
+    en = ACC * (np.abs(Bn) @ np.abs(ns))
+    worst = (np.abs(nt) + en).astype(np.float32)
+    rej = worst >= np.float32(1.875)
+    for k in list(np.flatnonzero(rej)[:4]) + list(np.flatnonzero(~rej)[:4]):
+        assert H.hc_pf_band_pack_reject(float(worst[k])) == int(rej[k]) == H.hc_pf_band_pack_reject(-float(worst[k]))
     return rej
 
 
@@ -173,20 +198,22 @@ def check_scene(H, X0, X1, Es, thr, n_real=None, max_survivors=None, scans_below
     Bn, Bt = point_slots(H, X0, X1, n_real)
     surv = 0
     guard = ZeroDivisorGuard(H, X1, n, B)
-    if rule == "band":
+    if rule in BAND_RULES:
         guard_b = ZeroDivisorGuard(H, X0, n, B, side=1)
         box = band_box(H, X0, X1, n, B)
     for E in Es:
-        if rule == "band":
+        if rule in BAND_RULES:
             e = np.ascontiguousarray(E, np.float32).reshape(9)
             with np.errstate(invalid="ignore", over="ignore"):
                 b_safe = not guard_b.decide(E)
-                sigma = 0.0 if guard.decide(E) else float(H.hc_pf_band_sigma(fp(e), thr, B, fp(box), int(b_safe)))
+                sigma = 0.0 if guard.decide(E) else band_sigma(H, e, thr, B, box, b_safe, rule)
             assert 0.0 <= sigma <= 262144.0
+            if rule == "band" and sigma > 0:
+                assert np.float32(sigma) == np.float32(H.hc_pf_band_sigma(fp(e), thr, B, fp(box), int(b_safe)))      # the default top is round 5's
             ns32 = np.zeros(32, np.float32)
             H.hc_pf_band_hyp_slots(fp(e), sigma, fp(ns32))
             assert ns32[27] == 1.0 and (sigma > 0 or not ns32[:27].any())
-            rej = rejected_band(H, ns32.astype(np.float64), Bn)
+            rej = (rejected_pack if rule == "pack" else rejected_band)(H, ns32.astype(np.float64), Bn)
         else:
             ns, ts, _ = hyp_slots(H, E, thr, B, guard.decide(E))
             rej = rejected(H, ns, ts, Bn, Bt)
@@ -214,7 +241,7 @@ def test_no_oracle_inlier_is_rejected(H, thr, focal, rule):
     Es = [O.hypothesis_E(X0, X1, O.sample8(99, h, n), 0) for h in range(96)]
     rate = check_scene(H, X0, X1, Es, np.float32(thr), scans_below=0.05, rule=rule)
     if thr == 1e-6 and focal == 2360.0:
-        assert rate < (0.04 if rule == "band" else 0.03)            # and it still filters: 1-2 % survive at the reference threshold
+        assert rate < (0.04 if rule in BAND_RULES else 0.03)        # and it still filters: 1-2 % survive at the reference threshold
 
 
 @pytest.mark.parametrize("rule", RULES)
@@ -255,12 +282,12 @@ def test_zero_divisor_pairs_survive(H, rule):
     check_scene(H, Y0, Y1, [E2], np.float32(1e-6), rule=rule)
     # the test is live: without the zero-divisor guard the rule WOULD reject those inliers
     Bn, Bt = point_slots(H, Y0, Y1)
-    if rule == "band":
-        sigma = float(H.hc_pf_band_sigma(fp(E2.reshape(9)), np.float32(1e-6), 0.3, fp(band_box(H, Y0, Y1, 8, 0.3)), 1))
+    if rule in BAND_RULES:
+        sigma = band_sigma(H, E2.reshape(9), np.float32(1e-6), 0.3, band_box(H, Y0, Y1, 8, 0.3), 1, rule)
         ns32 = np.zeros(32, np.float32)
         H.hc_pf_band_hyp_slots(fp(E2.reshape(9)), sigma, fp(ns32))
         # (the first divisor's maximum over the box is 0 here, so the constant is the error floor alone: |n| = 5e-4 and 9e-4 are far outside)
-        assert sigma > 0 and rejected_band(H, ns32.astype(np.float64), Bn)[:2].all()
+        assert sigma > 0 and (rejected_pack if rule == "pack" else rejected_band)(H, ns32.astype(np.float64), Bn)[:2].all()
     else:
         ns, ts, _ = hyp_slots(H, E2, np.float32(1e-6), 0.3, survive_all=False)
         assert rejected(H, ns, ts, Bn, Bt)[:2].all()
@@ -403,6 +430,7 @@ def test_committed_tie_cases_are_kept_and_their_splits_are_consistent(H):
         assert mask[0]
         check_scene(H, X0, X1, [E], float(np.float32(c["thr"])))
         check_scene(H, X0, X1, [E], float(np.float32(c["thr"])), rule="band")
+        check_scene(H, X0, X1, [E], float(np.float32(c["thr"])), rule="pack")
         p = np.float32(X1[0, 0] * X1[0, 0])
         assert abs(float(p) - float(np.float16(p))) * 2 == float(np.spacing(np.float16(p)))         # the tie
         Bn, Bt = point_slots(H, X0[:, :1], X1[:, :1])
@@ -410,7 +438,8 @@ def test_committed_tie_cases_are_kept_and_their_splits_are_consistent(H):
 
 
 # ---- band rule only ---------------------------------------------------------------------------------------------------------
-def test_band_second_divisor_zero_selects_the_weaker_constant(H):
+@pytest.mark.parametrize("rule", BAND_RULES)
+def test_band_second_divisor_zero_selects_the_weaker_constant(H, rule):
     """db_c == 0 zeroes the SECOND term: the pair is an inlier iff n^2 < thr da, which can exceed the harmonic constant
     thr Da Db / (Da + Db) the rule uses when no point can have db_c == 0.  The guard on the transposed system must notice."""
     thr = np.float32(1e-6)
@@ -430,18 +459,19 @@ def test_band_second_divisor_zero_selects_the_weaker_constant(H):
     assert 0.6 * thr < r < 0.95 * thr                                     # r = n^2 / da alone: the second term is zeroed
     cnt, mask = O.count_inliers(E, X0, X1, thr)
     assert mask[0] == 1
-    check_scene(H, X0, X1, [E], thr, rule="band")
+    check_scene(H, X0, X1, [E], thr, rule=rule)
     # live: with the harmonic constant (b_safe forced) the same pair is rejected
     Bn, _ = point_slots(H, X0, X1)
     box = band_box(H, X0, X1, n, 0.3)
     for b_safe, expect in ((1, True), (0, False)):
-        sigma = float(H.hc_pf_band_sigma(fp(E.reshape(9)), thr, 0.3, fp(box), b_safe))
+        sigma = band_sigma(H, E.reshape(9), thr, 0.3, box, b_safe, rule)
         ns32 = np.zeros(32, np.float32)
         H.hc_pf_band_hyp_slots(fp(E.reshape(9)), sigma, fp(ns32))
-        assert bool(rejected_band(H, ns32.astype(np.float64), Bn)[0]) == expect
+        assert bool((rejected_pack if rule == "pack" else rejected_band)(H, ns32.astype(np.float64), Bn)[0]) == expect
 
 
-def test_band_small_and_large_matrices_sigma_clamp(H):
+@pytest.mark.parametrize("rule", BAND_RULES)
+def test_band_small_and_large_matrices_sigma_clamp(H, rule):
     """Tiny first rows make the constant tiny and sigma hits its fp16-range clamp (2^18); the rule must stay conservative."""
     rng = np.random.default_rng(8)
     n = 512
@@ -457,10 +487,10 @@ def test_band_small_and_large_matrices_sigma_clamp(H):
     clamped = 0
     box = band_box(H, X0, X1, n, float(np.abs(np.concatenate([X0[:2].ravel(), X1[:2].ravel()])).max()))
     for E in Es:
-        clamped += float(H.hc_pf_band_sigma(fp(np.ascontiguousarray(E, np.float32).reshape(9)), np.float32(1e-6), 0.7, fp(box), 1)) == 262144.0
+        clamped += band_sigma(H, np.ascontiguousarray(E, np.float32).reshape(9), np.float32(1e-6), 0.7, box, 1, rule) == 262144.0
     assert clamped >= 12
     for thr in (1e-9, 1e-6, 1e-2):
-        check_scene(H, X0, X1, Es, np.float32(thr), rule="band")
+        check_scene(H, X0, X1, Es, np.float32(thr), rule=rule)
 
 
 def test_band_ordered_bits_and_boxes(H):
@@ -486,5 +516,36 @@ def test_band_survivor_rate_on_the_bench_scene(H):
     X0 = np.ascontiguousarray(X0[:, :n]); X1 = np.ascontiguousarray(X1[:, :n])
     Es = [O.hypothesis_E(X0, X1, O.sample8(0x5EED5F3D, h, n), 0) for h in range(200)]
     rate_b = check_scene(H, X0, X1, Es, np.float32(1e-6), rule="band")
+    rate_p = check_scene(H, X0, X1, Es, np.float32(1e-6), rule="pack")
     rate_g = check_scene(H, X0, X1, Es, np.float32(1e-6), rule="G")
-    assert rate_g < rate_b < 0.02
+    assert rate_g < rate_b < 0.02 and abs(rate_p - rate_b) < 0.002 * rate_b + 1e-4          # the scans cut at 2 / 1.998 and 1.875 / 1.873 of the same band
+
+
+def test_pack_survivor_table_against_a_model_of_the_conversion(H):
+    """pf_pack_code: v_cvt_scalef32_2xpk16_bf6_f32 writes accumulator j of step s as six-bit field f = 2 j + s (bits 6 f .. 6 f + 5 of
+    six registers; layout and rounding measured on the MI355X: profiles/r06_cvt_pack_probe.txt), the kernel merges the top exponent
+    bits (6 f + 4) of registers 0..2 into the even bits of a word and those of registers 3..5 into the odd ones.  Rebuilt here
+    with numpy for every single-survivor pattern; the table must name the slot.  (GPU twin: the band probe's pack_slots_ok.)"""
+    M0, M1, M2 = 0x10410410, 0x04104104, 0x41041041
+    assert M0 | M1 | M2 == 0x55555555 and M0 & M1 == 0 and M0 & M2 == 0 and M1 & M2 == 0
+    seen = set()
+    for j in range(16):
+        for s in range(2):
+            bits = 0                                     # 192-bit string: every field rejected (top exponent bit set) but (j, s)
+            for f in range(32):
+                if f != 2 * j + s:
+                    bits |= 1 << (6 * f + 4)
+                bits |= (f * 7 % 16) << (6 * f)           # rubbish in the mantissa / low exponent bits, and the sign
+                bits |= (f % 2) << (6 * f + 5)
+            d = [(bits >> (32 * r)) & 0xFFFFFFFF for r in range(6)]
+            wa = (d[0] & M0) | (d[1] & M1) | (d[2] & M2)
+            wb = (d[3] & M0) | (d[4] & M1) | (d[5] & M2)
+            rej = (wa & 0x55555555) | ((wb << 1) & 0xAAAAAAAA)
+            surv = ~rej & 0xFFFFFFFF
+            assert bin(surv).count("1") == 1
+            b = 32 - surv.bit_length()                   # count of leading zeros
+            assert H.hc_pf_pack_code(b) == ((j & 3) + 8 * (j >> 2)) | (s << 5), (j, s, b)
+            seen.add(b)
+    assert seen == set(range(32))
+    assert H.hc_pf_band_pack_reject(1.875) == 1 and H.hc_pf_band_pack_reject(float(np.nextafter(np.float32(1.875), np.float32(0)))) == 0
+    assert 1.87 < H.hc_pf_band_top(1) < 1.875 and 1.99 < H.hc_pf_band_top(0) < 2.0
