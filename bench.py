@@ -100,6 +100,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-extra", action="store_true", help="skip the short runs of the other BASELINE configurations")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU time budget of the cpu_baseline sample")
     ap.add_argument("--exchange-probe", action="store_true", help="internal: the child process of a one-GPU run that times the exchange step alone")
+    ap.add_argument("--no-exchange-probe", action="store_true", help="one GPU: do not start the child process that times the exchange step through a one-rank RCCL communicator "
+                                                                     "(skipped by itself under rocprofv3 / any preloaded tool)")
     ap.add_argument("--launch-timeout", type=float, default=900.0,
                     help="--gpus N started without a launcher: seconds after which bench.py's own launcher reports every rank's last stage, stops the ranks and exits 124")
     return ap.parse_args(argv)
@@ -755,6 +757,11 @@ def ctl_device(dev):
     return dev if dist_backend() == "nccl" else "cpu"
 
 
+def under_profiler():
+    """rocprofv3 (or another HSA / HIP tool) is preloaded into this process: child processes would inherit it."""
+    return any(k.startswith("ROCP") for k in os.environ) or bool(os.environ.get("HSA_TOOLS_LIB")) or "rocprof" in os.environ.get("LD_PRELOAD", "")
+
+
 def exchange_probe(S, torch, comm, ctx, pair, n, H, kernel, sweeps, seed, world, fence):
     """100 x (8-byte all-reduce of the key + finalize) on the context stream, back to back: the part of a sharded call that does not
     shrink with the shard."""
@@ -1015,12 +1022,15 @@ def rank_main(args):
     try:
         if comm is not None:
             xprobe = exchange_probe(S, torch, comm, ctx, pair, n, H, args.kernel, params.jacobi_sweeps, last_seed, world, fence)
-        elif world == 1 and not any(args.reserved) and args.regions > 0:
+        elif world == 1 and not any(args.reserved) and args.regions > 0 and not args.no_exchange_probe and not under_profiler():
             # one rank: the same probe through a one-rank RCCL communicator, in a CHILD process -- the one-GPU line must not depend on
-            # RCCL coming up (3-4 s, and a library this process otherwise never loads)
+            # RCCL coming up (3-4 s, and a library this process otherwise never loads).  Never under a profiler (its preloaded tool would
+            # follow the child, whose launches would be averaged into the parent's kernel summaries) -- and the child's environment
+            # carries none of the profiler's variables either way.
             stage("exchange probe (child process) next")
+            child_env = {k: v for k, v in os.environ.items() if not (k.startswith("ROCP") or k.startswith("ROCPROF") or k in ("LD_PRELOAD", "HSA_TOOLS_LIB"))}
             r = subprocess.run([sys.executable, os.path.abspath(__file__), "--exchange-probe", "--matches", str(n), "--hyps", str(H), "--kernel", str(args.kernel),
-                                "--sweeps", str(params.jacobi_sweeps)], capture_output=True, text=True, timeout=180)
+                                "--sweeps", str(params.jacobi_sweeps)], capture_output=True, text=True, timeout=180, env=child_env)
             lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
             xprobe = json.loads(lines[-1]) if (r.returncode == 0 and lines) else {"error": f"child exited {r.returncode}: {r.stderr[-300:]}"}
             stage("exchange probe done")

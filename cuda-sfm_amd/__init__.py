@@ -34,6 +34,9 @@ if not os.path.exists(LIB_PATH):
 import torch  # noqa: E402,F401
 
 _lib = C.CDLL(LIB_PATH)
+ABI_VERSION = 3                 # SFM_ABI_VERSION of include/sfm_amd.h this binding was written against
+if _lib.sfm_abi_version() != ABI_VERSION:
+    raise ImportError(f"{LIB_PATH} reports ABI version {_lib.sfm_abi_version()}, this binding needs {ABI_VERSION}: rebuild it (`make`)")
 
 # ---- constants (include/sfm_amd.h) --------------------------------------------------------------
 OK, E_INVALID, E_HIP, E_NOMEM, E_STATE, E_SINGULAR = 0, -1, -2, -3, -4, -5

@@ -94,7 +94,7 @@ int sfm_ctx_create(int device_id, sfm_ctx **out)
 int sfm_ctx_retain(sfm_ctx *ctx)
 {
     SFM_REQUIRE(ctx, SFM_E_INVALID, "null context");
-    ctx->refs++;
+    ctx->refs.fetch_add(1, std::memory_order_relaxed);
     return SFM_OK;
 }
 
@@ -104,8 +104,11 @@ static int ctx_destroy_now(sfm_ctx *ctx);
 static void ctx_release(sfm_ctx *ctx)
 {
     if (!ctx) return;
-    if (ctx->refs > 0) ctx->refs--;
-    if (ctx->refs == 0 && ctx->destroy_requested) (void)ctx_destroy_now(ctx);
+    // whoever takes the count to zero destroys a context its owner has already let go of (fetch_sub decides: two threads releasing
+    // at once cannot both see zero, nor both miss it)
+    const int before = ctx->refs.fetch_sub(1, std::memory_order_acq_rel);
+    if (before <= 0) { ctx->refs.fetch_add(1, std::memory_order_relaxed); return; }      // (release without a retain: ignored)
+    if (before == 1 && ctx->destroy_requested.load(std::memory_order_acquire)) (void)ctx_destroy_now(ctx);
 }
 
 int sfm_ctx_release(sfm_ctx *ctx)
@@ -118,17 +121,22 @@ int sfm_ctx_release(sfm_ctx *ctx)
 int sfm_ctx_destroy(sfm_ctx *ctx)
 {
     if (!ctx) return SFM_OK;
-    if (ctx->refs > 0) {                         // pairs / communicators still point here: the last of them destroys the context
-        ctx->destroy_requested = true;
-        return SFM_OK;
-    }
-    return ctx_destroy_now(ctx);
+    // The owner's handle counts as one reference from here on: taken, the request flagged, given back -- so that "the last one
+    // destroys" is decided by ONE fetch_sub whether the last pair goes before, after or during this call.
+    ctx->refs.fetch_add(1, std::memory_order_relaxed);
+    ctx->destroy_requested.store(true, std::memory_order_release);
+    if (ctx->refs.fetch_sub(1, std::memory_order_acq_rel) == 1) return ctx_destroy_now(ctx);
+    return SFM_OK;                               // pairs / communicators still point here: the last of them destroys the context
 }
 
 static int ctx_destroy_now(sfm_ctx *ctx)
 {
     (void)hipSetDevice(ctx->device);
-    (void)hipStreamSynchronize(ctx->stream);
+    // a borrowed stream (sfm_ctx_set_stream: e.g. a torch stream) may already have been destroyed by its owner when a deferred
+    // destruction gets here: wait for the device instead of touching it
+    if (ctx->own_stream || !ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    else (void)hipDeviceSynchronize();
+    if (ctx->match_poll_flag) (void)hipHostFree(ctx->match_poll_flag);
     if (ctx->match_ws) (void)hipFree(ctx->match_ws);
     if (ctx->match_poll_ws) (void)hipFree(ctx->match_poll_ws);
     if (ctx->match_jobs_ws) (void)hipFree(ctx->match_jobs_ws);
@@ -203,7 +211,7 @@ int sfm_ctx_synchronize(sfm_ctx *ctx)
 {
     SFM_REQUIRE(ctx, SFM_E_INVALID, "null context");
     SFM_HIP_TRY(hipStreamSynchronize(ctx->stream));
-    return SFM_OK;
+    return match_poll_check(ctx);
 }
 
 int sfm_ctx_get_stream(sfm_ctx *ctx, void **hip_stream)

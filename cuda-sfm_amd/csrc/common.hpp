@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stddef.h>
 #include <string>
+#include <atomic>
 #include "../../include/sfm_amd.h"
 #if SFM_AB
 #include "../../include/sfm_amd_ab.h"
@@ -47,8 +48,8 @@ struct sfm_ctx {
     // Objects that point at the context (every sfm_pair, every sfm_comm) hold a reference: sfm_ctx_destroy on a context that still
     // has some only marks it, the last of them to go destroys it -- whatever order a host language's finalizers run in (Python's
     // cyclic collector destroys a context and its pairs in arbitrary order), nobody is left with a dangling pointer.
-    int refs = 0;
-    bool destroy_requested = false;
+    std::atomic<int> refs{0};          // (pairs may be destroyed on a worker thread while the owner lets go of the context)
+    std::atomic<bool> destroy_requested{false};
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;           // created by sfm_ctx_own_stream, destroyed with the context
@@ -67,6 +68,7 @@ struct sfm_ctx {
     unsigned int match_epoch = 0;      // one-match launches of the exact matcher tag their partials with it (match.hip: POLL)
     void *match_poll_ws = nullptr;     // ... in a buffer nothing else writes (epoch-tagged 64-bit words)
     size_t match_poll_ws_bytes = 0;
+    unsigned int *match_poll_flag = nullptr;   // pinned host word: raised by a polled merge that gave up (match.hip: match_poll_check)
     void *match_jobs_ws = nullptr;     // launch_match_jobs: the job array, tickets and per-split partials of every match of the launch
     size_t match_jobs_ws_bytes = 0;     // zeroed ticket area in front of the partials (grows with the query-block count)
     // pre-filter matcher (match_prefilter.hip): fp16 copies, norms, per-split partials, candidate lists
@@ -253,6 +255,7 @@ int launch_match_none(sfm_ctx *ctx, int n1, sfm_sift_point *sift1);
 int launch_match_prefilter(sfm_ctx *ctx, const float *d1, int n1, int ld1, const float *d2, int n2, int ld2,
                            float *d_best, float *d_second, int32_t *d_index,
                            sfm_sift_point *sift1, const sfm_sift_point *sift2);
+int match_poll_check(sfm_ctx *ctx);                                                // SFM_E_HIP once after a polled merge gave up (match.hip)
 int launch_match(sfm_ctx *ctx, const float *d1, int n1, int ld1, const float *d2, int n2, int ld2,
                  float *d_best, float *d_second, int32_t *d_index,
                  sfm_sift_point *sift1, const sfm_sift_point *sift2);

@@ -118,10 +118,13 @@ __device__ __forceinline__ void stage_scores(const float *cur, const float (&bq)
 // 64-bit words (launch epoch << 32 | payload) and the block of the LAST split -- dispatched after every other split of its
 // query block, so it never holds a CU that a block it waits for still needs -- polls them instead of drawing a ticket.  What the
 // ticket scheme serialises (partials acknowledged -> ticket round trip, 16 atomics on one address -> loads of the partials -> merge)
-// becomes one wait for the slowest peer's words.  The wait is bounded (kPollLimit polls, ~0.1 s): a launch that gives up sets
-// tickets[qblock] to kPollGaveUp, which the next launch_match reports (nothing in the protocol can time out short of a lost block).
+// becomes one wait for the slowest peer's words.  The wait is bounded (kPollLimit polls, ~0.1 s).  A block that gives up emits
+// "no match" (index -1, scores 0) for its queries and raises the context's poll flag -- a word in pinned host memory that nothing else
+// writes, looked at by the host at the next launch_match and at every synchronising call of the context (match_poll_check): that
+// call fails with SFM_E_HIP and clears the flag.  The ticket workspace is not touched (it is shared with the ticket-scheme launches and
+// the fused matcher, which rely on its words being zero between calls).  Nothing in the protocol can time out short of a lost block
+// or a dispatcher that starts the last split's block long before the others; the lab-bench library can force it (SFM_MATCH_POLL_LIMIT).
 constexpr unsigned int kPollLimit = 1u << 20;
-constexpr unsigned int kPollGaveUp = 0xDEADu;
 
 template <int CT, int W, bool POLL = false>
 __device__ __forceinline__ void match_body(const float *__restrict__ q, int nq, int ldq,
@@ -130,7 +133,8 @@ __device__ __forceinline__ void match_body(const float *__restrict__ q, int nq, 
                        float *__restrict__ ws_best, float *__restrict__ ws_second, int *__restrict__ ws_idx,
                        unsigned int *__restrict__ tickets, float *__restrict__ out_best, float *__restrict__ out_second,
                        int *__restrict__ out_idx, sfm_sift_point *__restrict__ sift1, const sfm_sift_point *__restrict__ sift2,
-                       const int qblock, const int split, const int nsplit, const unsigned int epoch = 0u)
+                       const int qblock, const int split, const int nsplit, const unsigned int epoch = 0u,
+                       unsigned int *poll_flag = nullptr, const unsigned int poll_limit = kPollLimit)
 {
     __shared__ __attribute__((aligned(16))) float lds[2][kRowsPerStage * kLdsStride];
     const int lane = threadIdx.x & 63;
@@ -248,7 +252,7 @@ __device__ __forceinline__ void match_body(const float *__restrict__ q, int nq, 
 #pragma unroll
                         for (int c = 0; c < 3; ++c) fresh = fresh && (unsigned int)(wv[u][c] >> 32) == epoch;
                     if (fresh) break;
-                    if (++polls > kPollLimit) { gave_up = true; break; }
+                    if (++polls > poll_limit) { gave_up = true; break; }
                     __builtin_amdgcn_s_sleep(2);
                 }
                 if (gave_up) break;
@@ -262,7 +266,10 @@ __device__ __forceinline__ void match_body(const float *__restrict__ q, int nq, 
             }
             const Top2 mine{ own[3 * k], own[3 * k + 1], __float_as_int(own[3 * k + 2]) };
             t = first ? mine : top2_merge(t, mine);
-            if (gave_up) { tickets[qblock] = kPollGaveUp; t = Top2{ 0.0f, 0.0f, -1 }; }
+            if (gave_up) {
+                if (poll_flag) __hip_atomic_store(poll_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                t = Top2{ 0.0f, 0.0f, -1 };
+            }
             match_emit(p1, t, out_best, out_second, out_idx, sift1, sift2);
         }
         return;
@@ -331,10 +338,11 @@ void match_mfma_kernel(const float *__restrict__ q, int nq, int ldq,
                        int rows_per_split,
                        float *__restrict__ ws_best, float *__restrict__ ws_second, int *__restrict__ ws_idx,
                        unsigned int *__restrict__ tickets, float *__restrict__ out_best, float *__restrict__ out_second,
-                       int *__restrict__ out_idx, sfm_sift_point *__restrict__ sift1, const sfm_sift_point *__restrict__ sift2, unsigned int epoch)
+                       int *__restrict__ out_idx, sfm_sift_point *__restrict__ sift1, const sfm_sift_point *__restrict__ sift2, unsigned int epoch,
+                       unsigned int *poll_flag, unsigned int poll_limit)
 {
     match_body<CT, W, POLL>(q, nq, ldq, db, ndb, lddb, rows_per_split, ws_best, ws_second, ws_idx, tickets, out_best, out_second, out_idx, sift1, sift2,
-                            (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.y, epoch);
+                            (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.y, epoch, poll_flag, poll_limit);
 }
 
 // Many matches of ONE query set in one launch (sfm_process_pairs: all pairs (i, j) that share their first view i --
@@ -443,10 +451,25 @@ int match_jobs_workspace(sfm_ctx *ctx, int n1, int qblocks, int rows_unit, int r
     return SFM_OK;
 }
 
+// Did a polled merge of an earlier launch on this context give up (match_body<POLL>)?  The flag lives in pinned host memory, so this
+// is a plain load; it is only ever raised by a kernel that has already written "no match" for the queries concerned.
+int match_poll_check(sfm_ctx *ctx)
+{
+    if (!ctx->match_poll_flag) return SFM_OK;
+    volatile unsigned int *f = ctx->match_poll_flag;
+    if (*f == 0u) return SFM_OK;
+    *f = 0u;
+    set_error("exact matcher: the polled merge of an earlier sfm_match call on this context gave up waiting for the other splits' partials; "
+              "the matches of that call are invalid (SFM_MATCH_MERGE=ticket selects the ticket merge)");
+    return SFM_E_HIP;
+}
+
 int launch_match(sfm_ctx *ctx, const float *d1, int n1, int ld1, const float *d2, int n2, int ld2,
                  float *d_best, float *d_second, int32_t *d_index,
                  sfm_sift_point *sift1, const sfm_sift_point *sift2)
 {
+    const int prc = match_poll_check(ctx);                 // an earlier launch's give-up is reported here at the latest
+    if (prc != SFM_OK) return prc;
     if (n1 <= 0 || n2 <= 0) return SFM_OK;                 // matching.cu:1095-1096
     int pick = match_pick(ctx, n1, n2);
     // rows exactly a multiple of 512 bytes apart (plain descriptor arrays, ld = 128): the scattered 16-byte loads of the fused
@@ -489,11 +512,28 @@ int launch_match(sfm_ctx *ctx, const float *d1, int n1, int ld1, const float *d2
     if (wrc != SFM_OK) return wrc;
 
     const dim3 grid(qblocks, nsplit);
-    // Every block of a one-match launch is resident at once (at most one per CU), so the partials can be POLLED by the last split's
-    // block (match_body<POLL>): no ticket, no ordering round trips.  SFM_MATCH_MERGE=ticket (environment, read once; A/B runs and
-    // tests) keeps the ticket scheme of rounds 1-4.
+    // A one-match launch has at most one block per CU (qblocks x nsplit <= CUs by construction of nsplit above; re-checked here), so
+    // on an otherwise idle device all its blocks are resident at once and the partials can be POLLED by the last split's block
+    // (match_body<POLL>): no ticket, no ordering round trips (1-2 us per call, profiles/r05_ab_match_merge_poll.txt).  When the
+    // device is NOT idle (a second stream's kernels hold CUs, a CU mask is in force) some blocks wait for a CU; the poller still makes
+    // progress as long as workgroups are dispatched in grid order -- it is the LAST split of its query block, so every block it waits
+    // for was dispatched before it and finishes without it.  HIP does not promise that order; if it is ever violated the poller's wait
+    // runs out and the call is REPORTED as failed (match_poll_check), never silently wrong.  Needs nsplit > 1 (nothing to merge
+    // otherwise) and the flag word; SFM_MATCH_MERGE=ticket (environment, read once; A/B runs, tests, profilers) keeps the ticket scheme.
     static const char *merge_env = getenv("SFM_MATCH_MERGE");
-    const bool poll = !(merge_env && merge_env[0] == 't') && (long long)qblocks * nsplit <= 2ll * ctx->num_cus;
+    if (!ctx->match_poll_flag) {
+        void *hp = nullptr;
+        if (hipHostMalloc(&hp, 64, hipHostMallocMapped) == hipSuccess && hp) { ctx->match_poll_flag = static_cast<unsigned int *>(hp); *ctx->match_poll_flag = 0u; }
+        else (void)hipGetLastError();
+    }
+    unsigned int *d_poll_flag = nullptr;
+    if (ctx->match_poll_flag && hipHostGetDevicePointer(reinterpret_cast<void **>(&d_poll_flag), ctx->match_poll_flag, 0) != hipSuccess) { d_poll_flag = nullptr; (void)hipGetLastError(); }
+    const bool poll = !(merge_env && merge_env[0] == 't') && nsplit > 1 && d_poll_flag && (long long)qblocks * nsplit <= (long long)ctx->num_cus;
+    unsigned int poll_limit = kPollLimit;
+#if SFM_AB
+    const char *limit_env = getenv("SFM_MATCH_POLL_LIMIT");             // lab bench: force the give-up path (tests/test_gpu_ab.py); read per call
+    if (limit_env && limit_env[0]) poll_limit = (unsigned int)strtoul(limit_env, nullptr, 10);
+#endif
     // The polled partials live in a buffer of their OWN (24 bytes per (split, query): three epoch-tagged 64-bit words) that nothing
     // else ever writes: the ticket workspace above is shared with the fused matcher, whose floats and indices could land in the
     // upper half of a polled word and pass for the current epoch.  Zeroed when (re)allocated and when the epoch wraps; epoch 0 is
@@ -517,7 +557,7 @@ int launch_match(sfm_ctx *ctx, const float *d1, int n1, int ld1, const float *d2
     const unsigned int epoch = ctx->match_epoch;
 #define SFM_MATCH_LAUNCH(CT_, W_, POLL_)                                                                                                      \
     hipLaunchKernelGGL((match_mfma_kernel<CT_, W_, POLL_>), grid, dim3(W_ * 64), 0, ctx->stream,                                             \
-                       d1, n1, ld1, d2, n2, ld2, rows_per_split, wb, wsnd, wi, tickets, d_best, d_second, d_index, sift1, sift2, epoch)
+                       d1, n1, ld1, d2, n2, ld2, rows_per_split, wb, wsnd, wi, tickets, d_best, d_second, d_index, sift1, sift2, epoch, d_poll_flag, poll_limit)
     if (ct == 2) { if (poll) SFM_MATCH_LAUNCH(2, 8, true); else SFM_MATCH_LAUNCH(2, 8, false); }
     else if (wv == 8) { if (poll) SFM_MATCH_LAUNCH(1, 8, true); else SFM_MATCH_LAUNCH(1, 8, false); }
     else { if (poll) SFM_MATCH_LAUNCH(1, 4, true); else SFM_MATCH_LAUNCH(1, 4, false); }

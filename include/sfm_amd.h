@@ -31,8 +31,11 @@ extern "C" {
 #pragma GCC visibility push(default)
 
 /* 1: rounds 1-3.  2: sfm_ransac_params.reserved[] must be zero, kernel id 3 and the probe / trace hooks moved to the lab-bench
- * flavour (include/sfm_amd_ab.h, libsfm_amd_ab.so); sfm_ctx_last_pairs_batched added; sfm_amd_comm.h: count-sized feature exchange, sfm_comm_last_exchange. */
-#define SFM_ABI_VERSION 2
+ * flavour (include/sfm_amd_ab.h, libsfm_amd_ab.so); sfm_ctx_last_pairs_batched added; sfm_amd_comm.h: count-sized feature exchange, sfm_comm_last_exchange.
+ * 3: sfm_ctx_retain / sfm_ctx_release and reference-counted contexts (sfm_ctx_destroy on a context that pairs or communicators
+ * still point at returns SFM_OK and defers to the last of them; the count is atomic); sfm_ctx_synchronize and sfm_match* report a
+ * polled matcher merge that gave up (SFM_E_HIP, once); SFM_QUIRK_MATCH_AMBIGUITY. */
+#define SFM_ABI_VERSION 3
 
 #define SFM_OK           0
 #define SFM_E_INVALID   (-1)   /* bad argument                                     */

@@ -22,7 +22,7 @@ def test_header_symbols_exported():
     missing = [n for n in names if not hasattr(S.lib(), n)]
     assert not missing, missing
     assert sorted(S.EXPORTS) == names
-    assert S.lib().sfm_abi_version() == 2
+    assert S.lib().sfm_abi_version() == 3
     assert not S.AB and S.LIB_PATH.endswith("libsfm_amd.so")
 
 
@@ -62,7 +62,7 @@ def test_lab_bench_flavour_imports_next_to_the_product():
     import cuda_sfm_amd_ab as A
     assert A.AB and A.LIB_PATH.endswith("libsfm_amd_ab.so") and A.KERNEL_MFMA == 3 and not hasattr(S, "KERNEL_MFMA")
     assert not [n for n in A.EXPORTS if not hasattr(A.lib(), n)]
-    assert A.lib().sfm_abi_version() == 2
+    assert A.lib().sfm_abi_version() == 3
     with pytest.raises(ImportError):
         A.comm_lib()                                  # the communicator library is linked against the product
 
@@ -217,7 +217,7 @@ int main(void)
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
     ver, hyps, sweeps, floats = r.stdout.split()
-    assert (int(ver), int(hyps), int(sweeps)) == (2, 512, 0) and int(floats) > 8 * 1920 * 1080
+    assert (int(ver), int(hyps), int(sweeps)) == (3, 512, 0) and int(floats) > 8 * 1920 * 1080
 
 
 def test_comm_library_argument_and_lifecycle_paths_without_a_gpu():

@@ -18,7 +18,7 @@ pytestmark = pytest.mark.gpu
 
 def test_flavours():
     assert S.AB and not PROD.AB and S.LIB_PATH != PROD.LIB_PATH
-    assert S.lib().sfm_abi_version() == PROD.lib().sfm_abi_version() == 2
+    assert S.lib().sfm_abi_version() == PROD.lib().sfm_abi_version() == 3
     for name in S.AB_EXPORTS:
         assert hasattr(S.lib(), name) and not hasattr(PROD.lib(), name), name
 
@@ -360,3 +360,58 @@ def test_g_rule_kernel_still_equals_oracle(gpu_ab, n, H, thr):
     p.reserved[3] = 3                                                    # stand-alone record kernel, band rule
     pair.estimateE(p)
     P.check_all(pair, scene, p, H, n)
+
+
+def test_polled_merge_give_up_is_reported_and_contained(gpu_ab):
+    """The exact matcher's polled merge (match.hip, POLL) bounds its wait; a block that gives up must not leave silently wrong matches
+    or a poisoned workspace behind.  SFM_MATCH_POLL_LIMIT=0 (lab-bench library only, read per call) makes the poller give up whenever a
+    partial is not there at its first look: the give-up is reported once -- by the next sfm_match* call or sfm_ctx_synchronize, as
+    SFM_E_HIP -- the queries concerned carry index -1 / score 0 (never a stale or half-merged value), and with the limit back the
+    same context matches correctly again, through the polled merge and through the ticket-scheme fused matcher that shares the
+    ticket workspace."""
+    import os
+    torch, dev, ctx = gpu_ab
+    n1, n2 = 2155, 2112                # 14 splits of 160 database rows, the last one of 32: its block is done (and polls) long before the others
+    d1, _, _ = synth.descriptors(n1, seed=31)
+    d2, _, _ = synth.descriptors(n2, seed=32)
+    ob, os_, oi = O.match_desc(d1, d2)
+    t1, t2 = to_dev(torch, dev, d1), to_dev(torch, dev, d2)
+    best = torch.empty(n1, dtype=torch.float32, device=dev); sec = torch.empty_like(best); idx = torch.empty(n1, dtype=torch.int32, device=dev)
+    ctx.set_match_kernel(S.MATCH_EXACT)
+    reported = 0
+    try:
+        os.environ["SFM_MATCH_POLL_LIMIT"] = "0"
+        for it in range(200):
+            best.fill_(-1.0); sec.fill_(-1.0); idx.fill_(-9)
+            torch.cuda.synchronize()
+            try:
+                ctx.match_soa(t1, n1, 128, t2, n2, 128, best, sec, idx)
+                ctx.synchronize()
+            except S.SfmError as e:
+                assert e.code == S.E_HIP and "polled merge" in str(e)
+                reported += 1
+                torch.cuda.synchronize()
+                continue
+            # no report: every query either matched exactly or -- if the give-up of THIS launch is still to be reported -- says "no match"
+            i = idx.cpu().numpy(); b = best.cpu().numpy()
+            gave = i == -1
+            assert np.array_equal(i[~gave], oi[~gave]) and same_bits(b[~gave], ob[~gave]) and not (b[gave] != 0).any(), it
+            if gave.any():
+                with pytest.raises(S.SfmError):
+                    ctx.synchronize()                                  # ... which the next synchronising call does
+                reported += 1
+            if reported >= 3:
+                break
+        assert reported >= 1, "SFM_MATCH_POLL_LIMIT=0 never made a poller give up in 200 launches"
+    finally:
+        os.environ.pop("SFM_MATCH_POLL_LIMIT", None)
+    ctx.synchronize()                                                  # the flag was cleared by the report
+    try:
+        for kern in (S.MATCH_EXACT, S.MATCH_FUSED, S.MATCH_EXACT):
+            ctx.set_match_kernel(kern)
+            best.fill_(-1.0); sec.fill_(-1.0); idx.fill_(-9)
+            ctx.match_soa(t1, n1, 128, t2, n2, 128, best, sec, idx)
+            ctx.synchronize()
+            assert np.array_equal(idx.cpu().numpy(), oi) and same_bits(best.cpu().numpy(), ob) and same_bits(sec.cpu().numpy(), os_), kern
+    finally:
+        ctx.set_match_kernel(S.MATCH_AUTO)
