@@ -56,10 +56,12 @@ ALG_BYTES_PER_HYP = 72.0       # 32 B indices + 36 B E + 4 B count
 # irreducible work of the pre-filter scan per rule (prefilter_math.hpp): "band" (round 5, the product) = one v_alignbit_b32 per pair (bit 30 of
 # the accumulator into the lane's mask) and two v_mfma_f32_32x32x16_f16 per 32 x 32 pairs; "G" (rounds 2-4, lab bench, reserved[3] == 4) =
 # v_fma_f32 + v_alignbit_b32 per pair and three MFMAs
-PF_RULES = {"band": (1, 2), "G": (2, 3)}
+# scoring-kernel rules: (vector-issue cycles of a SIMD per 1024 pairs for the irreducible scan, fp16 MFMAs per 1024 pairs)
+#   pack: half a v_cvt_scalef32_2xpk16_bf6_f32 (64.6 cycles per 2048 pairs); band: 16 v_alignbit_b32 at 4.24; G: 16 v_fma_f32 at 2.54 + 16 v_alignbit_b32
+PF_RULES = {"pack": (32.3, 2), "band": (67.8, 2), "G": (108.5, 3)}
 PF_MFMA_CYCLES = 32           # issue interval of one 32x32x16 f16 MFMA on a SIMD (8 passes x 4 cycles; profiles/r02_mfma_rate_probe.txt)
 PF_SOURCES = ("ransac_prefilter.hip", "prefilter_math.hpp", "prefilter_record.hpp", "ransac.hip", "ransac_device.hpp", "device_math.hpp")
-TRAFFIC_JSON = os.path.join("profiles", "r05_traffic.json")
+TRAFFIC_JSON = os.path.join("profiles", "r06_traffic.json")
 PUBLISHED_ESTIMATE_E_MS = 24.12     # img/data.xlsx B5 / README.md:54 of the reference: estimateE on the dino pair, GTX 1080 Ti
 
 # BASELINE.json configs that are RANSAC workloads (configs[1] and [4] are pipelines: see `extra`)
@@ -364,7 +366,7 @@ def quoted_counters(kname, n, local_hyps):
         have = source_hash()
         if doc.get("code_sha256_16") != have:
             return None, (f"{TRAFFIC_JSON} was collected on kernel sources {doc.get('code_sha256_16')}, this tree has {have}: "
-                          "not quoted (re-run profiles/collect_r05.sh)")
+                          "not quoted (re-run profiles/collect_r06.sh)")
         t = dict(t)
         solve = doc.get("ransac_solve_lanes1_qr") or doc.get("ransac_solve_lanes2") or {}
         if solve.get("fetch_kb") is not None and solve.get("write_kb") is not None:
@@ -375,8 +377,17 @@ def quoted_counters(kname, n, local_hyps):
         return None, f"{TRAFFIC_JSON}: {type(e).__name__}"
 
 
-def roofline_block(kernel_id, n, local_hyps, score_s, solve_s, clock_mhz, measured_in, rule="band"):
-    PF_SCAN_VALU_PER_PAIR, PF_MFMA_PER_1024_PAIRS = PF_RULES[rule]
+def reserved_rule(reserved):
+    """Which scoring rule the lab-bench switches select (ransac_prefilter.hip: prefilter_rule)."""
+    r = list(reserved) + [0] * 4
+    if r[3] == 4 or r[3] >= 16:
+        return "G"
+    if r[3] == 5 or r[1] in (5, 7, 9):
+        return "band"
+    return "pack"
+
+
+def roofline_block(kernel_id, n, local_hyps, score_s, solve_s, clock_mhz, measured_in, rule="pack"):
     kname = KERNEL_NAMES.get(kernel_id, "?")
     pairs = float(local_hyps) * n
     alg_flops = pairs * FLOP_PER_POINT
@@ -388,43 +399,32 @@ def roofline_block(kernel_id, n, local_hyps, score_s, solve_s, clock_mhz, measur
               "algorithmic_equiv_note": "SURVEY 8(d): 38 FLOP per (hypothesis, point) pair over the launch time; the FP32 peak is 157.3 TFLOP/s",
               "pipeline_algorithmic_equiv_tflops": (float(local_hyps) * (FLOP_PER_HYP + FLOP_PER_POINT * n)) / max(score_s + solve_s, 1e-12) / 1e12}
     if kernel_id == 4:
+        # ONE floor: the work the kernel executes per 1024 pairs on its binding unit.  All three rules issue their fp16 MFMAs (32 cycles of a
+        # SIMD's matrix pipe each) next to the scan's vector instructions; the floor is whichever of the two takes longer at 2.4 GHz:
+        #   pack  (round 6, the product): 2 MFMAs = 64 cycles against 1/2 v_cvt_scalef32_2xpk16_bf6_f32 = 32.3 cycles  -> MFMA-bound
+        #   band  (round 5, lab bench):   2 MFMAs = 64 cycles against 16 v_alignbit_b32 = 67.8 cycles                  -> scan-bound (by 6 %)
+        #   G     (rounds 2-4, lab bench): 3 MFMAs = 96 cycles against 16 v_fma + 16 v_alignbit = 108 cycles
+        # (instruction costs measured on the MI355X: profiles/r05_valu_rate_table.txt, r06_cvt_pack_probe.txt)
         clock = PEAK_CLOCK_MHZ * 1e6
-        valu_floor = pairs * PF_SCAN_VALU_PER_PAIR / 64.0 / NUM_SIMDS * 4.0 / clock
-        mfma_floor = pairs / 1024.0 * PF_MFMA_PER_1024_PAIRS * PF_MFMA_CYCLES / NUM_SIMDS / clock
+        scan_cycles, mfmas = PF_RULES[rule]
+        valu_floor = pairs / 1024.0 * scan_cycles / NUM_SIMDS / clock
+        mfma_floor = pairs / 1024.0 * mfmas * PF_MFMA_CYCLES / NUM_SIMDS / clock
         floor = max(valu_floor, mfma_floor)
-        if valu_floor >= mfma_floor:
-            # one vector instruction-lane priced as one FMA slot (2 FLOP) of the plain (non-packed) FP32 vector rate
-            bound, peak = "valu_issue", FP32_PEAK_TFLOPS / 2.0
-            achieved = pairs * PF_SCAN_VALU_PER_PAIR * 2.0 / score_s / 1e12 if score_s > 0 else 0.0
-            detail = (f"vector-ALU issue: the irreducible scan of the {rule} rule is {PF_SCAN_VALU_PER_PAIR} vector instruction(s) per pair "
-                      + ("(v_alignbit_b32: bit 30 of the accumulator, |nt| >= 2, into the lane's mask), " if rule == "band" else "(v_fma_f32 G - nt^2, v_alignbit_b32), ")
-                      + "a VOP3 instruction, which a SIMD of gfx950 issues every 4.24 cycles (VOP2 fp32 / integer: 2.1; measured, profiles/r05_valu_rate_table.txt), "
-                      + "priced at 4 cycles per wave64 instruction = one FMA lane-slot (2 FLOP) of a 78.65 TFLOP/s rate (1024 SIMDs x 64 lanes / 4 cycles x 2 FLOP x 2.4 GHz); "
-                      f"the {PF_MFMA_PER_1024_PAIRS} fp16 MFMAs per 1024 pairs issue next to it (mfma_floor_ms)")
-        else:
-            bound, peak = "mfma", FP16_MFMA_PEAK_TFLOPS
-            achieved = pairs / 1024.0 * PF_MFMA_PER_1024_PAIRS * 32768.0 / score_s / 1e12 if score_s > 0 else 0.0
-            detail = f"fp16 MFMA issue: {PF_MFMA_PER_1024_PAIRS} v_mfma_f32_32x32x16_f16 (32768 FLOP each) per 1024 pairs"
-        out = {"bound": bound, "bound_detail": detail, "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+        mfma_tflops = pairs / 1024.0 * mfmas * 32768.0 / score_s / 1e12 if score_s > 0 else 0.0
+        out = {"bound": "mfma" if mfma_floor >= valu_floor else "valu_issue",
+               "bound_detail": (f"{rule} rule: {mfmas} x v_mfma_f32_32x32x16_f16 (32768 FLOP, 32 cycles of a SIMD's matrix pipe each) per 1024 (hypothesis, point) pairs; "
+                                f"the scan's vector instructions cost {scan_cycles:.1f} cycles of the SIMD's vector issue per 1024 pairs "
+                                "(profiles/r06_cvt_pack_probe.txt, r05_valu_rate_table.txt); floor_ms = the larger of the two at 2.4 GHz; "
+                                "achieved / peak are the fp16 MFMA FLOP the kernel executes against the dense fp16 MFMA peak (no sparsity)"),
+               "achieved": mfma_tflops, "peak": FP16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                "frac": (floor / score_s) if score_s > 0 else 0.0,
-               "valu_floor_ms": 1e3 * valu_floor, "mfma_floor_ms": 1e3 * mfma_floor,
-               "frac_at_sustained_clock": (floor / score_s * PEAK_CLOCK_MHZ / clock_mhz) if (score_s > 0 and clock_mhz > 0) else None}
-        # Continuity with rounds 2-4, whose kernel executed the G rule (2 vector instructions per pair: floor 0.2185 ms at 2^32 pairs), and
-        # the issue model fitted in round 3 (4 cycles per vector instruction, ~16 per 32x32x16 fp16 MFMA; round 5 measured why it fits: VOP3
-        # instructions -- the scan's v_alignbit_b32 -- take 4.24 cycles of a SIMD, VOP2 ones 2.1, profiles/r05_valu_rate_table.txt):
-        # frac = max(valu, mfma) floors of THIS rule over the launch time; the formulation's floor moved, the launch got shorter.
-        g_floor = pairs * 2 / 64.0 / NUM_SIMDS * 4.0 / clock
-        model = pairs / 1024.0 * (4.0 * 16 * PF_SCAN_VALU_PER_PAIR + 16.0 * PF_MFMA_PER_1024_PAIRS) / NUM_SIMDS / clock
-        out["rule"] = rule
-        out["frac_against_the_round4_floor"] = (g_floor / score_s) if score_s > 0 else 0.0
-        out["frac_against_the_issue_model"] = (model / score_s) if score_s > 0 else 0.0
-        out["issue_model_floor_ms"] = 1e3 * model
-        if rule == "band":
-            # measured in isolation (profiles/r05_mfma_valu_overlap_probe.txt): the scan phase of 1024 pairs -- two fp16 MFMAs and sixteen
-            # v_alignbit_b32 -- takes 85 cycles of a SIMD with four wavefronts on it (69 / 67 for either half alone), before any survivor
-            scan = pairs / 1024.0 * 85.0 / NUM_SIMDS / clock
-            out["measured_scan_floor_ms"] = 1e3 * scan
-            out["frac_against_the_measured_scan_floor"] = (scan / score_s) if score_s > 0 else 0.0
+               "floor_ms": 1e3 * floor, "mfma_floor_ms": 1e3 * mfma_floor, "valu_scan_floor_ms": 1e3 * valu_floor,
+               "frac_at_sustained_clock": (floor / score_s * PEAK_CLOCK_MHZ / clock_mhz) if (score_s > 0 and clock_mhz > 0) else None,
+               "rule": rule,
+               # SURVEY 8(d)'s figure, kept for the record and flagged: it prices 38 FLOP per pair that this kernel does not execute
+               "survey_8d_ratio": alg_tflops / FP32_PEAK_TFLOPS,
+               "survey_8d_note": ("> 1: not a roofline fraction -- 38 FLOP x pairs / launch time over the 157.3 TFLOP/s FP32 peak; the kernel is a work-reducing "
+                                  "pre-filter (fp16 MFMA contraction + one-bit test for every pair, the exact 38-FLOP test for the ~1.3 % that survive)")}
     else:
         out = {"bound": "valu_fp32",
                "bound_detail": ("FP32 vector ALU issue (v_pk_fma_f32 and friends); 157.3 TFLOP/s = 256 CU x 256 FLOP/clk x 2.4 GHz, "
@@ -499,7 +499,6 @@ def extra_ransac(S, synth, O, ctx, dev, torch, np, name, n, H, steps, hyp_count=
            "best_hypothesis": hyp, "inliers": cnt}
     if launch["kernel"] == 4 and score_ms > 0:
         r = roofline_block(4, n, local, score_ms / 1e3 / calls, solve_ms / 1e3 / calls, pair.last_clock_mhz(), "20 serial launches")
-        out["roofline_frac_against_the_round4_floor"] = r["frac_against_the_round4_floor"]
         out["roofline_frac"] = r["frac"]
     pair.close()
     if O is not None:
@@ -513,7 +512,7 @@ def extra_ransac(S, synth, O, ctx, dev, torch, np, name, n, H, steps, hyp_count=
     return out
 
 
-MATCH_TRAFFIC_JSON = os.path.join("profiles", "r05_match_traffic.json")
+MATCH_TRAFFIC_JSON = os.path.join("profiles", "r06_match_traffic.json")
 MATCH_SOURCES = ("match.hip", "match_fused.hip", "match_prefilter.hip", "match_common.hpp", "match_prefilter_math.hpp")
 
 
@@ -1155,7 +1154,7 @@ def rank_main(args):
                        "nccl_ranks": comm.nccl_ranks() if comm is not None else (world if mode == "torch" else 1),
                        "per_rank_kernel_ms": [{"rank": r, "solve": v[0], "score": v[1], "shader_clock_mhz": v[2]} for r, v in enumerate(per_rank)]},
             "roofline": roofline_block(launch["kernel"], n, local_hyps, score_s, solve_s, clock_mhz, measured_in,
-                                       rule="G" if (len(args.reserved) > 3 and (args.reserved[3] == 4 or args.reserved[3] >= 16)) else "band"),
+                                       rule=reserved_rule(args.reserved)),
             "result": {"best_hypothesis": hyp, "inliers": cnt, "mask_sum": mask_sum, "sampler_seed_of_this_result": last_seed},
         }
         if agree is not None:

@@ -44,6 +44,7 @@ KERNEL_AUTO, KERNEL_SPLIT, KERNEL_FUSED, KERNEL_PREFILTER = 0, 1, 2, 4
 if AB:
     KERNEL_MFMA = 3             # include/sfm_amd_ab.h
 QUIRK_MATCH_TAIL = 1
+QUIRK_MATCH_AMBIGUITY = 2
 MATCH_AUTO, MATCH_EXACT, MATCH_PREFILTER, MATCH_FUSED = 0, 1, 2, 3
 POSE_REFERENCE, POSE_CORRECT = 0, 1
 (BUF_X0, BUF_X1, BUF_U0, BUF_U1, BUF_E, BUF_P, BUF_PINV, BUF_POINTS, BUF_COUNTS, BUF_MASK, BUF_KEY,
@@ -233,7 +234,8 @@ class Context:
         _check(_lib.sfm_ctx_set_stream(self._h, stream), "sfm_ctx_set_stream")
 
     def set_quirks(self, flags):
-        """SFM_QUIRK_* behaviours of the reference for A/B runs (QUIRK_MATCH_TAIL: skip the last num_pts2 % 32 points)."""
+        """SFM_QUIRK_* behaviours of the reference for A/B runs (QUIRK_MATCH_TAIL: skip the last num_pts2 % 32 points;
+        QUIRK_MATCH_AMBIGUITY: FindMaxCorr10's own `ambiguity`, whose merge ignores seven of the eight second-best scores)."""
         _check(_lib.sfm_ctx_set_quirks(self._h, C.c_uint(int(flags))), "sfm_ctx_set_quirks")
 
     def set_match_kernel(self, kernel):

@@ -172,7 +172,7 @@ int sfm_ctx_set_stream(sfm_ctx *ctx, void *hip_stream)
 int sfm_ctx_set_quirks(sfm_ctx *ctx, unsigned int flags)
 {
     SFM_REQUIRE(ctx, SFM_E_INVALID, "null context");
-    SFM_REQUIRE((flags & ~SFM_QUIRK_MATCH_TAIL) == 0, SFM_E_INVALID, "unknown quirk flags 0x%x", flags);
+    SFM_REQUIRE((flags & ~(SFM_QUIRK_MATCH_TAIL | SFM_QUIRK_MATCH_AMBIGUITY)) == 0, SFM_E_INVALID, "unknown quirk flags 0x%x", flags);
     ctx->quirks = flags;
     for (sfm_ctx *l : ctx->lane) if (l) l->quirks = flags;          // the lane contexts of sfm_process_pairs / sfm_extract_views
     return SFM_OK;
@@ -346,7 +346,9 @@ int sfm_match(sfm_ctx *ctx, sfm_sift_point *d_sift1, int n1, const sfm_sift_poin
         if (n2 == 0) return launch_match_none(ctx, n1, d_sift1);
     }
     const int ld = (int)(sizeof(sfm_sift_point) / sizeof(float));
-    return launch_match(ctx, d_sift1->data, n1, ld, d_sift2->data, n2, ld, nullptr, nullptr, nullptr, d_sift1, d_sift2);
+    const int rc = launch_match(ctx, d_sift1->data, n1, ld, d_sift2->data, n2, ld, nullptr, nullptr, nullptr, d_sift1, d_sift2);
+    if (rc != SFM_OK || !(ctx->quirks & SFM_QUIRK_MATCH_AMBIGUITY)) return rc;
+    return launch_match_ambiguity_quirk(ctx, d_sift1->data, n1, ld, d_sift2->data, n2, ld, d_sift1, nullptr);      // matching.cu:378-396
 }
 
 int sfm_match_soa(sfm_ctx *ctx, const float *d_desc1, int n1, int ld1, const float *d_desc2, int n2, int ld2,
@@ -359,7 +361,9 @@ int sfm_match_soa(sfm_ctx *ctx, const float *d_desc1, int n1, int ld1, const flo
     SFM_REQUIRE(ld1 >= 128 && ld2 >= 128 && ld1 % 4 == 0 && ld2 % 4 == 0, SFM_E_INVALID, "row strides must be >= 128 and multiples of 4 floats");
     SFM_REQUIRE(((uintptr_t)d_desc1 & 15) == 0 && ((uintptr_t)d_desc2 & 15) == 0, SFM_E_INVALID, "descriptor rows must be 16-byte aligned");
     SFM_HIP_TRY(hipSetDevice(ctx->device));
-    return launch_match(ctx, d_desc1, n1, ld1, d_desc2, n2, ld2, d_best, d_second, d_index, nullptr, nullptr);
+    const int rc = launch_match(ctx, d_desc1, n1, ld1, d_desc2, n2, ld2, d_best, d_second, d_index, nullptr, nullptr);
+    if (rc != SFM_OK || !(ctx->quirks & SFM_QUIRK_MATCH_AMBIGUITY) || !d_second) return rc;
+    return launch_match_ambiguity_quirk(ctx, d_desc1, n1, ld1, d_desc2, n2, ld2, nullptr, d_second);
 }
 
 // ---- ExtractSift ---------------------------------------------------------------------------------
@@ -1280,6 +1284,10 @@ int sfm_process_pairs(sfm_ctx *ctx, const float h_K[9], const float h_Kinv[9], c
                 mj.back().sift1 = const_cast<sfm_sift_point *>(j.s1);             // as after the sequential loop: the last match's fields
                 keep_alive.push_back(std::move(mj));
                 rc = launch_match_jobs(c, j.s1->data, j.n, ldf, keep_alive.back().data(), (int)keep_alive.back().size(), run_kernel);
+                if (rc == SFM_OK && (c->quirks & SFM_QUIRK_MATCH_AMBIGUITY)) {     // the record fields are the LAST match's: so is the reference's ambiguity
+                    const MatchJob &last = keep_alive.back().back();
+                    rc = launch_match_ambiguity_quirk(c, j.s1->data, j.n, ldf, last.db, last.ndb, ldf, const_cast<sfm_sift_point *>(j.s1), nullptr);
+                }
                 k = k1;
                 continue;
             }
@@ -1295,6 +1303,7 @@ int sfm_process_pairs(sfm_ctx *ctx, const float h_K[9], const float h_Kinv[9], c
                 }
             } else {
                 rc = launch_match(c, j.s1->data, j.n, ldf, j.s2->data, n2, ldf, nullptr, nullptr, const_cast<int *>(j.m_idx), s1w, j.s2);
+                if (rc == SFM_OK && (c->quirks & SFM_QUIRK_MATCH_AMBIGUITY)) rc = launch_match_ambiguity_quirk(c, j.s1->data, j.n, ldf, j.s2->data, n2, ldf, s1w, nullptr);
             }
             ++k;
         }

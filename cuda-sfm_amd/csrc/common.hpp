@@ -255,6 +255,7 @@ int launch_match_none(sfm_ctx *ctx, int n1, sfm_sift_point *sift1);
 int launch_match_prefilter(sfm_ctx *ctx, const float *d1, int n1, int ld1, const float *d2, int n2, int ld2,
                            float *d_best, float *d_second, int32_t *d_index,
                            sfm_sift_point *sift1, const sfm_sift_point *sift2);
+int launch_match_ambiguity_quirk(sfm_ctx *ctx, const float *d1, int n1, int ld1, const float *d2, int n2, int ld2, sfm_sift_point *sift1, float *d_second);   // SFM_QUIRK_MATCH_AMBIGUITY
 int match_poll_check(sfm_ctx *ctx);                                                // SFM_E_HIP once after a polled merge gave up (match.hip)
 int launch_match(sfm_ctx *ctx, const float *d1, int n1, int ld1, const float *d2, int n2, int ld2,
                  float *d_best, float *d_second, int32_t *d_index,

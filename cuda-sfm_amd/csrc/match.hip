@@ -377,6 +377,87 @@ int launch_match_none(sfm_ctx *ctx, int n1, sfm_sift_point *sift1)
     return SFM_OK;
 }
 
+// SFM_QUIRK_MATCH_AMBIGUITY: the reference's `ambiguity` (matching.cu:301-397), which is NOT second best / best.  FindMaxCorr10 keeps
+// eight running (best, second, index) triples per query -- triple iy sees the rows r of the second set with (r mod 32) / 4 == iy, in
+// ascending order, strict > (:361-371) -- and merges them at the end (:378-396) starting from triple 0, comparing only the other
+// triples' BEST scores: the second-best scores of triples 1..7 never enter, so the result is a lower bound of the true second best
+// (equal for most queries, smaller whenever the runner-up shares its class with a better row).  FindHomography gates on it
+// (matching.cu:1034-1037), so the reference and the exact matcher can select different match subsets.  This kernel redoes the
+// reference's bookkeeping on the same scores (one fused chain per pair, d = 0..127 in order: the product's and the reference's
+// bits) and overwrites `ambiguity` (records) / `second` (plain arrays); score and index stay the main kernel's.
+// One block = 32 queries x 8 triples (256 threads), the second set streamed through LDS 32 rows at a time: 5 LDS reads per 16 FMAs,
+// ~18 us at 2048^2 -- a behaviour switch for A/B runs against the reference, not a hot path.
+constexpr int kAmbStride = 132;          // floats per staged descriptor row (16-byte aligned rows, 2-way bank conflicts at most)
+__global__ __launch_bounds__(256)
+void match_ambiguity_quirk_kernel(const float *__restrict__ q, int nq, int ldq, const float *__restrict__ db, int ndb, int lddb,
+                                  sfm_sift_point *__restrict__ sift1, float *__restrict__ out_second)
+{
+    __shared__ __attribute__((aligned(16))) float qs[32 * kAmbStride];
+    __shared__ __attribute__((aligned(16))) float bs[32 * kAmbStride];
+    const int tx = threadIdx.x & 31, iy = threadIdx.x >> 5;
+    const int bp1 = 32 * blockIdx.x;
+    for (int k = threadIdx.x; k < 32 * 32; k += 256) {                   // 32 queries x 32 float4
+        const int j = k >> 5, d = k & 31;
+        const int p1 = min(bp1 + j, nq - 1);                              // (:308: rows past the end repeat the last query)
+        reinterpret_cast<float4 *>(qs + j * kAmbStride)[d] = reinterpret_cast<const float4 *>(q + (size_t)p1 * ldq)[d];
+    }
+    float best = 0.0f, second = 0.0f;
+    int index = -1;
+    for (int bp2 = 0; bp2 < ndb; bp2 += 32) {
+        __syncthreads();
+        for (int k = threadIdx.x; k < 32 * 32; k += 256) {
+            const int j = k >> 5, d = k & 31;
+            const int p2 = min(bp2 + j, ndb - 1);
+            reinterpret_cast<float4 *>(bs + j * kAmbStride)[d] = reinterpret_cast<const float4 *>(db + (size_t)p2 * lddb)[d];
+        }
+        __syncthreads();
+        float score[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+        const float4 *v1p = reinterpret_cast<const float4 *>(qs + tx * kAmbStride);
+        for (int d = 0; d < 32; ++d) {
+            const float4 v1 = v1p[d];
+#pragma unroll
+            for (int dy = 0; dy < 4; ++dy) {
+                const float4 v2 = reinterpret_cast<const float4 *>(bs + (4 * iy + dy) * kAmbStride)[d];
+                score[dy] = fmaf(v1.x, v2.x, score[dy]);
+                score[dy] = fmaf(v1.y, v2.y, score[dy]);
+                score[dy] = fmaf(v1.z, v2.z, score[dy]);
+                score[dy] = fmaf(v1.w, v2.w, score[dy]);
+            }
+        }
+#pragma unroll
+        for (int dy = 0; dy < 4; ++dy) {
+            const int p2 = bp2 + 4 * iy + dy;
+            if (p2 >= ndb) break;                                         // (a last block of fewer than 32 rows: without SFM_QUIRK_MATCH_TAIL it is searched)
+            if (score[dy] > best) { second = best; best = score[dy]; index = p2; }
+            else if (score[dy] > second) second = score[dy];
+        }
+    }
+    __syncthreads();
+    float *scores1 = qs, *scores2 = qs + 256;
+    int *indices = reinterpret_cast<int *>(qs + 512);
+    scores1[iy * 32 + tx] = best; scores2[iy * 32 + tx] = second; indices[iy * 32 + tx] = index;
+    __syncthreads();
+    if (iy == 0 && bp1 + tx < nq) {                                       // the merge, as written (:378-390)
+        float mx = scores1[tx], sec = scores2[tx];
+        int idx = indices[tx];
+        for (int y = 0; y < 8; ++y)
+            if (idx != indices[y * 32 + tx]) {
+                if (scores1[y * 32 + tx] > mx) { sec = fmaxf(mx, sec); mx = scores1[y * 32 + tx]; idx = indices[y * 32 + tx]; }
+                else if (scores1[y * 32 + tx] > sec) sec = scores1[y * 32 + tx];
+            }
+        if (sift1) sift1[bp1 + tx].ambiguity = sec / (mx + 1e-6f);
+        if (out_second) out_second[bp1 + tx] = sec;
+    }
+}
+
+int launch_match_ambiguity_quirk(sfm_ctx *ctx, const float *d1, int n1, int ld1, const float *d2, int n2, int ld2, sfm_sift_point *sift1, float *d_second)
+{
+    if (n1 <= 0 || n2 <= 0 || (!sift1 && !d_second)) return SFM_OK;
+    hipLaunchKernelGGL(match_ambiguity_quirk_kernel, dim3((n1 + 31) / 32), dim3(256), 0, ctx->stream, d1, n1, ld1, d2, n2, ld2, sift1, d_second);
+    SFM_HIP_TRY(hipGetLastError());
+    return SFM_OK;
+}
+
 // scratch of a one-match launch: one ticket per query block (zero between calls: the merging block resets its own) + the
 // per-split partials.  The ticket area only ever grows (sized from the largest query-block count seen, so any n1 works); it
 // sits in front of the partials and is zeroed when the workspace is (re)allocated -- the partials of one call must never land

@@ -446,6 +446,26 @@ SFM_HD uint32_t pf_pack_code(int b)
     return (uint32_t)((j & 3) + 8 * (j >> 2)) | ((uint32_t)st << 5);
 }
 
+// The same as a shift out of a 64-bit constant (what the kernel runs): field f = 2 j + s of the survivor at bit (31 - b).  Bits 31 - b
+// and 30 - b (b even) share the even position p = 30 - b of the merged registers, whose field among the 16 of its half is 4 bits of
+// the table; the odd bit belongs to the second half (registers 3..5: + 16).
+SFM_HD constexpr uint32_t pf_pack_field_local(int p)              // p = 0, 2, .., 30: position within registers 0..2 (or 3..5)
+{
+    return (uint32_t)(p % 6 == 4 ? p / 6 : p % 6 == 2 ? p / 6 + 5 : p / 6 + 10);
+}
+SFM_HD constexpr unsigned long long pf_pack_table()
+{
+    unsigned long long t = 0ull;
+    for (int i = 0; i < 16; ++i) t |= (unsigned long long)pf_pack_field_local(30 - 2 * i) << (4 * i);      // index b >> 1
+    return t;
+}
+SFM_HD uint32_t pf_pack_field(int b)
+{
+    constexpr unsigned long long kTable = pf_pack_table();
+    const uint32_t local = (uint32_t)(kTable >> (((uint32_t)b << 1) & 60u)) & 15u;
+    return local + ((~(uint32_t)b & 1u) << 4);                    // bit (31 - b) odd <=> b even: the second half
+}
+
 // The coefficients of the OTHER divisor in the positions prefilter_zero_divisor_cells / prefilter_zero_divisor read:
 // b = A^T x1 + (e6, e7) has rows (e0 e3 e6), (e1 e4 e7), so the same code decides db_c = 0 for first-view positions.
 SFM_HD void prefilter_transposed(const float e[9], float et[9])

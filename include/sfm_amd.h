@@ -73,6 +73,13 @@ int  sfm_ctx_set_stream(sfm_ctx *ctx, void *hip_stream);    /* NULL = default st
  * SFM_QUIRK_MATCH_TAIL -- FindMaxCorr10's tile loop (matching.cu:325) never visits the last num_pts2 % 32 points of the
  * second set; with the flag sfm_match searches only the first num_pts2 - num_pts2 % 32 (none: match = -1, score = 0). */
 #define SFM_QUIRK_MATCH_TAIL 1u
+/* SFM_QUIRK_MATCH_AMBIGUITY -- FindMaxCorr10 keeps eight (best, second) pairs per query, one per group of rows (row mod 32) / 4 of
+ * the second set, and its final merge (matching.cu:378-396) compares only their BEST scores with the running pair: the second-best
+ * scores of groups 1..7 never enter, so its `ambiguity` = second / (best + 1e-6) is a lower bound of the true ratio (equal for most
+ * queries).  FindHomography gates on it (matching.cu:1034-1037).  With the flag sfm_match writes that value into `ambiguity`
+ * (sfm_match_soa: into d_second), bit for bit the reference's; score, match and match_xpos / ypos are unchanged.  Costs one extra
+ * plain-FMA pass over all pairs (~18 us at 2048 x 2048): for A/B runs against the reference, together with SFM_QUIRK_MATCH_TAIL. */
+#define SFM_QUIRK_MATCH_AMBIGUITY 2u
 int  sfm_ctx_set_quirks(sfm_ctx *ctx, unsigned int flags);
 /* Which matcher sfm_match / sfm_match_soa run (results are bit-identical; A/B runs and tests):
  * SFM_MATCH_EXACT     -- every score as the exact fp32 chain on v_mfma_f32_32x32x2_f32 (match.hip);

@@ -276,6 +276,16 @@ def match_desc(d1, d2, nthreads=0):
     return best, sec, idx
 
 
+def match_second_ref(d1, d2, nthreads=0):
+    """FindMaxCorr10's own bookkeeping (matching.cu:361-390): (best, its approximate second best, index) -- see sfm_oracle.c."""
+    d1 = _f32(d1); d2 = _f32(d2)
+    n1, n2 = d1.shape[0], d2.shape[0]
+    best = np.empty(n1, np.float32); sec = np.empty(n1, np.float32); idx = np.empty(n1, np.int32)
+    _L.orc_match_second_ref(_fp(d1), C.c_int(n1), C.c_int(d1.shape[1]), _fp(d2), C.c_int(n2), C.c_int(d2.shape[1]),
+                            _fp(best), _fp(sec), _ip(idx), C.c_int(nthreads))
+    return best, sec, idx
+
+
 def match_sift(s1, s2, nthreads=0):
     s1 = np.ascontiguousarray(s1, dtype=SIFT_DTYPE).copy()
     s2 = np.ascontiguousarray(s2, dtype=SIFT_DTYPE)

@@ -818,6 +818,44 @@ void orc_match_desc(const float *d1, int n1, int ld1, const float *d2, int n2, i
     }
 }
 
+/* FindMaxCorr10's own second-best score (CudaSift/matching.cu:301-397; the product's SFM_QUIRK_MATCH_AMBIGUITY).  The kernel keeps
+ * eight (best, second, index) triples per query: triple iy follows the rows r of the second set with (r mod 32) / 4 == iy, in
+ * ascending order with strict > (:361-371); the final merge (:378-390) starts from triple 0 and folds in only the BEST score of
+ * every triple whose index differs from the running one.  second_ref <= the exact second best; ambiguity = second_ref / (best + 1e-6).
+ * All n2 rows are visited (the tile loop of :325 stops num_pts2 % 32 rows short: callers that want that pass the truncated n2).
+ * Pinned by the reference's kernel run on the MI355X (oracle/ref_build_gpu.sh, tests/test_gpu_ref_kernels.py). */
+void orc_match_second_ref(const float *d1, int n1, int ld1, const float *d2, int n2, int ld2, float *best_out, float *second_ref, int *index_out, int nthreads)
+{
+#ifdef _OPENMP
+    if (nthreads <= 0) nthreads = omp_get_max_threads();
+#pragma omp parallel for schedule(static) num_threads(nthreads)
+#endif
+    for (int p1 = 0; p1 < n1; ++p1) {
+        const float *a = d1 + (size_t)p1 * ld1;
+        float mx[8], sc[8];
+        int ix[8];
+        for (int y = 0; y < 8; ++y) { mx[y] = 0.0f; sc[y] = 0.0f; ix[y] = -1; }
+        for (int p2 = 0; p2 < n2; ++p2) {
+            const float *b = d2 + (size_t)p2 * ld2;
+            float s = 0.0f;
+            for (int d = 0; d < 128; ++d) s = fmaf(a[d], b[d], s);
+            const int y = (p2 & 31) >> 2;
+            if (s > mx[y]) { sc[y] = mx[y]; mx[y] = s; ix[y] = p2; }
+            else if (s > sc[y]) sc[y] = s;
+        }
+        float best = mx[0], sec = sc[0];
+        int idx = ix[0];
+        for (int y = 0; y < 8; ++y)
+            if (idx != ix[y]) {
+                if (mx[y] > best) { sec = best > sec ? best : sec; best = mx[y]; idx = ix[y]; }
+                else if (mx[y] > sec) sec = mx[y];
+            }
+        if (best_out) best_out[p1] = best;
+        second_ref[p1] = sec;
+        if (index_out) index_out[p1] = idx;
+    }
+}
+
 /* MatchSiftData field update, matching.cu:391-395 / 1090-1206. */
 void orc_match_sift(orc_sift_point *s1, int n1, const orc_sift_point *s2, int n2, int nthreads)
 {

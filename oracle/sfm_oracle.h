@@ -103,6 +103,8 @@ void orc_triangulate(const float *X0, const float *X1, int n, const float Pm[16]
 void orc_match_desc(const float *d1, int n1, int ld1, const float *d2, int n2, int ld2,
                     float *best, float *second, int *index, int nthreads);
 void orc_match_sift(orc_sift_point *s1, int n1, const orc_sift_point *s2, int n2, int nthreads);
+/* FindMaxCorr10's own (approximate) second-best score and what its merge picks as best / index (matching.cu:361-390) */
+void orc_match_second_ref(const float *d1, int n1, int ld1, const float *d2, int n2, int ld2, float *best_out, float *second_ref, int *index_out, int nthreads);
 
 /* ---- homography RANSAC pre-filter (FindHomography, matching.cu:1000-1087) ---- */
 /* coord: 4 x ld row-major (x1; y1; x2; y2), pts[4]: sample.  h[8] (h33 = 1 implied).

@@ -1,7 +1,7 @@
-"""gpurun_out/pmc_r05_match_<n>_summary.txt (profiles/pmc_match.sh) -> profiles/r05_match_traffic.json: HBM KB per launch (FETCH_SIZE / WRITE_SIZE,
+"""gpurun_out/pmc_r06_match_<n>_summary.txt (profiles/pmc_match.sh) -> profiles/r06_match_traffic.json: HBM KB per launch (FETCH_SIZE / WRITE_SIZE,
 separate --pmc passes) and matrix-pipe / vector occupancy of the matcher kernels per size; bench.py quotes it in extra.match_<n>.traffic together
 with the GB/s at the time it measures (the north_star's "rocprof HBM GB/s on the match kernel").
-usage: python profiles/make_match_traffic_json.py <n>:<summary.txt> [<n>:<summary.txt> ...] > profiles/r05_match_traffic.json"""
+usage: python profiles/make_match_traffic_json.py <n>:<summary.txt> [<n>:<summary.txt> ...] > profiles/r06_match_traffic.json"""
 import hashlib
 import json
 import os

@@ -1,7 +1,7 @@
-"""gpurun_out/pmc_<tag>_summary.txt (profiles/pmc_pf.sh) -> profiles/r05_traffic.json (what bench.py quotes as roofline.traffic /
+"""gpurun_out/pmc_<tag>_summary.txt (profiles/pmc_pf.sh) -> profiles/r06_traffic.json (what bench.py quotes as roofline.traffic /
 issue_profiled): HBM KB per launch and issue-slot occupancy of the RANSAC kernels of the default bench command, together with
 the hash of the kernel sources they were collected on (bench.py refuses to quote them for other sources).
-usage: python profiles/make_traffic_json.py <summary.txt> [matches hypotheses] > profiles/r05_traffic.json"""
+usage: python profiles/make_traffic_json.py <summary.txt> [matches hypotheses] > profiles/r06_traffic.json"""
 import json
 import os
 import re

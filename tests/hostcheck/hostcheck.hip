@@ -114,6 +114,7 @@ float hc_pf_band_sigma_top(const float *e, float thr, float B, const float *box,
 float hc_pf_band_top(int pack) { return pack ? sfm::kPfBandTopPack : sfm::kPfBandTop; }
 int hc_pf_band_pack_reject(float nt) { return sfm::prefilter_band_pack_reject(nt) ? 1 : 0; }
 uint32_t hc_pf_pack_code(int b) { return sfm::pf_pack_code(b); }
+uint32_t hc_pf_pack_field(int b) { return sfm::pf_pack_field(b); }
 void hc_pf_transposed(const float *e, float *et) { sfm::prefilter_transposed(e, et); }
 uint32_t hc_pf_cell_key_side(int ix, int iy, int side) { return sfm::pf_cell_key_side(ix, iy, side); }
 // the boxes as the device derives them: ordered bits of the maxima of (x, -x, y, -y, u, -u, v, -v) -> PfBox (8 floats)

@@ -184,6 +184,63 @@ def test_findmaxcorr10_vs_product_matcher(R, gpu, n1, n2):
     assert np.array_equal(orc["match"], ref["match"]) and same_bits(orc["score"], ref["score"])
 
 
+@pytest.mark.parametrize("n1,n2", [(512, 512), (1024, 2048), (500, 1037), (96, 40)])
+def test_findmaxcorr10_every_field_under_the_quirks(R, gpu, n1, n2):
+    """SFM_QUIRK_MATCH_TAIL | SFM_QUIRK_MATCH_AMBIGUITY: the product's sfm_match against the reference's FindMaxCorr10 on the same
+    GPU, ALL five fields it writes bit for bit -- `ambiguity` included, whose merge (matching.cu:378-396) ignores seven of the
+    eight second-best scores -- on round and ragged sizes; the oracle's restatement agrees; and FindHomography, which gates on
+    score and ambiguity (matching.cu:1034-1037), then selects the same matches from either array."""
+    torch, dev, ctx = gpu
+    d1, _, _ = synth.descriptors(n1, seed=n1 + 7)
+    d2, _, _ = synth.descriptors(n2, seed=n2 + 8)
+    d2[: min(n1, n2) // 2] = d1[: min(n1, n2) // 2][::-1]              # true partners with a clear margin for half of them
+    d2[3] = d2[7 % n2]; d2[32 % n2] = d2[36 % n2]                         # duplicates: runner-up in the same / another row group
+    s1 = synth.sift_records(d1, seed=3); s2 = synth.sift_records(d2, seed=4)
+    ref = s1.copy()
+    assert R.refk_match(ref.ctypes.data_as(C.c_void_p), n1, s2.ctypes.data_as(C.c_void_p), n2) == 0
+    qctx = S.Context(0, torch.cuda.current_stream().cuda_stream)
+    qctx.set_quirks(S.QUIRK_MATCH_TAIL | S.QUIRK_MATCH_AMBIGUITY)
+    t1, t2 = to_dev(torch, dev, s1), to_dev(torch, dev, s2)
+    for kern in (S.MATCH_AUTO, S.MATCH_FUSED, S.MATCH_PREFILTER):
+        qctx.set_match_kernel(kern)
+        t1 = to_dev(torch, dev, s1)
+        qctx.match(t1, n1, t2, n2)
+        qctx.synchronize()
+        ours = t1.cpu().numpy().reshape(-1).view(synth.SIFT_DTYPE)
+        assert np.array_equal(ours["match"], ref["match"]), kern
+        for f in ("score", "match_xpos", "match_ypos", "ambiguity"):
+            assert same_bits(ours[f], ref[f]), (f, kern)
+    qctx.set_match_kernel(S.MATCH_AUTO)
+    # without the ambiguity quirk the product's value is the exact ratio: never below the reference's, and different somewhere
+    tctx = S.Context(0, torch.cuda.current_stream().cuda_stream)
+    tctx.set_quirks(S.QUIRK_MATCH_TAIL)
+    t1x = to_dev(torch, dev, s1)
+    tctx.match(t1x, n1, t2, n2)
+    tctx.synchronize()
+    exact = t1x.cpu().numpy().reshape(-1).view(synth.SIFT_DTYPE)
+    assert (ref["ambiguity"] <= exact["ambiguity"]).all()
+    if n2 >= 512:
+        assert (ref["ambiguity"] < exact["ambiguity"]).any()
+    # the oracle's restatement (its scores are the same fused chains)
+    n2s = n2 - n2 % 32
+    ob, osec, oi = O.match_second_ref(d1, d2[:n2s]) if n2s else (np.zeros(n1, np.float32), np.zeros(n1, np.float32), -np.ones(n1, np.int32))
+    assert same_bits(ob, ref["score"]) and np.array_equal(oi, ref["match"])
+    assert same_bits((osec / (ob + np.float32(1e-6))).astype(np.float32), ref["ambiguity"])
+    # plain-array entry point: d_second carries the reference's second-best score
+    best = torch.empty(n1, dtype=torch.float32, device=dev); sec = torch.empty_like(best); idx = torch.empty(n1, dtype=torch.int32, device=dev)
+    if n2s:
+        qctx.match_soa(to_dev(torch, dev, d1), n1, 128, to_dev(torch, dev, np.ascontiguousarray(d2[:n2s])), n2s, 128, best, sec, idx)
+        qctx.synchronize()
+        assert same_bits(sec.cpu().numpy(), osec) and same_bits(best.cpu().numpy(), ob)
+    # FindHomography's gate (score > min_score, ambiguity < max_ambiguity) on both arrays: the same subset, hence the same model
+    if n1 >= 500:
+        gate = lambda a: (a["score"] > 0.85) & (a["ambiguity"] < 0.95)
+        assert np.array_equal(gate(ours), gate(ref))
+        Hq, nq_ = qctx.find_homography(t1, n1, num_loops=256, seed=5)
+        Hr, nr_ = qctx.find_homography(to_dev(torch, dev, ref), n1, num_loops=256, seed=5)
+        assert nq_ == nr_ and same_bits(Hq, Hr)
+
+
 def test_findmaxcorr10_tail_quirk_q1(R, gpu):
     """Quirk Q1 (matching.cu:325): the reference's tile loop never visits the last numPts2 % 32 points of the
     second set.  The product visits all of them; restricted to the points the reference does visit it

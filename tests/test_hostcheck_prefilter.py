@@ -45,6 +45,8 @@ def H():
     h.hc_pf_band_pack_reject.argtypes = [C.c_float]
     h.hc_pf_pack_code.restype = C.c_uint32
     h.hc_pf_pack_code.argtypes = [C.c_int]
+    h.hc_pf_pack_field.restype = C.c_uint32
+    h.hc_pf_pack_field.argtypes = [C.c_int]
     h.hc_pf_transposed.argtypes = [f32p, f32p]
     h.hc_pf_cell_key_side.restype = C.c_uint32
     h.hc_pf_cell_key_side.argtypes = [C.c_int, C.c_int, C.c_int]
@@ -545,6 +547,7 @@ def test_pack_survivor_table_against_a_model_of_the_conversion(H):
             assert bin(surv).count("1") == 1
             b = 32 - surv.bit_length()                   # count of leading zeros
             assert H.hc_pf_pack_code(b) == ((j & 3) + 8 * (j >> 2)) | (s << 5), (j, s, b)
+            assert H.hc_pf_pack_field(b) == 2 * j + s, (j, s, b)          # the form the kernel runs (a shift out of a 64-bit table)
             seen.add(b)
     assert seen == set(range(32))
     assert H.hc_pf_band_pack_reject(1.875) == 1 and H.hc_pf_band_pack_reject(float(np.nextafter(np.float32(1.875), np.float32(0)))) == 0

@@ -225,3 +225,40 @@ def test_reference_self_test_literals():
         want = n * n / (a[0] ** 2 + a[1] ** 2) + n * n / (bb[0] ** 2 + bb[1] ** 2)
         got = O.residual(E, x1, x2)
         assert abs(got - want) <= 1e-5 * want
+
+
+def test_match_second_ref_restates_findmaxcorr10_bookkeeping():
+    """orc_match_second_ref (the oracle behind SFM_QUIRK_MATCH_AMBIGUITY) against an independent numpy model of
+    CudaSift/matching.cu:361-390: eight running (best, second, index) triples per query, one per row group (row mod 32) / 4, merged
+    from triple 0 by comparing only the other triples' BEST scores.  Descriptors are small multiples of 1/8, so every dot product is
+    exact in binary32 whatever the summation order and the model needs no fused chain; such descriptors also produce plenty of exact
+    ties, which the merge resolves by group order, not by row index."""
+    rng = np.random.default_rng(17)
+    for n1, n2 in ((70, 96), (33, 101), (5, 7), (64, 320)):
+        d1 = (rng.integers(0, 5, (n1, 128)) * (rng.random((n1, 128)) < 0.2) / 8.0).astype(np.float32)
+        d2 = (rng.integers(0, 5, (n2, 128)) * (rng.random((n2, 128)) < 0.2) / 8.0).astype(np.float32)
+        S = (d1.astype(np.float64) @ d2.astype(np.float64).T).astype(np.float32)
+        assert np.array_equal(S.astype(np.float64), d1.astype(np.float64) @ d2.astype(np.float64).T)       # exact
+        best, sec, idx = O.match_second_ref(d1, d2)
+        eb, es, ei = O.match_desc(d1, d2)
+        ties = 0
+        for p in range(n1):
+            mx = [0.0] * 8; sc = [0.0] * 8; ix = [-1] * 8
+            for r in range(n2):
+                y = (r % 32) // 4
+                s = float(S[p, r])
+                if s > mx[y]:
+                    sc[y] = mx[y]; mx[y] = s; ix[y] = r
+                elif s > sc[y]:
+                    sc[y] = s
+            b, s2, i = mx[0], sc[0], ix[0]
+            for y in range(8):
+                if i != ix[y]:
+                    if mx[y] > b:
+                        s2 = max(b, s2); b = mx[y]; i = ix[y]
+                    elif mx[y] > s2:
+                        s2 = mx[y]
+            assert (best[p], sec[p], idx[p]) == (np.float32(b), np.float32(s2), i), (n1, n2, p)
+            assert best[p] == eb[p] and sec[p] <= es[p]               # the same maximum; a LOWER bound of the exact second best
+            ties += int(idx[p] != ei[p])
+        assert n2 < 64 or ties > 0 or n1 < 10                         # (the tie rule differs: group order against lowest row)
