@@ -26,7 +26,12 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 
 // which rule a record / a scoring kernel instance follows (prefilter_math.hpp): the G rule of rounds 2-4, the band rule scanned with
 // v_alignbit_b32 (round 5) or with the six-bit conversion (round 6, the product; same record layout, sigma = 1.873 / W instead of 1.998 / W)
-constexpr int kPfRuleG = 0, kPfRuleBand = 1, kPfRuleBandPack = 2;
+// kPfRuleBandTile (round 6, the product): the packed scan with the band's constant taken over the bounding boxes of the TILE's points
+// (tiles are runs of the Morton-ordered copy of the correspondences) -- sigma and the coefficient slots are derived per (hypothesis,
+// tile) inside the scoring kernel, the per-hypothesis record shrinks to one flag word.
+constexpr int kPfRuleG = 0, kPfRuleBand = 1, kPfRuleBandPack = 2, kPfRuleBandTile = 3;
+constexpr uint32_t kPfTileFlagScan = 1u;      // the first divisor may vanish at a point of the pair: every tile checks its points
+constexpr uint32_t kPfTileFlagBSafe = 2u;     // no point of the pair can zero the second divisor: the harmonic constant applies
 constexpr int kPfGroup = 32;                       // hypotheses per pass of a scoring wavefront (one MFMA row block)
 constexpr unsigned short kPfFlagScan = 0x3C00u;    // "check every point" (any non-zero pattern would do; this one is fp16 1.0)
 
@@ -166,6 +171,37 @@ __device__ __forceinline__ void pf_band_store(const float e[9], float sigma, boo
     }
     uint4 *dst = reinterpret_cast<uint4 *>(out);
     dst[0] = q[0]; dst[1] = q[1]; dst[2] = q[2]; dst[3] = q[3];
+}
+
+// ---- kPfRuleBandTile: what is left per hypothesis (the two zero-divisor analyses over the pair's cell table), and the operands of one
+// (hypothesis, tile) as the scoring kernel derives them from E itself
+__device__ __forceinline__ uint32_t pf_tile_flags(const float e[9], float B, const uint32_t *__restrict__ cells, uint32_t cells_mask)
+{
+    const PfGrid grid = prefilter_grid(B);
+    int cx0, cx1, cy0, cy1;
+    const int zs = prefilter_zero_divisor_cells(e, B, grid, cx0, cx1, cy0, cy1);
+    bool scan = zs == 2;
+    if (zs == 1) scan = !cells || pf_cells_occupied(cells, cells_mask, cx0, cx1, cy0, cy1, 0);
+    float et[9];
+    prefilter_transposed(e, et);
+    const int zb = prefilter_zero_divisor_cells(et, B, grid, cx0, cx1, cy0, cy1);
+    bool b_safe = zb == 0;
+    if (zb == 1) b_safe = cells && !pf_cells_occupied(cells, cells_mask, cx0, cx1, cy0, cy1, 1);
+    return (scan ? kPfTileFlagScan : 0u) | (b_safe ? kPfTileFlagBSafe : 0u);
+}
+
+// this lane's half (k-slots 8 half .. 8 half + 7 of either k-step) of the coefficient fragments of hypothesis e for a tile whose
+// points lie in `box`: the very values pf_band_store would put into a record for the same sigma
+__device__ __forceinline__ void pf_tile_operands(const float e[9], uint32_t flags, float thr, float B, const PfBox &box, int half, h8 &n0, h8 &n1)
+{
+    // each half of the wavefront bounds ONE divisor over its view's box (lanes l and l + 32 hold the same hypothesis) and hands it over
+    const float d_mine = prefilter_band_divisor_max(e, B, box, half);
+    const float d_other = __shfl_xor(d_mine, 32);
+    const float sigma = prefilter_band_sigma_from_maxima(e, thr, B, half ? d_other : d_mine, half ? d_mine : d_other, (flags & kPfTileFlagBSafe) != 0u, kPfBandTopPack);
+    _Float16 ns[kPfSlots];
+    prefilter_band_hyp_slots(e, sigma, ns);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { n0[j] = half ? ns[8 + j] : ns[j]; n1[j] = half ? ns[24 + j] : ns[16 + j]; }
 }
 
 // The two A fragments of a lane out of its half of a band-rule record (r0 = words 0..3, r1 = words 4..7 of the half).

@@ -116,7 +116,8 @@ void ransac_solve_lanes1_qr(const float *__restrict__ X0, const float *__restric
         if (rule == kPfRuleG) pf_prep_store(E, thr, B, sc, cells, cells_mask, recs + i);
         else
 #endif
-        pf_band_prep_store(E, thr, B, pf_box_from_words(bound_word + 2, B), cells, cells_mask, recs + i, rule == kPfRuleBandPack ? kPfBandTopPack : kPfBandTop);
+        if (rule == kPfRuleBandTile) reinterpret_cast<uint32_t *>(recs)[i] = pf_tile_flags(E, B, cells, cells_mask);      // sigma and the slots: per tile, in the scoring kernel
+        else pf_band_prep_store(E, thr, B, pf_box_from_words(bound_word + 2, B), cells, cells_mask, recs + i, rule == kPfRuleBandPack ? kPfBandTopPack : kPfBandTop);
     }
     SFM_PHASE("end");
 }
@@ -412,7 +413,7 @@ int launch_ransac_score(sfm_pair *pair, const sfm_ransac_params &p, uint32_t h0,
     PfScales pf_sc = {};
     if (prefilter) (void)prefilter_scales(p.threshold, pf_sc);            // (checked by prefilter_usable)
     if (prefilter && !pf_r2) {                                            // the table of occupied cells the records are checked against
-        const int rcc = launch_pf_cells(pair);
+        const int rcc = launch_pf_cells(pair, prefilter_rule(p) == kPfRuleBandTile);
         if (rcc != SFM_OK) return rcc;
     }
     bool need_prep = prefilter && !pf_r2;

@@ -57,7 +57,7 @@ template <int RULE> struct PfLds {
     static constexpr int kBlockBytes = kFragsPerBlock * 64 * 16;   // one 32-point block: [n k-step 0 | n k-step 1 (| G)][lane][8 fp16]
     static constexpr int kFrag = 0;
     static constexpr int kTileMax = kPfTileMax;
-    int staged, pts, ring, wave, next, lut, bytes;
+    int staged, pts, ring, wave, next, lut, box, bytes;
     __host__ __device__ explicit PfLds(int tile, int ring_entries = kPfRing)
     {
         staged = (tile + 63) & ~63;                           // points staged: whole iterations of two blocks (beyond `tile`: padding)
@@ -68,7 +68,8 @@ template <int RULE> struct PfLds {
         wave = ring + kPfWaves * ring_entries * 8;            // per wavefront: E table 9 x 32 floats (component-major), 32 counters
         next = wave + kPfWaves * kPfWaveBytes;                // the block's pass counter
         lut = next + 16;                                      // packed scan: survivor bit -> (accumulator row, step), 32 bytes (pf_pack_code)
-        bytes = lut + 32;
+        box = lut + 32;                                       // tile rule: ordered bits of the tile's coordinate maxima (x, -x, y, -y, u, -u, v, -v)
+        bytes = box + 32;
     }
 };
 static_assert(kPfRing * 8 == 1024, "ring slots are addressed with (offset & 1023) | base");
@@ -214,14 +215,17 @@ __device__ __forceinline__ void mfma_step(const PfFrags &a, const PfFrags &b, f1
 constexpr int kPfVarTickets = 1;
 
 // FL2 (experiment): a ring of 256 entries, flushed 128 at a time -- two entries per lane, their LDS reads issued together
-template <int W, int VAR = 0, int RULE = kPfRuleBandPack, int FL2 = 0, int PIPE = 0>
+template <int W, int VAR = 0, int RULE = kPfRuleBandTile, int FL2 = 0, int PIPE = 0>
 __global__ __launch_bounds__(W * 64)
 void ransac_score_prefilter(const float *__restrict__ X0, const float *__restrict__ X1, int ld, int n,
                             const float *__restrict__ Ecand, const PfRecord *__restrict__ recs, uint32_t h0, uint32_t count, float thr,
                             int dynamic, int tile,
                             int *__restrict__ counts, uint32_t *__restrict__ tick,
-                            unsigned long long *best_key, unsigned long long *best_key2, unsigned long long *__restrict__ clk)
+                            unsigned long long *best_key, unsigned long long *best_key2, unsigned long long *__restrict__ clk,
+                            const unsigned long long *__restrict__ bound_word)
 {
+    // kPfRuleBandTile: X0 = the Morton-ordered (x1x, x1y, x2x, x2y) records (float4 per point, pair->d_pts4s), X1 unused, recs = one
+    // flag word per hypothesis (pf_tile_flags)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -246,7 +250,7 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
     const uint32_t npass = (count + (uint32_t)kPfGroup - 1u) / (uint32_t)kPfGroup;
     const uint32_t nstatic = gridDim.x * (uint32_t)W;             // passes handed out by position
     using LT = PfLds<RULE>;
-    constexpr bool kBand = RULE != kPfRuleG, kPack = RULE == kPfRuleBandPack;
+    constexpr bool kBand = RULE != kPfRuleG, kTile = RULE == kPfRuleBandTile, kPack = RULE == kPfRuleBandPack || kTile;
     static_assert(!(FL2 && kPack) && !(VAR && kPack), "the recorded variants were built on the v_alignbit scan");
     constexpr int kRing = FL2 ? 256 : kPfRing;
     const LT L(tile, kRing);
@@ -261,6 +265,13 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
     auto fetch_pass = [&](uint32_t pass, PfFrags &af, uint32_t &k0, float (&e)[9]) {
         const uint32_t hf = pass * (uint32_t)kPfGroup;
         const uint32_t h = hf + (uint32_t)min(row, (int)min((uint32_t)kPfGroup, count - hf) - 1);
+        if (kTile) {                                                                  // E and the flag word; the operands are derived at install time
+            const float *src = Ecand + 9 * (size_t)h;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) e[k] = src[k];
+            k0 = reinterpret_cast<const uint32_t *>(recs)[h];
+            return;
+        }
         const uint4 *r = reinterpret_cast<const uint4 *>(recs + h) + 2 * half;        // this lane's half of the record: 32 bytes
         const uint4 r0 = r[0], r1 = r[1];
         if (kBand) pf_band_record_expand(r0, r1, half, af.n0, af.n1, k0);
@@ -293,12 +304,28 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
     uint32_t *next_idx = reinterpret_cast<uint32_t *>(smem + L.next);
     if (threadIdx.x == 0) *next_idx = (uint32_t)W;
     if (kPack && threadIdx.x < 32) smem[L.lut + threadIdx.x] = (unsigned char)pf_pack_code((int)threadIdx.x);
+    uint32_t *boxw = reinterpret_cast<uint32_t *>(smem + L.box);
+    if (kTile && threadIdx.x < 8) boxw[threadIdx.x] = pf_order_bits(-INFINITY);
     __syncthreads();
     const int tile_first = blockIdx.y * tile;
+    float ext[8] = { -INFINITY, -INFINITY, -INFINITY, -INFINITY, -INFINITY, -INFINITY, -INFINITY, -INFINITY };
     for (int t = threadIdx.x; t < L.staged; t += W * 64) {
         const int p = tile_first + t;
         float u = 0.f, v = 0.f, x = 0.f, y = 0.f;
         const bool real = p < n && t < tile;                    // (a staged point beyond the tile belongs to the next one: padding here)
+        if (kTile) {
+            // the Morton-ordered copy: the n real points come first (those that carry features by key, the others behind them), the
+            // NaN padding of the row last -- so position < n still means "a real point"
+            if (real) {
+                const float4 q4 = reinterpret_cast<const float4 *>(X0)[p];
+                u = q4.x; v = q4.y; x = q4.z; y = q4.w;
+                const float big = fmaxf(fmaxf(fabsf(u), fabsf(v)), fmaxf(fabsf(x), fabsf(y)));
+                if (big <= 48.0f && u == u && v == v && x == x && y == y) {       // prefilter_point_slots' own test: the point carries features
+                    ext[0] = fmaxf(ext[0], x); ext[1] = fmaxf(ext[1], -x); ext[2] = fmaxf(ext[2], y); ext[3] = fmaxf(ext[3], -y);
+                    ext[4] = fmaxf(ext[4], u); ext[5] = fmaxf(ext[5], -u); ext[6] = fmaxf(ext[6], v); ext[7] = fmaxf(ext[7], -v);
+                }
+            }
+        } else
         if (real) { u = X0[p]; v = X0[(size_t)ld + p]; x = X1[p]; y = X1[(size_t)ld + p]; }
         _Float16 bn[kPfSlots], bt[kPfSlotsT];
         prefilter_point_slots(u, v, x, y, real, bn, bt);
@@ -325,7 +352,35 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
             }
         }
     }
+    if (kTile) {                                              // the tile's boxes: maxima over the wavefront, then over the block in LDS
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) ext[k] = fmaxf(ext[k], __shfl_xor(ext[k], off));
+        }
+        if (lane < 8) {
+            float mine = ext[0];
+#pragma unroll
+            for (int k = 1; k < 8; ++k) mine = lane == k ? ext[k] : mine;
+            atomicMax(&boxw[lane], pf_order_bits(mine));
+        }
+    }
     __syncthreads();
+    // tile rule: the pair's bound and this tile's boxes, and with them the first pass' operands (E and the flag word are in registers)
+    float pf_B = 0.0f;
+    PfBox tbox = {};
+    auto build_operands = [&](const float (&e)[9], uint32_t fl) {
+        pf_tile_operands(e, fl, thr, pf_B, tbox, half, afrag.n0, afrag.n1);
+        key0 = fl & kPfTileFlagScan;
+    };
+    if (kTile) {
+        pf_B = __uint_as_float((uint32_t)(*bound_word & 0xFFFFFFFFull));
+        uint32_t bw[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) bw[k] = (uint32_t)__builtin_amdgcn_readfirstlane((int)boxw[k]);
+        tbox = pf_box_from_bits(bw, pf_B);
+        if (have) build_operands(e_row, key0);
+    }
 #if SFM_AB
     if (probe) clk[2] = wall_clock64() - w0;
 #endif
@@ -653,7 +708,11 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
         }
         const int nvalid_done = nvalid;
         const uint32_t h_done = h_first;
-        if (have_next) { afrag = afrag_next; key0 = key0n; install_rows(e_row); }
+        if (have_next) {
+            if (kTile) build_operands(e_row, key0n);
+            else { afrag = afrag_next; key0 = key0n; }
+            install_rows(e_row);
+        }
         unsigned long long k = 0;
         if (lane < nvalid_done && (uint32_t)(old >> 32) == gridDim.y - 1u) {
             const uint32_t total = (uint32_t)old + c_mine;
@@ -740,10 +799,57 @@ void pf_cells_build_kernel(const float4 *__restrict__ pts4, int n, unsigned long
     }
 }
 
-int launch_pf_cells(sfm_pair *pair)
+// ---- the Morton-ordered copy of the correspondences (kPfRuleBandTile) -----------------------------------------------------------------
+// The scoring kernel's tiles are runs of THIS order, so that a tile's points sit in a small part of the first view (and, for the
+// inliers, of the second): the band rule's constant is a maximum over the tile's bounding boxes, and smaller boxes mean fewer pairs that
+// survive the matrix-core test (4096 points, 4 tiles: 1.30 % -> 1.05 %; 16384 points, 16 tiles: 1.21 % -> 0.78 % of the bench scenes).
+// Counts do not depend on the order of the points; the sampler, the finalize kernel and the mask keep the original order.
+// One block: keys (Morton code of the first view's position over its coordinate range << 32 | index) sorted in LDS by a bitonic network
+// (up to 16384 points: 128 KiB; beyond that the copy keeps the original order -- tiles with larger boxes, the same counts).  Points
+// without features (non-finite or beyond the fp16 range) go behind the others, the NaN padding of the row last.
+__global__ __launch_bounds__(1024)
+void pf_sort_kernel(const float4 *__restrict__ pts4, int ld, int np2, const unsigned long long *__restrict__ bound_word, float4 *__restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_sort[];
+    unsigned long long *sk = reinterpret_cast<unsigned long long *>(smem_sort);
+    const float B = __uint_as_float((uint32_t)(*bound_word & 0xFFFFFFFFull));
+    const PfBox box = pf_box_from_words(bound_word + 2, B);
+    for (int i = threadIdx.x; i < np2; i += blockDim.x) {
+        uint32_t key = 0xFFFFFFFFu;
+        if (i < ld) {
+            const float4 q = pts4[i];
+            const float big = fmaxf(fmaxf(fabsf(q.x), fabsf(q.y)), fmaxf(fabsf(q.z), fabsf(q.w)));
+            if (big <= 48.0f && q.x == q.x && q.y == q.y && q.z == q.z && q.w == q.w) key = pf_morton_key(q.x, q.y, box.ulo, box.uhi, box.vlo, box.vhi);
+        }
+        sk[i] = i < ld ? (((unsigned long long)key << 32) | (unsigned long long)(uint32_t)i) : ~0ull;
+    }
+    __syncthreads();
+    for (int k = 2; k <= np2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < np2; i += blockDim.x) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const unsigned long long a = sk[i], b = sk[ixj];
+                    const bool up = (i & k) == 0;
+                    if ((a > b) == up) { sk[i] = b; sk[ixj] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    for (int i = threadIdx.x; i < ld; i += blockDim.x) out[i] = pts4[(uint32_t)(sk[i] & 0xFFFFFFFFull)];
+}
+
+__global__ __launch_bounds__(256)
+void pf_copy_points_kernel(const float4 *__restrict__ pts4, int ld, float4 *__restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < ld) out[i] = pts4[i];
+}
+
+int launch_pf_cells(sfm_pair *pair, bool want_sorted)
 {
     hipStream_t st = pair->ctx->stream;
-    if (pair->cells_epoch == pair->bound_epoch && pair->d_cells) {                      // built for the current points
+    if (pair->cells_epoch == pair->bound_epoch && pair->d_cells && (!want_sorted || pair->sorted_epoch == pair->bound_epoch)) {   // built for the current points
         // ... possibly by a launch on another stream (the other slot of a pipelined burst): order this stream behind it
         if (st != pair->cells_stream) SFM_HIP_TRY(hipStreamWaitEvent(st, pair->cells_ev, 0));
         return SFM_OK;
@@ -762,6 +868,21 @@ int launch_pf_cells(sfm_pair *pair)
     hipLaunchKernelGGL(pf_cells_build_kernel, dim3((pair->n + 255) / 256), dim3(256), 0, st, pair->d_pts4, pair->n, pair->d_bound,
                        pair->d_cells, pair->cells_mask, pair->bound_epoch);
     SFM_HIP_TRY(hipGetLastError());
+    // the Morton-ordered copy (behind the cells kernel: it reads the first view's coordinate range)
+    if (want_sorted) {
+    pair->sorted_epoch = pair->bound_epoch;
+    if (!pair->d_pts4s) SFM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&pair->d_pts4s), (size_t)pair->ld * sizeof(float4)));
+    if (pair->ld <= 16384) {
+        int np2 = 64;
+        while (np2 < pair->ld) np2 <<= 1;
+        const int rc_lds = allow_big_lds(pair->ctx, reinterpret_cast<const void *>(&pf_sort_kernel));
+        if (rc_lds != SFM_OK) return rc_lds;
+        hipLaunchKernelGGL(pf_sort_kernel, dim3(1), dim3(1024), (size_t)np2 * 8, st, pair->d_pts4, pair->ld, np2, pair->d_bound, pair->d_pts4s);
+    } else {
+        hipLaunchKernelGGL(pf_copy_points_kernel, dim3((pair->ld + 255) / 256), dim3(256), 0, st, pair->d_pts4, pair->ld, pair->d_pts4s);
+    }
+    SFM_HIP_TRY(hipGetLastError());
+    }
     if (!pair->cells_ev) SFM_HIP_TRY(hipEventCreateWithFlags(&pair->cells_ev, hipEventDisableTiming));
     SFM_HIP_TRY(hipEventRecord(pair->cells_ev, st));
     pair->cells_stream = st;
@@ -783,7 +904,8 @@ void pf_prep_kernel(const float *__restrict__ Ecand, uint32_t count, float thr, 
 #pragma unroll
     for (int k = 0; k < 9; ++k) e[k] = Ecand[9 * (size_t)i + k];
     const float B = __uint_as_float((uint32_t)(*bound_word & 0xFFFFFFFFull));
-    if (RULE != kPfRuleG) pf_band_prep_store(e, thr, B, pf_box_from_words(bound_word + 2, B), cells, cells_mask, recs + i, RULE == kPfRuleBandPack ? kPfBandTopPack : kPfBandTop);
+    if (RULE == kPfRuleBandTile) reinterpret_cast<uint32_t *>(recs)[i] = pf_tile_flags(e, B, cells, cells_mask);
+    else if (RULE != kPfRuleG) pf_band_prep_store(e, thr, B, pf_box_from_words(bound_word + 2, B), cells, cells_mask, recs + i, RULE == kPfRuleBandPack ? kPfBandTopPack : kPfBandTop);
     else pf_prep_store(e, thr, B, sc, cells, cells_mask, recs + i);
 }
 
@@ -791,10 +913,13 @@ int launch_pf_prep(sfm_pair *pair, const sfm_ransac_params &p, uint32_t count)
 {
     PfScales sc;
     if (!prefilter_scales(p.threshold, sc)) { set_error("threshold %g outside the pre-filter's range", (double)p.threshold); return SFM_E_INVALID; }
-    if (prefilter_rule(p) == kPfRuleBandPack)
-        hipLaunchKernelGGL(pf_prep_kernel<kPfRuleBandPack>, dim3((count + 255) / 256), dim3(256), 0, pair->ctx->stream,
+    if (prefilter_rule(p) == kPfRuleBandTile)
+        hipLaunchKernelGGL(pf_prep_kernel<kPfRuleBandTile>, dim3((count + 255) / 256), dim3(256), 0, pair->ctx->stream,
                            pair->d_Ecand, count, p.threshold, sc, pair->d_bound, pair->d_cells, pair->cells_mask, reinterpret_cast<PfRecord *>(pair->d_pf));
 #if SFM_AB
+    else if (prefilter_rule(p) == kPfRuleBandPack)
+        hipLaunchKernelGGL(pf_prep_kernel<kPfRuleBandPack>, dim3((count + 255) / 256), dim3(256), 0, pair->ctx->stream,
+                           pair->d_Ecand, count, p.threshold, sc, pair->d_bound, pair->d_cells, pair->cells_mask, reinterpret_cast<PfRecord *>(pair->d_pf));
     else if (prefilter_rule(p) == kPfRuleBand)
         hipLaunchKernelGGL(pf_prep_kernel<kPfRuleBand>, dim3((count + 255) / 256), dim3(256), 0, pair->ctx->stream,
                            pair->d_Ecand, count, p.threshold, sc, pair->d_bound, pair->d_cells, pair->cells_mask, reinterpret_cast<PfRecord *>(pair->d_pf));
@@ -978,7 +1103,13 @@ int prefilter_rule(const sfm_ransac_params &p)
 {
     if (SFM_SW(p, 3) == 4 || SFM_SW(p, 3) >= 16) return kPfRuleG;
     if (SFM_SW(p, 3) == 5 || SFM_SW(p, 1) == 5 || SFM_SW(p, 1) == 7 || SFM_SW(p, 1) == 9) return kPfRuleBand;
-    return kPfRuleBandPack;
+    // Per-tile band constants (Morton-ordered tiles, sigma and the coefficient slots derived per (hypothesis, tile) inside the scoring
+    // kernel, a 4-byte record per hypothesis): 19 % (4096 points) to 36 % (16384) fewer survivors, an 8 % shorter lane solve, 60 bytes
+    // less written per hypothesis; the step is 3.7 % (headline) to 5.3 % (16384 x 2^20) shorter than with per-hypothesis records and
+    // whole-view boxes (lab bench, reserved[3] == 6: profiles/r06_ab_tile_rule_fast.txt; with the exact, twice-as-long derivation of
+    // sigma the two were level: r06_ab_tile_rule.txt).
+    if (SFM_SW(p, 3) == 6 || SFM_SW(p, 1) == 11 || SFM_SW(p, 1) == 12) return kPfRuleBandPack;
+    return kPfRuleBandTile;
 }
 
 bool prefilter_usable(const sfm_pair *pair, const sfm_ransac_params &p, uint32_t count)
@@ -1025,9 +1156,10 @@ int launch_score_prefilter(sfm_pair *pair, const sfm_ransac_params &p, uint32_t 
     auto launch = [&](auto kernel) -> int {
         const int rc_lds = allow_big_lds(ctx, reinterpret_cast<const void *>(kernel));
         if (rc_lds != SFM_OK) return rc_lds;
+        const float *x0 = rule == kPfRuleBandTile ? reinterpret_cast<const float *>(pair->d_pts4s) : pair->d_X[0];
         hipLaunchKernelGGL(kernel, dim3(cols, ntiles), dim3(waves * 64), lds_bytes, ctx->stream,
-                           pair->d_X[0], pair->d_X[1], pair->ld, pair->n, pair->d_Ecand, reinterpret_cast<const PfRecord *>(pair->d_pf), h0, count, p.threshold,
-                           dynamic, tile, pair->d_counts, pair->d_tick, pair->d_key, key2, pair->d_clk);
+                           x0, pair->d_X[1], pair->ld, pair->n, pair->d_Ecand, reinterpret_cast<const PfRecord *>(pair->d_pf), h0, count, p.threshold,
+                           dynamic, tile, pair->d_counts, pair->d_tick, pair->d_key, key2, pair->d_clk, pair->d_bound);
         return SFM_OK;
     };
     int rcl;
@@ -1040,9 +1172,10 @@ int launch_score_prefilter(sfm_pair *pair, const sfm_ransac_params &p, uint32_t 
     else if (rule == kPfRuleBand) rcl = launch(&ransac_score_prefilter<16, 0, kPfRuleBand>);
     else if (SFM_SW(p, 1) == 11) rcl = launch(&ransac_score_prefilter<16, 0, kPfRuleBandPack, 0, 1>);
     else if (SFM_SW(p, 1) == 12) rcl = launch(&ransac_score_prefilter<12, 0, kPfRuleBandPack, 0, 1>);
+    else if (rule == kPfRuleBandPack) rcl = launch(&ransac_score_prefilter<16, 0, kPfRuleBandPack>);
     else
 #endif
-    rcl = launch(&ransac_score_prefilter<16, 0, kPfRuleBandPack>);
+    rcl = launch(&ransac_score_prefilter<16, 0, kPfRuleBandTile>);
     (void)var; (void)fl2;
     if (rcl != SFM_OK) return rcl;
     SFM_HIP_TRY(hipGetLastError());

@@ -31,7 +31,10 @@ extern "C" {
  *   [2] k > 0: minimum hypothesis batches per scoring block (default 8); pre-filter kernel: grid columns;
  *   [3] 1 AUTO never picks SFM_KERNEL_PREFILTER; 2 the round-2 pre-filter kernel (csrc/ab/ransac_prefilter_r2.hip);
  *       3 per-hypothesis records from the stand-alone kernel instead of the lane-solve kernel; 4 the G rule of rounds 2-4
- *       (per-pair threshold, three MFMAs per 32 x 32 pairs) instead of the band rule; 5 the band rule scanned with one
+ *       (per-pair threshold, three MFMAs per 32 x 32 pairs) instead of the band rule; 6 the packed scan with per-hypothesis 64-byte
+ *       records and whole-view boxes instead of round 6's per-tile band constants (tiles = runs of a Morton-ordered copy of the
+ *       correspondences, sigma and the coefficient slots derived per (hypothesis, tile) inside the scoring kernel from a 4-byte
+ *       record: profiles/r06_ab_tile_rule_fast.txt); 5 the band rule scanned with one
  *       v_alignbit_b32 per pair (round 5) instead of the six-bit conversion of round 6 ([1] = 5, 7, 9 imply it: those variants were
  *       built on that scan); 16 + bits: recorded variants built on the G rule. */
 

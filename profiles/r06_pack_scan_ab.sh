@@ -1,4 +1,4 @@
-for r in "0 0 0 0" "0 12 0 0" "0 11 0 0" "0 0 0 5" "0 5 0 0"; do
+for r in "0 0 0 0" "0 0 0 6" "0 0 0 5" "0 0 0 0" "0 0 0 6" "0 0 0 5"; do
   echo "== reserved $r"
   timeout 300 python bench.py --no-extra --no-variants --cpu-seconds 3 --reserved $r 2>/dev/null | python -c "
 import sys,json

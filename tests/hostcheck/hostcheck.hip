@@ -115,6 +115,16 @@ float hc_pf_band_top(int pack) { return pack ? sfm::kPfBandTopPack : sfm::kPfBan
 int hc_pf_band_pack_reject(float nt) { return sfm::prefilter_band_pack_reject(nt) ? 1 : 0; }
 uint32_t hc_pf_pack_code(int b) { return sfm::pf_pack_code(b); }
 uint32_t hc_pf_pack_field(int b) { return sfm::pf_pack_field(b); }
+// the per-tile variant's sigma as the scoring kernel derives it: one divisor maximum per half of the wavefront, hardware reciprocal / square
+// root behind widened slack on the device (correctly rounded here)
+float hc_pf_tile_sigma(const float *e, float thr, float B, const float *box, int b_safe)
+{
+    const sfm::PfBox bx = { box[0], box[1], box[2], box[3], box[4], box[5], box[6], box[7] };
+    const float Da = sfm::prefilter_band_divisor_max(e, B, bx, 0), Db = sfm::prefilter_band_divisor_max(e, B, bx, 1);
+    return sfm::prefilter_band_sigma_from_maxima(e, thr, B, Da, Db, b_safe != 0, sfm::kPfBandTopPack);
+}
+// the tile order of the recorded per-tile variant (pf_sort_kernel): Morton key of a first-view position over the view's coordinate range
+uint32_t hc_pf_morton_key(float u, float v, float ulo, float uhi, float vlo, float vhi) { return sfm::pf_morton_key(u, v, ulo, uhi, vlo, vhi); }
 void hc_pf_transposed(const float *e, float *et) { sfm::prefilter_transposed(e, et); }
 uint32_t hc_pf_cell_key_side(int ix, int iy, int side) { return sfm::pf_cell_key_side(ix, iy, side); }
 // the boxes as the device derives them: ordered bits of the maxima of (x, -x, y, -y, u, -u, v, -v) -> PfBox (8 floats)

@@ -415,3 +415,28 @@ def test_polled_merge_give_up_is_reported_and_contained(gpu_ab):
             assert np.array_equal(idx.cpu().numpy(), oi) and same_bits(best.cpu().numpy(), ob) and same_bits(sec.cpu().numpy(), os_), kern
     finally:
         ctx.set_match_kernel(S.MATCH_AUTO)
+
+
+@pytest.mark.parametrize("n,H,thr", [(4096, 65536, 1e-6), (1000, 20000, 1e-4), (16384, 32768, 1e-6), (700, 16385, 1e-8), (5000, 20000, 1e-5)])
+def test_per_hypothesis_records_still_equal_oracle(gpu_ab, n, H, thr):
+    """The packed scan with per-hypothesis 64-byte records and whole-view boxes (reserved[3] = 6), kept for A/B runs against the
+    product's per-tile band constants (tiles = runs of a Morton-ordered copy of the correspondences, sigma and the coefficient slots
+    derived per (hypothesis, tile) inside the scoring kernel from a 4-byte flag record): every count, key, E, mask, either rule on the
+    same pair -- and again after a second fillXU of other points (the ordered copy is rebuilt per fillXU epoch)."""
+    scene = synth.two_view_scene(n, seed=12)
+    pair, _ = make_pair(S, gpu_ab, scene)
+    p = S.default_params(n, num_hypotheses=H, seed=6, kernel=S.KERNEL_PREFILTER, threshold=thr)
+    p.reserved[3] = 6
+    pair.estimateE(p)
+    assert pair.last_launch()["kernel"] == S.KERNEL_PREFILTER
+    P.check_all(pair, scene, p, H, n)
+    q = S.default_params(n, num_hypotheses=H, seed=6, kernel=S.KERNEL_PREFILTER, threshold=thr)      # the product's rule on the same pair
+    pair.estimateE(q)
+    P.check_all(pair, scene, q, H, n)
+    torch, dev, ctx = gpu_ab
+    scene2 = synth.two_view_scene(n, seed=13)
+    pair.fillXU(to_dev(torch, dev, scene2["sift"]))
+    pair.estimateE(q)
+    P.check_all(pair, scene2, q, H, n)
+    pair.estimateE(p)
+    P.check_all(pair, scene2, p, H, n)

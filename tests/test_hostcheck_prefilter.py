@@ -47,6 +47,10 @@ def H():
     h.hc_pf_pack_code.argtypes = [C.c_int]
     h.hc_pf_pack_field.restype = C.c_uint32
     h.hc_pf_pack_field.argtypes = [C.c_int]
+    h.hc_pf_tile_sigma.restype = C.c_float
+    h.hc_pf_tile_sigma.argtypes = [f32p, C.c_float, C.c_float, f32p, C.c_int]
+    h.hc_pf_morton_key.restype = C.c_uint32
+    h.hc_pf_morton_key.argtypes = [C.c_float] * 6
     h.hc_pf_transposed.argtypes = [f32p, f32p]
     h.hc_pf_cell_key_side.restype = C.c_uint32
     h.hc_pf_cell_key_side.argtypes = [C.c_int, C.c_int, C.c_int]
@@ -56,12 +60,19 @@ def H():
     return h
 
 
-RULES = ["pack", "band", "G"]
-BAND_RULES = ("pack", "band")
+RULES = ["pack", "tile", "band", "G"]
+BAND_RULES = ("pack", "tile", "band")
+HW_ULPS = 1.0 - 8 * 2.0 ** -23      # "tile": the device's 1-ulp reciprocal / square root can move sigma by a few ulp; the rule must hold for the LARGEST sigma the device can derive
 
 
 def band_sigma(H, e, thr, B, box, b_safe, rule):
-    """sigma of a hypothesis under either scan of the band rule (top = 1.998 / 1.873)."""
+    """sigma of a hypothesis under either scan of the band rule (top = 1.998 / 1.873); "tile": the per-tile variant's cheap form, pushed
+    UP by the hardware operations' error so that the check covers whatever the device computes."""
+    if rule == "tile":
+        s = float(H.hc_pf_tile_sigma(fp(np.ascontiguousarray(e, np.float32)), thr, B, fp(box), int(b_safe)))
+        exact = float(H.hc_pf_band_sigma_top(fp(np.ascontiguousarray(e, np.float32)), thr, B, fp(box), int(b_safe), H.hc_pf_band_top(1)))
+        assert s <= exact * (1 + 1e-6) + 1e-30 or s == 262144.0             # never bolder than the exact form beyond its slack
+        return min(s / HW_ULPS, 262144.0)
     return float(H.hc_pf_band_sigma_top(fp(e), thr, B, fp(box), int(b_safe), H.hc_pf_band_top(int(rule == "pack"))))
 
 
@@ -215,7 +226,7 @@ def check_scene(H, X0, X1, Es, thr, n_real=None, max_survivors=None, scans_below
             ns32 = np.zeros(32, np.float32)
             H.hc_pf_band_hyp_slots(fp(e), sigma, fp(ns32))
             assert ns32[27] == 1.0 and (sigma > 0 or not ns32[:27].any())
-            rej = (rejected_pack if rule == "pack" else rejected_band)(H, ns32.astype(np.float64), Bn)
+            rej = (rejected_band if rule == "band" else rejected_pack)(H, ns32.astype(np.float64), Bn)
         else:
             ns, ts, _ = hyp_slots(H, E, thr, B, guard.decide(E))
             rej = rejected(H, ns, ts, Bn, Bt)
@@ -289,7 +300,7 @@ def test_zero_divisor_pairs_survive(H, rule):
         ns32 = np.zeros(32, np.float32)
         H.hc_pf_band_hyp_slots(fp(E2.reshape(9)), sigma, fp(ns32))
         # (the first divisor's maximum over the box is 0 here, so the constant is the error floor alone: |n| = 5e-4 and 9e-4 are far outside)
-        assert sigma > 0 and (rejected_pack if rule == "pack" else rejected_band)(H, ns32.astype(np.float64), Bn)[:2].all()
+        assert sigma > 0 and (rejected_band if rule == "band" else rejected_pack)(H, ns32.astype(np.float64), Bn)[:2].all()
     else:
         ns, ts, _ = hyp_slots(H, E2, np.float32(1e-6), 0.3, survive_all=False)
         assert rejected(H, ns, ts, Bn, Bt)[:2].all()
@@ -469,7 +480,7 @@ def test_band_second_divisor_zero_selects_the_weaker_constant(H, rule):
         sigma = band_sigma(H, E.reshape(9), thr, 0.3, box, b_safe, rule)
         ns32 = np.zeros(32, np.float32)
         H.hc_pf_band_hyp_slots(fp(E.reshape(9)), sigma, fp(ns32))
-        assert bool((rejected_pack if rule == "pack" else rejected_band)(H, ns32.astype(np.float64), Bn)[0]) == expect
+        assert bool((rejected_band if rule == "band" else rejected_pack)(H, ns32.astype(np.float64), Bn)[0]) == expect
 
 
 @pytest.mark.parametrize("rule", BAND_RULES)
@@ -552,3 +563,29 @@ def test_pack_survivor_table_against_a_model_of_the_conversion(H):
     assert seen == set(range(32))
     assert H.hc_pf_band_pack_reject(1.875) == 1 and H.hc_pf_band_pack_reject(float(np.nextafter(np.float32(1.875), np.float32(0)))) == 0
     assert 1.87 < H.hc_pf_band_top(1) < 1.875 and 1.99 < H.hc_pf_band_top(0) < 2.0
+
+
+def test_per_tile_boxes_in_morton_order_never_reject_an_inlier(H):
+    """The recorded per-tile variant (kPfRuleBandTile, lab bench): the scoring tiles are runs of the Morton order of the first view's
+    positions and the band's constant is a maximum over the TILE's boxes.  Every tile is a scene of its own for the rule (check_scene
+    takes the boxes and the bound from the points it is given: the tile's own, smaller bound is the stricter test), so no oracle
+    inlier may be rejected in any tile -- and the tiles' survivor rate is below the whole-view rule's."""
+    n, tile = 4096, 1024
+    sc = synth.two_view_scene(n)
+    _, _, X0, X1 = O.fill_xu(sc["sift"], sc["Kinv"])
+    X0 = np.ascontiguousarray(X0[:, :n]); X1 = np.ascontiguousarray(X1[:, :n])
+    ulo, uhi, vlo, vhi = [float(f) for f in (X0[0].min(), X0[0].max(), X0[1].min(), X0[1].max())]
+    keys = np.array([H.hc_pf_morton_key(float(X0[0, j]), float(X0[1, j]), ulo, uhi, vlo, vhi) for j in range(n)], np.uint64)
+    order = np.argsort((keys << np.uint64(32)) | np.arange(n, dtype=np.uint64))
+    Es = [O.hypothesis_E(X0, X1, O.sample8(0x5EED5F3D, h, n), 0) for h in range(60)]
+    thr = np.float32(1e-6)
+    whole = check_scene(H, X0[:, :tile], X1[:, :tile], Es, thr, rule="pack")      # one unsorted tile's worth of points with ITS boxes (~ the whole view's)
+    rates, areas = [], []
+    assert keys.max() < 2 ** 30
+    for t0 in range(0, n, tile):
+        ids = order[t0:t0 + tile]
+        a = np.ascontiguousarray(X0[:, ids]); b = np.ascontiguousarray(X1[:, ids])
+        areas.append(float(np.ptp(a[0]) * np.ptp(a[1])))
+        rates.append(check_scene(H, a, b, Es, thr, rule="tile"))
+    assert np.mean(areas) < 0.7 * (uhi - ulo) * (vhi - vlo)                          # the order does what it is for: smaller first-view boxes
+    assert np.mean(rates) < whole
