@@ -114,10 +114,10 @@ void ransac_solve_lanes1_qr(const float *__restrict__ X0, const float *__restric
         const float B = __uint_as_float((uint32_t)(*bound_word & 0xFFFFFFFFull));
 #if SFM_AB
         if (rule == kPfRuleG) pf_prep_store(E, thr, B, sc, cells, cells_mask, recs + i);
+        else if (rule != kPfRuleBandTile) pf_band_prep_store(E, thr, B, pf_box_from_words(bound_word + 2, B), cells, cells_mask, recs + i, rule == kPfRuleBandPack ? kPfBandTopPack : kPfBandTop);
         else
 #endif
-        if (rule == kPfRuleBandTile) reinterpret_cast<uint32_t *>(recs)[i] = pf_tile_flags(E, B, cells, cells_mask);      // sigma and the slots: per tile, in the scoring kernel
-        else pf_band_prep_store(E, thr, B, pf_box_from_words(bound_word + 2, B), cells, cells_mask, recs + i, rule == kPfRuleBandPack ? kPfBandTopPack : kPfBandTop);
+        reinterpret_cast<uint32_t *>(recs)[i] = pf_tile_flags(E, B, cells, cells_mask);      // sigma and the slots: per (hypothesis, tile), in the scoring kernel
     }
     SFM_PHASE("end");
 }
