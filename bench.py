@@ -52,10 +52,9 @@ NUM_SIMDS = 1024              # 256 CU x 4
 FLOP_PER_POINT = 38           # residual of one (hypothesis, point)
 FLOP_PER_HYP = 720            # A^T A normal equations
 ALG_BYTES_PER_HYP = 72.0       # 32 B indices + 36 B E + 4 B count
-# ransac_score_prefilter, per (hypothesis, point) pair, what cannot be removed from this formulation:
-# irreducible work of the pre-filter scan per rule (prefilter_math.hpp): "band" (round 5, the product) = one v_alignbit_b32 per pair (bit 30 of
-# the accumulator into the lane's mask) and two v_mfma_f32_32x32x16_f16 per 32 x 32 pairs; "G" (rounds 2-4, lab bench, reserved[3] == 4) =
-# v_fma_f32 + v_alignbit_b32 per pair and three MFMAs
+# ransac_score_prefilter, per 1024 (hypothesis, point) pairs, what cannot be removed from the formulation a launch runs:
+# the fp16 MFMAs of the contraction and the scan that turns every accumulator into one reject bit -- "pack" (round 6, the product; with per-tile
+# or, reserved[3] == 6, per-hypothesis band constants), "band" (round 5, reserved[3] == 5), "G" (rounds 2-4, reserved[3] == 4)
 # scoring-kernel rules: (vector-issue cycles of a SIMD per 1024 pairs for the irreducible scan, fp16 MFMAs per 1024 pairs)
 #   pack: half a v_cvt_scalef32_2xpk16_bf6_f32 (64.6 cycles per 2048 pairs); band: 16 v_alignbit_b32 at 4.24; G: 16 v_fma_f32 at 2.54 + 16 v_alignbit_b32
 PF_RULES = {"pack": (32.3, 2), "band": (67.8, 2), "G": (108.5, 3)}
@@ -442,7 +441,8 @@ def roofline_block(kernel_id, n, local_hyps, score_s, solve_s, clock_mhz, measur
         out["traffic_step_over_algorithmic"] = out["traffic_step_bytes"] / out["traffic_algorithmic_bytes"]
         out["traffic_note"] = ("traffic = FETCH_SIZE + WRITE_SIZE of the scoring kernel per launch; traffic_step_bytes adds the lane-solve kernel of the same "
                                "step; algorithmic = 72 B per hypothesis + 16 B per match (SURVEY 8(d))")
-        out["issue_profiled"] = {k: quoted[k] for k in ("valu_busy_frac", "mfma_busy_frac", "valu_insts_per_launch", "lds_bank_conflict_frac", "kernel_cycles") if k in quoted}
+        out["issue_profiled"] = {k: quoted[k] for k in ("valu_busy_frac", "mfma_busy_frac", "lds_busy_frac", "valu_insts_per_launch", "lds_bank_conflict_frac", "kernel_cycles",
+                                                             "wave_issuing_frac", "wave_parked_at_waitcnt_frac", "wave_issue_stalled_frac") if k in quoted}
     else:
         out["traffic"] = None
         out["traffic_source"] = why_not

@@ -134,6 +134,8 @@ struct sfm_pair {
     float4 *d_pts4 = nullptr;          // (x1x, x1y, x2x, x2y) per correspondence, written by fillXU: ONE 16-byte gather per sampled point
     bool have_pts4 = false;            // d_pts4 describes the current points (fillXU with the unit-z layout)
     uint32_t sorted_epoch = 0;         // the fillXU epoch d_pts4s was built for
+    uint32_t *d_tile_boxes = nullptr;  // eight words per scoring tile of d_pts4s: ordered bits of its coordinate maxima (pf_tile_boxes_kernel)
+    int boxes_cap = 0, boxes_tile = 0; // tiles allocated / the tile size the boxes were computed for
     float4 *d_pts4s = nullptr;         // the same records in Morton order of the first view's position (pre-filter scoring: tiles with small
                                        // bounding boxes, ransac_prefilter.hip: pf_sort_kernel); built with the cell table, once per fillXU
     float *d_E = nullptr;              // 9
@@ -201,7 +203,8 @@ bool prefilter_usable(const sfm_pair *pair, const sfm_ransac_params &p, uint32_t
 int prefilter_rule(const sfm_ransac_params &p);                                 // kPfRuleBandPack (the product) / kPfRuleBand, kPfRuleG (lab bench, reserved[3] == 5 / 4)
 int launch_score_prefilter(sfm_pair *pair, const sfm_ransac_params &p, uint32_t h0, uint32_t count, unsigned long long *key2);
 int launch_pf_prep(sfm_pair *pair, const sfm_ransac_params &p, uint32_t count);
-int launch_pf_cells(sfm_pair *pair, bool want_sorted = false);                                            // the pair's cell table, (re)built when the points changed        // PfRecords from d_Ecand (paths whose solve kernel does not write them)
+int prefilter_tile_points(const sfm_pair *pair, const sfm_ransac_params &p);      // points per scoring tile of a launch on this pair
+int launch_pf_cells(sfm_pair *pair, bool want_sorted = false, int tile = 0);                                            // the pair's cell table, (re)built when the points changed        // PfRecords from d_Ecand (paths whose solve kernel does not write them)
 #if SFM_AB
 // ab/ransac_prefilter_r2.hip (the round-2 kernel: sfm_ransac_params.reserved[3] == 2)
 int launch_score_prefilter_r2(sfm_pair *pair, const sfm_ransac_params &p, uint32_t h0, uint32_t count, unsigned long long *key2);

@@ -413,7 +413,7 @@ int launch_ransac_score(sfm_pair *pair, const sfm_ransac_params &p, uint32_t h0,
     PfScales pf_sc = {};
     if (prefilter) (void)prefilter_scales(p.threshold, pf_sc);            // (checked by prefilter_usable)
     if (prefilter && !pf_r2) {                                            // the table of occupied cells the records are checked against
-        const int rcc = launch_pf_cells(pair, prefilter_rule(p) == kPfRuleBandTile);
+        const int rcc = launch_pf_cells(pair, prefilter_rule(p) == kPfRuleBandTile, prefilter_tile_points(pair, p));
         if (rcc != SFM_OK) return rcc;
     }
     bool need_prep = prefilter && !pf_r2;

@@ -57,7 +57,7 @@ template <int RULE> struct PfLds {
     static constexpr int kBlockBytes = kFragsPerBlock * 64 * 16;   // one 32-point block: [n k-step 0 | n k-step 1 (| G)][lane][8 fp16]
     static constexpr int kFrag = 0;
     static constexpr int kTileMax = kPfTileMax;
-    int staged, pts, ring, wave, next, lut, box, bytes;
+    int staged, pts, ring, wave, next, lut, bytes;
     __host__ __device__ explicit PfLds(int tile, int ring_entries = kPfRing)
     {
         staged = (tile + 63) & ~63;                           // points staged: whole iterations of two blocks (beyond `tile`: padding)
@@ -68,8 +68,7 @@ template <int RULE> struct PfLds {
         wave = ring + kPfWaves * ring_entries * 8;            // per wavefront: E table 9 x 32 floats (component-major), 32 counters
         next = wave + kPfWaves * kPfWaveBytes;                // the block's pass counter
         lut = next + 16;                                      // packed scan: survivor bit -> (accumulator row, step), 32 bytes (pf_pack_code)
-        box = lut + 32;                                       // tile rule: ordered bits of the tile's coordinate maxima (x, -x, y, -y, u, -u, v, -v)
-        bytes = box + 32;
+        bytes = lut + 32;
     }
 };
 static_assert(kPfRing * 8 == 1024, "ring slots are addressed with (offset & 1023) | base");
@@ -222,7 +221,7 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
                             int dynamic, int tile,
                             int *__restrict__ counts, uint32_t *__restrict__ tick,
                             unsigned long long *best_key, unsigned long long *best_key2, unsigned long long *__restrict__ clk,
-                            const unsigned long long *__restrict__ bound_word)
+                            const unsigned long long *__restrict__ bound_word, const uint32_t *__restrict__ tile_boxes)
 {
     // kPfRuleBandTile: X0 = the Morton-ordered (x1x, x1y, x2x, x2y) records (float4 per point, pair->d_pts4s), X1 unused, recs = one
     // flag word per hypothesis (pf_tile_flags)
@@ -304,11 +303,19 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
     uint32_t *next_idx = reinterpret_cast<uint32_t *>(smem + L.next);
     if (threadIdx.x == 0) *next_idx = (uint32_t)W;
     if (kPack && threadIdx.x < 32) smem[L.lut + threadIdx.x] = (unsigned char)pf_pack_code((int)threadIdx.x);
-    uint32_t *boxw = reinterpret_cast<uint32_t *>(smem + L.box);
-    if (kTile && threadIdx.x < 8) boxw[threadIdx.x] = pf_order_bits(-INFINITY);
+    // tile rule: the pair's bound and this tile's boxes (pf_tile_boxes_kernel, once per fillXU) are requested now and used after the staging
+    float pf_B = 0.0f;
+    uint32_t bw[8] = {};
+    uint32_t bw_lane = 0u;
+    if (kTile) {
+        // (one word per lane through the vector memory path, handed to the scalar registers with v_readlane after the staging: the
+        // eight-word scalar load the compiler builds for a uniform address came back with a wrong sign in the first box -- counts of
+        // 3000 / 7000-point pairs off by one in 0.4 % of the hypotheses, profiles/r06_tile_boxes_debug.txt)
+        pf_B = __uint_as_float((uint32_t)(__hip_atomic_load(reinterpret_cast<const uint32_t *>(bound_word), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
+        bw_lane = __hip_atomic_load(tile_boxes + 8 * blockIdx.y + (lane & 7), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     __syncthreads();
     const int tile_first = blockIdx.y * tile;
-    float ext[8] = { -INFINITY, -INFINITY, -INFINITY, -INFINITY, -INFINITY, -INFINITY, -INFINITY, -INFINITY };
     for (int t = threadIdx.x; t < L.staged; t += W * 64) {
         const int p = tile_first + t;
         float u = 0.f, v = 0.f, x = 0.f, y = 0.f;
@@ -319,11 +326,6 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
             if (real) {
                 const float4 q4 = reinterpret_cast<const float4 *>(X0)[p];
                 u = q4.x; v = q4.y; x = q4.z; y = q4.w;
-                const float big = fmaxf(fmaxf(fabsf(u), fabsf(v)), fmaxf(fabsf(x), fabsf(y)));
-                if (big <= 48.0f && u == u && v == v && x == x && y == y) {       // prefilter_point_slots' own test: the point carries features
-                    ext[0] = fmaxf(ext[0], x); ext[1] = fmaxf(ext[1], -x); ext[2] = fmaxf(ext[2], y); ext[3] = fmaxf(ext[3], -y);
-                    ext[4] = fmaxf(ext[4], u); ext[5] = fmaxf(ext[5], -u); ext[6] = fmaxf(ext[6], v); ext[7] = fmaxf(ext[7], -v);
-                }
             }
         } else
         if (real) { u = X0[p]; v = X0[(size_t)ld + p]; x = X1[p]; y = X1[(size_t)ld + p]; }
@@ -352,32 +354,17 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
             }
         }
     }
-    if (kTile) {                                              // the tile's boxes: maxima over the wavefront, then over the block in LDS
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) ext[k] = fmaxf(ext[k], __shfl_xor(ext[k], off));
-        }
-        if (lane < 8) {
-            float mine = ext[0];
-#pragma unroll
-            for (int k = 1; k < 8; ++k) mine = lane == k ? ext[k] : mine;
-            atomicMax(&boxw[lane], pf_order_bits(mine));
-        }
-    }
     __syncthreads();
-    // tile rule: the pair's bound and this tile's boxes, and with them the first pass' operands (E and the flag word are in registers)
-    float pf_B = 0.0f;
+    // tile rule: the first pass' operands (E and the flag word are in registers)
     PfBox tbox = {};
     auto build_operands = [&](const float (&e)[9], uint32_t fl) {
         pf_tile_operands(e, fl, thr, pf_B, tbox, half, afrag.n0, afrag.n1);
         key0 = fl & kPfTileFlagScan;
     };
     if (kTile) {
-        pf_B = __uint_as_float((uint32_t)(*bound_word & 0xFFFFFFFFull));
-        uint32_t bw[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) bw[k] = (uint32_t)__builtin_amdgcn_readfirstlane((int)boxw[k]);
+        for (int k = 0; k < 8; ++k) bw[k] = (uint32_t)__builtin_amdgcn_readlane((int)bw_lane, k);
+        pf_B = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(pf_B)));
         tbox = pf_box_from_bits(bw, pf_B);
         if (have) build_operands(e_row, key0);
     }
@@ -839,6 +826,37 @@ void pf_sort_kernel(const float4 *__restrict__ pts4, int ld, int np2, const unsi
     for (int i = threadIdx.x; i < ld; i += blockDim.x) out[i] = pts4[(uint32_t)(sk[i] & 0xFFFFFFFFull)];
 }
 
+// The bounding boxes of every tile of the ordered copy: ordered bits of the maxima of (x, -x, y, -y, u, -u, v, -v) over the tile's
+// feature-carrying points (eight words per tile; no such point: -inf, which pf_box_from_bits turns into the whole range).  One block per tile.
+__global__ __launch_bounds__(256)
+void pf_tile_boxes_kernel(const float4 *__restrict__ pts4s, int n, int tile, uint32_t *__restrict__ boxes)
+{
+    __shared__ uint32_t sw[8];
+    if (threadIdx.x < 8) sw[threadIdx.x] = pf_order_bits(-INFINITY);
+    __syncthreads();
+    float ext[8] = { -INFINITY, -INFINITY, -INFINITY, -INFINITY, -INFINITY, -INFINITY, -INFINITY, -INFINITY };
+    const int first = blockIdx.x * tile;
+    for (int t = threadIdx.x; t < tile && first + t < n; t += blockDim.x) {
+        const float4 q = pts4s[first + t];                      // (x1x, x1y, x2x, x2y) = (u, v, x, y)
+        const float big = fmaxf(fmaxf(fabsf(q.x), fabsf(q.y)), fmaxf(fabsf(q.z), fabsf(q.w)));
+        if (big <= 48.0f && q.x == q.x && q.y == q.y && q.z == q.z && q.w == q.w) {       // prefilter_point_slots' own test: the point carries features
+            ext[0] = fmaxf(ext[0], q.z); ext[1] = fmaxf(ext[1], -q.z); ext[2] = fmaxf(ext[2], q.w); ext[3] = fmaxf(ext[3], -q.w);
+            ext[4] = fmaxf(ext[4], q.x); ext[5] = fmaxf(ext[5], -q.x); ext[6] = fmaxf(ext[6], q.y); ext[7] = fmaxf(ext[7], -q.y);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) ext[k] = fmaxf(ext[k], __shfl_xor(ext[k], off));
+    }
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) atomicMax(&sw[k], pf_order_bits(ext[k]));
+    }
+    __syncthreads();
+    if (threadIdx.x < 8) boxes[8 * blockIdx.x + threadIdx.x] = sw[threadIdx.x];
+}
+
 __global__ __launch_bounds__(256)
 void pf_copy_points_kernel(const float4 *__restrict__ pts4, int ld, float4 *__restrict__ out)
 {
@@ -846,10 +864,10 @@ void pf_copy_points_kernel(const float4 *__restrict__ pts4, int ld, float4 *__re
     if (i < ld) out[i] = pts4[i];
 }
 
-int launch_pf_cells(sfm_pair *pair, bool want_sorted)
+int launch_pf_cells(sfm_pair *pair, bool want_sorted, int tile)
 {
     hipStream_t st = pair->ctx->stream;
-    if (pair->cells_epoch == pair->bound_epoch && pair->d_cells && (!want_sorted || pair->sorted_epoch == pair->bound_epoch)) {   // built for the current points
+    if (pair->cells_epoch == pair->bound_epoch && pair->d_cells && (!want_sorted || (pair->sorted_epoch == pair->bound_epoch && pair->boxes_tile == tile))) {   // built for the current points
         // ... possibly by a launch on another stream (the other slot of a pipelined burst): order this stream behind it
         if (st != pair->cells_stream) SFM_HIP_TRY(hipStreamWaitEvent(st, pair->cells_ev, 0));
         return SFM_OK;
@@ -882,6 +900,18 @@ int launch_pf_cells(sfm_pair *pair, bool want_sorted)
         hipLaunchKernelGGL(pf_copy_points_kernel, dim3((pair->ld + 255) / 256), dim3(256), 0, st, pair->d_pts4, pair->ld, pair->d_pts4s);
     }
     SFM_HIP_TRY(hipGetLastError());
+    // ... and its tiles' boxes (the tile size is a function of the row length, pf_tile_of)
+    const int ntiles = (pair->ld + tile - 1) / tile;
+    if (ntiles > pair->boxes_cap) {
+        SFM_HIP_TRY(hipStreamSynchronize(st));
+        if (pair->d_tile_boxes) (void)hipFree(pair->d_tile_boxes);
+        pair->d_tile_boxes = nullptr; pair->boxes_cap = 0;
+        SFM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&pair->d_tile_boxes), (size_t)ntiles * 8 * sizeof(uint32_t)));
+        pair->boxes_cap = ntiles;
+    }
+    hipLaunchKernelGGL(pf_tile_boxes_kernel, dim3(ntiles), dim3(256), 0, st, pair->d_pts4s, pair->n, tile, pair->d_tile_boxes);
+    SFM_HIP_TRY(hipGetLastError());
+    pair->boxes_tile = tile;
     }
     if (!pair->cells_ev) SFM_HIP_TRY(hipEventCreateWithFlags(&pair->cells_ev, hipEventDisableTiming));
     SFM_HIP_TRY(hipEventRecord(pair->cells_ev, st));
@@ -1126,6 +1156,8 @@ static int pf_tile_of(const sfm_pair *pair, const sfm_ransac_params &p)
     return pf_tile_points(pair->ld, kPfTileMax);
 }
 
+int prefilter_tile_points(const sfm_pair *pair, const sfm_ransac_params &p) { return pf_tile_of(pair, p); }
+
 int launch_score_prefilter(sfm_pair *pair, const sfm_ransac_params &p, uint32_t h0, uint32_t count, unsigned long long *key2)
 {
     sfm_ctx *ctx = pair->ctx;
@@ -1159,7 +1191,7 @@ int launch_score_prefilter(sfm_pair *pair, const sfm_ransac_params &p, uint32_t 
         const float *x0 = rule == kPfRuleBandTile ? reinterpret_cast<const float *>(pair->d_pts4s) : pair->d_X[0];
         hipLaunchKernelGGL(kernel, dim3(cols, ntiles), dim3(waves * 64), lds_bytes, ctx->stream,
                            x0, pair->d_X[1], pair->ld, pair->n, pair->d_Ecand, reinterpret_cast<const PfRecord *>(pair->d_pf), h0, count, p.threshold,
-                           dynamic, tile, pair->d_counts, pair->d_tick, pair->d_key, key2, pair->d_clk, pair->d_bound);
+                           dynamic, tile, pair->d_counts, pair->d_tick, pair->d_key, key2, pair->d_clk, pair->d_bound, pair->d_tile_boxes);
         return SFM_OK;
     };
     int rcl;

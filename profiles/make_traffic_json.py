@@ -38,5 +38,11 @@ for block in re.split(r"\n(?=sfm::)", text):
             e["lds_bank_conflict_frac"] = round(vals.get("SQ_LDS_BANK_CONFLICT", 0.0) / vals["SQ_LDS_IDX_ACTIVE"], 4)
         if vals.get("SQ_WAVE_CYCLES"):
             e["mean_resident_waves_per_simd"] = round(4.0 * vals["SQ_WAVE_CYCLES"] / (cyc * 1024.0), 3)
+            # where a wavefront's cycles go (disjoint: issuing / parked at s_waitcnt / stalled at issue)
+            for k, name in (("SQ_ACTIVE_INST_ANY", "wave_issuing_frac"), ("SQ_WAIT_ANY", "wave_parked_at_waitcnt_frac"), ("SQ_WAIT_INST_ANY", "wave_issue_stalled_frac")):
+                if k in vals:
+                    e[name] = round(vals[k] / vals["SQ_WAVE_CYCLES"], 4)
+        if vals.get("SQ_LDS_IDX_ACTIVE") and cyc > 0:
+            e["lds_busy_frac"] = round(vals["SQ_LDS_IDX_ACTIVE"] / (cyc * 256.0), 4)
     out[key] = e
 print(json.dumps(out, indent=1))

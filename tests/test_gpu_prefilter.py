@@ -26,6 +26,7 @@ def check_all(pair, scene, p, H, n):
 
 
 @pytest.mark.parametrize("n,H", [(1024, 16384), (1000, 20000), (4096, 32768), (4500, 17000), (700, 16385), (2048, 65536),
+                                 (1500, 20000), (2000, 40000), (3000, 40000), (7000, 40000), (9000, 20000), (12345, 16384),   # 2, 2, 3, 7, 9, 13 tiles (round 6: a box with a wrong sign showed at 3 and 7 tiles only, profiles/r06_tile_boxes_debug.txt)
                                  (70000, 16384), (270000, 16384)])      # 69 tiles (3 grid columns); 264 tiles: more tiles than CUs, one column
 def test_prefilter_counts_equal_oracle(gpu, n, H):
     scene = synth.two_view_scene(n, seed=200 + n)
