@@ -447,15 +447,23 @@ SFM_HD float pf_sqrt(float x)
 // bound as prefilter_band_sigma from the two divisor maxima Da, Db (each computed by ONE half of the wavefront, pf_band_corner_max over its
 // view's box), with the hardware's 1-ulp reciprocal and square root behind widened slack factors -- every deviation makes W larger, i.e.
 // sigma smaller, i.e. the rule more conservative; device and host may differ in the last bits of sigma, never in soundness.
-SFM_HD float prefilter_band_sigma_from_maxima(const float e[9], float thr, float B, float Da, float Db, bool b_safe, float top)
+// the per-hypothesis part of it, computed ONCE (lane solve / pf_prep_kernel) and carried in the hypothesis' 16-byte record: dn = the
+// contraction's error bound 3 * 2^-20 sabs (negative: the hypothesis is not tame -- an entry beyond 2 or not finite, or B > 48 -- and
+// every pair survives) and lin = B (|e0| + |e1| + |e3| + |e4|), the linear part of both divisors' rounding bound
+SFM_HD void prefilter_band_hyp_terms(const float e[9], float B, float &dn, float &lin)
 {
     float ae[9];
     bool tame = B <= 48.0f;
 #pragma unroll
     for (int k = 0; k < 9; ++k) { ae[k] = fabsf(e[k]); tame = tame && (ae[k] <= 2.0f); }
-    if (!tame) return 0.0f;
     const float sabs = ae[8] + B * (ae[2] + ae[5] + ae[6] + ae[7]) + B * B * (ae[0] + ae[1] + ae[3] + ae[4]);
-    const float dn = 2.8610229e-06f * sabs;                                                    // 3 * 2^-20
+    dn = tame ? 2.8610229e-06f * sabs : -1.0f;                                                 // 3 * 2^-20
+    lin = B * (ae[0] + ae[1] + ae[3] + ae[4]);
+}
+
+SFM_HD float prefilter_band_sigma_from_maxima(float dn, float thr, float B, float Da, float Db, bool b_safe, float top)
+{
+    if (!(dn >= 0.0f)) return 0.0f;
     float H = Da;
     if (b_safe) H = (Da * Db) * pf_rcp(Da + Db) * 1.000003f;
     const float C = (thr * 1.000002f) * H;
@@ -467,9 +475,8 @@ SFM_HD float prefilter_band_sigma_from_maxima(const float e[9], float thr, float
 }
 
 // the maximum of the first (side 0: second-view box) or second (side 1: first-view box) divisor over its box, as prefilter_band_sigma takes it
-SFM_HD float prefilter_band_divisor_max(const float e[9], float B, const PfBox &box, int side)
+SFM_HD float prefilter_band_divisor_max(const float e[9], float lin, const PfBox &box, int side)
 {
-    const float lin = B * (fabsf(e[0]) + fabsf(e[1]) + fabsf(e[3]) + fabsf(e[4]));
     const float c1 = side ? e[3] : e[1], c2 = side ? e[6] : e[2], c3 = side ? e[1] : e[3], c5 = side ? e[7] : e[5];
     const float lo0 = side ? box.ulo : box.xlo, hi0 = side ? box.uhi : box.xhi, lo1 = side ? box.vlo : box.ylo, hi1 = side ? box.vhi : box.yhi;
     const float eta = 2.3841858e-07f * (fabsf(c2) + fabsf(c5) + lin);                          // 4 * 2^-24

@@ -175,6 +175,15 @@ __device__ __forceinline__ void pf_band_store(const float e[9], float sigma, boo
 
 // ---- kPfRuleBandTile: what is left per hypothesis (the two zero-divisor analyses over the pair's cell table), and the operands of one
 // (hypothesis, tile) as the scoring kernel derives them from E itself
+// the 16-byte record of a hypothesis: { flags, dn, lin, 0 } (prefilter_band_hyp_terms)
+__device__ __forceinline__ uint32_t pf_tile_flags(const float e[9], float B, const uint32_t *__restrict__ cells, uint32_t cells_mask);
+__device__ __forceinline__ uint4 pf_tile_record(const float e[9], float B, const uint32_t *__restrict__ cells, uint32_t cells_mask)
+{
+    float dn, lin;
+    prefilter_band_hyp_terms(e, B, dn, lin);
+    return make_uint4(pf_tile_flags(e, B, cells, cells_mask), __float_as_uint(dn), __float_as_uint(lin), 0u);
+}
+
 __device__ __forceinline__ uint32_t pf_tile_flags(const float e[9], float B, const uint32_t *__restrict__ cells, uint32_t cells_mask)
 {
     const PfGrid grid = prefilter_grid(B);
@@ -192,12 +201,12 @@ __device__ __forceinline__ uint32_t pf_tile_flags(const float e[9], float B, con
 
 // this lane's half (k-slots 8 half .. 8 half + 7 of either k-step) of the coefficient fragments of hypothesis e for a tile whose
 // points lie in `box`: the very values pf_band_store would put into a record for the same sigma
-__device__ __forceinline__ void pf_tile_operands(const float e[9], uint32_t flags, float thr, float B, const PfBox &box, int half, h8 &n0, h8 &n1)
+__device__ __forceinline__ void pf_tile_operands(const float e[9], uint32_t flags, float dn, float lin, float thr, float B, const PfBox &box, int half, h8 &n0, h8 &n1)
 {
     // each half of the wavefront bounds ONE divisor over its view's box (lanes l and l + 32 hold the same hypothesis) and hands it over
-    const float d_mine = prefilter_band_divisor_max(e, B, box, half);
+    const float d_mine = prefilter_band_divisor_max(e, lin, box, half);
     const float d_other = __shfl_xor(d_mine, 32);
-    const float sigma = prefilter_band_sigma_from_maxima(e, thr, B, half ? d_other : d_mine, half ? d_mine : d_other, (flags & kPfTileFlagBSafe) != 0u, kPfBandTopPack);
+    const float sigma = prefilter_band_sigma_from_maxima(dn, thr, B, half ? d_other : d_mine, half ? d_mine : d_other, (flags & kPfTileFlagBSafe) != 0u, kPfBandTopPack);
     _Float16 ns[kPfSlots];
     prefilter_band_hyp_slots(e, sigma, ns);
 #pragma unroll

@@ -117,7 +117,7 @@ void ransac_solve_lanes1_qr(const float *__restrict__ X0, const float *__restric
         else if (rule != kPfRuleBandTile) pf_band_prep_store(E, thr, B, pf_box_from_words(bound_word + 2, B), cells, cells_mask, recs + i, rule == kPfRuleBandPack ? kPfBandTopPack : kPfBandTop);
         else
 #endif
-        reinterpret_cast<uint32_t *>(recs)[i] = pf_tile_flags(E, B, cells, cells_mask);      // sigma and the slots: per (hypothesis, tile), in the scoring kernel
+        reinterpret_cast<uint4 *>(recs)[i] = pf_tile_record(E, B, cells, cells_mask);        // sigma and the slots: per (hypothesis, tile), in the scoring kernel
     }
     SFM_PHASE("end");
 }

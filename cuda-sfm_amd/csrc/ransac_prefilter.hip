@@ -224,7 +224,7 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
                             const unsigned long long *__restrict__ bound_word, const uint32_t *__restrict__ tile_boxes)
 {
     // kPfRuleBandTile: X0 = the Morton-ordered (x1x, x1y, x2x, x2y) records (float4 per point, pair->d_pts4s), X1 unused, recs = one
-    // flag word per hypothesis (pf_tile_flags)
+    // 16-byte record per hypothesis (pf_tile_record: flags, dn, lin)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -260,6 +260,7 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
     // flag and its E row.  Rows beyond the range repeat the last hypothesis (never counted).
     PfFrags afrag = {};
     uint32_t key0 = 0u;
+    float rec_dn = 0.0f, rec_lin = 0.0f;                     // tile rule: the rest of the record fetch_pass has just read
     float e_row[9] = {};
     auto fetch_pass = [&](uint32_t pass, PfFrags &af, uint32_t &k0, float (&e)[9]) {
         const uint32_t hf = pass * (uint32_t)kPfGroup;
@@ -268,7 +269,8 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
             const float *src = Ecand + 9 * (size_t)h;
 #pragma unroll
             for (int k = 0; k < 9; ++k) e[k] = src[k];
-            k0 = reinterpret_cast<const uint32_t *>(recs)[h];
+            const uint4 rec = reinterpret_cast<const uint4 *>(recs)[h];
+            k0 = rec.x; rec_dn = __uint_as_float(rec.y); rec_lin = __uint_as_float(rec.z);
             return;
         }
         const uint4 *r = reinterpret_cast<const uint4 *>(recs + h) + 2 * half;        // this lane's half of the record: 32 bytes
@@ -358,7 +360,7 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
     // tile rule: the first pass' operands (E and the flag word are in registers)
     PfBox tbox = {};
     auto build_operands = [&](const float (&e)[9], uint32_t fl) {
-        pf_tile_operands(e, fl, thr, pf_B, tbox, half, afrag.n0, afrag.n1);
+        pf_tile_operands(e, fl, rec_dn, rec_lin, thr, pf_B, tbox, half, afrag.n0, afrag.n1);
         key0 = fl & kPfTileFlagScan;
     };
     if (kTile) {
@@ -934,7 +936,7 @@ void pf_prep_kernel(const float *__restrict__ Ecand, uint32_t count, float thr, 
 #pragma unroll
     for (int k = 0; k < 9; ++k) e[k] = Ecand[9 * (size_t)i + k];
     const float B = __uint_as_float((uint32_t)(*bound_word & 0xFFFFFFFFull));
-    if (RULE == kPfRuleBandTile) reinterpret_cast<uint32_t *>(recs)[i] = pf_tile_flags(e, B, cells, cells_mask);
+    if (RULE == kPfRuleBandTile) reinterpret_cast<uint4 *>(recs)[i] = pf_tile_record(e, B, cells, cells_mask);
     else if (RULE != kPfRuleG) pf_band_prep_store(e, thr, B, pf_box_from_words(bound_word + 2, B), cells, cells_mask, recs + i, RULE == kPfRuleBandPack ? kPfBandTopPack : kPfBandTop);
     else pf_prep_store(e, thr, B, sc, cells, cells_mask, recs + i);
 }

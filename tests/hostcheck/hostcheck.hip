@@ -120,8 +120,10 @@ uint32_t hc_pf_pack_field(int b) { return sfm::pf_pack_field(b); }
 float hc_pf_tile_sigma(const float *e, float thr, float B, const float *box, int b_safe)
 {
     const sfm::PfBox bx = { box[0], box[1], box[2], box[3], box[4], box[5], box[6], box[7] };
-    const float Da = sfm::prefilter_band_divisor_max(e, B, bx, 0), Db = sfm::prefilter_band_divisor_max(e, B, bx, 1);
-    return sfm::prefilter_band_sigma_from_maxima(e, thr, B, Da, Db, b_safe != 0, sfm::kPfBandTopPack);
+    float dn, lin;
+    sfm::prefilter_band_hyp_terms(e, B, dn, lin);
+    const float Da = sfm::prefilter_band_divisor_max(e, lin, bx, 0), Db = sfm::prefilter_band_divisor_max(e, lin, bx, 1);
+    return sfm::prefilter_band_sigma_from_maxima(dn, thr, B, Da, Db, b_safe != 0, sfm::kPfBandTopPack);
 }
 // the tile order of the recorded per-tile variant (pf_sort_kernel): Morton key of a first-view position over the view's coordinate range
 uint32_t hc_pf_morton_key(float u, float v, float ulo, float uhi, float vlo, float vhi) { return sfm::pf_morton_key(u, v, ulo, uhi, vlo, vhi); }
