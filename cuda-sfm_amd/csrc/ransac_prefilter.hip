@@ -58,14 +58,14 @@ template <int RULE> struct PfLds {
     static constexpr int kFrag = 0;
     static constexpr int kTileMax = kPfTileMax;
     int staged, pts, ring, wave, next, lut, bytes;
-    __host__ __device__ explicit PfLds(int tile, int ring_entries = kPfRing)
+    __host__ __device__ explicit PfLds(int tile, int ring_entries = kPfRing, int entry_bytes = 8)
     {
         staged = (tile + 63) & ~63;                           // points staged: whole iterations of two blocks (beyond `tile`: padding)
         pts = kFrag + (staged / 32) * kBlockBytes;            // float4 (x2x, x1x, x2y, x1y) per point
         ring = pts + staged * 16;                             // the wavefronts' survivor rings, 1024 bytes each, 1024-byte aligned (a slot's
                                                               // address is (offset & 1023) | base: one v_and_or_b32): staged is a multiple of 64
-        ring = (ring + ring_entries * 8 - 1) & ~(ring_entries * 8 - 1);
-        wave = ring + kPfWaves * ring_entries * 8;            // per wavefront: E table 9 x 32 floats (component-major), 32 counters
+        ring = (ring + ring_entries * entry_bytes - 1) & ~(ring_entries * entry_bytes - 1);
+        wave = ring + kPfWaves * ring_entries * entry_bytes;  // per wavefront: E table 9 x 32 floats (component-major), 32 counters
         next = wave + kPfWaves * kPfWaveBytes;                // the block's pass counter
         lut = next + 16;                                      // packed scan: survivor bit -> (accumulator row, step), 32 bytes (pf_pack_code)
         bytes = lut + 32;
@@ -133,6 +133,8 @@ __device__ __forceinline__ uint32_t pack_reject_bits(const u6v &d)
 typedef uint32_t u2v __attribute__((ext_vector_type(2)));
 typedef float f4v __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) u2v lds_u2;
+typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) u4v lds_u4;
 typedef __attribute__((address_space(3))) const f4v lds_cf4;
 typedef __attribute__((address_space(3))) const float lds_cf;
 typedef __attribute__((address_space(3))) int lds_i;
@@ -214,7 +216,8 @@ __device__ __forceinline__ void mfma_step(const PfFrags &a, const PfFrags &b, f1
 constexpr int kPfVarTickets = 1;
 
 // FL2 (experiment): a ring of 256 entries, flushed 128 at a time -- two entries per lane, their LDS reads issued together
-template <int W, int VAR = 0, int RULE = kPfRuleBandTile, int FL2 = 0, int PIPE = 0>
+// WIDE (experiment): ring entries of 16 bytes that cover FOUR steps (two conversions): half as many appends
+template <int W, int VAR = 0, int RULE = kPfRuleBandTile, int FL2 = 0, int PIPE = 0, int WIDE = 0>
 __global__ __launch_bounds__(W * 64)
 void ransac_score_prefilter(const float *__restrict__ X0, const float *__restrict__ X1, int ld, int n,
                             const float *__restrict__ Ecand, const PfRecord *__restrict__ recs, uint32_t h0, uint32_t count, float thr,
@@ -252,7 +255,9 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
     constexpr bool kBand = RULE != kPfRuleG, kTile = RULE == kPfRuleBandTile, kPack = RULE == kPfRuleBandPack || kTile;
     static_assert(!(FL2 && kPack) && !(VAR && kPack), "the recorded variants were built on the v_alignbit scan");
     constexpr int kRing = FL2 ? 256 : kPfRing;
-    const LT L(tile, kRing);
+    constexpr int kEnt = WIDE ? 16 : 8;                       // bytes per ring entry
+    static_assert(!WIDE || (kPack && !PIPE && !FL2), "wide entries: the packed scan's plain loop only");
+    const LT L(tile, kRing, kEnt);
     float *etab = reinterpret_cast<float *>(smem + L.wave + wave * kPfWaveBytes);
     int *cnt = reinterpret_cast<int *>(etab + 32 * kPfERow);
 
@@ -379,11 +384,14 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
     lds_cf *etab_l = (lds_cf *)etab;
     lds_i *cnt_l = (lds_i *)cnt;
     lds_cu8 *lut_l = (lds_cu8 *)(smem + L.lut);
-    const uint32_t ring_base = (uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char *)(smem + L.ring) + (uint32_t)wave * (uint32_t)(kRing * 8);
-    uint32_t ring_mask = (uint32_t)(kRing * 8 - 1);
+    const uint32_t ring_base = (uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char *)(smem + L.ring) + (uint32_t)wave * (uint32_t)(kRing * kEnt);
+    uint32_t ring_mask = (uint32_t)(kRing * kEnt - 1);
     asm("" : "+v"(ring_mask));                            // in a vector register: v_and_or_b32 takes one scalar operand, and that is the base
     auto ring_at = [&](uint32_t index8) {                 // index8 = 8 x (slot index, not yet wrapped)
         return (lds_u2 *)((__attribute__((address_space(3))) unsigned char *)0 + ((index8 & ring_mask) | ring_base));
+    };
+    auto ring_at16 = [&](uint32_t index16) {              // wide entries: 16 x (slot index, not yet wrapped)
+        return (lds_u4 *)((__attribute__((address_space(3))) unsigned char *)0 + ((index16 & ring_mask) | ring_base));
     };
     lds_ch8 *frag_lane = (lds_ch8 *)(smem + LT::kFrag) + lane;
     const ThrBand band = make_band(thr);
@@ -473,6 +481,36 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
             if (more) {
                 const int slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(more >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)more, 0u));
                 if (rest) *ring_at(((uint32_t)(head + nq) + (uint32_t)slot) * 8u) = u2v{ rest, tag };
+            }
+            head = (head + m) & (kRing - 1);
+            nq += __builtin_popcountll(more) - m;
+        };
+        // wide entries { survivors of phase 2 k, survivors of phase 2 k + 1, tag of phase 2 k, - }: the first survivor of the first word that has one
+        auto flush_w = [&](int m) {
+            uint32_t ra = 0, rb = 0, tag = 0;
+            if (lane < m) {
+                const u4v ent = *ring_at16(((uint32_t)head + (uint32_t)lane) * 16u);
+                tag = ent.z;
+                const bool second = ent.x == 0u;
+                const uint32_t surv = second ? ent.y : ent.x;
+                const int b = __builtin_clz(surv);
+                const uint32_t left = surv & ~(0x80000000u >> b);
+                ra = second ? 0u : left; rb = second ? left : ent.y;
+                const uint32_t code = lut_l[b];
+                const int hl = (int)(code & 31u) + (int)(tag & 4u);
+                if (hl < nvalid) {
+                    const f4v q = *(lds_cf4 *)((__attribute__((address_space(3))) const unsigned char *)0 + ((tag & ~15u) + ((code >> 5) << 9) + (second ? 1024u : 0u)));
+                    lds_cf *e = etab_l + hl;
+                    const v2f p0 = { e[0], e[32] }, p1 = { e[64], e[96] }, p2 = { e[128], e[160] }, p3 = { e[192], e[224] };
+                    const float e8 = e[256];
+                    if (pf_exact_inlier(p0, p1, p2, p3, e8, v2f{ q.x, q.y }, v2f{ q.z, q.w }, band))
+                        __hip_atomic_fetch_add(cnt_l + hl, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
+            const unsigned long long more = __ballot((ra | rb) != 0u);
+            if (more) {
+                const int slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(more >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)more, 0u));
+                if ((ra | rb) != 0u) *ring_at16(((uint32_t)(head + nq) + (uint32_t)slot) * 16u) = u4v{ ra, rb, tag, 0u };
             }
             head = (head + m) & (kRing - 1);
             nq += __builtin_popcountll(more) - m;
@@ -578,6 +616,23 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
                 nq += __builtin_popcountll(any);
             }
         };
+        uint32_t rej_even = 0xFFFFFFFFu;                    // wide entries: the reject bits of the even phase of a pair of phases
+        auto append_w = [&](uint32_t ra, uint32_t rb, int pp_even) {
+            const bool mine = (ra & rb) != 0xFFFFFFFFu;
+            const unsigned long long any = __ballot(mine);
+            if (any) {
+                while (nq >= 64) flush_w(64);
+                const int slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(any >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)any, 0u));
+                if (mine) *ring_at16(((uint32_t)(head + nq) + (uint32_t)slot) * 16u) = u4v{ ~ra, ~rb, lane_tag + ((uint32_t)pp_even << 10), 0u };
+                nq += __builtin_popcountll(any);
+            }
+        };
+        auto after_phase = [&](const u6v &d, int pp) {      // what happens to the conversion of phase pp
+            if (!WIDE) { append(d, pp); return; }
+            const uint32_t rej32 = pack_reject_bits(d);
+            if ((pp & 1) == 0) rej_even = rej32;
+            else append_w(rej_even, rej32, pp - 1);
+        };
         for (int pp = 0; pp < npp; ++pp) {
             SFM_PHASE("scan_two_steps");
             mfma_step<RULE>(afrag, fa, g0, n0);
@@ -588,12 +643,13 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
             fb = load_point_frags<RULE>(fp, 1);
             fp += 2 * (LT::kBlockBytes / 16);
             __builtin_amdgcn_sched_barrier(0);
-            if (pp > 0) append(dpk, pp - 1);
+            if (pp > 0) after_phase(dpk, pp - 1);
             __builtin_amdgcn_sched_barrier(0);
             dpk = __builtin_amdgcn_cvt_scalef32_2xpk16_bf6_f32(n0, n1, 1.0f);
             __builtin_amdgcn_sched_barrier(0);
         }
-        append(dpk, npp - 1);
+        after_phase(dpk, npp - 1);
+        if (WIDE && (npp & 1)) append_w(rej_even, 0xFFFFFFFFu, npp - 1);      // an odd number of phases: the last one alone
         } else {
         PfFrags fa = load_point_frags<RULE>(frag_lane, 0), fb = load_point_frags<RULE>(frag_lane, 1);
         f16v g0, n0, g1, n1;
@@ -645,6 +701,7 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
         if (have_next) fetch_pass(ps_next, afrag_next, key0n, e_row);
         SFM_PHASE("drain_flush");
         if (FL2) { while (nq >= 128) flush2(); }
+        if (WIDE) { while (nq > 0) flush_w(min(nq, 64)); }
         while (nq > 0) flush(min(nq, 64));
         SFM_PHASE("epilogue");
         PF_PHASE(7);
@@ -1185,7 +1242,8 @@ int launch_score_prefilter(sfm_pair *pair, const sfm_ransac_params &p, uint32_t 
     const int var = SFM_SW(p, 3) >= 16 ? SFM_SW(p, 3) - 16 : 0;                 // (AB build, reserved[3] = 16 + VAR bits)
     const int rule = prefilter_rule(p);
     const bool fl2 = rule == kPfRuleBand && waves == kPfWaves && SFM_SW(p, 1) == 9;      // (AB build: 256-entry ring, two entries per lane per flush)
-    const int lds_bytes = fl2 ? PfLds<kPfRuleBand>(tile, 256).bytes : rule != kPfRuleG ? PfLds<kPfRuleBand>(tile).bytes : PfLds<kPfRuleG>(tile).bytes;
+    const bool wide = rule == kPfRuleBandTile && SFM_SW(p, 1) == 13;                     // (AB build: 16-byte ring entries covering four steps)
+    const int lds_bytes = wide ? PfLds<kPfRuleBand>(tile, kPfRing, 16).bytes : fl2 ? PfLds<kPfRuleBand>(tile, 256).bytes : rule != kPfRuleG ? PfLds<kPfRuleBand>(tile).bytes : PfLds<kPfRuleG>(tile).bytes;
     if (lds_bytes > 160 * 1024) { set_error("pre-filter tile of %d points needs %d bytes of LDS", tile, lds_bytes); return SFM_E_INVALID; }
     auto launch = [&](auto kernel) -> int {
         const int rc_lds = allow_big_lds(ctx, reinterpret_cast<const void *>(kernel));
@@ -1207,10 +1265,11 @@ int launch_score_prefilter(sfm_pair *pair, const sfm_ransac_params &p, uint32_t 
     else if (SFM_SW(p, 1) == 11) rcl = launch(&ransac_score_prefilter<16, 0, kPfRuleBandPack, 0, 1>);
     else if (SFM_SW(p, 1) == 12) rcl = launch(&ransac_score_prefilter<12, 0, kPfRuleBandPack, 0, 1>);
     else if (rule == kPfRuleBandPack) rcl = launch(&ransac_score_prefilter<16, 0, kPfRuleBandPack>);
+    else if (wide) rcl = launch(&ransac_score_prefilter<16, 0, kPfRuleBandTile, 0, 0, 1>);
     else
 #endif
     rcl = launch(&ransac_score_prefilter<16, 0, kPfRuleBandTile>);
-    (void)var; (void)fl2;
+    (void)var; (void)fl2; (void)wide;
     if (rcl != SFM_OK) return rcl;
     SFM_HIP_TRY(hipGetLastError());
     pair->last_grid = (int)cols * ntiles; pair->last_block = waves * 64; pair->last_lds = lds_bytes;

@@ -27,7 +27,8 @@ extern "C" {
  *   [1] 1 tile loop inside the scoring block instead of the tile-parallel grid (n > 4096); 2 pre-filter passes handed out by
  *       position instead of through the block's LDS counter; 5 twelve wavefronts per pre-filter block; 7 tiles of up to 1536
  *       points; 9 a 256-entry ring flushed 128 entries at a time; 11 / 12 the packed scan software-pipelined over four accumulator
- *       sets with 16 / 12 wavefronts per block (30 spills / 140 registers: profiles/r06_ab_pack_scan.txt);
+ *       sets with 16 / 12 wavefronts per block (30 spills / 140 registers: profiles/r06_ab_pack_scan.txt); 13 ring entries of 16
+ *       bytes that cover four steps instead of 8 bytes per two steps (half as many appends: measured 3 % slower, r06_ab_wide_entries.txt);
  *   [2] k > 0: minimum hypothesis batches per scoring block (default 8); pre-filter kernel: grid columns;
  *   [3] 1 AUTO never picks SFM_KERNEL_PREFILTER; 2 the round-2 pre-filter kernel (csrc/ab/ransac_prefilter_r2.hip);
  *       3 per-hypothesis records from the stand-alone kernel instead of the lane-solve kernel; 4 the G rule of rounds 2-4

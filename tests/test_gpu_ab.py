@@ -440,3 +440,16 @@ def test_per_hypothesis_records_still_equal_oracle(gpu_ab, n, H, thr):
     P.check_all(pair, scene2, q, H, n)
     pair.estimateE(p)
     P.check_all(pair, scene2, p, H, n)
+
+
+@pytest.mark.parametrize("n,H", [(4096, 32768), (3000, 20000), (900, 16385)])
+def test_wide_ring_entries_still_equal_oracle(gpu_ab, n, H):
+    """Recorded variant (reserved[1] = 13): ring entries of 16 bytes covering four 32-point steps (two conversions) instead of 8 bytes
+    per two steps -- half as many appends, measured 3 % slower (profiles/r06_ab_wide_entries.txt): every count, key, E, mask."""
+    scene = synth.two_view_scene(n, seed=14)
+    pair, _ = make_pair(S, gpu_ab, scene)
+    p = S.default_params(n, num_hypotheses=H, seed=8, kernel=S.KERNEL_PREFILTER)
+    p.reserved[1] = 13
+    pair.estimateE(p)
+    assert pair.last_launch()["kernel"] == S.KERNEL_PREFILTER
+    P.check_all(pair, scene, p, H, n)
