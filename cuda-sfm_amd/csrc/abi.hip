@@ -495,7 +495,7 @@ int sfm_pair_destroy(sfm_pair *p)
     if (p->ctx) { (void)hipSetDevice(p->ctx->device); (void)hipStreamSynchronize(p->ctx->stream); }
     void *bufs[] = { p->d_K, p->d_Kinv, p->d_U[0], p->d_U[1], p->d_X[0], p->d_X[1], p->d_pts4, p->d_E, p->d_P, p->d_Pinv, p->d_Pind,
                      p->d_points, p->d_mask, p->d_key, p->d_best, p->d_counts, p->d_Ecand, p->d_clk, p->d_tick,
-                     p->alt_counts, p->alt_Ecand, p->alt_tick, p->alt_key, p->d_pf, p->alt_pf, p->d_bound, p->d_cells, p->d_pts4s, p->d_tile_boxes };
+                     p->alt_counts, p->alt_Ecand, p->alt_tick, p->alt_key, p->d_pf, p->alt_pf, p->d_bound, p->d_cells, p->d_pts4s, p->d_tile_boxes, p->d_buckets };
     for (void *b : bufs) if (b) (void)hipFree(b);
     if (p->pipe_stream) { (void)hipStreamSynchronize(p->pipe_stream); (void)hipStreamDestroy(p->pipe_stream); }
     for (hipEvent_t e : p->pipe_final) if (e) (void)hipEventDestroy(e);

@@ -134,6 +134,8 @@ struct sfm_pair {
     float4 *d_pts4 = nullptr;          // (x1x, x1y, x2x, x2y) per correspondence, written by fillXU: ONE 16-byte gather per sampled point
     bool have_pts4 = false;            // d_pts4 describes the current points (fillXU with the unit-z layout)
     uint32_t sorted_epoch = 0;         // the fillXU epoch d_pts4s was built for
+    uint32_t *d_buckets = nullptr;     // scratch of the bucket ordering: per-block histograms + bucket bases (pf_bucket_*_kernel)
+    size_t bucket_words = 0;
     uint32_t *d_tile_boxes = nullptr;  // eight words per scoring tile of d_pts4s: ordered bits of its coordinate maxima (pf_tile_boxes_kernel)
     int boxes_cap = 0, boxes_tile = 0; // tiles allocated / the tile size the boxes were computed for
     float4 *d_pts4s = nullptr;         // the same records in Morton order of the first view's position (pre-filter scoring: tiles with small

@@ -310,7 +310,7 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
     uint32_t *next_idx = reinterpret_cast<uint32_t *>(smem + L.next);
     if (threadIdx.x == 0) *next_idx = (uint32_t)W;
     if (kPack && threadIdx.x < 32) smem[L.lut + threadIdx.x] = (unsigned char)pf_pack_code((int)threadIdx.x);
-    // tile rule: the pair's bound and this tile's boxes (pf_tile_boxes_kernel, once per fillXU) are requested now and used after the staging
+    // tile rule: the pair's bound and this tile's boxes (pf_bucket_scatter_kernel, once per fillXU) are requested now and used after the staging
     float pf_B = 0.0f;
     uint32_t bw[8] = {};
     uint32_t bw_lane = 0u;
@@ -800,6 +800,121 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
 #endif
 }
 
+// ---- the Morton-ordered copy of the correspondences (kPfRuleBandTile) -----------------------------------------------------------------
+// The scoring kernel's tiles are runs of THIS order, so that a tile's points sit in a small part of the first view (and, for the
+// inliers, of the second): the band rule's constant is a maximum over the tile's bounding boxes, and smaller boxes mean fewer pairs that
+// survive the matrix-core test (4096 points, 4 tiles: 1.30 % -> 1.05 %; 16384 points, 16 tiles: 1.21 % -> 0.78 % of the bench scenes).
+// Counts do not depend on the order of the points; the sampler, the finalize kernel and the mask keep the original order.
+// Only the tiles' MEMBERSHIP matters, not the order inside a tile, so this is a bucket ordering, not a sort: bucket = the top ten bits
+// of the Morton code of the first view's position (a 32 x 32 grid over its coordinate range); points without features (non-finite or
+// beyond the fp16 range) go into a bucket behind those, the NaN padding of the row behind everything.  The grid spans [-B, B]^2 (the
+// bound fillXU leaves), so the buckets need nothing the cell table's kernel computes and are counted BY that kernel: the whole
+// once-per-fillXU work is three launches (a bitonic sort of key << 32 | index in one block's LDS took 59 us at 4096 and 257 us at 16384
+// points -- more than a whole configs[2] step, paid by the first estimateE after every fillXU):
+//   pf_cells_build_kernel     the cell table, the views' coordinate ranges and, per 256-point block, the population of every bucket
+//   pf_bucket_scan_kernel     one block: per bucket, the running offsets of the point blocks and the bucket's base (exclusive scans);
+//                             the tiles' boxes reset to "empty"
+//   pf_bucket_scatter_kernel  every point to base[bucket] + offset[block][bucket] + (points of the same bucket in earlier wavefronts
+//                             of the block) + (in lower lanes of its wavefront): the position does not depend on execution order; and
+//                             the boxes of the tile it lands in (maxima in LDS per block, then one atomicMax per touched word)
+constexpr int kPfBuckets = 1024 + 2;           // Morton cells + "no features" + "padding"
+constexpr int kPfBucketBlock = 256;            // points per block of the histogram / scatter kernels
+
+__device__ __forceinline__ int pf_bucket_of(const float4 q, float B)      // a REAL point's bucket (the padding of the row is placed behind all of them)
+{
+    const float big = fmaxf(fmaxf(fabsf(q.x), fabsf(q.y)), fmaxf(fabsf(q.z), fabsf(q.w)));
+    if (!(big <= 48.0f) || q.x != q.x || q.y != q.y || q.z != q.z || q.w != q.w) return kPfBuckets - 2;      // prefilter_point_slots' own test, negated
+    return (int)(pf_morton_key(q.x, q.y, -B, B, -B, B) >> 20);
+}
+
+// hist[block][bucket] -> the number of the bucket's points in EARLIER blocks; base[bucket] = points in earlier buckets
+__global__ __launch_bounds__(1024)
+void pf_bucket_scan_kernel(uint32_t *__restrict__ hist, int nblocks, uint32_t *__restrict__ base, uint32_t *__restrict__ boxes, int nbox_words)
+{
+    for (int k = threadIdx.x; k < nbox_words; k += blockDim.x) boxes[k] = pf_order_bits(-INFINITY);       // "no point yet" (pf_box_from_bits: the whole range)
+    __shared__ uint32_t total[kPfBuckets + 1024];
+    for (int b = threadIdx.x; b < kPfBuckets; b += blockDim.x) {
+        uint32_t run = 0u;
+        for (int k = 0; k < nblocks; ++k) {
+            const uint32_t c = hist[(size_t)k * kPfBuckets + b];
+            hist[(size_t)k * kPfBuckets + b] = run;
+            run += c;
+        }
+        total[b] = run;
+    }
+    __syncthreads();
+    // exclusive scan of the 1024 Morton buckets' totals over the block (one per thread), the two special buckets behind them
+    __shared__ uint32_t wsum[17];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t mine = total[threadIdx.x];
+    uint32_t v = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t t = __shfl_up(v, off);
+        if (lane >= off) v += t;
+    }
+    if (lane == 63) wsum[wave] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t run = 0u;
+        for (int w = 0; w < 16; ++w) { const uint32_t c = wsum[w]; wsum[w] = run; run += c; }
+        wsum[16] = run;
+    }
+    __syncthreads();
+    base[threadIdx.x] = wsum[wave] + v - mine;
+    if (threadIdx.x == 0) { base[1024] = wsum[16]; base[1025] = wsum[16] + total[1024]; }
+}
+static_assert(kPfBuckets == 1026, "pf_bucket_scan_kernel: 1024 Morton buckets scanned by 1024 threads + two special ones");
+
+constexpr int kPfBoxTilesLds = 512;            // tiles whose boxes a scatter block reduces in LDS (16 KiB); beyond that: global atomics only
+__global__ __launch_bounds__(kPfBucketBlock)
+void pf_bucket_scatter_kernel(const float4 *__restrict__ pts4, int n, int ld, const unsigned long long *__restrict__ bound_word,
+                              const uint32_t *__restrict__ hist, const uint32_t *__restrict__ base, float4 *__restrict__ out,
+                              int tile, int ntiles, uint32_t *__restrict__ boxes)
+{
+    constexpr int kWaves = kPfBucketBlock / 64;
+    __shared__ unsigned short hw[kWaves][kPfBuckets];       // the bucket populations of each wavefront of this block
+    extern __shared__ uint32_t bx[];                         // min(ntiles, kPfBoxTilesLds) x 8 words: this block's share of the tiles' boxes
+    const int nlds = min(ntiles, kPfBoxTilesLds);
+    for (int k = threadIdx.x; k < kWaves * kPfBuckets; k += blockDim.x) (&hw[0][0])[k] = 0;
+    for (int k = threadIdx.x; k < nlds * 8; k += blockDim.x) bx[k] = pf_order_bits(-INFINITY);
+    __syncthreads();
+    const float B = __uint_as_float((uint32_t)(*bound_word & 0xFFFFFFFFull));
+    const int i = blockIdx.x * kPfBucketBlock + threadIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+    int bucket = -1;                                         // (the row's padding and beyond: takes no part in the ranking)
+    if (i < n) { q = pts4[i]; bucket = pf_bucket_of(q, B); }
+    // points of my bucket in lower lanes of my wavefront, and in the whole wavefront (its highest lane of the bucket records that)
+    int below = 0, same = 0;
+    for (int j = 0; j < 64; ++j) {
+        const int bj = __builtin_amdgcn_readlane(bucket, j);
+        below += (bj == bucket && j < lane) ? 1 : 0;
+        same += (bj == bucket) ? 1 : 0;
+    }
+    if (bucket >= 0 && below == same - 1) hw[wave][bucket] = (unsigned short)same;
+    __syncthreads();
+    if (i >= n) {
+        if (i < ld) out[i] = pts4[i];                        // the NaN padding keeps its place behind the n real points
+    } else {
+        uint32_t earlier = 0u;
+        for (int w = 0; w < wave; ++w) earlier += hw[w][bucket];
+        const uint32_t dest = base[bucket] + hist[(size_t)blockIdx.x * kPfBuckets + bucket] + earlier + (uint32_t)below;
+        out[dest] = q;
+        if (bucket != kPfBuckets - 2) {                      // it carries features: the box of the tile it lands in
+            const int t = (int)dest / tile;
+            const float ext[8] = { q.z, -q.z, q.w, -q.w, q.x, -q.x, q.y, -q.y };      // (x1x, x1y, x2x, x2y) = (u, v, x, y): maxima of x, -x, y, -y, u, -u, v, -v
+            uint32_t *w = t < nlds ? bx + 8 * t : boxes + 8 * (size_t)t;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) atomicMax(w + k, pf_order_bits(ext[k]));
+        }
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < nlds * 8; k += blockDim.x) {
+        const uint32_t v = bx[k];
+        if (v != pf_order_bits(-INFINITY)) atomicMax(boxes + k, v);
+    }
+}
+
 // ---- the pair's table of occupied grid cells (prefilter_math.hpp (3)) ----------------------------------------------------
 // One key per point that carries features (finite, |coordinates| <= 48): the cell of its second-view position on the grid
 // whose pitch follows the bound over all points.  Built once per fillXU (the first scoring launch that needs it), looked up
@@ -809,8 +924,14 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
 // maxima of (x2x, -x2x, x2y, -x2y, x1x, -x1x, x1y, -x1y), atomicMax like the bound itself (a newer epoch beats every older word).
 __global__ __launch_bounds__(256)
 void pf_cells_build_kernel(const float4 *__restrict__ pts4, int n, unsigned long long *__restrict__ bound_word,
-                           uint32_t *__restrict__ cells, uint32_t mask, uint32_t epoch)
+                           uint32_t *__restrict__ cells, uint32_t mask, uint32_t epoch, uint32_t *__restrict__ hist)
 {
+    static_assert(kPfBucketBlock == 256, "one histogram per block of this kernel");
+    __shared__ uint32_t bh[kPfBuckets];                     // tile rule: this block's bucket populations (hist == nullptr: not wanted)
+    if (hist) {
+        for (int b = threadIdx.x; b < kPfBuckets; b += blockDim.x) bh[b] = 0u;
+        __syncthreads();
+    }
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
     bool feat = false;
@@ -830,8 +951,14 @@ void pf_cells_build_kernel(const float4 *__restrict__ pts4, int n, unsigned long
 #pragma unroll
         for (int k = 0; k < 8; ++k) atomicMax(bound_word + 2 + k, ((unsigned long long)epoch << 32) | pf_order_bits(ext[k]));
     }
+    const float Bq = __uint_as_float((uint32_t)(*bound_word & 0xFFFFFFFFull));
+    if (hist) {
+        if (j < n) atomicAdd(&bh[pf_bucket_of(q, Bq)], 1u);
+        __syncthreads();
+        for (int b = threadIdx.x; b < kPfBuckets; b += blockDim.x) hist[(size_t)blockIdx.x * kPfBuckets + b] = bh[b];
+    }
     if (!feat) return;
-    const PfGrid grid = prefilter_grid(__uint_as_float((uint32_t)(*bound_word & 0xFFFFFFFFull)));
+    const PfGrid grid = prefilter_grid(Bq);
     // second-view cell (first divisor) and first-view cell (second divisor, keys flipped: pf_cell_key_side) in one table
 #pragma unroll
     for (int side = 0; side < 2; ++side) {
@@ -843,84 +970,6 @@ void pf_cells_build_kernel(const float4 *__restrict__ pts4, int n, unsigned long
             sl = (sl + 1) & mask;
         }
     }
-}
-
-// ---- the Morton-ordered copy of the correspondences (kPfRuleBandTile) -----------------------------------------------------------------
-// The scoring kernel's tiles are runs of THIS order, so that a tile's points sit in a small part of the first view (and, for the
-// inliers, of the second): the band rule's constant is a maximum over the tile's bounding boxes, and smaller boxes mean fewer pairs that
-// survive the matrix-core test (4096 points, 4 tiles: 1.30 % -> 1.05 %; 16384 points, 16 tiles: 1.21 % -> 0.78 % of the bench scenes).
-// Counts do not depend on the order of the points; the sampler, the finalize kernel and the mask keep the original order.
-// One block: keys (Morton code of the first view's position over its coordinate range << 32 | index) sorted in LDS by a bitonic network
-// (up to 16384 points: 128 KiB; beyond that the copy keeps the original order -- tiles with larger boxes, the same counts).  Points
-// without features (non-finite or beyond the fp16 range) go behind the others, the NaN padding of the row last.
-__global__ __launch_bounds__(1024)
-void pf_sort_kernel(const float4 *__restrict__ pts4, int ld, int np2, const unsigned long long *__restrict__ bound_word, float4 *__restrict__ out)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_sort[];
-    unsigned long long *sk = reinterpret_cast<unsigned long long *>(smem_sort);
-    const float B = __uint_as_float((uint32_t)(*bound_word & 0xFFFFFFFFull));
-    const PfBox box = pf_box_from_words(bound_word + 2, B);
-    for (int i = threadIdx.x; i < np2; i += blockDim.x) {
-        uint32_t key = 0xFFFFFFFFu;
-        if (i < ld) {
-            const float4 q = pts4[i];
-            const float big = fmaxf(fmaxf(fabsf(q.x), fabsf(q.y)), fmaxf(fabsf(q.z), fabsf(q.w)));
-            if (big <= 48.0f && q.x == q.x && q.y == q.y && q.z == q.z && q.w == q.w) key = pf_morton_key(q.x, q.y, box.ulo, box.uhi, box.vlo, box.vhi);
-        }
-        sk[i] = i < ld ? (((unsigned long long)key << 32) | (unsigned long long)(uint32_t)i) : ~0ull;
-    }
-    __syncthreads();
-    for (int k = 2; k <= np2; k <<= 1)
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = threadIdx.x; i < np2; i += blockDim.x) {
-                const int ixj = i ^ j;
-                if (ixj > i) {
-                    const unsigned long long a = sk[i], b = sk[ixj];
-                    const bool up = (i & k) == 0;
-                    if ((a > b) == up) { sk[i] = b; sk[ixj] = a; }
-                }
-            }
-            __syncthreads();
-        }
-    for (int i = threadIdx.x; i < ld; i += blockDim.x) out[i] = pts4[(uint32_t)(sk[i] & 0xFFFFFFFFull)];
-}
-
-// The bounding boxes of every tile of the ordered copy: ordered bits of the maxima of (x, -x, y, -y, u, -u, v, -v) over the tile's
-// feature-carrying points (eight words per tile; no such point: -inf, which pf_box_from_bits turns into the whole range).  One block per tile.
-__global__ __launch_bounds__(256)
-void pf_tile_boxes_kernel(const float4 *__restrict__ pts4s, int n, int tile, uint32_t *__restrict__ boxes)
-{
-    __shared__ uint32_t sw[8];
-    if (threadIdx.x < 8) sw[threadIdx.x] = pf_order_bits(-INFINITY);
-    __syncthreads();
-    float ext[8] = { -INFINITY, -INFINITY, -INFINITY, -INFINITY, -INFINITY, -INFINITY, -INFINITY, -INFINITY };
-    const int first = blockIdx.x * tile;
-    for (int t = threadIdx.x; t < tile && first + t < n; t += blockDim.x) {
-        const float4 q = pts4s[first + t];                      // (x1x, x1y, x2x, x2y) = (u, v, x, y)
-        const float big = fmaxf(fmaxf(fabsf(q.x), fabsf(q.y)), fmaxf(fabsf(q.z), fabsf(q.w)));
-        if (big <= 48.0f && q.x == q.x && q.y == q.y && q.z == q.z && q.w == q.w) {       // prefilter_point_slots' own test: the point carries features
-            ext[0] = fmaxf(ext[0], q.z); ext[1] = fmaxf(ext[1], -q.z); ext[2] = fmaxf(ext[2], q.w); ext[3] = fmaxf(ext[3], -q.w);
-            ext[4] = fmaxf(ext[4], q.x); ext[5] = fmaxf(ext[5], -q.x); ext[6] = fmaxf(ext[6], q.y); ext[7] = fmaxf(ext[7], -q.y);
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) ext[k] = fmaxf(ext[k], __shfl_xor(ext[k], off));
-    }
-    if ((threadIdx.x & 63) == 0) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) atomicMax(&sw[k], pf_order_bits(ext[k]));
-    }
-    __syncthreads();
-    if (threadIdx.x < 8) boxes[8 * blockIdx.x + threadIdx.x] = sw[threadIdx.x];
-}
-
-__global__ __launch_bounds__(256)
-void pf_copy_points_kernel(const float4 *__restrict__ pts4, int ld, float4 *__restrict__ out)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < ld) out[i] = pts4[i];
 }
 
 int launch_pf_cells(sfm_pair *pair, bool want_sorted, int tile)
@@ -942,35 +991,40 @@ int launch_pf_cells(sfm_pair *pair, bool want_sorted, int tile)
     }
     pair->cells_mask = slots - 1u;
     SFM_HIP_TRY(hipMemsetAsync(pair->d_cells, 0, (size_t)slots * sizeof(uint32_t), st));
-    hipLaunchKernelGGL(pf_cells_build_kernel, dim3((pair->n + 255) / 256), dim3(256), 0, st, pair->d_pts4, pair->n, pair->d_bound,
-                       pair->d_cells, pair->cells_mask, pair->bound_epoch);
+    const int nblk = (pair->n + kPfBucketBlock - 1) / kPfBucketBlock;              // point blocks of the cells / scatter kernels (real points)
+    uint32_t *hist = nullptr, *base = nullptr;
+    const int ntiles = want_sorted ? (pair->ld + tile - 1) / tile : 0;
+    if (want_sorted) {                                                               // scratch of the bucket ordering, the ordered copy, the tiles' boxes
+        const size_t words = (size_t)(nblk + 1) * kPfBuckets;
+        if (words > pair->bucket_words || ntiles > pair->boxes_cap || !pair->d_pts4s) {
+            SFM_HIP_TRY(hipStreamSynchronize(st));
+            if (words > pair->bucket_words) {
+                if (pair->d_buckets) (void)hipFree(pair->d_buckets);
+                pair->d_buckets = nullptr; pair->bucket_words = 0;
+                SFM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&pair->d_buckets), words * sizeof(uint32_t)));
+                pair->bucket_words = words;
+            }
+            if (ntiles > pair->boxes_cap) {
+                if (pair->d_tile_boxes) (void)hipFree(pair->d_tile_boxes);
+                pair->d_tile_boxes = nullptr; pair->boxes_cap = 0;
+                SFM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&pair->d_tile_boxes), (size_t)ntiles * 8 * sizeof(uint32_t)));
+                pair->boxes_cap = ntiles;
+            }
+            if (!pair->d_pts4s) SFM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&pair->d_pts4s), (size_t)pair->ld * sizeof(float4)));
+        }
+        hist = pair->d_buckets; base = pair->d_buckets + (size_t)nblk * kPfBuckets;
+    }
+    hipLaunchKernelGGL(pf_cells_build_kernel, dim3(nblk), dim3(kPfBucketBlock), 0, st, pair->d_pts4, pair->n, pair->d_bound,
+                       pair->d_cells, pair->cells_mask, pair->bound_epoch, hist);
     SFM_HIP_TRY(hipGetLastError());
-    // the Morton-ordered copy (behind the cells kernel: it reads the first view's coordinate range)
     if (want_sorted) {
-    pair->sorted_epoch = pair->bound_epoch;
-    if (!pair->d_pts4s) SFM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&pair->d_pts4s), (size_t)pair->ld * sizeof(float4)));
-    if (pair->ld <= 16384) {
-        int np2 = 64;
-        while (np2 < pair->ld) np2 <<= 1;
-        const int rc_lds = allow_big_lds(pair->ctx, reinterpret_cast<const void *>(&pf_sort_kernel));
-        if (rc_lds != SFM_OK) return rc_lds;
-        hipLaunchKernelGGL(pf_sort_kernel, dim3(1), dim3(1024), (size_t)np2 * 8, st, pair->d_pts4, pair->ld, np2, pair->d_bound, pair->d_pts4s);
-    } else {
-        hipLaunchKernelGGL(pf_copy_points_kernel, dim3((pair->ld + 255) / 256), dim3(256), 0, st, pair->d_pts4, pair->ld, pair->d_pts4s);
-    }
-    SFM_HIP_TRY(hipGetLastError());
-    // ... and its tiles' boxes (the tile size is a function of the row length, pf_tile_of)
-    const int ntiles = (pair->ld + tile - 1) / tile;
-    if (ntiles > pair->boxes_cap) {
-        SFM_HIP_TRY(hipStreamSynchronize(st));
-        if (pair->d_tile_boxes) (void)hipFree(pair->d_tile_boxes);
-        pair->d_tile_boxes = nullptr; pair->boxes_cap = 0;
-        SFM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&pair->d_tile_boxes), (size_t)ntiles * 8 * sizeof(uint32_t)));
-        pair->boxes_cap = ntiles;
-    }
-    hipLaunchKernelGGL(pf_tile_boxes_kernel, dim3(ntiles), dim3(256), 0, st, pair->d_pts4s, pair->n, tile, pair->d_tile_boxes);
-    SFM_HIP_TRY(hipGetLastError());
-    pair->boxes_tile = tile;
+        const int nlds = ntiles < kPfBoxTilesLds ? ntiles : kPfBoxTilesLds;
+        hipLaunchKernelGGL(pf_bucket_scan_kernel, dim3(1), dim3(1024), 0, st, hist, nblk, base, pair->d_tile_boxes, ntiles * 8);
+        hipLaunchKernelGGL(pf_bucket_scatter_kernel, dim3((pair->ld + kPfBucketBlock - 1) / kPfBucketBlock), dim3(kPfBucketBlock), (size_t)nlds * 8 * sizeof(uint32_t), st,
+                           pair->d_pts4, pair->n, pair->ld, pair->d_bound, hist, base, pair->d_pts4s, tile, ntiles, pair->d_tile_boxes);
+        SFM_HIP_TRY(hipGetLastError());
+        pair->sorted_epoch = pair->bound_epoch;
+        pair->boxes_tile = tile;
     }
     if (!pair->cells_ev) SFM_HIP_TRY(hipEventCreateWithFlags(&pair->cells_ev, hipEventDisableTiming));
     SFM_HIP_TRY(hipEventRecord(pair->cells_ev, st));

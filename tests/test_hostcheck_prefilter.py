@@ -566,7 +566,7 @@ def test_pack_survivor_table_against_a_model_of_the_conversion(H):
 
 
 def test_per_tile_boxes_in_morton_order_never_reject_an_inlier(H):
-    """The recorded per-tile variant (kPfRuleBandTile, lab bench): the scoring tiles are runs of the Morton order of the first view's
+    """The per-tile rule (kPfRuleBandTile, the product): the scoring tiles are runs of the Morton-bucket order of the first view's
     positions and the band's constant is a maximum over the TILE's boxes.  Every tile is a scene of its own for the rule (check_scene
     takes the boxes and the bound from the points it is given: the tile's own, smaller bound is the stricter test), so no oracle
     inlier may be rejected in any tile -- and the tiles' survivor rate is below the whole-view rule's."""
@@ -576,7 +576,7 @@ def test_per_tile_boxes_in_morton_order_never_reject_an_inlier(H):
     X0 = np.ascontiguousarray(X0[:, :n]); X1 = np.ascontiguousarray(X1[:, :n])
     ulo, uhi, vlo, vhi = [float(f) for f in (X0[0].min(), X0[0].max(), X0[1].min(), X0[1].max())]
     keys = np.array([H.hc_pf_morton_key(float(X0[0, j]), float(X0[1, j]), ulo, uhi, vlo, vhi) for j in range(n)], np.uint64)
-    order = np.argsort((keys << np.uint64(32)) | np.arange(n, dtype=np.uint64))
+    order = np.argsort(keys >> np.uint64(20), kind="stable")          # the device's bucket ordering: the top ten bits of the key, the original order inside a bucket
     Es = [O.hypothesis_E(X0, X1, O.sample8(0x5EED5F3D, h, n), 0) for h in range(60)]
     thr = np.float32(1e-6)
     whole = check_scene(H, X0[:, :tile], X1[:, :tile], Es, thr, rule="pack")      # one unsorted tile's worth of points with ITS boxes (~ the whole view's)
