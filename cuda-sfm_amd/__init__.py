@@ -45,6 +45,7 @@ if AB:
     KERNEL_MFMA = 3             # include/sfm_amd_ab.h
 QUIRK_MATCH_TAIL = 1
 QUIRK_MATCH_AMBIGUITY = 2
+PREFILTER_PER_HYPOTHESIS, PREFILTER_PER_TILE = 2, 3      # sfm_ransac_last_prefilter_rule
 MATCH_AUTO, MATCH_EXACT, MATCH_PREFILTER, MATCH_FUSED = 0, 1, 2, 3
 POSE_REFERENCE, POSE_CORRECT = 0, 1
 (BUF_X0, BUF_X1, BUF_U0, BUF_U1, BUF_E, BUF_P, BUF_PINV, BUF_POINTS, BUF_COUNTS, BUF_MASK, BUF_KEY,
@@ -69,7 +70,7 @@ EXPORTS = [
     "sfm_pair_device_ptr", "sfm_pair_ld", "sfm_pair_num_points", "sfm_get_XU", "sfm_get_E", "sfm_get_best",
     "sfm_get_key", "sfm_get_inlier_counts", "sfm_get_inlier_mask", "sfm_get_E_candidates",
     "sfm_get_pose_candidates", "sfm_get_pose_inverses", "sfm_get_pose_index", "sfm_get_points", "sfm_copy_points_to_vbo",
-    "sfm_ransac_last_launch", "sfm_ransac_last_clock", "sfm_process_pairs", "sfm_ctx_last_pairs_batched", "sfm_extract_views", "sfm_extract_views_u8",
+    "sfm_ransac_last_launch", "sfm_ransac_last_clock", "sfm_ransac_last_prefilter_rule", "sfm_process_pairs", "sfm_ctx_last_pairs_batched", "sfm_extract_views", "sfm_extract_views_u8",
 ]
 AB_EXPORTS = ["sfm_ransac_last_phases", "sfm_ransac_last_trace", "sfm_prefilter_probe", "sfm_prefilter_band_probe"]      # include/sfm_amd_ab.h
 if AB:
@@ -156,6 +157,7 @@ if AB:
 _lib.sfm_ctx_last_pairs_batched.argtypes = [_vp, C.POINTER(C.c_int)]
 _lib.sfm_ransac_last_launch.argtypes = [_vp] + [C.POINTER(C.c_int)] * 4
 _lib.sfm_ransac_last_clock.argtypes = [_vp, C.POINTER(C.c_double)]
+_lib.sfm_ransac_last_prefilter_rule.argtypes = [_vp, C.POINTER(C.c_int)]
 
 
 class SfmError(RuntimeError):
@@ -524,7 +526,9 @@ class ImagePair:
     def last_launch(self):
         v = [C.c_int() for _ in range(4)]
         _check(_lib.sfm_ransac_last_launch(self._h, *[C.byref(x) for x in v]), "sfm_ransac_last_launch")
-        return {"kernel": v[0].value, "grid": v[1].value, "block": v[2].value, "lds_bytes": v[3].value}
+        r = C.c_int()
+        _check(_lib.sfm_ransac_last_prefilter_rule(self._h, C.byref(r)), "sfm_ransac_last_prefilter_rule")
+        return {"kernel": v[0].value, "grid": v[1].value, "block": v[2].value, "lds_bytes": v[3].value, "prefilter_rule": r.value}
 
     def last_clock_mhz(self):
         v = C.c_double()

@@ -1474,4 +1474,12 @@ int sfm_ransac_last_launch(sfm_pair *pair, int *kernel, int *grid, int *block, i
     return SFM_OK;
 }
 
+int sfm_ransac_last_prefilter_rule(sfm_pair *pair, int *rule)
+{
+    SFM_REQUIRE(pair, SFM_E_INVALID, "null pair");
+    SFM_REQUIRE(rule, SFM_E_INVALID, "null rule");
+    *rule = pair->last_kernel == SFM_KERNEL_PREFILTER ? pair->pf_rule : 0;
+    return SFM_OK;
+}
+
 } // extern "C"

@@ -134,6 +134,8 @@ struct sfm_pair {
     float4 *d_pts4 = nullptr;          // (x1x, x1y, x2x, x2y) per correspondence, written by fillXU: ONE 16-byte gather per sampled point
     bool have_pts4 = false;            // d_pts4 describes the current points (fillXU with the unit-z layout)
     uint32_t sorted_epoch = 0;         // the fillXU epoch d_pts4s was built for
+    uint32_t pf_seen_epoch = 0;        // the fillXU epoch of the last pre-filter launch (the first launch of an epoch runs per-hypothesis records)
+    int pf_rule = 0;                   // the rule of the launch being issued (prefilter_pick_rule)
     uint32_t *d_buckets = nullptr;     // scratch of the bucket ordering: per-block histograms + bucket bases (pf_bucket_*_kernel)
     size_t bucket_words = 0;
     uint32_t *d_tile_boxes = nullptr;  // eight words per scoring tile of d_pts4s: ordered bits of its coordinate maxima (pf_tile_boxes_kernel)
@@ -202,7 +204,7 @@ int launch_ransac_finalize(sfm_pair *pair, const sfm_ransac_params &p, const uns
 int launch_permutation_indices(sfm_ctx *ctx, int n, uint32_t seed, int32_t *d_indices);
 // ransac_prefilter.hip
 bool prefilter_usable(const sfm_pair *pair, const sfm_ransac_params &p, uint32_t count);
-int prefilter_rule(const sfm_ransac_params &p);                                 // kPfRuleBandPack (the product) / kPfRuleBand, kPfRuleG (lab bench, reserved[3] == 5 / 4)
+int prefilter_pick_rule(sfm_pair *pair, const sfm_ransac_params &p, uint32_t count);   // the rule of this launch (kPfRuleBandTile / kPfRuleBandPack; lab bench: any), kept in pair->pf_rule
 int launch_score_prefilter(sfm_pair *pair, const sfm_ransac_params &p, uint32_t h0, uint32_t count, unsigned long long *key2);
 int launch_pf_prep(sfm_pair *pair, const sfm_ransac_params &p, uint32_t count);
 int prefilter_tile_points(const sfm_pair *pair, const sfm_ransac_params &p);      // points per scoring tile of a launch on this pair

@@ -65,13 +65,16 @@ void ransac_solve_lanes(const float *__restrict__ X0, const float *__restrict__ 
 // registers of the packed kernel below, so twice the hypotheses are in flight per SIMD and every wavefront walks a chain of plain
 // (not packed) instructions: the latency-bound regime -- shards of up to a few hundred thousand hypotheses, where the packed
 // kernel is one wavefront per SIMD stepping through ~4900 dependent instructions.
-__global__ __launch_bounds__(64)
-void ransac_solve_lanes1_qr(const float *__restrict__ X0, const float *__restrict__ X1, int ld, int n,
-                            const int32_t *__restrict__ indices, uint32_t seed, uint32_t h0, uint32_t count,
-                            int sweeps, float *__restrict__ Ecand, unsigned long long *zero_key, unsigned long long *zero_key2,
-                            int *__restrict__ zero_counts, uint32_t *__restrict__ zero_ticks, uint32_t nzero, const float4 *__restrict__ pts4,
-                            PfRecord *__restrict__ recs, float thr, PfScales sc, const unsigned long long *__restrict__ bound_word,
-                            const uint32_t *__restrict__ cells, uint32_t cells_mask, int rule)
+// TILE: the record of the per-tile rule (16 bytes); otherwise the per-hypothesis operands of the packed scan (64 bytes; lab bench:
+// of the rule `rule` names).  Two kernels below so that the tile rule's solve keeps its shorter code and register allocation.
+template <bool TILE>
+__device__ __forceinline__
+void solve_lanes1_qr_body(const float *__restrict__ X0, const float *__restrict__ X1, int ld, int n,
+                          const int32_t *__restrict__ indices, uint32_t seed, uint32_t h0, uint32_t count,
+                          int sweeps, float *__restrict__ Ecand, unsigned long long *zero_key, unsigned long long *zero_key2,
+                          int *__restrict__ zero_counts, uint32_t *__restrict__ zero_ticks, uint32_t nzero, const float4 *__restrict__ pts4,
+                          PfRecord *__restrict__ recs, float thr, PfScales sc, const unsigned long long *__restrict__ bound_word,
+                          const uint32_t *__restrict__ cells, uint32_t cells_mask, int rule)
 {
     reset_keys(zero_key, zero_key2);
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -112,15 +115,30 @@ void ransac_solve_lanes1_qr(const float *__restrict__ X0, const float *__restric
     // the operands of the matrix-core pre-filter for this hypothesis (prefilter_record.hpp), once for all tiles
     if (recs) {
         const float B = __uint_as_float((uint32_t)(*bound_word & 0xFFFFFFFFull));
+        if (TILE) reinterpret_cast<uint4 *>(recs)[i] = pf_tile_record(E, B, cells, cells_mask);        // sigma and the slots: per (hypothesis, tile), in the scoring kernel
 #if SFM_AB
-        if (rule == kPfRuleG) pf_prep_store(E, thr, B, sc, cells, cells_mask, recs + i);
-        else if (rule != kPfRuleBandTile) pf_band_prep_store(E, thr, B, pf_box_from_words(bound_word + 2, B), cells, cells_mask, recs + i, rule == kPfRuleBandPack ? kPfBandTopPack : kPfBandTop);
-        else
+        else if (rule == kPfRuleG) pf_prep_store(E, thr, B, sc, cells, cells_mask, recs + i);
+        else if (rule == kPfRuleBand) pf_band_prep_store(E, thr, B, pf_box_from_words(bound_word + 2, B), cells, cells_mask, recs + i, kPfBandTop);
 #endif
-        reinterpret_cast<uint4 *>(recs)[i] = pf_tile_record(E, B, cells, cells_mask);        // sigma and the slots: per (hypothesis, tile), in the scoring kernel
+        else pf_band_prep_store(E, thr, B, pf_box_from_words(bound_word + 2, B), cells, cells_mask, recs + i, kPfBandTopPack);
     }
+    (void)sc; (void)rule;
     SFM_PHASE("end");
 }
+
+#define SFM_SOLVE1_PARAMS const float *__restrict__ X0, const float *__restrict__ X1, int ld, int n, \
+                          const int32_t *__restrict__ indices, uint32_t seed, uint32_t h0, uint32_t count, \
+                          int sweeps, float *__restrict__ Ecand, unsigned long long *zero_key, unsigned long long *zero_key2, \
+                          int *__restrict__ zero_counts, uint32_t *__restrict__ zero_ticks, uint32_t nzero, const float4 *__restrict__ pts4, \
+                          PfRecord *__restrict__ recs, float thr, PfScales sc, const unsigned long long *__restrict__ bound_word, \
+                          const uint32_t *__restrict__ cells, uint32_t cells_mask, int rule
+#define SFM_SOLVE1_ARGS X0, X1, ld, n, indices, seed, h0, count, sweeps, Ecand, zero_key, zero_key2, zero_counts, zero_ticks, nzero, pts4, \
+                        recs, thr, sc, bound_word, cells, cells_mask, rule
+__global__ __launch_bounds__(64)
+void ransac_solve_lanes1_qr(SFM_SOLVE1_PARAMS) { solve_lanes1_qr_body<true>(SFM_SOLVE1_ARGS); }
+// ... writing per-hypothesis operands: the first estimateE after a fillXU (no ordered copy of the correspondences yet)
+__global__ __launch_bounds__(64)
+void ransac_solve_lanes1_qr_rec(SFM_SOLVE1_PARAMS) { solve_lanes1_qr_body<false>(SFM_SOLVE1_ARGS); }
 
 // Two hypotheses per lane (2i, 2i+1): every mul / add / fma of the solver is a v_pk_*_f32.
 template <bool QR>
@@ -413,7 +431,10 @@ int launch_ransac_score(sfm_pair *pair, const sfm_ransac_params &p, uint32_t h0,
     PfScales pf_sc = {};
     if (prefilter) (void)prefilter_scales(p.threshold, pf_sc);            // (checked by prefilter_usable)
     if (prefilter && !pf_r2) {                                            // the table of occupied cells the records are checked against
-        const int rcc = launch_pf_cells(pair, prefilter_rule(p) == kPfRuleBandTile, prefilter_tile_points(pair, p));
+        // which rule this call runs (per-tile constants over an ordered copy of the correspondences, or -- the first call after a
+        // fillXU -- per-hypothesis operands): decided once, remembered in the pair for the launches below
+        const int pf_rule = prefilter_pick_rule(pair, p, count);
+        const int rcc = launch_pf_cells(pair, pf_rule == kPfRuleBandTile, prefilter_tile_points(pair, p));
         if (rcc != SFM_OK) return rcc;
     }
     bool need_prep = prefilter && !pf_r2;
@@ -431,11 +452,12 @@ int launch_ransac_score(sfm_pair *pair, const sfm_ransac_params &p, uint32_t h0,
 #endif
     else if (p.jacobi_sweeps <= 0 && (SFM_SW(p, 0) == 3 || (SFM_SW(p, 0) == 0 && (pts4 != nullptr || count <= kScalarSolveMax)))) {     // one hypothesis per lane
         const bool fuse = need_prep && SFM_SW(p, 3) != 3;                // (AB build, reserved[3] == 3: records from the stand-alone kernel)
-        hipLaunchKernelGGL(ransac_solve_lanes1_qr, dim3((count + 63) / 64), dim3(64), 0, ctx->stream,
+        const bool tile_rec = !fuse || pair->pf_rule == kPfRuleBandTile;
+        hipLaunchKernelGGL(tile_rec ? ransac_solve_lanes1_qr : ransac_solve_lanes1_qr_rec, dim3((count + 63) / 64), dim3(64), 0, ctx->stream,
                            pair->d_X[0], pair->d_X[1], pair->ld, pair->n, p.d_indices, p.seed, h0, count,
                            p.jacobi_sweeps, pair->d_Ecand, pair->d_key, key2, zero_counts, zero_ticks, nzero, pts4,
                            fuse ? reinterpret_cast<PfRecord *>(pair->d_pf) : nullptr, p.threshold, pf_sc, pair->d_bound, pair->d_cells, pair->cells_mask,
-                           prefilter_rule(p));
+                           pair->pf_rule);
         if (fuse) need_prep = false;
     }
     else if (p.jacobi_sweeps <= 0)   // default: two hypotheses per lane (packed math), Householder instantiation

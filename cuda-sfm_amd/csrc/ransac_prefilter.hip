@@ -947,7 +947,7 @@ void pf_cells_build_kernel(const float4 *__restrict__ pts4, int n, unsigned long
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) ext[k] = fmaxf(ext[k], __shfl_xor(ext[k], off));
     }
-    if ((threadIdx.x & 63) == 0) {
+    if (cells && (threadIdx.x & 63) == 0) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) atomicMax(bound_word + 2 + k, ((unsigned long long)epoch << 32) | pf_order_bits(ext[k]));
     }
@@ -957,7 +957,7 @@ void pf_cells_build_kernel(const float4 *__restrict__ pts4, int n, unsigned long
         __syncthreads();
         for (int b = threadIdx.x; b < kPfBuckets; b += blockDim.x) hist[(size_t)blockIdx.x * kPfBuckets + b] = bh[b];
     }
-    if (!feat) return;
+    if (!feat || !cells) return;                            // (cells == nullptr: the table of this fillXU exists, only the histogram was wanted)
     const PfGrid grid = prefilter_grid(Bq);
     // second-view cell (first divisor) and first-view cell (second divisor, keys flipped: pf_cell_key_side) in one table
 #pragma unroll
@@ -975,26 +975,28 @@ void pf_cells_build_kernel(const float4 *__restrict__ pts4, int n, unsigned long
 int launch_pf_cells(sfm_pair *pair, bool want_sorted, int tile)
 {
     hipStream_t st = pair->ctx->stream;
-    if (pair->cells_epoch == pair->bound_epoch && pair->d_cells && (!want_sorted || (pair->sorted_epoch == pair->bound_epoch && pair->boxes_tile == tile))) {   // built for the current points
-        // ... possibly by a launch on another stream (the other slot of a pipelined burst): order this stream behind it
-        if (st != pair->cells_stream) SFM_HIP_TRY(hipStreamWaitEvent(st, pair->cells_ev, 0));
-        return SFM_OK;
+    const bool cells_ok = pair->cells_epoch == pair->bound_epoch && pair->d_cells;                                             // built for the current points
+    const bool order_ok = !want_sorted || (pair->sorted_epoch == pair->bound_epoch && pair->boxes_tile == tile && pair->d_pts4s);
+    // ... possibly by a launch on another stream (the other slot of a pipelined burst): order this stream behind it
+    if (cells_ok && st != pair->cells_stream) SFM_HIP_TRY(hipStreamWaitEvent(st, pair->cells_ev, 0));
+    if (cells_ok && order_ok) return SFM_OK;
+    if (!cells_ok) {
+        uint32_t slots = 4096;
+        while (slots < 8u * (uint32_t)pair->n) slots <<= 1;                              // two keys per point, load factor <= 1/4
+        if (slots > pair->cells_cap) {
+            SFM_HIP_TRY(hipStreamSynchronize(st));
+            if (pair->d_cells) (void)hipFree(pair->d_cells);
+            pair->d_cells = nullptr; pair->cells_cap = 0;
+            SFM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&pair->d_cells), (size_t)slots * sizeof(uint32_t)));
+            pair->cells_cap = slots;
+        }
+        pair->cells_mask = slots - 1u;
+        SFM_HIP_TRY(hipMemsetAsync(pair->d_cells, 0, (size_t)slots * sizeof(uint32_t), st));
     }
-    uint32_t slots = 4096;
-    while (slots < 8u * (uint32_t)pair->n) slots <<= 1;                                  // two keys per point, load factor <= 1/4
-    if (slots > pair->cells_cap) {
-        SFM_HIP_TRY(hipStreamSynchronize(st));
-        if (pair->d_cells) (void)hipFree(pair->d_cells);
-        pair->d_cells = nullptr; pair->cells_cap = 0;
-        SFM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&pair->d_cells), (size_t)slots * sizeof(uint32_t)));
-        pair->cells_cap = slots;
-    }
-    pair->cells_mask = slots - 1u;
-    SFM_HIP_TRY(hipMemsetAsync(pair->d_cells, 0, (size_t)slots * sizeof(uint32_t), st));
     const int nblk = (pair->n + kPfBucketBlock - 1) / kPfBucketBlock;              // point blocks of the cells / scatter kernels (real points)
     uint32_t *hist = nullptr, *base = nullptr;
     const int ntiles = want_sorted ? (pair->ld + tile - 1) / tile : 0;
-    if (want_sorted) {                                                               // scratch of the bucket ordering, the ordered copy, the tiles' boxes
+    if (!order_ok) {                                                                 // scratch of the bucket ordering, the ordered copy, the tiles' boxes
         const size_t words = (size_t)(nblk + 1) * kPfBuckets;
         if (words > pair->bucket_words || ntiles > pair->boxes_cap || !pair->d_pts4s) {
             SFM_HIP_TRY(hipStreamSynchronize(st));
@@ -1014,10 +1016,11 @@ int launch_pf_cells(sfm_pair *pair, bool want_sorted, int tile)
         }
         hist = pair->d_buckets; base = pair->d_buckets + (size_t)nblk * kPfBuckets;
     }
+    // (a table that exists is left alone -- launches of the other slot's stream may be reading it -- and the pass only counts buckets)
     hipLaunchKernelGGL(pf_cells_build_kernel, dim3(nblk), dim3(kPfBucketBlock), 0, st, pair->d_pts4, pair->n, pair->d_bound,
-                       pair->d_cells, pair->cells_mask, pair->bound_epoch, hist);
+                       cells_ok ? nullptr : pair->d_cells, pair->cells_mask, pair->bound_epoch, hist);
     SFM_HIP_TRY(hipGetLastError());
-    if (want_sorted) {
+    if (!order_ok) {
         const int nlds = ntiles < kPfBoxTilesLds ? ntiles : kPfBoxTilesLds;
         hipLaunchKernelGGL(pf_bucket_scan_kernel, dim3(1), dim3(1024), 0, st, hist, nblk, base, pair->d_tile_boxes, ntiles * 8);
         hipLaunchKernelGGL(pf_bucket_scatter_kernel, dim3((pair->ld + kPfBucketBlock - 1) / kPfBucketBlock), dim3(kPfBucketBlock), (size_t)nlds * 8 * sizeof(uint32_t), st,
@@ -1026,6 +1029,7 @@ int launch_pf_cells(sfm_pair *pair, bool want_sorted, int tile)
         pair->sorted_epoch = pair->bound_epoch;
         pair->boxes_tile = tile;
     }
+    // one event for whatever was built last: a stream that waits for it has waited for everything built before (each build waited itself)
     if (!pair->cells_ev) SFM_HIP_TRY(hipEventCreateWithFlags(&pair->cells_ev, hipEventDisableTiming));
     SFM_HIP_TRY(hipEventRecord(pair->cells_ev, st));
     pair->cells_stream = st;
@@ -1056,14 +1060,14 @@ int launch_pf_prep(sfm_pair *pair, const sfm_ransac_params &p, uint32_t count)
 {
     PfScales sc;
     if (!prefilter_scales(p.threshold, sc)) { set_error("threshold %g outside the pre-filter's range", (double)p.threshold); return SFM_E_INVALID; }
-    if (prefilter_rule(p) == kPfRuleBandTile)
+    if (pair->pf_rule == kPfRuleBandTile)
         hipLaunchKernelGGL(pf_prep_kernel<kPfRuleBandTile>, dim3((count + 255) / 256), dim3(256), 0, pair->ctx->stream,
                            pair->d_Ecand, count, p.threshold, sc, pair->d_bound, pair->d_cells, pair->cells_mask, reinterpret_cast<PfRecord *>(pair->d_pf));
-#if SFM_AB
-    else if (prefilter_rule(p) == kPfRuleBandPack)
+    else if (pair->pf_rule == kPfRuleBandPack)
         hipLaunchKernelGGL(pf_prep_kernel<kPfRuleBandPack>, dim3((count + 255) / 256), dim3(256), 0, pair->ctx->stream,
                            pair->d_Ecand, count, p.threshold, sc, pair->d_bound, pair->d_cells, pair->cells_mask, reinterpret_cast<PfRecord *>(pair->d_pf));
-    else if (prefilter_rule(p) == kPfRuleBand)
+#if SFM_AB
+    else if (pair->pf_rule == kPfRuleBand)
         hipLaunchKernelGGL(pf_prep_kernel<kPfRuleBand>, dim3((count + 255) / 256), dim3(256), 0, pair->ctx->stream,
                            pair->d_Ecand, count, p.threshold, sc, pair->d_bound, pair->d_cells, pair->cells_mask, reinterpret_cast<PfRecord *>(pair->d_pf));
     else
@@ -1239,20 +1243,39 @@ int launch_prefilter_probe(sfm_ctx *ctx, const float *d_E, float thr, float B, c
 // (which also leaves the bound over all points), a threshold the fp16 scaling covers, and enough work to fill the chip with
 // 512-hypothesis x 1024-point block iterations (measured crossover against the plain wavefront kernel at 4096 points:
 // between 16k and 32k hypotheses, profiles/r02_prefilter_ab.txt).
-// Which rule a call runs: the band rule with the packed scan (round 6); the lab-bench library keeps round 5's v_alignbit scan behind
-// reserved[3] == 5 (and for the recorded variants that were built on it: 12 wavefronts, 1536-point tiles, the 256-entry ring) and the
-// G rule of rounds 2-4 behind reserved[3] == 4 (and for the ticket epilogue, reserved[3] >= 16).
-int prefilter_rule(const sfm_ransac_params &p)
+// Which rule a call runs.  The lab-bench library keeps round 5's v_alignbit scan behind reserved[3] == 5 (and for the recorded variants
+// that were built on it: 12 wavefronts, 1536-point tiles, the 256-entry ring), the G rule of rounds 2-4 behind reserved[3] == 4 (and
+// for the ticket epilogue, reserved[3] >= 16), per-hypothesis operands for every call behind reserved[3] == 6, the tile rule for every
+// call behind reserved[3] == 7.
+static int pf_rule_switch(const sfm_ransac_params &p)      // lab bench: the rule a switch names, -1 = the product's choice
 {
     if (SFM_SW(p, 3) == 4 || SFM_SW(p, 3) >= 16) return kPfRuleG;
     if (SFM_SW(p, 3) == 5 || SFM_SW(p, 1) == 5 || SFM_SW(p, 1) == 7 || SFM_SW(p, 1) == 9) return kPfRuleBand;
-    // Per-tile band constants (Morton-ordered tiles, sigma and the coefficient slots derived per (hypothesis, tile) inside the scoring
-    // kernel, a 4-byte record per hypothesis): 19 % (4096 points) to 36 % (16384) fewer survivors, an 8 % shorter lane solve, 60 bytes
-    // less written per hypothesis; the step is 3.7 % (headline) to 5.3 % (16384 x 2^20) shorter than with per-hypothesis records and
-    // whole-view boxes (lab bench, reserved[3] == 6: profiles/r06_ab_tile_rule_fast.txt; with the exact, twice-as-long derivation of
-    // sigma the two were level: r06_ab_tile_rule.txt).
     if (SFM_SW(p, 3) == 6 || SFM_SW(p, 1) == 11 || SFM_SW(p, 1) == 12) return kPfRuleBandPack;
-    return kPfRuleBandTile;
+    if (SFM_SW(p, 3) == 7 || SFM_SW(p, 1) == 13) return kPfRuleBandTile;
+    return -1;
+}
+
+// The product's choice.  Per-tile band constants (tiles = runs of a Morton-ordered copy of the correspondences, sigma and the coefficient
+// slots derived per (hypothesis, tile) inside the scoring kernel, a 16-byte record per hypothesis): 19 % (4096 points) to 36 % (16384)
+// fewer survivors, an 8 % shorter lane solve, 48 bytes less written per hypothesis; the step is 3.7 % (headline) to 5.3 %
+// (16384 x 2^20) shorter than with per-hypothesis operands and whole-view boxes (profiles/r06_ab_tile_rule_fast.txt).  The ordered copy
+// and the tiles' boxes cost three short launches per fillXU (~35 us of a stream's time with the cold solve behind them,
+// profiles/r06_fresh_pair_cost.txt), more than they save a single call below 2^33 pairs: the FIRST call after a fillXU runs the packed
+// scan on per-hypothesis operands (whole-view boxes: nothing to build but the cell table) unless it is that large; a second call
+// on the same points builds the order and every later one uses it.
+constexpr uint64_t kPfOrderFirstCallPairs = 1ull << 33;
+int prefilter_pick_rule(sfm_pair *pair, const sfm_ransac_params &p, uint32_t count)
+{
+    int rule = pf_rule_switch(p);
+    if (rule < 0) {
+        const bool ordered = pair->sorted_epoch == pair->bound_epoch && pair->d_pts4s != nullptr;
+        const bool first = pair->pf_seen_epoch != pair->bound_epoch;
+        rule = (!ordered && first && (uint64_t)count * (uint64_t)pair->ld < kPfOrderFirstCallPairs) ? kPfRuleBandPack : kPfRuleBandTile;
+    }
+    pair->pf_seen_epoch = pair->bound_epoch;
+    pair->pf_rule = rule;
+    return rule;
 }
 
 bool prefilter_usable(const sfm_pair *pair, const sfm_ransac_params &p, uint32_t count)
@@ -1265,7 +1288,7 @@ bool prefilter_usable(const sfm_pair *pair, const sfm_ransac_params &p, uint32_t
 // points per tile of a launch on this pair (AB build, reserved[1] == 7: up to 1536 points with the band rule)
 static int pf_tile_of(const sfm_pair *pair, const sfm_ransac_params &p)
 {
-    if (SFM_SW(p, 1) == 7 && prefilter_rule(p) == kPfRuleBand) return pf_tile_points(pair->ld, 1536);
+    if (SFM_SW(p, 1) == 7 && pair->pf_rule == kPfRuleBand) return pf_tile_points(pair->ld, 1536);
     return pf_tile_points(pair->ld, kPfTileMax);
 }
 
@@ -1294,7 +1317,7 @@ int launch_score_prefilter(sfm_pair *pair, const sfm_ransac_params &p, uint32_t 
     if (cols < 1) cols = 1;
     const int dynamic = SFM_SW(p, 1) == 2 ? 0 : 1;                               // (AB build, reserved[1] == 2: static striding)
     const int var = SFM_SW(p, 3) >= 16 ? SFM_SW(p, 3) - 16 : 0;                 // (AB build, reserved[3] = 16 + VAR bits)
-    const int rule = prefilter_rule(p);
+    const int rule = pair->pf_rule;
     const bool fl2 = rule == kPfRuleBand && waves == kPfWaves && SFM_SW(p, 1) == 9;      // (AB build: 256-entry ring, two entries per lane per flush)
     const bool wide = rule == kPfRuleBandTile && SFM_SW(p, 1) == 13;                     // (AB build: 16-byte ring entries covering four steps)
     const int lds_bytes = wide ? PfLds<kPfRuleBand>(tile, kPfRing, 16).bytes : fl2 ? PfLds<kPfRuleBand>(tile, 256).bytes : rule != kPfRuleG ? PfLds<kPfRuleBand>(tile).bytes : PfLds<kPfRuleG>(tile).bytes;
@@ -1318,11 +1341,11 @@ int launch_score_prefilter(sfm_pair *pair, const sfm_ransac_params &p, uint32_t 
     else if (rule == kPfRuleBand) rcl = launch(&ransac_score_prefilter<16, 0, kPfRuleBand>);
     else if (SFM_SW(p, 1) == 11) rcl = launch(&ransac_score_prefilter<16, 0, kPfRuleBandPack, 0, 1>);
     else if (SFM_SW(p, 1) == 12) rcl = launch(&ransac_score_prefilter<12, 0, kPfRuleBandPack, 0, 1>);
-    else if (rule == kPfRuleBandPack) rcl = launch(&ransac_score_prefilter<16, 0, kPfRuleBandPack>);
     else if (wide) rcl = launch(&ransac_score_prefilter<16, 0, kPfRuleBandTile, 0, 0, 1>);
     else
 #endif
-    rcl = launch(&ransac_score_prefilter<16, 0, kPfRuleBandTile>);
+    if (rule == kPfRuleBandPack) rcl = launch(&ransac_score_prefilter<16, 0, kPfRuleBandPack>);
+    else rcl = launch(&ransac_score_prefilter<16, 0, kPfRuleBandTile>);
     (void)var; (void)fl2; (void)wide;
     if (rcl != SFM_OK) return rcl;
     SFM_HIP_TRY(hipGetLastError());

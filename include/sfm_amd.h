@@ -362,6 +362,14 @@ int sfm_ctx_last_pairs_batched(sfm_ctx *ctx, int *batched);
 int sfm_copy_points_to_vbo(sfm_pair *pair, float *d_positions, float *d_velocities, float scale);
 /* Name and launch geometry of the RANSAC scoring kernel used by the last call (for profiling). */
 int sfm_ransac_last_launch(sfm_pair *pair, int *kernel, int *grid, int *block, int *lds_bytes);
+/* Which form of the matrix-core pre-filter the last scoring launch ran (SFM_KERNEL_PREFILTER; 0 otherwise):
+ * SFM_PREFILTER_PER_HYPOTHESIS -- operands per hypothesis, bounded over the whole views: the FIRST launch after a fillXU below 2^33
+ * (hypothesis, correspondence) pairs, which would not earn back the ordering of the correspondences;
+ * SFM_PREFILTER_PER_TILE -- operands per (hypothesis, tile) over a Morton-ordered copy of the correspondences, built by the first
+ * launch that uses it and kept until the next fillXU.  Both give the same counts, keys and E bit for bit. */
+#define SFM_PREFILTER_PER_HYPOTHESIS 2
+#define SFM_PREFILTER_PER_TILE 3
+int sfm_ransac_last_prefilter_rule(sfm_pair *pair, int *rule);
 /* Sustained shader clock (MHz) during the last scoring launch (SFM_KERNEL_SPLIT / _PREFILTER): shader-clock ticks over
  * 100 MHz ticks across the lifetime of its first block; 0 if that kernel has not run.  Synchronises. */
 int sfm_ransac_last_clock(sfm_pair *pair, double *shader_mhz);

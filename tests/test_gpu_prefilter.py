@@ -12,29 +12,86 @@ from helpers import same_bits, to_dev, make_pair, crafted_candidates, lattice_po
 pytestmark = pytest.mark.gpu
 
 
-def check_all(pair, scene, p, H, n):
-    _, _, X0, X1 = O.fill_xu(scene["sift"], scene["Kinv"])
-    key, ocounts, oE = O.ransac_range(X0, X1, 0, H, p.threshold, p.jacobi_sweeps, seed=p.seed, want_E=True)
+def check_all(pair, scene, p, H, n, want=None):
+    """Every count, the key, the winner, its E and mask against the oracle; returns the oracle's results for a second check."""
+    if want is None:
+        _, _, X0, X1 = O.fill_xu(scene["sift"], scene["Kinv"])
+        key, ocounts, oE = O.ransac_range(X0, X1, 0, H, p.threshold, p.jacobi_sweeps, seed=p.seed, want_E=True)
+        ocnt, ohyp = O.unpack_key(key)
+        want = (key, ocounts, oE[ohyp].reshape(3, 3), O.count_inliers(oE[ohyp], X0, X1, p.threshold)[1])
+    key, ocounts, oEbest, omask = want
     counts = pair.get_inlier_counts(H)
     bad = np.flatnonzero(counts != ocounts)
     assert bad.size == 0, f"{bad.size} counts differ, first: hyp {bad[:5]} gpu {counts[bad[:5]]} oracle {ocounts[bad[:5]]}"
     assert pair.get_key() == key
     ocnt, ohyp = O.unpack_key(key)
     assert pair.get_best() == (ohyp, ocnt)
-    assert same_bits(pair.get_E(), oE[ohyp].reshape(3, 3))
-    assert np.array_equal(pair.get_inlier_mask(), O.count_inliers(oE[ohyp], X0, X1, p.threshold)[1])
+    assert same_bits(pair.get_E(), oEbest)
+    assert np.array_equal(pair.get_inlier_mask(), omask)
+    return want
+
+
+def estimate_both_forms(pair, scene, p, H, n):
+    """estimateE twice on a pair fresh from fillXU: per-hypothesis operands, then per-tile operands; everything against the oracle."""
+    pair.estimateE(p)
+    assert pair.last_launch()["kernel"] == S.KERNEL_PREFILTER and pair.last_launch()["prefilter_rule"] == S.PREFILTER_PER_HYPOTHESIS
+    want = check_all(pair, scene, p, H, n)
+    pair.estimateE(p)
+    assert pair.last_launch()["kernel"] == S.KERNEL_PREFILTER and pair.last_launch()["prefilter_rule"] == S.PREFILTER_PER_TILE
+    check_all(pair, scene, p, H, n, want)
 
 
 @pytest.mark.parametrize("n,H", [(1024, 16384), (1000, 20000), (4096, 32768), (4500, 17000), (700, 16385), (2048, 65536),
                                  (1500, 20000), (2000, 40000), (3000, 40000), (7000, 40000), (9000, 20000), (12345, 16384),   # 2, 2, 3, 7, 9, 13 tiles (round 6: a box with a wrong sign showed at 3 and 7 tiles only, profiles/r06_tile_boxes_debug.txt)
                                  (70000, 16384), (270000, 16384)])      # 69 tiles (3 grid columns); 264 tiles: more tiles than CUs, one column
 def test_prefilter_counts_equal_oracle(gpu, n, H):
+    """Both forms of the kernel: the first call after a fillXU runs per-hypothesis operands, the second builds the ordered copy of the
+    correspondences and runs per-tile operands (sfm_ransac_last_prefilter_rule says which)."""
     scene = synth.two_view_scene(n, seed=200 + n)
     pair, _ = make_pair(S, gpu, scene)
     p = S.default_params(n, num_hypotheses=H, seed=n + 1, kernel=S.KERNEL_PREFILTER)
-    pair.estimateE(p)
-    assert pair.last_launch()["kernel"] == S.KERNEL_PREFILTER
-    check_all(pair, scene, p, H, n)
+    estimate_both_forms(pair, scene, p, H, n)
+
+
+def test_prefilter_form_follows_the_fillXU_epoch(gpu):
+    """Per-hypothesis operands for the first call after every fillXU, per-tile operands from the second on -- also when the calls
+    are pipelined on two streams (the second call builds the order on ITS stream while the first may still be scoring) -- and from the
+    first call on when that call alone is worth the ordering (2^33 pairs)."""
+    torch, dev, ctx = gpu
+    n, H = 3000, 40000
+    scene = synth.two_view_scene(n, seed=77)
+    pair, d_sift = make_pair(S, gpu, scene)
+    ps = [S.default_params(n, num_hypotheses=H, seed=s, kernel=S.KERNEL_PREFILTER) for s in (5, 6, 7)]
+    wants = []
+    for k, p in enumerate(ps):
+        pair.estimateE(p)
+        assert pair.last_launch()["prefilter_rule"] == (S.PREFILTER_PER_HYPOTHESIS if k == 0 else S.PREFILTER_PER_TILE)
+        wants.append(check_all(pair, scene, p, H, n))
+    for rounds in range(3):                                          # fillXU starts a new epoch: per-hypothesis again, then the order is rebuilt
+        pair.fillXU(d_sift)
+        for k in range(3):
+            p = ps[(k + rounds) % 3]
+            pair.estimateE(p)
+            assert pair.last_launch()["prefilter_rule"] == (S.PREFILTER_PER_HYPOTHESIS if k == 0 else S.PREFILTER_PER_TILE)
+            check_all(pair, scene, p, H, n, wants[(k + rounds) % 3])
+    for first in range(3):                                           # pipelined: slot 0 per hypothesis, slot 1 builds the order and runs per tile, ...
+        for upto in (1, 2, 3):
+            pair.fillXU(d_sift)
+            for k in range(upto):
+                pair.estimateE_pipelined(ps[(first + k) % 3])
+            assert pair.last_launch()["prefilter_rule"] == (S.PREFILTER_PER_HYPOTHESIS if upto == 1 else S.PREFILTER_PER_TILE)
+            key, _, oE, omask = wants[(first + upto - 1) % 3]       # (the counts of a slot are not readable through the pair: winner, E and mask)
+            ocnt, ohyp = O.unpack_key(key)
+            assert pair.get_best() == (ohyp, ocnt) and same_bits(pair.get_E(), oE) and np.array_equal(pair.get_inlier_mask(), omask), (first, upto)
+    # a first call of 2^33 pairs: per tile at once; every count equal to the plain kernel's
+    n2, H2 = 4096, 1 << 21
+    scene2 = synth.two_view_scene(n2, seed=78)
+    pair2, _ = make_pair(S, gpu, scene2)
+    pair2.estimateE(S.default_params(n2, num_hypotheses=H2, seed=3, kernel=S.KERNEL_SPLIT))
+    ref = (pair2.get_inlier_counts(H2).copy(), pair2.get_key(), pair2.get_E().copy())
+    pair2.estimateE(S.default_params(n2, num_hypotheses=H2, seed=3, kernel=S.KERNEL_PREFILTER))
+    assert pair2.last_launch()["prefilter_rule"] == S.PREFILTER_PER_TILE
+    assert np.array_equal(pair2.get_inlier_counts(H2), ref[0]) and pair2.get_key() == ref[1] and same_bits(pair2.get_E(), ref[2])
 
 
 @pytest.mark.parametrize("thr", [1e-8, 1e-7, 1e-5, 1e-4, 1e-3])
@@ -43,9 +100,7 @@ def test_prefilter_thresholds(gpu, thr):
     scene = synth.two_view_scene(n, seed=17)
     pair, _ = make_pair(S, gpu, scene)
     p = S.default_params(n, num_hypotheses=H, seed=5, kernel=S.KERNEL_PREFILTER, threshold=thr)
-    pair.estimateE(p)
-    assert pair.last_launch()["kernel"] == S.KERNEL_PREFILTER
-    check_all(pair, scene, p, H, n)
+    estimate_both_forms(pair, scene, p, H, n)
 
 
 @pytest.mark.parametrize("focal,noise", [(300.0, 0.5), (1200.0, 0.1), (2360.0, 0.0), (8000.0, 1.0)])
@@ -55,8 +110,7 @@ def test_prefilter_fields_of_view(gpu, focal, noise):
     scene = synth.two_view_scene(n, seed=23, focal=focal, noise_px=noise)
     pair, _ = make_pair(S, gpu, scene)
     p = S.default_params(n, num_hypotheses=H, seed=9, kernel=S.KERNEL_PREFILTER)
-    pair.estimateE(p)
-    check_all(pair, scene, p, H, n)
+    estimate_both_forms(pair, scene, p, H, n)
 
 
 @pytest.mark.parametrize("focal", [4.0, 9.0])
@@ -68,9 +122,7 @@ def test_prefilter_coordinates_beyond_the_fp16_feature_range(gpu, focal):
     scene = synth.two_view_scene(n, seed=3, focal=focal, noise_px=0.01)
     pair, _ = make_pair(S, gpu, scene)
     p = S.default_params(n, num_hypotheses=H, seed=2, kernel=S.KERNEL_PREFILTER, threshold=1e-3)
-    pair.estimateE(p)
-    assert pair.last_launch()["kernel"] == S.KERNEL_PREFILTER
-    check_all(pair, scene, p, H, n)
+    estimate_both_forms(pair, scene, p, H, n)
 
 
 def test_prefilter_with_the_jacobi_solver_and_explicit_tuples(gpu):
@@ -81,8 +133,7 @@ def test_prefilter_with_the_jacobi_solver_and_explicit_tuples(gpu):
     scene = synth.two_view_scene(n, seed=12)
     pair, _ = make_pair(S, gpu, scene)
     p = S.default_params(n, num_hypotheses=H, seed=4, kernel=S.KERNEL_PREFILTER, jacobi_sweeps=7)
-    pair.estimateE(p)
-    check_all(pair, scene, p, H, n)
+    estimate_both_forms(pair, scene, p, H, n)
     rng = np.random.default_rng(1)
     idx = np.stack([rng.choice(n, 8, replace=False) for _ in range(H)]).astype(np.int32).reshape(-1)
     d_idx = torch.from_numpy(idx).to(dev)
@@ -158,10 +209,12 @@ def test_prefilter_supplied_candidates_and_zero_divisors(gpu, n, scale, thr):
         zero_div_inliers += c
     assert zero_div_inliers > 0, "the crafted set should hold inliers that only the zero-divisor guard keeps"
     res = {}
-    for kernel in (S.KERNEL_PREFILTER, S.KERNEL_SPLIT):
+    for kernel in (S.KERNEL_PREFILTER, S.KERNEL_PREFILTER, S.KERNEL_SPLIT):        # (the pre-filter twice: per-hypothesis, then per-tile operands)
         p = S.default_params(n, num_hypotheses=H, kernel=kernel, threshold=thr)
         pair.ransac_score_candidates(p, d_E)
         assert pair.last_launch()["kernel"] == kernel
+        if kernel == S.KERNEL_PREFILTER:
+            assert pair.last_launch()["prefilter_rule"] == (S.PREFILTER_PER_TILE if kernel in res else S.PREFILTER_PER_HYPOTHESIS)
         res[kernel] = (pair.get_inlier_counts(H).copy(), pair.get_key())
         bad = np.flatnonzero(res[kernel][0] != ocounts)
         assert bad.size == 0, f"kernel {kernel}: {bad.size} counts differ, first: hyp {bad[:8]} kinds {bad[:8] % 16} gpu {res[kernel][0][bad[:8]]} oracle {ocounts[bad[:8]]}"
@@ -209,7 +262,7 @@ def test_prefilter_keeps_inliers_whose_feature_is_an_fp16_tie(gpu, case):
         want, mask = O.count_inliers(E, X0[:, :n], X1[:, :n], np.float32(thr))
         assert want >= 1 and mask[at]
         d_E = to_dev(torch, dev, np.repeat(E.reshape(1, 9), 64, 0).reshape(-1))
-        for kernel in (S.KERNEL_PREFILTER, S.KERNEL_SPLIT):
+        for kernel in (S.KERNEL_PREFILTER, S.KERNEL_PREFILTER, S.KERNEL_SPLIT):    # (per-hypothesis, then per-tile operands)
             p = S.default_params(n, num_hypotheses=64, kernel=kernel, threshold=thr)
             pair.ransac_score_candidates(p, d_E)
             assert pair.last_launch()["kernel"] == kernel
