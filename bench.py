@@ -1157,6 +1157,9 @@ def rank_main(args):
                                        rule=reserved_rule(args.reserved)),
             "result": {"best_hypothesis": hyp, "inliers": cnt, "mask_sum": mask_sum, "sampler_seed_of_this_result": last_seed},
         }
+        # which form of the pre-filter the timed steps ran (the first call after a fillXU runs per-hypothesis operands; the wake-up and warm-up
+        # steps come before the timed region, so the timed steps run per-tile operands): sfm_ransac_last_prefilter_rule
+        out["roofline"]["operands"] = {2: "per hypothesis (whole-view boxes)", 3: "per (hypothesis, tile) over the ordered copy"}.get(launch.get("prefilter_rule"))
         if agree is not None:
             out["result"]["multi_gpu"] = agree
         if variant is not None:

@@ -10,6 +10,11 @@ sh profiles/pmc_pf.sh ${TAG}_c4 --config c4 > /dev/null 2>&1
 sh profiles/pmc_pf.sh ${TAG}_rank8 --hyps 131072 > /dev/null 2>&1
 python3 profiles/make_traffic_json.py $O/pmc_${TAG}_headline_summary.txt > $O/${TAG}_traffic.json
 cp $O/${TAG}_traffic.json profiles/${TAG}_traffic.json          # (so that the bench lines below quote it; commit the copy)
+# 1b. matcher counters on the current kernels (2048^2: exact fp32 MFMA; 16384^2: fp16 pre-filter + exact candidates)
+sh profiles/pmc_match.sh 2048 > $O/pmc_${TAG}_match_2048_summary.txt 2>&1
+sh profiles/pmc_match.sh 16384 > $O/pmc_${TAG}_match_16384_summary.txt 2>&1
+python3 profiles/make_match_traffic_json.py 2048:$O/pmc_${TAG}_match_2048_summary.txt 16384:$O/pmc_${TAG}_match_16384_summary.txt > $O/${TAG}_match_traffic.json
+cp $O/${TAG}_match_traffic.json profiles/${TAG}_match_traffic.json
 # 2. bench lines: the default command (headline + cpu_baseline + variants + extra configs), serial steps, a rank's share, c3, c4, c5
 python3 bench.py > $O/${TAG}_bench_line.json 2> $O/${TAG}_bench.err
 python3 bench.py --serial --no-cpu --no-extra > $O/${TAG}_bench_line_serial.json 2>> $O/${TAG}_bench.err
@@ -27,11 +32,9 @@ bash profiles/r06_pack_scan_ab.sh > $O/${TAG}_ab_pack_scan_final.txt 2>&1
 # 4. stand-alone benches of the neighbouring rows
 MATCH_SIZES=1200,2048,3000,4096,5500,8192,16384 python3 profiles/match_bench.py > $O/${TAG}_match_bench.txt 2>/dev/null
 python3 profiles/small_h_bench.py > $O/${TAG}_small_h_bench.txt 2>/dev/null
+python3 profiles/fresh_pair_cost.py > $O/${TAG}_fresh_pair_cost.txt 2>/dev/null
+sh profiles/fresh_pair_timeline.sh > $O/${TAG}_fresh_pair_timeline.txt 2>&1
 { sh profiles/c1_timeline.sh 1024; sh profiles/c1_timeline.sh 269; } > $O/${TAG}_c1_timeline.txt 2>&1
-# 4b. matcher counters on the current kernels (2048^2: exact fp32 MFMA; 16384^2: fp16 pre-filter + exact candidates)
-sh profiles/pmc_match.sh 2048 > $O/pmc_${TAG}_match_2048_summary.txt 2>&1
-sh profiles/pmc_match.sh 16384 > $O/pmc_${TAG}_match_16384_summary.txt 2>&1
-python3 profiles/make_match_traffic_json.py 2048:$O/pmc_${TAG}_match_2048_summary.txt 16384:$O/pmc_${TAG}_match_16384_summary.txt > $O/${TAG}_match_traffic.json
 # 5. rocprof: kernel stats of the bench command (serial steps: one kernel at a time), c3, c4 and a rank's share; pipelined steps
 cd /tmp && export TMPDIR=/tmp
 for cfg in "headline:" "c3:--config c3" "c4:--config c4 --steps 30 --warmup 5" "rank8:--hyps 131072"; do

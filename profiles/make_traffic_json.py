@@ -22,10 +22,15 @@ for block in re.split(r"\n(?=sfm::)", text):
     if not name:
         continue
     vals = {m.group(1): float(m.group(2)) for m in re.finditer(r"^\s+(\w+)\s+(\d+) per launch", block, re.M)}
+    launches = max([int(m.group(1)) for m in re.finditer(r"\((\d+) launches\)", block)] or [0])
     key = name.split("<")[0]
-    if key not in ("ransac_score_prefilter", "ransac_solve_lanes2", "ransac_solve_lanes1_qr", "ransac_score_waves"):
+    # the scoring kernel's two forms: the first call after a fillXU runs per-hypothesis operands (<16, 0, 2, ...> with
+    # ransac_solve_lanes1_qr_rec), all later steps the tile form (<16, 0, 3, ...>): the latter is what the bench times
+    if key == "ransac_score_prefilter" and re.match(r"ransac_score_prefilter<16, 0, 2\b", name):
+        key = "ransac_score_prefilter_per_hypothesis_form"
+    if key not in ("ransac_score_prefilter", "ransac_score_prefilter_per_hypothesis_form", "ransac_solve_lanes2", "ransac_solve_lanes1_qr", "ransac_solve_lanes1_qr_rec", "ransac_score_waves"):
         continue
-    e = {"matches": matches, "hypotheses": hyps, "fetch_kb": vals.get("FETCH_SIZE"), "write_kb": vals.get("WRITE_SIZE"),
+    e = {"kernel": name, "launches_profiled": launches, "matches": matches, "hypotheses": hyps, "fetch_kb": vals.get("FETCH_SIZE"), "write_kb": vals.get("WRITE_SIZE"),
          "valu_insts_per_launch": vals.get("SQ_INSTS_VALU"), "salu_insts_per_launch": vals.get("SQ_INSTS_SALU"), "lds_insts_per_launch": vals.get("SQ_INSTS_LDS")}
     cyc = vals.get("GRBM_GUI_ACTIVE", 0.0) / 8.0
     if cyc > 0:
