@@ -1,6 +1,7 @@
 """Full-size parity soak of the matrix-core pre-filter: random scenes (field of view, noise, outliers, forward motion with
 correspondences on the epipole, duplicated points), 1100..14000 matches x 2^18 hypotheses each, EVERY count of
-SFM_KERNEL_PREFILTER against SFM_KERNEL_SPLIT (which the test-suite pins to the oracle), plus key / E / mask.
+SFM_KERNEL_PREFILTER -- both forms: the first call after the fillXU scores with per-hypothesis operands, the second with per-tile operands
+over the ordered copy -- against SFM_KERNEL_SPLIT (which the test-suite pins to the oracle), plus key / E / mask.
     python profiles/prefilter_soak.py [seconds] [seed]"""
 import json
 import os
@@ -45,16 +46,19 @@ while time.time() < t_end:
     pair = S.ImagePair(ctx, sc["K"], sc["Kinv"], 2, n)
     pair.fillXU(d_sift)
     res = []
-    for kernel in (S.KERNEL_SPLIT, S.KERNEL_PREFILTER):
+    for kernel in (S.KERNEL_SPLIT, S.KERNEL_PREFILTER, S.KERNEL_PREFILTER):
         p = S.default_params(n, num_hypotheses=H, seed=seed & 0xFFFF, kernel=kernel, threshold=thr, jacobi_sweeps=int(rng.choice([0, 0, 7])) if kernel == S.KERNEL_SPLIT else res_sweeps)
         res_sweeps = p.jacobi_sweeps
         pair.estimateE(p)
         assert pair.last_launch()["kernel"] == kernel
+        if kernel == S.KERNEL_PREFILTER:
+            assert pair.last_launch()["prefilter_rule"] == (S.PREFILTER_PER_HYPOTHESIS if len(res) == 1 else S.PREFILTER_PER_TILE)
         res.append((pair.get_inlier_counts(H).copy(), pair.get_key(), pair.get_E().copy(), pair.get_inlier_mask().copy()))
-    same = np.array_equal(res[0][0], res[1][0]) and res[0][1] == res[1][1] and np.array_equal(res[0][2].view(np.uint32), res[1][2].view(np.uint32)) \
-        and np.array_equal(res[0][3], res[1][3])
-    rounds += 1; pairs_checked += n * H
-    if not same:
-        bad.append({"n": n, "flavour": flavour, "seed": seed, "thr": thr, "sweeps": res_sweeps, "differing_counts": int((res[0][0] != res[1][0]).sum())})
+    rounds += 1
+    for form, r in (("per hypothesis", res[1]), ("per tile", res[2])):
+        same = np.array_equal(res[0][0], r[0]) and res[0][1] == r[1] and np.array_equal(res[0][2].view(np.uint32), r[2].view(np.uint32)) and np.array_equal(res[0][3], r[3])
+        pairs_checked += n * H
+        if not same:
+            bad.append({"n": n, "form": form, "flavour": flavour, "seed": seed, "thr": thr, "sweeps": res_sweeps, "differing_counts": int((res[0][0] != r[0]).sum())})
     pair.close()
 print(json.dumps({"seconds": budget, "rounds": rounds, "pairs_checked": pairs_checked, "mismatches": bad}))

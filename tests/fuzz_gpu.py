@@ -79,6 +79,9 @@ def make_rounds(S, torch, dev, ctx, rng):
             pair.fillXU(to_dev(torch, dev, sift))
         p = S.default_params(n, num_hypotheses=H, seed=sseed & 0xFFFF, kernel=kernel, jacobi_sweeps=sweeps, threshold=thr)
         pair.estimateE(p)
+        if kernel == S.KERNEL_PREFILTER and rng.random() < 0.6:       # a second call on the same points: per-tile operands over the ordered copy
+            pair.estimateE(p)
+            cfg["calls"] = 2
         key, ocounts, oE = O.ransac_range(X0, X1, 0, H, p.threshold, p.jacobi_sweeps, seed=p.seed, want_E=True)
         ok = np.array_equal(pair.get_inlier_counts(H), ocounts) and pair.get_key() == key and same_bits(pair.get_E_candidates(H), oE)
         if ok:

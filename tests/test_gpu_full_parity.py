@@ -54,6 +54,11 @@ def test_every_count_of_the_baseline_configs_equals_the_oracle(gpu, name, n, H, 
     assert pair.last_launch()["kernel"] == kernel, f"{name}: AUTO picked kernel {pair.last_launch()['kernel']}"
     key, ocounts, E, mask = oracle_all(scene, p, H)
     assert_all(pair, H, key, ocounts, E, mask, name)
+    # the first call after the fillXU ran per-hypothesis operands (below 2^33 pairs), the second runs per-tile operands: every count again
+    assert pair.last_launch()["prefilter_rule"] == (S.PREFILTER_PER_HYPOTHESIS if n * H < 2 ** 33 else S.PREFILTER_PER_TILE)
+    pair.estimateE(p)
+    assert pair.last_launch()["prefilter_rule"] == S.PREFILTER_PER_TILE
+    assert_all(pair, H, key, ocounts, E, mask, name + " (second call)")
     # the pipelined entry point bench.py times (two slots; the finalize re-derives E from the winner's id)
     pair.estimateE_pipelined(p)
     pair.estimateE_pipelined(p)

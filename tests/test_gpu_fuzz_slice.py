@@ -42,8 +42,10 @@ def test_random_scene_at_the_headline_size_every_count(gpu, k):
     pair, _ = make_pair(S, gpu, scene)
     p = S.default_params(n, num_hypotheses=H, seed=int(rng.integers(0, 1 << 31)), threshold=thr)
     t0 = time.time()
-    pair.estimateE(p)
+    for _ in range(k + 1):                                       # k = 0: the first call after the fillXU (per-hypothesis operands), 1: the second (per tile)
+        pair.estimateE(p)
     assert pair.last_launch()["kernel"] == S.KERNEL_PREFILTER
+    assert pair.last_launch()["prefilter_rule"] == (S.PREFILTER_PER_TILE if k else S.PREFILTER_PER_HYPOTHESIS)
     _, _, X0, X1 = O.fill_xu(scene["sift"], scene["Kinv"])
     key, ocounts, _ = O.ransac_range_fast(X0, X1, 0, H, p.threshold, p.jacobi_sweeps, seed=p.seed)
     counts = pair.get_inlier_counts(H)
