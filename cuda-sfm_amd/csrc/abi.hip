@@ -720,9 +720,10 @@ int sfm_estimate_E(sfm_pair *pair, const sfm_ransac_params *p)
     if (pair->pipe_pending) { const int rcf = sfm_pair_flush(pair); if (rcf != SFM_OK) return rcf; }
     SFM_REQUIRE(count > 0, SFM_E_INVALID, "empty hypothesis range");
     SFM_HIP_TRY(hipSetDevice(pair->ctx->device));
-    rc = launch_ransac_score(pair, *p, h0, count);
+    rc = launch_ransac_score(pair, *p, h0, count, nullptr, nullptr, true);
     if (rc != SFM_OK) return rc;
-    rc = launch_ransac_finalize(pair, *p, pair->d_key, 0, true);     // arg-max stays on the device
+    if (!pair->finalize_folded)                                      // (the fused kernel's last block finalizes itself: few hypotheses, one launch)
+        rc = launch_ransac_finalize(pair, *p, pair->d_key, 0, true);     // arg-max stays on the device
     if (rc == SFM_OK) { pair->have_E = true; pair->have_P = pair->have_pose = pair->have_points3d = false; }
     return rc;
 }

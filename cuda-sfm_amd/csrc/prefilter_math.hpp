@@ -349,6 +349,19 @@ SFM_HD PfBox pf_box_from_words(const unsigned long long *w, float B)
     return box;
 }
 
+// ... from the pair's bound words as they lie in memory (bound[0] = epoch << 32 | bound, bound[2..9] = epoch << 32 | ordered bits): a box word
+// that does not carry the bound's fillXU epoch -- no cell pass has run for these points, or one failed half-way -- describes another point
+// set, and a box that is too small makes sigma too large (inliers rejected): both views fall back to [-B, B] then.
+SFM_HD PfBox pf_box_from_bound(const unsigned long long *bound_word, float B)
+{
+    const unsigned long long epoch = bound_word[0] >> 32;
+    bool current = true;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) current = current && (bound_word[2 + k] >> 32) == epoch;
+    if (!current) { const PfBox whole = { -B, B, -B, B, -B, B, -B, B }; return whole; }
+    return pf_box_from_words(bound_word + 2, B);
+}
+
 // The boxes of ONE tile from eight words of ordered bits (maxima of x, -x, y, -y, u, -u, v, -v over the tile's feature-carrying points,
 // reduced in LDS by the scoring block that stages the tile); the same fall-backs as above.
 SFM_HD PfBox pf_box_from_bits(const uint32_t w[8], float B)
@@ -359,8 +372,8 @@ SFM_HD PfBox pf_box_from_bits(const uint32_t w[8], float B)
     return pf_box_from_words(q, B);
 }
 
-// Morton key of a first-view position for the tile order (pf_sort_kernel): 15 bits per axis over the view's coordinate range (a 30-bit
-// key: 0xFFFFFFFF stays free for "no features").  Equal-count runs of this order are not a k-d partition -- a run that ends inside a
+// Morton key of a first-view position for the tile order (ransac_prefilter.hip: pf_bucket_of takes its top ten bits): 15 bits per axis over
+// the coordinate bound (a 30-bit key).  Equal-count runs of this order are not a k-d partition -- a run that ends inside a
 // Morton quadrant drags its box over the neighbouring one -- but it is one sort, and on the bench scenes it brings the survivors from
 // 1.30 % to 1.05 % (4 tiles) / 1.21 % to 0.78 % (16 tiles).
 SFM_HD uint32_t pf_part1by1(uint32_t x)

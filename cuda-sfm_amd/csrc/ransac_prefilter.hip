@@ -217,7 +217,9 @@ constexpr int kPfVarTickets = 1;
 
 // FL2 (experiment): a ring of 256 entries, flushed 128 at a time -- two entries per lane, their LDS reads issued together
 // WIDE (experiment): ring entries of 16 bytes that cover FOUR steps (two conversions): half as many appends
-template <int W, int VAR = 0, int RULE = kPfRuleBandTile, int FL2 = 0, int PIPE = 0, int WIDE = 0>
+// PRIO (experiment): s_setprio -- 1: the wavefront issues its four MFMAs and fragment loads at raised priority; 2: the exact filter of a
+// flush runs at raised priority (the default is 0 everywhere: the oldest wavefront issues first)
+template <int W, int VAR = 0, int RULE = kPfRuleBandTile, int FL2 = 0, int PIPE = 0, int WIDE = 0, int PRIO = 0>
 __global__ __launch_bounds__(W * 64)
 void ransac_score_prefilter(const float *__restrict__ X0, const float *__restrict__ X1, int ld, int n,
                             const float *__restrict__ Ecand, const PfRecord *__restrict__ recs, uint32_t h0, uint32_t count, float thr,
@@ -451,6 +453,7 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
             // entry = { 32-bit mask of surviving accumulators (bit 31 - r: accumulator r of the pair's first point block, bit 15 - r:
             // of its second), LDS byte address of the lane's point in the pair's first block | 4 (lane >> 5) }.
             uint32_t rest = 0, tag = 0;
+            if (PRIO == 2) __builtin_amdgcn_s_setprio(2);
             if (lane < m) {
                 const u2v ent = *ring_at(((uint32_t)head + (uint32_t)lane) * 8u);
                 tag = ent.y;
@@ -484,6 +487,7 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
             }
             head = (head + m) & (kRing - 1);
             nq += __builtin_popcountll(more) - m;
+            if (PRIO == 2) __builtin_amdgcn_s_setprio(0);
         };
         // wide entries { survivors of phase 2 k, survivors of phase 2 k + 1, tag of phase 2 k, - }: the first survivor of the first word that has one
         auto flush_w = [&](int m) {
@@ -635,6 +639,7 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
         };
         for (int pp = 0; pp < npp; ++pp) {
             SFM_PHASE("scan_two_steps");
+            if (PRIO == 1) __builtin_amdgcn_s_setprio(2);
             mfma_step<RULE>(afrag, fa, g0, n0);
             mfma_step<RULE>(afrag, fb, g0, n1);
             // the fragments of the two steps after these (the last iteration reads past the tile, inside the block's LDS, into
@@ -642,6 +647,7 @@ void ransac_score_prefilter(const float *__restrict__ X0, const float *__restric
             fa = load_point_frags<RULE>(fp, 0);
             fb = load_point_frags<RULE>(fp, 1);
             fp += 2 * (LT::kBlockBytes / 16);
+            if (PRIO == 1) __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
             if (pp > 0) after_phase(dpk, pp - 1);
             __builtin_amdgcn_sched_barrier(0);
@@ -1052,7 +1058,7 @@ void pf_prep_kernel(const float *__restrict__ Ecand, uint32_t count, float thr, 
     for (int k = 0; k < 9; ++k) e[k] = Ecand[9 * (size_t)i + k];
     const float B = __uint_as_float((uint32_t)(*bound_word & 0xFFFFFFFFull));
     if (RULE == kPfRuleBandTile) reinterpret_cast<uint4 *>(recs)[i] = pf_tile_record(e, B, cells, cells_mask);
-    else if (RULE != kPfRuleG) pf_band_prep_store(e, thr, B, pf_box_from_words(bound_word + 2, B), cells, cells_mask, recs + i, RULE == kPfRuleBandPack ? kPfBandTopPack : kPfBandTop);
+    else if (RULE != kPfRuleG) pf_band_prep_store(e, thr, B, pf_box_from_bound(bound_word, B), cells, cells_mask, recs + i, RULE == kPfRuleBandPack ? kPfBandTopPack : kPfBandTop);
     else pf_prep_store(e, thr, B, sc, cells, cells_mask, recs + i);
 }
 
@@ -1252,7 +1258,7 @@ static int pf_rule_switch(const sfm_ransac_params &p)      // lab bench: the rul
     if (SFM_SW(p, 3) == 4 || SFM_SW(p, 3) >= 16) return kPfRuleG;
     if (SFM_SW(p, 3) == 5 || SFM_SW(p, 1) == 5 || SFM_SW(p, 1) == 7 || SFM_SW(p, 1) == 9) return kPfRuleBand;
     if (SFM_SW(p, 3) == 6 || SFM_SW(p, 1) == 11 || SFM_SW(p, 1) == 12) return kPfRuleBandPack;
-    if (SFM_SW(p, 3) == 7 || SFM_SW(p, 1) == 13) return kPfRuleBandTile;
+    if (SFM_SW(p, 3) == 7 || SFM_SW(p, 1) == 13 || SFM_SW(p, 1) == 14 || SFM_SW(p, 1) == 15) return kPfRuleBandTile;
     return -1;
 }
 
@@ -1342,6 +1348,8 @@ int launch_score_prefilter(sfm_pair *pair, const sfm_ransac_params &p, uint32_t 
     else if (SFM_SW(p, 1) == 11) rcl = launch(&ransac_score_prefilter<16, 0, kPfRuleBandPack, 0, 1>);
     else if (SFM_SW(p, 1) == 12) rcl = launch(&ransac_score_prefilter<12, 0, kPfRuleBandPack, 0, 1>);
     else if (wide) rcl = launch(&ransac_score_prefilter<16, 0, kPfRuleBandTile, 0, 0, 1>);
+    else if (rule == kPfRuleBandTile && SFM_SW(p, 1) == 14) rcl = launch(&ransac_score_prefilter<16, 0, kPfRuleBandTile, 0, 0, 0, 1>);     // (s_setprio experiments)
+    else if (rule == kPfRuleBandTile && SFM_SW(p, 1) == 15) rcl = launch(&ransac_score_prefilter<16, 0, kPfRuleBandTile, 0, 0, 0, 2>);
     else
 #endif
     if (rule == kPfRuleBandPack) rcl = launch(&ransac_score_prefilter<16, 0, kPfRuleBandPack>);

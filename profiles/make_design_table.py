@@ -44,14 +44,18 @@ def main():
     traffic = json.load(open(os.path.join(P, "r06_traffic.json")))
     rows = []
 
-    def row(label, d, stats_csv, src):
+    def row(label, d, stats_csv, src, overlapped_csv=None):
         r = d["roofline"]
         avg, mn, calls = kernel_avg_us(stats_csv, "ransac_score_prefilter") if stats_csv else (None, None, 0)
         prof = f"{avg:.1f} us avg / {mn:.1f} min over {calls} launches (`{stats_csv}`)" if avg else "-"
+        if overlapped_csv:          # pipelined steps: the solve of the next step runs beside the scoring launch, whose profiled duration grows with it
+            oavg, omn, ocalls = kernel_avg_us(overlapped_csv, "ransac_score_prefilter")
+            prof += f"; with the next step's solve beside it {oavg:.1f} us avg / {omn:.1f} min over {ocalls} (`{overlapped_csv}`)"
         rows.append(f"| {label} | {fmt(d['ms_per_step'])} | {d['value']:.3g} | {fmt(r['avg_launch_ms'])} ms live at {r['shader_clock_mhz']:.0f} MHz; rocprofv3: {prof} | "
                     f"{fmt(r['solve_kernel_avg_ms'])} | {r['frac']:.3f} ({fmt(r.get('frac_at_sustained_clock'), 3)} at the sustained clock) | `{src}` |")
 
-    row("headline 4096 x 2^20, pipelined (the contractual line)", head, "r06_bench_pipelined_kernel_stats.csv", "r06_bench_line.json")
+    row("headline 4096 x 2^20, pipelined (the contractual line; the launch is timed live in serial steps of the same run)", head, "r06_bench_headline_kernel_stats.csv", "r06_bench_line.json",
+        overlapped_csv="r06_bench_pipelined_kernel_stats.csv")
     row("headline, `--serial`", ser, "r06_bench_headline_kernel_stats.csv", "r06_bench_line_serial.json")
     row("one of 8 ranks' share (131072 hypotheses), pipelined", r8, "r06_bench_rank8_kernel_stats.csv", "r06_bench_rank8.json")
     row("the same, `--serial`", r8s, None, "r06_bench_rank8_serial.json")

@@ -136,6 +136,12 @@ void hc_pf_box_from_words(const unsigned long long *w /*8*/, float B, float *box
     const sfm::PfBox b = sfm::pf_box_from_words(w, B);
     box[0] = b.xlo; box[1] = b.xhi; box[2] = b.ylo; box[3] = b.yhi; box[4] = b.ulo; box[5] = b.uhi; box[6] = b.vlo; box[7] = b.vhi;
 }
+// ... from the bound words as the device finds them (epoch-tagged; a box word of another epoch -> both views [-B, B])
+void hc_pf_box_from_bound(const unsigned long long *bound_word /*10*/, float B, float *box /*8*/)
+{
+    const sfm::PfBox b = sfm::pf_box_from_bound(bound_word, B);
+    box[0] = b.xlo; box[1] = b.xhi; box[2] = b.ylo; box[3] = b.yhi; box[4] = b.ulo; box[5] = b.uhi; box[6] = b.vlo; box[7] = b.vhi;
+}
 
 void hc_sample8(uint32_t seed, uint32_t hyp, int n, int *idx) { sfm::sample8(seed, hyp, n, idx); }
 

@@ -57,6 +57,7 @@ def H():
     h.hc_pf_order_bits.restype = C.c_uint32
     h.hc_pf_order_bits.argtypes = [C.c_float]
     h.hc_pf_box_from_words.argtypes = [C.POINTER(C.c_uint64), C.c_float, f32p]
+    h.hc_pf_box_from_bound.argtypes = [C.POINTER(C.c_uint64), C.c_float, f32p]
     return h
 
 
@@ -519,6 +520,18 @@ def test_band_ordered_bits_and_boxes(H):
     words = (C.c_uint64 * 8)(*[(3 << 32) | H.hc_pf_order_bits(v) for v in m])
     H.hc_pf_box_from_words(words, 0.5, fp(box))
     assert np.allclose(box, [-0.125, 0.25, 0.1, 0.3, -0.5, 0.5, -0.5, 0.5])
+    # the words as they lie behind the bound: boxes of the bound's own fillXU epoch are taken, ONE word of another epoch (no cell pass for these
+    # points yet, or a failed one) sends both views back to [-B, B] -- a stale, smaller box would make sigma too large and reject inliers
+    m = [0.25, 0.125, 0.3, -0.1, 0.4, 0.2, 0.1, 0.1]
+    B = np.float32(0.5)
+    bound = (C.c_uint64 * 10)(*([(7 << 32) | int(B.view(np.uint32)), 0] + [(7 << 32) | H.hc_pf_order_bits(v) for v in m]))
+    H.hc_pf_box_from_bound(bound, float(B), fp(box))
+    assert np.allclose(box, [-0.125, 0.25, 0.1, 0.3, -0.2, 0.4, -0.1, 0.1])
+    for k in range(8):
+        stale = (C.c_uint64 * 10)(*bound)
+        stale[2 + k] = (6 << 32) | H.hc_pf_order_bits(m[k])
+        H.hc_pf_box_from_bound(stale, float(B), fp(box))
+        assert np.array_equal(box, np.float32([-0.5, 0.5] * 4)), k
 
 
 def test_band_survivor_rate_on_the_bench_scene(H):
