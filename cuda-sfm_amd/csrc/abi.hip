@@ -720,10 +720,9 @@ int sfm_estimate_E(sfm_pair *pair, const sfm_ransac_params *p)
     if (pair->pipe_pending) { const int rcf = sfm_pair_flush(pair); if (rcf != SFM_OK) return rcf; }
     SFM_REQUIRE(count > 0, SFM_E_INVALID, "empty hypothesis range");
     SFM_HIP_TRY(hipSetDevice(pair->ctx->device));
-    rc = launch_ransac_score(pair, *p, h0, count, nullptr, nullptr, true);
+    rc = launch_ransac_score(pair, *p, h0, count);
     if (rc != SFM_OK) return rc;
-    if (!pair->finalize_folded)                                      // (the fused kernel's last block finalizes itself: few hypotheses, one launch)
-        rc = launch_ransac_finalize(pair, *p, pair->d_key, 0, true);     // arg-max stays on the device
+    rc = launch_ransac_finalize(pair, *p, pair->d_key, 0, true);     // arg-max stays on the device
     if (rc == SFM_OK) { pair->have_E = true; pair->have_P = pair->have_pose = pair->have_points3d = false; }
     return rc;
 }
@@ -805,6 +804,13 @@ int sfm_pair_device_ptr(sfm_pair *pair, int which, void **d_ptr, size_t *bytes)
     case SFM_BUF_KEY: p = pair->d_key; b = 8; break;
     case SFM_BUF_ECAND: p = pair->d_Ecand; b = (size_t)pair->last_count * 36; break;
     case SFM_BUF_PIND: p = pair->d_Pind; b = 4; break;
+#if SFM_AB
+    // lab bench: what the pre-filter works from (profiles/fuzz_case.py): the per-hypothesis records of the last launch (64 bytes each; 16 with the
+    // per-tile rule), the bound words (bound, -, eight box words), the cell table
+    case SFM_AB_BUF_PF_RECORDS: p = pair->d_pf; b = (size_t)pair->last_count * 64; break;
+    case SFM_AB_BUF_BOUND_WORDS: p = pair->d_bound; b = 10 * sizeof(unsigned long long); break;
+    case SFM_AB_BUF_CELLS: p = pair->d_cells; b = pair->d_cells ? ((size_t)pair->cells_mask + 1) * sizeof(uint32_t) : 0; break;
+#endif
     default: set_error("unknown buffer id %d", which); return SFM_E_INVALID;
     }
     *d_ptr = p;

@@ -149,7 +149,6 @@ struct sfm_pair {
     float *d_points = nullptr;         // 4 x n
     uint8_t *d_mask = nullptr;         // n
     unsigned long long *d_key = nullptr;   // [0] packed best of last score, [1] scratch
-    bool finalize_folded = false;          // the last score launch (fused kernel under sfm_estimate_E) wrote E, mask and best itself
     bool key_clean = false;                // d_key is known to be zero (pair creation, fillXU): the next score launch needs no memset
     uint32_t *d_best = nullptr;        // [0] hyp, [1] count of the finalized hypothesis
     // [8 ...]: trace of the last pre-filter scoring launch, kTraceWords per block (sfm_ransac_last_trace)
@@ -199,7 +198,7 @@ namespace sfm {
 
 // ransac.hip
 int launch_ransac_score(sfm_pair *pair, const sfm_ransac_params &p, uint32_t h0, uint32_t count, unsigned long long *key2 = nullptr,
-                        const float *d_E_given = nullptr, bool fold_finalize = false);     // fold_finalize: sets pair->finalize_folded when the launch finalized too
+                        const float *d_E_given = nullptr);
 int launch_ransac_finalize(sfm_pair *pair, const sfm_ransac_params &p, const unsigned long long *d_key, uint32_t hyp_host, bool from_key,
                            hipStream_t stream = nullptr, bool rederive = false);
 int launch_permutation_indices(sfm_ctx *ctx, int n, uint32_t seed, int32_t *d_indices);
@@ -219,7 +218,7 @@ int launch_prefilter_probe(sfm_ctx *ctx, const float *d_E, float thr, float B, c
 int launch_prefilter_band_probe(sfm_ctx *ctx, const float *d_E, float thr, float B, const float box[8], int b_safe, const float pt[4], int survive_all, float *d_out);
 #endif
 // ransac_fused.hip
-int launch_ransac_fused(sfm_pair *pair, const sfm_ransac_params &p, uint32_t h0, uint32_t count, bool finalize = false);
+int launch_ransac_fused(sfm_pair *pair, const sfm_ransac_params &p, uint32_t h0, uint32_t count);
 int launch_finalize_block(sfm_pair *pair, const sfm_ransac_params &p, const unsigned long long *d_key, uint32_t hyp_host, bool from_key,
                           hipStream_t stream, bool rederive);
 

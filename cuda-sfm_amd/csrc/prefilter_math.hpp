@@ -338,12 +338,24 @@ SFM_HD float pf_order_float(uint32_t k)
 
 // The pair's boxes from the eight words pf_cells_build_kernel leaves behind the bound (low halves: ordered bits of the maxima of
 // x, -x, y, -y of the second view, then u, -u, v, -v of the first); a side without any point falls back to [-B, B].
+// hipcc 7.0 (ROCm 7.2) miscompiles the plain form of this function on the device: the negation of m[1] is dropped -- xlo comes out as +m[1] and
+// the validity test as m[0] >= m[1] -- while the y, u and v bounds of the same expression are right; it does so with the words in scalar and
+// in vector registers alike (profiles/r06_box_decode_isa.txt), i.e. before instruction selection, and only in some callers (the scoring kernel's
+// tile boxes, round 6: r06_tile_boxes_debug.txt; pf_prep_kernel, found by the fuzz as wrong counts behind the Jacobi solver; the lane-solve
+// kernel's copy is right).  A box with a wrong lower bound is SMALLER than the points' range: sigma too large, inliers rejected.  The decoded
+// maxima and the finished bounds therefore pass through empty asm statements, which the optimiser cannot look through.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SFM_PF_OPAQUE(x) asm volatile("" : "+v"(x))
+#else
+#define SFM_PF_OPAQUE(x) do { } while (0)
+#endif
 SFM_HD PfBox pf_box_from_words(const unsigned long long *w, float B)
 {
     float m[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) m[k] = pf_order_float((uint32_t)(w[k] & 0xFFFFFFFFull));
+    for (int k = 0; k < 8; ++k) { m[k] = pf_order_float((uint32_t)(w[k] & 0xFFFFFFFFull)); SFM_PF_OPAQUE(m[k]); }
     PfBox box = { -m[1], m[0], -m[3], m[2], -m[5], m[4], -m[7], m[6] };
+    SFM_PF_OPAQUE(box.xlo); SFM_PF_OPAQUE(box.ylo); SFM_PF_OPAQUE(box.ulo); SFM_PF_OPAQUE(box.vlo);
     if (!(box.xlo <= box.xhi) || !(box.ylo <= box.yhi) || !(box.xhi <= B) || !(box.xlo >= -B) || !(box.yhi <= B) || !(box.ylo >= -B)) { box.xlo = box.ylo = -B; box.xhi = box.yhi = B; }
     if (!(box.ulo <= box.uhi) || !(box.vlo <= box.vhi) || !(box.uhi <= B) || !(box.ulo >= -B) || !(box.vhi <= B) || !(box.vlo >= -B)) { box.ulo = box.vlo = -B; box.uhi = box.vhi = B; }
     return box;
@@ -352,14 +364,23 @@ SFM_HD PfBox pf_box_from_words(const unsigned long long *w, float B)
 // ... from the pair's bound words as they lie in memory (bound[0] = epoch << 32 | bound, bound[2..9] = epoch << 32 | ordered bits): a box word
 // that does not carry the bound's fillXU epoch -- no cell pass has run for these points, or one failed half-way -- describes another point
 // set, and a box that is too small makes sigma too large (inliers rejected): both views fall back to [-B, B] then.
+// (the words are fetched with agent-scope atomic loads: through the vector memory path, like the scoring kernel's tile boxes)
 SFM_HD PfBox pf_box_from_bound(const unsigned long long *bound_word, float B)
 {
-    const unsigned long long epoch = bound_word[0] >> 32;
+    unsigned long long w[10];
+#pragma unroll
+    for (int k = 0; k < 10; ++k)
+#if defined(__HIP_DEVICE_COMPILE__)
+        w[k] = __hip_atomic_load(bound_word + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+        w[k] = bound_word[k];
+#endif
+    const unsigned long long epoch = w[0] >> 32;
     bool current = true;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) current = current && (bound_word[2 + k] >> 32) == epoch;
+    for (int k = 0; k < 8; ++k) current = current && (w[2 + k] >> 32) == epoch;
     if (!current) { const PfBox whole = { -B, B, -B, B, -B, B, -B, B }; return whole; }
-    return pf_box_from_words(bound_word + 2, B);
+    return pf_box_from_words(w + 2, B);
 }
 
 // The boxes of ONE tile from eight words of ordered bits (maxima of x, -x, y, -y, u, -u, v, -v over the tile's feature-carrying points,

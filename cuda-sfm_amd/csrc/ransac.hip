@@ -354,10 +354,9 @@ static int launch_score_t(sfm_pair *pair, uint32_t h0, uint32_t count, float thr
 // 3 = scalar, 4 = scattered gathers.
 constexpr uint32_t kScalarSolveMax = 262144u;
 
-int launch_ransac_score(sfm_pair *pair, const sfm_ransac_params &p, uint32_t h0, uint32_t count, unsigned long long *key2, const float *d_E_given, bool fold_finalize)
+int launch_ransac_score(sfm_pair *pair, const sfm_ransac_params &p, uint32_t h0, uint32_t count, unsigned long long *key2, const float *d_E_given)
 {
     sfm_ctx *ctx = pair->ctx;
-    pair->finalize_folded = false;
     // which kernel family: decided first, because the lane-solve kernel of the SPLIT family clears the keys itself
     const uint32_t fused_max_early = p.jacobi_sweeps > 0 ? 4096u : 1024u;
     int family = p.kernel == SFM_KERNEL_AUTO ? (count <= fused_max_early ? SFM_KERNEL_FUSED : SFM_KERNEL_SPLIT) : p.kernel;
@@ -392,7 +391,7 @@ int launch_ransac_score(sfm_pair *pair, const sfm_ransac_params &p, uint32_t h0,
     if (p.kernel == SFM_KERNEL_AUTO && kernel == SFM_KERNEL_SPLIT && prefilter_usable(pair, p, count) && SFM_SW(p, 3) != 1) kernel = SFM_KERNEL_PREFILTER;
     pair->last_kernel = kernel;
     if (kernel == SFM_KERNEL_FUSED) {
-        rc = launch_ransac_fused(pair, p, h0, count, fold_finalize);
+        rc = launch_ransac_fused(pair, p, h0, count);
         if (rc == SFM_OK && key2) SFM_HIP_TRY(hipMemcpyAsync(key2, pair->d_key, sizeof(unsigned long long), hipMemcpyDeviceToDevice, ctx->stream));
         return rc;
     }

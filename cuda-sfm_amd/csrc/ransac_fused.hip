@@ -257,66 +257,15 @@ __device__ __forceinline__ void fused_body(float *lds, const float *__restrict__
     }
 }
 
-// sfm_estimate_E on this kernel: the block that finishes LAST also does what ransac_finalize_block does for a winner whose candidate is at
-// hand -- E, inlier mask, count -- instead of a second launch (4.5 us + a launch gap of the ~55 us a dino pair takes end to end).  The
-// ticket is the scratch word behind the key (zero whenever the key is: fillXU, the memset in front of a fused launch; put back to zero
-// by the last block).  Blocks publish counts / candidates / key with a device-scope fence in front of their ticket; the last block fences
-// again before it reads them.
-struct FusedFinalize { float *E_out; uint8_t *mask; uint32_t *best_out; unsigned int *ticket; uint32_t num_hypotheses; };
-
 template <int WPB, bool UNITZ>
 __global__ __launch_bounds__(WPB * 64)
 void ransac_fused_waves(const float *__restrict__ X0, const float *__restrict__ X1, int ld, int n,
                         const int32_t *__restrict__ indices, uint32_t seed, int sweeps,
                         uint32_t h0, uint32_t count, float thr, int tile, int ntiles,
-                        int *__restrict__ counts, float *__restrict__ Ecand, unsigned long long *best_key, FusedFinalize fin)
+                        int *__restrict__ counts, float *__restrict__ Ecand, unsigned long long *best_key)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     fused_body<WPB, UNITZ>(lds, X0, X1, ld, n, indices, seed, sweeps, h0, count, thr, tile, ntiles, counts, Ecand, best_key, blockIdx.x, gridDim.x);
-    if (!fin.E_out) return;
-    __shared__ int s_last;
-    __shared__ float sE[9];
-    __shared__ int scount[WPB];
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0) s_last = atomicAdd(fin.ticket, 1u) == gridDim.x - 1u ? 1 : 0;
-    __syncthreads();
-    if (!s_last) return;
-    if (threadIdx.x == 0) atomicExch(fin.ticket, 0u);
-    __threadfence();
-    const unsigned long long key = __hip_atomic_load(best_key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const uint32_t hyp = 0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFull);
-    if (hyp >= fin.num_hypotheses || hyp < h0 || hyp - h0 >= count) {       // no winner (every count zero cannot happen: a key is never 0 then; an empty range can)
-        if (threadIdx.x < 9) fin.E_out[threadIdx.x] = 0.0f;
-        if (threadIdx.x == 0) { fin.best_out[0] = 0xFFFFFFFFu; fin.best_out[1] = 0; }
-        for (int j = threadIdx.x; j < n; j += blockDim.x) fin.mask[j] = 0;
-        return;
-    }
-    if (threadIdx.x < 9)
-        sE[threadIdx.x] = __uint_as_float(__hip_atomic_load(reinterpret_cast<const uint32_t *>(Ecand) + 9 * (size_t)(hyp - h0) + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    __syncthreads();
-    if (threadIdx.x < 9) fin.E_out[threadIdx.x] = sE[threadIdx.x];
-    const Ess E{ sE[0], sE[1], sE[2], sE[3], sE[4], sE[5], sE[6], sE[7], sE[8] };
-    int c = 0;
-    for (int j0 = 0; j0 < n; j0 += blockDim.x) {
-        const int j = j0 + threadIdx.x;
-        bool in = false;
-        if (j < n) {
-            const float r = residual(E, X0[j], X0[(size_t)ld + j], X0[2 * (size_t)ld + j], X1[j], X1[(size_t)ld + j], X1[2 * (size_t)ld + j]);
-            in = r < thr;
-            fin.mask[j] = in ? 1 : 0;
-        }
-        c += __builtin_popcountll(__ballot(in));
-    }
-    if ((threadIdx.x & 63) == 0) scount[threadIdx.x >> 6] = c;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int total = 0;
-#pragma unroll
-        for (int w = 0; w < WPB; ++w) total += scount[w];
-        fin.best_out[0] = hyp;
-        fin.best_out[1] = (uint32_t)total;
-    }
 }
 
 // Many pairs in ONE launch (sfm_process_pairs, BASELINE configs[4]): blockIdx.y names the pair, its blocks are blockIdx.x.
@@ -437,19 +386,19 @@ void ransac_finalize_block(const float *__restrict__ X0, const float *__restrict
 }
 
 template <int WPB, bool UNITZ>
-static int launch_fused_t(sfm_pair *pair, const sfm_ransac_params &p, uint32_t h0, uint32_t count, int tile, int ntiles, int grid, size_t lds, const FusedFinalize &fin)
+static int launch_fused_t(sfm_pair *pair, const sfm_ransac_params &p, uint32_t h0, uint32_t count, int tile, int ntiles, int grid, size_t lds)
 {
     const int rc_lds = allow_big_lds(pair->ctx, reinterpret_cast<const void *>(&ransac_fused_waves<WPB, UNITZ>));
     if (rc_lds != SFM_OK) return rc_lds;
     hipLaunchKernelGGL((ransac_fused_waves<WPB, UNITZ>), dim3(grid), dim3(WPB * 64), lds, pair->ctx->stream,
                        pair->d_X[0], pair->d_X[1], pair->ld, pair->n, p.d_indices, p.seed, p.jacobi_sweeps,
-                       h0, count, p.threshold, tile, ntiles, pair->d_counts, pair->d_Ecand, pair->d_key, fin);
+                       h0, count, p.threshold, tile, ntiles, pair->d_counts, pair->d_Ecand, pair->d_key);
     SFM_HIP_TRY(hipGetLastError());
     pair->last_grid = grid; pair->last_block = WPB * 64; pair->last_lds = (int)lds;
     return SFM_OK;
 }
 
-int launch_ransac_fused(sfm_pair *pair, const sfm_ransac_params &p, uint32_t h0, uint32_t count, bool finalize)
+int launch_ransac_fused(sfm_pair *pair, const sfm_ransac_params &p, uint32_t h0, uint32_t count)
 {
     sfm_ctx *ctx = pair->ctx;
     const int tile = pair->ld < kTileMax ? pair->ld : kTileMax;
@@ -464,15 +413,11 @@ int launch_ransac_fused(sfm_pair *pair, const sfm_ransac_params &p, uint32_t h0,
     const bool timed = ctx->timing && ctx->tcount < sfm_ctx::kTimingSlots;
     hipEvent_t *tev = timed ? ctx->tev[ctx->tcount] : nullptr;
     if (timed) { SFM_HIP_TRY(hipEventRecord(tev[0], ctx->stream)); SFM_HIP_TRY(hipEventRecord(tev[1], ctx->stream)); }
-    // (finalize: the caller is sfm_estimate_E -- winner's E, mask and count by the last block of this launch; the key's scratch word is its ticket)
-    const FusedFinalize fin = finalize ? FusedFinalize{ pair->d_E, pair->d_mask, pair->d_best, reinterpret_cast<unsigned int *>(pair->d_key + 1), p.num_hypotheses }
-                                       : FusedFinalize{ nullptr, nullptr, nullptr, nullptr, 0u };
     int rc;
     switch (wpb) {
-    case 8:  rc = uz ? launch_fused_t<8, true>(pair, p, h0, count, tile, ntiles, grid, lds, fin) : launch_fused_t<8, false>(pair, p, h0, count, tile, ntiles, grid, lds, fin); break;
-    default: rc = uz ? launch_fused_t<4, true>(pair, p, h0, count, tile, ntiles, grid, lds, fin) : launch_fused_t<4, false>(pair, p, h0, count, tile, ntiles, grid, lds, fin); break;
+    case 8:  rc = uz ? launch_fused_t<8, true>(pair, p, h0, count, tile, ntiles, grid, lds) : launch_fused_t<8, false>(pair, p, h0, count, tile, ntiles, grid, lds); break;
+    default: rc = uz ? launch_fused_t<4, true>(pair, p, h0, count, tile, ntiles, grid, lds) : launch_fused_t<4, false>(pair, p, h0, count, tile, ntiles, grid, lds); break;
     }
-    pair->finalize_folded = rc == SFM_OK && finalize;
     if (rc == SFM_OK && timed) { SFM_HIP_TRY(hipEventRecord(tev[2], ctx->stream)); ctx->tcount++; }
     return rc;
 }

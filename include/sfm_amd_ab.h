@@ -14,6 +14,11 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* sfm_pair_device_ptr ids of the lab-bench library: the per-hypothesis records of the last pre-filter launch (64 bytes each, 16 with the per-tile
+ * rule), the pair's bound words (bound | - | eight box words, each epoch << 32 | bits) and its table of occupied cells. */
+#define SFM_AB_BUF_PF_RECORDS 100
+#define SFM_AB_BUF_BOUND_WORDS 101
+#define SFM_AB_BUF_CELLS 102
 #pragma GCC visibility push(default)
 
 /* Scoring with E.X on the f32 matrix cores (32 hypotheses per wavefront; csrc/ab/ransac_mfma.hip): bit-exact, measured

@@ -83,11 +83,18 @@ def make_rounds(S, torch, dev, ctx, rng):
             pair.estimateE(p)
             cfg["calls"] = 2
         key, ocounts, oE = O.ransac_range(X0, X1, 0, H, p.threshold, p.jacobi_sweeps, seed=p.seed, want_E=True)
-        ok = np.array_equal(pair.get_inlier_counts(H), ocounts) and pair.get_key() == key and same_bits(pair.get_E_candidates(H), oE)
-        if ok:
-            ocnt, ohyp = O.unpack_key(key)
-            _, omask = O.count_inliers(oE[ohyp], X0, X1, p.threshold)
-            ok = np.array_equal(pair.get_inlier_mask(), omask) and same_bits(pair.get_E(), oE[ohyp].reshape(3, 3))
+        ocnt, ohyp = O.unpack_key(key)
+        _, omask = O.count_inliers(oE[ohyp], X0, X1, p.threshold)
+        checks = {"counts": np.array_equal(pair.get_inlier_counts(H), ocounts), "key": pair.get_key() == key,
+                  "candidates": same_bits(pair.get_E_candidates(H), oE), "mask": np.array_equal(pair.get_inlier_mask(), omask),
+                  "E": same_bits(pair.get_E(), oE[ohyp].reshape(3, 3))}
+        ok = all(checks.values())
+        if not ok:                                    # which comparison failed, and what ran
+            cfg["failed"] = [k for k, v in checks.items() if not v]
+            cfg["launch"] = pair.last_launch()
+            if os.environ.get("FUZZ_DUMP"):           # the whole case, for a closer look (profiles/fuzz_case.py)
+                np.savez(os.path.join(os.environ["FUZZ_DUMP"], f"fuzz_fail_{n}_{H}.npz"), sift=sift.view(np.uint8), K=scene["K"], Kinv=scene["Kinv"], thr=p.threshold,
+                         seed=p.seed, sweeps=sweeps, H=H, n=n, kernel=kernel, counts=pair.get_inlier_counts(H), ocounts=ocounts, calls=cfg.get("calls", 1))
         return ok, cfg
 
     def pose_round():

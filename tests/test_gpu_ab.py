@@ -2,6 +2,8 @@
 include/sfm_amd_ab.h): the A/B switches behind sfm_ransac_params.reserved[], the recorded slower kernel variants (f32
 matrix-core scoring, the round-2 pre-filter kernel, the generic lane-solve kernel) and the probe hook -- each against the
 oracle, like the product's kernels.  And the other side of the split: the PRODUCT library refuses all of it."""
+import os
+
 import numpy as np
 import pytest
 
@@ -453,3 +455,35 @@ def test_wide_ring_entries_still_equal_oracle(gpu_ab, n, H):
     pair.estimateE(p)
     assert pair.last_launch()["kernel"] == S.KERNEL_PREFILTER
     P.check_all(pair, scene, p, H, n)
+
+
+def _view_box_case():
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "prefilter_view_box_case.npz"))
+    n = int(d["n"])
+    sift = np.zeros(n, synth.SIFT_DTYPE)
+    for f in ("xpos", "ypos", "match_xpos", "match_ypos"):
+        sift[f] = d[f]
+    return {"sift": sift, "K": d["K"], "Kinv": d["Kinv"]}, n, int(d["H"]), float(d["thr"]), int(d["seed"])
+
+
+@pytest.mark.parametrize("sweeps", [0, 7])
+def test_view_boxes_of_every_record_builder_on_the_case_the_fuzz_found(gpu, gpu_ab, sweeps):
+    """Round 6: hipcc dropped the negation of ONE lower bound of the whole-view boxes in the stand-alone record kernel (pf_box_from_words:
+    xlo = +max(-x), a box smaller than the points' range, sigma up to 20 % too large) -- 23 (Jacobi solver) / 152 (Householder + stand-alone
+    records) of 1607 hypotheses of this scene lost inliers; the lane-solve kernel's copy of the same function was right, so only paths behind
+    pf_prep_kernel showed it (profiles/NOTES_r06.md).  Every per-hypothesis record builder and the per-tile form, both solvers, both calls."""
+    scene, n, H, thr, seed = _view_box_case()
+    _, _, X0, X1 = O.fill_xu(scene["sift"], scene["Kinv"])
+    key, ocounts, _ = O.ransac_range(X0, X1, 0, H, np.float32(thr), sweeps, seed=seed)
+    for lib, g, r3 in ((PROD, gpu, 0), (S, gpu_ab, 6), (S, gpu_ab, 7), (S, gpu_ab, 5), (S, gpu_ab, 3)):
+        pair, _ = make_pair(lib, g, scene)
+        p = lib.default_params(n, num_hypotheses=H, seed=seed, kernel=lib.KERNEL_PREFILTER, jacobi_sweeps=sweeps, threshold=thr)
+        p.reserved[3] = r3
+        for call in range(2):
+            pair.estimateE(p)
+            assert pair.last_launch()["kernel"] == lib.KERNEL_PREFILTER
+            c = pair.get_inlier_counts(H)
+            bad = np.flatnonzero(c != ocounts)
+            assert bad.size == 0, f"reserved[3] = {r3}, call {call + 1}: {bad.size} counts differ, gpu - oracle in [{int((c - ocounts).min())}, {int((c - ocounts).max())}]"
+            assert pair.get_key() == key
+        pair.close()
