@@ -97,6 +97,80 @@ def make_rounds(S, torch, dev, ctx, rng):
                          seed=p.seed, sweeps=sweeps, H=H, n=n, kernel=kernel, counts=pair.get_inlier_counts(H), ocounts=ocounts, calls=cfg.get("calls", 1))
         return ok, cfg
 
+    def calls_round():
+        """ONE pair through a random sequence of calls -- what depends on the pair's state: the fillXU epoch (bound, cell table, whole-view boxes,
+        the ordered copy and its tile boxes), which form of the pre-filter a call runs (first call after a fillXU per hypothesis, later ones per
+        tile), the two slots of pipelined calls, records written by the lane-solve kernel / by the stand-alone kernel (Jacobi solver, supplied
+        candidates).  Every step is checked: counts, key, E and mask (pipelined bursts: winner, E, mask)."""
+        n = int(rng.choice([rng.integers(300, 1500), rng.integers(1500, 6000)]))
+        sseed = int(rng.integers(1, 1 << 30))
+        cfg = dict(path="calls", n=n, scene_seed=sseed, steps=[])
+        pair = S.ImagePair(ctx, np.eye(3, dtype=np.float32), np.eye(3, dtype=np.float32), 2, n)
+        state = {}
+
+        def refill():
+            sc = synth.two_view_scene(n, seed=int(rng.integers(1, 1 << 30)), noise_px=float(rng.choice([0.0, 0.3, 2.0])), outlier_frac=float(rng.choice([0.0, 0.3, 0.8])),
+                                      focal=float(rng.choice([600.0, 2360.0, 2360.0, 9000.0])))
+            # (the pair keeps its K: X = U with K = I would leave pixel coordinates; use the scene's normalised coordinates as "pixels" of an identity camera)
+            _, _, X0, X1 = O.fill_xu(sc["sift"], sc["Kinv"])
+            sift = np.zeros(n, synth.SIFT_DTYPE)
+            sift["xpos"], sift["ypos"], sift["match_xpos"], sift["match_ypos"] = X0[0, :n], X0[1, :n], X1[0, :n], X1[1, :n]
+            pair.fillXU(to_dev(torch, dev, sift))
+            _, _, state["X0"], state["X1"] = O.fill_xu(sift, np.eye(3, dtype=np.float32))
+
+        def params():
+            H = int(rng.choice([rng.integers(64, 1500), rng.integers(1500, 8000), rng.integers(16384, 24000)]))
+            kernel = int(rng.choice([S.KERNEL_AUTO, S.KERNEL_SPLIT, S.KERNEL_PREFILTER, S.KERNEL_PREFILTER, S.KERNEL_PREFILTER]))
+            return H, S.default_params(n, num_hypotheses=H, seed=int(rng.integers(0, 1 << 16)), kernel=kernel, jacobi_sweeps=int(rng.choice([0, 0, 0, 7, 3])),
+                                       threshold=float(np.float32(10.0 ** rng.uniform(-7, -3))))
+
+        def want(H, p):
+            key, ocounts, oE = O.ransac_range(state["X0"], state["X1"], 0, H, p.threshold, p.jacobi_sweeps, seed=p.seed, want_E=True)
+            ocnt, ohyp = O.unpack_key(key)
+            return key, ocounts, oE[ohyp].reshape(3, 3), O.count_inliers(oE[ohyp], state["X0"], state["X1"], p.threshold)[1], (ohyp, ocnt)
+
+        refill()
+        for step in range(int(rng.integers(2, 7))):
+            op = str(rng.choice(["estimate", "estimate", "estimate", "pipelined", "candidates", "refill"]))
+            if op == "refill":
+                refill()
+                cfg["steps"].append(op)
+                continue
+            H, p = params()
+            cfg["steps"].append(dict(op=op, H=H, kernel=p.kernel, sweeps=p.jacobi_sweeps, thr=p.threshold, seed=p.seed))
+            if op == "estimate":
+                pair.estimateE(p)
+                key, ocounts, oEb, omask, best = want(H, p)
+                ok = np.array_equal(pair.get_inlier_counts(H), ocounts) and pair.get_key() == key and same_bits(pair.get_E(), oEb) and np.array_equal(pair.get_inlier_mask(), omask)
+            elif op == "pipelined":
+                burst = [(H, p)] + [params() for _ in range(int(rng.integers(0, 3)))]
+                for _, q in burst:
+                    pair.estimateE_pipelined(q)
+                key, ocounts, oEb, omask, best = want(*burst[-1])
+                ok = pair.get_best() == best and same_bits(pair.get_E(), oEb) and np.array_equal(pair.get_inlier_mask(), omask)
+                cfg["steps"][-1]["burst"] = len(burst)
+            else:                                     # caller-supplied candidates: hypotheses of another sampler seed, a few of them scaled / negated / transposed
+                _, _, oE = O.ransac_range(state["X0"], state["X1"], 0, H, p.threshold, 0, seed=p.seed ^ 0x5A5A, want_E=True)
+                Es = oE.reshape(H, 9).copy()
+                k = rng.integers(0, H, max(1, H // 16))
+                Es[k] *= np.float32(rng.choice([-1.0, 0.25, 3.0]))
+                k = rng.integers(0, H, max(1, H // 16))
+                Es[k] = Es[k].reshape(-1, 3, 3).transpose(0, 2, 1).reshape(-1, 9)
+                if p.kernel == S.KERNEL_AUTO:
+                    p.kernel = S.KERNEL_PREFILTER
+                pair.ransac_score_candidates(p, to_dev(torch, dev, Es.reshape(-1)))
+                with np.errstate(invalid="ignore", over="ignore"):
+                    oc = np.array([O.count_inliers_fast(Es[h].reshape(3, 3), state["X0"], state["X1"], np.float32(p.threshold)) for h in range(H)], np.int32)
+                bi = int(np.argmax(oc))
+                ok = np.array_equal(pair.get_inlier_counts(H), oc) and pair.get_key() == O.pack_key(int(oc[bi]), bi)
+            if not ok:
+                cfg["failed_step"] = step
+                cfg["launch"] = pair.last_launch()
+                pair.close()
+                return False, cfg
+        pair.close()
+        return True, cfg
+
     def pose_round():
         """fillXU -> estimateE (few hypotheses) -> poses + triangulation, one launch (sfm_pose_chain) or the three calls, both pose
         modes: candidates, inverses, index and every triangulated point against the oracle, bit for bit.  Flavours: plain /
@@ -186,7 +260,8 @@ def make_rounds(S, torch, dev, ctx, rng):
             ok = all(same_bits(a[f], b[f]) for f in ("xpos", "ypos", "scale", "sharpness", "edgeness", "orientation", "subsampling", "data"))
         return ok, dict(path="sift", w=w, h=h, octaves=octaves, up=up, thresh=thresh, blur=blur, lowest=lowest, seed=sseed, max_pts=max_pts, npts=int(npts))
 
-    return [("ransac", ransac_round, 0.45), ("pose", pose_round, 0.15), ("match", match_round, 0.14), ("homography", homography_round, 0.13), ("sift", sift_round, 0.13)]
+    return [("ransac", ransac_round, 0.37), ("calls", calls_round, 0.12), ("pose", pose_round, 0.14), ("match", match_round, 0.13), ("homography", homography_round, 0.12),
+            ("sift", sift_round, 0.12)]
 
 
 def run_rounds(table, rng, budget_s=None, max_rounds=None, max_bad=20):
