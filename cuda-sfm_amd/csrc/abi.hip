@@ -599,7 +599,11 @@ int sfm_ransac_score_into_slot(sfm_pair *pair, const sfm_ransac_params *p, uint6
     // the caller's stream for the duration of the (asynchronous) launches -- kernel arguments are captured at launch
     if (slot == 1 && !pair->alt_key) {
         SFM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&pair->alt_key), 2 * sizeof(unsigned long long)));
-        SFM_HIP_TRY(hipMemset(pair->alt_key, 0, 2 * sizeof(unsigned long long)));
+        // cleared on the stream the launches below go to.  (Until round 6 this was a plain hipMemset: it runs on the NULL stream, which a
+        // non-blocking stream does not wait for -- queued behind slot 0's kernels when the context works on the null stream, it cleared slot
+        // 1's key while or after slot 1's first fused-kernel launch wrote it: the first pipelined call of a pair on slot 1 could finalize a
+        // partial or empty key.  Found by the fuzz's stateful round; profiles/pipelined_burst_case.py.)
+        SFM_HIP_TRY(hipMemsetAsync(pair->alt_key, 0, 2 * sizeof(unsigned long long), hip_stream ? static_cast<hipStream_t>(hip_stream) : pair->ctx->stream));
     }
     auto swap_slot = [&]() {
         std::swap(pair->d_counts, pair->alt_counts); std::swap(pair->d_tick, pair->alt_tick);

@@ -130,7 +130,17 @@ def make_rounds(S, torch, dev, ctx, rng):
             return key, ocounts, oE[ohyp].reshape(3, 3), O.count_inliers(oE[ohyp], state["X0"], state["X1"], p.threshold)[1], (ohyp, ocnt)
 
         refill()
-        for step in range(int(rng.integers(2, 7))):
+        nsteps = int(rng.integers(2, 7))
+        try:
+            return calls_steps(pair, state, cfg, nsteps, refill, params, want)
+        except Exception as e:                        # keep the sequence that led to it
+            cfg["exception"] = repr(e)
+            cfg["launch"] = pair.last_launch()
+            return False, cfg
+
+    def calls_steps(pair, state, cfg, nsteps, refill, params, want):
+        n = cfg["n"]
+        for step in range(nsteps):
             op = str(rng.choice(["estimate", "estimate", "estimate", "pipelined", "candidates", "refill"]))
             if op == "refill":
                 refill()
@@ -144,11 +154,11 @@ def make_rounds(S, torch, dev, ctx, rng):
                 ok = np.array_equal(pair.get_inlier_counts(H), ocounts) and pair.get_key() == key and same_bits(pair.get_E(), oEb) and np.array_equal(pair.get_inlier_mask(), omask)
             elif op == "pipelined":
                 burst = [(H, p)] + [params() for _ in range(int(rng.integers(0, 3)))]
+                cfg["steps"][-1]["burst"] = [dict(H=h, kernel=q.kernel, sweeps=q.jacobi_sweeps, thr=q.threshold, seed=q.seed) for h, q in burst]
                 for _, q in burst:
                     pair.estimateE_pipelined(q)
                 key, ocounts, oEb, omask, best = want(*burst[-1])
                 ok = pair.get_best() == best and same_bits(pair.get_E(), oEb) and np.array_equal(pair.get_inlier_mask(), omask)
-                cfg["steps"][-1]["burst"] = len(burst)
             else:                                     # caller-supplied candidates: hypotheses of another sampler seed, a few of them scaled / negated / transposed
                 _, _, oE = O.ransac_range(state["X0"], state["X1"], 0, H, p.threshold, 0, seed=p.seed ^ 0x5A5A, want_E=True)
                 Es = oE.reshape(H, 9).copy()

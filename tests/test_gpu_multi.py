@@ -11,7 +11,8 @@ import pytest
 
 import cuda_sfm_amd as S
 from cuda_sfm_amd import synth
-from helpers import same_bits, make_pair
+from helpers import same_bits, make_pair, to_dev
+import oracle as O
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -165,3 +166,31 @@ def test_estimate_E_pipelined_equals_estimateE(gpu):
     pair.fillXU(d_sift)                                       # flushes the pending steps before it rewrites the points
     pair.estimateE(S.default_params(n, num_hypotheses=50000, seed=9))
     assert pair.get_best() == refs[(9, 50000)][0]
+
+
+def test_first_pipelined_call_on_the_second_slot_of_a_fresh_pair(gpu):
+    """Round 6 (found by the stateful round of tests/fuzz_gpu.py): the second slot's key buffer was cleared with a plain hipMemset when it was
+    allocated -- on the NULL stream, which the slot's non-blocking stream does not wait for.  With the context on the null stream (torch's default)
+    the memset queued behind slot 0's kernel and cleared slot 1's key while or after its first fused-kernel launch wrote it: a partial or empty
+    key reached the finalize (88 of 200 fresh pairs for two fused calls with the same solver; profiles/pipelined_burst_case.py).  Fresh pairs,
+    two pipelined calls each, the kernel families that copy their key (fused) and that write it themselves (split)."""
+    torch, dev, ctx = gpu
+    n = 4735
+    scene = synth.two_view_scene(n, seed=522527723)
+    _, _, X0, X1 = O.fill_xu(scene["sift"], scene["Kinv"])
+    d_sift = to_dev(torch, dev, scene["sift"])
+    big, small = (20309, 3, 6.18e-7, 58246), (546, 7, 1.27e-5, 50380)
+    for kernels, sweeps in (((S.KERNEL_FUSED, S.KERNEL_FUSED), (3, 7)), ((S.KERNEL_FUSED, S.KERNEL_FUSED), (0, 0)), ((S.KERNEL_SPLIT, S.KERNEL_FUSED), (3, 7)),
+                            ((S.KERNEL_FUSED, S.KERNEL_SPLIT), (0, 0))):
+        H, _, thr, seed = small
+        key, _, oE = O.ransac_range(X0, X1, 0, H, np.float32(thr), sweeps[1], seed=seed, want_E=True)
+        ocnt, ohyp = O.unpack_key(key)
+        omask = O.count_inliers(oE[ohyp], X0, X1, np.float32(thr))[1]
+        for rep in range(40):
+            pair = S.ImagePair(ctx, scene["K"], scene["Kinv"], 2, n)
+            pair.fillXU(d_sift)
+            for (h, _, t, sd), kern, sw in zip((big, small), kernels, sweeps):
+                pair.estimateE_pipelined(S.default_params(n, num_hypotheses=h, seed=sd, kernel=kern, jacobi_sweeps=sw, threshold=t))
+            assert pair.get_best() == (ohyp, ocnt), (kernels, sweeps, rep)
+            assert same_bits(pair.get_E(), oE[ohyp].reshape(3, 3)) and np.array_equal(pair.get_inlier_mask(), omask)
+            pair.close()
