@@ -105,8 +105,16 @@ def make_rounds(S, torch, dev, ctx, rng):
         n = int(rng.choice([rng.integers(300, 1500), rng.integers(1500, 6000)]))
         sseed = int(rng.integers(1, 1 << 30))
         cfg = dict(path="calls", n=n, scene_seed=sseed, steps=[])
-        pair = S.ImagePair(ctx, np.eye(3, dtype=np.float32), np.eye(3, dtype=np.float32), 2, n)
-        state = {}
+        # the context: the shared one (torch's default stream, i.e. the null stream) or one of its own on a non-blocking stream -- what is
+        # ordered by accident on the null stream is not on the other
+        own = bool(rng.random() < 0.4)
+        cfg["own_stream"] = own
+        c = ctx
+        if own:
+            c = S.Context(0)
+            c.own_stream()
+        pair = S.ImagePair(c, np.eye(3, dtype=np.float32), np.eye(3, dtype=np.float32), 2, n)
+        state = {"ctx": c}
 
         def refill():
             sc = synth.two_view_scene(n, seed=int(rng.integers(1, 1 << 30)), noise_px=float(rng.choice([0.0, 0.3, 2.0])), outlier_frac=float(rng.choice([0.0, 0.3, 0.8])),
@@ -141,7 +149,7 @@ def make_rounds(S, torch, dev, ctx, rng):
     def calls_steps(pair, state, cfg, nsteps, refill, params, want):
         n = cfg["n"]
         for step in range(nsteps):
-            op = str(rng.choice(["estimate", "estimate", "estimate", "pipelined", "candidates", "refill"]))
+            op = str(rng.choice(["estimate", "estimate", "estimate", "pipelined", "candidates", "shards", "refill"]))
             if op == "refill":
                 refill()
                 cfg["steps"].append(op)
@@ -159,6 +167,25 @@ def make_rounds(S, torch, dev, ctx, rng):
                     pair.estimateE_pipelined(q)
                 key, ocounts, oEb, omask, best = want(*burst[-1])
                 ok = pair.get_best() == best and same_bits(pair.get_E(), oEb) and np.array_equal(pair.get_inlier_mask(), omask)
+            elif op == "shards":                      # what G ranks do, one after the other: score a shard into a caller's key, reduce, finalize from the key
+                G = int(rng.integers(2, 5))
+                cfg["steps"][-1]["G"] = G
+                key, ocounts, oEb, omask, best = want(H, p)
+                key_t = torch.zeros(1, dtype=torch.int64, device=dev)
+                torch.cuda.synchronize()              # (torch fills it on ITS stream; the pair's context may work on another)
+                keys, ok = [], True
+                for r in range(G):
+                    b, cnt = S.shard_range(H, r, G)
+                    q = S.default_params(n, num_hypotheses=H, seed=p.seed, kernel=p.kernel, jacobi_sweeps=p.jacobi_sweeps, threshold=p.threshold, hyp_begin=b, hyp_count=cnt)
+                    pair.ransac_score(q, key_out=key_t)
+                    state["ctx"].synchronize()
+                    ok = ok and np.array_equal(pair.get_inlier_counts(cnt), ocounts[b:b + cnt]) and int(key_t.item()) == pair.get_key()
+                    keys.append(pair.get_key())
+                ok = ok and max(keys) == key
+                key_t[0] = max(keys)
+                torch.cuda.synchronize()
+                pair.ransac_finalize_key(q, key_t)
+                ok = ok and pair.get_best() == best and same_bits(pair.get_E(), oEb) and np.array_equal(pair.get_inlier_mask(), omask)
             else:                                     # caller-supplied candidates: hypotheses of another sampler seed, a few of them scaled / negated / transposed
                 _, _, oE = O.ransac_range(state["X0"], state["X1"], 0, H, p.threshold, 0, seed=p.seed ^ 0x5A5A, want_E=True)
                 Es = oE.reshape(H, 9).copy()
@@ -179,6 +206,8 @@ def make_rounds(S, torch, dev, ctx, rng):
                 pair.close()
                 return False, cfg
         pair.close()
+        if state["ctx"] is not ctx:
+            state["ctx"].close()
         return True, cfg
 
     def pose_round():
