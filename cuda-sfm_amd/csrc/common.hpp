@@ -138,10 +138,10 @@ struct sfm_pair {
     int pf_rule = 0;                   // the rule of the launch being issued (prefilter_pick_rule)
     uint32_t *d_buckets = nullptr;     // scratch of the bucket ordering: per-block histograms + bucket bases (pf_bucket_*_kernel)
     size_t bucket_words = 0;
-    uint32_t *d_tile_boxes = nullptr;  // eight words per scoring tile of d_pts4s: ordered bits of its coordinate maxima (pf_tile_boxes_kernel)
+    uint32_t *d_tile_boxes = nullptr;  // eight words per scoring tile of d_pts4s: ordered bits of its coordinate maxima (pf_bucket_scatter_kernel)
     int boxes_cap = 0, boxes_tile = 0; // tiles allocated / the tile size the boxes were computed for
     float4 *d_pts4s = nullptr;         // the same records in Morton order of the first view's position (pre-filter scoring: tiles with small
-                                       // bounding boxes, ransac_prefilter.hip: pf_sort_kernel); built with the cell table, once per fillXU
+                                       // bounding boxes, ransac_prefilter.hip: pf_bucket_*_kernel); built by the second scoring launch after a fillXU (launch_pf_cells)
     float *d_E = nullptr;              // 9
     float *d_P = nullptr;              // 4 x 16 candidates
     float *d_Pinv = nullptr;           // 4 x 16 inverses

@@ -34,13 +34,16 @@ extern "C" {
  *       points; 9 a 256-entry ring flushed 128 entries at a time; 11 / 12 the packed scan software-pipelined over four accumulator
  *       sets with 16 / 12 wavefronts per block (30 spills / 140 registers: profiles/r06_ab_pack_scan.txt); 13 ring entries of 16
  *       bytes that cover four steps instead of 8 bytes per two steps (half as many appends: measured 3 % slower, r06_ab_wide_entries.txt);
+ *       14 / 15 s_setprio 2 around the MFMA issue / around the exact filter of a flush (level: r06_ab_prio.txt); 13-15 run the per-tile form
+ *       on every call;
  *   [2] k > 0: minimum hypothesis batches per scoring block (default 8); pre-filter kernel: grid columns;
  *   [3] 1 AUTO never picks SFM_KERNEL_PREFILTER; 2 the round-2 pre-filter kernel (csrc/ab/ransac_prefilter_r2.hip);
  *       3 per-hypothesis records from the stand-alone kernel instead of the lane-solve kernel; 4 the G rule of rounds 2-4
  *       (per-pair threshold, three MFMAs per 32 x 32 pairs) instead of the band rule; 6 the packed scan with per-hypothesis 64-byte
- *       records and whole-view boxes instead of round 6's per-tile band constants (tiles = runs of a Morton-ordered copy of the
- *       correspondences, sigma and the coefficient slots derived per (hypothesis, tile) inside the scoring kernel from a 4-byte
- *       record: profiles/r06_ab_tile_rule_fast.txt); 5 the band rule scanned with one
+ *       records and whole-view boxes on EVERY call (the product: on the first call after a fillXU below 2^33 pairs); 7 round 6's
+ *       per-tile band constants on every call, the first included (tiles = runs of a Morton-bucket-ordered copy of the correspondences,
+ *       sigma and the coefficient slots derived per (hypothesis, tile) inside the scoring kernel from a 16-byte record:
+ *       profiles/r06_ab_tile_rule_fast.txt, r06_fresh_pair_cost.txt); 5 the band rule scanned with one
  *       v_alignbit_b32 per pair (round 5) instead of the six-bit conversion of round 6 ([1] = 5, 7, 9 imply it: those variants were
  *       built on that scan); 16 + bits: recorded variants built on the G rule. */
 
