@@ -149,10 +149,35 @@ def make_rounds(S, torch, dev, ctx, rng):
     def calls_steps(pair, state, cfg, nsteps, refill, params, want):
         n = cfg["n"]
         for step in range(nsteps):
-            op = str(rng.choice(["estimate", "estimate", "estimate", "pipelined", "candidates", "shards", "refill"]))
+            op = str(rng.choice(["estimate", "estimate", "estimate", "pipelined", "candidates", "shards", "refill", "pose"]))
             if op == "refill":
                 refill()
+                state["have_E"] = False
                 cfg["steps"].append(op)
+                continue
+            if op == "pose":                          # the pose stages on whatever E the last step left (they flush pending pipelined steps themselves)
+                if not state.get("have_E"):
+                    continue
+                mode = int(rng.choice([S.POSE_REFERENCE, S.POSE_CORRECT]))
+                chain = bool(rng.random() < 0.5)
+                cfg["steps"].append(dict(op=op, mode=mode, chain=chain))
+                if chain:
+                    pair.pose_chain(mode)
+                else:
+                    pair.computePosecandidates(mode); pair.choosePose(mode); pair.linear_triangulation(mode)
+                oP = O.pose_candidates(pair.get_E(), mode)
+                oind, oPinv, _, _ = O.choose_pose(state["X0"], state["X1"], oP, mode, sweeps=8)
+                try:
+                    ind = pair.get_pose_index()
+                except S.SfmError as e:               # a singular chosen candidate is reported
+                    if e.code != S.E_SINGULAR: raise
+                    continue
+                ok = ind == oind and same_bits(pair.get_pose_candidates(), oP) and same_bits(pair.get_pose_inverses(), oPinv)
+                ok = ok and same_bits(pair.get_points(), O.triangulate(state["X0"], state["X1"], oPinv[oind] if mode == S.POSE_REFERENCE else oP[oind], sweeps=8))
+                if not ok:
+                    cfg["failed_step"] = step
+                    pair.close()
+                    return False, cfg
                 continue
             H, p = params()
             cfg["steps"].append(dict(op=op, H=H, kernel=p.kernel, sweeps=p.jacobi_sweeps, thr=p.threshold, seed=p.seed))
@@ -200,6 +225,7 @@ def make_rounds(S, torch, dev, ctx, rng):
                     oc = np.array([O.count_inliers_fast(Es[h].reshape(3, 3), state["X0"], state["X1"], np.float32(p.threshold)) for h in range(H)], np.int32)
                 bi = int(np.argmax(oc))
                 ok = np.array_equal(pair.get_inlier_counts(H), oc) and pair.get_key() == O.pack_key(int(oc[bi]), bi)
+            state["have_E"] = op != "candidates" and state.get("have_E", False) or op in ("estimate", "pipelined", "shards")
             if not ok:
                 cfg["failed_step"] = step
                 cfg["launch"] = pair.last_launch()
